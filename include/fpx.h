@@ -1,0 +1,241 @@
+/*
+ * fpx.h -- C ABI of libfpx: the MI355X (gfx950) Phase-2 accept / quorum-tally engine.
+ *
+ * This is the drop-in boundary for ONE hot path of mwhittaker/frankenpaxos:
+ *
+ *   a1  multipaxos.Acceptor.handlePhase2a     shared/src/main/scala/frankenpaxos/multipaxos/Acceptor.scala:184-220
+ *   a2  mencius.Acceptor.handlePhase2a        shared/src/main/scala/frankenpaxos/mencius/Acceptor.scala:202-235
+ *   a3  multipaxos.ProxyLeader.handlePhase2b  shared/src/main/scala/frankenpaxos/multipaxos/ProxyLeader.scala:217-258
+ *   a4  mencius.ProxyLeader.handlePhase2b     shared/src/main/scala/frankenpaxos/mencius/ProxyLeader.scala:305-353
+ *   a5  quorums.*.isWriteQuorum / isSuperSetOfWriteQuorum
+ *                                             shared/src/main/scala/frankenpaxos/quorums/{SimpleMajority,Grid,UnanimousWrites}.scala
+ *   a6  multipaxos.ProxyLeader.handlePhase2a  shared/src/main/scala/frankenpaxos/multipaxos/ProxyLeader.scala:175-215
+ *   a7  roundsystem.ClassicRoundRobin         shared/src/main/scala/frankenpaxos/roundsystem/RoundSystem.scala:60-87
+ *   a8  simulator.FakeTransport (delivery)    shared/src/main/scala/frankenpaxos/FakeTransport.scala:89-159
+ *
+ * The reference has no FFI of its own (it is pure Scala); the seam is the Actor/Transport trait
+ * surface.  A JNI shim marshals one event-loop tick worth of Phase2a / Phase2b
+ * protobuf messages into the struct-of-arrays batches below and calls these entry points once per
+ * batch.  Everything is plain pointers + sizes; no torch / HIP types appear in a signature (a HIP
+ * stream crosses as void*).
+ *
+ * Conventions
+ *   - Every function returns an int32 status (FPX_OK == 0).  FPX_EINVAL corresponds to a Scala
+ *     require(...) failure; FPX_EFATAL_UNKNOWN_SLOTROUND to logger.fatal in
+ *     ProxyLeader.handlePhase2b (ProxyLeader.scala:220-225).  A stale round is NOT an error: it
+ *     produces a Nack exactly as in the reference.
+ *   - A context is NOT thread-safe: one caller thread per context, mirroring "All Transport
+ *     implementations MUST be single-threaded" (shared/src/main/scala/frankenpaxos/Transport.scala:37-39).
+ *   - Entry points without a suffix take HOST pointers, are synchronous, and accept ANY batch: the
+ *     library splits it into device "runs" so that the result equals message-at-a-time delivery in
+ *     array order.  Entry points ending in _dev take DEVICE pointers (resident in HBM), enqueue on
+ *     the context's stream and return immediately; the batch must already satisfy the run contract
+ *     (below) -- a violation is detected on the device, nothing is applied, and the next fpx_sync()
+ *     returns FPX_EORDER.
+ *   - Run contract (one kernel launch): (1) slots in the batch are pairwise distinct; (2) in
+ *     FPX_BALLOT_ACCEPTOR mode the rounds of the messages addressed to one acceptor group are
+ *     non-decreasing in array order.  Under (2) the acceptor's running-max `round`
+ *     (Acceptor.scala:95,204) seen by message i equals max(round at batch start, round[i]) for every
+ *     acceptor, which is what lets a batch be evaluated data-parallel and still be bit-exact.
+ *   - Bitmaps: one message's set of acceptors is 4 x uint64 (256 bits); bit j of the 256-bit
+ *     little-endian integer is acceptor index j of the slot's acceptor group (for a Grid:
+ *     j = row * grid_cols + col, row = groupIndex, col = acceptorIndex).
+ *   - value_id is an int32 standing in for CommandBatchOrNoop (FPX_NOOP == -1 is Noop).
+ */
+#ifndef FPX_H
+#define FPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FPX_VERSION 100
+
+#define FPX_MAX_REPLICAS 256
+#define FPX_MASK_WORDS 4
+#define FPX_NOOP (-1)
+
+/* status codes */
+enum {
+  FPX_OK = 0,
+  FPX_EINVAL = 1,                   /* == Scala require(...) / IllegalArgumentException            */
+  FPX_EFATAL_UNKNOWN_SLOTROUND = 2, /* == logger.fatal, ProxyLeader.scala:220-225                    */
+  FPX_EHIP = 3,                     /* a HIP runtime call failed (fpx_last_hip_error has the code)   */
+  FPX_ENODEVICE = 4,                /* no gfx950 device / HIP runtime: there is NO CPU fallback      */
+  FPX_ECAPACITY = 5,                /* more than tally_ways live (slot, round) tallies for one slot  */
+  FPX_EORDER = 6,                   /* a _dev batch violated the run contract; nothing was applied   */
+  FPX_ENOMEM = 7
+};
+
+typedef enum {
+  FPX_Q_THRESHOLD = 0,       /* |X| >= f+1             ProxyLeader.scala:238 (non-flexible)          */
+  FPX_Q_SIMPLE_MAJORITY = 1, /* |X| >= n/2+1           SimpleMajority.scala:30,41-49                 */
+  FPX_Q_GRID = 2,            /* every row intersects X Grid.scala:43-50                              */
+  FPX_Q_UNANIMOUS = 3        /* X == members           UnanimousWrites.scala:44-51                   */
+} fpx_quorum_kind;
+
+typedef enum {
+  /* one promised `round` per acceptor, shared by all its slots: multipaxos/mencius Acceptor
+   * (Acceptor.scala:95).  Faithful model. */
+  FPX_BALLOT_ACCEPTOR = 0,
+  /* one ballot per (slot, acceptor) cell, stored in HBM next to voteRound / voteValue: the
+   * per-instance ballot of epaxos.Replica.handleAccept (epaxos/Replica.scala:1421-1510) and the
+   * "generalised ballot[S x R]" model of SURVEY.md section 8(d). */
+  FPX_BALLOT_PER_SLOT = 1
+} fpx_ballot_mode;
+
+/* flags */
+#define FPX_F_TRUSTED 1u /* _dev entry points skip the run-contract validation pass (caller guarantees it) */
+
+typedef struct {
+  int32_t num_slots;         /* S: log window held in HBM; slots are 0 .. S-1                          */
+  int32_t num_replicas;      /* R: acceptors per acceptor group, 1 .. 256                               */
+  int32_t num_groups;        /* acceptor groups per leader group; slot -> group as below                */
+  int32_t num_leader_groups; /* 1 for MultiPaxos.  Mencius: leader group = slot % num_leader_groups,
+                                acceptor group = (slot / num_leader_groups) % num_groups
+                                (mencius/ProxyLeader.scala:231-234); group id = lg * num_groups + ag     */
+  int32_t f;                 /* FPX_Q_THRESHOLD: quorum size f+1                                         */
+  int32_t quorum_kind;       /* fpx_quorum_kind                                                          */
+  int32_t grid_rows, grid_cols; /* FPX_Q_GRID: rows * cols == num_replicas                               */
+  int32_t num_leaders;       /* ClassicRoundRobin(num_leaders): Nack routing, Acceptor.scala:197         */
+  int32_t ballot_mode;       /* fpx_ballot_mode                                                          */
+  int32_t tally_ways;        /* live (slot, round) tallies kept per slot, 1 .. 8 (ProxyLeader.states is
+                                keyed by SlotRound, ProxyLeader.scala:87,135)                            */
+  int32_t replica_base;      /* multi-GPU replica-axis sharding: this context owns acceptors
+                                [replica_base, replica_base + num_replicas) of a group of
+                                replicas_total acceptors; multiple of 4; 0 when not sharded             */
+  int32_t replicas_total;    /* 0 => num_replicas.  Quorum predicates are over replicas_total.          */
+  int32_t device;            /* HIP device ordinal                                                       */
+  uint32_t flags;            /* FPX_F_*                                                                  */
+} fpx_config;
+
+typedef struct fpx_ctx fpx_ctx;
+
+/* ---- lifecycle ------------------------------------------------------------------------------- */
+int32_t fpx_version(void);
+const char* fpx_strerror(int32_t status);
+/* validates the config exactly like Config.checkValid-style require()s (FPX_EINVAL), no GPU needed */
+int32_t fpx_config_check(const fpx_config* cfg);
+/* allocates HBM state: acceptors start with round = -1 and no votes (Acceptor.scala:95-104),
+ * the proxy leader with no tallies (ProxyLeader.scala:135). */
+int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out);
+int32_t fpx_destroy(fpx_ctx* ctx);
+/* re-initialises all state to the freshly-created state (device memset, async on the stream) */
+int32_t fpx_reset(fpx_ctx* ctx);
+/* hip_stream is a hipStream_t; NULL selects the context's own stream */
+int32_t fpx_set_stream(fpx_ctx* ctx, void* hip_stream);
+/* waits for the stream; returns the sticky device status of the _dev calls since the last sync
+ * (FPX_OK, FPX_EORDER, FPX_ECAPACITY, FPX_EFATAL_UNKNOWN_SLOTROUND, FPX_EINVAL) and clears it */
+int32_t fpx_sync(fpx_ctx* ctx);
+/* index / slot / round of the first offending message of the last non-OK status */
+int32_t fpx_error_detail(fpx_ctx* ctx, int32_t* index, int32_t* slot, int32_t* round);
+int32_t fpx_last_hip_error(fpx_ctx* ctx);
+/* HBM bytes held by the context */
+int64_t fpx_device_bytes(fpx_ctx* ctx);
+
+/* ---- a7: roundsystem.ClassicRoundRobin (RoundSystem.scala:60-87); pure host scalars ----------- */
+int32_t fpx_round_leader(int32_t num_leaders, int32_t round);                         /* :63     */
+int32_t fpx_next_classic_round(int32_t num_leaders, int32_t leader_index, int32_t round); /* :66-81 */
+
+/* ---- a5: quorum predicates on the device ----------------------------------------------------- */
+/* Evaluates isWriteQuorum (strict = 1: FPX_EINVAL if a bit outside the member set is present, the
+ * require() of SimpleMajority.scala:42 / Grid.scala:44 / UnanimousWrites.scala:45) or
+ * isSuperSetOfWriteQuorum (strict = 0: foreign bits ignored) for n node sets; nodes is n x 4 words,
+ * out is n bytes (host pointers).  Only the quorum fields of cfg are read.  Runs the same device
+ * function the tally kernels use. */
+int32_t fpx_quorum_eval(const fpx_config* cfg, int32_t n, const uint64_t* nodes, int32_t strict,
+                        uint8_t* out);
+int32_t fpx_is_write_quorum(const fpx_config* cfg, const uint64_t nodes[4], int32_t strict,
+                            uint8_t* out);
+/* isReadQuorum / isSuperSetOfReadQuorum with the same conventions (SimpleMajority.scala:41-47,
+ * Grid.scala:36-41,52-53, UnanimousWrites.scala:36-42,53-54) */
+int32_t fpx_read_quorum_eval(const fpx_config* cfg, int32_t n, const uint64_t* nodes, int32_t strict,
+                             uint8_t* out);
+
+/* ---- a1/a2 (K1): acceptors handle Phase2a -------------------------------------------------------
+ * Delivers Phase2a(slot[i], round[i], value_id[i]), i = 0..n-1 in array order, to the acceptors of
+ * the slot's group selected by target_mask (n x 4 words; NULL = every acceptor of the group).  Per
+ * targeted acceptor (Acceptor.scala:192-219): round[i] < its round -> Nack(its round); otherwise
+ * its round := round[i], states[slot] := (round[i], value_id[i]), maxVotedSlot := max(.., slot),
+ * Phase2b.  Outputs (each may be NULL): vote_bits n x 4 words = acceptors that sent Phase2b;
+ * nack_bits n x 4 words = acceptors that sent Nack; nack_round n ints = the largest round carried
+ * by a Nack for message i, -1 if none (the only field Leader.handleNack, Leader.scala:672-697,
+ * reacts to; destination leader = fpx_round_leader(num_leaders, round[i])). */
+int32_t fpx_acceptor_phase2a(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round,
+                             const int32_t* value_id, const uint64_t* target_mask,
+                             uint64_t* vote_bits, uint64_t* nack_bits, int32_t* nack_round);
+int32_t fpx_acceptor_phase2a_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot,
+                                 const int32_t* d_round, const int32_t* d_value_id,
+                                 const uint64_t* d_target_mask, uint64_t* d_vote_bits,
+                                 uint64_t* d_nack_bits, int32_t* d_nack_round);
+
+/* Phase1a (Acceptor.scala:148-182), needed so that rounds can move: acceptors of `group` selected
+ * by target_mask[4] (NULL = all) with round > their round promise it (round := round), the others
+ * Nack.  In FPX_BALLOT_PER_SLOT mode the promise applies to every cell of the group with
+ * slot >= chosen_watermark.  promised_bits / nack_bits: 4 words each (may be NULL).
+ * NOTE multipaxos uses `phase1a.round < round -> Nack` (Acceptor.scala:155), i.e. an EQUAL round is
+ * promised again; that is what is implemented. */
+int32_t fpx_acceptor_phase1a(fpx_ctx* ctx, int32_t group, int32_t round, int32_t chosen_watermark,
+                             const uint64_t* target_mask, uint64_t* promised_bits,
+                             uint64_t* nack_bits);
+
+/* ---- a6: ProxyLeader.handlePhase2a bookkeeping ---------------------------------------------------
+ * Opens the tally Pending(phase2a, {}) for (slot[i], round[i]) (ProxyLeader.scala:213).  A (slot,
+ * round) that is already known is ignored (:177-184) and reported as is_new[i] = 0.  The reference
+ * picks a thrifty random quorum here (:190-196, unseeded RNG, F12 in SURVEY.md); which acceptors a
+ * Phase2a goes to is the caller's target_mask in fpx_acceptor_phase2a. */
+int32_t fpx_proxy_open(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round,
+                       const int32_t* value_id, uint8_t* is_new);
+int32_t fpx_proxy_open_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,
+                           const int32_t* d_value_id, uint8_t* d_is_new);
+
+/* ---- a3/a4 (K2): ProxyLeader.handlePhase2b ----------------------------------------------------------
+ * Message i carries the Phase2b's of the acceptors in vote_bits[i] for (slot[i], round[i]) (an
+ * all-zero row is "no message").  Unknown (slot, round) -> FPX_EFATAL_UNKNOWN_SLOTROUND (:220-225);
+ * Done -> ignored (:227-232); Pending -> votes are recorded keyed by acceptor (a duplicate vote
+ * changes nothing, :237) and, when the quorum predicate holds (:238-243), Chosen(slot,
+ * pending.phase2a.value) is emitted exactly once (:246-256): newly_chosen[i] = 1,
+ * chosen_round[i] = round[i], chosen_value[i] = the value given to fpx_proxy_open; otherwise
+ * newly_chosen[i] = 0, chosen_round[i] = chosen_value[i] = -1. */
+int32_t fpx_proxy_phase2b(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round,
+                          const uint64_t* vote_bits, uint8_t* newly_chosen, int32_t* chosen_round,
+                          int32_t* chosen_value);
+int32_t fpx_proxy_phase2b_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,
+                              const uint64_t* d_vote_bits, uint8_t* d_newly_chosen,
+                              int32_t* d_chosen_round, int32_t* d_chosen_value);
+
+/* ---- K3: fused step = fpx_proxy_open + fpx_acceptor_phase2a + fpx_proxy_phase2b ------------------
+ * For each message in order: open (slot, round) (duplicates are ignored and NOT forwarded to the
+ * acceptors, :177-184), deliver the Phase2a to the targeted acceptors (target_mask NULL = all: the
+ * dense schedule of SURVEY.md section 8(d)), feed their Phase2b's to the tally.  The vote bitmap never
+ * leaves the chip.  nack_round may be NULL. */
+int32_t fpx_phase2_fused(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round,
+                         const int32_t* value_id, const uint64_t* target_mask, uint8_t* chosen,
+                         int32_t* chosen_round, int32_t* chosen_value, int32_t* nack_round);
+int32_t fpx_phase2_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,
+                             const int32_t* d_value_id, const uint64_t* d_target_mask,
+                             uint8_t* d_chosen, int32_t* d_chosen_round, int32_t* d_chosen_value,
+                             int32_t* d_nack_round);
+
+/* ---- state readback (parity) ------------------------------------------------------------------- */
+/* acceptor `replica` of `group`: its round (FPX_BALLOT_ACCEPTOR; -1 in PER_SLOT mode),
+ * maxVotedSlot, and for every slot s in [0, S): vote_round[s] / vote_value[s] (-1 / -1 when the
+ * acceptor has no vote in s or s belongs to another group) and, in PER_SLOT mode, ballot[s].
+ * Array arguments may be NULL. */
+int32_t fpx_read_acceptor(fpx_ctx* ctx, int32_t group, int32_t replica, int32_t* promised,
+                          int32_t* max_voted_slot, int32_t* vote_round, int32_t* vote_value,
+                          int32_t* ballot);
+/* whole-array readback, slot-major [S][R] int32 (may be NULL each) */
+int32_t fpx_read_state(fpx_ctx* ctx, int32_t* vote_round, int32_t* vote_value, int32_t* ballot);
+/* per-acceptor scalars, [num_leader_groups * num_groups][R] */
+int32_t fpx_read_scalars(fpx_ctx* ctx, int32_t* promised, int32_t* max_voted_slot);
+/* proxy-leader tallies of one slot: up to tally_ways entries; state 0 = Pending, 1 = Done */
+int32_t fpx_read_tally(fpx_ctx* ctx, int32_t slot, int32_t* num_entries, int32_t* rounds,
+                       int32_t* states, int32_t* values, uint64_t* vote_bits /* ways x 4 */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPX_H */

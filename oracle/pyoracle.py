@@ -1,0 +1,417 @@
+"""ctypes loader for the CPU oracle (oracle/libfpx_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the cpu_baseline leg of
+bench.py -- never by the frankenpaxos_amd package.  See oracle/fpx_oracle.h for the parity status.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libfpx_oracle.so")
+
+
+class Config(C.Structure):
+    """Layout-identical to fpx_config / fpo_config."""
+
+    _fields_ = [
+        ("num_slots", C.c_int32),
+        ("num_replicas", C.c_int32),
+        ("num_groups", C.c_int32),
+        ("num_leader_groups", C.c_int32),
+        ("f", C.c_int32),
+        ("quorum_kind", C.c_int32),
+        ("grid_rows", C.c_int32),
+        ("grid_cols", C.c_int32),
+        ("num_leaders", C.c_int32),
+        ("ballot_mode", C.c_int32),
+        ("tally_ways", C.c_int32),
+        ("replica_base", C.c_int32),
+        ("replicas_total", C.c_int32),
+        ("device", C.c_int32),
+        ("flags", C.c_uint32),
+    ]
+
+
+def make_config(num_slots, num_replicas, num_groups=1, num_leader_groups=1, f=0, quorum_kind=0,
+                grid_rows=0, grid_cols=0, num_leaders=2, ballot_mode=0, tally_ways=4,
+                replica_base=0, replicas_total=0, device=0, flags=0):
+    return Config(num_slots, num_replicas, num_groups, num_leader_groups, f, quorum_kind, grid_rows,
+                  grid_cols, num_leaders, ballot_mode, tally_ways, replica_base, replicas_total,
+                  device, flags)
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, "fpx_oracle.c"), os.path.join(_HERE, "fpx_oracle.h")]
+    if (not force and os.path.exists(_SO)
+            and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in src)):
+        return _SO
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libfpx_oracle.so"],
+                          stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+I32P = C.POINTER(C.c_int32)
+U64P = C.POINTER(C.c_uint64)
+U8P = C.POINTER(C.c_uint8)
+INTP = C.POINTER(C.c_int)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        build()
+    L = C.CDLL(_SO)
+    L.fpo_round_leader.argtypes = [C.c_int, C.c_int]
+    L.fpo_next_classic_round.argtypes = [C.c_int, C.c_int, C.c_int]
+    for name in ("fpo_qs_simple_majority", "fpo_qs_unanimous_writes"):
+        getattr(L, name).argtypes = [INTP, C.c_int]
+        getattr(L, name).restype = C.c_void_p
+    L.fpo_qs_grid.argtypes = [INTP, C.c_int, C.c_int]
+    L.fpo_qs_grid.restype = C.c_void_p
+    L.fpo_qs_free.argtypes = [C.c_void_p]
+    L.fpo_qs_nodes.argtypes = [C.c_void_p, INTP]
+    for name in ("fpo_qs_is_read_quorum", "fpo_qs_is_write_quorum",
+                 "fpo_qs_is_superset_of_read_quorum", "fpo_qs_is_superset_of_write_quorum"):
+        getattr(L, name).argtypes = [C.c_void_p, INTP, C.c_int]
+    for name in ("fpo_qs_random_read_quorum", "fpo_qs_random_write_quorum"):
+        getattr(L, name).argtypes = [C.c_void_p, U64P, INTP]
+    L.fpo_splitmix64.argtypes = [U64P]
+    L.fpo_splitmix64.restype = C.c_uint64
+    L.fpo_log_new.argtypes = [C.c_int]
+    L.fpo_log_new.restype = C.c_void_p
+    L.fpo_log_free.argtypes = [C.c_void_p]
+    L.fpo_log_get.argtypes = [C.c_void_p, C.c_int, INTP]
+    L.fpo_log_put.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.fpo_log_garbage_collect.argtypes = [C.c_void_p, C.c_int]
+    L.fpo_log_chosen.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.fpo_log_executed_watermark.argtypes = [C.c_void_p]
+    L.fpo_log_largest_key.argtypes = [C.c_void_p]
+    L.fpo_config_check.argtypes = [C.POINTER(Config)]
+    L.fpo_sys_new.argtypes = [C.POINTER(Config)]
+    L.fpo_sys_new.restype = C.c_void_p
+    L.fpo_sys_free.argtypes = [C.c_void_p]
+    L.fpo_sys_reset.argtypes = [C.c_void_p]
+    L.fpo_group_of_slot.argtypes = [C.POINTER(Config), C.c_int]
+    L.fpo_acceptor_handle_phase2a.argtypes = [C.c_void_p] + [C.c_int] * 5 + [INTP]
+    L.fpo_acceptor_handle_phase1a.argtypes = [C.c_void_p] + [C.c_int] * 4 + [INTP]
+    L.fpo_proxy_handle_phase2a.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.fpo_proxy_handle_phase2b.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, INTP]
+    L.fpo_sys_is_write_quorum.argtypes = [C.POINTER(Config), U64P, C.c_int]
+    L.fpo_sys_is_read_quorum.argtypes = [C.POINTER(Config), U64P, C.c_int]
+    L.fpo_acceptor_phase2a.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, U64P, U64P, U64P,
+                                       I32P]
+    L.fpo_acceptor_phase1a.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, U64P, U64P, U64P]
+    L.fpo_proxy_open.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, U8P]
+    L.fpo_proxy_phase2b.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, U64P, U8P, I32P, I32P]
+    for name in ("fpo_phase2_fused", "fpo_phase2_fifo_pump"):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, U64P, U8P, I32P, I32P,
+                                     I32P]
+    L.fpo_error_detail.argtypes = [C.c_void_p, I32P, I32P, I32P]
+    L.fpo_read_acceptor.argtypes = [C.c_void_p, C.c_int32, C.c_int32, I32P, I32P, I32P, I32P, I32P]
+    L.fpo_read_state.argtypes = [C.c_void_p, I32P, I32P, I32P]
+    L.fpo_read_scalars.argtypes = [C.c_void_p, I32P, I32P]
+    L.fpo_read_tally.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, I32P, U64P]
+    _lib = L
+    return L
+
+
+def _p(a, typ):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+def _i32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _u64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def ints(xs):
+    xs = list(xs)
+    arr = (C.c_int * max(len(xs), 1))(*xs)
+    return arr, len(xs)
+
+
+class QuorumSystem:
+    """Set[Int]-based quorum system of the oracle (SimpleMajority / UnanimousWrites / Grid)."""
+
+    def __init__(self, handle, max_nodes):
+        if not handle:
+            raise ValueError("require() failed constructing the quorum system")
+        self._h = handle
+        self._max = max_nodes
+
+    @classmethod
+    def simple_majority(cls, members):
+        a, n = ints(members)
+        return cls(lib().fpo_qs_simple_majority(a, n), n)
+
+    @classmethod
+    def unanimous_writes(cls, members):
+        a, n = ints(members)
+        return cls(lib().fpo_qs_unanimous_writes(a, n), n)
+
+    @classmethod
+    def grid(cls, rows):
+        rows = [list(r) for r in rows]
+        flat = [x for r in rows for x in r]
+        a, _ = ints(flat)
+        return cls(lib().fpo_qs_grid(a, len(rows), len(rows[0]) if rows else 0), len(flat))
+
+    def __del__(self):
+        try:
+            lib().fpo_qs_free(self._h)
+        except Exception:
+            pass
+
+    def _call(self, name, xs):
+        a, n = ints(xs)
+        r = getattr(lib(), name)(self._h, a, n)
+        if r < 0:
+            raise ValueError("IllegalArgumentException (require failed)")
+        return bool(r)
+
+    def nodes(self):
+        out = (C.c_int * self._max)()
+        n = lib().fpo_qs_nodes(self._h, out)
+        return set(out[:n])
+
+    def is_read_quorum(self, xs):
+        return self._call("fpo_qs_is_read_quorum", xs)
+
+    def is_write_quorum(self, xs):
+        return self._call("fpo_qs_is_write_quorum", xs)
+
+    def is_superset_of_read_quorum(self, xs):
+        return self._call("fpo_qs_is_superset_of_read_quorum", xs)
+
+    def is_superset_of_write_quorum(self, xs):
+        return self._call("fpo_qs_is_superset_of_write_quorum", xs)
+
+    def _rand(self, name, rng):
+        out = (C.c_int * self._max)()
+        st = C.c_uint64(rng[0])
+        n = getattr(lib(), name)(self._h, C.byref(st), out)
+        rng[0] = st.value
+        return set(out[:n])
+
+    def random_read_quorum(self, rng):
+        return self._rand("fpo_qs_random_read_quorum", rng)
+
+    def random_write_quorum(self, rng):
+        return self._rand("fpo_qs_random_write_quorum", rng)
+
+
+class Log:
+    """util.BufferMap + Replica executed-watermark."""
+
+    def __init__(self, grow_size=5000):
+        self._h = lib().fpo_log_new(grow_size)
+
+    def __del__(self):
+        try:
+            lib().fpo_log_free(self._h)
+        except Exception:
+            pass
+
+    def get(self, key):
+        v = C.c_int(0)
+        return v.value if lib().fpo_log_get(self._h, key, C.byref(v)) else None
+
+    def put(self, key, value):
+        lib().fpo_log_put(self._h, key, value)
+
+    def garbage_collect(self, watermark):
+        lib().fpo_log_garbage_collect(self._h, watermark)
+
+    def chosen(self, slot, value):
+        return lib().fpo_log_chosen(self._h, slot, value)
+
+    def iterator_from(self, key=0):
+        """BufferMap.iteratorFrom (BufferMap.scala:64-103): (key, value) pairs from `key` to largestKey."""
+        out = []
+        for k in range(key, lib().fpo_log_largest_key(self._h) + 1):
+            v = self.get(k)
+            if v is not None:
+                out.append((k, v))
+        return out
+
+    @property
+    def executed_watermark(self):
+        return lib().fpo_log_executed_watermark(self._h)
+
+
+class System:
+    """The oracle's Phase-2 system; method-for-method the same surface as frankenpaxos_amd.Context."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        if lib().fpo_config_check(C.byref(cfg)) != 0:
+            raise ValueError("FPX_EINVAL: bad config")
+        self._h = lib().fpo_sys_new(C.byref(cfg))
+        self.S, self.R = cfg.num_slots, cfg.num_replicas
+        self.ngroups = cfg.num_groups * cfg.num_leader_groups
+
+    def __del__(self):
+        try:
+            lib().fpo_sys_free(self._h)
+        except Exception:
+            pass
+
+    def reset(self):
+        lib().fpo_sys_reset(self._h)
+
+    def group_of_slot(self, slot):
+        return lib().fpo_group_of_slot(C.byref(self.cfg), slot)
+
+    # single-message handlers
+    def acceptor_handle_phase2a(self, group, replica, slot, round_, value):
+        rr = C.c_int(0)
+        ok = lib().fpo_acceptor_handle_phase2a(self._h, group, replica, slot, round_, value,
+                                               C.byref(rr))
+        return bool(ok), rr.value
+
+    def acceptor_handle_phase1a(self, group, replica, round_, watermark=0):
+        rr = C.c_int(0)
+        ok = lib().fpo_acceptor_handle_phase1a(self._h, group, replica, round_, watermark,
+                                               C.byref(rr))
+        return bool(ok), rr.value
+
+    def proxy_handle_phase2a(self, slot, round_, value):
+        return bool(lib().fpo_proxy_handle_phase2a(self._h, slot, round_, value))
+
+    def proxy_handle_phase2b(self, acceptor_bit, slot, round_):
+        v = C.c_int(-1)
+        rc = lib().fpo_proxy_handle_phase2b(self._h, acceptor_bit, slot, round_, C.byref(v))
+        return rc, v.value
+
+    # batch entry points
+    def acceptor_phase2a(self, slot, round_, value, target_mask=None):
+        slot, round_, value, target_mask = _i32(slot), _i32(round_), _i32(value), _u64(target_mask)
+        n = len(slot)
+        vb = np.zeros((n, 4), np.uint64)
+        nb = np.zeros((n, 4), np.uint64)
+        nr = np.zeros(n, np.int32)
+        st = lib().fpo_acceptor_phase2a(self._h, n, _p(slot, I32P), _p(round_, I32P),
+                                        _p(value, I32P), _p(target_mask, U64P), _p(vb, U64P),
+                                        _p(nb, U64P), _p(nr, I32P))
+        return st, vb, nb, nr
+
+    def acceptor_phase1a(self, group, round_, watermark=0, target_mask=None):
+        target_mask = _u64(target_mask)
+        pb = np.zeros(4, np.uint64)
+        nb = np.zeros(4, np.uint64)
+        st = lib().fpo_acceptor_phase1a(self._h, group, round_, watermark, _p(target_mask, U64P),
+                                        _p(pb, U64P), _p(nb, U64P))
+        return st, pb, nb
+
+    def proxy_open(self, slot, round_, value):
+        slot, round_, value = _i32(slot), _i32(round_), _i32(value)
+        n = len(slot)
+        new = np.zeros(n, np.uint8)
+        st = lib().fpo_proxy_open(self._h, n, _p(slot, I32P), _p(round_, I32P), _p(value, I32P),
+                                  _p(new, U8P))
+        return st, new
+
+    def proxy_phase2b(self, slot, round_, vote_bits):
+        slot, round_, vote_bits = _i32(slot), _i32(round_), _u64(vote_bits)
+        n = len(slot)
+        ch = np.zeros(n, np.uint8)
+        cr = np.zeros(n, np.int32)
+        cv = np.zeros(n, np.int32)
+        st = lib().fpo_proxy_phase2b(self._h, n, _p(slot, I32P), _p(round_, I32P),
+                                     _p(vote_bits, U64P), _p(ch, U8P), _p(cr, I32P), _p(cv, I32P))
+        return st, ch, cr, cv
+
+    def _fused(self, fn, slot, round_, value, target_mask):
+        slot, round_, value, target_mask = _i32(slot), _i32(round_), _i32(value), _u64(target_mask)
+        n = len(slot)
+        ch = np.zeros(n, np.uint8)
+        cr = np.zeros(n, np.int32)
+        cv = np.zeros(n, np.int32)
+        nr = np.zeros(n, np.int32)
+        st = fn(self._h, n, _p(slot, I32P), _p(round_, I32P), _p(value, I32P),
+                _p(target_mask, U64P), _p(ch, U8P), _p(cr, I32P), _p(cv, I32P), _p(nr, I32P))
+        return st, ch, cr, cv, nr
+
+    def phase2_fused(self, slot, round_, value, target_mask=None):
+        return self._fused(lib().fpo_phase2_fused, slot, round_, value, target_mask)
+
+    def phase2_fifo_pump(self, slot, round_, value, target_mask=None):
+        return self._fused(lib().fpo_phase2_fifo_pump, slot, round_, value, target_mask)
+
+    def error_detail(self):
+        i, s, r = C.c_int32(), C.c_int32(), C.c_int32()
+        lib().fpo_error_detail(self._h, C.byref(i), C.byref(s), C.byref(r))
+        return i.value, s.value, r.value
+
+    # readback
+    def read_acceptor(self, group, replica):
+        p, m = C.c_int32(), C.c_int32()
+        vr = np.zeros(self.S, np.int32)
+        vv = np.zeros(self.S, np.int32)
+        bl = np.zeros(self.S, np.int32)
+        st = lib().fpo_read_acceptor(self._h, group, replica, C.byref(p), C.byref(m), _p(vr, I32P),
+                                     _p(vv, I32P), _p(bl, I32P))
+        if st:
+            raise ValueError("FPX_EINVAL")
+        return p.value, m.value, vr, vv, bl
+
+    def read_state(self):
+        vr = np.zeros((self.S, self.R), np.int32)
+        vv = np.zeros((self.S, self.R), np.int32)
+        bl = np.zeros((self.S, self.R), np.int32)
+        lib().fpo_read_state(self._h, _p(vr, I32P), _p(vv, I32P), _p(bl, I32P))
+        return vr, vv, bl
+
+    def read_scalars(self):
+        pr = np.zeros((self.ngroups, self.R), np.int32)
+        mv = np.zeros((self.ngroups, self.R), np.int32)
+        lib().fpo_read_scalars(self._h, _p(pr, I32P), _p(mv, I32P))
+        return pr, mv
+
+    def read_tally(self, slot):
+        n = C.c_int32()
+        rounds = np.zeros(64, np.int32)
+        states = np.zeros(64, np.int32)
+        values = np.zeros(64, np.int32)
+        bits = np.zeros((64, 4), np.uint64)
+        lib().fpo_read_tally(self._h, slot, C.byref(n), _p(rounds, I32P), _p(states, I32P),
+                             _p(values, I32P), _p(bits, U64P))
+        k = n.value
+        return [(int(rounds[i]), int(states[i]), int(values[i]), tuple(int(x) for x in bits[i]))
+                for i in range(k)]
+
+    def is_write_quorum(self, nodes, strict=True):
+        nodes = _u64(nodes)
+        r = lib().fpo_sys_is_write_quorum(C.byref(self.cfg), _p(nodes, U64P), int(strict))
+        if r < 0:
+            raise ValueError("IllegalArgumentException (require failed)")
+        return bool(r)
+
+    def is_read_quorum(self, nodes, strict=True):
+        nodes = _u64(nodes)
+        r = lib().fpo_sys_is_read_quorum(C.byref(self.cfg), _p(nodes, U64P), int(strict))
+        if r < 0:
+            raise ValueError("IllegalArgumentException (require failed)")
+        return bool(r)
+
+
+def bits_of(indices):
+    """256-bit set as 4 little-endian uint64 words."""
+    v = np.zeros(4, np.uint64)
+    for j in indices:
+        v[j >> 6] |= np.uint64(1) << np.uint64(j & 63)
+    return v
+
+
+def indices_of(words):
+    return [j for j in range(256) if (int(words[j >> 6]) >> (j & 63)) & 1]
