@@ -1,0 +1,238 @@
+"""Context: a Python handle on one libfpx context (= the acceptor groups + one proxy leader of
+SURVEY.md section 8 living in the HBM of one MI355X).
+
+Host-pointer methods take / return numpy arrays and accept any batch; `*_dev` methods take torch
+CUDA tensors (already resident in HBM), enqueue on the context's stream and return immediately.
+Every method ends up in a HIP kernel; nothing here computes protocol results on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FpxConfig, FpxError
+
+
+def make_config(num_slots, num_replicas, num_groups=1, num_leader_groups=1, f=0,
+                quorum_kind=_lib.FPX_Q_THRESHOLD, grid_rows=0, grid_cols=0, num_leaders=2,
+                ballot_mode=_lib.FPX_BALLOT_ACCEPTOR, tally_ways=4, replica_base=0, replicas_total=0,
+                device=0, flags=0):
+    return FpxConfig(num_slots, num_replicas, num_groups, num_leader_groups, f, quorum_kind,
+                     grid_rows, grid_cols, num_leaders, ballot_mode, tally_ways, replica_base,
+                     replicas_total, device, flags)
+
+
+def _i32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _u64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def _hp(a):
+    return None if a is None else a.ctypes.data
+
+
+def _dp(t):
+    """device pointer of a torch tensor (or None)"""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device entry points take contiguous CUDA tensors"
+    return t.data_ptr()
+
+
+class Context:
+    def __init__(self, cfg):
+        self.L = _lib.lib()
+        self.cfg = cfg
+        st = self.L.fpx_config_check(C.byref(cfg))
+        if st:
+            raise FpxError(st, "fpx_config_check")
+        h = C.c_void_p()
+        st = self.L.fpx_create(C.byref(cfg), C.byref(h))
+        if st:
+            raise FpxError(st, "fpx_create")
+        self._h = h
+        self.S, self.R = cfg.num_slots, cfg.num_replicas
+        self.ngroups = cfg.num_groups * cfg.num_leader_groups
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.fpx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- lifecycle -------------------------------------------------------------------------
+    def reset(self):
+        st = self.L.fpx_reset(self._h)
+        if st:
+            raise FpxError(st, "fpx_reset")
+
+    def set_stream(self, hip_stream):
+        """hip_stream: integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or None"""
+        st = self.L.fpx_set_stream(self._h, hip_stream)
+        if st:
+            raise FpxError(st, "fpx_set_stream")
+
+    def sync(self):
+        """waits for the stream; returns the sticky device status of the _dev calls"""
+        return self.L.fpx_sync(self._h)
+
+    def error_detail(self):
+        i, s, r = C.c_int32(), C.c_int32(), C.c_int32()
+        self.L.fpx_error_detail(self._h, C.byref(i), C.byref(s), C.byref(r))
+        return i.value, s.value, r.value
+
+    @property
+    def device_bytes(self):
+        return self.L.fpx_device_bytes(self._h)
+
+    # ---- host-pointer entry points (numpy) ---------------------------------------------------
+    def acceptor_phase2a(self, slot, round_, value, target_mask=None):
+        slot, round_, value, target_mask = _i32(slot), _i32(round_), _i32(value), _u64(target_mask)
+        n = len(slot)
+        vb = np.zeros((n, 4), np.uint64)
+        nb = np.zeros((n, 4), np.uint64)
+        nr = np.zeros(n, np.int32)
+        st = self.L.fpx_acceptor_phase2a(self._h, n, _hp(slot), _hp(round_), _hp(value),
+                                         _hp(target_mask), _hp(vb), _hp(nb), _hp(nr))
+        return st, vb, nb, nr
+
+    def acceptor_phase1a(self, group, round_, watermark=0, target_mask=None):
+        target_mask = _u64(target_mask)
+        pb = np.zeros(4, np.uint64)
+        nb = np.zeros(4, np.uint64)
+        st = self.L.fpx_acceptor_phase1a(self._h, group, round_, watermark, _hp(target_mask),
+                                         _hp(pb), _hp(nb))
+        return st, pb, nb
+
+    def proxy_open(self, slot, round_, value):
+        slot, round_, value = _i32(slot), _i32(round_), _i32(value)
+        n = len(slot)
+        new = np.zeros(n, np.uint8)
+        st = self.L.fpx_proxy_open(self._h, n, _hp(slot), _hp(round_), _hp(value), _hp(new))
+        return st, new
+
+    def proxy_phase2b(self, slot, round_, vote_bits):
+        slot, round_, vote_bits = _i32(slot), _i32(round_), _u64(vote_bits)
+        n = len(slot)
+        ch = np.zeros(n, np.uint8)
+        cr = np.zeros(n, np.int32)
+        cv = np.zeros(n, np.int32)
+        st = self.L.fpx_proxy_phase2b(self._h, n, _hp(slot), _hp(round_), _hp(vote_bits), _hp(ch),
+                                      _hp(cr), _hp(cv))
+        return st, ch, cr, cv
+
+    def phase2_fused(self, slot, round_, value, target_mask=None):
+        slot, round_, value, target_mask = _i32(slot), _i32(round_), _i32(value), _u64(target_mask)
+        n = len(slot)
+        ch = np.zeros(n, np.uint8)
+        cr = np.zeros(n, np.int32)
+        cv = np.zeros(n, np.int32)
+        nr = np.zeros(n, np.int32)
+        st = self.L.fpx_phase2_fused(self._h, n, _hp(slot), _hp(round_), _hp(value),
+                                     _hp(target_mask), _hp(ch), _hp(cr), _hp(cv), _hp(nr))
+        return st, ch, cr, cv, nr
+
+    # ---- device-pointer entry points (torch CUDA tensors, async) ------------------------------
+    def acceptor_phase2a_dev(self, slot, round_, value, target_mask=None, vote_bits=None,
+                             nack_bits=None, nack_round=None):
+        st = self.L.fpx_acceptor_phase2a_dev(self._h, slot.numel(), _dp(slot), _dp(round_),
+                                             _dp(value), _dp(target_mask), _dp(vote_bits),
+                                             _dp(nack_bits), _dp(nack_round))
+        if st:
+            raise FpxError(st, "fpx_acceptor_phase2a_dev")
+
+    def proxy_open_dev(self, slot, round_, value, is_new=None):
+        st = self.L.fpx_proxy_open_dev(self._h, slot.numel(), _dp(slot), _dp(round_), _dp(value),
+                                       _dp(is_new))
+        if st:
+            raise FpxError(st, "fpx_proxy_open_dev")
+
+    def proxy_phase2b_dev(self, slot, round_, vote_bits, newly_chosen=None, chosen_round=None,
+                          chosen_value=None):
+        st = self.L.fpx_proxy_phase2b_dev(self._h, slot.numel(), _dp(slot), _dp(round_),
+                                          _dp(vote_bits), _dp(newly_chosen), _dp(chosen_round),
+                                          _dp(chosen_value))
+        if st:
+            raise FpxError(st, "fpx_proxy_phase2b_dev")
+
+    def phase2_fused_dev(self, slot, round_, value, target_mask=None, chosen=None, chosen_round=None,
+                         chosen_value=None, nack_round=None):
+        st = self.L.fpx_phase2_fused_dev(self._h, slot.numel(), _dp(slot), _dp(round_), _dp(value),
+                                         _dp(target_mask), _dp(chosen), _dp(chosen_round),
+                                         _dp(chosen_value), _dp(nack_round))
+        if st:
+            raise FpxError(st, "fpx_phase2_fused_dev")
+
+    # ---- readback ------------------------------------------------------------------------------
+    def read_acceptor(self, group, replica):
+        p, m = C.c_int32(), C.c_int32()
+        vr = np.zeros(self.S, np.int32)
+        vv = np.zeros(self.S, np.int32)
+        bl = np.zeros(self.S, np.int32)
+        st = self.L.fpx_read_acceptor(self._h, group, replica, C.byref(p), C.byref(m), _hp(vr),
+                                      _hp(vv), _hp(bl))
+        if st:
+            raise FpxError(st, "fpx_read_acceptor")
+        return p.value, m.value, vr, vv, bl
+
+    def read_state(self):
+        vr = np.zeros((self.S, self.R), np.int32)
+        vv = np.zeros((self.S, self.R), np.int32)
+        bl = np.zeros((self.S, self.R), np.int32)
+        st = self.L.fpx_read_state(self._h, _hp(vr), _hp(vv), _hp(bl))
+        if st:
+            raise FpxError(st, "fpx_read_state")
+        return vr, vv, bl
+
+    def read_scalars(self):
+        pr = np.zeros((self.ngroups, self.R), np.int32)
+        mv = np.zeros((self.ngroups, self.R), np.int32)
+        st = self.L.fpx_read_scalars(self._h, _hp(pr), _hp(mv))
+        if st:
+            raise FpxError(st, "fpx_read_scalars")
+        return pr, mv
+
+    def read_tally(self, slot):
+        n = C.c_int32()
+        rounds = np.zeros(8, np.int32)
+        states = np.zeros(8, np.int32)
+        values = np.zeros(8, np.int32)
+        bits = np.zeros((8, 4), np.uint64)
+        st = self.L.fpx_read_tally(self._h, slot, C.byref(n), _hp(rounds), _hp(states), _hp(values),
+                                   _hp(bits))
+        if st:
+            raise FpxError(st, "fpx_read_tally")
+        return [(int(rounds[i]), int(states[i]), int(values[i]), tuple(int(x) for x in bits[i]))
+                for i in range(n.value)]
+
+
+# ---- a5 / a7 free functions ----------------------------------------------------------------------
+def quorum_eval(cfg, nodes, strict=True, read=False):
+    """isWriteQuorum / isReadQuorum (strict) or the isSuperSetOf* variants for n node sets
+    (n x 4 uint64), evaluated by the device predicate the tally kernels use."""
+    L = _lib.lib()
+    nodes = np.ascontiguousarray(nodes, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros(len(nodes), np.uint8)
+    fn = L.fpx_read_quorum_eval if read else L.fpx_quorum_eval
+    st = fn(C.byref(cfg), len(nodes), _hp(nodes), int(strict), _hp(out))
+    if st == _lib.FPX_EINVAL:
+        raise ValueError("IllegalArgumentException (require failed)")
+    if st:
+        raise FpxError(st, "fpx_quorum_eval")
+    return out.astype(bool)
+
+
+def round_leader(num_leaders, round_):
+    return _lib.lib().fpx_round_leader(num_leaders, round_)
+
+
+def next_classic_round(num_leaders, leader_index, round_):
+    return _lib.lib().fpx_next_classic_round(num_leaders, leader_index, round_)

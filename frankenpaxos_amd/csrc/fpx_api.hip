@@ -1,0 +1,802 @@
+// fpx_api.hip -- the C ABI of include/fpx.h on top of the gfx950 kernels in fpx_kernels.hpp.
+//
+// There is NO CPU path in this file: every entry point that computes anything launches a HIP kernel
+// and fails with FPX_ENODEVICE / FPX_EHIP when no device is usable.
+#include "../../include/fpx.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "fpx_kernels.hpp"
+
+using namespace fpx;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct fpx_ctx {
+  fpx_config cfg;
+  Geom g;
+  State st;
+  hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;
+  int lanes_per_slot = 64;  // G
+  bool vec = false;
+  int num_cus = 256;
+  int max_grid = 2048;
+  uint32_t run_id = 0;
+  int64_t bytes = 0;
+  int last_hip = 0;
+  int32_t err_index = -1, err_slot = -1, err_round = -1;
+  // host-API staging (device)
+  DevBuf d_slot, d_round, d_value, d_target, d_bits_a, d_bits_b, d_i32_a, d_i32_b, d_i32_c, d_u8, d_scratch;
+  // host-side run splitting
+  std::vector<uint32_t> hstamp;
+  uint32_t hrun = 0;
+  std::vector<int32_t> hround;
+};
+
+namespace {
+
+#define HIPCHK(ctx, expr)                       \
+  do {                                          \
+    hipError_t _e = (expr);                     \
+    if (_e != hipSuccess) {                     \
+      if (ctx) (ctx)->last_hip = (int)_e;       \
+      return _e == hipErrorOutOfMemory ? FPX_ENOMEM : FPX_EHIP; \
+    }                                           \
+  } while (0)
+
+int check_config(const fpx_config* c) {
+  if (!c) return FPX_EINVAL;
+  if (c->num_slots < 1) return FPX_EINVAL;
+  if (c->num_replicas < 1 || c->num_replicas > FPX_MAX_REPLICAS) return FPX_EINVAL;
+  if (c->num_groups < 1 || c->num_leader_groups < 1) return FPX_EINVAL;
+  if (c->num_leaders < 1) return FPX_EINVAL;
+  if (c->tally_ways < 1 || c->tally_ways > 8) return FPX_EINVAL;
+  if (c->ballot_mode != FPX_BALLOT_ACCEPTOR && c->ballot_mode != FPX_BALLOT_PER_SLOT) return FPX_EINVAL;
+  const int total = c->replicas_total ? c->replicas_total : c->num_replicas;
+  if (total < 1 || total > FPX_MAX_REPLICAS) return FPX_EINVAL;
+  if (c->replica_base < 0 || (c->replica_base & 3) || c->replica_base + c->num_replicas > total) return FPX_EINVAL;
+  // the per-block maxima tables live in LDS
+  if ((int64_t)c->num_groups * c->num_leader_groups * c->num_replicas > 8192) return FPX_EINVAL;
+  switch (c->quorum_kind) {
+    case FPX_Q_THRESHOLD:
+      if (c->f < 0 || c->f + 1 > total) return FPX_EINVAL;
+      break;
+    case FPX_Q_SIMPLE_MAJORITY:
+    case FPX_Q_UNANIMOUS:
+      break;
+    case FPX_Q_GRID:
+      if (c->grid_rows < 1 || c->grid_cols < 1 || c->grid_rows * c->grid_cols != total) return FPX_EINVAL;
+      break;
+    default:
+      return FPX_EINVAL;
+  }
+  return FPX_OK;
+}
+
+void make_geom(const fpx_config& c, Geom* g) {
+  memset(g, 0, sizeof(*g));
+  g->S = c.num_slots;
+  g->R = c.num_replicas;
+  g->num_groups = c.num_groups;
+  g->num_leader_groups = c.num_leader_groups;
+  g->ngroups = c.num_groups * c.num_leader_groups;
+  g->qkind = c.quorum_kind;
+  g->total = c.replicas_total ? c.replicas_total : c.num_replicas;
+  g->base = c.replica_base;
+  switch (c.quorum_kind) {
+    case FPX_Q_THRESHOLD: g->qsize = c.f + 1; break;                 // ProxyLeader.scala:238
+    case FPX_Q_SIMPLE_MAJORITY: g->qsize = g->total / 2 + 1; break;  // SimpleMajority.scala:30
+    case FPX_Q_UNANIMOUS: g->qsize = g->total; break;                // UnanimousWrites.scala:50
+    default: g->qsize = 0;
+  }
+  g->grid_rows = c.grid_rows;
+  g->grid_cols = c.grid_cols;
+  g->per_slot = c.ballot_mode == FPX_BALLOT_PER_SLOT;
+  g->ways = c.tally_ways;
+  g->wp = c.tally_ways <= 4 ? 4 : 8;
+  for (int w = 0; w < 4; ++w) {
+    const int lo = w * 64;
+    g->member[w] = g->total >= lo + 64 ? ~0ull : (g->total <= lo ? 0ull : ((1ull << (g->total - lo)) - 1ull));
+  }
+}
+
+int grow(fpx_ctx* ctx, DevBuf* b, size_t bytes) {
+  if (bytes <= b->cap) return FPX_OK;
+  if (b->p) HIPCHK(ctx, hipFree(b->p));
+  b->p = nullptr;
+  b->cap = 0;
+  size_t cap = std::max<size_t>(bytes, 4096);
+  HIPCHK(ctx, hipMalloc(&b->p, cap));
+  b->cap = cap;
+  return FPX_OK;
+}
+
+template <typename T>
+int dalloc(fpx_ctx* ctx, T** p, size_t count) {
+  HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+  ctx->bytes += (int64_t)(count * sizeof(T));
+  return FPX_OK;
+}
+
+size_t lds_bytes(const fpx_ctx* ctx, bool fused) {
+  const size_t tab = (((size_t)ctx->g.ngroups * ctx->g.R * 8) + 15) & ~(size_t)15;
+  return tab + 4 * (fused ? sizeof(WaveOut<true>) : sizeof(WaveOut<false>));
+}
+
+int grid_for(const fpx_ctx* ctx, int n) {
+  const int need = (n + 255) / 256;
+  return std::max(1, std::min(need, ctx->max_grid));
+}
+
+template <int G, bool VEC, bool PERSLOT>
+void launch_phase2_3(fpx_ctx* ctx, const Batch& b, bool fused, int grid) {
+  const size_t lds = lds_bytes(ctx, fused);
+  if (fused)
+    hipLaunchKernelGGL((k_phase2<G, VEC, PERSLOT, true>), dim3(grid), dim3(256), lds, ctx->stream, ctx->g, ctx->st, b);
+  else
+    hipLaunchKernelGGL((k_phase2<G, VEC, PERSLOT, false>), dim3(grid), dim3(256), lds, ctx->stream, ctx->g, ctx->st, b);
+}
+
+template <int G>
+void launch_phase2_2(fpx_ctx* ctx, const Batch& b, bool fused, int grid) {
+  const bool ps = ctx->g.per_slot != 0;
+  if (ctx->vec) {
+    if (ps) launch_phase2_3<G, true, true>(ctx, b, fused, grid);
+    else launch_phase2_3<G, true, false>(ctx, b, fused, grid);
+  } else {
+    if (ps) launch_phase2_3<G, false, true>(ctx, b, fused, grid);
+    else launch_phase2_3<G, false, false>(ctx, b, fused, grid);
+  }
+}
+
+void launch_phase2(fpx_ctx* ctx, const Batch& b, bool fused, int grid) {
+  switch (ctx->lanes_per_slot) {
+    case 1: launch_phase2_2<1>(ctx, b, fused, grid); break;
+    case 2: launch_phase2_2<2>(ctx, b, fused, grid); break;
+    case 4: launch_phase2_2<4>(ctx, b, fused, grid); break;
+    case 8: launch_phase2_2<8>(ctx, b, fused, grid); break;
+    case 16: launch_phase2_2<16>(ctx, b, fused, grid); break;
+    case 32: launch_phase2_2<32>(ctx, b, fused, grid); break;
+    default: launch_phase2_2<64>(ctx, b, fused, grid); break;
+  }
+}
+
+int launch_check(fpx_ctx* ctx) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    ctx->last_hip = (int)e;
+    return FPX_EHIP;
+  }
+  return FPX_OK;
+}
+
+// validation pass of one device run (skipped with FPX_F_TRUSTED)
+int enqueue_validate(fpx_ctx* ctx, Batch& b, bool check_round) {
+  b.run_id = ++ctx->run_id;
+  if (ctx->run_id == 0xFFFFFFFFu) {  // stamp space exhausted: start over
+    HIPCHK(ctx, hipMemsetAsync(ctx->st.stamp, 0, sizeof(uint32_t) * (size_t)ctx->g.S, ctx->stream));
+    ctx->run_id = 0;
+    b.run_id = ++ctx->run_id;
+  }
+  if (ctx->cfg.flags & FPX_F_TRUSTED) return FPX_OK;
+  b.check_round = check_round && !ctx->g.per_slot;
+  if (b.check_round)
+    HIPCHK(ctx, hipMemsetAsync(ctx->st.run_round, 0xFF, sizeof(int32_t) * (size_t)ctx->g.ngroups, ctx->stream));
+  hipLaunchKernelGGL(k_validate, dim3((b.n + 255) / 256), dim3(256), 0, ctx->stream, ctx->g, ctx->st, b);
+  return launch_check(ctx);
+}
+
+// K1 / K3 on one device run
+int enqueue_phase2(fpx_ctx* ctx, Batch& b, bool fused) {
+  if (b.n == 0) return FPX_OK;
+  int rc = enqueue_validate(ctx, b, true);
+  if (rc) return rc;
+  const int grid = grid_for(ctx, b.n);
+  launch_phase2(ctx, b, fused, grid);
+  rc = launch_check(ctx);
+  if (rc) return rc;
+  const int ntab = ctx->g.ngroups * ctx->g.R;
+  hipLaunchKernelGGL(k_finalize, dim3((ntab + 63) / 64), dim3(256), 0, ctx->stream, ctx->g, ctx->st, grid);
+  return launch_check(ctx);
+}
+
+int enqueue_open(fpx_ctx* ctx, Batch& b) {
+  if (b.n == 0) return FPX_OK;
+  int rc = enqueue_validate(ctx, b, false);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_open, dim3((b.n + 255) / 256), dim3(256), 0, ctx->stream, ctx->g, ctx->st, b);
+  return launch_check(ctx);
+}
+
+int enqueue_tally(fpx_ctx* ctx, Batch& b) {
+  if (b.n == 0) return FPX_OK;
+  int rc = enqueue_validate(ctx, b, false);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_tally, dim3((b.n + 255) / 256), dim3(256), 0, ctx->stream, ctx->g, ctx->st, b);
+  return launch_check(ctx);
+}
+
+// fetch + clear the sticky device status (synchronises the stream)
+int fetch_status(fpx_ctx* ctx) {
+  int32_t h[4] = {0, 0, 0, 0};
+  HIPCHK(ctx, hipMemcpyAsync(h, ctx->st.status, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (h[0] != 0) {
+    ctx->err_index = h[ST_INDEX];
+    ctx->err_slot = h[ST_SLOT];
+    ctx->err_round = h[ST_ROUND];
+    HIPCHK(ctx, hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * 8, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return h[0];
+}
+
+int init_state(fpx_ctx* ctx) {
+  const Geom& g = ctx->g;
+  State& st = ctx->st;
+  const size_t ncell = (size_t)g.S * g.R, nsc = (size_t)g.ngroups * g.R;
+  HIPCHK(ctx, hipMemsetAsync(st.promised, 0xFF, nsc * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.max_voted, 0xFF, nsc * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.vote_round, 0xFF, ncell * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.vote_value, 0xFF, ncell * 4, ctx->stream));
+  if (st.ballot) HIPCHK(ctx, hipMemsetAsync(st.ballot, 0xFF, ncell * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.pl_key, 0, (size_t)g.S * g.wp * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.pl_value, 0xFF, (size_t)g.S * g.wp * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.pl_bits, 0, (size_t)g.S * g.wp * 32, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.stamp, 0, (size_t)g.S * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.run_round, 0xFF, (size_t)g.ngroups * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.status, 0, 8 * 4, ctx->stream));
+  ctx->run_id = 0;
+  ctx->hrun = 0;
+  std::fill(ctx->hstamp.begin(), ctx->hstamp.end(), 0u);
+  return FPX_OK;
+}
+
+void free_state(fpx_ctx* ctx) {
+  State& st = ctx->st;
+  void* ps[] = {st.promised, st.max_voted, st.vote_round, st.vote_value, st.ballot, st.pl_key, st.pl_value,
+                st.pl_bits,  st.stamp,     st.run_round,  st.status,     st.part};
+  for (void* p : ps)
+    if (p) (void)hipFree(p);
+  DevBuf* bs[] = {&ctx->d_slot,   &ctx->d_round, &ctx->d_value, &ctx->d_target, &ctx->d_bits_a, &ctx->d_bits_b,
+                  &ctx->d_i32_a,  &ctx->d_i32_b, &ctx->d_i32_c, &ctx->d_u8,     &ctx->d_scratch};
+  for (DevBuf* b : bs)
+    if (b->p) (void)hipFree(b->p);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+}
+
+// ---- host-side run splitting ---------------------------------------------------------------------
+// Cuts [0, n) into maximal runs that satisfy the run contract, so that running them back to back
+// equals message-at-a-time delivery in array order.
+int host_group(const fpx_config& c, int slot) {
+  const int lg = slot % c.num_leader_groups;
+  const int ag = (slot / c.num_leader_groups) % c.num_groups;
+  return lg * c.num_groups + ag;
+}
+
+void split_runs(fpx_ctx* ctx, int n, const int32_t* slot, const int32_t* round, bool check_round,
+                std::vector<int>* cuts) {
+  cuts->clear();
+  cuts->push_back(0);
+  if (ctx->hstamp.empty()) ctx->hstamp.assign((size_t)ctx->g.S, 0u);
+  if (ctx->hround.empty()) ctx->hround.assign((size_t)ctx->g.ngroups, -1);
+  check_round = check_round && !ctx->g.per_slot;
+  std::vector<int> touched;
+  auto new_run = [&]() {
+    if (++ctx->hrun == 0) {
+      std::fill(ctx->hstamp.begin(), ctx->hstamp.end(), 0u);
+      ctx->hrun = 1;
+    }
+    for (int gidx : touched) ctx->hround[gidx] = -1;
+    touched.clear();
+  };
+  new_run();
+  for (int i = 0; i < n; ++i) {
+    const int s = slot[i];
+    bool cut = ctx->hstamp[s] == ctx->hrun;
+    int gidx = 0;
+    if (check_round) {
+      gidx = ctx->g.ngroups == 1 ? 0 : host_group(ctx->cfg, s);
+      if (ctx->hround[gidx] != -1 && ctx->hround[gidx] != round[i]) cut = true;
+    }
+    if (cut) {
+      cuts->push_back(i);
+      new_run();
+    }
+    ctx->hstamp[s] = ctx->hrun;
+    if (check_round) {
+      if (ctx->hround[gidx] == -1) touched.push_back(gidx);
+      ctx->hround[gidx] = round[i];
+    }
+  }
+  cuts->push_back(n);
+  for (int gidx : touched) ctx->hround[gidx] = -1;
+}
+
+int check_inputs(fpx_ctx* ctx, int n, const int32_t* slot, const int32_t* round) {
+  if (!ctx || n < 0 || (n > 0 && (!slot || !round))) return FPX_EINVAL;
+  for (int i = 0; i < n; ++i) {
+    if (slot[i] < 0 || slot[i] >= ctx->g.S || round[i] < 0) {
+      ctx->err_index = i;
+      ctx->err_slot = slot[i];
+      ctx->err_round = round[i];
+      return FPX_EINVAL;
+    }
+  }
+  return FPX_OK;
+}
+
+template <typename T>
+int h2d(fpx_ctx* ctx, DevBuf* b, const T* src, size_t count) {
+  int rc = grow(ctx, b, count * sizeof(T));
+  if (rc) return rc;
+  if (src && count) HIPCHK(ctx, hipMemcpyAsync(b->p, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  return FPX_OK;
+}
+
+template <typename T>
+int d2h(fpx_ctx* ctx, T* dst, const DevBuf& b, size_t count) {
+  if (dst && count) HIPCHK(ctx, hipMemcpyAsync(dst, b.p, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+  return FPX_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int32_t fpx_version(void) { return FPX_VERSION; }
+
+const char* fpx_strerror(int32_t s) {
+  switch (s) {
+    case FPX_OK: return "ok";
+    case FPX_EINVAL: return "invalid argument (require failed)";
+    case FPX_EFATAL_UNKNOWN_SLOTROUND: return "Phase2b for a (slot, round) that was never opened (logger.fatal)";
+    case FPX_EHIP: return "HIP runtime error";
+    case FPX_ENODEVICE: return "no usable gfx950 device (libfpx has no CPU fallback)";
+    case FPX_ECAPACITY: return "more live (slot, round) tallies for one slot than tally_ways";
+    case FPX_EORDER: return "device batch violates the run contract; nothing was applied";
+    case FPX_ENOMEM: return "out of device memory";
+    default: return "unknown status";
+  }
+}
+
+int32_t fpx_config_check(const fpx_config* cfg) { return check_config(cfg); }
+
+int32_t fpx_round_leader(int32_t n, int32_t round) { return round % n; }
+
+int32_t fpx_next_classic_round(int32_t n, int32_t leader_index, int32_t round) {
+  if (round < 0) return leader_index;
+  const int32_t smallest_multiple = n * (round / n);
+  const int32_t offset = leader_index % n;
+  return smallest_multiple + offset > round ? smallest_multiple + offset : smallest_multiple + n + offset;
+}
+
+int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
+  if (!out) return FPX_EINVAL;
+  *out = nullptr;
+  int rc = check_config(cfg);
+  if (rc) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
+    return FPX_ENODEVICE;
+  fpx_ctx* ctx = new (std::nothrow) fpx_ctx();
+  if (!ctx) return FPX_ENOMEM;
+  ctx->cfg = *cfg;
+  if (!ctx->cfg.replicas_total) ctx->cfg.replicas_total = cfg->num_replicas;
+  make_geom(ctx->cfg, &ctx->g);
+  memset(&ctx->st, 0, sizeof(ctx->st));
+  if (hipSetDevice(cfg->device) != hipSuccess) {
+    delete ctx;
+    return FPX_ENODEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+  ctx->max_grid = ctx->num_cus * 8;
+  int G = 1;
+  while (G * 4 < ctx->g.R) G <<= 1;
+  ctx->lanes_per_slot = G;
+  ctx->vec = (ctx->g.R % 4) == 0;
+  // big tables: fewer resident blocks so that the partial table stays small
+  const int ntab = ctx->g.ngroups * ctx->g.R;
+  if (ntab > 1024) ctx->max_grid = std::max(ctx->num_cus, ctx->max_grid * 1024 / ntab);
+
+  auto fail = [&](int code) {
+    free_state(ctx);
+    delete ctx;
+    return code;
+  };
+  if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(FPX_EHIP);
+  ctx->stream = ctx->own_stream;
+  const Geom& g = ctx->g;
+  State& st = ctx->st;
+  const size_t ncell = (size_t)g.S * g.R, nsc = (size_t)g.ngroups * g.R;
+  if ((rc = dalloc(ctx, &st.promised, nsc))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.max_voted, nsc))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.vote_round, ncell))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.vote_value, ncell))) return fail(rc);
+  if (g.per_slot && (rc = dalloc(ctx, &st.ballot, ncell))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.pl_key, (size_t)g.S * g.wp))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.pl_value, (size_t)g.S * g.wp))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.pl_bits, (size_t)g.S * g.wp * 4))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.stamp, (size_t)g.S))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.run_round, (size_t)g.ngroups))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.status, (size_t)8))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.part, (size_t)ctx->max_grid * 2 * ntab))) return fail(rc);
+  if ((rc = init_state(ctx))) return fail(rc);
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(FPX_EHIP);
+  *out = ctx;
+  return FPX_OK;
+}
+
+int32_t fpx_destroy(fpx_ctx* ctx) {
+  if (!ctx) return FPX_EINVAL;
+  (void)hipSetDevice(ctx->cfg.device);
+  (void)hipStreamSynchronize(ctx->stream);
+  free_state(ctx);
+  delete ctx;
+  return FPX_OK;
+}
+
+int32_t fpx_reset(fpx_ctx* ctx) {
+  if (!ctx) return FPX_EINVAL;
+  return init_state(ctx);
+}
+
+int32_t fpx_set_stream(fpx_ctx* ctx, void* hip_stream) {
+  if (!ctx) return FPX_EINVAL;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return FPX_OK;
+}
+
+int32_t fpx_sync(fpx_ctx* ctx) {
+  if (!ctx) return FPX_EINVAL;
+  return fetch_status(ctx);
+}
+
+int32_t fpx_error_detail(fpx_ctx* ctx, int32_t* index, int32_t* slot, int32_t* round) {
+  if (!ctx) return FPX_EINVAL;
+  if (index) *index = ctx->err_index;
+  if (slot) *slot = ctx->err_slot;
+  if (round) *round = ctx->err_round;
+  return FPX_OK;
+}
+
+int32_t fpx_last_hip_error(fpx_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
+int64_t fpx_device_bytes(fpx_ctx* ctx) { return ctx ? ctx->bytes : 0; }
+
+// ---- a5 --------------------------------------------------------------------------------------------
+static int32_t quorum_eval_impl(const fpx_config* cfg, int32_t n, const uint64_t* nodes, int32_t strict, int read,
+                                uint8_t* out) {
+  if (!cfg || n < 0 || (n > 0 && (!nodes || !out))) return FPX_EINVAL;
+  fpx_config c = *cfg;
+  // only the quorum fields matter here; make the rest valid
+  if (c.num_slots < 1) c.num_slots = 1;
+  if (c.num_groups < 1) c.num_groups = 1;
+  if (c.num_leader_groups < 1) c.num_leader_groups = 1;
+  if (c.num_leaders < 1) c.num_leaders = 1;
+  if (c.tally_ways < 1) c.tally_ways = 1;
+  int rc = check_config(&c);
+  if (rc) return rc;
+  if (n == 0) return FPX_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FPX_ENODEVICE;
+  Geom g;
+  make_geom(c, &g);
+  uint64_t* d_nodes = nullptr;
+  uint8_t* d_out = nullptr;
+  int32_t* d_status = nullptr;
+  fpx_ctx* none = nullptr;
+  HIPCHK(none, hipMalloc((void**)&d_nodes, (size_t)n * 32));
+  HIPCHK(none, hipMalloc((void**)&d_out, (size_t)n));
+  HIPCHK(none, hipMalloc((void**)&d_status, 32));
+  HIPCHK(none, hipMemset(d_status, 0, 32));
+  HIPCHK(none, hipMemcpy(d_nodes, nodes, (size_t)n * 32, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_quorum_eval, dim3((n + 255) / 256), dim3(256), 0, 0, g, n, d_nodes, strict, read, d_out, d_status);
+  HIPCHK(none, hipGetLastError());
+  int32_t hs[2] = {0, 0};
+  HIPCHK(none, hipMemcpy(out, d_out, (size_t)n, hipMemcpyDeviceToHost));
+  HIPCHK(none, hipMemcpy(hs, d_status, sizeof(hs), hipMemcpyDeviceToHost));
+  (void)hipFree(d_nodes);
+  (void)hipFree(d_out);
+  (void)hipFree(d_status);
+  return hs[0];
+}
+
+int32_t fpx_quorum_eval(const fpx_config* cfg, int32_t n, const uint64_t* nodes, int32_t strict, uint8_t* out) {
+  return quorum_eval_impl(cfg, n, nodes, strict, 0, out);
+}
+int32_t fpx_read_quorum_eval(const fpx_config* cfg, int32_t n, const uint64_t* nodes, int32_t strict, uint8_t* out) {
+  return quorum_eval_impl(cfg, n, nodes, strict, 1, out);
+}
+int32_t fpx_is_write_quorum(const fpx_config* cfg, const uint64_t nodes[4], int32_t strict, uint8_t* out) {
+  return quorum_eval_impl(cfg, 1, nodes, strict, 0, out);
+}
+
+// ---- device-pointer entry points -----------------------------------------------------------------
+int32_t fpx_acceptor_phase2a_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,
+                                 const int32_t* d_value_id, const uint64_t* d_target_mask, uint64_t* d_vote_bits,
+                                 uint64_t* d_nack_bits, int32_t* d_nack_round) {
+  if (!ctx || n < 0) return FPX_EINVAL;
+  Batch b;
+  memset(&b, 0, sizeof(b));
+  b.n = n, b.slot = d_slot, b.round = d_round, b.value = d_value_id, b.target = d_target_mask;
+  b.vote_bits = d_vote_bits, b.nack_bits = d_nack_bits, b.nack_round = d_nack_round;
+  return enqueue_phase2(ctx, b, false);
+}
+
+int32_t fpx_phase2_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,
+                             const int32_t* d_value_id, const uint64_t* d_target_mask, uint8_t* d_chosen,
+                             int32_t* d_chosen_round, int32_t* d_chosen_value, int32_t* d_nack_round) {
+  if (!ctx || n < 0) return FPX_EINVAL;
+  Batch b;
+  memset(&b, 0, sizeof(b));
+  b.n = n, b.slot = d_slot, b.round = d_round, b.value = d_value_id, b.target = d_target_mask;
+  b.chosen = d_chosen, b.chosen_round = d_chosen_round, b.chosen_value = d_chosen_value, b.nack_round = d_nack_round;
+  return enqueue_phase2(ctx, b, true);
+}
+
+int32_t fpx_proxy_open_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,
+                           const int32_t* d_value_id, uint8_t* d_is_new) {
+  if (!ctx || n < 0) return FPX_EINVAL;
+  Batch b;
+  memset(&b, 0, sizeof(b));
+  b.n = n, b.slot = d_slot, b.round = d_round, b.value = d_value_id, b.is_new = d_is_new;
+  return enqueue_open(ctx, b);
+}
+
+int32_t fpx_proxy_phase2b_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,
+                              const uint64_t* d_vote_bits, uint8_t* d_newly_chosen, int32_t* d_chosen_round,
+                              int32_t* d_chosen_value) {
+  if (!ctx || n < 0) return FPX_EINVAL;
+  Batch b;
+  memset(&b, 0, sizeof(b));
+  b.n = n, b.slot = d_slot, b.round = d_round, b.vote_bits = const_cast<uint64_t*>(d_vote_bits);
+  b.chosen = d_newly_chosen, b.chosen_round = d_chosen_round, b.chosen_value = d_chosen_value;
+  return enqueue_tally(ctx, b);
+}
+
+// ---- host-pointer entry points: stage, split into runs, run, copy back ----------------------------
+int32_t fpx_acceptor_phase2a(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round,
+                             const int32_t* value_id, const uint64_t* target_mask, uint64_t* vote_bits,
+                             uint64_t* nack_bits, int32_t* nack_round) {
+  int rc = check_inputs(ctx, n, slot, round);
+  if (rc) return rc;
+  if (n == 0) return FPX_OK;
+  if (!value_id) return FPX_EINVAL;
+  if ((rc = h2d(ctx, &ctx->d_slot, slot, n))) return rc;
+  if ((rc = h2d(ctx, &ctx->d_round, round, n))) return rc;
+  if ((rc = h2d(ctx, &ctx->d_value, value_id, n))) return rc;
+  if (target_mask && (rc = h2d(ctx, &ctx->d_target, target_mask, (size_t)n * 4))) return rc;
+  if ((rc = grow(ctx, &ctx->d_bits_a, (size_t)n * 32))) return rc;
+  if ((rc = grow(ctx, &ctx->d_bits_b, (size_t)n * 32))) return rc;
+  if ((rc = grow(ctx, &ctx->d_i32_a, (size_t)n * 4))) return rc;
+  std::vector<int> cuts;
+  split_runs(ctx, n, slot, round, true, &cuts);
+  for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+    const int lo = cuts[k], len = cuts[k + 1] - cuts[k];
+    rc = fpx_acceptor_phase2a_dev(ctx, len, (int32_t*)ctx->d_slot.p + lo, (int32_t*)ctx->d_round.p + lo,
+                                  (int32_t*)ctx->d_value.p + lo,
+                                  target_mask ? (uint64_t*)ctx->d_target.p + (size_t)lo * 4 : nullptr,
+                                  (uint64_t*)ctx->d_bits_a.p + (size_t)lo * 4,
+                                  nack_bits ? (uint64_t*)ctx->d_bits_b.p + (size_t)lo * 4 : nullptr,
+                                  (int32_t*)ctx->d_i32_a.p + lo);
+    if (rc) return rc;
+  }
+  if ((rc = d2h(ctx, vote_bits, ctx->d_bits_a, (size_t)n * 4))) return rc;
+  if ((rc = d2h(ctx, nack_bits, ctx->d_bits_b, (size_t)n * 4))) return rc;
+  if ((rc = d2h(ctx, nack_round, ctx->d_i32_a, (size_t)n))) return rc;
+  return fetch_status(ctx);
+}
+
+int32_t fpx_phase2_fused(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round, const int32_t* value_id,
+                         const uint64_t* target_mask, uint8_t* chosen, int32_t* chosen_round, int32_t* chosen_value,
+                         int32_t* nack_round) {
+  int rc = check_inputs(ctx, n, slot, round);
+  if (rc) return rc;
+  if (n == 0) return FPX_OK;
+  if (!value_id) return FPX_EINVAL;
+  if ((rc = h2d(ctx, &ctx->d_slot, slot, n))) return rc;
+  if ((rc = h2d(ctx, &ctx->d_round, round, n))) return rc;
+  if ((rc = h2d(ctx, &ctx->d_value, value_id, n))) return rc;
+  if (target_mask && (rc = h2d(ctx, &ctx->d_target, target_mask, (size_t)n * 4))) return rc;
+  if ((rc = grow(ctx, &ctx->d_u8, (size_t)n))) return rc;
+  if ((rc = grow(ctx, &ctx->d_i32_a, (size_t)n * 4))) return rc;
+  if ((rc = grow(ctx, &ctx->d_i32_b, (size_t)n * 4))) return rc;
+  if ((rc = grow(ctx, &ctx->d_i32_c, (size_t)n * 4))) return rc;
+  std::vector<int> cuts;
+  split_runs(ctx, n, slot, round, true, &cuts);
+  for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+    const int lo = cuts[k], len = cuts[k + 1] - cuts[k];
+    rc = fpx_phase2_fused_dev(ctx, len, (int32_t*)ctx->d_slot.p + lo, (int32_t*)ctx->d_round.p + lo,
+                              (int32_t*)ctx->d_value.p + lo,
+                              target_mask ? (uint64_t*)ctx->d_target.p + (size_t)lo * 4 : nullptr,
+                              (uint8_t*)ctx->d_u8.p + lo, (int32_t*)ctx->d_i32_a.p + lo, (int32_t*)ctx->d_i32_b.p + lo,
+                              (int32_t*)ctx->d_i32_c.p + lo);
+    if (rc) return rc;
+  }
+  if ((rc = d2h(ctx, chosen, ctx->d_u8, (size_t)n))) return rc;
+  if ((rc = d2h(ctx, chosen_round, ctx->d_i32_a, (size_t)n))) return rc;
+  if ((rc = d2h(ctx, chosen_value, ctx->d_i32_b, (size_t)n))) return rc;
+  if ((rc = d2h(ctx, nack_round, ctx->d_i32_c, (size_t)n))) return rc;
+  return fetch_status(ctx);
+}
+
+int32_t fpx_proxy_open(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round, const int32_t* value_id,
+                       uint8_t* is_new) {
+  int rc = check_inputs(ctx, n, slot, round);
+  if (rc) return rc;
+  if (n == 0) return FPX_OK;
+  if (!value_id) return FPX_EINVAL;
+  if ((rc = h2d(ctx, &ctx->d_slot, slot, n))) return rc;
+  if ((rc = h2d(ctx, &ctx->d_round, round, n))) return rc;
+  if ((rc = h2d(ctx, &ctx->d_value, value_id, n))) return rc;
+  if ((rc = grow(ctx, &ctx->d_u8, (size_t)n))) return rc;
+  std::vector<int> cuts;
+  split_runs(ctx, n, slot, round, false, &cuts);
+  for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+    const int lo = cuts[k], len = cuts[k + 1] - cuts[k];
+    rc = fpx_proxy_open_dev(ctx, len, (int32_t*)ctx->d_slot.p + lo, (int32_t*)ctx->d_round.p + lo,
+                            (int32_t*)ctx->d_value.p + lo, (uint8_t*)ctx->d_u8.p + lo);
+    if (rc) return rc;
+  }
+  if ((rc = d2h(ctx, is_new, ctx->d_u8, (size_t)n))) return rc;
+  return fetch_status(ctx);
+}
+
+int32_t fpx_proxy_phase2b(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round, const uint64_t* vote_bits,
+                          uint8_t* newly_chosen, int32_t* chosen_round, int32_t* chosen_value) {
+  int rc = check_inputs(ctx, n, slot, round);
+  if (rc) return rc;
+  if (n == 0) return FPX_OK;
+  if (!vote_bits) return FPX_EINVAL;
+  if ((rc = h2d(ctx, &ctx->d_slot, slot, n))) return rc;
+  if ((rc = h2d(ctx, &ctx->d_round, round, n))) return rc;
+  if ((rc = h2d(ctx, &ctx->d_bits_a, vote_bits, (size_t)n * 4))) return rc;
+  if ((rc = grow(ctx, &ctx->d_u8, (size_t)n))) return rc;
+  if ((rc = grow(ctx, &ctx->d_i32_a, (size_t)n * 4))) return rc;
+  if ((rc = grow(ctx, &ctx->d_i32_b, (size_t)n * 4))) return rc;
+  std::vector<int> cuts;
+  split_runs(ctx, n, slot, round, false, &cuts);
+  for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+    const int lo = cuts[k], len = cuts[k + 1] - cuts[k];
+    rc = fpx_proxy_phase2b_dev(ctx, len, (int32_t*)ctx->d_slot.p + lo, (int32_t*)ctx->d_round.p + lo,
+                               (uint64_t*)ctx->d_bits_a.p + (size_t)lo * 4, (uint8_t*)ctx->d_u8.p + lo,
+                               (int32_t*)ctx->d_i32_a.p + lo, (int32_t*)ctx->d_i32_b.p + lo);
+    if (rc) return rc;
+  }
+  if ((rc = d2h(ctx, newly_chosen, ctx->d_u8, (size_t)n))) return rc;
+  if ((rc = d2h(ctx, chosen_round, ctx->d_i32_a, (size_t)n))) return rc;
+  if ((rc = d2h(ctx, chosen_value, ctx->d_i32_b, (size_t)n))) return rc;
+  return fetch_status(ctx);
+}
+
+int32_t fpx_acceptor_phase1a(fpx_ctx* ctx, int32_t group, int32_t round, int32_t chosen_watermark,
+                             const uint64_t* target_mask, uint64_t* promised_bits, uint64_t* nack_bits) {
+  if (!ctx || group < 0 || group >= ctx->g.ngroups || round < 0) return FPX_EINVAL;
+  int rc;
+  if ((rc = grow(ctx, &ctx->d_scratch, 128))) return rc;
+  uint64_t* d_out = (uint64_t*)ctx->d_scratch.p;       // [8]: promised bits, nack bits
+  uint64_t* d_tgt = target_mask ? d_out + 8 : nullptr;  // [4]
+  HIPCHK(ctx, hipMemsetAsync(d_out, 0, 64, ctx->stream));
+  if (target_mask) HIPCHK(ctx, hipMemcpyAsync(d_tgt, target_mask, 32, hipMemcpyHostToDevice, ctx->stream));
+  uint64_t h[8];
+  if (!ctx->g.per_slot) {
+    hipLaunchKernelGGL(k_phase1a_scalar, dim3((ctx->g.R + 63) / 64), dim3(64), 0, ctx->stream, ctx->g, ctx->st, group,
+                       round, d_tgt, d_out);
+    if ((rc = launch_check(ctx))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(h, d_out, 64, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  } else {
+    hipLaunchKernelGGL(k_phase1a_perslot, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, ctx->g, ctx->st, group,
+                       round, chosen_watermark, d_tgt, d_out);
+    if ((rc = launch_check(ctx))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(h, d_out, 64, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // promised = targeted own acceptors that did not nack
+    for (int r = 0; r < ctx->g.R; ++r) {
+      const int bit = ctx->g.base + r;
+      const bool tgt = !target_mask || ((target_mask[bit >> 6] >> (bit & 63)) & 1ull);
+      const bool nck = (h[4 + (bit >> 6)] >> (bit & 63)) & 1ull;
+      if (tgt && !nck) h[bit >> 6] |= 1ull << (bit & 63);
+    }
+  }
+  if (promised_bits) memcpy(promised_bits, h, 32);
+  if (nack_bits) memcpy(nack_bits, h + 4, 32);
+  return FPX_OK;
+}
+
+// ---- readback ----------------------------------------------------------------------------------------
+int32_t fpx_read_state(fpx_ctx* ctx, int32_t* vote_round, int32_t* vote_value, int32_t* ballot) {
+  if (!ctx) return FPX_EINVAL;
+  const size_t ncell = (size_t)ctx->g.S * ctx->g.R;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (vote_round) HIPCHK(ctx, hipMemcpy(vote_round, ctx->st.vote_round, ncell * 4, hipMemcpyDeviceToHost));
+  if (vote_value) HIPCHK(ctx, hipMemcpy(vote_value, ctx->st.vote_value, ncell * 4, hipMemcpyDeviceToHost));
+  if (ballot) {
+    if (ctx->st.ballot)
+      HIPCHK(ctx, hipMemcpy(ballot, ctx->st.ballot, ncell * 4, hipMemcpyDeviceToHost));
+    else
+      std::fill(ballot, ballot + ncell, -1);
+  }
+  return FPX_OK;
+}
+
+int32_t fpx_read_scalars(fpx_ctx* ctx, int32_t* promised, int32_t* max_voted_slot) {
+  if (!ctx) return FPX_EINVAL;
+  const size_t nsc = (size_t)ctx->g.ngroups * ctx->g.R;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (promised) HIPCHK(ctx, hipMemcpy(promised, ctx->st.promised, nsc * 4, hipMemcpyDeviceToHost));
+  if (max_voted_slot) HIPCHK(ctx, hipMemcpy(max_voted_slot, ctx->st.max_voted, nsc * 4, hipMemcpyDeviceToHost));
+  return FPX_OK;
+}
+
+int32_t fpx_read_acceptor(fpx_ctx* ctx, int32_t group, int32_t replica, int32_t* promised, int32_t* max_voted_slot,
+                          int32_t* vote_round, int32_t* vote_value, int32_t* ballot) {
+  if (!ctx || group < 0 || group >= ctx->g.ngroups || replica < 0 || replica >= ctx->g.R) return FPX_EINVAL;
+  const size_t e = (size_t)group * ctx->g.R + replica;
+  const size_t S = (size_t)ctx->g.S;
+  int rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (promised) {
+    if (ctx->g.per_slot) *promised = -1;
+    else HIPCHK(ctx, hipMemcpy(promised, ctx->st.promised + e, 4, hipMemcpyDeviceToHost));
+  }
+  if (max_voted_slot) HIPCHK(ctx, hipMemcpy(max_voted_slot, ctx->st.max_voted + e, 4, hipMemcpyDeviceToHost));
+  if (vote_round || vote_value || ballot) {
+    if ((rc = grow(ctx, &ctx->d_scratch, S * 12 + 128))) return rc;
+    int32_t* base = (int32_t*)((char*)ctx->d_scratch.p + 128);
+    hipLaunchKernelGGL(k_gather_acceptor, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream, ctx->g, ctx->st,
+                       group, replica, base, base + S, base + 2 * S);
+    if ((rc = launch_check(ctx))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (vote_round) HIPCHK(ctx, hipMemcpy(vote_round, base, S * 4, hipMemcpyDeviceToHost));
+    if (vote_value) HIPCHK(ctx, hipMemcpy(vote_value, base + S, S * 4, hipMemcpyDeviceToHost));
+    if (ballot) HIPCHK(ctx, hipMemcpy(ballot, base + 2 * S, S * 4, hipMemcpyDeviceToHost));
+  }
+  return FPX_OK;
+}
+
+int32_t fpx_read_tally(fpx_ctx* ctx, int32_t slot, int32_t* num_entries, int32_t* rounds, int32_t* states,
+                       int32_t* values, uint64_t* vote_bits) {
+  if (!ctx || slot < 0 || slot >= ctx->g.S) return FPX_EINVAL;
+  const int wp = ctx->g.wp;
+  uint32_t keys[8];
+  int32_t vals[8];
+  uint64_t bits[32];
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipMemcpy(keys, ctx->st.pl_key + (size_t)slot * wp, (size_t)wp * 4, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(vals, ctx->st.pl_value + (size_t)slot * wp, (size_t)wp * 4, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(bits, ctx->st.pl_bits + (size_t)slot * wp * 4, (size_t)wp * 32, hipMemcpyDeviceToHost));
+  int cnt = 0;
+  for (int w = 0; w < ctx->g.ways; ++w) {
+    if (keys[w] == 0) continue;
+    const bool done = keys[w] & KEY_DONE;
+    if (rounds) rounds[cnt] = (int32_t)((keys[w] & KEY_ROUND_MASK) - 1u);
+    if (states) states[cnt] = done ? 1 : 0;
+    // a Done entry has dropped its Pending payload (ProxyLeader.scala:256)
+    if (values) values[cnt] = done ? -1 : vals[w];
+    if (vote_bits)
+      for (int k = 0; k < 4; ++k) vote_bits[(size_t)cnt * 4 + k] = done ? 0ull : bits[w * 4 + k];
+    ++cnt;
+  }
+  if (num_entries) *num_entries = cnt;
+  return FPX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,732 @@
+// fpx_kernels.hpp -- hand-written HIP kernels for gfx950 (MI355X / CDNA4), wave64.
+//
+// The hot path of SURVEY.md section 8 as data-parallel kernels over a (log-slot x acceptor)
+// struct-of-arrays resident in HBM:
+//
+//   vote_round[S][R], vote_value[S][R] (+ ballot[S][R] in FPX_BALLOT_PER_SLOT mode), int32,
+//   slot-major: the R cells of one slot are contiguous (1 KiB at R = 256), so one wavefront moves
+//   one slot row with a single 16-byte-per-lane access.
+//
+// Kernels (names follow SURVEY.md section 2.1):
+//   k_validate   run-contract check of a device batch (slot range, slot uniqueness, one round per
+//                acceptor group)
+//   k_phase2     K1 (acceptor vote: a1/a2) and K3 (fused open + vote + tally: a6 + a1 + a3/a4/a5)
+//   k_open       a6  ProxyLeader.handlePhase2a bookkeeping
+//   k_tally      K2  ProxyLeader.handlePhase2b (a3/a4) using the K2q predicates (a5)
+//   k_finalize   folds per-block maxima into the per-acceptor scalars round / maxVotedSlot
+//   k_phase1a_*  Acceptor.handlePhase1a
+//   k_quorum_eval  a5 standalone
+//
+// This path is integer compare / bit reduce at ~0.1 op/byte: HBM-bound, no MFMA.  What matters is
+// full-line coalesced traffic, enough loads in flight per wave, and never re-reading a row: the vote
+// bitmap of a slot is built in registers (one nibble per lane, OR-reduced across the lanes of the
+// slot with cross-lane shuffles), tallied on the spot with popcount / mask tests, and only the
+// 8-byte chosen record leaves the chip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fpx {
+
+typedef int int4v __attribute__((ext_vector_type(4)));
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+
+enum : uint32_t { KEY_DONE = 0x80000000u, KEY_ROUND_MASK = 0x7fffffffu };
+
+// status word layout in HBM (int32[8])
+enum { ST_CODE = 0, ST_INDEX = 1, ST_SLOT = 2, ST_ROUND = 3 };
+
+struct Geom {
+  int32_t S, R;
+  int32_t num_groups, num_leader_groups, ngroups;  // ngroups = num_leader_groups * num_groups
+  int32_t qkind, qsize;                            // qsize: threshold for THRESHOLD / MAJORITY / UNANIMOUS
+  int32_t grid_rows, grid_cols;
+  int32_t per_slot;                                // ballot mode
+  int32_t ways, wp;                                // tally ways, padded row length (4 or 8)
+  int32_t base, total;                             // replica_base, replicas_total
+  uint64_t member[4];                              // bits [0, total)
+};
+
+struct State {
+  int32_t* promised;    // [ngroups][R]   Acceptor.round
+  int32_t* max_voted;   // [ngroups][R]   Acceptor.maxVotedSlot
+  int32_t* vote_round;  // [S][R]
+  int32_t* vote_value;  // [S][R]
+  int32_t* ballot;      // [S][R] or null
+  uint32_t* pl_key;     // [S][wp]        0 = empty, else (round + 1) | KEY_DONE
+  int32_t* pl_value;    // [S][wp]
+  uint64_t* pl_bits;    // [S][wp][4]
+  uint32_t* stamp;      // [S]            run id of the last run that touched the slot
+  int32_t* run_round;   // [ngroups]      the single round of the current run per group (-1 = none)
+  int32_t* status;      // [8]
+  int32_t* part;        // [grid][2][ngroups*R] per-block maxima (accepted round, voted slot)
+};
+
+struct Batch {
+  int32_t n;
+  const int32_t* slot;
+  const int32_t* round;
+  const int32_t* value;
+  const uint64_t* target;  // n x 4 or null
+  uint64_t* vote_bits;     // K1
+  uint64_t* nack_bits;     // K1
+  int32_t* nack_round;     // K1 / K3
+  uint8_t* chosen;         // K3 (K2: newly_chosen)
+  int32_t* chosen_round;
+  int32_t* chosen_value;
+  uint8_t* is_new;         // k_open
+  uint32_t run_id;
+  int32_t check_round;     // validate: enforce one round per group (ACCEPTOR ballot mode)
+};
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int group_of_slot(const Geom& g, int slot) {
+  // multipaxos/ProxyLeader.scala:190 ; mencius/ProxyLeader.scala:169-176,231-234
+  if (g.ngroups == 1) return 0;
+  const int lg = slot % g.num_leader_groups;
+  const int ag = (slot / g.num_leader_groups) % g.num_groups;
+  return lg * g.num_groups + ag;
+}
+
+__device__ __forceinline__ void report(const State& st, int code, int index, int slot, int round) {
+  if (atomicCAS(&st.status[ST_CODE], 0, code) == 0) {
+    st.status[ST_INDEX] = index;
+    st.status[ST_SLOT] = slot;
+    st.status[ST_ROUND] = round;
+  }
+}
+
+__device__ __forceinline__ int popc256(const uint64_t x[4]) {
+  return __popcll(x[0]) + __popcll(x[1]) + __popcll(x[2]) + __popcll(x[3]);
+}
+
+// bits [lo, lo + n) of the 256-bit set, restricted to word w
+__device__ __forceinline__ uint64_t range_mask(int lo, int n, int w) {
+  const int wlo = w * 64;
+  const int a = lo > wlo ? lo : wlo;
+  const int b = (lo + n) < (wlo + 64) ? (lo + n) : (wlo + 64);
+  if (a >= b) return 0ull;
+  const int len = b - a;
+  const uint64_t m = len == 64 ? ~0ull : ((1ull << len) - 1ull);
+  return m << (a - wlo);
+}
+
+// K2q: isWriteQuorum on a member-masked 256-bit acceptor set.
+//   THRESHOLD        ProxyLeader.scala:238      |X| >= f + 1
+//   SIMPLE_MAJORITY  SimpleMajority.scala:30,46 |X| >= n / 2 + 1
+//   UNANIMOUS        UnanimousWrites.scala:50   X == members
+//   GRID             Grid.scala:43-50           every row has a member of X
+__device__ __forceinline__ bool is_write_quorum(const Geom& g, const uint64_t x[4]) {
+  if (g.qkind != 2) return popc256(x) >= g.qsize;
+  bool ok = true;
+  for (int r = 0; r < g.grid_rows; ++r) {
+    const int lo = r * g.grid_cols;
+    uint64_t hit = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) hit |= x[w] & range_mask(lo, g.grid_cols, w);
+    ok = ok && (hit != 0);
+  }
+  return ok;
+}
+
+//   THRESHOLD        n - f (the sets that intersect every (f+1)-subset)
+//   SIMPLE_MAJORITY  SimpleMajority.scala:41-47
+//   UNANIMOUS        UnanimousWrites.scala:36-42  non-empty
+//   GRID             Grid.scala:36-41             some row fully contained
+__device__ __forceinline__ bool is_read_quorum(const Geom& g, const uint64_t x[4]) {
+  const int c = popc256(x);
+  switch (g.qkind) {
+    case 0: return c >= g.total - (g.qsize - 1);
+    case 1: return c >= g.qsize;
+    case 3: return c >= 1;
+    default: break;
+  }
+  bool any = false;
+  for (int r = 0; r < g.grid_rows; ++r) {
+    const int lo = r * g.grid_cols;
+    bool all = true;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint64_t m = range_mask(lo, g.grid_cols, w);
+      all = all && ((x[w] & m) == m);
+    }
+    any = any || all;
+  }
+  return any;
+}
+
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
+  return (uint64_t)__shfl((unsigned long long)v, src);
+}
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int m) {
+  return (uint64_t)__shfl_xor((unsigned long long)v, m);
+}
+
+// 256-bit left shift by sh (0 <= sh < 256, multiple of 4)
+__device__ __forceinline__ void shl256(uint64_t x[4], int sh) {
+  if (sh == 0) return;
+  const int ws = sh >> 6, bs = sh & 63;
+  // whole-word moves with static register indices (a runtime-indexed array would go to scratch)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (ws > i) {
+      x[3] = x[2];
+      x[2] = x[1];
+      x[1] = x[0];
+      x[0] = 0ull;
+    }
+  }
+  if (bs != 0) {
+    x[3] = (x[3] << bs) | (x[2] >> (64 - bs));
+    x[2] = (x[2] << bs) | (x[1] >> (64 - bs));
+    x[1] = (x[1] << bs) | (x[0] >> (64 - bs));
+    x[0] = x[0] << bs;
+  }
+}
+
+// Assemble the per-slot bitmap from per-lane nibbles.  A slot is handled by G consecutive lanes
+// (lane gi of the group owns local acceptors 4*gi .. 4*gi+3).  Every lane of the group returns the
+// full bitmap (bit position = global acceptor index = base + local index).
+template <int G>
+__device__ __forceinline__ void assemble_bits(uint32_t nibble, int lane, int base, uint64_t out[4]) {
+  const int gi = lane & (G - 1);
+  uint64_t v = (uint64_t)nibble << (4 * (gi & 15));
+  constexpr int ROW = G < 16 ? G : 16;
+#pragma unroll
+  for (int m = 1; m < ROW; m <<= 1) v |= shfl_xor64(v, m);
+  // every lane of a 16-lane row now holds that row's 64-bit word
+  const int gbase = lane & ~(G - 1);
+  if (G == 64) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, w * 16);
+      const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), w * 16);
+      out[w] = ((uint64_t)hi << 32) | lo;
+    }
+  } else {
+    out[0] = (G > 16) ? shfl64(v, gbase) : v;
+    out[1] = (G > 16) ? shfl64(v, gbase + 16) : 0ull;
+    out[2] = 0ull;
+    out[3] = 0ull;
+  }
+  shl256(out, base);
+}
+
+// max over the G lanes of a slot group
+template <int G>
+__device__ __forceinline__ int group_max(int v) {
+#pragma unroll
+  for (int m = 1; m < G; m <<= 1) {
+    const int o = __shfl_xor(v, m);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// wave-level ordering of LDS traffic between lanes of one wavefront (DS ops of a wave execute in
+// order; this keeps the compiler from moving them)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_validate: run contract of a device batch.  One thread per message.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_validate(const Geom g, const State st, const Batch b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.n) return;
+  const int s = b.slot[i], r = b.round[i];
+  if (s < 0 || s >= g.S || r < 0) {
+    report(st, 1 /*FPX_EINVAL*/, i, s, r);
+    return;
+  }
+  // (1) slots pairwise distinct within the run
+  const uint32_t old = atomicExch(&st.stamp[s], b.run_id);
+  if (old == b.run_id) report(st, 6 /*FPX_EORDER*/, i, s, r);
+  // (2) one round per acceptor group within the run
+  if (b.check_round) {
+    int* rr = &st.run_round[group_of_slot(g, s)];
+    int cur = __hip_atomic_load(rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == -1) {
+      cur = atomicCAS(rr, -1, r);
+      if (cur == -1) cur = r;
+    }
+    if (cur != r) report(st, 6, i, s, r);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_phase2<G, VEC, PERSLOT, FUSED>
+//   G       lanes per slot (power of two, 4*G >= R): 64 for R in (128, 256], ... 1 for R <= 4
+//   VEC     R % 4 == 0: 16-byte row accesses
+//   PERSLOT ballot[S][R] in HBM instead of the per-acceptor scalar
+//   FUSED   K3 (open + vote + tally) instead of K1 (vote, bitmaps out)
+// A wavefront owns 64 consecutive messages: it stages their (slot, round, value) in registers with
+// one coalesced load each, then walks them Q = 64/G at a time, U steps in flight.
+// LDS: [2][ntab] per-block maxima tables, then per-wave staging of the outputs so that they leave
+// the CU as full coalesced lines.
+// ------------------------------------------------------------------------------------------------
+template <bool FUSED>
+struct WaveOut;
+template <>
+struct WaveOut<false> {    // K1: per-wave LDS staging of the per-slot bitmaps, indexed by message-in-chunk
+  uint64_t votes[64][4];
+  uint64_t nacks[64][4];
+  int32_t nack_round[64];
+};
+template <>
+struct WaveOut<true> {     // K3: only the chosen records are staged; bitmaps stay in registers
+  int32_t nack_round[64];
+  int32_t chosen_round[64];
+  int32_t chosen_value[64];
+  int32_t chosen[64];
+};
+
+template <int G, bool VEC, bool PERSLOT, bool FUSED>
+__global__ void __launch_bounds__(256)
+    k_phase2(const Geom g, const State st, const Batch b) {
+  constexpr int Q = 64 / G;           // slots per step
+  constexpr int U = G >= 4 ? 4 : G;   // steps in flight
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  if (st.status[ST_CODE] != 0) return;  // a failed validation applies nothing
+
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  const int gi = lane & (G - 1);
+  const int q = lane / G;
+  const int ntab = g.ngroups * g.R;
+  int32_t* tab_pr = reinterpret_cast<int32_t*>(smem);
+  int32_t* tab_mv = tab_pr + ntab;
+  WaveOut<FUSED>* wo = reinterpret_cast<WaveOut<FUSED>*>(smem + (((size_t)ntab * 8 + 15) & ~(size_t)15)) + wib;
+
+  for (int i = threadIdx.x; i < 2 * ntab; i += blockDim.x) tab_pr[i] = -1;
+  __syncthreads();
+
+  const bool one_group = g.ngroups == 1;
+  const int r0 = 4 * gi;  // first local acceptor of this lane
+  uint32_t own = 0;       // which of my 4 acceptors exist
+#pragma unroll
+  for (int k = 0; k < 4; ++k) own |= (r0 + k < g.R) ? (1u << k) : 0u;
+  const int bitpos = g.base + r0;  // global bit of my first acceptor
+
+  // per-lane maxima when there is one acceptor group (registers; folded into LDS at the end)
+  int acc_pr[4] = {-1, -1, -1, -1}, acc_mv[4] = {-1, -1, -1, -1};
+  int4v init_thr = {-1, -1, -1, -1};
+  if (!PERSLOT && one_group) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (own >> k & 1) init_thr[k] = st.promised[r0 + k];
+  }
+
+  const int nchunks = (b.n + 63) >> 6;
+  for (int chunk = blockIdx.x * 4 + wib; chunk < nchunks; chunk += gridDim.x * 4) {
+    const int m = chunk * 64 + lane;
+    const bool mv = m < b.n;
+    const int myslot = mv ? b.slot[m] : -1;
+    const int myround = mv ? b.round[m] : 0;
+    const int myvalue = mv ? b.value[m] : 0;
+
+    for (int t = 0; t < G; t += U) {
+      int s_[U], r_[U], v_[U], grp_[U];
+      int4v thr_[U];
+      uint4v k0_[U], k1_[U];
+      uint64_t tw_[U];
+      // ---- issue every load of U steps ------------------------------------------------------
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int src = (t + u) * Q + q;
+        s_[u] = __shfl(myslot, src);
+        r_[u] = __shfl(myround, src);
+        v_[u] = __shfl(myvalue, src);
+        grp_[u] = 0;
+        thr_[u] = init_thr;
+        k0_[u] = uint4v{0, 0, 0, 0};
+        k1_[u] = uint4v{0, 0, 0, 0};
+        tw_[u] = ~0ull;
+        if (s_[u] >= 0) {
+          const size_t row = (size_t)s_[u] * (size_t)g.R + (size_t)r0;
+          if (!one_group) grp_[u] = group_of_slot(g, s_[u]);
+          if (PERSLOT) {
+            if (VEC) {
+              if (own) thr_[u] = *reinterpret_cast<const int4v*>(st.ballot + row);
+            } else {
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                if (own >> k & 1) thr_[u][k] = st.ballot[row + k];
+            }
+          } else if (!one_group) {
+            const int32_t* pr = st.promised + (size_t)grp_[u] * g.R + r0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (own >> k & 1) thr_[u][k] = pr[k];
+          }
+          if (FUSED) {
+            const uint32_t* kr = st.pl_key + (size_t)s_[u] * g.wp;
+            k0_[u] = *reinterpret_cast<const uint4v*>(kr);
+            if (g.wp == 8) k1_[u] = *reinterpret_cast<const uint4v*>(kr + 4);
+          }
+          if (b.target && own) tw_[u] = b.target[(size_t)(chunk * 64 + src) * 4 + (bitpos >> 6)];
+        }
+      }
+      // ---- process ---------------------------------------------------------------------------
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int src = (t + u) * Q + q;
+        const int s = s_[u], rnd = r_[u], val = v_[u];
+        const bool live = s >= 0;
+        int way = -1;
+        bool dup = false;
+        if (FUSED) {
+          // ProxyLeader.scala:176-184: a known (slot, round) is ignored and not forwarded
+          const uint32_t want = (uint32_t)rnd + 1u;
+          uint32_t keys[8] = {k0_[u][0], k0_[u][1], k0_[u][2], k0_[u][3],
+                              k1_[u][0], k1_[u][1], k1_[u][2], k1_[u][3]};
+#pragma unroll
+          for (int w = 7; w >= 0; --w) {
+            if (w < g.ways) {
+              dup = dup || ((keys[w] & KEY_ROUND_MASK) == want);
+              if (keys[w] == 0) way = w;
+            }
+          }
+        }
+        const bool deliver = live && (!FUSED || (!dup && way >= 0));
+        if (FUSED && live && !dup && way < 0 && gi == 0) report(st, 5 /*FPX_ECAPACITY*/, chunk * 64 + src, s, rnd);
+
+        // Acceptor.scala:192: phase2a.round < round -> Nack ; else vote
+        uint32_t tn = deliver ? (own & (uint32_t)((tw_[u] >> (bitpos & 63)) & 0xFull)) : 0u;
+        uint32_t acc = 0, nck = 0;
+        int nr = -1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool tk = (tn >> k) & 1u;
+          const bool ok = tk && (rnd >= thr_[u][k]);
+          acc |= ok ? (1u << k) : 0u;
+          if (tk && !ok) {
+            nck |= 1u << k;
+            nr = thr_[u][k] > nr ? thr_[u][k] : nr;
+          }
+        }
+        // Acceptor.scala:204-208: round = phase2a.round; states(slot) = State(round, value)
+        if (acc) {
+          const size_t row = (size_t)s * (size_t)g.R + (size_t)r0;
+          if (VEC && acc == 0xFu) {
+            const int4v rr = {rnd, rnd, rnd, rnd};
+            const int4v vv = {val, val, val, val};
+            __builtin_nontemporal_store(rr, reinterpret_cast<int4v*>(st.vote_round + row));
+            __builtin_nontemporal_store(vv, reinterpret_cast<int4v*>(st.vote_value + row));
+            if (PERSLOT) {
+              const int4v old = thr_[u];
+              if (old[0] != rnd || old[1] != rnd || old[2] != rnd || old[3] != rnd)
+                __builtin_nontemporal_store(rr, reinterpret_cast<int4v*>(st.ballot + row));
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (acc >> k & 1u) {
+                st.vote_round[row + k] = rnd;
+                st.vote_value[row + k] = val;
+                if (PERSLOT && thr_[u][k] != rnd) st.ballot[row + k] = rnd;
+              }
+            }
+          }
+          // maxVotedSlot (Acceptor.scala:209) and the acceptor's new round
+          if (one_group) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (acc >> k & 1u) {
+                acc_mv[k] = s > acc_mv[k] ? s : acc_mv[k];
+                acc_pr[k] = rnd > acc_pr[k] ? rnd : acc_pr[k];
+              }
+            }
+          } else {
+            const int e = grp_[u] * g.R + r0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (acc >> k & 1u) {
+                atomicMax(&tab_mv[e + k], s);
+                atomicMax(&tab_pr[e + k], rnd);
+              }
+            }
+          }
+        }
+
+        // ---- the slot's vote bitmap, in registers ---------------------------------------------
+        uint64_t vb[4];
+        assemble_bits<G>(acc, lane, g.base, vb);
+        const int nrm = group_max<G>(nr);
+
+        if constexpr (!FUSED) {
+          uint64_t nb[4] = {0, 0, 0, 0};
+          if (b.nack_bits) assemble_bits<G>(nck, lane, g.base, nb);
+          if (gi == 0) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              wo->votes[src][w] = vb[w];
+              wo->nacks[src][w] = nb[w];
+            }
+            wo->nack_round[src] = nrm;
+          }
+        } else {
+          // ProxyLeader.scala:235-256: record votes, test the quorum, Chosen exactly once
+          bool ch = false;
+          if (deliver) {
+            uint64_t x[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) x[w] = vb[w] & g.member[w];
+            ch = is_write_quorum(g, x);
+            if (gi == 0) {
+              const size_t e = (size_t)s * g.wp + way;
+              st.pl_key[e] = ((uint32_t)rnd + 1u) | (ch ? KEY_DONE : 0u);
+              if (!ch) {
+                st.pl_value[e] = val;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) st.pl_bits[e * 4 + w] = x[w];
+              }
+            }
+          }
+          if (gi == 0) {
+            wo->chosen[src] = ch ? 1 : 0;
+            wo->chosen_round[src] = ch ? rnd : -1;
+            wo->chosen_value[src] = ch ? val : -1;
+            wo->nack_round[src] = nrm;
+          }
+        }
+      }
+    }
+
+    // ---- outputs of the 64 messages leave as coalesced lines ------------------------------------
+    wave_lds_sync();
+    if (mv) {
+      if constexpr (!FUSED) {
+        if (b.vote_bits) {
+          uint64_t* o = b.vote_bits + (size_t)m * 4;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) o[w] = wo->votes[lane][w];
+        }
+        if (b.nack_bits) {
+          uint64_t* o = b.nack_bits + (size_t)m * 4;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) o[w] = wo->nacks[lane][w];
+        }
+      } else {
+        if (b.chosen) b.chosen[m] = (uint8_t)wo->chosen[lane];
+        if (b.chosen_round) b.chosen_round[m] = wo->chosen_round[lane];
+        if (b.chosen_value) b.chosen_value[m] = wo->chosen_value[lane];
+      }
+      if (b.nack_round) b.nack_round[m] = wo->nack_round[lane];
+    }
+    wave_lds_sync();
+  }
+
+  // ---- fold maxima: registers -> LDS -> this block's row of the partial table ------------------
+  if (one_group) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (own >> k & 1u) {
+        if (acc_mv[k] >= 0) atomicMax(&tab_mv[r0 + k], acc_mv[k]);
+        if (acc_pr[k] >= 0) atomicMax(&tab_pr[r0 + k], acc_pr[k]);
+      }
+    }
+  }
+  __syncthreads();
+  int32_t* prow = st.part + (size_t)blockIdx.x * 2 * ntab;
+  for (int i = threadIdx.x; i < 2 * ntab; i += blockDim.x) prow[i] = tab_pr[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_finalize: promised[e] = max(promised[e], max_b part[b][0][e]); max_voted likewise.
+// grid.x = ceil(ntab / 64); block = 256 threads = 64 entries x 4 slices of the block axis.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_finalize(const Geom g, const State st, int nblocks) {
+  __shared__ int32_t red[2][4][64];
+  if (st.status[ST_CODE] != 0) return;
+  const int ntab = g.ngroups * g.R;
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int slice = threadIdx.x >> 6;
+  int pr = -1, mvs = -1;
+  if (e < ntab) {
+    for (int bl = slice; bl < nblocks; bl += 4) {
+      const int32_t* prow = st.part + (size_t)bl * 2 * ntab;
+      const int a = prow[e], c = prow[ntab + e];
+      pr = a > pr ? a : pr;
+      mvs = c > mvs ? c : mvs;
+    }
+  }
+  red[0][slice][threadIdx.x & 63] = pr;
+  red[1][slice][threadIdx.x & 63] = mvs;
+  __syncthreads();
+  if (slice == 0 && e < ntab) {
+    for (int k = 1; k < 4; ++k) {
+      pr = red[0][k][threadIdx.x] > pr ? red[0][k][threadIdx.x] : pr;
+      mvs = red[1][k][threadIdx.x] > mvs ? red[1][k][threadIdx.x] : mvs;
+    }
+    if (!g.per_slot && pr > st.promised[e]) st.promised[e] = pr;
+    if (mvs > st.max_voted[e]) st.max_voted[e] = mvs;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_open: ProxyLeader.handlePhase2a bookkeeping (ProxyLeader.scala:175-184, 213). Thread / message.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_open(const Geom g, const State st, const Batch b) {
+  if (st.status[ST_CODE] != 0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.n) return;
+  const int s = b.slot[i], rnd = b.round[i];
+  uint32_t* kr = st.pl_key + (size_t)s * g.wp;
+  const uint32_t want = (uint32_t)rnd + 1u;
+  int way = -1;
+  bool dup = false;
+  for (int w = g.ways - 1; w >= 0; --w) {
+    const uint32_t k = kr[w];
+    dup = dup || ((k & KEY_ROUND_MASK) == want);
+    if (k == 0) way = w;
+  }
+  uint8_t fresh = 0;
+  if (!dup) {
+    if (way < 0) {
+      report(st, 5, i, s, rnd);
+    } else {
+      const size_t e = (size_t)s * g.wp + way;
+      st.pl_key[e] = want;
+      st.pl_value[e] = b.value[i];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) st.pl_bits[e * 4 + w] = 0ull;
+      fresh = 1;
+    }
+  }
+  if (b.is_new) b.is_new[i] = fresh;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_tally (K2): ProxyLeader.handlePhase2b (ProxyLeader.scala:217-258). Thread / message; the slots
+// of a run are distinct so a tally entry has exactly one writer.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_tally(const Geom g, const State st, const Batch b) {
+  if (st.status[ST_CODE] != 0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.n) return;
+  const int s = b.slot[i], rnd = b.round[i];
+  uint64_t in[4];
+  const uint64_t* vin = b.vote_bits + (size_t)i * 4;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) in[w] = vin[w] & g.member[w];
+  uint8_t ch = 0;
+  int cr = -1, cv = -1;
+  if ((in[0] | in[1] | in[2] | in[3]) != 0) {
+    const uint32_t* kr = st.pl_key + (size_t)s * g.wp;
+    const uint32_t want = (uint32_t)rnd + 1u;
+    int way = -1;
+    uint32_t key = 0;
+    for (int w = 0; w < g.ways; ++w) {
+      const uint32_t k = kr[w];
+      if ((k & KEY_ROUND_MASK) == want) way = w, key = k;
+    }
+    if (way < 0) {
+      report(st, 2 /*FPX_EFATAL_UNKNOWN_SLOTROUND*/, i, s, rnd);  // :220-225
+    } else if (!(key & KEY_DONE)) {                                 // Done -> ignored, :227-232
+      const size_t e = (size_t)s * g.wp + way;
+      uint64_t x[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) x[w] = st.pl_bits[e * 4 + w] | in[w];  // :237
+      if (is_write_quorum(g, x)) {                                        // :238-243
+        ch = 1;
+        cr = rnd;
+        cv = st.pl_value[e];  // :246-253  Chosen(slot, pending.phase2a.value)
+        st.pl_key[e] = key | KEY_DONE;  // :256
+      } else {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) st.pl_bits[e * 4 + w] = x[w];
+      }
+    }
+  }
+  if (b.chosen) b.chosen[i] = ch;
+  if (b.chosen_round) b.chosen_round[i] = cr;
+  if (b.chosen_value) b.chosen_value[i] = cv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Phase1a (Acceptor.scala:148-182)
+// ------------------------------------------------------------------------------------------------
+// ACCEPTOR mode: one thread per acceptor of the group.  out[0..3] promised bits, out[4..7] nack bits
+__global__ void k_phase1a_scalar(const Geom g, const State st, int group, int round, const uint64_t* target,
+                                 uint64_t* out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= g.R) return;
+  const int bit = g.base + r;
+  if (target && !((target[bit >> 6] >> (bit & 63)) & 1ull)) return;
+  int* pr = &st.promised[(size_t)group * g.R + r];
+  if (round < *pr) {  // :155 Nack
+    atomicOr((unsigned long long*)&out[4 + (bit >> 6)], 1ull << (bit & 63));
+  } else {            // :166 round = phase1a.round
+    *pr = round;
+    atomicOr((unsigned long long*)&out[bit >> 6], 1ull << (bit & 63));
+  }
+}
+
+// PER_SLOT mode: one thread per cell, grid-stride; a cell ahead of the leader keeps its ballot and
+// marks its acceptor as nacking.
+__global__ void __launch_bounds__(256) k_phase1a_perslot(const Geom g, const State st, int group, int round,
+                                                         int watermark, const uint64_t* target, uint64_t* out) {
+  const size_t ncell = (size_t)g.S * g.R;
+  const size_t first = (size_t)(watermark < 0 ? 0 : watermark) * g.R;
+  for (size_t c = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncell;
+       c += (size_t)gridDim.x * blockDim.x) {
+    const int s = (int)(c / g.R), r = (int)(c % g.R);
+    if (group_of_slot(g, s) != group) continue;
+    const int bit = g.base + r;
+    if (target && !((target[bit >> 6] >> (bit & 63)) & 1ull)) continue;
+    const int cur = st.ballot[c];
+    if (cur > round) {
+      atomicOr((unsigned long long*)&out[4 + (bit >> 6)], 1ull << (bit & 63));
+    } else if (cur != round) {
+      st.ballot[c] = round;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a5 standalone: n node sets -> isWriteQuorum / isReadQuorum (strict: foreign bit => status EINVAL)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_quorum_eval(const Geom g, int n, const uint64_t* nodes, int strict,
+                                                     int read, uint8_t* out, int32_t* status) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t x[4];
+  bool foreign = false;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const uint64_t v = nodes[(size_t)i * 4 + w];
+    foreign = foreign || ((v & ~g.member[w]) != 0);
+    x[w] = v & g.member[w];
+  }
+  if (strict && foreign) {
+    if (atomicCAS(&status[ST_CODE], 0, 1) == 0) status[ST_INDEX] = i;
+    out[i] = 0;
+    return;
+  }
+  out[i] = (read ? is_read_quorum(g, x) : is_write_quorum(g, x)) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// readback helper: the log of one acceptor (a strided column of the SoA)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gather_acceptor(const Geom g, const State st, int group, int replica,
+                                                         int32_t* vr, int32_t* vv, int32_t* bl) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= g.S) return;
+  const bool mine = group_of_slot(g, s) == group;
+  const size_t c = (size_t)s * g.R + replica;
+  vr[s] = mine ? st.vote_round[c] : -1;
+  vv[s] = mine ? st.vote_value[c] : -1;
+  bl[s] = (mine && st.ballot) ? st.ballot[c] : -1;
+}
+
+}  // namespace fpx

@@ -1,0 +1,442 @@
+"""GPU parity: the HIP path (through the C ABI of include/fpx.h) against the CPU oracle on the same
+seeded inputs -- bit-exact on every output and on the whole acceptor / proxy-leader state.
+
+Run on the MI355X box: python -m pytest tests -m gpu
+"""
+import numpy as np
+import pytest
+
+from tests import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import frankenpaxos_amd
+
+    frankenpaxos_amd.lib()  # raises if libfpx.so is missing: no fallback
+    return frankenpaxos_amd
+
+
+def both(fa, oracle, **kw):
+    gpu = fa.Context(fa.make_config(**kw))
+    ref = oracle.System(oracle.make_config(**kw))
+    return gpu, ref
+
+
+def check(gpu, ref, script, tally_slots=()):
+    W.assert_same_outputs(W.run_script(gpu, script), W.run_script(ref, script))
+    W.assert_same_state(gpu, ref, tally_slots)
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json configs[1]: MultiPaxos f=1, 64k slots x 3 acceptors, bit-exact bring-up
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ballot_mode", [0, 1])
+def test_config2_64k_slots_3_acceptors(fa, oracle, ballot_mode):
+    S = 65536
+    gpu, ref = both(fa, oracle, num_slots=S, num_replicas=3, f=1, ballot_mode=ballot_mode)
+    slot, rnd, val = W.steady_stream(S)
+    check(gpu, ref, [("fused", slot, rnd, val, None)], tally_slots=[0, 1, S - 1])
+    st, ch, cr, cv, nr = gpu.phase2_fused(slot, rnd, val)  # same (slot, round) again: ignored
+    assert st == 0 and not ch.any()
+    assert (gpu.read_scalars()[1] == S - 1).all()
+
+
+@pytest.mark.parametrize("ballot_mode", [0, 1])
+def test_config2_unfused_pipeline(fa, oracle, ballot_mode):
+    S = 4096
+    gpu, ref = both(fa, oracle, num_slots=S, num_replicas=3, f=1, ballot_mode=ballot_mode)
+    slot, rnd, val = W.steady_stream(S)
+    dup = np.zeros(S, bool)
+    dup[::7] = True
+    check(gpu, ref, [("k1k2", slot, rnd, val, None, dup)], tally_slots=[0, 5, S - 1])
+
+
+# ---------------------------------------------------------------------------------------------------
+# the headline shape: R = 256, threshold f = 127 (q = 128)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ballot_mode", [0, 1])
+def test_steady_256_replicas(fa, oracle, ballot_mode):
+    S = 8192
+    gpu, ref = both(fa, oracle, num_slots=S, num_replicas=256, f=127, ballot_mode=ballot_mode)
+    slot, rnd, val = W.steady_stream(S)
+    script = [("phase1a", 0, 0, 0, None), ("fused", slot, rnd, val, None)]
+    check(gpu, ref, script, tally_slots=[0, 100, S - 1])
+    out = W.run_script(gpu, [("fused", slot, rnd + 1, val, None)])
+    assert out[0][2].all()  # re-proposal in round 1: every slot chosen again
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("ballot_mode", [0, 1])
+@pytest.mark.parametrize("fused", [True, False])
+def test_adversarial_256_replicas(fa, oracle, seed, ballot_mode, fused):
+    S = 4096
+    gpu, ref = both(fa, oracle, num_slots=S, num_replicas=256, f=127, ballot_mode=ballot_mode,
+                    tally_ways=8)
+    script = W.adversarial_script(S, 256, 128, seed, epochs=64, fused=fused)
+    check(gpu, ref, script, tally_slots=range(0, S, 97))
+
+
+# ---------------------------------------------------------------------------------------------------
+# every lanes-per-slot instantiation: R from 1 to 256, odd sizes included
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R", [1, 2, 3, 4, 5, 7, 8, 12, 16, 17, 31, 32, 33, 64, 65, 100, 128, 129, 255])
+@pytest.mark.parametrize("ballot_mode", [0, 1])
+def test_all_replica_counts(fa, oracle, R, ballot_mode):
+    S = 1024
+    q = R // 2 + 1
+    gpu, ref = both(fa, oracle, num_slots=S, num_replicas=R, quorum_kind=1, ballot_mode=ballot_mode,
+                    tally_ways=8)
+    check(gpu, ref, W.adversarial_script(S, R, q, 7 + R, epochs=16, fused=True),
+          tally_slots=range(0, S, 61))
+    gpu.reset()
+    ref.reset()
+    check(gpu, ref, W.adversarial_script(S, R, q, 11 + R, epochs=16, fused=False),
+          tally_slots=range(0, S, 61))
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2]: 16 independent 2x2 grid quorums ; Mencius slot -> group map
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ballot_mode", [0, 1])
+def test_config3_grid_2x2_16_groups(fa, oracle, ballot_mode):
+    S = 16384
+    kw = dict(num_slots=S, num_replicas=4, num_groups=16, quorum_kind=2, grid_rows=2, grid_cols=2,
+              ballot_mode=ballot_mode, tally_ways=8)
+    gpu, ref = both(fa, oracle, **kw)
+    check(gpu, ref, W.adversarial_script(S, 4, 2, 5, epochs=32, fused=True, ngroups=16),
+          tally_slots=range(0, S, 331))
+    gpu.reset()
+    ref.reset()
+    check(gpu, ref, W.adversarial_script(S, 4, 2, 6, epochs=32, fused=False, ngroups=16),
+          tally_slots=range(0, S, 331))
+
+
+def test_config5_mencius_slot_map(fa, oracle):
+    """mencius: leader group = slot % L, acceptor group = (slot / L) % A (mencius/ProxyLeader.scala:231-234)"""
+    S = 8192
+    kw = dict(num_slots=S, num_replicas=3, num_groups=2, num_leader_groups=8, f=1, tally_ways=8)
+    gpu, ref = both(fa, oracle, **kw)
+    check(gpu, ref, W.adversarial_script(S, 3, 2, 9, epochs=32, fused=True, ngroups=16),
+          tally_slots=range(0, S, 257))
+    # leader groups move through rounds independently: one batch, different rounds per group
+    gpu.reset()
+    ref.reset()
+    slot = np.arange(S, dtype=np.int32)
+    rnd = (slot % 8).astype(np.int32)  # round = leader group index
+    val = W.steady_values(slot)
+    check(gpu, ref, [("fused", slot, rnd, val, None)], tally_slots=[0, 1, 9, S - 1])
+
+
+def test_large_grid_16x16(fa, oracle):
+    S = 2048
+    kw = dict(num_slots=S, num_replicas=256, quorum_kind=2, grid_rows=16, grid_cols=16, tally_ways=8)
+    gpu, ref = both(fa, oracle, **kw)
+    # a 16x16 grid needs one acceptor per row: use target subsets around half the grid
+    check(gpu, ref, W.adversarial_script(S, 256, 40, 13, epochs=16, fused=True),
+          tally_slots=range(0, S, 101))
+    gpu.reset()
+    ref.reset()
+    check(gpu, ref, W.adversarial_script(S, 256, 40, 14, epochs=16, fused=False),
+          tally_slots=range(0, S, 101))
+
+
+def test_unanimous_writes(fa, oracle):
+    S = 1024
+    gpu, ref = both(fa, oracle, num_slots=S, num_replicas=5, quorum_kind=3, tally_ways=8)
+    check(gpu, ref, W.adversarial_script(S, 5, 5, 21, epochs=8, fused=True), tally_slots=range(0, S, 31))
+
+
+# ---------------------------------------------------------------------------------------------------
+# any batch through the host entry points: duplicate slots, rounds going up and down
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ballot_mode", [0, 1])
+@pytest.mark.parametrize("R", [3, 256])
+def test_arbitrary_batches_are_split_exactly(fa, oracle, ballot_mode, R):
+    S = 512
+    gpu, ref = both(fa, oracle, num_slots=S, num_replicas=R, quorum_kind=1, ballot_mode=ballot_mode,
+                    tally_ways=8)
+    rng = np.random.default_rng(123 + R)
+    script = []
+    for _ in range(6):
+        n = 700
+        slot = rng.integers(0, S, n).astype(np.int32)         # many duplicates
+        rnd = rng.integers(0, 5, n).astype(np.int32)          # non-monotone rounds
+        val = rng.integers(0, 1 << 30, n).astype(np.int32)
+        tgt = W.bits_from_bool(W.random_subsets(rng, n, R, 1, R))
+        script.append(("fused", slot, rnd, val, tgt))
+        script.append(("phase2a", slot[:100], rnd[:100], val[:100], tgt[:100]))
+    check(gpu, ref, script, tally_slots=range(0, S, 17))
+
+
+def test_fifo_pump_equals_fused(oracle):
+    pass  # CPU-only twin lives in tests/test_oracle_traces.py
+
+
+# ---------------------------------------------------------------------------------------------------
+# error paths
+# ---------------------------------------------------------------------------------------------------
+def test_phase2b_unknown_slot_round_is_fatal(fa, oracle):
+    gpu, ref = both(fa, oracle, num_slots=64, num_replicas=3, f=1)
+    slot = np.array([5], np.int32)
+    vb = W.bits_from_bool(np.array([[True, True, False]]))
+    for be in (gpu, ref):
+        st, ch, cr, cv = be.proxy_phase2b(slot, np.array([0], np.int32), vb)
+        assert st == fa.FPX_EFATAL_UNKNOWN_SLOTROUND and not ch.any()
+        assert be.error_detail() == (0, 5, 0)
+        be.proxy_open(slot, np.array([2], np.int32), np.array([77], np.int32))
+        st, *_ = be.proxy_phase2b(slot, np.array([1], np.int32), vb)  # round 1 never opened
+        assert st == fa.FPX_EFATAL_UNKNOWN_SLOTROUND
+        st, ch, cr, cv = be.proxy_phase2b(slot, np.array([2], np.int32), vb)
+        assert st == 0 and ch[0] == 1 and cr[0] == 2 and cv[0] == 77
+        st, ch, cr, cv = be.proxy_phase2b(slot, np.array([2], np.int32), vb)  # after Done: ignored
+        assert st == 0 and ch[0] == 0 and cr[0] == -1 and cv[0] == -1
+
+
+def test_invalid_arguments(fa):
+    gpu = fa.Context(fa.make_config(num_slots=64, num_replicas=3, f=1))
+    one = np.array([0], np.int32)
+    assert gpu.phase2_fused(np.array([64], np.int32), one, one)[0] == fa.FPX_EINVAL
+    assert gpu.phase2_fused(np.array([-1], np.int32), one, one)[0] == fa.FPX_EINVAL
+    assert gpu.phase2_fused(one, np.array([-3], np.int32), one)[0] == fa.FPX_EINVAL
+    assert gpu.error_detail() == (0, 0, -3)
+    with pytest.raises(fa.FpxError):
+        fa.Context(fa.make_config(num_slots=64, num_replicas=257))
+    with pytest.raises(fa.FpxError):
+        fa.Context(fa.make_config(num_slots=64, num_replicas=6, quorum_kind=2, grid_rows=2, grid_cols=2))
+
+
+def test_tally_capacity(fa):
+    gpu = fa.Context(fa.make_config(num_slots=8, num_replicas=3, f=1, tally_ways=2))
+    s = np.array([3], np.int32)
+    none = W.bits_from_bool(np.zeros((1, 3), bool))
+    for r in range(2):
+        assert gpu.phase2_fused(s, np.array([r], np.int32), s, none)[0] == 0
+    assert gpu.phase2_fused(s, np.array([2], np.int32), s, none)[0] == fa.FPX_ECAPACITY
+
+
+def test_dev_batches_violating_the_run_contract_apply_nothing(fa):
+    import torch
+
+    S = 256
+    gpu = fa.Context(fa.make_config(num_slots=S, num_replicas=3, f=1))
+    dev = torch.device("cuda:0")
+    before = gpu.read_state()
+
+    def run(slot, rnd):
+        t = lambda a: torch.tensor(a, dtype=torch.int32, device=dev)
+        ch = torch.zeros(len(slot), dtype=torch.uint8, device=dev)
+        gpu.phase2_fused_dev(t(slot), t(rnd), t([1] * len(slot)), chosen=ch)
+        return gpu.sync(), ch.cpu().numpy()
+
+    st, ch = run([1, 2, 1], [0, 0, 0])  # duplicate slot
+    assert st == fa.FPX_EORDER and not ch.any()
+    st, ch = run([1, 2, 3], [0, 1, 0])  # two rounds for one acceptor group
+    assert st == fa.FPX_EORDER
+    after = gpu.read_state()
+    for a, b in zip(before, after):
+        np.testing.assert_array_equal(a, b)
+    st, ch = run([1, 2, 3], [0, 0, 0])
+    assert st == 0 and ch.all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# device-pointer entry points == host entry points
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ballot_mode", [0, 1])
+def test_dev_entry_points(fa, oracle, ballot_mode):
+    import torch
+
+    S, R = 4096, 256
+    gpu, ref = both(fa, oracle, num_slots=S, num_replicas=R, f=127, ballot_mode=ballot_mode)
+    dev = torch.device("cuda:0")
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    slot, rnd, val = W.steady_stream(S)
+    rng = np.random.default_rng(5)
+    tgt = W.bits_from_bool(W.random_subsets(rng, S, R, 100, R))
+    t_slot, t_rnd, t_val = (torch.from_numpy(x).to(dev) for x in (slot, rnd, val))
+    t_tgt = torch.from_numpy(tgt.view(np.int64)).to(dev)
+    ch = torch.empty(S, dtype=torch.uint8, device=dev)
+    cr = torch.empty(S, dtype=torch.int32, device=dev)
+    cv = torch.empty(S, dtype=torch.int32, device=dev)
+    nr = torch.empty(S, dtype=torch.int32, device=dev)
+    gpu.phase2_fused_dev(t_slot, t_rnd, t_val, t_tgt, ch, cr, cv, nr)
+    assert gpu.sync() == 0
+    st, ch_r, cr_r, cv_r, nr_r = ref.phase2_fused(slot, rnd, val, tgt)
+    np.testing.assert_array_equal(ch.cpu().numpy(), ch_r)
+    np.testing.assert_array_equal(cr.cpu().numpy(), cr_r)
+    np.testing.assert_array_equal(cv.cpu().numpy(), cv_r)
+    np.testing.assert_array_equal(nr.cpu().numpy(), nr_r)
+    W.assert_same_state(gpu, ref, tally_slots=range(0, S, 111))
+    # K1 -> K2 on device, vote bitmaps stay in HBM
+    gpu.reset()
+    ref.reset()
+    vb = torch.empty((S, 4), dtype=torch.int64, device=dev)
+    nb = torch.empty((S, 4), dtype=torch.int64, device=dev)
+    gpu.proxy_open_dev(t_slot, t_rnd, t_val)
+    gpu.acceptor_phase2a_dev(t_slot, t_rnd, t_val, t_tgt, vb, nb, nr)
+    gpu.proxy_phase2b_dev(t_slot, t_rnd, vb, ch, cr, cv)
+    assert gpu.sync() == 0
+    ref.proxy_open(slot, rnd, val)
+    st, vb_r, nb_r, nr_r = ref.acceptor_phase2a(slot, rnd, val, tgt)
+    st, ch_r, cr_r, cv_r = ref.proxy_phase2b(slot, rnd, vb_r)
+    np.testing.assert_array_equal(vb.cpu().numpy().view(np.uint64), vb_r)
+    np.testing.assert_array_equal(nb.cpu().numpy().view(np.uint64), nb_r)
+    np.testing.assert_array_equal(ch.cpu().numpy(), ch_r)
+    np.testing.assert_array_equal(cv.cpu().numpy(), cv_r)
+    W.assert_same_state(gpu, ref, tally_slots=range(0, S, 111))
+    gpu.set_stream(None)
+
+
+# ---------------------------------------------------------------------------------------------------
+# replica-axis sharding: two contexts own 128 acceptors each; the OR (== sum, the
+# bit ranges are disjoint) of their partial bitmaps feeds one tally
+# ---------------------------------------------------------------------------------------------------
+def test_replica_axis_sharding(fa, oracle):
+    S, R = 2048, 256
+    whole = oracle.System(oracle.make_config(num_slots=S, num_replicas=R, f=127, tally_ways=8))
+    shards = [fa.Context(fa.make_config(num_slots=S, num_replicas=128, f=127, replica_base=b,
+                                        replicas_total=R, tally_ways=8)) for b in (0, 128)]
+    rng = np.random.default_rng(77)
+    slot, rnd, val = W.steady_stream(S)
+    tgt = W.bits_from_bool(W.random_subsets(rng, S, R, 120, 140))
+    whole.proxy_open(slot, rnd, val)
+    st, vb_ref, nb_ref, nr_ref = whole.acceptor_phase2a(slot, rnd, val, tgt)
+    st, ch_ref, cr_ref, cv_ref = whole.proxy_phase2b(slot, rnd, vb_ref)
+    parts = [sh.acceptor_phase2a(slot, rnd, val, tgt)[1] for sh in shards]
+    assert not (parts[0] & parts[1]).any()
+    summed = parts[0] + parts[1]  # what an RCCL all-reduce(sum) produces
+    np.testing.assert_array_equal(summed, vb_ref)
+    shards[0].proxy_open(slot, rnd, val)
+    st, ch, cr, cv = shards[0].proxy_phase2b(slot, rnd, summed)
+    np.testing.assert_array_equal(ch, ch_ref)
+    np.testing.assert_array_equal(cv, cv_ref)
+    assert 0 < ch.sum() < S
+
+
+# ---------------------------------------------------------------------------------------------------
+# a5 on the device: the reference's known-answer tests through fpx_quorum_eval
+# ---------------------------------------------------------------------------------------------------
+def _sets(fa, cfg, sets, strict=True, read=False):
+    nodes = np.stack([W.bits_from_bool(np.isin(np.arange(256), list(s))[None, :])[0] for s in sets])
+    return list(fa.quorum_eval(cfg, nodes, strict=strict, read=read))
+
+
+def test_device_grid_quorums(fa):
+    """quorums/GridTest.scala:11-102 with nodes 1..6 -> bits 0..5, 9001 -> bit 200"""
+    from tests.test_oracle_golden import GRID_WRITE_CASES
+
+    cfg = fa.make_config(num_slots=1, num_replicas=6, quorum_kind=2, grid_rows=2, grid_cols=3)
+    b = lambda xs: [x - 1 if x != 9001 else 200 for x in xs]
+    cases = [c for c in GRID_WRITE_CASES] + [([i], False) for i in range(1, 7)]
+    assert _sets(fa, cfg, [b(xs) for xs, _ in cases]) == [w for _, w in cases]
+    assert _sets(fa, cfg, [b(xs) for xs, _ in cases], strict=False) == [w for _, w in cases]
+    sup = [([9001] + xs, w) for xs, w in GRID_WRITE_CASES if xs]
+    assert _sets(fa, cfg, [b(xs) for xs, _ in sup], strict=False) == [w for _, w in sup]
+    with pytest.raises(ValueError):
+        _sets(fa, cfg, [b([9001, 1, 4])], strict=True)
+    reads = [([1, 2, 4], False), ([4, 5, 3], False), ([1, 2, 3], True), ([4, 5, 6], True),
+             ([1, 2, 3, 4], True), ([1, 2, 3, 4, 5, 6], True), ([], False), ([1, 2], False)]
+    assert _sets(fa, cfg, [b(xs) for xs, _ in reads], read=True) == [w for _, w in reads]
+    assert _sets(fa, cfg, [b([9001] + xs) for xs, _ in reads], strict=False, read=True) == [w for _, w in reads]
+
+
+def test_device_majority_and_unanimous_quorums(fa):
+    """quorums/SimpleMajorityTest.scala:11-63, quorums/UnanimousWrites.scala:11-75 (node 5 -> bit 5, foreign)"""
+    maj = fa.make_config(num_slots=1, num_replicas=5, quorum_kind=1)
+    cases = [([], False), ([0], False), ([0, 1], False), ([0, 1, 2], True), ([0, 1, 2, 3], True),
+             ([0, 1, 2, 3, 4], True)]
+    for read in (False, True):
+        assert _sets(fa, maj, [xs for xs, _ in cases], read=read) == [w for _, w in cases]
+        assert _sets(fa, maj, [xs + [5] for xs, _ in cases], strict=False, read=read) == [w for _, w in cases]
+    una = fa.make_config(num_slots=1, num_replicas=5, quorum_kind=3)
+    wcases = [([], False), ([0], False), ([0, 1], False), ([0, 1, 2], False), ([0, 1, 2, 3], False),
+              ([0, 1, 2, 3, 4], True)]
+    assert _sets(fa, una, [xs for xs, _ in wcases]) == [w for _, w in wcases]
+    assert _sets(fa, una, [xs + [5] for xs, _ in wcases], strict=False) == [w for _, w in wcases]
+    rcases = [([], False), ([0], True), ([3], True), ([0, 1], True), ([0, 1, 2, 3, 4], True)]
+    assert _sets(fa, una, [xs for xs, _ in rcases], read=True) == [w for _, w in rcases]
+    assert _sets(fa, una, [[5]], strict=False, read=True) == [False]
+    with pytest.raises(ValueError):
+        _sets(fa, maj, [[0, 1, 5]], strict=True)
+
+
+def test_device_quorum_predicates_match_oracle_exhaustively(fa, oracle):
+    """every subset of small systems + random subsets of big ones, device == oracle"""
+    rng = np.random.default_rng(3)
+    systems = [dict(num_replicas=n, quorum_kind=1) for n in range(1, 10)]
+    systems += [dict(num_replicas=n, quorum_kind=3) for n in range(1, 10)]
+    systems += [dict(num_replicas=r * c, quorum_kind=2, grid_rows=r, grid_cols=c)
+                for r in range(2, 6) for c in range(2, 6)]
+    systems += [dict(num_replicas=n, quorum_kind=0, f=f) for n, f in ((3, 1), (5, 2), (255, 127), (256, 127))]
+    systems += [dict(num_replicas=256, quorum_kind=2, grid_rows=16, grid_cols=16),
+                dict(num_replicas=252, quorum_kind=2, grid_rows=4, grid_cols=63)]
+    for kw in systems:
+        n = kw["num_replicas"]
+        if n <= 10:
+            mat = ((np.arange(1 << n)[:, None] >> np.arange(n)[None, :]) & 1).astype(bool)
+        else:
+            mat = W.random_subsets(rng, 512, n, 0, n)
+        nodes = W.bits_from_bool(mat)
+        cfg = fa.make_config(num_slots=1, **kw)
+        ocfg = oracle.make_config(num_slots=1, **kw)
+        ref = oracle.System(ocfg)
+        for read in (False, True):
+            got = fa.quorum_eval(cfg, nodes, strict=True, read=read)
+            want = [ref.is_read_quorum(x) if read else ref.is_write_quorum(x) for x in nodes]
+            assert list(got) == want, (kw, read)
+
+
+def test_round_system_through_the_abi(fa):
+    """roundsystem/RoundSystemTest.scala:13-62"""
+    from tests.test_oracle_golden import NEXT_CLASSIC_ROUND
+
+    assert [fa.round_leader(3, r) for r in range(9)] == [0, 1, 2, 0, 1, 2, 0, 1, 2]
+    for leader, wants in NEXT_CLASSIC_ROUND.items():
+        assert [fa.next_classic_round(3, leader, r) for r in range(-1, 7)] == wants
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json full size (2^20 slots x 256 acceptors): size-independent properties
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ballot_mode", [0, 1])
+def test_full_size_grid_properties(fa, ballot_mode):
+    import torch
+
+    S, R = 1 << 20, 256
+    gpu = fa.Context(fa.make_config(num_slots=S, num_replicas=R, f=127, ballot_mode=ballot_mode,
+                                    flags=fa.FPX_F_TRUSTED))
+    dev = torch.device("cuda:0")
+    slot, rnd, val = W.steady_stream(S)
+    t_slot, t_rnd, t_val = (torch.from_numpy(x).to(dev) for x in (slot, rnd, val))
+    ch = torch.empty(S, dtype=torch.uint8, device=dev)
+    cr = torch.empty(S, dtype=torch.int32, device=dev)
+    cv = torch.empty(S, dtype=torch.int32, device=dev)
+    assert gpu.acceptor_phase1a(0, 0)[0] == 0
+    gpu.phase2_fused_dev(t_slot, t_rnd, t_val, None, ch, cr, cv)
+    assert gpu.sync() == 0
+    # every slot chosen in round 0 with its proposed value (SURVEY.md 8d "Expected")
+    assert bool(ch.all()) and bool((cr == 0).all()) and bool((cv == t_val).all())
+    # idempotence: the same Phase2a's again are ignored by the proxy leader
+    gpu.phase2_fused_dev(t_slot, t_rnd, t_val, None, ch, cr, cv)
+    assert gpu.sync() == 0 and not bool(ch.any())
+    # the acceptors' logs: every cell voted (round 0, value of its slot): checksum of checksums
+    vr, vv, bl = gpu.read_state()
+    assert (vr == 0).all()
+    assert (vv == val[:, None]).all()
+    pr, mv = gpu.read_scalars()
+    assert (mv == S - 1).all() and (pr == (0 if ballot_mode == 0 else -1)).all()
+    # a minority of acceptors ahead of the leader: 129 Nack => nothing is chosen, nack_round = 5
+    ahead = W.bits_from_bool((np.arange(R) < 129)[None, :])[0]
+    assert gpu.acceptor_phase1a(0, 5, 0, ahead)[0] == 0
+    nr = torch.empty(S, dtype=torch.int32, device=dev)
+    gpu.phase2_fused_dev(t_slot, t_rnd + 1, t_val, None, ch, cr, cv, nr)
+    assert gpu.sync() == 0 and not bool(ch.any()) and bool((nr == 5).all())
+    # ... and 128 of 256 promised ahead leaves exactly a quorum of 128 voters => chosen in round 2
+    gpu2 = fa.Context(fa.make_config(num_slots=4096, num_replicas=R, f=127, ballot_mode=ballot_mode))
+    ahead = W.bits_from_bool((np.arange(R) < 128)[None, :])[0]
+    gpu2.acceptor_phase1a(0, 5, 0, ahead)
+    st, ch2, cr2, cv2, nr2 = gpu2.phase2_fused(slot[:4096], rnd[:4096] + 2, val[:4096])
+    assert st == 0 and ch2.all() and (cr2 == 2).all() and (nr2 == 5).all()
