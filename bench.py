@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py -- committed log slots / second of the fused Phase-2 step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json metric; SURVEY.md section 8d "steady"): a "step" is one fused pass
+(ProxyLeader.handlePhase2a -> Acceptor.handlePhase2a x 256 -> ProxyLeader.handlePhase2b) over one
+batch of 2^20 fresh log slots x 256 acceptors, threshold quorum f+1 = 128, dense delivery, values
+splitmix64(0xF9A405 + slot) & 0x7fffffff, after the leader's one-off Phase 1 in round 0.  Inputs are
+resident in HBM; every step works on the next 2^20 slots of the log, so every row is cold.
+
+Ballot model: FPX_BALLOT_PER_SLOT (the "generalised ballot[S x R]" model of SURVEY.md 8d, 3088
+algorithmic B/slot: read ballot row 1024 + proposal 8, write voteRound 1024 + voteValue 1024 +
+chosen record 8).  `--ballot acceptor` runs the faithful per-acceptor scalar model (2064 B/slot).
+
+N > 1: one process per GPU, every rank owns its own acceptor groups (its own 2^20 x 256 grid per
+step): slot-partition sharding, no data-path collective; weak scaling.
+`--shard replica` instead splits the 256 acceptors of ONE grid across the ranks and all-reduces the
+per-slot vote bitmaps over RCCL; strong scaling of the replica axis.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+SLOTS_PER_STEP = 1 << 20
+REPLICAS = 256
+F = 127
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MAX_WINDOWS = 40       # log windows kept in HBM (3.2 GiB each in PER_SLOT mode)
+
+
+def splitmix64_torch(x):
+    """one splitmix64 output per int64 state (wrap-around arithmetic), on the tensor's device"""
+    def lsr(v, k):  # logical shift right on int64
+        return (v >> k) & ((1 << (64 - k)) - 1)
+    z = x + (-0x61C8864680B583EB)  # 0x9E3779B97F4A7C15 as int64
+    z = (z ^ lsr(z, 30)) * (-0x40A7B892E31B1A47)  # 0xBF58476D1CE4E5B9
+    z = (z ^ lsr(z, 27)) * (-0x6B2FB644ECCEEE15)  # 0x94D049BB133111EB
+    return z ^ lsr(z, 31)
+
+
+def steady_values_torch(slot):
+    return (splitmix64_torch(slot.to(torch.int64) + 0xF9A405) & 0x7FFFFFFF).to(torch.int32)
+
+
+def algorithmic_bytes_per_slot(ballot_mode):
+    r = REPLICAS
+    if ballot_mode == 1:  # SURVEY.md 8d generalised model
+        return 4 * r + 8 + 8 * r + 8  # 3088
+    return 8 + 8 * r + 8              # faithful scalar model: reads 8 B/slot (+1 KiB/batch)
+
+
+def cpu_baseline(ballot_mode):
+    """The CPU oracle (a plain-C, single-threaded port of the reference handlers; the JVM reference
+    cannot run here) timed on this box on a bounded sample of the same workload."""
+    from oracle import pyoracle
+    from tests import workloads as W
+
+    pyoracle.build()
+    S = 1 << 19
+    ref = pyoracle.System(pyoracle.make_config(num_slots=S, num_replicas=REPLICAS, f=F,
+                                               ballot_mode=ballot_mode))
+    ref.acceptor_phase1a(0, 0)
+    slot, rnd, val = W.steady_stream(S)
+    t0 = time.perf_counter()
+    st, ch, cr, cv, nr = ref.phase2_fused(slot, rnd, val)
+    dt = time.perf_counter() - t0
+    assert st == 0 and int(ch.sum()) == S
+    # the same handlers behind a strict FIFO message pump (stand-in for the in-process Transport)
+    Sp = 1 << 15
+    ref2 = pyoracle.System(pyoracle.make_config(num_slots=Sp, num_replicas=REPLICAS, f=F,
+                                                ballot_mode=ballot_mode))
+    ref2.acceptor_phase1a(0, 0)
+    t1 = time.perf_counter()
+    ref2.phase2_fifo_pump(slot[:Sp], rnd[:Sp], val[:Sp])
+    dtp = time.perf_counter() - t1
+    return {
+        "value": S / dt, "unit": "slots/s", "cores": 1, "kind": "port",
+        "sample": "oracle/fpx_oracle.c fpo_phase2_fused, 2^19 slots x 256 acceptors, steady stream, "
+                  "1 thread (reference Transport is single-threaded); same handlers behind a FIFO "
+                  "message pump on 2^15 slots: %.3e slots/s; nproc=%d" % (Sp / dtp, os.cpu_count()),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ballot", choices=["per_slot", "acceptor"], default="per_slot")
+    ap.add_argument("--shard", choices=["group", "replica"], default="group")
+    ap.add_argument("--validate", action="store_true",
+                    help="keep the run-contract validation kernel in the timed region")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libfpx has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    import frankenpaxos_amd as fa
+
+    ballot_mode = fa.FPX_BALLOT_PER_SLOT if args.ballot == "per_slot" else fa.FPX_BALLOT_ACCEPTOR
+    K, Wm = args.steps, args.warmup
+    windows = min(K + Wm, MAX_WINDOWS)
+    S_total = windows * SLOTS_PER_STEP
+    replica_shard = args.shard == "replica" and world > 1
+    R_local = REPLICAS // world if replica_shard else REPLICAS
+    flags = 0 if args.validate else fa.FPX_F_TRUSTED
+    ctx = fa.Context(fa.make_config(
+        num_slots=S_total, num_replicas=R_local, f=F, quorum_kind=fa.FPX_Q_THRESHOLD,
+        ballot_mode=ballot_mode, tally_ways=4, device=local_rank, flags=flags,
+        replica_base=(rank * R_local if replica_shard else 0),
+        replicas_total=(REPLICAS if replica_shard else 0)))
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    # the leader's Phase 1 in round 0 (once, before any Phase 2): every acceptor promises round 0
+    st, pb, nb = ctx.acceptor_phase1a(0, 0)
+    assert st == 0
+
+    # synthetic command stream, resident in HBM
+    steps = []
+    for i in range(K + Wm):
+        w = i % windows
+        lap = i // windows  # after a lap over the window ring the slots are re-proposed in round lap
+        slot = torch.arange(w * SLOTS_PER_STEP, (w + 1) * SLOTS_PER_STEP, dtype=torch.int32, device=dev)
+        rnd = torch.full((SLOTS_PER_STEP,), lap, dtype=torch.int32, device=dev)
+        val = steady_values_torch(slot)
+        ch = torch.zeros(SLOTS_PER_STEP, dtype=torch.uint8, device=dev)
+        steps.append((slot, rnd, val, ch))
+    cr = torch.empty(SLOTS_PER_STEP, dtype=torch.int32, device=dev)
+    cv = torch.empty(SLOTS_PER_STEP, dtype=torch.int32, device=dev)
+    if replica_shard:
+        vb = torch.empty((SLOTS_PER_STEP, 4), dtype=torch.int64, device=dev)
+
+    def step(i):
+        slot, rnd, val, ch = steps[i]
+        if not replica_shard:
+            ctx.phase2_fused_dev(slot, rnd, val, None, ch, cr, cv)
+        else:
+            # K1 on my acceptors -> all-reduce(sum) of the disjoint partial bitmaps over xGMI -> K2
+            ctx.proxy_open_dev(slot, rnd, val)
+            ctx.acceptor_phase2a_dev(slot, rnd, val, None, vb, None, None)
+            dist.all_reduce(vb, op=dist.ReduceOp.SUM)
+            ctx.proxy_phase2b_dev(slot, rnd, vb, ch, cr, cv)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(Wm):
+        step(i)
+    assert ctx.sync() == 0
+    ctx.profile_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(Wm, Wm + K):
+        step(i)
+    fence()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    launches, kernel_ms = ctx.profile_read()
+    assert ctx.sync() == 0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # every timed step must have committed all of its slots, with the proposed value
+    committed = sum(int(steps[i][3].sum().item()) for i in range(Wm, Wm + K))
+    assert committed == K * SLOTS_PER_STEP, (committed, K * SLOTS_PER_STEP)
+    assert bool((cv == steps[Wm + K - 1][2]).all())
+    if dist is not None and not replica_shard:
+        t = torch.tensor([committed], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        committed = int(t.item())
+
+    if rank == 0:
+        bps = algorithmic_bytes_per_slot(ballot_mode)
+        avg_kernel_s = (kernel_ms / max(launches, 1)) * 1e-3
+        slots_per_launch = SLOTS_PER_STEP
+        achieved = bps * slots_per_launch / avg_kernel_s / 1e9 if launches else None
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(args.ballot)
+            except Exception:
+                traffic = None
+        kernel = "k_phase2<64,vec4,%s,%s>" % ("per_slot" if ballot_mode == 1 else "acceptor",
+                                               "K1" if replica_shard else "fused")
+        line = {
+            "metric": "committed log slots/sec at 1M slots x 256 replicas",
+            "value": committed / elapsed,
+            "unit": "slots/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": Wm,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong" if replica_shard else "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {
+                "workload": "MultiPaxos Phase-2 fused step (open + 256 acceptor votes + f+1=128 tally), "
+                            "steady stream, 2^20 fresh slots x 256 acceptors per step per GPU",
+                "slots_per_step": SLOTS_PER_STEP, "replicas": REPLICAS, "quorum": F + 1,
+                "ballot_model": args.ballot, "sharding": args.shard if world > 1 else "none",
+                "run_contract_validation_in_timed_region": bool(args.validate),
+                "log_windows_in_hbm": windows, "hbm_bytes": ctx.device_bytes,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": kernel,
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                "traffic": traffic,
+                "algorithmic_bytes_per_slot": bps, "slots_per_launch": slots_per_launch,
+                "avg_kernel_ms": kernel_ms / max(launches, 1), "launches_timed": launches,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(ballot_mode)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libfpx.so")
+SO_PATH = os.environ.get("FPX_LIB") or os.path.join(CSRC, "libfpx.so")  # FPX_LIB: tuning builds
 
 FPX_OK = 0
 FPX_EINVAL = 1
@@ -74,6 +74,8 @@ SIGNATURES = {
     "fpx_error_detail": (C.c_int32, [VP, I32P, I32P, I32P]),
     "fpx_last_hip_error": (C.c_int32, [VP]),
     "fpx_device_bytes": (C.c_int64, [VP]),
+    "fpx_profile_enable": (C.c_int32, [VP, C.c_int32]),
+    "fpx_profile_read": (C.c_int32, [VP, I32P, C.POINTER(C.c_double)]),
     "fpx_round_leader": (C.c_int32, [C.c_int32, C.c_int32]),
     "fpx_next_classic_round": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "fpx_quorum_eval": (C.c_int32, [CFGP, C.c_int32, VP, C.c_int32, VP]),

@@ -89,6 +89,19 @@ class Context:
         self.L.fpx_error_detail(self._h, C.byref(i), C.byref(s), C.byref(r))
         return i.value, s.value, r.value
 
+    def profile_enable(self, on=True):
+        st = self.L.fpx_profile_enable(self._h, int(on))
+        if st:
+            raise FpxError(st, "fpx_profile_enable")
+
+    def profile_read(self):
+        """(launches, total_ms) of the dominant kernel since the last read (HIP events on the stream)"""
+        n, ms = C.c_int32(), C.c_double()
+        st = self.L.fpx_profile_read(self._h, C.byref(n), C.byref(ms))
+        if st:
+            raise FpxError(st, "fpx_profile_read")
+        return n.value, ms.value
+
     @property
     def device_bytes(self):
         return self.L.fpx_device_bytes(self._h)

@@ -27,6 +27,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// tuning knobs (compile time)
+#ifndef FPX_U
+#define FPX_U 1   // slot rows in flight per wavefront (measured r01: 1 > 2 > 4, occupancy wins)
+#endif
+#ifndef FPX_NT
+#define FPX_NT 1  // vote rows are written once and not re-read soon: nontemporal stores
+#endif
+
 namespace fpx {
 
 typedef int int4v __attribute__((ext_vector_type(4)));
@@ -98,6 +106,14 @@ __device__ __forceinline__ void report(const State& st, int code, int index, int
     st.status[ST_SLOT] = slot;
     st.status[ST_ROUND] = round;
   }
+}
+
+__device__ __forceinline__ void row_store(int4v v, int4v* p) {
+#if FPX_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
 }
 
 __device__ __forceinline__ int popc256(const uint64_t x[4]) {
@@ -292,7 +308,7 @@ template <int G, bool VEC, bool PERSLOT, bool FUSED>
 __global__ void __launch_bounds__(256)
     k_phase2(const Geom g, const State st, const Batch b) {
   constexpr int Q = 64 / G;           // slots per step
-  constexpr int U = G >= 4 ? 4 : G;   // steps in flight
+  constexpr int U = G >= FPX_U ? FPX_U : G;   // steps in flight
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   if (st.status[ST_CODE] != 0) return;  // a failed validation applies nothing
@@ -419,12 +435,12 @@ __global__ void __launch_bounds__(256)
           if (VEC && acc == 0xFu) {
             const int4v rr = {rnd, rnd, rnd, rnd};
             const int4v vv = {val, val, val, val};
-            __builtin_nontemporal_store(rr, reinterpret_cast<int4v*>(st.vote_round + row));
-            __builtin_nontemporal_store(vv, reinterpret_cast<int4v*>(st.vote_value + row));
+            row_store(rr, reinterpret_cast<int4v*>(st.vote_round + row));
+            row_store(vv, reinterpret_cast<int4v*>(st.vote_value + row));
             if (PERSLOT) {
               const int4v old = thr_[u];
               if (old[0] != rnd || old[1] != rnd || old[2] != rnd || old[3] != rnd)
-                __builtin_nontemporal_store(rr, reinterpret_cast<int4v*>(st.ballot + row));
+                row_store(rr, reinterpret_cast<int4v*>(st.ballot + row));
             }
           } else {
 #pragma unroll
@@ -544,6 +560,9 @@ __global__ void __launch_bounds__(256)
 // k_finalize: promised[e] = max(promised[e], max_b part[b][0][e]); max_voted likewise.
 // grid.x = ceil(ntab / 64); block = 256 threads = 64 entries x 4 slices of the block axis.
 // ------------------------------------------------------------------------------------------------
+// grid = (ceil(ntab / 64), FINALIZE_SLICES): blockIdx.y strides over the rows of the partial table,
+// the 4 waves of a block stride within that; one atomicMax per (entry, blockIdx.y) that improves.
+constexpr int FINALIZE_SLICES = 32;
 __global__ void __launch_bounds__(256) k_finalize(const Geom g, const State st, int nblocks) {
   __shared__ int32_t red[2][4][64];
   if (st.status[ST_CODE] != 0) return;
@@ -552,7 +571,8 @@ __global__ void __launch_bounds__(256) k_finalize(const Geom g, const State st, 
   const int slice = threadIdx.x >> 6;
   int pr = -1, mvs = -1;
   if (e < ntab) {
-    for (int bl = slice; bl < nblocks; bl += 4) {
+#pragma unroll 4
+    for (int bl = blockIdx.y * 4 + slice; bl < nblocks; bl += 4 * FINALIZE_SLICES) {
       const int32_t* prow = st.part + (size_t)bl * 2 * ntab;
       const int a = prow[e], c = prow[ntab + e];
       pr = a > pr ? a : pr;
@@ -567,8 +587,8 @@ __global__ void __launch_bounds__(256) k_finalize(const Geom g, const State st, 
       pr = red[0][k][threadIdx.x] > pr ? red[0][k][threadIdx.x] : pr;
       mvs = red[1][k][threadIdx.x] > mvs ? red[1][k][threadIdx.x] : mvs;
     }
-    if (!g.per_slot && pr > st.promised[e]) st.promised[e] = pr;
-    if (mvs > st.max_voted[e]) st.max_voted[e] = mvs;
+    if (!g.per_slot && pr > st.promised[e]) atomicMax(&st.promised[e], pr);
+    if (mvs > st.max_voted[e]) atomicMax(&st.max_voted[e], mvs);
   }
 }
 

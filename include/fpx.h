@@ -33,10 +33,12 @@
  *     (below) -- a violation is detected on the device, nothing is applied, and the next fpx_sync()
  *     returns FPX_EORDER.
  *   - Run contract (one kernel launch): (1) slots in the batch are pairwise distinct; (2) in
- *     FPX_BALLOT_ACCEPTOR mode the rounds of the messages addressed to one acceptor group are
- *     non-decreasing in array order.  Under (2) the acceptor's running-max `round`
+ *     FPX_BALLOT_ACCEPTOR mode all messages addressed to one acceptor group carry the same round
+ *     (different groups may be in different rounds).  Under (2) the acceptor's running-max `round`
  *     (Acceptor.scala:95,204) seen by message i equals max(round at batch start, round[i]) for every
- *     acceptor, which is what lets a batch be evaluated data-parallel and still be bit-exact.
+ *     acceptor, which is what lets a batch be evaluated data-parallel and still be bit-exact.  A
+ *     proxy leader's event-loop tick satisfies both in steady state; the host entry points cut any
+ *     other batch at the offending message and launch the pieces back to back.
  *   - Bitmaps: one message's set of acceptors is 4 x uint64 (256 bits); bit j of the 256-bit
  *     little-endian integer is acceptor index j of the slot's acceptor group (for a Grid:
  *     j = row * grid_cols + col, row = groupIndex, col = acceptorIndex).
@@ -134,6 +136,11 @@ int32_t fpx_error_detail(fpx_ctx* ctx, int32_t* index, int32_t* slot, int32_t* r
 int32_t fpx_last_hip_error(fpx_ctx* ctx);
 /* HBM bytes held by the context */
 int64_t fpx_device_bytes(fpx_ctx* ctx);
+/* Kernel timing for roofline accounting: while enabled, every K1 / K3 call brackets its dominant
+ * kernel (k_phase2) with HIP events on the context's stream.  fpx_profile_read waits for the stream
+ * and returns the number of bracketed launches since the last read and the sum of their durations. */
+int32_t fpx_profile_enable(fpx_ctx* ctx, int32_t on);
+int32_t fpx_profile_read(fpx_ctx* ctx, int32_t* launches, double* total_ms);
 
 /* ---- a7: roundsystem.ClassicRoundRobin (RoundSystem.scala:60-87); pure host scalars ----------- */
 int32_t fpx_round_leader(int32_t num_leaders, int32_t round);                         /* :63     */

@@ -171,8 +171,20 @@ def test_arbitrary_batches_are_split_exactly(fa, oracle, ballot_mode, R):
     check(gpu, ref, script, tally_slots=range(0, S, 17))
 
 
-def test_fifo_pump_equals_fused(oracle):
-    pass  # CPU-only twin lives in tests/test_oracle_traces.py
+@pytest.mark.parametrize("R,f", [(3, 1), (5, 2)])
+def test_random_delivery_orders_message_at_a_time(fa, oracle, R, f):
+    """the reference's randomized-schedule test style (tests/paxos_sim.py): the same random schedule
+    of single-message deliveries, drops, duplicates and leader changes on GPU and oracle gives the
+    same trace and never violates safety"""
+    from tests import paxos_sim
+
+    for seed in range(6):
+        kw = dict(num_slots=6, num_replicas=R, f=f, tally_ways=8)
+        gpu, ref = both(fa, oracle, **kw)
+        tr_g, ch_g = paxos_sim.simulate(gpu, seed, R=R, f=f, S=6, steps=300)
+        tr_r, ch_r = paxos_sim.simulate(ref, seed, R=R, f=f, S=6, steps=300)
+        assert tr_g == tr_r and ch_g == ch_r
+        W.assert_same_state(gpu, ref, tally_slots=range(6))
 
 
 # ---------------------------------------------------------------------------------------------------
