@@ -1,0 +1,106 @@
+/*
+ * fpx_jni.c -- the JNI shim between the reference's JVM actors and the C ABI of include/fpx.h.
+ *
+ * Source only: this image has no JDK (no jni.h), so the shim cannot be compiled or run here; build it
+ * on a machine with a JDK via `make -C frankenpaxos_amd/jni JAVA_HOME=/path/to/jdk`.  It is
+ * deliberately thin: every function pins the primitive arrays of one SoA batch and forwards to one
+ * entry point of libfpx.  Scala side: frankenpaxos_amd/jni/Native.scala.
+ *
+ * Class: frankenpaxos.gpu.Native (all methods static native, returning the int32 status).
+ */
+#include <jni.h>
+#include <stdint.h>
+
+#include "../../include/fpx.h"
+
+#define PIN(env, arr) ((arr) ? (*(env))->GetPrimitiveArrayCritical((env), (arr), NULL) : NULL)
+#define UNPIN(env, arr, p, mode) \
+  do { if (arr) (*(env))->ReleasePrimitiveArrayCritical((env), (arr), (p), (mode)); } while (0)
+
+/* long create(int[] cfg /* the 15 fpx_config fields in order *\/) -> handle or -status */
+JNIEXPORT jlong JNICALL Java_frankenpaxos_gpu_Native_create(JNIEnv* env, jclass cls, jintArray jcfg) {
+  fpx_config cfg;
+  jint* c = (jint*)PIN(env, jcfg);
+  cfg.num_slots = c[0]; cfg.num_replicas = c[1]; cfg.num_groups = c[2]; cfg.num_leader_groups = c[3];
+  cfg.f = c[4]; cfg.quorum_kind = c[5]; cfg.grid_rows = c[6]; cfg.grid_cols = c[7]; cfg.num_leaders = c[8];
+  cfg.ballot_mode = c[9]; cfg.tally_ways = c[10]; cfg.replica_base = c[11]; cfg.replicas_total = c[12];
+  cfg.device = c[13]; cfg.flags = (uint32_t)c[14];
+  UNPIN(env, jcfg, c, JNI_ABORT);
+  fpx_ctx* ctx = NULL;
+  int32_t st = fpx_create(&cfg, &ctx);
+  return st == FPX_OK ? (jlong)(intptr_t)ctx : -(jlong)st;
+}
+
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_destroy(JNIEnv* env, jclass cls, jlong h) {
+  return fpx_destroy((fpx_ctx*)(intptr_t)h);
+}
+
+/* Acceptor.handlePhase2a for one tick: multipaxos/Acceptor.scala:184-220 */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_acceptorPhase2a(
+    JNIEnv* env, jclass cls, jlong h, jint n, jintArray slot, jintArray round, jintArray value,
+    jlongArray targetMask, jlongArray voteBits, jlongArray nackBits, jintArray nackRound) {
+  jint *s = PIN(env, slot), *r = PIN(env, round), *v = PIN(env, value), *nr = PIN(env, nackRound);
+  jlong *t = PIN(env, targetMask), *vb = PIN(env, voteBits), *nb = PIN(env, nackBits);
+  int32_t st = fpx_acceptor_phase2a((fpx_ctx*)(intptr_t)h, n, s, r, v, (const uint64_t*)t, (uint64_t*)vb,
+                                    (uint64_t*)nb, nr);
+  UNPIN(env, nackBits, nb, 0); UNPIN(env, voteBits, vb, 0); UNPIN(env, targetMask, t, JNI_ABORT);
+  UNPIN(env, nackRound, nr, 0); UNPIN(env, value, v, JNI_ABORT); UNPIN(env, round, r, JNI_ABORT);
+  UNPIN(env, slot, s, JNI_ABORT);
+  return st;
+}
+
+/* ProxyLeader.handlePhase2a bookkeeping: multipaxos/ProxyLeader.scala:175-215 */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_proxyOpen(JNIEnv* env, jclass cls, jlong h, jint n,
+                                                              jintArray slot, jintArray round, jintArray value,
+                                                              jbyteArray isNew) {
+  jint *s = PIN(env, slot), *r = PIN(env, round), *v = PIN(env, value);
+  jbyte* f = PIN(env, isNew);
+  int32_t st = fpx_proxy_open((fpx_ctx*)(intptr_t)h, n, s, r, v, (uint8_t*)f);
+  UNPIN(env, isNew, f, 0); UNPIN(env, value, v, JNI_ABORT); UNPIN(env, round, r, JNI_ABORT);
+  UNPIN(env, slot, s, JNI_ABORT);
+  return st;
+}
+
+/* ProxyLeader.handlePhase2b: multipaxos/ProxyLeader.scala:217-258 */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_proxyPhase2b(JNIEnv* env, jclass cls, jlong h, jint n,
+                                                                 jintArray slot, jintArray round, jlongArray voteBits,
+                                                                 jbyteArray newlyChosen, jintArray chosenRound,
+                                                                 jintArray chosenValue) {
+  jint *s = PIN(env, slot), *r = PIN(env, round), *cr = PIN(env, chosenRound), *cv = PIN(env, chosenValue);
+  jlong* vb = PIN(env, voteBits);
+  jbyte* ch = PIN(env, newlyChosen);
+  int32_t st = fpx_proxy_phase2b((fpx_ctx*)(intptr_t)h, n, s, r, (const uint64_t*)vb, (uint8_t*)ch, cr, cv);
+  UNPIN(env, newlyChosen, ch, 0); UNPIN(env, voteBits, vb, JNI_ABORT); UNPIN(env, chosenValue, cv, 0);
+  UNPIN(env, chosenRound, cr, 0); UNPIN(env, round, r, JNI_ABORT); UNPIN(env, slot, s, JNI_ABORT);
+  return st;
+}
+
+/* the fused tick (open + Phase2a to the targeted acceptors + tally) */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_phase2Fused(
+    JNIEnv* env, jclass cls, jlong h, jint n, jintArray slot, jintArray round, jintArray value,
+    jlongArray targetMask, jbyteArray chosen, jintArray chosenRound, jintArray chosenValue, jintArray nackRound) {
+  jint *s = PIN(env, slot), *r = PIN(env, round), *v = PIN(env, value);
+  jint *cr = PIN(env, chosenRound), *cv = PIN(env, chosenValue), *nr = PIN(env, nackRound);
+  jlong* t = PIN(env, targetMask);
+  jbyte* ch = PIN(env, chosen);
+  int32_t st = fpx_phase2_fused((fpx_ctx*)(intptr_t)h, n, s, r, v, (const uint64_t*)t, (uint8_t*)ch, cr, cv, nr);
+  UNPIN(env, chosen, ch, 0); UNPIN(env, targetMask, t, JNI_ABORT); UNPIN(env, nackRound, nr, 0);
+  UNPIN(env, chosenValue, cv, 0); UNPIN(env, chosenRound, cr, 0); UNPIN(env, value, v, JNI_ABORT);
+  UNPIN(env, round, r, JNI_ABORT); UNPIN(env, slot, s, JNI_ABORT);
+  return st;
+}
+
+/* quorums.*.isWriteQuorum / isSuperSetOfWriteQuorum on bitmaps: quorums/QuorumSystem.scala:21,24 */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_quorumEval(JNIEnv* env, jclass cls, jintArray jcfg, jint n,
+                                                               jlongArray nodes, jint strict, jbyteArray out) {
+  fpx_config cfg = {0};
+  jint* c = (jint*)PIN(env, jcfg);
+  cfg.num_slots = 1; cfg.num_replicas = c[1]; cfg.num_groups = 1; cfg.num_leader_groups = 1; cfg.f = c[4];
+  cfg.quorum_kind = c[5]; cfg.grid_rows = c[6]; cfg.grid_cols = c[7]; cfg.num_leaders = 1; cfg.tally_ways = 1;
+  UNPIN(env, jcfg, c, JNI_ABORT);
+  jlong* nd = PIN(env, nodes);
+  jbyte* o = PIN(env, out);
+  int32_t st = fpx_quorum_eval(&cfg, n, (const uint64_t*)nd, strict, (uint8_t*)o);
+  UNPIN(env, out, o, 0); UNPIN(env, nodes, nd, JNI_ABORT);
+  return st;
+}
