@@ -184,6 +184,45 @@ class Context:
         if st:
             raise FpxError(st, "fpx_phase2_fused_dev")
 
+    # ---- f1: replica log / f2: Phase-1 recovery scan ----------------------------------------------
+    def replica_chosen(self, slot, value, mask=None):
+        slot, value = _i32(slot), _i32(value)
+        mask = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        wm, nc = C.c_int32(), C.c_int32()
+        st = self.L.fpx_replica_chosen(self._h, len(slot), _hp(slot), _hp(value), _hp(mask),
+                                       C.byref(wm), C.byref(nc))
+        return st, wm.value, nc.value
+
+    def replica_chosen_dev(self, slot, value, mask=None):
+        st = self.L.fpx_replica_chosen_dev(self._h, slot.numel(), _dp(slot), _dp(value), _dp(mask))
+        if st:
+            raise FpxError(st, "fpx_replica_chosen_dev")
+
+    def replica_state(self):
+        wm, nc = C.c_int32(), C.c_int32()
+        st = self.L.fpx_replica_state(self._h, C.byref(wm), C.byref(nc))
+        if st:
+            raise FpxError(st, "fpx_replica_state")
+        return wm.value, nc.value
+
+    def replica_read_log(self, first, count):
+        vals = np.zeros(count, np.int32)
+        pres = np.zeros(count, np.uint8)
+        st = self.L.fpx_replica_read_log(self._h, first, count, _hp(vals), _hp(pres))
+        if st:
+            raise FpxError(st, "fpx_replica_read_log")
+        return vals, pres
+
+    def leader_phase1b_scan(self, watermark, quorum_masks, cap):
+        q = np.ascontiguousarray(quorum_masks, dtype=np.uint64).reshape(self.ngroups, 4)
+        mx = C.c_int32()
+        sr = np.full(cap, -7, np.int32)
+        sv = np.full(cap, -7, np.int32)
+        st = self.L.fpx_leader_phase1b_scan(self._h, watermark, _hp(q), cap, C.byref(mx), _hp(sr),
+                                            _hp(sv))
+        k = max(0, min(cap, mx.value - watermark + 1))
+        return st, mx.value, sr[:k], sv[:k]
+
     # ---- readback ------------------------------------------------------------------------------
     def read_acceptor(self, group, replica):
         p, m = C.c_int32(), C.c_int32()

@@ -270,6 +270,13 @@ int init_state(fpx_ctx* ctx) {
   HIPCHK(ctx, hipMemsetAsync(st.stamp, 0, (size_t)g.S * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.run_round, 0xFF, (size_t)g.ngroups * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.status, 0, 8 * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.log_value, 0xFF, (size_t)g.S * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.log_present, 0, (size_t)g.S, ctx->stream));
+  {
+    // executedWatermark = 0, numChosen = 0, largestKey = -1, scan result = 0
+    static const int32_t init[8] = {0, 0, -1, 0, 0, 0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(st.log_scalars, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  }
   ctx->run_id = 0;
   ctx->hrun = 0;
   std::fill(ctx->hstamp.begin(), ctx->hstamp.end(), 0u);
@@ -279,7 +286,8 @@ int init_state(fpx_ctx* ctx) {
 void free_state(fpx_ctx* ctx) {
   State& st = ctx->st;
   void* ps[] = {st.promised, st.max_voted, st.vote_round, st.vote_value, st.ballot, st.pl_key, st.pl_value,
-                st.pl_bits,  st.stamp,     st.run_round,  st.status,     st.part};
+                st.pl_bits,  st.stamp,     st.run_round,  st.status,     st.part,
+                st.log_value, st.log_present, st.log_scalars};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   DevBuf* bs[] = {&ctx->d_slot,   &ctx->d_round, &ctx->d_value, &ctx->d_target, &ctx->d_bits_a, &ctx->d_bits_b,
@@ -358,6 +366,14 @@ int h2d(fpx_ctx* ctx, DevBuf* b, const T* src, size_t count) {
   if (rc) return rc;
   if (src && count) HIPCHK(ctx, hipMemcpyAsync(b->p, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
   return FPX_OK;
+}
+
+template <int G>
+void launch_p1b(fpx_ctx* ctx, const uint64_t* d_q, int wm, int count, int32_t* d_sr, int32_t* d_sv) {
+  const int per_block = 4 * (64 / G);
+  const int grid = std::max(1, std::min((count + per_block - 1) / per_block, ctx->num_cus * 16));
+  hipLaunchKernelGGL((k_phase1b_scan<G>), dim3(grid), dim3(256), 0, ctx->stream, ctx->g, ctx->st, d_q, wm, count,
+                     ctx->vec ? 1 : 0, d_sr, d_sv);
 }
 
 template <typename T>
@@ -454,6 +470,9 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
   if ((rc = dalloc(ctx, &st.run_round, (size_t)g.ngroups))) return fail(rc);
   if ((rc = dalloc(ctx, &st.status, (size_t)8))) return fail(rc);
   if ((rc = dalloc(ctx, &st.part, (size_t)ctx->max_grid * 2 * ntab))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.log_value, (size_t)g.S))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.log_present, (size_t)g.S))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.log_scalars, (size_t)8))) return fail(rc);
   if ((rc = init_state(ctx))) return fail(rc);
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(FPX_EHIP);
   *out = ctx;
@@ -761,6 +780,116 @@ int32_t fpx_acceptor_phase1a(fpx_ctx* ctx, int32_t group, int32_t round, int32_t
   }
   if (promised_bits) memcpy(promised_bits, h, 32);
   if (nack_bits) memcpy(nack_bits, h + 4, 32);
+  return FPX_OK;
+}
+
+// ---- f1: replica log ------------------------------------------------------------------------------------
+int32_t fpx_replica_chosen_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_value_id,
+                               const uint8_t* d_mask) {
+  if (!ctx || n < 0) return FPX_EINVAL;
+  if (n == 0) return FPX_OK;
+  Batch b;
+  memset(&b, 0, sizeof(b));
+  b.n = n, b.slot = d_slot, b.value = d_value_id, b.mask = d_mask;
+  int rc = enqueue_validate(ctx, b, false);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_log_ingest, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->g, ctx->st, b);
+  hipLaunchKernelGGL(k_log_prep, dim3(1), dim3(1), 0, ctx->stream, ctx->g, ctx->st);
+  hipLaunchKernelGGL(k_log_scan, dim3(ctx->num_cus * 4), dim3(256), 0, ctx->stream, ctx->g, ctx->st);
+  hipLaunchKernelGGL(k_log_commit, dim3(1), dim3(1), 0, ctx->stream, ctx->st);
+  return launch_check(ctx);
+}
+
+int32_t fpx_replica_state(fpx_ctx* ctx, int32_t* executed_watermark, int32_t* num_chosen) {
+  if (!ctx) return FPX_EINVAL;
+  int32_t h[2] = {0, 0};
+  HIPCHK(ctx, hipMemcpyAsync(h, ctx->st.log_scalars, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (executed_watermark) *executed_watermark = h[0];
+  if (num_chosen) *num_chosen = h[1];
+  return FPX_OK;
+}
+
+int32_t fpx_replica_chosen(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* value_id, const uint8_t* mask,
+                           int32_t* executed_watermark, int32_t* num_chosen) {
+  if (!ctx || n < 0 || (n > 0 && (!slot || !value_id))) return FPX_EINVAL;
+  for (int i = 0; i < n; ++i) {
+    if ((!mask || mask[i]) && (slot[i] < 0 || slot[i] >= ctx->g.S)) {
+      ctx->err_index = i, ctx->err_slot = slot[i], ctx->err_round = -1;
+      return FPX_EINVAL;
+    }
+  }
+  int rc;
+  if (n > 0) {
+    // masked-out messages must not trip the slot checks on the device: compact them away
+    std::vector<int32_t> s, v;
+    s.reserve(n), v.reserve(n);
+    for (int i = 0; i < n; ++i)
+      if (!mask || mask[i]) s.push_back(slot[i]), v.push_back(value_id[i]);
+    const int m = (int)s.size();
+    if (m > 0) {
+      if ((rc = h2d(ctx, &ctx->d_slot, s.data(), m))) return rc;
+      if ((rc = h2d(ctx, &ctx->d_value, v.data(), m))) return rc;
+      std::vector<int> cuts;
+      split_runs(ctx, m, s.data(), nullptr, false, &cuts);
+      for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+        const int lo = cuts[k], len = cuts[k + 1] - cuts[k];
+        rc = fpx_replica_chosen_dev(ctx, len, (int32_t*)ctx->d_slot.p + lo, (int32_t*)ctx->d_value.p + lo, nullptr);
+        if (rc) return rc;
+      }
+    }
+  }
+  if ((rc = fpx_replica_state(ctx, executed_watermark, num_chosen))) return rc;
+  return fetch_status(ctx);
+}
+
+int32_t fpx_replica_read_log(fpx_ctx* ctx, int32_t first, int32_t count, int32_t* values, uint8_t* present) {
+  if (!ctx || first < 0 || count < 0 || (int64_t)first + count > ctx->g.S) return FPX_EINVAL;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (values && count) HIPCHK(ctx, hipMemcpy(values, ctx->st.log_value + first, (size_t)count * 4, hipMemcpyDeviceToHost));
+  if (present && count) HIPCHK(ctx, hipMemcpy(present, ctx->st.log_present + first, (size_t)count, hipMemcpyDeviceToHost));
+  return FPX_OK;
+}
+
+// ---- f2: Phase-1 recovery scan ------------------------------------------------------------------------
+int32_t fpx_leader_phase1b_scan(fpx_ctx* ctx, int32_t chosen_watermark, const uint64_t* quorum_masks, int32_t cap,
+                                int32_t* max_slot, int32_t* safe_round, int32_t* safe_value) {
+  if (!ctx || !quorum_masks || chosen_watermark < 0 || cap < 0) return FPX_EINVAL;
+  const int ng = ctx->g.ngroups;
+  int rc;
+  if ((rc = grow(ctx, &ctx->d_target, (size_t)ng * 32 + 64))) return rc;
+  uint64_t* d_q = (uint64_t*)ctx->d_target.p;
+  int32_t* d_max = (int32_t*)(d_q + (size_t)ng * 4);
+  HIPCHK(ctx, hipMemcpyAsync(d_q, quorum_masks, (size_t)ng * 32, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(d_max, 0xFF, 4, ctx->stream));
+  const int ntab = ng * ctx->g.R;
+  hipLaunchKernelGGL(k_quorum_max_slot, dim3((ntab + 255) / 256), dim3(256), 0, ctx->stream, ctx->g, ctx->st, d_q,
+                     chosen_watermark, d_max);
+  if ((rc = launch_check(ctx))) return rc;
+  int32_t hmax = -1;
+  HIPCHK(ctx, hipMemcpyAsync(&hmax, d_max, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (max_slot) *max_slot = hmax;
+  // for (slot <- chosenWatermark to maxSlot)   Leader.scala:553
+  const int64_t want = (int64_t)hmax - chosen_watermark + 1;
+  const int count = (int)std::max<int64_t>(0, std::min<int64_t>(want, cap));
+  if (count == 0) return FPX_OK;
+  if ((rc = grow(ctx, &ctx->d_i32_a, (size_t)count * 4))) return rc;
+  if ((rc = grow(ctx, &ctx->d_i32_b, (size_t)count * 4))) return rc;
+  int32_t *d_sr = (int32_t*)ctx->d_i32_a.p, *d_sv = (int32_t*)ctx->d_i32_b.p;
+  switch (ctx->lanes_per_slot) {
+    case 1: launch_p1b<1>(ctx, d_q, chosen_watermark, count, d_sr, d_sv); break;
+    case 2: launch_p1b<2>(ctx, d_q, chosen_watermark, count, d_sr, d_sv); break;
+    case 4: launch_p1b<4>(ctx, d_q, chosen_watermark, count, d_sr, d_sv); break;
+    case 8: launch_p1b<8>(ctx, d_q, chosen_watermark, count, d_sr, d_sv); break;
+    case 16: launch_p1b<16>(ctx, d_q, chosen_watermark, count, d_sr, d_sv); break;
+    case 32: launch_p1b<32>(ctx, d_q, chosen_watermark, count, d_sr, d_sv); break;
+    default: launch_p1b<64>(ctx, d_q, chosen_watermark, count, d_sr, d_sv); break;
+  }
+  if ((rc = launch_check(ctx))) return rc;
+  if ((rc = d2h(ctx, safe_round, ctx->d_i32_a, (size_t)count))) return rc;
+  if ((rc = d2h(ctx, safe_value, ctx->d_i32_b, (size_t)count))) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FPX_OK;
 }
 

@@ -69,6 +69,9 @@ struct State {
   int32_t* run_round;   // [ngroups]      the single round of the current run per group (-1 = none)
   int32_t* status;      // [8]
   int32_t* part;        // [grid][2][ngroups*R] per-block maxima (accepted round, voted slot)
+  int32_t* log_value;   // [S]  the replica's log (BufferMap), -1 where absent
+  uint8_t* log_present; // [S]
+  int32_t* log_scalars; // [8]  LG_*: executedWatermark, numChosen, largestKey, scan result
 };
 
 struct Batch {
@@ -84,6 +87,7 @@ struct Batch {
   int32_t* chosen_round;
   int32_t* chosen_value;
   uint8_t* is_new;         // k_open
+  const uint8_t* mask;     // k_log_ingest: which messages are Chosen (null = all)
   uint32_t run_id;
   int32_t check_round;     // validate: enforce one round per group (ACCEPTOR ballot mode)
 };
@@ -257,7 +261,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 __global__ void __launch_bounds__(256) k_validate(const Geom g, const State st, const Batch b) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b.n) return;
-  const int s = b.slot[i], r = b.round[i];
+  const int s = b.slot[i], r = b.round ? b.round[i] : 0;
   if (s < 0 || s >= g.S || r < 0) {
     report(st, 1 /*FPX_EINVAL*/, i, s, r);
     return;
@@ -747,6 +751,131 @@ __global__ void __launch_bounds__(256) k_gather_acceptor(const Geom g, const Sta
   vr[s] = mine ? st.vote_round[c] : -1;
   vv[s] = mine ? st.vote_value[c] : -1;
   bl[s] = (mine && st.ballot) ? st.ballot[c] : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// f1: the replica's log.  Replica.handleChosen (multipaxos/Replica.scala:572-590): a slot that is
+// already in the log is ignored, otherwise log.put + numChosen += 1; executeLog (:394-404) advances
+// executedWatermark over the contiguous prefix.
+// ------------------------------------------------------------------------------------------------
+enum { LG_WATERMARK = 0, LG_NUM_CHOSEN = 1, LG_LARGEST = 2, LG_FIRST_MISSING = 3 };
+
+__global__ void __launch_bounds__(256) k_log_ingest(const Geom g, const State st, const Batch b) {
+  if (st.status[ST_CODE] != 0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool fresh = false;
+  int s = -1;
+  if (i < b.n && (!b.mask || b.mask[i])) {
+    s = b.slot[i];
+    if (!st.log_present[s]) {  // BufferMap.get == None
+      st.log_value[s] = b.value[i];
+      st.log_present[s] = 1;
+      fresh = true;
+    }
+  }
+  const unsigned long long m = __ballot(fresh);
+  int top = fresh ? s : -1;  // BufferMap.largestKey
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) {
+    const int o = __shfl_xor(top, k);
+    top = o > top ? o : top;
+  }
+  if ((threadIdx.x & 63) == 0 && m) {
+    atomicAdd(&st.log_scalars[LG_NUM_CHOSEN], __popcll(m));
+    atomicMax(&st.log_scalars[LG_LARGEST], top);
+  }
+}
+
+// scan range = [executedWatermark, min(S, largestKey + 1)): the slot after largestKey is absent by
+// definition, so LG_FIRST_MISSING starts at the end of the range and only ever decreases
+__global__ void k_log_prep(const Geom g, const State st) {
+  if (st.status[ST_CODE] != 0) return;
+  const int hi = st.log_scalars[LG_LARGEST] + 1;
+  st.log_scalars[LG_FIRST_MISSING] = hi < g.S ? hi : g.S;
+}
+
+__global__ void __launch_bounds__(256) k_log_scan(const Geom g, const State st) {
+  if (st.status[ST_CODE] != 0) return;
+  const int lo = st.log_scalars[LG_WATERMARK];
+  const int hi0 = st.log_scalars[LG_LARGEST] + 1;
+  const int hi = hi0 < g.S ? hi0 : g.S;
+  const int stride = gridDim.x * blockDim.x;
+  for (int s = lo + blockIdx.x * blockDim.x + threadIdx.x; s < hi; s += stride) {
+    if (!st.log_present[s]) {
+      atomicMin(&st.log_scalars[LG_FIRST_MISSING], s);
+      break;  // later slots of this thread are larger
+    }
+  }
+}
+
+__global__ void k_log_commit(const State st) {
+  if (st.status[ST_CODE] != 0) return;
+  const int fm = st.log_scalars[LG_FIRST_MISSING];
+  if (fm > st.log_scalars[LG_WATERMARK]) st.log_scalars[LG_WATERMARK] = fm;
+}
+
+// ------------------------------------------------------------------------------------------------
+// f2: Leader.handlePhase1b recovery scan (multipaxos/Leader.scala:306-329, 543-566).
+// k_quorum_max_slot: maxSlot over the quorum's acceptors; k_phase1b_scan<G>: per slot the arg-max
+// voteRound over the quorum's acceptors of the slot's group (ties: lowest acceptor index).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_quorum_max_slot(const Geom g, const State st, const uint64_t* qmask, int watermark, int32_t* out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= g.ngroups * g.R) return;
+  const int grp = e / g.R, bit = g.base + e % g.R;
+  if (!((qmask[(size_t)grp * 4 + (bit >> 6)] >> (bit & 63)) & 1ull)) return;
+  const int mv = st.max_voted[e];
+  if (mv >= watermark) atomicMax(out, mv);  // maxPhase1bSlot over info from chosenWatermark
+}
+
+template <int G>
+__global__ void __launch_bounds__(256)
+    k_phase1b_scan(const Geom g, const State st, const uint64_t* qmask, int watermark, int count, int vec,
+                   int32_t* safe_round, int32_t* safe_value) {
+  constexpr int Q = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int gi = lane & (G - 1), q = lane / G;
+  const int r0 = 4 * gi;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int base = wave * Q; base < count; base += nwaves * Q) {
+    const int idx = base + q;
+    const bool live = idx < count;
+    const int s = watermark + idx;
+    int best_round = -1, best_val = -1, best_idx = 1 << 30;
+    if (live && r0 < g.R) {
+      const int grp = group_of_slot(g, s);
+      const size_t row = (size_t)s * g.R + r0;
+      int vr[4] = {-1, -1, -1, -1}, vv[4] = {-1, -1, -1, -1};
+      if (vec) {
+        const int4v a = *reinterpret_cast<const int4v*>(st.vote_round + row);
+        const int4v c = *reinterpret_cast<const int4v*>(st.vote_value + row);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vr[k] = a[k], vv[k] = c[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (r0 + k < g.R) vr[k] = st.vote_round[row + k], vv[k] = st.vote_value[row + k];
+      }
+      const int bit = g.base + r0;
+      const uint32_t qn = (uint32_t)((qmask[(size_t)grp * 4 + (bit >> 6)] >> (bit & 63)) & 0xFull);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        // phase1b.info.find(_.slot == slot): only acceptors of the quorum that voted in the slot
+        if ((qn >> k & 1u) && vr[k] > best_round) best_round = vr[k], best_val = vv[k], best_idx = r0 + k;
+      }
+    }
+    // slotInfos.maxBy(_.voteRound) across the lanes of the slot
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) {
+      const int orr = __shfl_xor(best_round, m), ov = __shfl_xor(best_val, m), oi = __shfl_xor(best_idx, m);
+      if (orr > best_round || (orr == best_round && oi < best_idx)) best_round = orr, best_val = ov, best_idx = oi;
+    }
+    if (live && gi == 0) {
+      safe_round[idx] = best_round;
+      safe_value[idx] = best_round >= 0 ? best_val : -1;  // Noop when nobody voted (Leader.scala:323-325)
+    }
+  }
 }
 
 }  // namespace fpx

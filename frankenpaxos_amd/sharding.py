@@ -26,7 +26,7 @@ def groups_of_rank(num_groups_total, world, rank):
 
 
 def group_of_slot(slot, num_groups, num_leader_groups=1):
-    """slot -> group id, vectorised (same map as the kernels / the oracle)"""
+    """slot -> group id, vectorised (the same map the kernels use: fpx_kernels.hpp group_of_slot)"""
     slot = np.asarray(slot)
     return (slot % num_leader_groups) * num_groups + (slot // num_leader_groups) % num_groups
 

@@ -226,6 +226,35 @@ int32_t fpx_phase2_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, con
                              uint8_t* d_chosen, int32_t* d_chosen_round, int32_t* d_chosen_value,
                              int32_t* d_nack_round);
 
+/* ---- next rows of SURVEY.md section 8(f) ----------------------------------------------------------
+ *
+ * f1  Replica.handleChosen + executeLog (multipaxos/Replica.scala:572-590, 394-447;
+ *     util/BufferMap.scala:29-51): the receiver of Chosen.  One replica log per context (every replica
+ *     receives the same Chosen stream).  For i in order with mask[i] != 0 (mask NULL = all):
+ *     log.get(slot) defined -> ignored (redundantly chosen); else log.put(slot, value), numChosen += 1;
+ *     then the contiguous prefix executes: executedWatermark advances while log.get(it) is defined.
+ *     Outputs (may be NULL): the new executedWatermark and numChosen. */
+int32_t fpx_replica_chosen(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* value_id,
+                           const uint8_t* mask, int32_t* executed_watermark, int32_t* num_chosen);
+/* device-resident inputs; the result is read with fpx_replica_state after fpx_sync */
+int32_t fpx_replica_chosen_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot,
+                               const int32_t* d_value_id, const uint8_t* d_mask);
+int32_t fpx_replica_state(fpx_ctx* ctx, int32_t* executed_watermark, int32_t* num_chosen);
+/* log entries [first, first + count): value (-1 where absent) and present flag */
+int32_t fpx_replica_read_log(fpx_ctx* ctx, int32_t first, int32_t count, int32_t* values,
+                             uint8_t* present);
+
+/* f2  Leader.handlePhase1b recovery scan (multipaxos/Leader.scala:306-329 safeValue, :543-566).
+ *     quorum_masks: one 4-word set per acceptor group (num_leader_groups * num_groups x 4): the
+ *     acceptors whose Phase1b the leader holds.  maxSlot = the largest slot >= chosen_watermark in
+ *     which any of them voted (-1 if none).  For slot = chosen_watermark .. maxSlot (at most cap
+ *     entries are written): safe_round = the highest voteRound among the quorum's acceptors of the
+ *     slot's group that voted in the slot (-1 if none voted), safe_value = the value voted in that
+ *     round (FPX_NOOP if none: "everything is safe, we return Noop"). */
+int32_t fpx_leader_phase1b_scan(fpx_ctx* ctx, int32_t chosen_watermark, const uint64_t* quorum_masks,
+                                int32_t cap, int32_t* max_slot, int32_t* safe_round,
+                                int32_t* safe_value);
+
 /* ---- state readback (parity) ------------------------------------------------------------------- */
 /* acceptor `replica` of `group`: its round (FPX_BALLOT_ACCEPTOR; -1 in PER_SLOT mode),
  * maxVotedSlot, and for every slot s in [0, S): vote_round[s] / vote_value[s] (-1 / -1 when the

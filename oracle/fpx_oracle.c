@@ -364,6 +364,7 @@ struct fpo_sys {
   size_t tab_cap, tab_n;
   int seq;
   int err_index, err_slot, err_round;
+  fpo_log* log; /* the replica's log (f1), created on first use */
 };
 
 int fpo_config_check(const fpo_config* c) {
@@ -417,6 +418,8 @@ void fpo_sys_reset(fpo_sys* s) {
   s->tab_n = 0;
   s->seq = 0;
   s->err_index = s->err_slot = s->err_round = -1;
+  if (s->log) fpo_log_free(s->log);
+  s->log = NULL;
 }
 
 fpo_sys* fpo_sys_new(const fpo_config* cfg) {
@@ -446,6 +449,7 @@ void fpo_sys_free(fpo_sys* s) {
   free(s->vote_value);
   free(s->ballot);
   free(s->tab);
+  if (s->log) fpo_log_free(s->log);
   free(s);
 }
 
@@ -863,6 +867,74 @@ int fpo_phase2_fifo_pump(fpo_sys* s, int32_t n, const int32_t* slot, const int32
     }
   }
   free(q);
+  return FPO_OK;
+}
+
+/* ---- f1: the replica's log --------------------------------------------------------------------- */
+
+static fpo_log* sys_log(fpo_sys* s) {
+  if (!s->log) s->log = fpo_log_new(5000); /* BufferMap default growSize, BufferMap.scala:8 */
+  return s->log;
+}
+
+int fpo_replica_chosen(fpo_sys* s, int32_t n, const int32_t* slot, const int32_t* value_id,
+                       const uint8_t* mask, int32_t* executed_watermark, int32_t* num_chosen) {
+  if (n < 0) return FPO_EINVAL;
+  for (int i = 0; i < n; ++i)
+    if ((!mask || mask[i]) && (slot[i] < 0 || slot[i] >= s->cfg.num_slots)) {
+      s->err_index = i, s->err_slot = slot[i], s->err_round = -1;
+      return FPO_EINVAL;
+    }
+  fpo_log* l = sys_log(s);
+  /* Replica.scala:572-590 for every Chosen in delivery order */
+  for (int i = 0; i < n; ++i)
+    if (!mask || mask[i]) fpo_log_chosen(l, slot[i], value_id[i]);
+  if (executed_watermark) *executed_watermark = l->executed_watermark;
+  if (num_chosen) *num_chosen = l->num_chosen;
+  return FPO_OK;
+}
+
+int fpo_replica_read_log(fpo_sys* s, int32_t first, int32_t count, int32_t* values, uint8_t* present) {
+  fpo_log* l = sys_log(s);
+  for (int i = 0; i < count; ++i) {
+    int v = -1;
+    int some = fpo_log_get(l, first + i, &v);
+    if (values) values[i] = some ? v : -1;
+    if (present) present[i] = (uint8_t)some;
+  }
+  return FPO_OK;
+}
+
+/* ---- f2: Phase-1 recovery ------------------------------------------------------------------------ */
+
+int fpo_leader_phase1b_scan(fpo_sys* s, int32_t chosen_watermark, const uint64_t* quorum_masks,
+                            int32_t cap, int32_t* max_slot, int32_t* safe_round, int32_t* safe_value) {
+  const int R = s->cfg.num_replicas, base = s->cfg.replica_base;
+  if (chosen_watermark < 0 || cap < 0) return FPO_EINVAL;
+  /* Leader.scala:543-549: maxSlot = max over the Phase1b's of maxPhase1bSlot (largest slot in
+   * `info`, which an acceptor fills from chosenWatermark on: Acceptor.scala:171-180), -1 if empty */
+  int mx = -1;
+  for (int g = 0; g < s->ngroups; ++g)
+    for (int r = 0; r < R; ++r) {
+      if (!test_bit(quorum_masks + (size_t)g * 4, base + r)) continue;
+      int mv = s->max_voted_slot[(size_t)g * R + r];
+      if (mv >= chosen_watermark && mv > mx) mx = mv;
+    }
+  if (max_slot) *max_slot = mx;
+  /* :553-565  for (slot <- chosenWatermark to maxSlot) propose safeValue(group.values, slot) */
+  for (int slot = chosen_watermark, k = 0; slot <= mx && k < cap; ++slot, ++k) {
+    int g = fpo_group_of_slot(&s->cfg, slot);
+    /* Leader.scala:319-328 safeValue: slotInfos = the quorum's votes in this slot; empty -> Noop;
+     * else maxBy(voteRound).voteValue */
+    int best_round = -1, best_value = -1;
+    for (int r = 0; r < R; ++r) {
+      if (!test_bit(quorum_masks + (size_t)g * 4, base + r)) continue;
+      size_t cell = (size_t)slot * R + r;
+      if (s->vote_round[cell] > best_round) best_round = s->vote_round[cell], best_value = s->vote_value[cell];
+    }
+    if (safe_round) safe_round[k] = best_round;
+    if (safe_value) safe_value[k] = best_round >= 0 ? best_value : -1;
+  }
   return FPO_OK;
 }
 

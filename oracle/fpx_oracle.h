@@ -123,6 +123,14 @@ int fpo_phase2_fifo_pump(fpo_sys* sys, int32_t n, const int32_t* slot, const int
                          const int32_t* value_id, const uint64_t* target_mask, uint8_t* chosen,
                          int32_t* chosen_round, int32_t* chosen_value, int32_t* nack_round);
 
+/* f1: Replica.handleChosen per message (multipaxos/Replica.scala:572-590) on the system's replica log */
+int fpo_replica_chosen(fpo_sys* sys, int32_t n, const int32_t* slot, const int32_t* value_id,
+                       const uint8_t* mask, int32_t* executed_watermark, int32_t* num_chosen);
+int fpo_replica_read_log(fpo_sys* sys, int32_t first, int32_t count, int32_t* values, uint8_t* present);
+/* f2: Leader.handlePhase1b recovery (multipaxos/Leader.scala:306-329 safeValue, :543-566) */
+int fpo_leader_phase1b_scan(fpo_sys* sys, int32_t chosen_watermark, const uint64_t* quorum_masks,
+                            int32_t cap, int32_t* max_slot, int32_t* safe_round, int32_t* safe_value);
+
 int fpo_error_detail(fpo_sys* sys, int32_t* index, int32_t* slot, int32_t* round);
 int fpo_read_acceptor(fpo_sys* sys, int32_t group, int32_t replica, int32_t* promised,
                       int32_t* max_voted_slot, int32_t* vote_round, int32_t* vote_value,

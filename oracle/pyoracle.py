@@ -113,6 +113,9 @@ def lib():
     for name in ("fpo_phase2_fused", "fpo_phase2_fifo_pump"):
         getattr(L, name).argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, U64P, U8P, I32P, I32P,
                                      I32P]
+    L.fpo_replica_chosen.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, U8P, I32P, I32P]
+    L.fpo_replica_read_log.argtypes = [C.c_void_p, C.c_int32, C.c_int32, I32P, U8P]
+    L.fpo_leader_phase1b_scan.argtypes = [C.c_void_p, C.c_int32, U64P, C.c_int32, I32P, I32P, I32P]
     L.fpo_error_detail.argtypes = [C.c_void_p, I32P, I32P, I32P]
     L.fpo_read_acceptor.argtypes = [C.c_void_p, C.c_int32, C.c_int32, I32P, I32P, I32P, I32P, I32P]
     L.fpo_read_state.argtypes = [C.c_void_p, I32P, I32P, I32P]
@@ -347,6 +350,30 @@ class System:
 
     def phase2_fifo_pump(self, slot, round_, value, target_mask=None):
         return self._fused(lib().fpo_phase2_fifo_pump, slot, round_, value, target_mask)
+
+    def replica_chosen(self, slot, value, mask=None):
+        slot, value = _i32(slot), _i32(value)
+        mask = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        wm, nc = C.c_int32(), C.c_int32()
+        st = lib().fpo_replica_chosen(self._h, len(slot), _p(slot, I32P), _p(value, I32P),
+                                      _p(mask, U8P), C.byref(wm), C.byref(nc))
+        return st, wm.value, nc.value
+
+    def replica_read_log(self, first, count):
+        vals = np.zeros(count, np.int32)
+        pres = np.zeros(count, np.uint8)
+        lib().fpo_replica_read_log(self._h, first, count, _p(vals, I32P), _p(pres, U8P))
+        return vals, pres
+
+    def leader_phase1b_scan(self, watermark, quorum_masks, cap):
+        q = np.ascontiguousarray(quorum_masks, dtype=np.uint64).reshape(self.ngroups, 4)
+        mx = C.c_int32()
+        sr = np.full(cap, -7, np.int32)
+        sv = np.full(cap, -7, np.int32)
+        st = lib().fpo_leader_phase1b_scan(self._h, watermark, _p(q, U64P), cap, C.byref(mx),
+                                           _p(sr, I32P), _p(sv, I32P))
+        k = max(0, min(cap, mx.value - watermark + 1))
+        return st, mx.value, sr[:k], sv[:k]
 
     def error_detail(self):
         i, s, r = C.c_int32(), C.c_int32(), C.c_int32()
