@@ -90,6 +90,9 @@ SIGNATURES = {
     "fpx_proxy_phase2b_dev": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP, VP, VP]),
     "fpx_phase2_fused": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP, VP, VP, VP, VP]),
     "fpx_phase2_fused_dev": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP, VP, VP, VP, VP]),
+    "fpx_acceptor_phase2a_noop_range": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, VP, VP, VP, I32P]),
+    "fpx_proxy_open_noop_range": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, U8P]),
+    "fpx_proxy_phase2b_noop_range": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, VP, U8P]),
     "fpx_replica_chosen": (C.c_int32, [VP, C.c_int32, VP, VP, VP, I32P, I32P]),
     "fpx_replica_chosen_dev": (C.c_int32, [VP, C.c_int32, VP, VP, VP]),
     "fpx_replica_state": (C.c_int32, [VP, I32P, I32P]),

@@ -184,6 +184,29 @@ class Context:
         if st:
             raise FpxError(st, "fpx_phase2_fused_dev")
 
+    # ---- K4: Mencius noop ranges ----------------------------------------------------------------
+    def acceptor_phase2a_noop_range(self, slot_start, slot_end, round_, target_masks=None):
+        A = self.cfg.num_groups
+        target_masks = _u64(target_masks)
+        vb = np.zeros((A, 4), np.uint64)
+        nb = np.zeros((A, 4), np.uint64)
+        nr = C.c_int32(-1)
+        st = self.L.fpx_acceptor_phase2a_noop_range(self._h, slot_start, slot_end, round_,
+                                                    _hp(target_masks), _hp(vb), _hp(nb), C.byref(nr))
+        return st, vb, nb, nr.value
+
+    def proxy_open_noop_range(self, slot_start, slot_end, round_):
+        new = C.c_uint8(0)
+        st = self.L.fpx_proxy_open_noop_range(self._h, slot_start, slot_end, round_, C.byref(new))
+        return st, new.value
+
+    def proxy_phase2b_noop_range(self, slot_start, slot_end, round_, vote_bits):
+        vote_bits = _u64(vote_bits)
+        ch = C.c_uint8(0)
+        st = self.L.fpx_proxy_phase2b_noop_range(self._h, slot_start, slot_end, round_, _hp(vote_bits),
+                                                 C.byref(ch))
+        return st, ch.value
+
     # ---- f1: replica log / f2: Phase-1 recovery scan ----------------------------------------------
     def replica_chosen(self, slot, value, mask=None):
         slot, value = _i32(slot), _i32(value)

@@ -272,6 +272,8 @@ int init_state(fpx_ctx* ctx) {
   HIPCHK(ctx, hipMemsetAsync(st.status, 0, 8 * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.log_value, 0xFF, (size_t)g.S * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.log_present, 0, (size_t)g.S, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.rt_key, 0, (size_t)RANGE_TALLIES * 16, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.rt_bits, 0, (size_t)RANGE_TALLIES * 32, ctx->stream));
   {
     // executedWatermark = 0, numChosen = 0, largestKey = -1, scan result = 0
     static const int32_t init[8] = {0, 0, -1, 0, 0, 0, 0, 0};
@@ -287,7 +289,7 @@ void free_state(fpx_ctx* ctx) {
   State& st = ctx->st;
   void* ps[] = {st.promised, st.max_voted, st.vote_round, st.vote_value, st.ballot, st.pl_key, st.pl_value,
                 st.pl_bits,  st.stamp,     st.run_round,  st.status,     st.part,
-                st.log_value, st.log_present, st.log_scalars};
+                st.log_value, st.log_present, st.log_scalars, st.rt_key, st.rt_bits};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   DevBuf* bs[] = {&ctx->d_slot,   &ctx->d_round, &ctx->d_value, &ctx->d_target, &ctx->d_bits_a, &ctx->d_bits_b,
@@ -350,7 +352,7 @@ void split_runs(fpx_ctx* ctx, int n, const int32_t* slot, const int32_t* round, 
 int check_inputs(fpx_ctx* ctx, int n, const int32_t* slot, const int32_t* round) {
   if (!ctx || n < 0 || (n > 0 && (!slot || !round))) return FPX_EINVAL;
   for (int i = 0; i < n; ++i) {
-    if (slot[i] < 0 || slot[i] >= ctx->g.S || round[i] < 0) {
+    if (slot[i] < 0 || slot[i] >= ctx->g.S || round[i] < 0 || round[i] > MAX_ROUND) {
       ctx->err_index = i;
       ctx->err_slot = slot[i];
       ctx->err_round = round[i];
@@ -473,6 +475,8 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
   if ((rc = dalloc(ctx, &st.log_value, (size_t)g.S))) return fail(rc);
   if ((rc = dalloc(ctx, &st.log_present, (size_t)g.S))) return fail(rc);
   if ((rc = dalloc(ctx, &st.log_scalars, (size_t)8))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.rt_key, (size_t)RANGE_TALLIES * 4))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.rt_bits, (size_t)RANGE_TALLIES * 4))) return fail(rc);
   if ((rc = init_state(ctx))) return fail(rc);
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(FPX_EHIP);
   *out = ctx;
@@ -783,6 +787,80 @@ int32_t fpx_acceptor_phase1a(fpx_ctx* ctx, int32_t group, int32_t round, int32_t
   return FPX_OK;
 }
 
+// ---- K4: Mencius noop ranges ----------------------------------------------------------------------------
+static int32_t range_args_ok(fpx_ctx* ctx, int32_t start, int32_t end, int32_t round) {
+  if (!ctx) return FPX_EINVAL;
+  if (ctx->g.per_slot) return FPX_EINVAL;
+  if ((int64_t)ctx->g.num_groups * ctx->g.total > 256) return FPX_EINVAL;
+  if (start < 0 || end < start || end > ctx->g.S || round < 0 || round > MAX_ROUND) return FPX_EINVAL;
+  return FPX_OK;
+}
+
+int32_t fpx_acceptor_phase2a_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end, int32_t round,
+                                        const uint64_t* target_masks, uint64_t* vote_bits, uint64_t* nack_bits,
+                                        int32_t* nack_round) {
+  int rc = range_args_ok(ctx, slot_start, slot_end, round);
+  if (rc) return rc;
+  const int A = ctx->g.num_groups;
+  const size_t words = (size_t)A * 4;
+  if ((rc = grow(ctx, &ctx->d_scratch, (3 * words + 1) * 8))) return rc;
+  uint64_t* d_out = (uint64_t*)ctx->d_scratch.p;  // [A][4] votes, [A][4] nacks, nack_round
+  uint64_t* d_tgt = target_masks ? d_out + 2 * words + 1 : nullptr;
+  HIPCHK(ctx, hipMemsetAsync(d_out, 0, 2 * words * 8, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(d_out + 2 * words, 0xFF, 8, ctx->stream));
+  if (target_masks) HIPCHK(ctx, hipMemcpyAsync(d_tgt, target_masks, words * 8, hipMemcpyHostToDevice, ctx->stream));
+  const int nacc = A * ctx->g.R;
+  hipLaunchKernelGGL(k_noop_scalar, dim3((nacc + 255) / 256), dim3(256), 0, ctx->stream, ctx->g, ctx->st, slot_start,
+                     slot_end, round, d_tgt, d_out);
+  const long long rows = ((long long)slot_end - slot_start + ctx->g.num_leader_groups - 1) / ctx->g.num_leader_groups;
+  if (rows > 0) {
+    const long long cells = rows * ctx->g.R;
+    const int grid = (int)std::max<long long>(1, std::min<long long>((cells + 255) / 256, ctx->num_cus * 16));
+    hipLaunchKernelGGL(k_noop_fill, dim3(grid), dim3(256), 0, ctx->stream, ctx->g, ctx->st, slot_start, slot_end, round,
+                       d_out);
+  }
+  if ((rc = launch_check(ctx))) return rc;
+  std::vector<uint64_t> h(2 * words + 1);
+  HIPCHK(ctx, hipMemcpyAsync(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (vote_bits) memcpy(vote_bits, h.data(), words * 8);
+  if (nack_bits) memcpy(nack_bits, h.data() + words, words * 8);
+  if (nack_round) memcpy(nack_round, h.data() + 2 * words, 4);
+  return FPX_OK;
+}
+
+int32_t fpx_proxy_open_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end, int32_t round, uint8_t* is_new) {
+  int rc = range_args_ok(ctx, slot_start, slot_end, round);
+  if (rc) return rc;
+  if ((rc = grow(ctx, &ctx->d_u8, 16))) return rc;
+  hipLaunchKernelGGL(k_range_open, dim3(1), dim3(64), 0, ctx->stream, ctx->g, ctx->st, slot_start, slot_end, round,
+                     (uint8_t*)ctx->d_u8.p);
+  if ((rc = launch_check(ctx))) return rc;
+  uint8_t h = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&h, ctx->d_u8.p, 1, hipMemcpyDeviceToHost, ctx->stream));
+  rc = fetch_status(ctx);
+  if (is_new) *is_new = h;
+  return rc;
+}
+
+int32_t fpx_proxy_phase2b_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end, int32_t round,
+                                     const uint64_t* vote_bits, uint8_t* newly_chosen) {
+  int rc = range_args_ok(ctx, slot_start, slot_end, round);
+  if (rc) return rc;
+  if (!vote_bits) return FPX_EINVAL;
+  const size_t words = (size_t)ctx->g.num_groups * 4;
+  if ((rc = grow(ctx, &ctx->d_u8, 16))) return rc;
+  if ((rc = h2d(ctx, &ctx->d_bits_a, vote_bits, words))) return rc;
+  hipLaunchKernelGGL(k_range_tally, dim3(1), dim3(64), 0, ctx->stream, ctx->g, ctx->st, slot_start, slot_end, round,
+                     ctx->cfg.f + 1, (const uint64_t*)ctx->d_bits_a.p, (uint8_t*)ctx->d_u8.p);
+  if ((rc = launch_check(ctx))) return rc;
+  uint8_t h = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&h, ctx->d_u8.p, 1, hipMemcpyDeviceToHost, ctx->stream));
+  rc = fetch_status(ctx);
+  if (newly_chosen) *newly_chosen = h;
+  return rc;
+}
+
 // ---- f1: replica log ------------------------------------------------------------------------------------
 int32_t fpx_replica_chosen_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_value_id,
                                const uint8_t* d_mask) {
@@ -957,7 +1035,7 @@ int32_t fpx_read_tally(fpx_ctx* ctx, int32_t slot, int32_t* num_entries, int32_t
   HIPCHK(ctx, hipMemcpy(bits, ctx->st.pl_bits + (size_t)slot * wp * 4, (size_t)wp * 32, hipMemcpyDeviceToHost));
   int cnt = 0;
   for (int w = 0; w < ctx->g.ways; ++w) {
-    if (keys[w] == 0) continue;
+    if (keys[w] == 0 || (keys[w] & KEY_RANGE)) continue;  // range tallies are not per-slot tallies
     const bool done = keys[w] & KEY_DONE;
     if (rounds) rounds[cnt] = (int32_t)((keys[w] & KEY_ROUND_MASK) - 1u);
     if (states) states[cnt] = done ? 1 : 0;

@@ -40,7 +40,12 @@ namespace fpx {
 typedef int int4v __attribute__((ext_vector_type(4)));
 typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 
-enum : uint32_t { KEY_DONE = 0x80000000u, KEY_ROUND_MASK = 0x7fffffffu };
+// tally key word: 0 = empty, else (round + 1) | flags.  KEY_RANGE marks the per-slot shadow of a
+// Mencius noop range of length one (mencius SlotRound(slot, slot + 1, round) collides with the
+// single-slot key, mencius/ProxyLeader.scala:86-90).
+enum : uint32_t { KEY_DONE = 0x80000000u, KEY_RANGE = 0x40000000u, KEY_ROUND_MASK = 0x3fffffffu };
+constexpr int MAX_ROUND = 0x3ffffffe;
+constexpr int RANGE_TALLIES = 1024;  // live Mencius noop-range tallies per context
 
 // status word layout in HBM (int32[8])
 enum { ST_CODE = 0, ST_INDEX = 1, ST_SLOT = 2, ST_ROUND = 3 };
@@ -72,6 +77,8 @@ struct State {
   int32_t* log_value;   // [S]  the replica's log (BufferMap), -1 where absent
   uint8_t* log_present; // [S]
   int32_t* log_scalars; // [8]  LG_*: executedWatermark, numChosen, largestKey, scan result
+  int32_t* rt_key;      // [RANGE_TALLIES][4]  start, end, round, state (0 empty, 1 Pending, 2 Done)
+  uint64_t* rt_bits;    // [RANGE_TALLIES][4]  Phase2bNoopRange votes, bit = acceptorGroup * R + acceptor
 };
 
 struct Batch {
@@ -262,7 +269,7 @@ __global__ void __launch_bounds__(256) k_validate(const Geom g, const State st, 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b.n) return;
   const int s = b.slot[i], r = b.round ? b.round[i] : 0;
-  if (s < 0 || s >= g.S || r < 0) {
+  if (s < 0 || s >= g.S || r < 0 || r > MAX_ROUND) {
     report(st, 1 /*FPX_EINVAL*/, i, s, r);
     return;
   }
@@ -655,7 +662,8 @@ __global__ void __launch_bounds__(256) k_tally(const Geom g, const State st, con
     }
     if (way < 0) {
       report(st, 2 /*FPX_EFATAL_UNKNOWN_SLOTROUND*/, i, s, rnd);  // :220-225
-    } else if (!(key & KEY_DONE)) {                                 // Done -> ignored, :227-232
+    } else if (!(key & (KEY_DONE | KEY_RANGE))) {  // Done -> ignored, :227-232; a pending noop range
+                                                   // under the same key -> ignored, mencius :327-333
       const size_t e = (size_t)s * g.wp + way;
       uint64_t x[4];
 #pragma unroll
@@ -751,6 +759,138 @@ __global__ void __launch_bounds__(256) k_gather_acceptor(const Geom g, const Sta
   vr[s] = mine ? st.vote_round[c] : -1;
   vv[s] = mine ? st.vote_value[c] : -1;
   bl[s] = (mine && st.ballot) ? st.ballot[c] : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: Mencius noop ranges.
+//   k_noop_scalar  mencius/Acceptor.scala:245-260: per acceptor of the leader group: Nack or round := round
+//   k_noop_fill    mencius/Acceptor.scala:262-277: every slot of [start, end) owned by the leader group
+//                  (slot = start + k * L) gets (round, Noop) from the voting acceptors of its acceptor group
+//   k_range_open   mencius/ProxyLeader.scala:255-303 bookkeeping
+//   k_range_tally  mencius/ProxyLeader.scala:355-411
+// out layout: [A][4] vote bits, [A][4] nack bits, then one int32 nack_round
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_noop_scalar(const Geom g, const State st, int start, int end, int round, const uint64_t* target, uint64_t* out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int A = g.num_groups, L = g.num_leader_groups;
+  if (e >= A * g.R) return;
+  const int ag = e / g.R, r = e % g.R, bit = g.base + r;
+  if (target && !((target[(size_t)ag * 4 + (bit >> 6)] >> (bit & 63)) & 1ull)) return;
+  const int lg = start % L;  // slotSystem.leader(slotStartInclusive)
+  const size_t acc = (size_t)(lg * A + ag) * g.R + r;
+  const int pr = st.promised[acc];
+  if (round < pr) {  // :245-256 Nack(round = my round)
+    atomicOr((unsigned long long*)&out[(size_t)(A + ag) * 4 + (bit >> 6)], 1ull << (bit & 63));
+    atomicMax(reinterpret_cast<int*>(out + (size_t)2 * A * 4), pr);
+    return;
+  }
+  st.promised[acc] = round;  // :260
+  atomicOr((unsigned long long*)&out[(size_t)ag * 4 + (bit >> 6)], 1ull << (bit & 63));
+  // the largest slot of the range owned by my acceptor group (for maxVotedSlot)
+  const int rows = (end - start + L - 1) / L;
+  for (int j = rows - 1; j >= 0 && j >= rows - A; --j) {
+    const int s = start + j * L;
+    if ((s / L) % A == ag) {
+      if (s > st.max_voted[acc]) st.max_voted[acc] = s;
+      break;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    k_noop_fill(const Geom g, const State st, int start, int end, int round, const uint64_t* votes) {
+  const int A = g.num_groups, L = g.num_leader_groups;
+  const long long rows = ((long long)end - start + L - 1) / L;
+  const long long total = rows * g.R;
+  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total;
+       c += (long long)gridDim.x * blockDim.x) {
+    const int s = start + (int)(c / g.R) * L;
+    const int r = (int)(c % g.R);
+    const int ag = (s / L) % A, bit = g.base + r;
+    if ((votes[(size_t)ag * 4 + (bit >> 6)] >> (bit & 63)) & 1ull) {
+      const size_t cell = (size_t)s * g.R + r;
+      st.vote_round[cell] = round;  // :271-276 State(voteRound = round, voteValue = Noop)
+      st.vote_value[cell] = -1;
+    }
+  }
+}
+
+__global__ void k_range_open(const Geom g, const State st, int start, int end, int round, uint8_t* is_new) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  *is_new = 0;
+  int free_e = -1;
+  for (int i = 0; i < RANGE_TALLIES; ++i) {
+    const int32_t* k = st.rt_key + (size_t)i * 4;
+    if (k[3] == 0) {
+      if (free_e < 0) free_e = i;
+    } else if (k[0] == start && k[1] == end && k[2] == round) {
+      return;  // :259-266 already known: ignored
+    }
+  }
+  int way = -1;
+  if (end == start + 1) {  // the key collides with the single-slot key (slot, slot + 1, round)
+    const uint32_t* kr = st.pl_key + (size_t)start * g.wp;
+    for (int w = g.ways - 1; w >= 0; --w) {
+      if ((kr[w] & KEY_ROUND_MASK) == (uint32_t)round + 1u) return;
+      if (kr[w] == 0) way = w;
+    }
+    if (way < 0) {
+      report(st, 5, 0, start, round);
+      return;
+    }
+  }
+  if (free_e < 0) {
+    report(st, 5, 0, start, round);
+    return;
+  }
+  int32_t* k = st.rt_key + (size_t)free_e * 4;
+  k[0] = start, k[1] = end, k[2] = round, k[3] = 1;
+  for (int w = 0; w < 4; ++w) st.rt_bits[(size_t)free_e * 4 + w] = 0ull;
+  if (way >= 0) st.pl_key[(size_t)start * g.wp + way] = ((uint32_t)round + 1u) | KEY_RANGE;
+  *is_new = 1;
+}
+
+// votes: [A][4] (bit = acceptor index within the group); quorum = f + 1 from EVERY acceptor group
+__global__ void k_range_tally(const Geom g, const State st, int start, int end, int round, int quorum,
+                              const uint64_t* votes, uint8_t* chosen) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  *chosen = 0;
+  int e = -1;
+  for (int i = 0; i < RANGE_TALLIES && e < 0; ++i) {
+    const int32_t* k = st.rt_key + (size_t)i * 4;
+    if (k[3] != 0 && k[0] == start && k[1] == end && k[2] == round) e = i;
+  }
+  if (e < 0) {
+    // a single-slot tally under the same key swallows the message (:378-385); otherwise fatal (:361-368)
+    if (end == start + 1) {
+      const uint32_t* kr = st.pl_key + (size_t)start * g.wp;
+      for (int w = 0; w < g.ways; ++w)
+        if ((kr[w] & KEY_ROUND_MASK) == (uint32_t)round + 1u) return;
+    }
+    report(st, 2, 0, start, round);
+    return;
+  }
+  int32_t* k = st.rt_key + (size_t)e * 4;
+  if (k[3] == 2) return;  // Done: ignored (:370-376)
+  uint64_t x[4];
+  for (int w = 0; w < 4; ++w) x[w] = st.rt_bits[(size_t)e * 4 + w];
+  const int A = g.num_groups, T = g.total;
+  bool all = true;
+  for (int ag = 0; ag < A; ++ag) {
+    int c = 0;
+    for (int r = 0; r < T; ++r) {
+      const int bit = ag * T + r;
+      if ((votes[(size_t)ag * 4 + (r >> 6)] >> (r & 63)) & 1ull) x[bit >> 6] |= 1ull << (bit & 63);  // :389-390
+      c += (int)((x[bit >> 6] >> (bit & 63)) & 1ull);
+    }
+    all = all && c >= quorum;  // :391
+  }
+  for (int w = 0; w < 4; ++w) st.rt_bits[(size_t)e * 4 + w] = x[w];
+  if (all) {
+    k[3] = 2;  // :410 ; ChosenNoopRange(start, end) :395-407
+    *chosen = 1;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

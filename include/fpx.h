@@ -226,6 +226,31 @@ int32_t fpx_phase2_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, con
                              uint8_t* d_chosen, int32_t* d_chosen_round, int32_t* d_chosen_value,
                              int32_t* d_nack_round);
 
+/* ---- a2/a4 (K4): Mencius noop ranges -----------------------------------------------------------------
+ * Needs FPX_BALLOT_ACCEPTOR and num_groups * replicas_total <= 256.  Rounds must be < 2^30 - 1
+ * everywhere (one key bit marks the per-slot shadow of a length-1 range).
+ *
+ * mencius.Acceptor.handlePhase2aNoopRange (mencius/Acceptor.scala:237-291) delivered to the acceptors
+ * of EVERY acceptor group of the leader group that owns slot_start (the proxy leader relays a range to
+ * each group, mencius/ProxyLeader.scala:276-291), selected by target_masks (num_groups x 4 words,
+ * NULL = all).  An acceptor with round > `round` Nacks; otherwise round := `round` and every slot of
+ * [slot_start, slot_end) owned by its acceptor group (slot = slot_start + k * num_leader_groups with
+ * (slot / num_leader_groups) % num_groups == its group) votes (round, Noop).  Outputs (may be NULL):
+ * vote_bits / nack_bits num_groups x 4 words, nack_round = largest round carried by a Nack or -1. */
+int32_t fpx_acceptor_phase2a_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end,
+                                        int32_t round, const uint64_t* target_masks,
+                                        uint64_t* vote_bits, uint64_t* nack_bits, int32_t* nack_round);
+/* mencius.ProxyLeader.handlePhase2aNoopRange bookkeeping (mencius/ProxyLeader.scala:255-303): opens
+ * PendingPhase2aNoopRange for (slot_start, slot_end, round); a known key is ignored (is_new = 0). */
+int32_t fpx_proxy_open_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end, int32_t round,
+                                  uint8_t* is_new);
+/* mencius.ProxyLeader.handlePhase2bNoopRange (mencius/ProxyLeader.scala:355-411): vote_bits is
+ * num_groups x 4 words (bit = acceptor index in its group).  Unknown key -> FPX_EFATAL_UNKNOWN_SLOTROUND;
+ * Done or a single-slot tally under the same key -> ignored; ChosenNoopRange (newly_chosen = 1) once
+ * every acceptor group has f+1 votes. */
+int32_t fpx_proxy_phase2b_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end, int32_t round,
+                                     const uint64_t* vote_bits, uint8_t* newly_chosen);
+
 /* ---- next rows of SURVEY.md section 8(f) ----------------------------------------------------------
  *
  * f1  Replica.handleChosen + executeLog (multipaxos/Replica.scala:572-590, 394-447;

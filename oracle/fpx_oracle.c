@@ -343,7 +343,9 @@ int fpo_log_largest_key(const fpo_log* l) { return l->largest_key; }
 
 /* ProxyLeader.states: Map[SlotRound, State]  ProxyLeader.scala:87-99,135 */
 typedef struct {
-  uint64_t key;  /* slot << 32 | round ; valid iff state != 0 */
+  uint64_t key;  /* slot(Start) << 32 | round ; valid iff state != 0 */
+  int end;       /* slotEndExclusive: slot + 1 for a single-slot tally (mencius SlotRound, ProxyLeader.scala:86-90) */
+  int is_range;  /* PendingPhase2aNoopRange (mencius/ProxyLeader.scala:99-104) */
   int state;     /* 0 empty, 1 Pending, 2 Done */
   int value;     /* pending.phase2a.commandBatchOrNoop */
   uint64_t v[4]; /* phase2bs.keys as a set of acceptor bits */
@@ -529,6 +531,8 @@ static int popcount256(const uint64_t v[4]) {
          __builtin_popcountll(v[3]);
 }
 
+static void set_bit(uint64_t* v, int j) { v[j >> 6] |= 1ull << (j & 63); }
+
 static int test_bit(const uint64_t v[4], int j) { return (int)((v[j >> 6] >> (j & 63)) & 1u); }
 
 static int has_foreign(const fpo_config* c, const uint64_t v[4]) {
@@ -606,13 +610,15 @@ static size_t thash(uint64_t k) {
   return (size_t)k;
 }
 
-static tally_t* tab_find(fpo_sys* s, uint64_t key) {
+static tally_t* tab_find2(fpo_sys* s, uint64_t key, int end) {
   size_t mask = s->tab_cap - 1;
   for (size_t i = thash(key) & mask;; i = (i + 1) & mask) {
     if (s->tab[i].state == 0) return NULL;
-    if (s->tab[i].key == key) return &s->tab[i];
+    if (s->tab[i].key == key && s->tab[i].end == end) return &s->tab[i];
   }
 }
+
+static tally_t* tab_find(fpo_sys* s, uint64_t key) { return tab_find2(s, key, (int)(key >> 32) + 1); }
 
 static void tab_grow(fpo_sys* s) {
   tally_t* old = s->tab;
@@ -636,6 +642,7 @@ static tally_t* tab_insert(fpo_sys* s, uint64_t key) {
   while (s->tab[i].state != 0) i = (i + 1) & mask;
   memset(&s->tab[i], 0, sizeof(tally_t));
   s->tab[i].key = key;
+  s->tab[i].end = (int)(key >> 32) + 1;
   s->tab[i].seq = s->seq++;
   s->tab_n++;
   return &s->tab[i];
@@ -657,6 +664,8 @@ int fpo_proxy_handle_phase2b(fpo_sys* s, int acceptor_bit, int slot, int round, 
   if (!t) return -1;
   /* :227-232  case Some(Done) => ignored */
   if (t->state == 2) return 2;
+  /* mencius/ProxyLeader.scala:327-333  case Some(_: PendingPhase2aNoopRange) => ignored */
+  if (t->is_range) return 2;
   /* :235-237  phase2bs((groupIndex, acceptorIndex)) = phase2b   (map key => duplicates collapse) */
   t->v[acceptor_bit >> 6] |= 1ull << (acceptor_bit & 63);
   /* :238-243  non-flexible: size < f+1 -> return ; flexible: !grid.isWriteQuorum(keys) -> return */
@@ -666,6 +675,126 @@ int fpo_proxy_handle_phase2b(fpo_sys* s, int acceptor_bit, int slot, int round, 
   /* :256  states(slotround) = Done */
   t->state = 2;
   return 1;
+}
+
+/* ---- Mencius noop ranges (K4) --------------------------------------------------------------------- */
+
+/* mencius/Acceptor.scala:237-291 handlePhase2aNoopRange for acceptor `replica` of group `group`
+ * (= leaderGroup * num_groups + acceptorGroup).  Returns 1 = Phase2bNoopRange, 0 = Nack(*reply_round). */
+int fpo_acceptor_handle_phase2a_noop_range(fpo_sys* s, int group, int replica, int slot_start, int slot_end,
+                                           int round, int* reply_round) {
+  const int R = s->cfg.num_replicas, L = s->cfg.num_leader_groups, A = s->cfg.num_groups;
+  int* my_round = &s->promised[(size_t)group * R + replica];
+  /* :245-256 */
+  if (round < *my_round) {
+    *reply_round = *my_round;
+    return 0;
+  }
+  /* :260 */
+  *my_round = round;
+  /* :262-267  find the first slot owned by this acceptor group */
+  const int my_ag = group % A;
+  int start = slot_start;
+  while (start < slot_end && (start / L) % A != my_ag) start += L;
+  /* :269-277  for (slot <- startSlot until slotEndExclusive by numLeaderGroups * numAcceptorGroups) */
+  for (int slot = start; slot < slot_end; slot += L * A) {
+    size_t cell = (size_t)slot * R + replica;
+    s->vote_round[cell] = round;
+    s->vote_value[cell] = -1; /* Noop */
+    int* mvs = &s->max_voted_slot[(size_t)group * R + replica];
+    if (slot > *mvs) *mvs = slot;
+  }
+  *reply_round = round;
+  return 1;
+}
+
+/* mencius/ProxyLeader.scala:255-303: 1 = new PendingPhase2aNoopRange, 0 = ignored (key already known) */
+int fpo_proxy_handle_phase2a_noop_range(fpo_sys* s, int slot_start, int slot_end, int round) {
+  if (tab_find2(s, tkey(slot_start, round), slot_end)) return 0;
+  tally_t* t = tab_insert(s, tkey(slot_start, round));
+  t->end = slot_end;
+  t->is_range = 1;
+  t->state = 1;
+  t->value = -1;
+  return 1;
+}
+
+/* mencius/ProxyLeader.scala:355-411: vote of acceptor (acceptor_group, acceptor_index).
+ * 1 = ChosenNoopRange emitted, 0 = waiting, 2 = ignored (Done or a single-slot Phase2a is pending
+ * under the same key), -1 = logger.fatal */
+int fpo_proxy_handle_phase2b_noop_range(fpo_sys* s, int acceptor_group, int acceptor_index, int slot_start,
+                                        int slot_end, int round) {
+  const int R = s->cfg.replicas_total, A = s->cfg.num_groups;
+  tally_t* t = tab_find2(s, tkey(slot_start, round), slot_end);
+  if (!t) return -1;                 /* :361-368 */
+  if (t->state == 2) return 2;       /* :370-376 */
+  if (!t->is_range) return 2;        /* :378-385 PendingPhase2a => ignored */
+  /* :389-390  phase2bs(acceptorGroupIndex)(acceptorIndex) = phase2b */
+  int bit = acceptor_group * R + acceptor_index;
+  t->v[bit >> 6] |= 1ull << (bit & 63);
+  /* :391  if (phase2bs.exists(_.size < config.quorumSize)) return */
+  for (int ag = 0; ag < A; ++ag) {
+    int c = 0;
+    for (int r = 0; r < R; ++r) c += test_bit(t->v, ag * R + r);
+    if (c < s->cfg.f + 1) return 0;
+  }
+  t->state = 2; /* :410 ; ChosenNoopRange(start, end) :395-407 */
+  return 1;
+}
+
+/* batch-of-one entry points with the semantics of fpx_acceptor_phase2a_noop_range & co (fpx.h) */
+int fpo_acceptor_phase2a_noop_range(fpo_sys* s, int32_t slot_start, int32_t slot_end, int32_t round,
+                                    const uint64_t* target_masks, uint64_t* vote_bits, uint64_t* nack_bits,
+                                    int32_t* nack_round) {
+  const int R = s->cfg.num_replicas, A = s->cfg.num_groups, L = s->cfg.num_leader_groups;
+  if (s->cfg.ballot_mode != 0 || slot_start < 0 || slot_end < slot_start || slot_end > s->cfg.num_slots || round < 0)
+    return FPO_EINVAL;
+  const int lg = slot_start % L; /* slotSystem.leader(slotStartInclusive), ProxyLeader.scala:275 */
+  int nr = -1;
+  for (int ag = 0; ag < A; ++ag) {
+    uint64_t vb[4] = {0, 0, 0, 0}, nb[4] = {0, 0, 0, 0};
+    for (int r = 0; r < R; ++r) {
+      int bit = s->cfg.replica_base + r;
+      if (target_masks && !test_bit(target_masks + (size_t)ag * 4, bit)) continue;
+      int reply;
+      if (fpo_acceptor_handle_phase2a_noop_range(s, lg * A + ag, r, slot_start, slot_end, round, &reply)) {
+        set_bit(vb, bit);
+      } else {
+        set_bit(nb, bit);
+        if (reply > nr) nr = reply;
+      }
+    }
+    if (vote_bits) memcpy(vote_bits + (size_t)ag * 4, vb, sizeof vb);
+    if (nack_bits) memcpy(nack_bits + (size_t)ag * 4, nb, sizeof nb);
+  }
+  if (nack_round) *nack_round = nr;
+  return FPO_OK;
+}
+
+int fpo_proxy_open_noop_range(fpo_sys* s, int32_t slot_start, int32_t slot_end, int32_t round, uint8_t* is_new) {
+  if (slot_start < 0 || slot_end < slot_start || slot_end > s->cfg.num_slots || round < 0) return FPO_EINVAL;
+  int fresh = fpo_proxy_handle_phase2a_noop_range(s, slot_start, slot_end, round);
+  if (is_new) *is_new = (uint8_t)fresh;
+  return FPO_OK;
+}
+
+int fpo_proxy_phase2b_noop_range(fpo_sys* s, int32_t slot_start, int32_t slot_end, int32_t round,
+                                 const uint64_t* vote_bits, uint8_t* newly_chosen) {
+  const int R = s->cfg.replicas_total, A = s->cfg.num_groups;
+  int chosen = 0, status = FPO_OK;
+  for (int ag = 0; ag < A && status == FPO_OK; ++ag)
+    for (int r = 0; r < R; ++r) {
+      if (!test_bit(vote_bits + (size_t)ag * 4, r)) continue;
+      int rc = fpo_proxy_handle_phase2b_noop_range(s, ag, r, slot_start, slot_end, round);
+      if (rc == -1) {
+        status = FPO_EFATAL_UNKNOWN_SLOTROUND;
+        s->err_index = 0, s->err_slot = slot_start, s->err_round = round;
+        break;
+      }
+      if (rc == 1) chosen = 1;
+    }
+  if (newly_chosen) *newly_chosen = (uint8_t)chosen;
+  return status;
 }
 
 /* ---- batch entry points (same semantics as fpx.h host entry points) --------------------------- */
@@ -683,7 +812,6 @@ static int check_msg(fpo_sys* s, int i, int slot, int round) {
   return 1;
 }
 
-static void set_bit(uint64_t* v, int j) { v[j >> 6] |= 1ull << (j & 63); }
 
 int fpo_acceptor_phase2a(fpo_sys* s, int32_t n, const int32_t* slot, const int32_t* round,
                          const int32_t* value_id, const uint64_t* target_mask, uint64_t* vote_bits,
@@ -990,7 +1118,7 @@ int fpo_read_tally(fpo_sys* s, int32_t slot, int32_t* num_entries, int32_t* roun
   int order[64];
   size_t where[64];
   for (size_t i = 0; i < s->tab_cap && cnt < 64; ++i) {
-    if (s->tab[i].state == 0 || (int)(s->tab[i].key >> 32) != slot) continue;
+    if (s->tab[i].state == 0 || (int)(s->tab[i].key >> 32) != slot || s->tab[i].is_range) continue;
     order[cnt] = s->tab[i].seq;
     where[cnt] = i;
     ++cnt;

@@ -123,6 +123,19 @@ int fpo_phase2_fifo_pump(fpo_sys* sys, int32_t n, const int32_t* slot, const int
                          const int32_t* value_id, const uint64_t* target_mask, uint8_t* chosen,
                          int32_t* chosen_round, int32_t* chosen_value, int32_t* nack_round);
 
+/* K4: Mencius noop ranges (mencius/Acceptor.scala:237-291, mencius/ProxyLeader.scala:255-303, 355-411) */
+int fpo_acceptor_handle_phase2a_noop_range(fpo_sys* sys, int group, int replica, int slot_start, int slot_end,
+                                           int round, int* reply_round);
+int fpo_proxy_handle_phase2a_noop_range(fpo_sys* sys, int slot_start, int slot_end, int round);
+int fpo_proxy_handle_phase2b_noop_range(fpo_sys* sys, int acceptor_group, int acceptor_index, int slot_start,
+                                        int slot_end, int round);
+int fpo_acceptor_phase2a_noop_range(fpo_sys* sys, int32_t slot_start, int32_t slot_end, int32_t round,
+                                    const uint64_t* target_masks, uint64_t* vote_bits, uint64_t* nack_bits,
+                                    int32_t* nack_round);
+int fpo_proxy_open_noop_range(fpo_sys* sys, int32_t slot_start, int32_t slot_end, int32_t round, uint8_t* is_new);
+int fpo_proxy_phase2b_noop_range(fpo_sys* sys, int32_t slot_start, int32_t slot_end, int32_t round,
+                                 const uint64_t* vote_bits, uint8_t* newly_chosen);
+
 /* f1: Replica.handleChosen per message (multipaxos/Replica.scala:572-590) on the system's replica log */
 int fpo_replica_chosen(fpo_sys* sys, int32_t n, const int32_t* slot, const int32_t* value_id,
                        const uint8_t* mask, int32_t* executed_watermark, int32_t* num_chosen);

@@ -113,6 +113,10 @@ def lib():
     for name in ("fpo_phase2_fused", "fpo_phase2_fifo_pump"):
         getattr(L, name).argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, U64P, U8P, I32P, I32P,
                                      I32P]
+    L.fpo_acceptor_phase2a_noop_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, U64P, U64P,
+                                                  U64P, I32P]
+    L.fpo_proxy_open_noop_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, U8P]
+    L.fpo_proxy_phase2b_noop_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, U64P, U8P]
     L.fpo_replica_chosen.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, U8P, I32P, I32P]
     L.fpo_replica_read_log.argtypes = [C.c_void_p, C.c_int32, C.c_int32, I32P, U8P]
     L.fpo_leader_phase1b_scan.argtypes = [C.c_void_p, C.c_int32, U64P, C.c_int32, I32P, I32P, I32P]
@@ -350,6 +354,29 @@ class System:
 
     def phase2_fifo_pump(self, slot, round_, value, target_mask=None):
         return self._fused(lib().fpo_phase2_fifo_pump, slot, round_, value, target_mask)
+
+    def acceptor_phase2a_noop_range(self, slot_start, slot_end, round_, target_masks=None):
+        A = self.cfg.num_groups
+        target_masks = _u64(target_masks)
+        vb = np.zeros((A, 4), np.uint64)
+        nb = np.zeros((A, 4), np.uint64)
+        nr = C.c_int32(-1)
+        st = lib().fpo_acceptor_phase2a_noop_range(self._h, slot_start, slot_end, round_,
+                                                   _p(target_masks, U64P), _p(vb, U64P), _p(nb, U64P),
+                                                   C.byref(nr))
+        return st, vb, nb, nr.value
+
+    def proxy_open_noop_range(self, slot_start, slot_end, round_):
+        new = C.c_uint8(0)
+        st = lib().fpo_proxy_open_noop_range(self._h, slot_start, slot_end, round_, C.byref(new))
+        return st, new.value
+
+    def proxy_phase2b_noop_range(self, slot_start, slot_end, round_, vote_bits):
+        vote_bits = _u64(vote_bits)
+        ch = C.c_uint8(0)
+        st = lib().fpo_proxy_phase2b_noop_range(self._h, slot_start, slot_end, round_,
+                                                _p(vote_bits, U64P), C.byref(ch))
+        return st, ch.value
 
     def replica_chosen(self, slot, value, mask=None):
         slot, value = _i32(slot), _i32(value)
