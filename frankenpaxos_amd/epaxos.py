@@ -1,0 +1,90 @@
+"""EPaxos pre-accept fast path (K5) on the GPU: python handle on an fpx_epx context.
+
+Every result is computed by the HIP kernels of csrc/fpx_epaxos.hip; there is no CPU path here."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FpxError
+
+
+class FpxEpxConfig(C.Structure):
+    _fields_ = [("num_replicas", C.c_int32), ("num_keys", C.c_int32), ("device", C.c_int32),
+                ("flags", C.c_uint32)]
+
+
+def _bind(L):
+    if getattr(L, "_epx_bound", False):
+        return
+    VP = C.c_void_p
+    L.fpx_epx_create.argtypes = [C.POINTER(FpxEpxConfig), C.POINTER(VP)]
+    L.fpx_epx_destroy.argtypes = [VP]
+    L.fpx_epx_set_stream.argtypes = [VP, VP]
+    L.fpx_epx_sync.argtypes = [VP]
+    L.fpx_epx_preaccept.argtypes = [VP, C.c_int32] + [VP] * 9
+    L.fpx_epx_preaccept_dev.argtypes = [VP, C.c_int32] + [VP] * 9
+    L.fpx_epx_read_index.argtypes = [VP, C.c_int32, C.c_int32, VP, VP]
+    L._epx_bound = True
+
+
+class EPaxos:
+    def __init__(self, num_replicas, num_keys, device=0):
+        self.L = _lib.lib()
+        _bind(self.L)
+        self.n, self.num_keys = num_replicas, num_keys
+        cfg = FpxEpxConfig(num_replicas, num_keys, device, 0)
+        h = C.c_void_p()
+        st = self.L.fpx_epx_create(C.byref(cfg), C.byref(h))
+        if st:
+            raise FpxError(st, "fpx_epx_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.fpx_epx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, s):
+        st = self.L.fpx_epx_set_stream(self._h, s)
+        if st:
+            raise FpxError(st, "fpx_epx_set_stream")
+
+    def sync(self):
+        return self.L.fpx_epx_sync(self._h)
+
+    def preaccept(self, leader, number, key, is_set, resp_mask, rank):
+        a32 = lambda x: np.ascontiguousarray(x, dtype=np.int32)
+        a8 = lambda x: np.ascontiguousarray(x, dtype=np.uint8)
+        leader, number, key, rank = a32(leader), a32(number), a32(key), a32(rank)
+        is_set, resp_mask = a8(is_set), a8(resp_mask)
+        m = len(leader)
+        fast = np.zeros(m, np.uint8)
+        deps = np.zeros((m, self.n), np.int32)
+        ldeps = np.zeros((m, self.n), np.int32)
+        p = lambda a: a.ctypes.data
+        st = self.L.fpx_epx_preaccept(self._h, m, p(leader), p(number), p(key), p(is_set), p(resp_mask),
+                                      p(rank), p(fast), p(deps), p(ldeps))
+        return st, fast, deps, ldeps
+
+    def preaccept_dev(self, leader, number, key, is_set, resp_mask, rank, fast=None, deps=None,
+                      leader_deps=None):
+        d = lambda t: None if t is None else t.data_ptr()
+        st = self.L.fpx_epx_preaccept_dev(self._h, leader.numel(), d(leader), d(number), d(key), d(is_set),
+                                          d(resp_mask), d(rank), d(fast), d(deps), d(leader_deps))
+        if st:
+            raise FpxError(st, "fpx_epx_preaccept_dev")
+
+    def read_index(self, replica, key):
+        g = np.zeros(self.n, np.int32)
+        s = np.zeros(self.n, np.int32)
+        st = self.L.fpx_epx_read_index(self._h, replica, key, g.ctypes.data, s.ctypes.data)
+        if st:
+            raise FpxError(st, "fpx_epx_read_index")
+        return g, s

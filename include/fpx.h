@@ -251,6 +251,46 @@ int32_t fpx_proxy_open_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot
 int32_t fpx_proxy_phase2b_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end, int32_t round,
                                      const uint64_t* vote_bits, uint8_t* newly_chosen);
 
+/* ---- a9 (K5): EPaxos pre-accept fast path -------------------------------------------------------------
+ * One tick of FRESH instances through the pre-accept phase of n = 2f+1 EPaxos replicas with the
+ * key-value store's top-one conflict index (epaxos/Replica.scala:569-600, 633-729, 1159-1419;
+ * statemachine/KeyValueStore.scala:225-302; util/TopOne.scala; Util.scala:19-21).
+ *
+ * Message i: instance (leader[i], number[i]) with a single-key command on key[i] (is_set[i] = 1:
+ * SetRequest, 0: GetRequest); the leader sends PreAccept to the n-2 other replicas in resp_mask[i]
+ * (thrifty fast quorum, Replica.scala:705-706).  rank is n x m: rank[r * m + i] = the position of
+ * message i in replica r's processing order (a permutation of 0..m-1 per replica; only replicas that
+ * take part in message i -- its leader and resp_mask[i] -- matter).  Every participating replica
+ * computes the command's conflicts against ITS conflict index in ITS order (getTopOneConflicts), the
+ * leader's become the PreAccept's dependencies, the others answer PreAcceptOk with the union; the
+ * leader takes the fast path iff the n-2 answers are identical (popularItems(..., n-2)), otherwise
+ * the slow path proposes the union of all answers (preAcceptingSlowPath, :796-813).  After the tick
+ * the commits reach every replica's conflict index (commit -> updateConflictIndex, :815-828).
+ * Outputs (may be NULL): fast[i]; deps[i * n + l] = committed (fast) or Accept-phase (slow)
+ * dependency watermark for leader l; leader_deps likewise for the PreAccept.  Sequence numbers are the
+ * constant 0 the reference uses with top-k dependencies (:575-578). */
+typedef struct fpx_epx fpx_epx;
+typedef struct {
+  int32_t num_replicas; /* n: 3, 5 or 7 */
+  int32_t num_keys;
+  int32_t device;
+  uint32_t flags;
+} fpx_epx_config;
+int32_t fpx_epx_create(const fpx_epx_config* cfg, fpx_epx** out);
+int32_t fpx_epx_destroy(fpx_epx* epx);
+int32_t fpx_epx_set_stream(fpx_epx* epx, void* hip_stream);
+int32_t fpx_epx_preaccept(fpx_epx* epx, int32_t m, const int32_t* leader, const int32_t* number,
+                          const int32_t* key, const uint8_t* is_set, const uint8_t* resp_mask,
+                          const int32_t* rank, uint8_t* fast, int32_t* deps, int32_t* leader_deps);
+/* device-resident inputs / outputs, asynchronous; fpx_epx_sync returns the sticky status */
+int32_t fpx_epx_preaccept_dev(fpx_epx* epx, int32_t m, const int32_t* d_leader, const int32_t* d_number,
+                              const int32_t* d_key, const uint8_t* d_is_set, const uint8_t* d_resp_mask,
+                              const int32_t* d_rank, uint8_t* d_fast, int32_t* d_deps,
+                              int32_t* d_leader_deps);
+int32_t fpx_epx_sync(fpx_epx* epx);
+/* replica's conflict-index entry of one key: gets[n], sets[n] (TopOne vectors) */
+int32_t fpx_epx_read_index(fpx_epx* epx, int32_t replica, int32_t key, int32_t* gets, int32_t* sets);
+
 /* ---- next rows of SURVEY.md section 8(f) ----------------------------------------------------------
  *
  * f1  Replica.handleChosen + executeLog (multipaxos/Replica.scala:572-590, 394-447;

@@ -1,0 +1,151 @@
+"""K5 (BASELINE.json configs[3]): EPaxos pre-accept fast path.
+CPU: pins the oracle's TopOne and popularItems on the reference's known-answer tests
+(shared/src/test/scala/util/TopOneTest.scala, shared/src/test/scala/UtilTest.scala:20-26) and checks a
+hand-computed tick.  GPU: libfpx (fpx_epx_*) == oracle on random ticks."""
+import numpy as np
+import pytest
+
+
+# ------------------------------------------------------------- golden vectors (CPU) ------------
+def test_top_one_golden(oracle):
+    """util/TopOneTest.scala:15-86"""
+    t = oracle.top_one
+    assert t(3) == [0, 0, 0]
+    assert t(3, [(0, 0)]) == [1, 0, 0]
+    assert t(3, [(0, 0), (1, 1), (2, 2)]) == [1, 2, 3]
+    assert t(5, [(0, 0), (0, 1), (0, 2), (1, 1), (1, 10), (2, 2), (4, 3), (4, 1), (4, 7), (4, 1)]) == [3, 11, 3, 0, 8]
+    assert t(3, [], merge_with=t(3)) == [0, 0, 0]
+    assert t(3, [], merge_with=t(3, [(0, 0), (1, 1), (2, 2)])) == [1, 2, 3]
+    assert t(3, [(0, 0), (1, 1), (2, 2)], merge_with=t(3)) == [1, 2, 3]
+    assert t(3, [(0, 0), (1, 1), (2, 2)], merge_with=t(3, [(0, 0), (1, 10)])) == [1, 11, 3]
+
+
+def test_popular_items_golden(oracle):
+    """UtilTest.scala:20-26"""
+    p = oracle.popular_items
+    assert p([], 42) == set()
+    assert p([1, 2, 3, 4], 2) == set()
+    assert p([1, 2, 4, 3, 4], 2) == {4}
+    assert p([4, 1, 2, 1, 3, 4], 2) == {1, 4}
+    assert p([4, 1, 2, 1, 4, 3, 4], 2) == {1, 4}
+    assert p([(0, 1), (0, 1), (1, 0)], 2) == {(0, 1)}
+
+
+# ------------------------------------------------------------------- a tick by hand (CPU) -------
+def test_oracle_tick_by_hand(oracle):
+    """n = 3 (f = 1): fast quorum n-1 = 2, the leader asks ONE other replica (n-2 = 1), so every
+    fresh command takes the fast path and commits the union of its and the other's conflicts."""
+    e = oracle.EPaxos(3, 4)
+    #            leader number key is_set  asks
+    msgs = [(0, 0, 1, 1, 0b010),   # A = set k1 by replica 0, asks replica 1
+            (1, 0, 1, 0, 0b100),   # B = get k1 by replica 1, asks replica 2
+            (2, 0, 1, 1, 0b001),   # C = set k1 by replica 2, asks replica 0
+            (0, 1, 2, 0, 0b100)]   # D = get k2 by replica 0, asks replica 2 (no conflicts at all)
+    leader, number, key, is_set, mask = (np.array(x) for x in zip(*msgs))
+    # processing orders: replica 0: A, C, D ; replica 1: B, A ; replica 2: C, B, D
+    rank = np.array([[0, 3, 1, 2],     # positions of A, B, C, D at replica 0 (B does not reach it)
+                     [1, 0, 2, 3],     # replica 1: B first, then A
+                     [3, 1, 0, 2]])    # replica 2: C, B, D
+    st, fast, deps, ldeps = e.preaccept(leader, number, key, is_set, mask, rank)
+    assert st == 0
+    # A at its leader (replica 0, first): no conflicts -> [0,0,0]; at replica 1 after B (a get by 1,
+    # instance 0): a set conflicts with gets -> [0,1,0]; one answer => fast, deps = [0,1,0]
+    assert ldeps[0].tolist() == [0, 0, 0] and deps[0].tolist() == [0, 1, 0] and fast[0] == 1
+    # B at replica 1 (first): nothing; at replica 2 after C (set by 2, instance 0): get vs set -> [0,0,1]
+    assert ldeps[1].tolist() == [0, 0, 0] and deps[1].tolist() == [0, 0, 1]
+    # C at replica 2 (first): nothing; at replica 0 after A (set by 0): [1,0,0]
+    assert ldeps[2].tolist() == [0, 0, 0] and deps[2].tolist() == [1, 0, 0]
+    assert ldeps[3].tolist() == [0, 0, 0] and deps[3].tolist() == [0, 0, 0]
+    assert fast.tolist() == [1, 1, 1, 1]
+    # after the tick every replica's index knows every instance (commit -> updateConflictIndex)
+    for r in range(3):
+        g, s = e.read_index(r, 1)
+        assert g.tolist() == [0, 1, 0] and s.tolist() == [1, 0, 1]
+        g, s = e.read_index(r, 2)
+        assert g.tolist() == [2, 0, 0] and s.tolist() == [0, 0, 0]
+    # next tick: a get of k1 by replica 1 conflicts with both sets everywhere: identical answers
+    st, fast, deps, ldeps = e.preaccept([1], [1], [1], [0], [0b001], np.zeros((3, 1), np.int32))
+    assert fast[0] == 1 and deps[0].tolist() == [1, 0, 1] and ldeps[0].tolist() == [1, 0, 1]
+
+
+def test_oracle_slow_path_by_hand(oracle):
+    """n = 5: the leader asks 3 others; two of them saw a conflicting set first, one did not =>
+    the answers differ => slow path with the union (preAcceptingSlowPath)."""
+    e = oracle.EPaxos(5, 2)
+    # X = set k0 by replica 4 (instance 0), asks 1, 2, 3.   Y = set k0 by replica 0 (instance 7), asks 1, 2, 3
+    leader, number, key, is_set = [4, 0], [0, 7], [0, 0], [1, 1]
+    mask = [0b01110, 0b01110]
+    # replica 1 and 2 process X then Y; replica 3 processes Y then X
+    rank = np.array([[0, 1], [0, 1], [0, 1], [1, 0], [0, 1]])
+    st, fast, deps, ldeps = e.preaccept(leader, number, key, is_set, mask, rank)
+    assert st == 0
+    # Y's answers: replicas 1, 2 saw X -> [0,0,0,0,1]; replica 3 did not -> [0,0,0,0,0]  => slow, union
+    assert fast[1] == 0 and deps[1].tolist() == [0, 0, 0, 0, 1]
+    # X's answers: replicas 1, 2 saw nothing -> [0..]; replica 3 saw Y (instance 7 of leader 0) -> [8,0,0,0,0]
+    assert fast[0] == 0 and deps[0].tolist() == [8, 0, 0, 0, 0]
+    assert e.preaccept([0], [0], [0], [1], [0b00110], np.zeros((5, 1), np.int32))[0] == 1  # 2 != n-2 others
+    assert e.preaccept([0], [0], [0], [1], [0b00111], np.zeros((5, 1), np.int32))[0] == 1  # asks itself
+
+
+# ----------------------------------------------------------------------------- GPU parity -------
+def random_tick(rng, n, num_keys, m, next_number, skew):
+    leader = rng.integers(0, n, m).astype(np.int32)
+    number = np.zeros(m, np.int32)
+    for i in range(m):  # instance numbers increase per leader (Replica.scala nextAvailableInstance)
+        number[i] = next_number[leader[i]]
+        next_number[leader[i]] += 1
+    key = rng.integers(0, num_keys, m).astype(np.int32)
+    is_set = (rng.random(m) < 0.5).astype(np.uint8)  # Bernoulli get/set, J/Workload.scala:75-103
+    mask = np.zeros(m, np.uint8)
+    for i in range(m):
+        others = [r for r in range(n) if r != leader[i]]
+        drop = rng.integers(0, n - 1)
+        mask[i] = sum(1 << r for j, r in enumerate(others) if j != drop)
+    # every replica sees the tick in roughly the global order, perturbed by a replica-specific skew
+    rank = np.zeros((n, m), np.int32)
+    for r in range(n):
+        noisy = np.arange(m) + rng.normal(0, skew, m)
+        rank[r, np.argsort(noisy, kind="stable")] = np.arange(m)
+    return leader, number, key, is_set, mask, rank
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,num_keys,m,skew", [(3, 8, 500, 3.0), (5, 16, 4000, 5.0), (5, 1024, 20000, 50.0),
+                                               (7, 64, 3000, 10.0), (5, 1, 300, 2.0)])
+def test_epaxos_ticks_match_oracle(oracle, n, num_keys, m, skew):
+    from frankenpaxos_amd.epaxos import EPaxos
+
+    gpu, ref = EPaxos(n, num_keys), oracle.EPaxos(n, num_keys)
+    rng = np.random.default_rng(n * 1000 + num_keys)
+    nxt = [0] * n
+    seen_fast = seen_slow = 0
+    for tick in range(4):
+        args = random_tick(rng, n, num_keys, m, nxt, skew)
+        a, b = gpu.preaccept(*args), ref.preaccept(*args)
+        assert a[0] == b[0] == 0
+        for x, y in zip(a[1:], b[1:]):
+            np.testing.assert_array_equal(x, y)
+        seen_fast += int(a[1].sum())
+        seen_slow += int((a[1] == 0).sum())
+    for r in range(n):
+        for k in range(0, num_keys, max(1, num_keys // 16)):
+            ga, sa = gpu.read_index(r, k)
+            gb, sb = ref.read_index(r, k)
+            assert ga.tolist() == gb.tolist() and sa.tolist() == sb.tolist()
+    assert seen_fast > 0 and (seen_slow > 0 or n == 3)
+
+
+@pytest.mark.gpu
+def test_epaxos_invalid_ticks(oracle):
+    from frankenpaxos_amd.epaxos import EPaxos
+    import frankenpaxos_amd as fa
+
+    gpu = EPaxos(5, 4)
+    z = np.zeros((5, 1), np.int32)
+    assert gpu.preaccept([0], [0], [0], [1], [0b00110], z)[0] == fa.FPX_EINVAL   # not n-2 others
+    assert gpu.preaccept([0], [0], [0], [1], [0b00111], z)[0] == fa.FPX_EINVAL   # asks itself
+    assert gpu.preaccept([0], [0], [9], [1], [0b01110], z)[0] == fa.FPX_EINVAL   # key out of range
+    st, fast, deps, ldeps = gpu.preaccept([0], [0], [0], [1], [0b01110], z)
+    assert st == 0 and fast[0] == 1 and deps[0].tolist() == [0] * 5
+    with pytest.raises(fa.FpxError):
+        EPaxos(4, 4)
