@@ -28,8 +28,12 @@
 #include <stdint.h>
 
 // tuning knobs (compile time)
-#ifndef FPX_U
-#define FPX_U 1   // slot rows in flight per wavefront (measured r01: 1 > 2 > 4, occupancy wins)
+// One slot row in flight per wavefront: batching 2 / 4 rows per wave cost occupancy and measured
+// slower (profiles/r01_tuning_sweep.txt); requesting the next row's ballots one step ahead measured
+// no better than not doing it (profiles/r01_tuning_sweep2.txt) -- the other 5-6 waves of the SIMD
+// already cover the latency.
+#ifndef FPX_PREFETCH
+#define FPX_PREFETCH 0
 #endif
 #ifndef FPX_NT
 #define FPX_NT 1  // vote rows are written once and not re-read soon: nontemporal stores
@@ -308,10 +312,8 @@ struct WaveOut<false> {    // K1: per-wave LDS staging of the per-slot bitmaps, 
   int32_t nack_round[64];
 };
 template <>
-struct WaveOut<true> {     // K3: only the chosen records are staged; bitmaps stay in registers
+struct WaveOut<true> {     // K3: only the chosen flags are staged; bitmaps stay in registers
   int32_t nack_round[64];
-  int32_t chosen_round[64];
-  int32_t chosen_value[64];
   int32_t chosen[64];
 };
 
@@ -319,7 +321,6 @@ template <int G, bool VEC, bool PERSLOT, bool FUSED>
 __global__ void __launch_bounds__(256)
     k_phase2(const Geom g, const State st, const Batch b) {
   constexpr int Q = 64 / G;           // slots per step
-  constexpr int U = G >= FPX_U ? FPX_U : G;   // steps in flight
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   if (st.status[ST_CODE] != 0) return;  // a failed validation applies nothing
@@ -354,178 +355,181 @@ __global__ void __launch_bounds__(256)
 
   const int nchunks = (b.n + 63) >> 6;
   for (int chunk = blockIdx.x * 4 + wib; chunk < nchunks; chunk += gridDim.x * 4) {
+    // ---- stage the chunk: lane i owns message i -------------------------------------------------
     const int m = chunk * 64 + lane;
     const bool mv = m < b.n;
     const int myslot = mv ? b.slot[m] : -1;
     const int myround = mv ? b.round[m] : 0;
     const int myvalue = mv ? b.value[m] : 0;
+    // ProxyLeader.handlePhase2a for 64 messages at once (ProxyLeader.scala:176-184): lane i reads the
+    // tally-key row of its slot (one gathered 16-byte access per lane), detects a known (slot, round)
+    // and picks the free way.  The key word is written back after the walk, one lane per message.
+    int myway = -1;
+    bool mydeliver = mv;
+    if (FUSED && mv) {
+      const uint32_t* kr = st.pl_key + (size_t)myslot * g.wp;
+      const uint4v k0 = *reinterpret_cast<const uint4v*>(kr);
+      uint4v k1 = uint4v{0, 0, 0, 0};
+      if (g.wp == 8) k1 = *reinterpret_cast<const uint4v*>(kr + 4);
+      const uint32_t want = (uint32_t)myround + 1u;
+      const uint32_t keys[8] = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
+      bool dup = false;
+#pragma unroll
+      for (int w = 7; w >= 0; --w) {
+        if (w < g.ways) {
+          dup = dup || ((keys[w] & KEY_ROUND_MASK) == want);
+          if (keys[w] == 0) myway = w;
+        }
+      }
+      mydeliver = !dup && myway >= 0;  // a known (slot, round) is ignored and NOT forwarded
+      if (!dup && myway < 0) report(st, 5 /*FPX_ECAPACITY*/, m, myslot, myround);
+    }
 
-    for (int t = 0; t < G; t += U) {
-      int s_[U], r_[U], v_[U], grp_[U];
-      int4v thr_[U];
-      uint4v k0_[U], k1_[U];
-      uint64_t tw_[U];
-      // ---- issue every load of U steps ------------------------------------------------------
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int src = (t + u) * Q + q;
-        s_[u] = __shfl(myslot, src);
-        r_[u] = __shfl(myround, src);
-        v_[u] = __shfl(myvalue, src);
-        grp_[u] = 0;
-        thr_[u] = init_thr;
-        k0_[u] = uint4v{0, 0, 0, 0};
-        k1_[u] = uint4v{0, 0, 0, 0};
-        tw_[u] = ~0ull;
-        if (s_[u] >= 0) {
-          const size_t row = (size_t)s_[u] * (size_t)g.R + (size_t)r0;
-          if (!one_group) grp_[u] = group_of_slot(g, s_[u]);
-          if (PERSLOT) {
-            if (VEC) {
-              if (own) thr_[u] = *reinterpret_cast<const int4v*>(st.ballot + row);
-            } else {
-#pragma unroll
-              for (int k = 0; k < 4; ++k)
-                if (own >> k & 1) thr_[u][k] = st.ballot[row + k];
-            }
-          } else if (!one_group) {
-            const int32_t* pr = st.promised + (size_t)grp_[u] * g.R + r0;
+    // ---- walk the chunk, Q slots per step; the ballot row of the next step is already in flight ----
+    auto load_thr = [&](int step, int& s_out, int& grp_out) -> int4v {
+      const int src = step * Q + q;
+      const int s = __shfl(myslot, src);
+      s_out = s;
+      grp_out = 0;
+      int4v thr = init_thr;
+      if (s >= 0) {
+        const size_t row = (size_t)s * (size_t)g.R + (size_t)r0;
+        if (!one_group) grp_out = group_of_slot(g, s);
+        if (PERSLOT) {
+          if (VEC) {
+            if (own) thr = *reinterpret_cast<const int4v*>(st.ballot + row);
+          } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-              if (own >> k & 1) thr_[u][k] = pr[k];
+              if (own >> k & 1) thr[k] = st.ballot[row + k];
           }
-          if (FUSED) {
-            const uint32_t* kr = st.pl_key + (size_t)s_[u] * g.wp;
-            k0_[u] = *reinterpret_cast<const uint4v*>(kr);
-            if (g.wp == 8) k1_[u] = *reinterpret_cast<const uint4v*>(kr + 4);
-          }
-          if (b.target && own) tw_[u] = b.target[(size_t)(chunk * 64 + src) * 4 + (bitpos >> 6)];
+        } else if (!one_group) {
+          const int32_t* pr = st.promised + (size_t)grp_out * g.R + r0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (own >> k & 1) thr[k] = pr[k];
         }
       }
-      // ---- process ---------------------------------------------------------------------------
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int src = (t + u) * Q + q;
-        const int s = s_[u], rnd = r_[u], val = v_[u];
-        const bool live = s >= 0;
-        int way = -1;
-        bool dup = false;
-        if (FUSED) {
-          // ProxyLeader.scala:176-184: a known (slot, round) is ignored and not forwarded
-          const uint32_t want = (uint32_t)rnd + 1u;
-          uint32_t keys[8] = {k0_[u][0], k0_[u][1], k0_[u][2], k0_[u][3],
-                              k1_[u][0], k1_[u][1], k1_[u][2], k1_[u][3]};
-#pragma unroll
-          for (int w = 7; w >= 0; --w) {
-            if (w < g.ways) {
-              dup = dup || ((keys[w] & KEY_ROUND_MASK) == want);
-              if (keys[w] == 0) way = w;
-            }
-          }
-        }
-        const bool deliver = live && (!FUSED || (!dup && way >= 0));
-        if (FUSED && live && !dup && way < 0 && gi == 0) report(st, 5 /*FPX_ECAPACITY*/, chunk * 64 + src, s, rnd);
+      return thr;
+    };
 
-        // Acceptor.scala:192: phase2a.round < round -> Nack ; else vote
-        uint32_t tn = deliver ? (own & (uint32_t)((tw_[u] >> (bitpos & 63)) & 0xFull)) : 0u;
-        uint32_t acc = 0, nck = 0;
-        int nr = -1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const bool tk = (tn >> k) & 1u;
-          const bool ok = tk && (rnd >= thr_[u][k]);
-          acc |= ok ? (1u << k) : 0u;
-          if (tk && !ok) {
-            nck |= 1u << k;
-            nr = thr_[u][k] > nr ? thr_[u][k] : nr;
-          }
-        }
-        // Acceptor.scala:204-208: round = phase2a.round; states(slot) = State(round, value)
-        if (acc) {
-          const size_t row = (size_t)s * (size_t)g.R + (size_t)r0;
-          if (VEC && acc == 0xFu) {
-            const int4v rr = {rnd, rnd, rnd, rnd};
-            const int4v vv = {val, val, val, val};
-            row_store(rr, reinterpret_cast<int4v*>(st.vote_round + row));
-            row_store(vv, reinterpret_cast<int4v*>(st.vote_value + row));
-            if (PERSLOT) {
-              const int4v old = thr_[u];
-              if (old[0] != rnd || old[1] != rnd || old[2] != rnd || old[3] != rnd)
-                row_store(rr, reinterpret_cast<int4v*>(st.ballot + row));
-            }
-          } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              if (acc >> k & 1u) {
-                st.vote_round[row + k] = rnd;
-                st.vote_value[row + k] = val;
-                if (PERSLOT && thr_[u][k] != rnd) st.ballot[row + k] = rnd;
-              }
-            }
-          }
-          // maxVotedSlot (Acceptor.scala:209) and the acceptor's new round
-          if (one_group) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              if (acc >> k & 1u) {
-                acc_mv[k] = s > acc_mv[k] ? s : acc_mv[k];
-                acc_pr[k] = rnd > acc_pr[k] ? rnd : acc_pr[k];
-              }
-            }
-          } else {
-            const int e = grp_[u] * g.R + r0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              if (acc >> k & 1u) {
-                atomicMax(&tab_mv[e + k], s);
-                atomicMax(&tab_pr[e + k], rnd);
-              }
-            }
-          }
-        }
+    int s_cur, grp_cur;
+    int4v thr_cur = load_thr(0, s_cur, grp_cur);
+    for (int t = 0; t < G; ++t) {
+      int s_nxt = -1, grp_nxt = 0;
+      int4v thr_nxt = init_thr;
+#if FPX_PREFETCH
+      if (t + 1 < G) thr_nxt = load_thr(t + 1, s_nxt, grp_nxt);
+#endif
+      const int src = t * Q + q;
+      const int s = s_cur;
+      const int rnd = __shfl(myround, src);
+      const int val = __shfl(myvalue, src);
+      const bool deliver = __shfl((int)mydeliver, src) != 0 && s >= 0;
+      const int4v thr = thr_cur;
+      uint64_t tw = ~0ull;
+      if (b.target && own && s >= 0) tw = b.target[(size_t)(chunk * 64 + src) * 4 + (bitpos >> 6)];
 
-        // ---- the slot's vote bitmap, in registers ---------------------------------------------
-        uint64_t vb[4];
-        assemble_bits<G>(acc, lane, g.base, vb);
-        const int nrm = group_max<G>(nr);
-
-        if constexpr (!FUSED) {
-          uint64_t nb[4] = {0, 0, 0, 0};
-          if (b.nack_bits) assemble_bits<G>(nck, lane, g.base, nb);
-          if (gi == 0) {
+      // Acceptor.scala:192: phase2a.round < round -> Nack ; else vote
+      const uint32_t tn = deliver ? (own & (uint32_t)((tw >> (bitpos & 63)) & 0xFull)) : 0u;
+      uint32_t acc = 0, nck = 0;
+      int nr = -1;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-              wo->votes[src][w] = vb[w];
-              wo->nacks[src][w] = nb[w];
-            }
-            wo->nack_round[src] = nrm;
+      for (int k = 0; k < 4; ++k) {
+        const bool tk = (tn >> k) & 1u;
+        const bool ok = tk && (rnd >= thr[k]);
+        acc |= ok ? (1u << k) : 0u;
+        if (tk && !ok) {
+          nck |= 1u << k;
+          nr = thr[k] > nr ? thr[k] : nr;
+        }
+      }
+      // Acceptor.scala:204-208: round = phase2a.round; states(slot) = State(round, value)
+      if (acc) {
+        const size_t row = (size_t)s * (size_t)g.R + (size_t)r0;
+        if (VEC && acc == 0xFu) {
+          const int4v rr = {rnd, rnd, rnd, rnd};
+          const int4v vv = {val, val, val, val};
+          row_store(rr, reinterpret_cast<int4v*>(st.vote_round + row));
+          row_store(vv, reinterpret_cast<int4v*>(st.vote_value + row));
+          if (PERSLOT) {
+            if (thr[0] != rnd || thr[1] != rnd || thr[2] != rnd || thr[3] != rnd)
+              row_store(rr, reinterpret_cast<int4v*>(st.ballot + row));
           }
         } else {
-          // ProxyLeader.scala:235-256: record votes, test the quorum, Chosen exactly once
-          bool ch = false;
-          if (deliver) {
-            uint64_t x[4];
 #pragma unroll
-            for (int w = 0; w < 4; ++w) x[w] = vb[w] & g.member[w];
-            ch = is_write_quorum(g, x);
-            if (gi == 0) {
-              const size_t e = (size_t)s * g.wp + way;
-              st.pl_key[e] = ((uint32_t)rnd + 1u) | (ch ? KEY_DONE : 0u);
-              if (!ch) {
-                st.pl_value[e] = val;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) st.pl_bits[e * 4 + w] = x[w];
-              }
+          for (int k = 0; k < 4; ++k) {
+            if (acc >> k & 1u) {
+              st.vote_round[row + k] = rnd;
+              st.vote_value[row + k] = val;
+              if (PERSLOT && thr[k] != rnd) st.ballot[row + k] = rnd;
             }
           }
-          if (gi == 0) {
-            wo->chosen[src] = ch ? 1 : 0;
-            wo->chosen_round[src] = ch ? rnd : -1;
-            wo->chosen_value[src] = ch ? val : -1;
-            wo->nack_round[src] = nrm;
+        }
+        // maxVotedSlot (Acceptor.scala:209) and the acceptor's new round
+        if (one_group) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (acc >> k & 1u) {
+              acc_mv[k] = s > acc_mv[k] ? s : acc_mv[k];
+              acc_pr[k] = rnd > acc_pr[k] ? rnd : acc_pr[k];
+            }
+          }
+        } else {
+          const int e = grp_cur * g.R + r0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (acc >> k & 1u) {
+              atomicMax(&tab_mv[e + k], s);
+              atomicMax(&tab_pr[e + k], rnd);
+            }
           }
         }
       }
+
+      // ---- the slot's vote bitmap, in registers -----------------------------------------------
+      uint64_t vb[4];
+      assemble_bits<G>(acc, lane, g.base, vb);
+      int nrm = -1;
+      const bool any_nack = __any(nck != 0u);  // wave-uniform: the Nack reductions are rare
+      if (any_nack) nrm = group_max<G>(nr);
+
+      if constexpr (!FUSED) {
+        uint64_t nb[4] = {0, 0, 0, 0};
+        if (b.nack_bits && any_nack) assemble_bits<G>(nck, lane, g.base, nb);
+        if (gi == 0) {
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            wo->votes[src][w] = vb[w];
+            wo->nacks[src][w] = nb[w];
+          }
+          wo->nack_round[src] = nrm;
+        }
+      } else {
+        // ProxyLeader.scala:235-256: record votes, test the quorum, Chosen exactly once
+        bool ch = false;
+        const int way = __shfl(myway, src);
+        if (deliver) {
+          uint64_t x[4];
+#pragma unroll
+          for (int w = 0; w < 4; ++w) x[w] = vb[w] & g.member[w];
+          ch = is_write_quorum(g, x);
+          if (!ch && gi == 0) {  // stays Pending: keep the votes (the key word is written below)
+            const size_t e = (size_t)s * g.wp + way;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) st.pl_bits[e * 4 + w] = x[w];
+          }
+        }
+        if (gi == 0) {
+          wo->chosen[src] = ch ? 1 : 0;
+          wo->nack_round[src] = nrm;
+        }
+      }
+#if FPX_PREFETCH
+      s_cur = s_nxt, grp_cur = grp_nxt, thr_cur = thr_nxt;
+#else
+      if (t + 1 < G) thr_cur = load_thr(t + 1, s_cur, grp_cur);
+#endif
     }
 
     // ---- outputs of the 64 messages leave as coalesced lines ------------------------------------
@@ -543,9 +547,16 @@ __global__ void __launch_bounds__(256)
           for (int w = 0; w < 4; ++w) o[w] = wo->nacks[lane][w];
         }
       } else {
-        if (b.chosen) b.chosen[m] = (uint8_t)wo->chosen[lane];
-        if (b.chosen_round) b.chosen_round[m] = wo->chosen_round[lane];
-        if (b.chosen_value) b.chosen_value[m] = wo->chosen_value[lane];
+        const bool ch = wo->chosen[lane] != 0;
+        if (mydeliver) {
+          // states(slotround) = Done (ProxyLeader.scala:256) or Pending(phase2a, votes) (:213)
+          const size_t e = (size_t)myslot * g.wp + myway;
+          st.pl_key[e] = ((uint32_t)myround + 1u) | (ch ? KEY_DONE : 0u);
+          if (!ch) st.pl_value[e] = myvalue;
+        }
+        if (b.chosen) b.chosen[m] = ch ? 1 : 0;
+        if (b.chosen_round) b.chosen_round[m] = ch ? myround : -1;
+        if (b.chosen_value) b.chosen_value[m] = ch ? myvalue : -1;
       }
       if (b.nack_round) b.nack_round[m] = wo->nack_round[lane];
     }
