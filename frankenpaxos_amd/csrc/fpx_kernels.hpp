@@ -416,9 +416,9 @@ __global__ void __launch_bounds__(256)
     int s_cur, grp_cur;
     int4v thr_cur = load_thr(0, s_cur, grp_cur);
     for (int t = 0; t < G; ++t) {
+#if FPX_PREFETCH
       int s_nxt = -1, grp_nxt = 0;
       int4v thr_nxt = init_thr;
-#if FPX_PREFETCH
       if (t + 1 < G) thr_nxt = load_thr(t + 1, s_nxt, grp_nxt);
 #endif
       const int src = t * Q + q;
