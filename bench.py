@@ -109,6 +109,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libfpx has no CPU path)")
+    # test hooks (tests/test_bench_distributed.py): run several ranks on ONE GPU over gloo, so that the
+    # N > 1 control flow of this file can be exercised on a 1-GPU box.  Never set by the driver.
+    share_gpu = os.environ.get("FPX_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("FPX_BENCH_BACKEND", "nccl")
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -116,7 +122,19 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
+
+    def all_reduce(t, op):
+        """all-reduce of a device tensor; staged through the host only under the gloo test hook"""
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+        else:
+            c = t.cpu()
+            dist.all_reduce(c, op=op)
+            t.copy_(c)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
@@ -163,7 +181,7 @@ def main():
             # K1 on my acceptors -> all-reduce(sum) of the disjoint partial bitmaps over xGMI -> K2
             ctx.proxy_open_dev(slot, rnd, val)
             ctx.acceptor_phase2a_dev(slot, rnd, val, None, vb, None, None)
-            dist.all_reduce(vb, op=dist.ReduceOp.SUM)
+            all_reduce(vb, dist.ReduceOp.SUM)
             ctx.proxy_phase2b_dev(slot, rnd, vb, ch, cr, cv)
 
     def fence():
@@ -187,7 +205,7 @@ def main():
     assert ctx.sync() == 0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # every timed step must have committed all of its slots, with the proposed value
@@ -196,7 +214,7 @@ def main():
     assert bool((cv == steps[Wm + K - 1][2]).all())
     if dist is not None and not replica_shard:
         t = torch.tensor([committed], dtype=torch.int64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        all_reduce(t, dist.ReduceOp.SUM)
         committed = int(t.item())
 
     if rank == 0:
