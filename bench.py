@@ -84,11 +84,36 @@ def cpu_baseline(ballot_mode):
     t1 = time.perf_counter()
     ref2.phase2_fifo_pump(slot[:Sp], rnd[:Sp], val[:Sp])
     dtp = time.perf_counter() - t1
+    # B1 "faithful shapes" (BASELINE.md section 2): the same handlers over the reference's data structures
+    # (SortedMap per acceptor, HashMap of Pending with a vote map, one heap object per message, FIFO pump)
+    import ctypes as C
+    faithful = None
+    fso = os.path.join(ROOT, "oracle", "libfpx_faithful.so")
+    if not os.path.exists(fso):
+        import subprocess
+        subprocess.call(["make", "-C", os.path.join(ROOT, "oracle"), "libfpx_faithful.so"],
+                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    if os.path.exists(fso):
+        L = C.CDLL(fso)
+        L.fpo_faithful_run.restype = C.c_int64
+        L.fpo_faithful_run.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]
+        Sf = 1 << 14
+        v = np.ascontiguousarray(val[:Sf])
+        cs = C.c_int64()
+        t2 = time.perf_counter()
+        n = L.fpo_faithful_run(Sf, REPLICAS, F, v.ctypes.data, C.byref(cs))
+        dtf = time.perf_counter() - t2
+        assert n == Sf and cs.value == int(v.astype(np.int64).sum())
+        faithful = Sf / dtf
     return {
         "value": S / dt, "unit": "slots/s", "cores": 1, "kind": "port",
-        "sample": "oracle/fpx_oracle.c fpo_phase2_fused, 2^19 slots x 256 acceptors, steady stream, "
-                  "1 thread (reference Transport is single-threaded); same handlers behind a FIFO "
-                  "message pump on 2^15 slots: %.3e slots/s; nproc=%d" % (Sp / dtp, os.cpu_count()),
+        "sample": "oracle/fpx_oracle.c fpo_phase2_fused (flat arrays), 2^19 slots x 256 acceptors, steady "
+                  "stream, 1 thread (reference Transport is single-threaded); same handlers behind a FIFO "
+                  "message pump on 2^15 slots: %.3e slots/s; with the reference's data-structure shapes "
+                  "(oracle/fpx_faithful.cpp: std::map per acceptor, hash map of Pending, heap message per "
+                  "Phase2a/2b) on 2^14 slots: %s slots/s; C/C++ restatements, not the JVM; nproc=%d"
+                  % (Sp / dtp, ("%.3e" % faithful) if faithful else "n/a", os.cpu_count()),
+        "faithful_shapes_value": faithful,
     }
 
 

@@ -32,6 +32,13 @@
 // slower (profiles/r01_tuning_sweep.txt); requesting the next row's ballots one step ahead measured
 // no better than not doing it (profiles/r01_tuning_sweep2.txt) -- the other 5-6 waves of the SIMD
 // already cover the latency.
+#ifndef FPX_CHUNK
+#define FPX_CHUNK 32   // messages per wavefront chunk at R in (128, 256]: 64 / 32 / 16 / 8 measured,
+                       // 32 and 16 are best (profiles/r01_tuning_sweep4.txt): finer units balance the XCDs
+#endif
+#ifndef FPX_NT_LOAD
+#define FPX_NT_LOAD 0  // ballot rows are read once: nontemporal loads
+#endif
 #ifndef FPX_PREFETCH
 #define FPX_PREFETCH 0
 #endif
@@ -353,11 +360,12 @@ __global__ void __launch_bounds__(256)
       if (own >> k & 1) init_thr[k] = st.promised[r0 + k];
   }
 
-  const int nchunks = (b.n + 63) >> 6;
+  constexpr int CH = (G == 64) ? FPX_CHUNK : 64;  // messages per wavefront chunk
+  const int nchunks = (b.n + CH - 1) / CH;
   for (int chunk = blockIdx.x * 4 + wib; chunk < nchunks; chunk += gridDim.x * 4) {
     // ---- stage the chunk: lane i owns message i -------------------------------------------------
-    const int m = chunk * 64 + lane;
-    const bool mv = m < b.n;
+    const int m = chunk * CH + lane;
+    const bool mv = lane < CH && m < b.n;
     const int myslot = mv ? b.slot[m] : -1;
     const int myround = mv ? b.round[m] : 0;
     const int myvalue = mv ? b.value[m] : 0;
@@ -397,7 +405,11 @@ __global__ void __launch_bounds__(256)
         if (!one_group) grp_out = group_of_slot(g, s);
         if (PERSLOT) {
           if (VEC) {
+#if FPX_NT_LOAD
+            if (own) thr = __builtin_nontemporal_load(reinterpret_cast<const int4v*>(st.ballot + row));
+#else
             if (own) thr = *reinterpret_cast<const int4v*>(st.ballot + row);
+#endif
           } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -415,7 +427,7 @@ __global__ void __launch_bounds__(256)
 
     int s_cur, grp_cur;
     int4v thr_cur = load_thr(0, s_cur, grp_cur);
-    for (int t = 0; t < G; ++t) {
+    for (int t = 0; t < G * CH / 64; ++t) {
 #if FPX_PREFETCH
       int s_nxt = -1, grp_nxt = 0;
       int4v thr_nxt = init_thr;
@@ -428,7 +440,7 @@ __global__ void __launch_bounds__(256)
       const bool deliver = __shfl((int)mydeliver, src) != 0 && s >= 0;
       const int4v thr = thr_cur;
       uint64_t tw = ~0ull;
-      if (b.target && own && s >= 0) tw = b.target[(size_t)(chunk * 64 + src) * 4 + (bitpos >> 6)];
+      if (b.target && own && s >= 0) tw = b.target[(size_t)(chunk * CH + src) * 4 + (bitpos >> 6)];
 
       // Acceptor.scala:192: phase2a.round < round -> Nack ; else vote
       const uint32_t tn = deliver ? (own & (uint32_t)((tw >> (bitpos & 63)) & 0xFull)) : 0u;
