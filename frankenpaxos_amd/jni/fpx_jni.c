@@ -9,6 +9,7 @@
  * Class: frankenpaxos.gpu.Native (all methods static native, returning the int32 status).
  */
 #include <jni.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/fpx.h"
