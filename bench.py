@@ -36,7 +36,7 @@ SLOTS_PER_STEP = 1 << 20
 REPLICAS = 256
 F = 127
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MAX_WINDOWS = 40       # log windows kept in HBM (3.2 GiB each in PER_SLOT mode)
+MAX_WINDOWS = 56       # log windows kept in HBM (3.3 GiB each in PER_SLOT mode: 185 GiB of 288 GB)
 
 
 def splitmix64_torch(x):
@@ -168,13 +168,15 @@ def main():
     ballot_mode = fa.FPX_BALLOT_PER_SLOT if args.ballot == "per_slot" else fa.FPX_BALLOT_ACCEPTOR
     K, Wm = args.steps, args.warmup
     windows = min(K + Wm, MAX_WINDOWS)
+    # live (slot, round) tallies per slot: 4 unless the run laps the window ring more than 4 times
+    TALLY_WAYS = 4 if K + Wm <= 4 * windows else 8
     S_total = windows * SLOTS_PER_STEP
     replica_shard = args.shard == "replica" and world > 1
     R_local = REPLICAS // world if replica_shard else REPLICAS
     flags = 0 if args.validate else fa.FPX_F_TRUSTED
     ctx = fa.Context(fa.make_config(
         num_slots=S_total, num_replicas=R_local, f=F, quorum_kind=fa.FPX_Q_THRESHOLD,
-        ballot_mode=ballot_mode, tally_ways=4, device=local_rank, flags=flags,
+        ballot_mode=ballot_mode, tally_ways=TALLY_WAYS, device=local_rank, flags=flags,
         replica_base=(rank * R_local if replica_shard else 0),
         replicas_total=(REPLICAS if replica_shard else 0)))
     stream = torch.cuda.current_stream()
@@ -200,6 +202,11 @@ def main():
 
     def step(i):
         slot, rnd, val, ch = steps[i]
+        lap = i // windows
+        if lap > 0 and lap % TALLY_WAYS == 0:
+            # a window of the log is re-proposed once more than the proxy leader keeps tallies for:
+            # garbage-collect its (chosen and executed) tallies first -- timed like everything else
+            ctx.proxy_forget((i % windows) * SLOTS_PER_STEP, SLOTS_PER_STEP)
         if not replica_shard:
             ctx.phase2_fused_dev(slot, rnd, val, None, ch, cr, cv)
         else:
@@ -244,6 +251,11 @@ def main():
 
     if rank == 0:
         bps = algorithmic_bytes_per_slot(ballot_mode)
+        # steps beyond the first lap over the window ring re-propose old slots in a higher round: in the
+        # PER_SLOT model that also rewrites the ballot row (+4 R bytes per slot), which is algorithmic
+        wrapped = sum(1 for i in range(Wm, Wm + K) if i // windows > 0)
+        if ballot_mode == 1 and wrapped:
+            bps = (bps * (K - wrapped) + (bps + 4 * REPLICAS) * wrapped) / K
         avg_kernel_s = (kernel_ms / max(launches, 1)) * 1e-3
         slots_per_launch = SLOTS_PER_STEP
         achieved = bps * slots_per_launch / avg_kernel_s / 1e9 if launches else None
@@ -276,6 +288,7 @@ def main():
                 "ballot_model": args.ballot, "sharding": args.shard if world > 1 else "none",
                 "run_contract_validation_in_timed_region": bool(args.validate),
                 "log_windows_in_hbm": windows, "hbm_bytes": ctx.device_bytes,
+                "steps_reproposing_old_slots": sum(1 for i in range(Wm, Wm + K) if i // windows > 0),
             },
             "roofline": {
                 "bound": "hbm", "kernel": kernel,

@@ -93,6 +93,7 @@ SIGNATURES = {
     "fpx_acceptor_phase2a_noop_range": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, VP, VP, VP, I32P]),
     "fpx_proxy_open_noop_range": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, U8P]),
     "fpx_proxy_phase2b_noop_range": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, VP, U8P]),
+    "fpx_proxy_forget": (C.c_int32, [VP, C.c_int32, C.c_int32]),
     "fpx_epx_create": (C.c_int32, [VP, C.POINTER(VP)]),
     "fpx_epx_destroy": (C.c_int32, [VP]),
     "fpx_epx_set_stream": (C.c_int32, [VP, VP]),

@@ -184,6 +184,12 @@ class Context:
         if st:
             raise FpxError(st, "fpx_phase2_fused_dev")
 
+    def proxy_forget(self, first_slot, count):
+        """GC of the proxy leader's tallies of a slot range (async on the context's stream)"""
+        st = self.L.fpx_proxy_forget(self._h, first_slot, count)
+        if st:
+            raise FpxError(st, "fpx_proxy_forget")
+
     # ---- K4: Mencius noop ranges ----------------------------------------------------------------
     def acceptor_phase2a_noop_range(self, slot_start, slot_end, round_, target_masks=None):
         A = self.cfg.num_groups

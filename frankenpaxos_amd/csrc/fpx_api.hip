@@ -136,7 +136,7 @@ int dalloc(fpx_ctx* ctx, T** p, size_t count) {
 }
 
 size_t lds_bytes(const fpx_ctx* ctx, bool fused) {
-  const size_t tab = (((size_t)ctx->g.ngroups * ctx->g.R * 8) + 15) & ~(size_t)15;
+  const size_t tab = (((size_t)ctx->g.ngroups * ctx->g.R * 8) + 16 + 15) & ~(size_t)15;  // tables + 4 workgroup words
   return tab + 4 * (fused ? sizeof(WaveOut<true>) : sizeof(WaveOut<false>));
 }
 
@@ -221,7 +221,7 @@ int enqueue_phase2(fpx_ctx* ctx, Batch& b, bool fused) {
   }
   const int ntab = ctx->g.ngroups * ctx->g.R;
   hipLaunchKernelGGL(k_finalize, dim3((ntab + 63) / 64, FINALIZE_SLICES), dim3(256), 0, ctx->stream, ctx->g, ctx->st,
-                     grid);
+                     (int)(b.run_id & 1u));
   return launch_check(ctx);
 }
 
@@ -271,6 +271,8 @@ int init_state(fpx_ctx* ctx) {
   HIPCHK(ctx, hipMemsetAsync(st.stamp, 0, (size_t)g.S * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.run_round, 0xFF, (size_t)g.ngroups * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.status, 0, 8 * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.part_cnt, 0, 2 * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.part_all, 0xFF, (size_t)2 * 64 * PART_ALL_STRIDE * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.log_value, 0xFF, (size_t)g.S * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.log_present, 0, (size_t)g.S, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.rt_key, 0, (size_t)RANGE_TALLIES * 16, ctx->stream));
@@ -290,7 +292,7 @@ void free_state(fpx_ctx* ctx) {
   State& st = ctx->st;
   void* ps[] = {st.promised, st.max_voted, st.vote_round, st.vote_value, st.ballot, st.pl_key, st.pl_value,
                 st.pl_bits,  st.stamp,     st.run_round,  st.status,     st.part,
-                st.log_value, st.log_present, st.log_scalars, st.rt_key, st.rt_bits};
+                st.log_value, st.log_present, st.log_scalars, st.rt_key, st.rt_bits, st.part_cnt, st.part_all};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   DevBuf* bs[] = {&ctx->d_slot,   &ctx->d_round, &ctx->d_value, &ctx->d_target, &ctx->d_bits_a, &ctx->d_bits_b,
@@ -474,6 +476,8 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
   if ((rc = dalloc(ctx, &st.run_round, (size_t)g.ngroups))) return fail(rc);
   if ((rc = dalloc(ctx, &st.status, (size_t)8))) return fail(rc);
   if ((rc = dalloc(ctx, &st.part, (size_t)ctx->max_grid * 2 * ntab))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.part_cnt, (size_t)2))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.part_all, (size_t)2 * 64 * PART_ALL_STRIDE))) return fail(rc);
   if ((rc = dalloc(ctx, &st.log_value, (size_t)g.S))) return fail(rc);
   if ((rc = dalloc(ctx, &st.log_present, (size_t)g.S))) return fail(rc);
   if ((rc = dalloc(ctx, &st.log_scalars, (size_t)8))) return fail(rc);
@@ -786,6 +790,15 @@ int32_t fpx_acceptor_phase1a(fpx_ctx* ctx, int32_t group, int32_t round, int32_t
   }
   if (promised_bits) memcpy(promised_bits, h, 32);
   if (nack_bits) memcpy(nack_bits, h + 4, 32);
+  return FPX_OK;
+}
+
+int32_t fpx_proxy_forget(fpx_ctx* ctx, int32_t first_slot, int32_t count) {
+  if (!ctx || first_slot < 0 || count < 0 || (int64_t)first_slot + count > ctx->g.S) return FPX_EINVAL;
+  if (count == 0) return FPX_OK;
+  // an empty key word is all a tally entry needs to be free again (values / bitmaps are rewritten on open)
+  HIPCHK(ctx, hipMemsetAsync(ctx->st.pl_key + (size_t)first_slot * ctx->g.wp, 0, (size_t)count * ctx->g.wp * 4,
+                             ctx->stream));
   return FPX_OK;
 }
 

@@ -57,6 +57,7 @@ typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 enum : uint32_t { KEY_DONE = 0x80000000u, KEY_RANGE = 0x40000000u, KEY_ROUND_MASK = 0x3fffffffu };
 constexpr int MAX_ROUND = 0x3ffffffe;
 constexpr int RANGE_TALLIES = 1024;  // live Mencius noop-range tallies per context
+constexpr int PART_ALL_STRIDE = 32;  // ints: one 128-byte line per shard of the whole-group maxima
 
 // status word layout in HBM (int32[8])
 enum { ST_CODE = 0, ST_INDEX = 1, ST_SLOT = 2, ST_ROUND = 3 };
@@ -84,7 +85,9 @@ struct State {
   uint32_t* stamp;      // [S]            run id of the last run that touched the slot
   int32_t* run_round;   // [ngroups]      the single round of the current run per group (-1 = none)
   int32_t* status;      // [8]
-  int32_t* part;        // [grid][2][ngroups*R] per-block maxima (accepted round, voted slot)
+  int32_t* part;        // [grid][2][ngroups*R] per-workgroup maxima rows (accepted round, voted slot)
+  int32_t* part_cnt;    // [2]   rows of `part` claimed by the current launch, per launch parity
+  int32_t* part_all;    // [2][64][PART_ALL_STRIDE] whole-group maxima (round, slot), 64 lines, per launch parity
   int32_t* log_value;   // [S]  the replica's log (BufferMap), -1 where absent
   uint8_t* log_present; // [S]
   int32_t* log_scalars; // [8]  LG_*: executedWatermark, numChosen, largestKey, scan result
@@ -339,10 +342,14 @@ __global__ void __launch_bounds__(256)
   const int ntab = g.ngroups * g.R;
   int32_t* tab_pr = reinterpret_cast<int32_t*>(smem);
   int32_t* tab_mv = tab_pr + ntab;
-  WaveOut<FUSED>* wo = reinterpret_cast<WaveOut<FUSED>*>(smem + (((size_t)ntab * 8 + 15) & ~(size_t)15)) + wib;
+  // [0] this workgroup used the tables, [1] its partial-table row, [2] [3] whole-group maxima (round, slot)
+  int32_t* blk_flag = tab_pr + 2 * ntab;
+  WaveOut<FUSED>* wo = reinterpret_cast<WaveOut<FUSED>*>(smem + (((size_t)ntab * 8 + 16 + 15) & ~(size_t)15)) + wib;
 
-  for (int i = threadIdx.x; i < 2 * ntab; i += blockDim.x) tab_pr[i] = -1;
+  for (int i = threadIdx.x; i < 2 * ntab + 4; i += blockDim.x) tab_pr[i] = (i < 2 * ntab || i >= 2 * ntab + 2) ? -1 : 0;
   __syncthreads();
+  int w_slot = -1, w_round = -1;  // maxima over the steps in which the whole group voted (wave-uniform)
+  bool table_used = false;
 
   const bool one_group = g.ngroups == 1;
   const int r0 = 4 * gi;  // first local acceptor of this lane
@@ -478,7 +485,14 @@ __global__ void __launch_bounds__(256)
             }
           }
         }
-        // maxVotedSlot (Acceptor.scala:209) and the acceptor's new round
+      }
+      // maxVotedSlot (Acceptor.scala:209) and the acceptor's new round.  When the WHOLE group voted
+      // (the steady state) the maxima are the same for every acceptor: two wave-uniform scalars.
+      const bool whole_group = (G == 64) && one_group && __all(acc == own);
+      if (whole_group) {
+        w_slot = s > w_slot ? s : w_slot;
+        w_round = rnd > w_round ? rnd : w_round;
+      } else if (acc) {
         if (one_group) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -488,6 +502,7 @@ __global__ void __launch_bounds__(256)
             }
           }
         } else {
+          table_used = true;
           const int e = grp_cur * g.R + r0;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -575,19 +590,41 @@ __global__ void __launch_bounds__(256)
     wave_lds_sync();
   }
 
-  // ---- fold maxima: registers -> LDS -> this block's row of the partial table ------------------
+  // ---- fold maxima --------------------------------------------------------------------------------
+  // (a) steps in which the WHOLE group voted only raised two wave-uniform scalars: one pair of
+  //     atomics per wavefront into a 64-way sharded table (the common case: nothing else to do);
+  // (b) everything else went through registers / LDS tables: the workgroup appends ONE row to the
+  //     partial table, claimed with a counter, only if it saw such a step.
+  const int par = b.run_id & 1u;
+  if (lane == 0 && w_slot >= 0) {  // wave -> workgroup (LDS)
+    atomicMax(&blk_flag[2], w_round);
+    atomicMax(&blk_flag[3], w_slot);
+  }
+  bool any_table = false;
   if (one_group) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (own >> k & 1u) {
-        if (acc_mv[k] >= 0) atomicMax(&tab_mv[r0 + k], acc_mv[k]);
-        if (acc_pr[k] >= 0) atomicMax(&tab_pr[r0 + k], acc_pr[k]);
+        if (acc_mv[k] >= 0) atomicMax(&tab_mv[r0 + k], acc_mv[k]), any_table = true;
+        if (acc_pr[k] >= 0) atomicMax(&tab_pr[r0 + k], acc_pr[k]), any_table = true;
       }
     }
+  } else {
+    any_table = table_used;
   }
+  if (any_table) blk_flag[0] = 1;
   __syncthreads();
-  int32_t* prow = st.part + (size_t)blockIdx.x * 2 * ntab;
-  for (int i = threadIdx.x; i < 2 * ntab; i += blockDim.x) prow[i] = tab_pr[i];
+  if (threadIdx.x == 0 && blk_flag[3] >= 0) {  // workgroup -> one of 64 cache lines (2 atomics per workgroup)
+    int32_t* pa = st.part_all + ((size_t)par * 64 + (blockIdx.x & 63)) * PART_ALL_STRIDE;
+    atomicMax(&pa[0], blk_flag[2]);
+    atomicMax(&pa[1], blk_flag[3]);
+  }
+  if (blk_flag[0]) {
+    if (threadIdx.x == 0) blk_flag[1] = atomicAdd(&st.part_cnt[par], 1);
+    __syncthreads();
+    int32_t* prow = st.part + (size_t)blk_flag[1] * 2 * ntab;
+    for (int i = threadIdx.x; i < 2 * ntab; i += blockDim.x) prow[i] = tab_pr[i];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -596,14 +633,29 @@ __global__ void __launch_bounds__(256)
 // ------------------------------------------------------------------------------------------------
 // grid = (ceil(ntab / 64), FINALIZE_SLICES): blockIdx.y strides over the rows of the partial table,
 // the 4 waves of a block stride within that; one atomicMax per (entry, blockIdx.y) that improves.
-constexpr int FINALIZE_SLICES = 32;
-__global__ void __launch_bounds__(256) k_finalize(const Geom g, const State st, int nblocks) {
+constexpr int FINALIZE_SLICES = 8;
+__global__ void __launch_bounds__(256) k_finalize(const Geom g, const State st, int par) {
   __shared__ int32_t red[2][4][64];
+  // the buffers of the OTHER parity are used by the next launch: clear them here, whatever happens
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
+    if (threadIdx.x == 0) st.part_cnt[par ^ 1] = 0;
+    if (threadIdx.x < 128)
+      st.part_all[((size_t)(par ^ 1) * 64 + (threadIdx.x >> 1)) * PART_ALL_STRIDE + (threadIdx.x & 1)] = -1;
+  }
   if (st.status[ST_CODE] != 0) return;
   const int ntab = g.ngroups * g.R;
+  const int nblocks = st.part_cnt[par];
   const int e = blockIdx.x * 64 + (threadIdx.x & 63);
   const int slice = threadIdx.x >> 6;
   int pr = -1, mvs = -1;
+  if (blockIdx.y == 0 && slice == 0 && g.ngroups == 1) {
+    // steps in which the whole group voted (k_phase2 (a)): the same maxima for every acceptor
+    const int32_t* pa = st.part_all + (size_t)par * 64 * PART_ALL_STRIDE;
+    for (int i = 0; i < 64; ++i) {
+      pr = pa[i * PART_ALL_STRIDE] > pr ? pa[i * PART_ALL_STRIDE] : pr;
+      mvs = pa[i * PART_ALL_STRIDE + 1] > mvs ? pa[i * PART_ALL_STRIDE + 1] : mvs;
+    }
+  }
   if (e < ntab) {
 #pragma unroll 4
     for (int bl = blockIdx.y * 4 + slice; bl < nblocks; bl += 4 * FINALIZE_SLICES) {

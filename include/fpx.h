@@ -213,6 +213,13 @@ int32_t fpx_proxy_phase2b_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, co
                               const uint64_t* d_vote_bits, uint8_t* d_newly_chosen,
                               int32_t* d_chosen_round, int32_t* d_chosen_value);
 
+/* Garbage collection of the proxy leader (NOT in the reference, whose ProxyLeader.states grows forever,
+ * ProxyLeader.scala:135): forgets every tally -- Pending or Done -- of the slots
+ * [first_slot, first_slot + count), so that a long-running simulation can re-propose a chosen-and-executed
+ * window of the log in further rounds without exhausting tally_ways.  Acceptor state is untouched.
+ * Asynchronous on the context's stream.  After it, a Phase2b for a forgotten (slot, round) is "unknown". */
+int32_t fpx_proxy_forget(fpx_ctx* ctx, int32_t first_slot, int32_t count);
+
 /* ---- K3: fused step = fpx_proxy_open + fpx_acceptor_phase2a + fpx_proxy_phase2b ------------------
  * For each message in order: open (slot, round) (duplicates are ignored and NOT forwarded to the
  * acceptors, :177-184), deliver the Phase2a to the targeted acceptors (target_mask NULL = all: the
