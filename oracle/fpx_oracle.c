@@ -648,6 +648,28 @@ static tally_t* tab_insert(fpo_sys* s, uint64_t key) {
   return &s->tab[i];
 }
 
+/* GC extension of fpx.h (fpx_proxy_forget; not in the reference): drop every single-slot tally of the
+ * slots [first_slot, first_slot + count) */
+int fpo_proxy_forget(fpo_sys* s, int32_t first_slot, int32_t count) {
+  if (first_slot < 0 || count < 0 || (int64_t)first_slot + count > s->cfg.num_slots) return FPO_EINVAL;
+  tally_t* old = s->tab;
+  size_t old_cap = s->tab_cap;
+  s->tab = (tally_t*)calloc(s->tab_cap, sizeof(tally_t));
+  s->tab_n = 0;
+  size_t mask = s->tab_cap - 1;
+  for (size_t i = 0; i < old_cap; ++i) {
+    if (old[i].state == 0) continue;
+    int slot = (int)(old[i].key >> 32);
+    if (!old[i].is_range && slot >= first_slot && slot < first_slot + count) continue;
+    size_t j = thash(old[i].key) & mask;
+    while (s->tab[j].state != 0) j = (j + 1) & mask;
+    s->tab[j] = old[i];
+    s->tab_n++;
+  }
+  free(old);
+  return FPO_OK;
+}
+
 int fpo_proxy_handle_phase2a(fpo_sys* s, int slot, int round, int value) {
   /* ProxyLeader.scala:176-184  states.get(slotround) match { case Some(_) => ignore */
   if (tab_find(s, tkey(slot, round))) return 0;

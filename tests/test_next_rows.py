@@ -130,3 +130,38 @@ def test_phase1b_scan_matches_oracle(fa, oracle, R, kw):
                 assert a[0] == b[0] == 0 and a[1] == b[1]
                 np.testing.assert_array_equal(a[2], b[2])
                 np.testing.assert_array_equal(a[3], b[3])
+
+
+@pytest.mark.gpu
+def test_proxy_forget_gc(fa, oracle):
+    """fpx_proxy_forget: the proxy leader forgets the tallies of a slot window (extension; the
+    reference's ProxyLeader.states grows forever) so that more rounds than tally_ways can follow."""
+    import ctypes as C
+
+    S = 256
+    gpu, ref = both(fa, oracle, num_slots=S, num_replicas=3, f=1, tally_ways=2)
+    L = oracle.lib()
+    L.fpo_proxy_forget.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    slot = np.arange(S, dtype=np.int32)
+    val = W.steady_values(slot)
+    for rnd in range(7):
+        if rnd and rnd % 2 == 0:  # both ways of every slot are taken: forget slots [64, 192)
+            gpu.proxy_forget(64, 128)
+            assert L.fpo_proxy_forget(ref._h, 64, 128) == 0
+        rr = np.full(S, rnd, np.int32)
+        a = gpu.phase2_fused(slot, rr, val)
+        b = ref.phase2_fused(slot, rr, val)
+        if rnd < 2:
+            assert a[0] == b[0] == 0
+            for x, y in zip(a[1:], b[1:]):
+                np.testing.assert_array_equal(x, y)
+        else:
+            # slots outside the forgotten window have no free way left: the device reports it,
+            # the forgotten window keeps working and matches the oracle
+            assert a[0] == fa.FPX_ECAPACITY
+            np.testing.assert_array_equal(a[1][64:192], b[1][64:192])
+            np.testing.assert_array_equal(a[3][64:192], b[3][64:192])
+            assert a[1][64:192].all() and not a[1][:64].any()
+    assert gpu.read_tally(100) == ref.read_tally(100)
+    with pytest.raises(fa.FpxError):
+        gpu.proxy_forget(0, S + 1)
