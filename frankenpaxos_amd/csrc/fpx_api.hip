@@ -45,6 +45,7 @@ struct fpx_ctx {
   uint32_t hrun = 0;
   std::vector<int32_t> hround;
   // kernel timing (fpx_profile_*)
+  void* slab = nullptr;  // vote_round | vote_value | ballot
   bool profiling = false;
   std::vector<hipEvent_t> ev;  // start/stop pairs
   size_t ev_used = 0;
@@ -290,7 +291,7 @@ int init_state(fpx_ctx* ctx) {
 
 void free_state(fpx_ctx* ctx) {
   State& st = ctx->st;
-  void* ps[] = {st.promised, st.max_voted, st.vote_round, st.vote_value, st.ballot, st.pl_key, st.pl_value,
+  void* ps[] = {st.promised, st.max_voted, ctx->slab, st.pl_key, st.pl_value,
                 st.pl_bits,  st.stamp,     st.run_round,  st.status,     st.part,
                 st.log_value, st.log_present, st.log_scalars, st.rt_key, st.rt_bits, st.part_cnt, st.part_all};
   for (void* p : ps)
@@ -466,9 +467,22 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
   const size_t ncell = (size_t)g.S * g.R, nsc = (size_t)g.ngroups * g.R;
   if ((rc = dalloc(ctx, &st.promised, nsc))) return fail(rc);
   if ((rc = dalloc(ctx, &st.max_voted, nsc))) return fail(rc);
-  if ((rc = dalloc(ctx, &st.vote_round, ncell))) return fail(rc);
-  if ((rc = dalloc(ctx, &st.vote_value, ncell))) return fail(rc);
-  if (g.per_slot && (rc = dalloc(ctx, &st.ballot, ncell))) return fail(rc);
+  {
+    // the 2-3 cell arrays are streamed in lockstep (row s of each at the same time): one slab, the
+    // arrays staggered by FPX_STAGGER bytes so that their rows do not all start in the same DRAM
+    // channel / bank (tuning aid; measured in profiles/r01_stagger.txt)
+    size_t stagger = 0;
+    if (const char* e = getenv("FPX_STAGGER")) stagger = (size_t)atoll(e) & ~(size_t)15;
+    const int narr = g.per_slot ? 3 : 2;
+    const size_t stride = ncell * 4 + stagger;
+    char* slab = nullptr;
+    if (hipMalloc((void**)&slab, stride * narr) != hipSuccess) return fail(FPX_ENOMEM);
+    ctx->bytes += (int64_t)(stride * narr);
+    ctx->slab = slab;
+    st.vote_round = (int32_t*)slab;
+    st.vote_value = (int32_t*)(slab + stride);
+    st.ballot = g.per_slot ? (int32_t*)(slab + 2 * stride) : nullptr;
+  }
   if ((rc = dalloc(ctx, &st.pl_key, (size_t)g.S * g.wp))) return fail(rc);
   if ((rc = dalloc(ctx, &st.pl_value, (size_t)g.S * g.wp))) return fail(rc);
   if ((rc = dalloc(ctx, &st.pl_bits, (size_t)g.S * g.wp * 4))) return fail(rc);
