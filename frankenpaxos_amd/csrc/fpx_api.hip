@@ -791,16 +791,12 @@ int32_t fpx_acceptor_phase1a(fpx_ctx* ctx, int32_t group, int32_t round, int32_t
   } else {
     hipLaunchKernelGGL(k_phase1a_perslot, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, ctx->g, ctx->st, group,
                        round, chosen_watermark, d_tgt, d_out);
+    // promised = the targeted acceptors none of whose cells was ahead (second, tiny kernel)
+    hipLaunchKernelGGL(k_phase1a_perslot_finish, dim3((ctx->g.R + 63) / 64), dim3(64), 0, ctx->stream, ctx->g, d_tgt,
+                       d_out);
     if ((rc = launch_check(ctx))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(h, d_out, 64, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    // promised = targeted own acceptors that did not nack
-    for (int r = 0; r < ctx->g.R; ++r) {
-      const int bit = ctx->g.base + r;
-      const bool tgt = !target_mask || ((target_mask[bit >> 6] >> (bit & 63)) & 1ull);
-      const bool nck = (h[4 + (bit >> 6)] >> (bit & 63)) & 1ull;
-      if (tgt && !nck) h[bit >> 6] |= 1ull << (bit & 63);
-    }
   }
   if (promised_bits) memcpy(promised_bits, h, 32);
   if (nack_bits) memcpy(nack_bits, h + 4, 32);

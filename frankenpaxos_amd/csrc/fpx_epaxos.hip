@@ -2,15 +2,17 @@
 //
 // Per replica the conflict scan is a segmented (by key) exclusive prefix-max over the tick's commands
 // in that replica's delivery order, on n-wide watermark vectors (util/TopOne.scala): data-parallel as
-//   1. k_epx_keys      sort key (key << 32 | rank in the replica's order) per (replica, message)
-//   2. rocprim radix sort per replica            (a plain library primitive; everything else is hand-written)
+//   1. k_epx_keys      scatter every command to its position in the replica's delivery order (rank is a
+//                      permutation) + the tick's own TopOne contribution per key (atomicMax, once per command)
+//   2. rocprim radix sort per replica on the key bits only (stable => (key, delivery order)); a plain
+//                      library primitive, everything else is hand-written
 //   3. k_epx_segments  [lo, hi) of every (replica, key) segment by binary search
 //   4. k_epx_scan<N>   one wavefront per (replica, key): 64 commands per step, wave-level max-scan of the
 //                      2N watermark columns with __shfl_up, carry in registers
 //   5. k_epx_decide<N> one thread per command: PreAcceptOk = local conflicts U leader's deps; fast path iff
 //                      the n-2 answers agree (Util.popularItems), else the union (preAcceptingSlowPath)
 //   6. k_epx_commit    every replica's conflict index learns the tick's instances (commit ->
-//                      updateConflictIndex)
+//                      updateConflictIndex): elementwise max with the per-key tick table
 // Integer max / compare only: HBM- and latency-bound, no MFMA.
 #include <hip/hip_runtime.h>
 
@@ -39,9 +41,10 @@ struct EpxBatch {
   const uint8_t* is_set;
   const uint8_t* resp_mask;
   const int32_t* rank;   // [n][m]
-  uint64_t* sk;          // [n][m] sort keys
+  uint32_t* sk;          // [n][m] sort keys: the command's key, in the replica's delivery order
   int32_t* sv;           // [n][m] sort values (message index)
-  uint64_t* sk_sorted;   // [n][m]
+  uint32_t* sk_sorted;   // [n][m]
+  int32_t* tick;         // [num_keys][2][n] the tick's own TopOne contribution per key (gets, sets)
   int32_t* sv_sorted;    // [n][m]
   int32_t* seg;          // [n][num_keys][2]
   int32_t* conf;         // [m][n][n] local conflicts of replica r for message i
@@ -66,18 +69,28 @@ __global__ void __launch_bounds__(256) k_epx_keys(const EpxState st, const EpxBa
     const int p = b.rank[(size_t)r * b.m + i];
     ok = ok && p >= 0 && p < b.m;
     const bool part = ok && (r == L || ((mask >> r) & 1u));
-    b.sk[(size_t)r * b.m + i] = part ? (((uint64_t)(uint32_t)k << 32) | (uint32_t)p) : ~0ull;
-    b.sv[(size_t)r * b.m + i] = i;
+    // rank is a permutation: scattering to position p lays the tick out in replica r's delivery order;
+    // a stable sort by key alone then yields (key, delivery order).  Non-participants sort last.
+    if (ok) {
+      b.sk[(size_t)r * b.m + p] = part ? (uint32_t)k : (uint32_t)st.num_keys;
+      b.sv[(size_t)r * b.m + p] = i;
+    }
   }
-  if (!ok) epx_report(st.status, FPX_EINVAL, i);
+  if (!ok) {
+    epx_report(st.status, FPX_EINVAL, i);
+    return;
+  }
+  // what every replica's conflict index learns from this tick (commit -> updateConflictIndex): once per
+  // key, not once per replica
+  atomicMax(&b.tick[((size_t)k * 2 + (b.is_set[i] ? 1 : 0)) * n + L], b.number[i] + 1);
 }
 
 __global__ void __launch_bounds__(256) k_epx_segments(const EpxState st, const EpxBatch b) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= st.n * st.num_keys) return;
   const int r = t / st.num_keys, k = t % st.num_keys;
-  const uint64_t* a = b.sk_sorted + (size_t)r * b.m;
-  auto lower = [&](uint64_t x) {
+  const uint32_t* a = b.sk_sorted + (size_t)r * b.m;
+  auto lower = [&](uint32_t x) {
     int lo = 0, hi = b.m;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
@@ -85,8 +98,8 @@ __global__ void __launch_bounds__(256) k_epx_segments(const EpxState st, const E
     }
     return lo;
   };
-  b.seg[(size_t)t * 2] = lower((uint64_t)(uint32_t)k << 32);
-  b.seg[(size_t)t * 2 + 1] = lower((uint64_t)(uint32_t)(k + 1) << 32);
+  b.seg[(size_t)t * 2] = lower((uint32_t)k);
+  b.seg[(size_t)t * 2 + 1] = lower((uint32_t)(k + 1));
 }
 
 // one wavefront per (replica, key) segment
@@ -179,11 +192,17 @@ __global__ void __launch_bounds__(256) k_epx_decide(const EpxState st, const Epx
 
 __global__ void __launch_bounds__(256) k_epx_commit(const EpxState st, const EpxBatch b) {
   if (st.status[0] != 0) return;
+  const long long per = (long long)st.num_keys * st.n;            // entries of one replica's gets (or sets)
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long)b.m * st.n) return;
-  const int i = (int)(t / st.n), r = (int)(t % st.n);
-  int32_t* base = b.is_set[i] ? st.sets : st.gets;
-  atomicMax(&base[((size_t)r * st.num_keys + b.key[i]) * st.n + b.leader[i]], b.number[i] + 1);
+  if (t >= per * st.n) return;
+  const int r = (int)(t / per);
+  const long long e = t % per;                                    // key * n + leader
+  const int k = (int)(e / st.n), l = (int)(e % st.n);
+  const int tg = b.tick[((size_t)k * 2 + 0) * st.n + l], ts = b.tick[((size_t)k * 2 + 1) * st.n + l];
+  int32_t* g = &st.gets[(size_t)r * per + e];
+  int32_t* s2 = &st.sets[(size_t)r * per + e];
+  if (tg > *g) *g = tg;
+  if (ts > *s2) *s2 = ts;
 }
 
 struct Buf {
@@ -198,7 +217,7 @@ struct fpx_epx {
   EpxState st;
   hipStream_t stream = nullptr, own_stream = nullptr;
   int last_hip = 0;
-  Buf sk, sv, sk2, sv2, seg, conf, tmp, h_leader, h_number, h_key, h_set, h_mask, h_rank, o_fast, o_deps, o_ldeps;
+  Buf sk, sv, sk2, sv2, seg, conf, tmp, tick, h_leader, h_number, h_key, h_set, h_mask, h_rank, o_fast, o_deps, o_ldeps;
 };
 
 namespace {
@@ -272,7 +291,7 @@ int32_t fpx_epx_destroy(fpx_epx* e) {
   void* ps[] = {e->st.gets, e->st.sets, e->st.status};
   for (void* p : ps)
     if (p) (void)hipFree(p);
-  Buf* bs[] = {&e->sk, &e->sv, &e->sk2, &e->sv2, &e->seg, &e->conf, &e->tmp, &e->h_leader, &e->h_number,
+  Buf* bs[] = {&e->sk, &e->sv, &e->sk2, &e->sv2, &e->seg, &e->conf, &e->tmp, &e->tick, &e->h_leader, &e->h_number,
                &e->h_key, &e->h_set, &e->h_mask, &e->h_rank, &e->o_fast, &e->o_deps, &e->o_ldeps};
   for (Buf* b : bs)
     if (b->p) (void)hipFree(b->p);
@@ -307,8 +326,10 @@ int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, co
   if (m == 0) return FPX_OK;
   const int n = e->st.n;
   int rc;
-  if ((rc = grow(e, &e->sk, (size_t)n * m * 8))) return rc;
-  if ((rc = grow(e, &e->sk2, (size_t)n * m * 8))) return rc;
+  if ((rc = grow(e, &e->sk, (size_t)n * m * 4))) return rc;
+  if ((rc = grow(e, &e->sk2, (size_t)n * m * 4))) return rc;
+  if ((rc = grow(e, &e->tick, (size_t)e->st.num_keys * 2 * n * 4))) return rc;
+  EHIP(e, hipMemsetAsync(e->tick.p, 0, (size_t)e->st.num_keys * 2 * n * 4, e->stream));
   if ((rc = grow(e, &e->sv, (size_t)n * m * 4))) return rc;
   if ((rc = grow(e, &e->sv2, (size_t)n * m * 4))) return rc;
   if ((rc = grow(e, &e->seg, (size_t)n * e->st.num_keys * 8))) return rc;
@@ -317,18 +338,21 @@ int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, co
   memset(&b, 0, sizeof(b));
   b.m = m, b.leader = d_leader, b.number = d_number, b.key = d_key, b.is_set = d_is_set, b.resp_mask = d_resp_mask;
   b.rank = d_rank;
-  b.sk = (uint64_t*)e->sk.p, b.sv = (int32_t*)e->sv.p, b.sk_sorted = (uint64_t*)e->sk2.p, b.sv_sorted = (int32_t*)e->sv2.p;
+  b.sk = (uint32_t*)e->sk.p, b.sv = (int32_t*)e->sv.p, b.sk_sorted = (uint32_t*)e->sk2.p, b.sv_sorted = (int32_t*)e->sv2.p;
+  b.tick = (int32_t*)e->tick.p;
   b.seg = (int32_t*)e->seg.p, b.conf = (int32_t*)e->conf.p;
   b.fast = d_fast, b.deps = d_deps, b.leader_deps = d_leader_deps;
   hipLaunchKernelGGL(k_epx_keys, dim3((m + 255) / 256), dim3(256), 0, e->stream, e->st, b);
-  // the keys are (key, rank): sort all 64 bits (non-participants are ~0 and end up last)
+  // stable LSD radix sort on the key bits only (the sequence already is in delivery order)
+  unsigned bits = 1;
+  while ((1u << bits) <= (unsigned)e->st.num_keys) ++bits;
   size_t tmp_bytes = 0;
-  EHIP(e, rocprim::radix_sort_pairs(nullptr, tmp_bytes, b.sk, b.sk_sorted, b.sv, b.sv_sorted, (size_t)m, 0, 64, e->stream));
+  EHIP(e, rocprim::radix_sort_pairs(nullptr, tmp_bytes, b.sk, b.sk_sorted, b.sv, b.sv_sorted, (size_t)m, 0, bits, e->stream));
   if ((rc = grow(e, &e->tmp, tmp_bytes))) return rc;
   for (int r = 0; r < n; ++r) {
     size_t tb = e->tmp.cap;
     EHIP(e, rocprim::radix_sort_pairs(e->tmp.p, tb, b.sk + (size_t)r * m, b.sk_sorted + (size_t)r * m,
-                                      b.sv + (size_t)r * m, b.sv_sorted + (size_t)r * m, (size_t)m, 0, 64, e->stream));
+                                      b.sv + (size_t)r * m, b.sv_sorted + (size_t)r * m, (size_t)m, 0, bits, e->stream));
   }
   const int segs = n * e->st.num_keys;
   hipLaunchKernelGGL(k_epx_segments, dim3((segs + 255) / 256), dim3(256), 0, e->stream, e->st, b);
@@ -337,7 +361,7 @@ int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, co
     case 5: launch_scan_decide<5>(e, b); break;
     default: launch_scan_decide<7>(e, b); break;
   }
-  const long long tot = (long long)m * n;
+  const long long tot = (long long)e->st.num_keys * n * n;
   hipLaunchKernelGGL(k_epx_commit, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, e->stream, e->st, b);
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) {

@@ -799,6 +799,15 @@ __global__ void __launch_bounds__(256) k_phase1a_perslot(const Geom g, const Sta
   }
 }
 
+__global__ void k_phase1a_perslot_finish(const Geom g, const uint64_t* target, uint64_t* out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= g.R) return;
+  const int bit = g.base + r;
+  const bool tgt = !target || ((target[bit >> 6] >> (bit & 63)) & 1ull);
+  const bool nck = (out[4 + (bit >> 6)] >> (bit & 63)) & 1ull;
+  if (tgt && !nck) atomicOr((unsigned long long*)&out[bit >> 6], 1ull << (bit & 63));
+}
+
 // ------------------------------------------------------------------------------------------------
 // a5 standalone: n node sets -> isWriteQuorum / isReadQuorum (strict: foreign bit => status EINVAL)
 // ------------------------------------------------------------------------------------------------
