@@ -75,8 +75,9 @@ class Context:
             raise FpxError(st, "fpx_reset")
 
     def set_stream(self, hip_stream):
-        """hip_stream: integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or None"""
-        st = self.L.fpx_set_stream(self._h, hip_stream)
+        """hip_stream: integer hipStream_t, e.g. torch.cuda.current_stream().cuda_stream (0 = the
+        device's default stream); None selects the context's private stream (FPX_STREAM_OWN)"""
+        st = self.L.fpx_set_stream(self._h, C.c_void_p(-1 if hip_stream is None else int(hip_stream)))
         if st:
             raise FpxError(st, "fpx_set_stream")
 

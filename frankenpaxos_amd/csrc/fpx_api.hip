@@ -46,6 +46,7 @@ struct fpx_ctx {
   std::vector<int32_t> hround;
   // kernel timing (fpx_profile_*)
   void* slab = nullptr;  // vote_round | vote_value | ballot
+  uint32_t phase2_launches = 0;
   bool profiling = false;
   std::vector<hipEvent_t> ev;  // start/stop pairs
   size_t ev_used = 0;
@@ -211,6 +212,7 @@ int enqueue_phase2(fpx_ctx* ctx, Batch& b, bool fused) {
   int rc = enqueue_validate(ctx, b, true);
   if (rc) return rc;
   const int grid = grid_for(ctx, b.n);
+  b.parity = (int32_t)(ctx->phase2_launches++ & 1u);  // every K1 / K3 launch is followed by its k_finalize
   const bool prof = ctx->profiling && ctx->ev_used + 2 <= ctx->ev.size();
   if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[ctx->ev_used], ctx->stream));
   launch_phase2(ctx, b, fused, grid);
@@ -222,7 +224,7 @@ int enqueue_phase2(fpx_ctx* ctx, Batch& b, bool fused) {
   }
   const int ntab = ctx->g.ngroups * ctx->g.R;
   hipLaunchKernelGGL(k_finalize, dim3((ntab + 63) / 64, FINALIZE_SLICES), dim3(256), 0, ctx->stream, ctx->g, ctx->st,
-                     (int)(b.run_id & 1u));
+                     (int)b.parity);
   return launch_check(ctx);
 }
 
@@ -489,6 +491,7 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
   if ((rc = dalloc(ctx, &st.stamp, (size_t)g.S))) return fail(rc);
   if ((rc = dalloc(ctx, &st.run_round, (size_t)g.ngroups))) return fail(rc);
   if ((rc = dalloc(ctx, &st.status, (size_t)8))) return fail(rc);
+  ctx->g.part_rows = ctx->max_grid;
   if ((rc = dalloc(ctx, &st.part, (size_t)ctx->max_grid * 2 * ntab))) return fail(rc);
   if ((rc = dalloc(ctx, &st.part_cnt, (size_t)2))) return fail(rc);
   if ((rc = dalloc(ctx, &st.part_all, (size_t)2 * 64 * PART_ALL_STRIDE))) return fail(rc);
@@ -520,7 +523,7 @@ int32_t fpx_reset(fpx_ctx* ctx) {
 int32_t fpx_set_stream(fpx_ctx* ctx, void* hip_stream) {
   if (!ctx) return FPX_EINVAL;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  ctx->stream = hip_stream == FPX_STREAM_OWN ? ctx->own_stream : (hipStream_t)hip_stream;
   return FPX_OK;
 }
 

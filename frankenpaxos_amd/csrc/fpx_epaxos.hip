@@ -303,7 +303,7 @@ int32_t fpx_epx_destroy(fpx_epx* e) {
 int32_t fpx_epx_set_stream(fpx_epx* e, void* hip_stream) {
   if (!e) return FPX_EINVAL;
   EHIP(e, hipStreamSynchronize(e->stream));
-  e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+  e->stream = hip_stream == FPX_STREAM_OWN ? e->own_stream : (hipStream_t)hip_stream;
   return FPX_OK;
 }
 

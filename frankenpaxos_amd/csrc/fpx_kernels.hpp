@@ -71,6 +71,7 @@ struct Geom {
   int32_t ways, wp;                                // tally ways, padded row length (4 or 8)
   int32_t base, total;                             // replica_base, replicas_total
   uint64_t member[4];                              // bits [0, total)
+  int32_t part_rows;                               // rows of State::part (= the largest launch grid)
 };
 
 struct State {
@@ -110,6 +111,7 @@ struct Batch {
   uint8_t* is_new;         // k_open
   const uint8_t* mask;     // k_log_ingest: which messages are Chosen (null = all)
   uint32_t run_id;
+  int32_t parity;          // K1 / K3 launch counter & 1: which half of part_cnt / part_all this launch uses
   int32_t check_round;     // validate: enforce one round per group (ACCEPTOR ballot mode)
 };
 
@@ -595,7 +597,7 @@ __global__ void __launch_bounds__(256)
   //     atomics per wavefront into a 64-way sharded table (the common case: nothing else to do);
   // (b) everything else went through registers / LDS tables: the workgroup appends ONE row to the
   //     partial table, claimed with a counter, only if it saw such a step.
-  const int par = b.run_id & 1u;
+  const int par = b.parity;
   if (lane == 0 && w_slot >= 0) {  // wave -> workgroup (LDS)
     atomicMax(&blk_flag[2], w_round);
     atomicMax(&blk_flag[3], w_slot);
@@ -622,8 +624,10 @@ __global__ void __launch_bounds__(256)
   if (blk_flag[0]) {
     if (threadIdx.x == 0) blk_flag[1] = atomicAdd(&st.part_cnt[par], 1);
     __syncthreads();
-    int32_t* prow = st.part + (size_t)blk_flag[1] * 2 * ntab;
-    for (int i = threadIdx.x; i < 2 * ntab; i += blockDim.x) prow[i] = tab_pr[i];
+    if (blk_flag[1] < g.part_rows) {  // always true unless a finalize launch was lost: never write out of bounds
+      int32_t* prow = st.part + (size_t)blk_flag[1] * 2 * ntab;
+      for (int i = threadIdx.x; i < 2 * ntab; i += blockDim.x) prow[i] = tab_pr[i];
+    }
   }
 }
 
@@ -644,7 +648,7 @@ __global__ void __launch_bounds__(256) k_finalize(const Geom g, const State st, 
   }
   if (st.status[ST_CODE] != 0) return;
   const int ntab = g.ngroups * g.R;
-  const int nblocks = st.part_cnt[par];
+  const int nblocks = st.part_cnt[par] < g.part_rows ? st.part_cnt[par] : g.part_rows;
   const int e = blockIdx.x * 64 + (threadIdx.x & 63);
   const int slice = threadIdx.x >> 6;
   int pr = -1, mvs = -1;

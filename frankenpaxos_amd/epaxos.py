@@ -52,7 +52,7 @@ class EPaxos:
             pass
 
     def set_stream(self, s):
-        st = self.L.fpx_epx_set_stream(self._h, s)
+        st = self.L.fpx_epx_set_stream(self._h, C.c_void_p(-1 if s is None else int(s)))
         if st:
             raise FpxError(st, "fpx_epx_set_stream")
 

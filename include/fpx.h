@@ -126,7 +126,11 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out);
 int32_t fpx_destroy(fpx_ctx* ctx);
 /* re-initialises all state to the freshly-created state (device memset, async on the stream) */
 int32_t fpx_reset(fpx_ctx* ctx);
-/* hip_stream is a hipStream_t; NULL selects the context's own stream */
+/* hip_stream is a hipStream_t passed through as it is: NULL is the device's default (null) stream --
+ * which is what torch.cuda.current_stream().cuda_stream is unless the caller switched streams --
+ * and FPX_STREAM_OWN selects the context's private stream (the state after fpx_create).  The _dev
+ * entry points enqueue on this stream: device inputs must be produced on it (or ordered before it). */
+#define FPX_STREAM_OWN ((void*)(intptr_t)-1)
 int32_t fpx_set_stream(fpx_ctx* ctx, void* hip_stream);
 /* waits for the stream; returns the sticky device status of the _dev calls since the last sync
  * (FPX_OK, FPX_EORDER, FPX_ECAPACITY, FPX_EFATAL_UNKNOWN_SLOTROUND, FPX_EINVAL) and clears it */

@@ -452,3 +452,28 @@ def test_full_size_grid_properties(fa, ballot_mode):
     gpu2.acceptor_phase1a(0, 5, 0, ahead)
     st, ch2, cr2, cv2, nr2 = gpu2.phase2_fused(slot[:4096], rnd[:4096] + 2, val[:4096])
     assert st == 0 and ch2.all() and (cr2 == 2).all() and (nr2 == 5).all()
+
+
+def test_dev_inputs_produced_on_the_torch_stream_are_ordered(fa):
+    """Regression (r01): torch.cuda.current_stream().cuda_stream is 0 (the default stream) unless the
+    caller switched streams; fpx_set_stream must take it as the default stream, not as "use the private
+    stream" -- otherwise the _dev kernels race with the torch kernels that produce their inputs."""
+    import torch
+
+    S, R = 1 << 20, 256
+    dev = torch.device("cuda:0")
+    gpu = fa.Context(fa.make_config(num_slots=S, num_replicas=R, f=127, flags=fa.FPX_F_TRUSTED))
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    for rep in range(3):
+        # a long chain of torch kernels whose LAST result is the slot array; no synchronisation
+        x = torch.rand(1 << 24, device=dev)
+        perm = torch.argsort(x)[:S] % S
+        slot = torch.unique(perm.to(torch.int32))            # distinct slots, produced just in time
+        rnd = torch.full_like(slot, rep)
+        val = slot * 3 + 1
+        ch = torch.zeros(slot.numel(), dtype=torch.uint8, device=dev)
+        cv = torch.zeros(slot.numel(), dtype=torch.int32, device=dev)
+        gpu.phase2_fused_dev(slot, rnd, val, None, ch, None, cv)
+        assert gpu.sync() == 0
+        assert bool(ch.all()) and bool((cv == val).all())
+    gpu.set_stream(None)
