@@ -96,6 +96,7 @@ void make_geom(const fpx_config& c, Geom* g) {
   memset(g, 0, sizeof(*g));
   g->S = c.num_slots;
   g->R = c.num_replicas;
+  g->RS = (c.num_replicas + 3) & ~3;
   g->num_groups = c.num_groups;
   g->num_leader_groups = c.num_leader_groups;
   g->ngroups = c.num_groups * c.num_leader_groups;
@@ -159,14 +160,9 @@ void launch_phase2_3(fpx_ctx* ctx, const Batch& b, bool fused, int grid) {
 
 template <int G>
 void launch_phase2_2(fpx_ctx* ctx, const Batch& b, bool fused, int grid) {
-  const bool ps = ctx->g.per_slot != 0;
-  if (ctx->vec) {
-    if (ps) launch_phase2_3<G, true, true>(ctx, b, fused, grid);
-    else launch_phase2_3<G, true, false>(ctx, b, fused, grid);
-  } else {
-    if (ps) launch_phase2_3<G, false, true>(ctx, b, fused, grid);
-    else launch_phase2_3<G, false, false>(ctx, b, fused, grid);
-  }
+  // rows are padded to a multiple of 4 cells (Geom::RS), so the int4 (VEC) instantiation serves every R
+  if (ctx->g.per_slot) launch_phase2_3<G, true, true>(ctx, b, fused, grid);
+  else launch_phase2_3<G, true, false>(ctx, b, fused, grid);
 }
 
 void launch_phase2(fpx_ctx* ctx, const Batch& b, bool fused, int grid) {
@@ -262,7 +258,7 @@ int fetch_status(fpx_ctx* ctx) {
 int init_state(fpx_ctx* ctx) {
   const Geom& g = ctx->g;
   State& st = ctx->st;
-  const size_t ncell = (size_t)g.S * g.R, nsc = (size_t)g.ngroups * g.R;
+  const size_t ncell = (size_t)g.S * g.RS, nsc = (size_t)g.ngroups * g.R;
   HIPCHK(ctx, hipMemsetAsync(st.promised, 0xFF, nsc * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.max_voted, 0xFF, nsc * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.vote_round, 0xFF, ncell * 4, ctx->stream));
@@ -452,7 +448,7 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
   int G = 1;
   while (G * 4 < ctx->g.R) G <<= 1;
   ctx->lanes_per_slot = G;
-  ctx->vec = (ctx->g.R % 4) == 0;
+  ctx->vec = true;  // rows are padded to a multiple of 4 cells (Geom::RS)
   // big tables: fewer resident blocks so that the partial table stays small
   const int ntab = ctx->g.ngroups * ctx->g.R;
   if (ntab > 1024) ctx->max_grid = std::max(ctx->num_cus, ctx->max_grid * 1024 / ntab);
@@ -466,7 +462,7 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
   ctx->stream = ctx->own_stream;
   const Geom& g = ctx->g;
   State& st = ctx->st;
-  const size_t ncell = (size_t)g.S * g.R, nsc = (size_t)g.ngroups * g.R;
+  const size_t ncell = (size_t)g.S * g.RS, nsc = (size_t)g.ngroups * g.R;
   if ((rc = dalloc(ctx, &st.promised, nsc))) return fail(rc);
   if ((rc = dalloc(ctx, &st.max_voted, nsc))) return fail(rc);
   {
@@ -1002,15 +998,18 @@ int32_t fpx_leader_phase1b_scan(fpx_ctx* ctx, int32_t chosen_watermark, const ui
 // ---- readback ----------------------------------------------------------------------------------------
 int32_t fpx_read_state(fpx_ctx* ctx, int32_t* vote_round, int32_t* vote_value, int32_t* ballot) {
   if (!ctx) return FPX_EINVAL;
-  const size_t ncell = (size_t)ctx->g.S * ctx->g.R;
+  const size_t S = (size_t)ctx->g.S, R = (size_t)ctx->g.R, RS = (size_t)ctx->g.RS;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  if (vote_round) HIPCHK(ctx, hipMemcpy(vote_round, ctx->st.vote_round, ncell * 4, hipMemcpyDeviceToHost));
-  if (vote_value) HIPCHK(ctx, hipMemcpy(vote_value, ctx->st.vote_value, ncell * 4, hipMemcpyDeviceToHost));
+  // device rows are RS cells long, the caller's are R
+  if (vote_round)
+    HIPCHK(ctx, hipMemcpy2D(vote_round, R * 4, ctx->st.vote_round, RS * 4, R * 4, S, hipMemcpyDeviceToHost));
+  if (vote_value)
+    HIPCHK(ctx, hipMemcpy2D(vote_value, R * 4, ctx->st.vote_value, RS * 4, R * 4, S, hipMemcpyDeviceToHost));
   if (ballot) {
     if (ctx->st.ballot)
-      HIPCHK(ctx, hipMemcpy(ballot, ctx->st.ballot, ncell * 4, hipMemcpyDeviceToHost));
+      HIPCHK(ctx, hipMemcpy2D(ballot, R * 4, ctx->st.ballot, RS * 4, R * 4, S, hipMemcpyDeviceToHost));
     else
-      std::fill(ballot, ballot + ncell, -1);
+      std::fill(ballot, ballot + S * R, -1);
   }
   return FPX_OK;
 }

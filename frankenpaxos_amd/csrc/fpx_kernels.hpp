@@ -64,6 +64,8 @@ enum { ST_CODE = 0, ST_INDEX = 1, ST_SLOT = 2, ST_ROUND = 3 };
 
 struct Geom {
   int32_t S, R;
+  int32_t RS;                                      // row stride of the cell arrays: R rounded up to a multiple of 4,
+                                                   // so that every lane moves one aligned int4 whatever R is
   int32_t num_groups, num_leader_groups, ngroups;  // ngroups = num_leader_groups * num_groups
   int32_t qkind, qsize;                            // qsize: threshold for THRESHOLD / MAJORITY / UNANIMOUS
   int32_t grid_rows, grid_cols;
@@ -410,7 +412,7 @@ __global__ void __launch_bounds__(256)
       grp_out = 0;
       int4v thr = init_thr;
       if (s >= 0) {
-        const size_t row = (size_t)s * (size_t)g.R + (size_t)r0;
+        const size_t row = (size_t)s * (size_t)g.RS + (size_t)r0;
         if (!one_group) grp_out = group_of_slot(g, s);
         if (PERSLOT) {
           if (VEC) {
@@ -467,14 +469,16 @@ __global__ void __launch_bounds__(256)
       }
       // Acceptor.scala:204-208: round = phase2a.round; states(slot) = State(round, value)
       if (acc) {
-        const size_t row = (size_t)s * (size_t)g.R + (size_t)r0;
-        if (VEC && acc == 0xFu) {
+        const size_t row = (size_t)s * (size_t)g.RS + (size_t)r0;
+        // whole-lane fast path: every acceptor this lane owns voted (padding cells may be overwritten)
+        if (VEC && (acc | (~own & 0xFu)) == 0xFu) {
           const int4v rr = {rnd, rnd, rnd, rnd};
           const int4v vv = {val, val, val, val};
           row_store(rr, reinterpret_cast<int4v*>(st.vote_round + row));
           row_store(vv, reinterpret_cast<int4v*>(st.vote_value + row));
           if (PERSLOT) {
-            if (thr[0] != rnd || thr[1] != rnd || thr[2] != rnd || thr[3] != rnd)
+            if (((own & 1u) && thr[0] != rnd) || ((own & 2u) && thr[1] != rnd) || ((own & 4u) && thr[2] != rnd) ||
+                ((own & 8u) && thr[3] != rnd))
               row_store(rr, reinterpret_cast<int4v*>(st.ballot + row));
           }
         } else {
@@ -786,12 +790,12 @@ __global__ void k_phase1a_scalar(const Geom g, const State st, int group, int ro
 // marks its acceptor as nacking.
 __global__ void __launch_bounds__(256) k_phase1a_perslot(const Geom g, const State st, int group, int round,
                                                          int watermark, const uint64_t* target, uint64_t* out) {
-  const size_t ncell = (size_t)g.S * g.R;
-  const size_t first = (size_t)(watermark < 0 ? 0 : watermark) * g.R;
+  const size_t ncell = (size_t)g.S * g.RS;
+  const size_t first = (size_t)(watermark < 0 ? 0 : watermark) * g.RS;
   for (size_t c = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncell;
        c += (size_t)gridDim.x * blockDim.x) {
-    const int s = (int)(c / g.R), r = (int)(c % g.R);
-    if (group_of_slot(g, s) != group) continue;
+    const int s = (int)(c / g.RS), r = (int)(c % g.RS);
+    if (r >= g.R || group_of_slot(g, s) != group) continue;
     const int bit = g.base + r;
     if (target && !((target[bit >> 6] >> (bit & 63)) & 1ull)) continue;
     const int cur = st.ballot[c];
@@ -843,7 +847,7 @@ __global__ void __launch_bounds__(256) k_gather_acceptor(const Geom g, const Sta
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= g.S) return;
   const bool mine = group_of_slot(g, s) == group;
-  const size_t c = (size_t)s * g.R + replica;
+  const size_t c = (size_t)s * g.RS + replica;
   vr[s] = mine ? st.vote_round[c] : -1;
   vv[s] = mine ? st.vote_value[c] : -1;
   bl[s] = (mine && st.ballot) ? st.ballot[c] : -1;
@@ -897,7 +901,7 @@ __global__ void __launch_bounds__(256)
     const int r = (int)(c % g.R);
     const int ag = (s / L) % A, bit = g.base + r;
     if ((votes[(size_t)ag * 4 + (bit >> 6)] >> (bit & 63)) & 1ull) {
-      const size_t cell = (size_t)s * g.R + r;
+      const size_t cell = (size_t)s * g.RS + r;
       st.vote_round[cell] = round;  // :271-276 State(voteRound = round, voteValue = Noop)
       st.vote_value[cell] = -1;
     }
@@ -1073,7 +1077,7 @@ __global__ void __launch_bounds__(256)
     int best_round = -1, best_val = -1, best_idx = 1 << 30;
     if (live && r0 < g.R) {
       const int grp = group_of_slot(g, s);
-      const size_t row = (size_t)s * g.R + r0;
+      const size_t row = (size_t)s * g.RS + r0;
       int vr[4] = {-1, -1, -1, -1}, vv[4] = {-1, -1, -1, -1};
       if (vec) {
         const int4v a = *reinterpret_cast<const int4v*>(st.vote_round + row);
@@ -1090,7 +1094,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         // phase1b.info.find(_.slot == slot): only acceptors of the quorum that voted in the slot
-        if ((qn >> k & 1u) && vr[k] > best_round) best_round = vr[k], best_val = vv[k], best_idx = r0 + k;
+        if ((qn >> k & 1u) && r0 + k < g.R && vr[k] > best_round) best_round = vr[k], best_val = vv[k], best_idx = r0 + k;
       }
     }
     // slotInfos.maxBy(_.voteRound) across the lanes of the slot
