@@ -3,23 +3,27 @@
 // Per replica the conflict scan is a segmented (by key) exclusive prefix-max over the tick's commands
 // in that replica's delivery order, on n-wide watermark vectors (util/TopOne.scala): data-parallel as
 //   1. k_epx_keys      scatter every command to its position in the replica's delivery order (rank is a
-//                      permutation) + the tick's own TopOne contribution per key (atomicMax, once per command)
-//   2. rocprim radix sort per replica on the key bits only (stable => (key, delivery order)); a plain
-//                      library primitive, everything else is hand-written
+//                      permutation)
+//   2. k_rs_hist / k_rs_scan / k_rs_scatter   stable LSD radix sort (8-bit digits) of all replicas' sequences
+//                      at once, on the key bits only (stable => (key, delivery order)); one wavefront owns a
+//                      tile of 1024 consecutive elements and ranks equal digits with 8 ballots per 64 elements
 //   3. k_epx_segments  [lo, hi) of every (replica, key) segment by binary search
 //   4. k_epx_scan<N>   one wavefront per (replica, key): 64 commands per step, wave-level max-scan of the
-//                      2N watermark columns with __shfl_up, carry in registers
+//                      2N watermark columns on the DPP network (row_shr / row_bcast), carry in registers;
+//                      leader and get/set travel in the sort key's spare bits, the answer row is one aligned
+//                      16- / 32-byte store
 //   5. k_epx_decide<N> one thread per command: PreAcceptOk = local conflicts U leader's deps; fast path iff
 //                      the n-2 answers agree (Util.popularItems), else the union (preAcceptingSlowPath)
 //   6. k_epx_commit    every replica's conflict index learns the tick's instances (commit ->
-//                      updateConflictIndex): elementwise max with the per-key tick table
+//                      updateConflictIndex): elementwise max with what the scans saw of this tick (every
+//                      command is scanned by its leader's replica at least, so the max over replicas is the
+//                      whole tick -- no atomics anywhere)
 // Integer max / compare only: HBM- and latency-bound, no MFMA.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstring>
 #include <new>
-#include <rocprim/rocprim.hpp>
 #include <vector>
 
 #include "../../include/fpx.h"
@@ -41,17 +45,39 @@ struct EpxBatch {
   const uint8_t* is_set;
   const uint8_t* resp_mask;
   const int32_t* rank;   // [n][m]
-  uint32_t* sk;          // [n][m] sort keys: the command's key, in the replica's delivery order
-  int32_t* sv;           // [n][m] sort values (message index)
-  uint32_t* sk_sorted;   // [n][m]
-  int32_t* tick;         // [num_keys][2][n] the tick's own TopOne contribution per key (gets, sets)
-  int32_t* sv_sorted;    // [n][m]
+  uint2* kv;             // [n][m] in the replica's delivery order: x = key | is_set << 27 | leader << 28
+                         // (only the key bits are sorted on), y = message index
+  uint2* kv_sorted;      // [n][m]
+  int32_t* tick;         // [n][num_keys][2][n] the puts (gets, sets) replica r's scan saw for the key this tick
   int32_t* seg;          // [n][num_keys][2]
-  int32_t* conf;         // [m][n][n] local conflicts of replica r for message i
+  int32_t* conf;         // [m][n][NP] local conflicts of replica r for message i; rows padded to NP = 4 (n = 3)
+                         // or 8 ints so a row is one aligned 16- / 32-byte store
   uint8_t* fast;
   int32_t* deps;
   int32_t* leader_deps;
 };
+
+constexpr uint32_t EPX_KEY_MASK = (1u << 27) - 1u;
+constexpr int EPX_SET_SHIFT = 27, EPX_LEADER_SHIFT = 28;
+template <int N> struct ConfRow { static constexpr int NP = N <= 4 ? 4 : 8; };
+
+// wave64 inclusive max-scan / shifts on the DPP network (values are >= 0, so 0 is the identity): 4 row_shr
+// steps inside each row of 16, then row_bcast:15 / row_bcast:31 carry the row totals across rows
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp0(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int wave_incl_max(int v) {
+  v = imax(v, dpp0<0x111, 0xF>(v));  // row_shr:1
+  v = imax(v, dpp0<0x112, 0xF>(v));  // row_shr:2
+  v = imax(v, dpp0<0x114, 0xF>(v));  // row_shr:4
+  v = imax(v, dpp0<0x118, 0xF>(v));  // row_shr:8
+  v = imax(v, dpp0<0x142, 0xA>(v));  // row_bcast:15 -> rows 1, 3
+  v = imax(v, dpp0<0x143, 0xC>(v));  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+__device__ __forceinline__ int wave_shr1(int v) { return dpp0<0x138, 0xF>(v); }  // lane 0 gets 0
 
 __device__ __forceinline__ void epx_report(int32_t* status, int code, int index) {
   if (atomicCAS(&status[0], 0, code) == 0) status[1] = index;
@@ -72,29 +98,138 @@ __global__ void __launch_bounds__(256) k_epx_keys(const EpxState st, const EpxBa
     // rank is a permutation: scattering to position p lays the tick out in replica r's delivery order;
     // a stable sort by key alone then yields (key, delivery order).  Non-participants sort last.
     if (ok) {
-      b.sk[(size_t)r * b.m + p] = part ? (uint32_t)k : (uint32_t)st.num_keys;
-      b.sv[(size_t)r * b.m + p] = i;
+      const uint32_t flags = ((uint32_t)(b.is_set[i] ? 1 : 0) << EPX_SET_SHIFT) | ((uint32_t)L << EPX_LEADER_SHIFT);
+      b.kv[(size_t)r * b.m + p] = make_uint2((part ? (uint32_t)k : (uint32_t)st.num_keys) | flags, (uint32_t)i);
     }
   }
   if (!ok) {
     epx_report(st.status, FPX_EINVAL, i);
     return;
   }
-  // what every replica's conflict index learns from this tick (commit -> updateConflictIndex): once per
-  // key, not once per replica
-  atomicMax(&b.tick[((size_t)k * 2 + (b.is_set[i] ? 1 : 0)) * n + L], b.number[i] + 1);
+}
+
+// ---- stable LSD radix sort, 8-bit digits, all replicas in one launch (blockIdx.y = replica) ------------
+// A wavefront owns a tile of RS_TILE consecutive elements, so walking the tile 64 at a time in lane order
+// is the input order: ranking equal digits by (tile, step, lane) keeps the sort stable.
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE = 64 * RS_ITEMS;
+
+struct RsArgs {
+  int m, tiles, shift;
+  const uint2* src;  // [n][m] (key word, payload)
+  uint2* dst;
+  uint32_t* hist;  // [n][256][tiles] per-tile digit counts -> exclusive offsets within the digit
+  uint32_t* tot;   // [n][256] digit totals
+};
+
+__global__ void __launch_bounds__(256) k_rs_hist(const RsArgs a) {
+  __shared__ uint32_t h[4][256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = blockIdx.y;
+  const int tile = blockIdx.x * 4 + w;
+  for (int j = lane; j < 256; j += 64) h[w][j] = 0;
+  if (tile >= a.tiles) return;
+  const uint2* k = a.src + (size_t)r * a.m;
+  uint32_t x[RS_ITEMS];
+#pragma unroll
+  for (int it = 0; it < RS_ITEMS; ++it) {  // all the tile's loads in flight before the first LDS atomic
+    const int idx = tile * RS_TILE + it * 64 + lane;
+    x[it] = idx < a.m ? k[idx].x : 0xffffffffu;
+  }
+#pragma unroll
+  for (int it = 0; it < RS_ITEMS; ++it)
+    if (tile * RS_TILE + it * 64 + lane < a.m) atomicAdd(&h[w][(x[it] >> a.shift) & 255u], 1u);
+  for (int j = lane; j < 256; j += 64) a.hist[((size_t)r * 256 + j) * a.tiles + tile] = h[w][j];
+}
+
+// one workgroup per (replica, digit): exclusive scan of that digit's per-tile counts, in place
+__global__ void __launch_bounds__(256) k_rs_scan(const RsArgs a) {
+  __shared__ uint32_t wsum[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t* row = a.hist + ((size_t)blockIdx.y * 256 + blockIdx.x) * a.tiles;
+  uint32_t carry = 0;
+  for (int c = 0; c < a.tiles; c += 256) {
+    const int t = c + threadIdx.x;
+    const uint32_t x = t < a.tiles ? row[t] : 0u;
+    uint32_t inc = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d);
+      if (lane >= d) inc += o;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      before += j < w ? wsum[j] : 0u;
+      total += wsum[j];
+    }
+    if (t < a.tiles) row[t] = carry + before + inc - x;
+    carry += total;
+  }
+  if (threadIdx.x == 0) a.tot[blockIdx.y * 256 + blockIdx.x] = carry;
+}
+
+__global__ void __launch_bounds__(256) k_rs_scatter(const RsArgs a) {
+  __shared__ uint32_t cnt[4][256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = blockIdx.y;
+  const int tile = blockIdx.x * 4 + w;
+  if (tile >= a.tiles) return;
+  {
+    // where each digit starts (exclusive scan of the 256 totals across the wave, 4 digits per lane) plus
+    // this tile's offset within the digit
+    uint32_t t4[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t4[j] = a.tot[r * 256 + lane * 4 + j], s += t4[j];
+    uint32_t inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d);
+      if (lane >= d) inc += o;
+    }
+    uint32_t base = inc - s;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int dg = lane * 4 + j;
+      cnt[w][dg] = base + a.hist[((size_t)r * 256 + dg) * a.tiles + tile];
+      base += t4[j];
+    }
+  }
+  const uint2* src = a.src + (size_t)r * a.m;
+  uint2* dst = a.dst + (size_t)r * a.m;
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int it = 0; it < RS_ITEMS; ++it) {
+    const int idx = tile * RS_TILE + it * 64 + lane;
+    const bool valid = idx < a.m;
+    const uint2 kv = valid ? src[idx] : make_uint2(0u, 0u);
+    const uint32_t dg = (kv.x >> a.shift) & 255u;
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool on = (dg >> bit) & 1u;
+      const unsigned long long bb = __ballot(on);
+      peers &= on ? bb : ~bb;
+    }
+    const uint32_t before = __popcll(peers & lt);
+    const uint32_t at = cnt[w][dg];
+    __builtin_amdgcn_wave_barrier();
+    if (valid && before == 0) cnt[w][dg] = at + (uint32_t)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    if (valid) dst[at + before] = kv;
+  }
 }
 
 __global__ void __launch_bounds__(256) k_epx_segments(const EpxState st, const EpxBatch b) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= st.n * st.num_keys) return;
   const int r = t / st.num_keys, k = t % st.num_keys;
-  const uint32_t* a = b.sk_sorted + (size_t)r * b.m;
+  const uint2* a = b.kv_sorted + (size_t)r * b.m;
   auto lower = [&](uint32_t x) {
     int lo = 0, hi = b.m;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
-      if (a[mid] < x) lo = mid + 1; else hi = mid;
+      if ((a[mid].x & EPX_KEY_MASK) < x) lo = mid + 1; else hi = mid;
     }
     return lo;
   };
@@ -111,49 +246,50 @@ __global__ void __launch_bounds__(256) k_epx_scan(const EpxState st, const EpxBa
   if (seg >= N * st.num_keys) return;
   const int r = seg / st.num_keys, k = seg % st.num_keys;
   const int lo = b.seg[(size_t)seg * 2], hi = b.seg[(size_t)seg * 2 + 1];
-  const int32_t* sv = b.sv_sorted + (size_t)r * b.m;
+  const uint2* kvs = b.kv_sorted + (size_t)r * b.m;
+  constexpr int NP = ConfRow<N>::NP;
   int cg[N], cs[N];  // carry: the replica's TopOne vectors for this key (KeyValueStore.scala:229-230)
   const size_t ib = ((size_t)r * st.num_keys + k) * N;
 #pragma unroll
   for (int l = 0; l < N; ++l) cg[l] = st.gets[ib + l], cs[l] = st.sets[ib + l];
+  int ng[N], ns[N];  // this tick's puts alone: what the commit teaches the other replicas
+#pragma unroll
+  for (int l = 0; l < N; ++l) ng[l] = 0, ns[l] = 0;
   for (int base = lo; base < hi; base += 64) {
     const int p = base + lane;
     const bool valid = p < hi;
-    const int i = valid ? sv[p] : 0;
-    const int L = b.leader[i];
+    const uint2 kv = valid ? kvs[p] : make_uint2(0u, 0u);
+    const int i = (int)kv.y;
+    const int L = (int)(kv.x >> EPX_LEADER_SHIFT);
+    const bool t = (kv.x >> EPX_SET_SHIFT) & 1u;
     const int id1 = b.number[i] + 1;  // TopOne.put: max(.., id + 1), util/TopOne.scala:12-15
-    const bool t = b.is_set[i] != 0;
-    int ig[N], is[N];  // inclusive prefix maxima of this chunk
+    int dep[NP];
+#pragma unroll
+    for (int l = 0; l < NP; ++l) dep[l] = 0;
 #pragma unroll
     for (int l = 0; l < N; ++l) {
-      ig[l] = (valid && !t && L == l) ? id1 : 0;
-      is[l] = (valid && t && L == l) ? id1 : 0;
-    }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-      for (int l = 0; l < N; ++l) {
-        const int og = __shfl_up(ig[l], d), os = __shfl_up(is[l], d);
-        if (lane >= d) {
-          ig[l] = og > ig[l] ? og : ig[l];
-          is[l] = os > is[l] ? os : is[l];
-        }
-      }
-    }
-#pragma unroll
-    for (int l = 0; l < N; ++l) {
+      // inclusive prefix maxima of this chunk's puts into column l
+      const int ig = wave_incl_max((valid && !t && L == l) ? id1 : 0);
+      const int is = wave_incl_max((valid && t && L == l) ? id1 : 0);
       // exclusive prefix (the command's own put comes after its conflict lookup) + carry
-      int eg = __shfl_up(ig[l], 1), es = __shfl_up(is[l], 1);
-      if (lane == 0) eg = 0, es = 0;
-      eg = eg > cg[l] ? eg : cg[l];
-      es = es > cs[l] ? es : cs[l];
+      const int eg = imax(wave_shr1(ig), cg[l]);
+      const int es = imax(wave_shr1(is), cs[l]);
       // KeyValueStore.scala:259-302: a get conflicts with sets, a set with sets and gets
-      const int dep = t ? (es > eg ? es : eg) : es;
-      if (valid) b.conf[((size_t)i * N + r) * N + l] = dep;
-      const int tg = __shfl(ig[l], 63), ts = __shfl(is[l], 63);
-      cg[l] = tg > cg[l] ? tg : cg[l];
-      cs[l] = ts > cs[l] ? ts : cs[l];
+      dep[l] = t ? imax(es, eg) : es;
+      const int tg = __builtin_amdgcn_readlane(ig, 63), ts = __builtin_amdgcn_readlane(is, 63);
+      cg[l] = imax(cg[l], tg), cs[l] = imax(cs[l], ts);
+      ng[l] = imax(ng[l], tg), ns[l] = imax(ns[l], ts);
     }
+    if (valid) {
+      int4* row = reinterpret_cast<int4*>(b.conf + ((size_t)i * N + r) * NP);
+      row[0] = make_int4(dep[0], dep[1], dep[2], dep[3]);
+      if constexpr (NP == 8) row[1] = make_int4(dep[4], dep[5], dep[6], dep[7]);
+    }
+  }
+  if (lane == 0) {
+    int32_t* out = b.tick + (size_t)seg * 2 * N;
+#pragma unroll
+    for (int l = 0; l < N; ++l) out[l] = ng[l], out[N + l] = ns[l];
   }
 }
 
@@ -164,17 +300,32 @@ __global__ void __launch_bounds__(256) k_epx_decide(const EpxState st, const Epx
   if (i >= b.m) return;
   const int L = b.leader[i];
   const unsigned mask = b.resp_mask[i];
-  const int32_t* c = b.conf + (size_t)i * N * N;
-  int D[N], uni[N], first[N];
+  constexpr int NP = ConfRow<N>::NP;
+  const int32_t* c = b.conf + (size_t)i * N * NP;
+  auto load_row = [&](int r, int* out) {
+    const int4* row = reinterpret_cast<const int4*>(c + r * NP);
+    const int4 a = row[0];
+    int tmp[8] = {a.x, a.y, a.z, a.w, 0, 0, 0, 0};
+    if constexpr (NP == 8) {
+      const int4 b2 = row[1];
+      tmp[4] = b2.x, tmp[5] = b2.y, tmp[6] = b2.z, tmp[7] = b2.w;
+    }
 #pragma unroll
-  for (int l = 0; l < N; ++l) D[l] = c[L * N + l], uni[l] = D[l], first[l] = 0;
+    for (int l = 0; l < N; ++l) out[l] = tmp[l];
+  };
+  int D[N], uni[N], first[N];
+  load_row(L, D);
+#pragma unroll
+  for (int l = 0; l < N; ++l) uni[l] = D[l], first[l] = 0;
   bool have_first = false, all_equal = true;
   for (int r = 0; r < N; ++r) {
     if (!((mask >> r) & 1u)) continue;
     bool same = true;
+    int cr[N];
+    load_row(r, cr);
 #pragma unroll
     for (int l = 0; l < N; ++l) {
-      const int cl = c[r * N + l];
+      const int cl = cr[l];
       const int resp = cl > D[l] ? cl : D[l];  // handlePreAccept: local conflicts U preAccept.dependencies
       uni[l] = resp > uni[l] ? resp : uni[l];  // preAcceptingSlowPath: union of all answers
       if (!have_first) first[l] = resp; else same = same && (first[l] == resp);
@@ -198,7 +349,11 @@ __global__ void __launch_bounds__(256) k_epx_commit(const EpxState st, const Epx
   const int r = (int)(t / per);
   const long long e = t % per;                                    // key * n + leader
   const int k = (int)(e / st.n), l = (int)(e % st.n);
-  const int tg = b.tick[((size_t)k * 2 + 0) * st.n + l], ts = b.tick[((size_t)k * 2 + 1) * st.n + l];
+  int tg = 0, ts = 0;
+  for (int q = 0; q < st.n; ++q) {
+    const int32_t* seen = b.tick + (((size_t)q * st.num_keys + k) * 2) * st.n;
+    tg = imax(tg, seen[l]), ts = imax(ts, seen[st.n + l]);
+  }
   int32_t* g = &st.gets[(size_t)r * per + e];
   int32_t* s2 = &st.sets[(size_t)r * per + e];
   if (tg > *g) *g = tg;
@@ -217,7 +372,7 @@ struct fpx_epx {
   EpxState st;
   hipStream_t stream = nullptr, own_stream = nullptr;
   int last_hip = 0;
-  Buf sk, sv, sk2, sv2, seg, conf, tmp, tick, h_leader, h_number, h_key, h_set, h_mask, h_rank, o_fast, o_deps, o_ldeps;
+  Buf kv, kv2, seg, conf, tmp, tick, h_leader, h_number, h_key, h_set, h_mask, h_rank, o_fast, o_deps, o_ldeps;
 };
 
 namespace {
@@ -291,7 +446,7 @@ int32_t fpx_epx_destroy(fpx_epx* e) {
   void* ps[] = {e->st.gets, e->st.sets, e->st.status};
   for (void* p : ps)
     if (p) (void)hipFree(p);
-  Buf* bs[] = {&e->sk, &e->sv, &e->sk2, &e->sv2, &e->seg, &e->conf, &e->tmp, &e->tick, &e->h_leader, &e->h_number,
+  Buf* bs[] = {&e->kv, &e->kv2, &e->seg, &e->conf, &e->tmp, &e->tick, &e->h_leader, &e->h_number,
                &e->h_key, &e->h_set, &e->h_mask, &e->h_rank, &e->o_fast, &e->o_deps, &e->o_ldeps};
   for (Buf* b : bs)
     if (b->p) (void)hipFree(b->p);
@@ -326,19 +481,16 @@ int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, co
   if (m == 0) return FPX_OK;
   const int n = e->st.n;
   int rc;
-  if ((rc = grow(e, &e->sk, (size_t)n * m * 4))) return rc;
-  if ((rc = grow(e, &e->sk2, (size_t)n * m * 4))) return rc;
-  if ((rc = grow(e, &e->tick, (size_t)e->st.num_keys * 2 * n * 4))) return rc;
-  EHIP(e, hipMemsetAsync(e->tick.p, 0, (size_t)e->st.num_keys * 2 * n * 4, e->stream));
-  if ((rc = grow(e, &e->sv, (size_t)n * m * 4))) return rc;
-  if ((rc = grow(e, &e->sv2, (size_t)n * m * 4))) return rc;
+  if ((rc = grow(e, &e->kv, (size_t)n * m * 8))) return rc;
+  if ((rc = grow(e, &e->kv2, (size_t)n * m * 8))) return rc;
+  if ((rc = grow(e, &e->tick, (size_t)n * e->st.num_keys * 2 * n * 4))) return rc;
   if ((rc = grow(e, &e->seg, (size_t)n * e->st.num_keys * 8))) return rc;
-  if ((rc = grow(e, &e->conf, (size_t)m * n * n * 4))) return rc;
+  if ((rc = grow(e, &e->conf, (size_t)m * n * (n <= 4 ? 4 : 8) * 4))) return rc;
   EpxBatch b;
   memset(&b, 0, sizeof(b));
   b.m = m, b.leader = d_leader, b.number = d_number, b.key = d_key, b.is_set = d_is_set, b.resp_mask = d_resp_mask;
   b.rank = d_rank;
-  b.sk = (uint32_t*)e->sk.p, b.sv = (int32_t*)e->sv.p, b.sk_sorted = (uint32_t*)e->sk2.p, b.sv_sorted = (int32_t*)e->sv2.p;
+  b.kv = (uint2*)e->kv.p, b.kv_sorted = (uint2*)e->kv2.p;
   b.tick = (int32_t*)e->tick.p;
   b.seg = (int32_t*)e->seg.p, b.conf = (int32_t*)e->conf.p;
   b.fast = d_fast, b.deps = d_deps, b.leader_deps = d_leader_deps;
@@ -346,14 +498,21 @@ int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, co
   // stable LSD radix sort on the key bits only (the sequence already is in delivery order)
   unsigned bits = 1;
   while ((1u << bits) <= (unsigned)e->st.num_keys) ++bits;
-  size_t tmp_bytes = 0;
-  EHIP(e, rocprim::radix_sort_pairs(nullptr, tmp_bytes, b.sk, b.sk_sorted, b.sv, b.sv_sorted, (size_t)m, 0, bits, e->stream));
-  if ((rc = grow(e, &e->tmp, tmp_bytes))) return rc;
-  for (int r = 0; r < n; ++r) {
-    size_t tb = e->tmp.cap;
-    EHIP(e, rocprim::radix_sort_pairs(e->tmp.p, tb, b.sk + (size_t)r * m, b.sk_sorted + (size_t)r * m,
-                                      b.sv + (size_t)r * m, b.sv_sorted + (size_t)r * m, (size_t)m, 0, bits, e->stream));
+  RsArgs a;
+  a.m = m, a.tiles = (m + RS_TILE - 1) / RS_TILE;
+  if ((rc = grow(e, &e->tmp, ((size_t)n * 256 * a.tiles + (size_t)n * 256) * 4))) return rc;
+  a.hist = (uint32_t*)e->tmp.p, a.tot = a.hist + (size_t)n * 256 * a.tiles;
+  uint2* buf[2] = {b.kv, b.kv_sorted};
+  int cur = 0;
+  for (unsigned shift = 0; shift < bits; shift += 8, cur ^= 1) {
+    a.shift = (int)shift;
+    a.src = buf[cur], a.dst = buf[cur ^ 1];
+    const dim3 tg((a.tiles + 3) / 4, n);
+    hipLaunchKernelGGL(k_rs_hist, tg, dim3(256), 0, e->stream, a);
+    hipLaunchKernelGGL(k_rs_scan, dim3(256, n), dim3(256), 0, e->stream, a);
+    hipLaunchKernelGGL(k_rs_scatter, tg, dim3(256), 0, e->stream, a);
   }
+  b.kv_sorted = buf[cur];  // where the last pass left the sequence
   const int segs = n * e->st.num_keys;
   hipLaunchKernelGGL(k_epx_segments, dim3((segs + 255) / 256), dim3(256), 0, e->stream, e->st, b);
   switch (n) {

@@ -111,7 +111,10 @@ def random_tick(rng, n, num_keys, m, next_number, skew):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,num_keys,m,skew", [(3, 8, 500, 3.0), (5, 16, 4000, 5.0), (5, 1024, 20000, 50.0),
-                                               (7, 64, 3000, 10.0), (5, 1, 300, 2.0)])
+                                               (7, 64, 3000, 10.0), (5, 1, 300, 2.0),
+                                               # sort shapes: whole tiles / 2 digit passes, 3 digit passes,
+                                               # 255 keys + the non-participant bucket = exactly one digit
+                                               (3, 256, 2048, 4.0), (5, 70000, 5000, 20.0), (3, 255, 1025, 7.0)])
 def test_epaxos_ticks_match_oracle(oracle, n, num_keys, m, skew):
     from frankenpaxos_amd.epaxos import EPaxos
 
