@@ -73,5 +73,5 @@ with open(os.path.join(out, tag + "_pmc_summary.md"), "w") as f:
         f.write("| %s | %.1f | %.1f | %.0f | %.0f | %.0f | %d | %.4f |\n" % (label, fe, wr, rd_b, wr_b, tot, alg, tot / alg))
     f.write("\nThe ~2 % above the SURVEY.md 8(d) byte model is the proxy leader's tally table (a 16 B key row "
             "read + 4 B key written per slot), the 12 B proposal instead of 8 B (the slot index is read too), "
-            "the 1-byte chosen flag and the 8 MiB of per-workgroup maxima.  No row is read twice.\n")
+            "the 1-byte chosen flag (the whole-group maxima are two atomics per workgroup).  No row is read twice.\n")
 print(open(os.path.join(out, tag + "_pmc_summary.md")).read())
