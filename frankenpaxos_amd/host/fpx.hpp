@@ -7,6 +7,13 @@
 //   frankenpaxos.quorums.{QuorumSystem,SimpleMajority,Grid,UnanimousWrites}  quorums/*.scala
 //   frankenpaxos.multipaxos.Acceptor.handlePhase2a           multipaxos/Acceptor.scala:184-220
 //   frankenpaxos.multipaxos.ProxyLeader.handlePhase2a/2b     multipaxos/ProxyLeader.scala:175-258
+//   frankenpaxos.multipaxos.Acceptor.handlePhase1a           multipaxos/Acceptor.scala:148-182
+//   frankenpaxos.multipaxos.Replica.handleChosen             multipaxos/Replica.scala:572-590, 394-447
+//   frankenpaxos.multipaxos.Leader.handlePhase1b (safeValue) multipaxos/Leader.scala:306-329, 543-566
+//   frankenpaxos.mencius.{Acceptor,ProxyLeader}.handlePhase2aNoopRange / handlePhase2bNoopRange
+//                                                            mencius/Acceptor.scala:237-291,
+//                                                            mencius/ProxyLeader.scala:255-303, 355-411
+//   frankenpaxos.epaxos.Replica pre-accept fast path         epaxos/Replica.scala:569-600, 633-729, 1159-1419
 //
 // but batched: a handler takes the messages one event-loop tick delivered and returns the messages
 // the reference handlers would have sent.  require(...) failures throw std::invalid_argument
@@ -16,6 +23,7 @@
 
 #include <cstdint>
 #include <map>
+#include <optional>
 #include <set>
 #include <stdexcept>
 #include <string>
@@ -298,6 +306,59 @@ class Phase2Engine {
     return out;
   }
 
+  // ---- Acceptor.handlePhase1a (Acceptor.scala:148-182) delivered to the acceptors of one group (empty
+  // `acceptors` => all of them).  Returns the acceptor indices that answered Phase1b (their vote info
+  // stays in HBM; leaderHandlePhase1bs reads it); the others Nack with their round.
+  std::vector<int> acceptorsHandlePhase1a(int groupIndex, int round, int chosenWatermark,
+                                          const std::vector<int>& acceptors = {}) {
+    uint64_t tgt[4] = {0, 0, 0, 0}, promised[4], nack[4];
+    for (int a : acceptors) {
+      if (a < 0 || a >= fcfg_.num_replicas) throw std::invalid_argument("acceptor index out of range");
+      tgt[a >> 6] |= 1ull << (a & 63);
+    }
+    check(fpx_acceptor_phase1a(ctx_, groupIndex, round, chosenWatermark, acceptors.empty() ? nullptr : tgt, promised,
+                               nack),
+          "Acceptor.handlePhase1a");
+    std::vector<int> out;
+    for (int b = 0; b < fcfg_.num_replicas; ++b)
+      if ((promised[b >> 6] >> (b & 63)) & 1) out.push_back(b);
+    return out;
+  }
+
+  // ---- Leader.handlePhase1b once a read quorum of Phase1b's is in (Leader.scala:543-566): for every
+  // slot in [chosenWatermark, maxSlot] the safe value (Leader.scala:306-329) to re-propose.
+  // quorum[g] = acceptor indices of group g whose Phase1b the leader holds.
+  struct SafeValue { int32_t slot, voteRound, value; };
+  std::vector<SafeValue> leaderHandlePhase1bs(int chosenWatermark, const std::vector<std::vector<int>>& quorum) {
+    if ((int)quorum.size() != fcfg_.num_groups) throw std::invalid_argument("one Phase1b set per acceptor group");
+    std::vector<uint64_t> masks((size_t)fcfg_.num_groups * 4, 0);
+    for (int g = 0; g < fcfg_.num_groups; ++g)
+      for (int a : quorum[g]) masks[(size_t)g * 4 + (a >> 6)] |= 1ull << (a & 63);
+    int32_t maxSlot = -1;
+    check(fpx_leader_phase1b_scan(ctx_, chosenWatermark, masks.data(), 0, &maxSlot, nullptr, nullptr),
+          "Leader.handlePhase1b");
+    const int cap = maxSlot >= chosenWatermark ? maxSlot - chosenWatermark + 1 : 0;
+    std::vector<int32_t> sr(cap), sv(cap);
+    if (cap > 0)
+      check(fpx_leader_phase1b_scan(ctx_, chosenWatermark, masks.data(), cap, &maxSlot, sr.data(), sv.data()),
+            "Leader.handlePhase1b");
+    std::vector<SafeValue> out;
+    for (int k = 0; k < cap; ++k) out.push_back(SafeValue{chosenWatermark + k, sr[k], sv[k]});
+    return out;
+  }
+
+  // ---- Replica.handleChosen + executeLog (Replica.scala:572-590, 394-447): returns executedWatermark
+  int replicaHandleChosen(const std::vector<Chosen>& msgs) {
+    std::vector<int32_t> slot(msgs.size()), value(msgs.size());
+    for (size_t i = 0; i < msgs.size(); ++i) slot[i] = msgs[i].slot, value[i] = msgs[i].value;
+    int32_t wm = 0, nc = 0;
+    check(fpx_replica_chosen(ctx_, (int)msgs.size(), slot.data(), value.data(), nullptr, &wm, &nc),
+          "Replica.handleChosen");
+    numChosen_ = nc;
+    return wm;
+  }
+  int numChosen() const { return numChosen_; }
+
   fpx_ctx* context() { return ctx_; }
 
  private:
@@ -341,7 +402,220 @@ class Phase2Engine {
   fpx_config fcfg_;
   fpx_ctx* ctx_ = nullptr;
   std::vector<int32_t> slot_, round_, value_;
+  int numChosen_ = 0;
 };
 
 }  // namespace multipaxos
+
+namespace mencius {
+
+// mencius/Mencius.proto:160-203
+struct Phase2aNoopRange { int32_t slotStartInclusive, slotEndExclusive, round; };
+struct Phase2bNoopRange { int32_t acceptorGroupIndex, acceptorIndex, slotStartInclusive, slotEndExclusive, round; };
+struct ChosenNoopRange { int32_t slotStartInclusive, slotEndExclusive; };
+struct Nack { int32_t round; };
+
+// The subset of mencius/Config.scala the noop-range path reads: numLeaderGroups leader groups own the
+// slots round-robin (slot % numLeaderGroups); each has numAcceptorGroups groups of 2f+1 acceptors.
+struct Config {
+  int f = 1;
+  int numLeaderGroups = 1;
+  int numLeadersPerGroup = 2;
+  int numAcceptorGroups = 1;
+  int numSlots = 1 << 16;
+  int tallyWays = 8;
+  int device = 0;
+
+  void checkValid() const {
+    if (f < 1) throw std::invalid_argument("f must be >= 1.");
+    if (numLeaderGroups < 1) throw std::invalid_argument("numLeaderGroups must be >= 1.");
+    if (numLeadersPerGroup < f + 1) throw std::invalid_argument("every leader group needs >= f + 1 leaders.");
+    if (numAcceptorGroups < 1) throw std::invalid_argument("numAcceptorGroups must be >= 1.");
+  }
+  fpx_config toFpx() const {
+    fpx_config c{};
+    c.num_slots = numSlots;
+    c.num_replicas = 2 * f + 1;
+    c.num_groups = numAcceptorGroups;
+    c.num_leader_groups = numLeaderGroups;
+    c.num_leaders = numLeadersPerGroup;
+    c.f = f;
+    c.quorum_kind = FPX_Q_THRESHOLD;
+    c.ballot_mode = FPX_BALLOT_ACCEPTOR;
+    c.tally_ways = tallyWays;
+    c.device = device;
+    return c;
+  }
+};
+
+// The acceptors of every leader group plus one proxy leader, for the noop-range messages a Mencius
+// leader sends when it skips its slots (mencius/Leader.scala sends Phase2aNoopRange to a proxy leader).
+class NoopRangeEngine {
+ public:
+  explicit NoopRangeEngine(const Config& config) : config_(config) {
+    config.checkValid();
+    fcfg_ = config.toFpx();
+    check(fpx_create(&fcfg_, &ctx_), "fpx_create");
+  }
+  ~NoopRangeEngine() {
+    if (ctx_) fpx_destroy(ctx_);
+  }
+  NoopRangeEngine(const NoopRangeEngine&) = delete;
+  NoopRangeEngine& operator=(const NoopRangeEngine&) = delete;
+
+  // mencius.ProxyLeader.handlePhase2aNoopRange (ProxyLeader.scala:255-303): true = new, relayed to every
+  // acceptor group; false = a known (start, end, round), ignored
+  bool proxyLeaderHandlePhase2aNoopRange(const Phase2aNoopRange& m) {
+    uint8_t fresh = 0;
+    check(fpx_proxy_open_noop_range(ctx_, m.slotStartInclusive, m.slotEndExclusive, m.round, &fresh),
+          "ProxyLeader.handlePhase2aNoopRange");
+    return fresh != 0;
+  }
+
+  // mencius.Acceptor.handlePhase2aNoopRange (Acceptor.scala:237-291) at every acceptor of the owning
+  // leader group's acceptor groups
+  void acceptorsHandlePhase2aNoopRange(const Phase2aNoopRange& m, std::vector<Phase2bNoopRange>* phase2bs,
+                                       std::vector<Nack>* nacks) {
+    const int A = fcfg_.num_groups, R = fcfg_.num_replicas;
+    std::vector<uint64_t> votes((size_t)A * 4), nk((size_t)A * 4);
+    int32_t nackRound = -1;
+    check(fpx_acceptor_phase2a_noop_range(ctx_, m.slotStartInclusive, m.slotEndExclusive, m.round, nullptr,
+                                          votes.data(), nk.data(), &nackRound),
+          "Acceptor.handlePhase2aNoopRange");
+    for (int g = 0; g < A; ++g)
+      for (int b = 0; b < R; ++b)
+        if ((votes[(size_t)g * 4 + (b >> 6)] >> (b & 63)) & 1)
+          phase2bs->push_back(Phase2bNoopRange{g, b, m.slotStartInclusive, m.slotEndExclusive, m.round});
+    if (nackRound >= 0) nacks->push_back(Nack{nackRound});
+  }
+
+  // mencius.ProxyLeader.handlePhase2bNoopRange (ProxyLeader.scala:355-411): all messages must carry the
+  // same (start, end, round); ChosenNoopRange once every acceptor group has f + 1 votes.
+  std::optional<ChosenNoopRange> proxyLeaderHandlePhase2bNoopRange(const std::vector<Phase2bNoopRange>& msgs) {
+    if (msgs.empty()) return std::nullopt;
+    const Phase2bNoopRange& h = msgs[0];
+    std::vector<uint64_t> votes((size_t)fcfg_.num_groups * 4, 0);
+    for (auto& m : msgs) {
+      if (m.slotStartInclusive != h.slotStartInclusive || m.slotEndExclusive != h.slotEndExclusive || m.round != h.round)
+        throw std::invalid_argument("one (start, end, round) per call");
+      if (m.acceptorGroupIndex < 0 || m.acceptorGroupIndex >= fcfg_.num_groups || m.acceptorIndex < 0 ||
+          m.acceptorIndex >= fcfg_.num_replicas)
+        throw std::invalid_argument("acceptor out of range");
+      votes[(size_t)m.acceptorGroupIndex * 4 + (m.acceptorIndex >> 6)] |= 1ull << (m.acceptorIndex & 63);
+    }
+    uint8_t chosen = 0;
+    check(fpx_proxy_phase2b_noop_range(ctx_, h.slotStartInclusive, h.slotEndExclusive, h.round, votes.data(), &chosen),
+          "ProxyLeader.handlePhase2bNoopRange");
+    if (!chosen) return std::nullopt;
+    return ChosenNoopRange{h.slotStartInclusive, h.slotEndExclusive};
+  }
+
+  fpx_ctx* context() { return ctx_; }
+
+ private:
+  Config config_;
+  fpx_config fcfg_;
+  fpx_ctx* ctx_ = nullptr;
+};
+
+}  // namespace mencius
+
+namespace epaxos {
+
+// epaxos/EPaxos.proto:35-41
+struct Instance { int32_t replicaIndex, instanceNumber; };
+// a single-key key-value-store command (statemachine/KeyValueStore.scala:225-302: GetRequest / SetRequest)
+struct Command { int32_t key; bool isSet; };
+// one fresh instance entering the pre-accept phase in this tick
+struct Proposal {
+  Instance instance;
+  Command command;
+  std::vector<int> fastQuorum;  // the n-2 other replicas the leader sends PreAccept to (Replica.scala:705-706)
+};
+// what the leader does with it after the PreAcceptOk's are in
+struct Decision {
+  bool fastPath;                      // committed on the fast path (Replica.scala:1399-1405)
+  std::vector<int32_t> dependencies;  // per leader replica: the dependency watermark (committed or Accept-phase)
+  std::vector<int32_t> preAcceptDependencies;  // what the PreAccept carried (the leader's own conflicts)
+};
+
+// The conflict indices of the n replicas, resident in HBM.
+class PreAcceptEngine {
+ public:
+  PreAcceptEngine(int f, int numKeys, int device = 0) : n_(2 * f + 1) {
+    if (f < 1) throw std::invalid_argument("f must be >= 1.");
+    fpx_epx_config c{};
+    c.num_replicas = n_;
+    c.num_keys = numKeys;
+    c.device = device;
+    check(fpx_epx_create(&c, &epx_), "fpx_epx_create");
+  }
+  ~PreAcceptEngine() {
+    if (epx_) fpx_epx_destroy(epx_);
+  }
+  PreAcceptEngine(const PreAcceptEngine&) = delete;
+  PreAcceptEngine& operator=(const PreAcceptEngine&) = delete;
+  int numReplicas() const { return n_; }
+
+  // One tick.  deliveryOrder[r] = the order (indices into `proposals`) in which replica r processes the
+  // tick's messages; empty => array order at every replica.
+  std::vector<Decision> handleTick(const std::vector<Proposal>& proposals,
+                                   const std::vector<std::vector<int>>& deliveryOrder = {}) {
+    const int m = (int)proposals.size();
+    std::vector<int32_t> leader(m), number(m), key(m), rank((size_t)n_ * m);
+    std::vector<uint8_t> isSet(m), mask(m);
+    for (int i = 0; i < m; ++i) {
+      const Proposal& p = proposals[i];
+      leader[i] = p.instance.replicaIndex, number[i] = p.instance.instanceNumber;
+      key[i] = p.command.key, isSet[i] = p.command.isSet ? 1 : 0;
+      unsigned b = 0;
+      for (int r : p.fastQuorum) {
+        if (r < 0 || r >= n_) throw std::invalid_argument("replica index out of range");
+        b |= 1u << r;
+      }
+      mask[i] = (uint8_t)b;
+    }
+    if (!deliveryOrder.empty() && (int)deliveryOrder.size() != n_)
+      throw std::invalid_argument("one delivery order per replica");
+    for (int r = 0; r < n_; ++r) {
+      if (deliveryOrder.empty()) {
+        for (int i = 0; i < m; ++i) rank[(size_t)r * m + i] = i;
+      } else {
+        if ((int)deliveryOrder[r].size() != m) throw std::invalid_argument("a delivery order is a permutation");
+        std::vector<char> seen(m, 0);
+        for (int pos = 0; pos < m; ++pos) {
+          const int i = deliveryOrder[r][pos];
+          if (i < 0 || i >= m || seen[i]) throw std::invalid_argument("a delivery order is a permutation");
+          seen[i] = 1;
+          rank[(size_t)r * m + i] = pos;
+        }
+      }
+    }
+    std::vector<uint8_t> fast(m);
+    std::vector<int32_t> deps((size_t)m * n_), ldeps((size_t)m * n_);
+    check(fpx_epx_preaccept(epx_, m, leader.data(), number.data(), key.data(), isSet.data(), mask.data(), rank.data(),
+                            fast.data(), deps.data(), ldeps.data()),
+          "Replica.handlePreAccept");
+    std::vector<Decision> out(m);
+    for (int i = 0; i < m; ++i) {
+      out[i].fastPath = fast[i] != 0;
+      out[i].dependencies.assign(deps.begin() + (size_t)i * n_, deps.begin() + (size_t)(i + 1) * n_);
+      out[i].preAcceptDependencies.assign(ldeps.begin() + (size_t)i * n_, ldeps.begin() + (size_t)(i + 1) * n_);
+    }
+    return out;
+  }
+
+  // replica's conflict-index entry of a key: the TopOne watermarks of gets and of sets (util/TopOne.scala)
+  std::pair<std::vector<int32_t>, std::vector<int32_t>> conflictIndex(int replica, int key) {
+    std::vector<int32_t> g(n_), s2(n_);
+    check(fpx_epx_read_index(epx_, replica, key, g.data(), s2.data()), "conflictIndex");
+    return {g, s2};
+  }
+
+ private:
+  int n_;
+  fpx_epx* epx_ = nullptr;
+};
+
+}  // namespace epaxos
 }  // namespace frankenpaxos

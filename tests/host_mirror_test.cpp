@@ -2,7 +2,8 @@
 // mirror (frankenpaxos_amd/host/fpx.hpp) so that they read like the Scala originals:
 //   shared/src/test/scala/quorums/{GridTest,SimpleMajorityTest,UnanimousWrites}.scala
 //   shared/src/test/scala/roundsystem/RoundSystemTest.scala:13-62
-// plus BASELINE.json configs[0]: MultiPaxos f = 1, 1000 commands through proxy leader + acceptors.
+// plus BASELINE.json configs[0]: MultiPaxos f = 1, 1000 commands through proxy leader + acceptors, a leader
+// change (Phase1a -> Phase1b safe values -> replica log), Mencius noop ranges and two EPaxos pre-accept ticks.
 // Needs a GPU (every predicate / handler runs in libfpx).  Built and run by tests/test_host_mirror.py.
 #include <algorithm>
 #include <cstdio>
@@ -198,6 +199,135 @@ static void multiPaxos1kCommands(bool flexible) {
   }
 }
 
+using V = std::vector<int32_t>;
+
+// multipaxos leader change: Acceptor.handlePhase1a -> Leader.handlePhase1b (safeValue) -> re-proposal ->
+// Replica.handleChosen.  Values worked out by hand from Acceptor.scala:148-220, Leader.scala:306-329, 543-566.
+static void multiPaxosRecovery() {
+  multipaxos::Config config;
+  config.f = 1, config.numLeaders = 2, config.numAcceptorGroups = 2, config.acceptorsPerGroup = 3;
+  config.numSlots = 64;
+  multipaxos::Phase2Engine engine(config);
+  // round 0 (leader 0): slots 0..5; slot 2 reaches only acceptor 0 of its group, slot 5 reaches nobody useful
+  std::vector<multipaxos::Phase2a> r0;
+  std::vector<std::vector<std::pair<int, int>>> targets;
+  for (int slot = 0; slot < 5; ++slot) {
+    r0.push_back({slot, 0, 500 + slot});
+    if (slot == 2) targets.push_back({{0, 0}}); else targets.push_back({});
+  }
+  std::vector<multipaxos::Chosen> chosen = engine.handlePhase2(r0, targets);
+  SHOULD_BE(chosen.size(), (size_t)4);  // slot 2 has one vote of the f + 1 = 2 it needs
+  SHOULD_BE(engine.replicaHandleChosen(chosen), 2);  // executes 0, 1; hole at 2
+  SHOULD_BE(engine.numChosen(), 4);
+  // leader 1 takes over in round 1: all acceptors promise (1 > 0)
+  SHOULD_BE(engine.acceptorsHandlePhase1a(0, 1, 2), (std::vector<int>{0, 1, 2}));
+  SHOULD_BE(engine.acceptorsHandlePhase1a(1, 1, 2, {1, 2}), (std::vector<int>{1, 2}));
+  // a stale Phase1a (round 0 < 1) is Nacked by everyone it reaches (Acceptor.scala:155-163)
+  SHOULD_BE(engine.acceptorsHandlePhase1a(0, 0, 2).size(), (size_t)0);
+  // Phase1b's of acceptors {1, 2} of group 0 and {1, 2} of group 1, from chosenWatermark 2
+  std::vector<multipaxos::Phase2Engine::SafeValue> safe = engine.leaderHandlePhase1bs(2, {{1, 2}, {1, 2}});
+  SHOULD_BE(safe.size(), (size_t)3);  // maxSlot = 4
+  // slot 2: its only vote is at acceptor 0, outside the quorum -> nothing voted -> Noop is safe
+  SHOULD_BE(safe[0].slot, 2); SHOULD_BE(safe[0].voteRound, -1); SHOULD_BE(safe[0].value, FPX_NOOP);
+  SHOULD_BE(safe[1].slot, 3); SHOULD_BE(safe[1].voteRound, 0); SHOULD_BE(safe[1].value, 503);
+  SHOULD_BE(safe[2].slot, 4); SHOULD_BE(safe[2].voteRound, 0); SHOULD_BE(safe[2].value, 504);
+  // with acceptor 0 in the quorum the vote for slot 2 is seen
+  safe = engine.leaderHandlePhase1bs(2, {{0, 1}, {1, 2}});
+  SHOULD_BE(safe[0].voteRound, 0); SHOULD_BE(safe[0].value, 502);
+  // re-propose the safe values in round 1; everything is chosen, the replica's log fills up
+  std::vector<multipaxos::Phase2a> r1;
+  for (auto& sv : safe) r1.push_back({sv.slot, 1, sv.value});
+  chosen = engine.handlePhase2(r1);
+  SHOULD_BE(chosen.size(), (size_t)3);
+  SHOULD_BE(engine.replicaHandleChosen(chosen), 5);
+  SHOULD_BE(engine.numChosen(), 5);  // 3 and 4 were chosen before: redundantly chosen, not counted again
+}
+
+// mencius noop ranges, mencius/Acceptor.scala:237-291 and mencius/ProxyLeader.scala:255-303, 355-411
+static void menciusNoopRange() {
+  mencius::Config config;
+  config.f = 1, config.numLeaderGroups = 3, config.numAcceptorGroups = 2, config.numSlots = 256;
+  mencius::NoopRangeEngine engine(config);
+  // acceptor 2 of (leader group 1, acceptor group 0) was promised round 5 by someone else
+  const uint64_t only2[4] = {1ull << 2, 0, 0, 0};
+  SHOULD_BE(fpx_acceptor_phase1a(engine.context(), 1 * 2 + 0, 5, 0, only2, nullptr, nullptr), FPX_OK);
+  // leader group 1 owns slots 1, 4, 7, ...; it skips [4, 14) in round 2
+  const mencius::Phase2aNoopRange range{4, 14, 2};
+  bool fatal = false;
+  try {
+    engine.proxyLeaderHandlePhase2bNoopRange({{0, 0, 4, 14, 2}});
+  } catch (const std::logic_error&) {
+    fatal = true;
+  }
+  SHOULD_BE(fatal, true);  // never opened: logger.fatal (ProxyLeader.scala:360-366)
+  SHOULD_BE(engine.proxyLeaderHandlePhase2aNoopRange(range), true);
+  SHOULD_BE(engine.proxyLeaderHandlePhase2aNoopRange(range), false);  // known: ignored
+  std::vector<mencius::Phase2bNoopRange> phase2bs;
+  std::vector<mencius::Nack> nacks;
+  engine.acceptorsHandlePhase2aNoopRange(range, &phase2bs, &nacks);
+  SHOULD_BE(phase2bs.size(), (size_t)5);  // acceptor group 0: {0, 1} (2 Nacks), acceptor group 1: {0, 1, 2}
+  SHOULD_BE(nacks.size(), (size_t)1);
+  SHOULD_BE(nacks[0].round, 5);
+  for (auto& m : phase2bs) SHOULD_BE(m.acceptorGroupIndex == 0 && m.acceptorIndex == 2, false);
+  // f + 1 = 2 votes from EVERY acceptor group
+  SHOULD_BE(engine.proxyLeaderHandlePhase2bNoopRange({{0, 0, 4, 14, 2}, {0, 1, 4, 14, 2}}).has_value(), false);
+  SHOULD_BE(engine.proxyLeaderHandlePhase2bNoopRange({{1, 2, 4, 14, 2}}).has_value(), false);
+  std::optional<mencius::ChosenNoopRange> chosen = engine.proxyLeaderHandlePhase2bNoopRange({{1, 0, 4, 14, 2}});
+  SHOULD_BE(chosen.has_value(), true);
+  SHOULD_BE(chosen->slotStartInclusive, 4);
+  SHOULD_BE(chosen->slotEndExclusive, 14);
+  SHOULD_BE(engine.proxyLeaderHandlePhase2bNoopRange(phase2bs).has_value(), false);  // Done: ignored
+  // the votes are in the acceptors' logs: (round 2, Noop) in the slots of [4, 14) that leader group 1 owns
+  std::vector<int32_t> voteRound(256), voteValue(256);
+  SHOULD_BE(fpx_read_acceptor(engine.context(), 1 * 2 + 1, 0, nullptr, nullptr, voteRound.data(), voteValue.data(), nullptr),
+            FPX_OK);
+  SHOULD_BE(voteRound[4], 2); SHOULD_BE(voteValue[4], FPX_NOOP);    // slot 4 -> acceptor group (4 / 3) % 2 = 1
+  SHOULD_BE(voteRound[10], 2); SHOULD_BE(voteRound[7], -1);         // slot 7 belongs to acceptor group 0
+  SHOULD_BE(voteRound[16], -1);                                     // outside the range
+}
+
+// epaxos pre-accept, the two hand-worked ticks of tests/test_epaxos.py (Replica.scala:569-600, 633-729,
+// 1159-1419; KeyValueStore.scala:259-302)
+static void epaxosPreAccept() {
+  {
+    epaxos::PreAcceptEngine engine(1, 4);  // n = 3: the leader asks one other replica, always fast
+    std::vector<epaxos::Proposal> tick = {
+        {{0, 0}, {1, true}, {1}},   // A = set k1 by replica 0, asks replica 1
+        {{1, 0}, {1, false}, {2}},  // B = get k1 by replica 1, asks replica 2
+        {{2, 0}, {1, true}, {0}},   // C = set k1 by replica 2, asks replica 0
+        {{0, 1}, {2, false}, {2}},  // D = get k2 by replica 0, asks replica 2
+    };
+    // replica 0 sees A, C, D; replica 1 sees B, A; replica 2 sees C, B, D
+    std::vector<epaxos::Decision> d = engine.handleTick(tick, {{0, 2, 3, 1}, {1, 0, 2, 3}, {2, 1, 3, 0}});
+    SHOULD_BE(d[0].preAcceptDependencies, (V{0, 0, 0})); SHOULD_BE(d[0].dependencies, (V{0, 1, 0}));
+    SHOULD_BE(d[1].preAcceptDependencies, (V{0, 0, 0})); SHOULD_BE(d[1].dependencies, (V{0, 0, 1}));
+    SHOULD_BE(d[2].preAcceptDependencies, (V{0, 0, 0})); SHOULD_BE(d[2].dependencies, (V{1, 0, 0}));
+    SHOULD_BE(d[3].dependencies, (V{0, 0, 0}));
+    for (auto& x : d) SHOULD_BE(x.fastPath, true);
+    for (int r = 0; r < 3; ++r) {
+      SHOULD_BE(engine.conflictIndex(r, 1).first, (V{0, 1, 0}));
+      SHOULD_BE(engine.conflictIndex(r, 1).second, (V{1, 0, 1}));
+      SHOULD_BE(engine.conflictIndex(r, 2).first, (V{2, 0, 0}));
+    }
+    d = engine.handleTick({{{1, 1}, {1, false}, {0}}});
+    SHOULD_BE(d[0].fastPath, true);
+    SHOULD_BE(d[0].dependencies, (V{1, 0, 1}));
+  }
+  {
+    epaxos::PreAcceptEngine engine(2, 2);  // n = 5: answers that differ force the slow path
+    std::vector<epaxos::Proposal> tick = {
+        {{4, 0}, {0, true}, {1, 2, 3}},  // X = set k0 by replica 4
+        {{0, 7}, {0, true}, {1, 2, 3}},  // Y = set k0 by replica 0
+    };
+    // replicas 1, 2 process X then Y; replica 3 processes Y then X
+    std::vector<epaxos::Decision> d = engine.handleTick(tick, {{0, 1}, {0, 1}, {0, 1}, {1, 0}, {0, 1}});
+    SHOULD_BE(d[1].fastPath, false); SHOULD_BE(d[1].dependencies, (V{0, 0, 0, 0, 1}));
+    SHOULD_BE(d[0].fastPath, false); SHOULD_BE(d[0].dependencies, (V{8, 0, 0, 0, 0}));
+    SHOULD_THROW(engine.handleTick({{{0, 0}, {0, true}, {1, 2}}}));     // a fast quorum has n - 2 others
+    SHOULD_THROW(engine.handleTick({{{0, 0}, {0, true}, {0, 1, 2}}}));  // the leader does not ask itself
+  }
+}
+
 int main() {
   gridTest();
   simpleMajorityTest();
@@ -205,6 +335,9 @@ int main() {
   roundSystemTest();
   multiPaxos1kCommands(false);
   multiPaxos1kCommands(true);
+  multiPaxosRecovery();
+  menciusNoopRange();
+  epaxosPreAccept();
   if (failures) {
     std::printf("%d failure(s)\n", failures);
     return 1;
