@@ -74,6 +74,8 @@ SIGNATURES = {
     "fpx_error_detail": (C.c_int32, [VP, I32P, I32P, I32P]),
     "fpx_last_hip_error": (C.c_int32, [VP]),
     "fpx_device_bytes": (C.c_int64, [VP]),
+    "fpx_host_alloc": (C.c_int32, [C.c_int64, C.POINTER(C.c_void_p)]),
+    "fpx_host_free": (C.c_int32, [VP]),
     "fpx_profile_enable": (C.c_int32, [VP, C.c_int32]),
     "fpx_profile_read": (C.c_int32, [VP, I32P, C.POINTER(C.c_double)]),
     "fpx_round_leader": (C.c_int32, [C.c_int32, C.c_int32]),

@@ -297,6 +297,35 @@ class Context:
 
 
 # ---- a5 / a7 free functions ----------------------------------------------------------------------
+class PinnedArray:
+    """A numpy array over page-locked host memory (fpx_host_alloc): batches built in it cross PCIe by
+    DMA.  Keep the object alive while `array` is in use; `free()` (or garbage collection) releases it."""
+
+    def __init__(self, shape, dtype):
+        self._L = _lib.lib()
+        dtype = np.dtype(dtype)
+        nbytes = max(1, int(np.prod(shape)) * dtype.itemsize)
+        p = C.c_void_p()
+        st = self._L.fpx_host_alloc(nbytes, C.byref(p))
+        if st:
+            raise FpxError(st, "fpx_host_alloc")
+        self._p = p
+        buf = (C.c_char * nbytes).from_address(p.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if self._p is not None:
+            self.array = None
+            self._L.fpx_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def quorum_eval(cfg, nodes, strict=True, read=False):
     """isWriteQuorum / isReadQuorum (strict) or the isSuperSetOf* variants for n node sets
     (n x 4 uint64), evaluated by the device predicate the tally kernels use."""

@@ -5,6 +5,7 @@
 #include "../../include/fpx.h"
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -47,6 +48,9 @@ struct fpx_ctx {
   // kernel timing (fpx_profile_*)
   void* slab = nullptr;  // vote_round | vote_value | ballot
   uint32_t phase2_launches = 0;
+  bool batch_increasing = false, batch_one_round = false;  // check_inputs' findings about the current host batch
+  bool force_validate = false;  // host-pointer K3's optimistic whole-batch run is validated even under FPX_F_TRUSTED
+  bool host_validated = false;  // set while a host entry point drives runs it cut itself (split_runs)
   bool profiling = false;
   std::vector<hipEvent_t> ev;  // start/stop pairs
   size_t ev_used = 0;
@@ -186,6 +190,14 @@ int launch_check(fpx_ctx* ctx) {
   return FPX_OK;
 }
 
+// While a host entry point drives its own device runs the run contract holds by construction
+// (split_runs), so the device-side validation pass is skipped.
+struct HostRun {
+  fpx_ctx* ctx;
+  explicit HostRun(fpx_ctx* c) : ctx(c) { ctx->host_validated = true; }
+  ~HostRun() { ctx->host_validated = false; }
+};
+
 // validation pass of one device run (skipped with FPX_F_TRUSTED)
 int enqueue_validate(fpx_ctx* ctx, Batch& b, bool check_round) {
   b.run_id = ++ctx->run_id;
@@ -194,7 +206,7 @@ int enqueue_validate(fpx_ctx* ctx, Batch& b, bool check_round) {
     ctx->run_id = 0;
     b.run_id = ++ctx->run_id;
   }
-  if (ctx->cfg.flags & FPX_F_TRUSTED) return FPX_OK;
+  if (((ctx->cfg.flags & FPX_F_TRUSTED) && !ctx->force_validate) || ctx->host_validated) return FPX_OK;
   b.check_round = check_round && !ctx->g.per_slot;
   if (b.check_round)
     HIPCHK(ctx, hipMemsetAsync(ctx->st.run_round, 0xFF, sizeof(int32_t) * (size_t)ctx->g.ngroups, ctx->stream));
@@ -316,6 +328,13 @@ void split_runs(fpx_ctx* ctx, int n, const int32_t* slot, const int32_t* round, 
                 std::vector<int>* cuts) {
   cuts->clear();
   cuts->push_back(0);
+  // check_inputs saw strictly increasing slots (hence distinct) in one round: one run
+  const bool one_run = ctx->batch_increasing && (ctx->batch_one_round || !check_round || ctx->g.per_slot);
+  ctx->batch_increasing = ctx->batch_one_round = false;  // findings are about one batch only
+  if (one_run) {
+    cuts->push_back(n);
+    return;
+  }
   if (ctx->hstamp.empty()) ctx->hstamp.assign((size_t)ctx->g.S, 0u);
   if (ctx->hround.empty()) ctx->hround.assign((size_t)ctx->g.ngroups, -1);
   check_round = check_round && !ctx->g.per_slot;
@@ -351,17 +370,37 @@ void split_runs(fpx_ctx* ctx, int n, const int32_t* slot, const int32_t* round, 
   for (int gidx : touched) ctx->hround[gidx] = -1;
 }
 
+int check_args(fpx_ctx* ctx, int n, const int32_t* slot, const int32_t* round) {
+  return (!ctx || n < 0 || (n > 0 && (!slot || !round))) ? FPX_EINVAL : FPX_OK;
+}
+
+// range check of a host batch; the host entry points run it (and split_runs) AFTER enqueueing the uploads,
+// so with page-locked buffers (fpx_host_alloc) the CPU passes overlap the DMA.  Nothing is launched on
+// a bad batch: the staging copies alone change no protocol state.
 int check_inputs(fpx_ctx* ctx, int n, const int32_t* slot, const int32_t* round) {
-  if (!ctx || n < 0 || (n > 0 && (!slot || !round))) return FPX_EINVAL;
+  // one branch-free pass (vectorises): range of slots and rounds, and whether the batch is the common
+  // shape -- strictly increasing slots in one round -- that split_runs can accept as a single run
+  int32_t smin = INT32_MAX, smax = INT32_MIN, rmin = INT32_MAX, rmax = INT32_MIN;
+  int32_t unordered = 0;
+  for (int i = 0; i < n; ++i) {
+    smin = std::min(smin, slot[i]), smax = std::max(smax, slot[i]);
+    rmin = std::min(rmin, round[i]), rmax = std::max(rmax, round[i]);
+  }
+  for (int i = 1; i < n; ++i) unordered |= (int32_t)(slot[i] <= slot[i - 1]);
+  ctx->batch_increasing = unordered == 0;
+  ctx->batch_one_round = rmin == rmax;
+  if (smin >= 0 && smax < ctx->g.S && rmin >= 0 && rmax <= MAX_ROUND) return FPX_OK;
   for (int i = 0; i < n; ++i) {
     if (slot[i] < 0 || slot[i] >= ctx->g.S || round[i] < 0 || round[i] > MAX_ROUND) {
       ctx->err_index = i;
       ctx->err_slot = slot[i];
       ctx->err_round = round[i];
-      return FPX_EINVAL;
+      break;
     }
   }
-  return FPX_OK;
+  ctx->batch_increasing = ctx->batch_one_round = false;
+  (void)hipStreamSynchronize(ctx->stream);  // the caller's buffers are free again when we return
+  return FPX_EINVAL;
 }
 
 template <typename T>
@@ -565,6 +604,24 @@ int32_t fpx_profile_read(fpx_ctx* ctx, int32_t* launches, double* total_ms) {
 int32_t fpx_last_hip_error(fpx_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
 int64_t fpx_device_bytes(fpx_ctx* ctx) { return ctx ? ctx->bytes : 0; }
 
+int32_t fpx_host_alloc(int64_t bytes, void** out) {
+  if (!out || bytes <= 0) return FPX_EINVAL;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FPX_ENODEVICE;
+  const hipError_t e = hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    *out = nullptr;
+    return e == hipErrorOutOfMemory ? FPX_ENOMEM : FPX_EHIP;
+  }
+  return FPX_OK;
+}
+
+int32_t fpx_host_free(void* p) {
+  if (!p) return FPX_EINVAL;
+  return hipHostFree(p) == hipSuccess ? FPX_OK : FPX_EHIP;
+}
+
 // ---- a5 --------------------------------------------------------------------------------------------
 static int32_t quorum_eval_impl(const fpx_config* cfg, int32_t n, const uint64_t* nodes, int32_t strict, int read,
                                 uint8_t* out) {
@@ -660,7 +717,7 @@ int32_t fpx_proxy_phase2b_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, co
 int32_t fpx_acceptor_phase2a(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round,
                              const int32_t* value_id, const uint64_t* target_mask, uint64_t* vote_bits,
                              uint64_t* nack_bits, int32_t* nack_round) {
-  int rc = check_inputs(ctx, n, slot, round);
+  int rc = check_args(ctx, n, slot, round);
   if (rc) return rc;
   if (n == 0) return FPX_OK;
   if (!value_id) return FPX_EINVAL;
@@ -671,6 +728,8 @@ int32_t fpx_acceptor_phase2a(fpx_ctx* ctx, int32_t n, const int32_t* slot, const
   if ((rc = grow(ctx, &ctx->d_bits_a, (size_t)n * 32))) return rc;
   if ((rc = grow(ctx, &ctx->d_bits_b, (size_t)n * 32))) return rc;
   if ((rc = grow(ctx, &ctx->d_i32_a, (size_t)n * 4))) return rc;
+  if ((rc = check_inputs(ctx, n, slot, round))) return rc;
+  HostRun host_run(ctx);
   std::vector<int> cuts;
   split_runs(ctx, n, slot, round, true, &cuts);
   for (size_t k = 0; k + 1 < cuts.size(); ++k) {
@@ -689,42 +748,73 @@ int32_t fpx_acceptor_phase2a(fpx_ctx* ctx, int32_t n, const int32_t* slot, const
   return fetch_status(ctx);
 }
 
+// Host-pointer K3.  Optimistic: the uploads are followed at once by the whole batch as ONE validated
+// device run (k_validate checks ranges and the run contract on the GPU), so a well-formed batch -- the
+// common case -- costs no CPU pass over the messages.  Only when the device reports a contract violation
+// (nothing was applied) does the host cut the batch into runs itself and replay them.
 int32_t fpx_phase2_fused(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round, const int32_t* value_id,
                          const uint64_t* target_mask, uint8_t* chosen, int32_t* chosen_round, int32_t* chosen_value,
                          int32_t* nack_round) {
-  int rc = check_inputs(ctx, n, slot, round);
+  int rc = check_args(ctx, n, slot, round);
   if (rc) return rc;
   if (n == 0) return FPX_OK;
   if (!value_id) return FPX_EINVAL;
-  if ((rc = h2d(ctx, &ctx->d_slot, slot, n))) return rc;
-  if ((rc = h2d(ctx, &ctx->d_round, round, n))) return rc;
-  if ((rc = h2d(ctx, &ctx->d_value, value_id, n))) return rc;
-  if (target_mask && (rc = h2d(ctx, &ctx->d_target, target_mask, (size_t)n * 4))) return rc;
   if ((rc = grow(ctx, &ctx->d_u8, (size_t)n))) return rc;
   if ((rc = grow(ctx, &ctx->d_i32_a, (size_t)n * 4))) return rc;
   if ((rc = grow(ctx, &ctx->d_i32_b, (size_t)n * 4))) return rc;
   if ((rc = grow(ctx, &ctx->d_i32_c, (size_t)n * 4))) return rc;
+  if ((rc = h2d(ctx, &ctx->d_slot, slot, n))) return rc;
+  if ((rc = h2d(ctx, &ctx->d_round, round, n))) return rc;
+  if ((rc = h2d(ctx, &ctx->d_value, value_id, n))) return rc;
+  if (target_mask && (rc = h2d(ctx, &ctx->d_target, target_mask, (size_t)n * 4))) return rc;
+  int32_t *d_slot = (int32_t*)ctx->d_slot.p, *d_round = (int32_t*)ctx->d_round.p, *d_value = (int32_t*)ctx->d_value.p;
+  uint64_t* d_target = target_mask ? (uint64_t*)ctx->d_target.p : nullptr;
+  uint8_t* d_ch = (uint8_t*)ctx->d_u8.p;
+  int32_t *d_cr = (int32_t*)ctx->d_i32_a.p, *d_cv = (int32_t*)ctx->d_i32_b.p, *d_nr = (int32_t*)ctx->d_i32_c.p;
+  auto download = [&]() -> int {
+    int r2;
+    if ((r2 = d2h(ctx, chosen, ctx->d_u8, (size_t)n))) return r2;
+    if ((r2 = d2h(ctx, chosen_round, ctx->d_i32_a, (size_t)n))) return r2;
+    if ((r2 = d2h(ctx, chosen_value, ctx->d_i32_b, (size_t)n))) return r2;
+    return d2h(ctx, nack_round, ctx->d_i32_c, (size_t)n);
+  };
+  {
+    ctx->force_validate = true;  // also under FPX_F_TRUSTED: that flag is a promise about _dev batches only
+    rc = fpx_phase2_fused_dev(ctx, n, d_slot, d_round, d_value, d_target, d_ch, d_cr, d_cv, d_nr);
+    ctx->force_validate = false;
+    if (rc == FPX_OK) rc = download();
+    if (rc) {
+      (void)hipStreamSynchronize(ctx->stream);
+      return rc;
+    }
+    rc = fetch_status(ctx);
+    if (rc == FPX_EINVAL) return check_inputs(ctx, n, slot, round);  // the FIRST offender, for fpx_error_detail
+    if (rc != FPX_EORDER) return rc;
+  }
+  // the batch is not a single run: cut it on the host and replay (the staged copies are still there)
+  if ((rc = check_inputs(ctx, n, slot, round))) return rc;
+  HostRun host_run(ctx);
   std::vector<int> cuts;
   split_runs(ctx, n, slot, round, true, &cuts);
   for (size_t k = 0; k + 1 < cuts.size(); ++k) {
     const int lo = cuts[k], len = cuts[k + 1] - cuts[k];
-    rc = fpx_phase2_fused_dev(ctx, len, (int32_t*)ctx->d_slot.p + lo, (int32_t*)ctx->d_round.p + lo,
-                              (int32_t*)ctx->d_value.p + lo,
-                              target_mask ? (uint64_t*)ctx->d_target.p + (size_t)lo * 4 : nullptr,
-                              (uint8_t*)ctx->d_u8.p + lo, (int32_t*)ctx->d_i32_a.p + lo, (int32_t*)ctx->d_i32_b.p + lo,
-                              (int32_t*)ctx->d_i32_c.p + lo);
-    if (rc) return rc;
+    rc = fpx_phase2_fused_dev(ctx, len, d_slot + lo, d_round + lo, d_value + lo,
+                              d_target ? d_target + (size_t)lo * 4 : nullptr, d_ch + lo, d_cr + lo, d_cv + lo, d_nr + lo);
+    if (rc) {
+      (void)hipStreamSynchronize(ctx->stream);
+      return rc;
+    }
   }
-  if ((rc = d2h(ctx, chosen, ctx->d_u8, (size_t)n))) return rc;
-  if ((rc = d2h(ctx, chosen_round, ctx->d_i32_a, (size_t)n))) return rc;
-  if ((rc = d2h(ctx, chosen_value, ctx->d_i32_b, (size_t)n))) return rc;
-  if ((rc = d2h(ctx, nack_round, ctx->d_i32_c, (size_t)n))) return rc;
+  if ((rc = download())) {
+    (void)hipStreamSynchronize(ctx->stream);
+    return rc;
+  }
   return fetch_status(ctx);
 }
 
 int32_t fpx_proxy_open(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round, const int32_t* value_id,
                        uint8_t* is_new) {
-  int rc = check_inputs(ctx, n, slot, round);
+  int rc = check_args(ctx, n, slot, round);
   if (rc) return rc;
   if (n == 0) return FPX_OK;
   if (!value_id) return FPX_EINVAL;
@@ -732,6 +822,8 @@ int32_t fpx_proxy_open(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32
   if ((rc = h2d(ctx, &ctx->d_round, round, n))) return rc;
   if ((rc = h2d(ctx, &ctx->d_value, value_id, n))) return rc;
   if ((rc = grow(ctx, &ctx->d_u8, (size_t)n))) return rc;
+  if ((rc = check_inputs(ctx, n, slot, round))) return rc;
+  HostRun host_run(ctx);
   std::vector<int> cuts;
   split_runs(ctx, n, slot, round, false, &cuts);
   for (size_t k = 0; k + 1 < cuts.size(); ++k) {
@@ -746,7 +838,7 @@ int32_t fpx_proxy_open(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32
 
 int32_t fpx_proxy_phase2b(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round, const uint64_t* vote_bits,
                           uint8_t* newly_chosen, int32_t* chosen_round, int32_t* chosen_value) {
-  int rc = check_inputs(ctx, n, slot, round);
+  int rc = check_args(ctx, n, slot, round);
   if (rc) return rc;
   if (n == 0) return FPX_OK;
   if (!vote_bits) return FPX_EINVAL;
@@ -756,6 +848,8 @@ int32_t fpx_proxy_phase2b(fpx_ctx* ctx, int32_t n, const int32_t* slot, const in
   if ((rc = grow(ctx, &ctx->d_u8, (size_t)n))) return rc;
   if ((rc = grow(ctx, &ctx->d_i32_a, (size_t)n * 4))) return rc;
   if ((rc = grow(ctx, &ctx->d_i32_b, (size_t)n * 4))) return rc;
+  if ((rc = check_inputs(ctx, n, slot, round))) return rc;
+  HostRun host_run(ctx);
   std::vector<int> cuts;
   split_runs(ctx, n, slot, round, false, &cuts);
   for (size_t k = 0; k + 1 < cuts.size(); ++k) {

@@ -140,6 +140,12 @@ int32_t fpx_error_detail(fpx_ctx* ctx, int32_t* index, int32_t* slot, int32_t* r
 int32_t fpx_last_hip_error(fpx_ctx* ctx);
 /* HBM bytes held by the context */
 int64_t fpx_device_bytes(fpx_ctx* ctx);
+/* Page-locked host memory for the host-pointer entry points: batches that live in it cross PCIe by DMA at
+ * link rate instead of through the runtime's pageable staging copies.  A JVM caller wraps the region in
+ * a direct ByteBuffer (JNI NewDirectByteBuffer), the counterpart of the Netty direct buffers the
+ * reference's transports hand to the handlers.  Any other host pointer stays legal, only slower. */
+int32_t fpx_host_alloc(int64_t bytes, void** out);
+int32_t fpx_host_free(void* p);
 /* Kernel timing for roofline accounting: while enabled, every K1 / K3 call brackets its dominant
  * kernel (k_phase2) with HIP events on the context's stream.  fpx_profile_read waits for the stream
  * and returns the number of bracketed launches since the last read and the sum of their durations. */

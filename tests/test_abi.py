@@ -87,6 +87,9 @@ def test_no_cpu_fallback(fa):
     with pytest.raises(fa.FpxError) as e:
         fa.quorum_eval(cfg, np.zeros((1, 4), np.uint64))
     assert e.value.status == fa.FPX_ENODEVICE
+    with pytest.raises(fa.FpxError) as e:
+        fa.PinnedArray((16,), np.int32)
+    assert e.value.status == fa.FPX_ENODEVICE
 
 
 def test_product_never_imports_the_oracle():

@@ -477,3 +477,30 @@ def test_dev_inputs_produced_on_the_torch_stream_are_ordered(fa):
         assert gpu.sync() == 0
         assert bool(ch.all()) and bool((cv == val).all())
     gpu.set_stream(None)
+
+
+@pytest.mark.gpu
+def test_page_locked_host_batches(fa, oracle):
+    """fpx_host_alloc: the host-pointer entry points take page-locked buffers (the DMA path) with the
+    same results as pageable numpy arrays"""
+    kw = dict(num_slots=4096, num_replicas=7, f=3, num_groups=2)
+    gpu, ref = fa.Context(fa.make_config(**kw)), oracle.System(oracle.make_config(**kw))
+    n = 3000
+    rng = np.random.default_rng(11)
+    pins = [fa.PinnedArray((n,), np.int32) for _ in range(3)]
+    slot, rnd, val = (p.array for p in pins)
+    slot[:] = rng.permutation(4096)[:n]
+    rnd[:] = 0
+    val[:] = rng.integers(0, 1 << 30, n)
+    tm = fa.PinnedArray((n, 4), np.uint64)
+    tm.array[:] = 0
+    tm.array[:, 0] = rng.integers(1, 128, n).astype(np.uint64)
+    a = gpu.phase2_fused(slot, rnd, val, tm.array)
+    b = ref.phase2_fused(slot.copy(), rnd.copy(), val.copy(), tm.array.copy())
+    assert a[0] == b[0] == 0
+    for x, y in zip(a[1:], b[1:]):
+        np.testing.assert_array_equal(x, y)
+    W.assert_same_state(gpu, ref)
+    for p in pins + [tm]:
+        p.free()
+    assert fa.lib().fpx_host_free(None) == fa.FPX_EINVAL
