@@ -38,6 +38,38 @@ object Native {
   @native def quorumEval(cfg: Array[Int], n: Int, nodes: Array[Long], strict: Int,
                          out: Array[Byte]): Int
 
+  // page-locked batches: direct buffers over fpx_host_alloc memory (fill through asIntBuffer /
+  // asLongBuffer views in ByteOrder.nativeOrder), DMA'd without pinning or copying
+  @native def hostAlloc(bytes: Long): java.nio.ByteBuffer // null on failure
+  @native def hostFree(buffer: java.nio.ByteBuffer): Int
+  @native def phase2FusedDirect(handle: Long, n: Int, slot: java.nio.ByteBuffer,
+                                round: java.nio.ByteBuffer, value: java.nio.ByteBuffer,
+                                targetMask: java.nio.ByteBuffer, chosen: java.nio.ByteBuffer,
+                                chosenRound: java.nio.ByteBuffer, chosenValue: java.nio.ByteBuffer,
+                                nackRound: java.nio.ByteBuffer): Int
+
+  // the rows around the fused step
+  @native def acceptorPhase1a(handle: Long, group: Int, round: Int, chosenWatermark: Int,
+                              targetMask: Array[Long], bits: Array[Long]): Int
+  @native def leaderPhase1bScan(handle: Long, chosenWatermark: Int, quorumMasks: Array[Long],
+                                cap: Int, maxSlot: Array[Int], safeRound: Array[Int],
+                                safeValue: Array[Int]): Int
+  @native def replicaChosen(handle: Long, n: Int, slot: Array[Int], value: Array[Int],
+                            mask: Array[Byte], state: Array[Int]): Int
+  @native def acceptorPhase2aNoopRange(handle: Long, slotStart: Int, slotEnd: Int, round: Int,
+                                       numGroups: Int, targetMasks: Array[Long],
+                                       bits: Array[Long], nackRound: Array[Int]): Int
+  @native def proxyOpenNoopRange(handle: Long, slotStart: Int, slotEnd: Int, round: Int,
+                                 isNew: Array[Byte]): Int
+  @native def proxyPhase2bNoopRange(handle: Long, slotStart: Int, slotEnd: Int, round: Int,
+                                    voteBits: Array[Long], newlyChosen: Array[Byte]): Int
+  @native def epxCreate(numReplicas: Int, numKeys: Int, device: Int): Long // < 0: -status
+  @native def epxDestroy(handle: Long): Int
+  @native def epxPreaccept(handle: Long, m: Int, leader: Array[Int], number: Array[Int],
+                           key: Array[Int], isSet: Array[Byte], respMask: Array[Byte],
+                           rank: Array[Int], fast: Array[Byte], deps: Array[Int],
+                           leaderDeps: Array[Int]): Int
+
   def check(status: Int, logger: Logger): Unit = status match {
     case OK                       => ()
     case EINVAL                   => throw new IllegalArgumentException("libfpx: require failed")

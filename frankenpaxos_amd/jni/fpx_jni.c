@@ -105,3 +105,125 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_quorumEval(JNIEnv* env, jcla
   UNPIN(env, out, o, 0); UNPIN(env, nodes, nd, JNI_ABORT);
   return st;
 }
+
+/* ---- page-locked batches: direct ByteBuffers over fpx_host_alloc memory ------------------------------
+ * A tick's SoA batch lives in direct buffers the JVM fills in place (IntBuffer / LongBuffer views, native
+ * byte order), the counterpart of the Netty direct buffers the reference's transport decodes from: no
+ * array pinning, no copy, DMA straight out of the buffer. */
+JNIEXPORT jobject JNICALL Java_frankenpaxos_gpu_Native_hostAlloc(JNIEnv* env, jclass cls, jlong bytes) {
+  void* p = NULL;
+  if (fpx_host_alloc(bytes, &p) != FPX_OK) return NULL;
+  return (*env)->NewDirectByteBuffer(env, p, bytes);
+}
+
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_hostFree(JNIEnv* env, jclass cls, jobject buffer) {
+  return fpx_host_free(buffer ? (*env)->GetDirectBufferAddress(env, buffer) : NULL);
+}
+
+#define ADDR(env, buf) ((buf) ? (*(env))->GetDirectBufferAddress((env), (buf)) : NULL)
+
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_phase2FusedDirect(
+    JNIEnv* env, jclass cls, jlong h, jint n, jobject slot, jobject round, jobject value, jobject targetMask,
+    jobject chosen, jobject chosenRound, jobject chosenValue, jobject nackRound) {
+  return fpx_phase2_fused((fpx_ctx*)(intptr_t)h, n, (const int32_t*)ADDR(env, slot), (const int32_t*)ADDR(env, round),
+                          (const int32_t*)ADDR(env, value), (const uint64_t*)ADDR(env, targetMask),
+                          (uint8_t*)ADDR(env, chosen), (int32_t*)ADDR(env, chosenRound),
+                          (int32_t*)ADDR(env, chosenValue), (int32_t*)ADDR(env, nackRound));
+}
+
+/* ---- the rows around the fused step ---------------------------------------------------------------------- */
+/* Acceptor.handlePhase1a: multipaxos/Acceptor.scala:148-182.  bits: promised[4] then nack[4] */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_acceptorPhase1a(JNIEnv* env, jclass cls, jlong h, jint group,
+                                                                    jint round, jint chosenWatermark,
+                                                                    jlongArray targetMask, jlongArray bits) {
+  jlong *t = PIN(env, targetMask), *b = PIN(env, bits);
+  int32_t st = fpx_acceptor_phase1a((fpx_ctx*)(intptr_t)h, group, round, chosenWatermark, (const uint64_t*)t,
+                                    (uint64_t*)b, b ? (uint64_t*)b + 4 : NULL);
+  UNPIN(env, bits, b, 0); UNPIN(env, targetMask, t, JNI_ABORT);
+  return st;
+}
+
+/* Leader.handlePhase1b safe values: multipaxos/Leader.scala:306-329, 543-566.  out[0] = maxSlot */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_leaderPhase1bScan(JNIEnv* env, jclass cls, jlong h,
+                                                                      jint chosenWatermark, jlongArray quorumMasks,
+                                                                      jint cap, jintArray maxSlot,
+                                                                      jintArray safeRound, jintArray safeValue) {
+  jlong* q = PIN(env, quorumMasks);
+  jint *mx = PIN(env, maxSlot), *sr = PIN(env, safeRound), *sv = PIN(env, safeValue);
+  int32_t st = fpx_leader_phase1b_scan((fpx_ctx*)(intptr_t)h, chosenWatermark, (const uint64_t*)q, cap, mx, sr, sv);
+  UNPIN(env, safeValue, sv, 0); UNPIN(env, safeRound, sr, 0); UNPIN(env, maxSlot, mx, 0);
+  UNPIN(env, quorumMasks, q, JNI_ABORT);
+  return st;
+}
+
+/* Replica.handleChosen + executeLog: multipaxos/Replica.scala:572-590, 394-447.  state = {executedWatermark, numChosen} */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_replicaChosen(JNIEnv* env, jclass cls, jlong h, jint n,
+                                                                  jintArray slot, jintArray value, jbyteArray mask,
+                                                                  jintArray state) {
+  jint *s = PIN(env, slot), *v = PIN(env, value), *o = PIN(env, state);
+  jbyte* m = PIN(env, mask);
+  int32_t st = fpx_replica_chosen((fpx_ctx*)(intptr_t)h, n, s, v, (const uint8_t*)m, o, o ? o + 1 : NULL);
+  UNPIN(env, mask, m, JNI_ABORT); UNPIN(env, state, o, 0); UNPIN(env, value, v, JNI_ABORT);
+  UNPIN(env, slot, s, JNI_ABORT);
+  return st;
+}
+
+/* mencius noop ranges: mencius/Acceptor.scala:237-291, mencius/ProxyLeader.scala:255-303, 355-411.
+ * bits: vote[numGroups x 4] then nack[numGroups x 4]; nackRound[0] */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_acceptorPhase2aNoopRange(
+    JNIEnv* env, jclass cls, jlong h, jint slotStart, jint slotEnd, jint round, jint numGroups, jlongArray targetMasks,
+    jlongArray bits, jintArray nackRound) {
+  jlong *t = PIN(env, targetMasks), *b = PIN(env, bits);
+  jint* nr = PIN(env, nackRound);
+  int32_t st = fpx_acceptor_phase2a_noop_range((fpx_ctx*)(intptr_t)h, slotStart, slotEnd, round, (const uint64_t*)t,
+                                               (uint64_t*)b, b ? (uint64_t*)b + (size_t)numGroups * 4 : NULL, nr);
+  UNPIN(env, nackRound, nr, 0); UNPIN(env, bits, b, 0); UNPIN(env, targetMasks, t, JNI_ABORT);
+  return st;
+}
+
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_proxyOpenNoopRange(JNIEnv* env, jclass cls, jlong h,
+                                                                       jint slotStart, jint slotEnd, jint round,
+                                                                       jbyteArray isNew) {
+  jbyte* f = PIN(env, isNew);
+  int32_t st = fpx_proxy_open_noop_range((fpx_ctx*)(intptr_t)h, slotStart, slotEnd, round, (uint8_t*)f);
+  UNPIN(env, isNew, f, 0);
+  return st;
+}
+
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_proxyPhase2bNoopRange(JNIEnv* env, jclass cls, jlong h,
+                                                                          jint slotStart, jint slotEnd, jint round,
+                                                                          jlongArray voteBits, jbyteArray newlyChosen) {
+  jlong* vb = PIN(env, voteBits);
+  jbyte* c = PIN(env, newlyChosen);
+  int32_t st = fpx_proxy_phase2b_noop_range((fpx_ctx*)(intptr_t)h, slotStart, slotEnd, round, (const uint64_t*)vb,
+                                            (uint8_t*)c);
+  UNPIN(env, newlyChosen, c, 0); UNPIN(env, voteBits, vb, JNI_ABORT);
+  return st;
+}
+
+/* EPaxos pre-accept fast path: epaxos/Replica.scala:569-600, 633-729, 1159-1419 */
+JNIEXPORT jlong JNICALL Java_frankenpaxos_gpu_Native_epxCreate(JNIEnv* env, jclass cls, jint numReplicas,
+                                                               jint numKeys, jint device) {
+  fpx_epx_config cfg = {numReplicas, numKeys, device, 0};
+  fpx_epx* e = NULL;
+  int32_t st = fpx_epx_create(&cfg, &e);
+  return st == FPX_OK ? (jlong)(intptr_t)e : -(jlong)st;
+}
+
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxDestroy(JNIEnv* env, jclass cls, jlong h) {
+  return fpx_epx_destroy((fpx_epx*)(intptr_t)h);
+}
+
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxPreaccept(
+    JNIEnv* env, jclass cls, jlong h, jint m, jintArray leader, jintArray number, jintArray key, jbyteArray isSet,
+    jbyteArray respMask, jintArray rank, jbyteArray fast, jintArray deps, jintArray leaderDeps) {
+  jint *l = PIN(env, leader), *nu = PIN(env, number), *k = PIN(env, key), *rk = PIN(env, rank);
+  jint *d = PIN(env, deps), *ld = PIN(env, leaderDeps);
+  jbyte *is = PIN(env, isSet), *rm = PIN(env, respMask), *f = PIN(env, fast);
+  int32_t st = fpx_epx_preaccept((fpx_epx*)(intptr_t)h, m, l, nu, k, (const uint8_t*)is, (const uint8_t*)rm, rk,
+                                 (uint8_t*)f, d, ld);
+  UNPIN(env, fast, f, 0); UNPIN(env, respMask, rm, JNI_ABORT); UNPIN(env, isSet, is, JNI_ABORT);
+  UNPIN(env, leaderDeps, ld, 0); UNPIN(env, deps, d, 0); UNPIN(env, rank, rk, JNI_ABORT);
+  UNPIN(env, key, k, JNI_ABORT); UNPIN(env, number, nu, JNI_ABORT); UNPIN(env, leader, l, JNI_ABORT);
+  return st;
+}

@@ -23,3 +23,15 @@ def test_scala_natives_have_shim_functions():
     assert len(natives) >= 7
     for name in natives:
         assert "Java_frankenpaxos_gpu_Native_" + name in shim, name
+
+
+def test_every_pinned_array_is_released():
+    """GetPrimitiveArrayCritical without its Release would wedge the JVM's garbage collector"""
+    shim = open(os.path.join(JNI, "fpx_jni.c")).read()
+    bodies = re.split(r"\nJNIEXPORT ", shim)[1:]
+    assert len(bodies) >= 19
+    for body in bodies:
+        name = re.search(r"Java_frankenpaxos_gpu_Native_(\w+)", body).group(1)
+        released = re.findall(r"UNPIN\(env, (\w+),", body)
+        only_pins = [a for a in re.findall(r"(?<!UN)PIN\(env, (\w+)\)", body)]
+        assert sorted(only_pins) == sorted(released), (name, only_pins, released)
