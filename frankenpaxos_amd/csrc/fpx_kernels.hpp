@@ -13,7 +13,8 @@
 //   k_phase2     K1 (acceptor vote: a1/a2) and K3 (fused open + vote + tally: a6 + a1 + a3/a4/a5)
 //   k_open       a6  ProxyLeader.handlePhase2a bookkeeping
 //   k_tally      K2  ProxyLeader.handlePhase2b (a3/a4) using the K2q predicates (a5)
-//   k_finalize   folds per-block maxima into the per-acceptor scalars round / maxVotedSlot
+//   k_finalize   folds the whole-group shards and the claimed per-block rows of maxima into the
+//                per-acceptor scalars round / maxVotedSlot
 //   k_phase1a_*  Acceptor.handlePhase1a
 //   k_quorum_eval  a5 standalone
 //
@@ -309,13 +310,14 @@ __global__ void __launch_bounds__(256) k_validate(const Geom g, const State st, 
 // ------------------------------------------------------------------------------------------------
 // k_phase2<G, VEC, PERSLOT, FUSED>
 //   G       lanes per slot (power of two, 4*G >= R): 64 for R in (128, 256], ... 1 for R <= 4
-//   VEC     R % 4 == 0: 16-byte row accesses
+//   VEC     16-byte row accesses (always true from the host: rows are padded to a multiple of 4 cells)
 //   PERSLOT ballot[S][R] in HBM instead of the per-acceptor scalar
 //   FUSED   K3 (open + vote + tally) instead of K1 (vote, bitmaps out)
-// A wavefront owns 64 consecutive messages: it stages their (slot, round, value) in registers with
-// one coalesced load each, then walks them Q = 64/G at a time, U steps in flight.
-// LDS: [2][ntab] per-block maxima tables, then per-wave staging of the outputs so that they leave
-// the CU as full coalesced lines.
+// A wavefront owns a chunk of consecutive messages (FPX_CHUNK = 32 at G = 64, else 64): it stages
+// their (slot, round, value) in registers with one coalesced load each, runs the proxy leader's open
+// step for all of them at once (K3), then walks them Q = 64/G at a time.
+// LDS: the workgroup's maxima (whole-group scalars, or [2][ntab] tables after a partial vote), then
+// per-wave staging of the outputs so that they leave the CU as full coalesced lines.
 // ------------------------------------------------------------------------------------------------
 template <bool FUSED>
 struct WaveOut;
