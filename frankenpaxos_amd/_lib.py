@@ -29,6 +29,7 @@ FPX_BALLOT_ACCEPTOR = 0
 FPX_BALLOT_PER_SLOT = 1
 
 FPX_F_TRUSTED = 1
+FPX_F_SCATTERED_TARGETS = 2
 
 FPX_NOOP = -1
 

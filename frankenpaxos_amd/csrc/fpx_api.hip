@@ -153,20 +153,26 @@ int grid_for(const fpx_ctx* ctx, int n) {
   return std::max(1, std::min(need, ctx->max_grid));
 }
 
-template <int G, bool VEC, bool PERSLOT>
+template <int G, bool RMW, bool PERSLOT>
 void launch_phase2_3(fpx_ctx* ctx, const Batch& b, bool fused, int grid) {
   const size_t lds = lds_bytes(ctx, fused);
   if (fused)
-    hipLaunchKernelGGL((k_phase2<G, VEC, PERSLOT, true>), dim3(grid), dim3(256), lds, ctx->stream, ctx->g, ctx->st, b);
+    hipLaunchKernelGGL((k_phase2<G, RMW, PERSLOT, true>), dim3(grid), dim3(256), lds, ctx->stream, ctx->g, ctx->st, b);
   else
-    hipLaunchKernelGGL((k_phase2<G, VEC, PERSLOT, false>), dim3(grid), dim3(256), lds, ctx->stream, ctx->g, ctx->st, b);
+    hipLaunchKernelGGL((k_phase2<G, RMW, PERSLOT, false>), dim3(grid), dim3(256), lds, ctx->stream, ctx->g, ctx->st, b);
 }
 
 template <int G>
 void launch_phase2_2(fpx_ctx* ctx, const Batch& b, bool fused, int grid) {
-  // rows are padded to a multiple of 4 cells (Geom::RS), so the int4 (VEC) instantiation serves every R
-  if (ctx->g.per_slot) launch_phase2_3<G, true, true>(ctx, b, fused, grid);
-  else launch_phase2_3<G, true, false>(ctx, b, fused, grid);
+  // rows are padded to a multiple of 4 cells (Geom::RS), so int4 accesses serve every R
+  const bool rmw = b.target && (ctx->cfg.flags & FPX_F_SCATTERED_TARGETS);
+  if (ctx->g.per_slot) {
+    if (rmw) launch_phase2_3<G, true, true>(ctx, b, fused, grid);
+    else launch_phase2_3<G, false, true>(ctx, b, fused, grid);
+  } else {
+    if (rmw) launch_phase2_3<G, true, false>(ctx, b, fused, grid);
+    else launch_phase2_3<G, false, false>(ctx, b, fused, grid);
+  }
 }
 
 void launch_phase2(fpx_ctx* ctx, const Batch& b, bool fused, int grid) {

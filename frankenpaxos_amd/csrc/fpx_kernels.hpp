@@ -308,9 +308,11 @@ __global__ void __launch_bounds__(256) k_validate(const Geom g, const State st, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_phase2<G, VEC, PERSLOT, FUSED>
+// k_phase2<G, RMW, PERSLOT, FUSED>
 //   G       lanes per slot (power of two, 4*G >= R): 64 for R in (128, 256], ... 1 for R <= 4
-//   VEC     16-byte row accesses (always true from the host: rows are padded to a multiple of 4 cells)
+//   RMW     partially voted 16-byte cells are written by load / blend / store instead of 4-byte stores
+//           (FPX_F_SCATTERED_TARGETS launches with target masks; rows are always moved as int4's, they are
+//           padded to a multiple of 4 cells)
 //   PERSLOT ballot[S][R] in HBM instead of the per-acceptor scalar
 //   FUSED   K3 (open + vote + tally) instead of K1 (vote, bitmaps out)
 // A wavefront owns a chunk of consecutive messages (FPX_CHUNK = 32 at G = 64, else 64): it stages
@@ -333,9 +335,10 @@ struct WaveOut<true> {     // K3: only the chosen flags are staged; bitmaps stay
   int32_t chosen[64];
 };
 
-template <int G, bool VEC, bool PERSLOT, bool FUSED>
+template <int G, bool RMW, bool PERSLOT, bool FUSED>
 __global__ void __launch_bounds__(256)
     k_phase2(const Geom g, const State st, const Batch b) {
+  constexpr bool VEC = true;  // 16-byte row accesses
   constexpr int Q = 64 / G;           // slots per step
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -470,10 +473,11 @@ __global__ void __launch_bounds__(256)
         }
       }
       // Acceptor.scala:204-208: round = phase2a.round; states(slot) = State(round, value)
+      const bool full_cell = (acc | (~own & 0xFu)) == 0xFu;
       if (acc) {
         const size_t row = (size_t)s * (size_t)g.RS + (size_t)r0;
         // whole-lane fast path: every acceptor this lane owns voted (padding cells may be overwritten)
-        if (VEC && (acc | (~own & 0xFu)) == 0xFu) {
+        if (VEC && full_cell) {
           const int4v rr = {rnd, rnd, rnd, rnd};
           const int4v vv = {val, val, val, val};
           row_store(rr, reinterpret_cast<int4v*>(st.vote_round + row));
@@ -483,6 +487,28 @@ __global__ void __launch_bounds__(256)
                 ((own & 8u) && thr[3] != rnd))
               row_store(rr, reinterpret_cast<int4v*>(st.ballot + row));
           }
+        } else if (RMW) {
+          // some of the lane's acceptors voted (thrifty delivery to a random f+1): read-modify-write of whole
+          // 16-byte cells keeps the traffic full-line -- 4-byte stores leave the L2 with partially written
+          // sectors that cost a DRAM read-modify-write each at eviction (+15 % on random f+1 of 255,
+          // profiles/r01_thrifty.txt).  Its own instantiation: the load in the step costs registers (one
+          // wave less per SIMD) and a wait that contiguous or dense targets do not want.
+          int4v* pr = reinterpret_cast<int4v*>(st.vote_round + row);
+          int4v* pv = reinterpret_cast<int4v*>(st.vote_value + row);
+          int4v orr = *pr, ovv = *pv;
+          int4v nb = {thr[0], thr[1], thr[2], thr[3]};
+          bool ballot_moves = false;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (acc >> k & 1u) {
+              orr[k] = rnd, ovv[k] = val;
+              ballot_moves = ballot_moves || thr[k] != rnd;
+              nb[k] = rnd;
+            }
+          }
+          row_store(orr, pr);
+          row_store(ovv, pv);
+          if (PERSLOT && ballot_moves) row_store(nb, reinterpret_cast<int4v*>(st.ballot + row));
         } else {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {

@@ -90,6 +90,10 @@ typedef enum {
 
 /* flags */
 #define FPX_F_TRUSTED 1u /* _dev entry points skip the run-contract validation pass (caller guarantees it) */
+/* Hint: target masks are scattered subsets of the group -- the reference's thrifty default, a random f+1
+ * of 2f+1 (ProxyLeader.scala:190-191).  K1 / K3 launches that carry target masks then write partially
+ * voted 16-byte cells by read-modify-write instead of 4-byte stores.  Results are identical either way. */
+#define FPX_F_SCATTERED_TARGETS 2u
 
 typedef struct {
   int32_t num_slots;         /* S: log window held in HBM; slots are 0 .. S-1                          */

@@ -14,6 +14,7 @@ import frankenpaxos_amd as fa
 S, R, F = 1 << 20, 255, 127
 dev = torch.device("cuda:0")
 ballot = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+scattered = len(sys.argv) > 2 and sys.argv[2] == "scattered"  # FPX_F_SCATTERED_TARGETS hint
 windows = 6
 
 
@@ -45,7 +46,7 @@ def rotating_masks(n):
 
 for name, maker in (("random f+1 subsets", random_masks), ("rotating f+1 run", rotating_masks), ("dense", None)):
     ctx = fa.Context(fa.make_config(num_slots=windows * S, num_replicas=R, f=F, ballot_mode=ballot,
-                                    flags=fa.FPX_F_TRUSTED))
+                                    flags=fa.FPX_F_TRUSTED | (fa.FPX_F_SCATTERED_TARGETS if scattered else 0)))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.acceptor_phase1a(0, 0)
     print('ctx ok', name, flush=True)

@@ -504,3 +504,21 @@ def test_page_locked_host_batches(fa, oracle):
     for p in pins + [tm]:
         p.free()
     assert fa.lib().fpx_host_free(None) == fa.FPX_EINVAL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R", [3, 7, 33, 255, 256])
+@pytest.mark.parametrize("ballot_mode", [0, 1])
+def test_scattered_targets_hint_changes_nothing(fa, oracle, R, ballot_mode):
+    """FPX_F_SCATTERED_TARGETS (16-byte read-modify-write of partially voted cells) is a pure
+    performance hint: same votes, same tallies, same state as the oracle on the adversarial stream
+    whose target masks are random subsets -- fused and unfused"""
+    S = 2048
+    q = R // 2 + 1
+    kw = dict(num_slots=S, num_replicas=R, quorum_kind=1, ballot_mode=ballot_mode, tally_ways=8)
+    gpu = fa.Context(fa.make_config(flags=fa.FPX_F_SCATTERED_TARGETS, **kw))
+    ref = oracle.System(oracle.make_config(**kw))
+    check(gpu, ref, W.adversarial_script(S, R, q, 23 + R, epochs=16, fused=True), tally_slots=range(0, S, 61))
+    gpu.reset()
+    ref.reset()
+    check(gpu, ref, W.adversarial_script(S, R, q, 29 + R, epochs=16, fused=False), tally_slots=range(0, S, 61))
