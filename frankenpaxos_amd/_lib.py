@@ -107,6 +107,7 @@ SIGNATURES = {
     "fpx_replica_chosen": (C.c_int32, [VP, C.c_int32, VP, VP, VP, I32P, I32P]),
     "fpx_replica_chosen_dev": (C.c_int32, [VP, C.c_int32, VP, VP, VP]),
     "fpx_replica_state": (C.c_int32, [VP, I32P, I32P]),
+    "fpx_replica_chosen_noop_range": (C.c_int32, [VP, C.c_int32, C.c_int32, I32P, I32P]),
     "fpx_replica_read_log": (C.c_int32, [VP, C.c_int32, C.c_int32, VP, VP]),
     "fpx_leader_phase1b_scan": (C.c_int32, [VP, C.c_int32, VP, C.c_int32, I32P, VP, VP]),
     "fpx_read_acceptor": (C.c_int32, [VP, C.c_int32, C.c_int32, I32P, I32P, VP, VP, VP]),

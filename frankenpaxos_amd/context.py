@@ -223,6 +223,11 @@ class Context:
                                        C.byref(wm), C.byref(nc))
         return st, wm.value, nc.value
 
+    def replica_chosen_noop_range(self, slot_start, slot_end):
+        wm, nc = C.c_int32(), C.c_int32()
+        st = self.L.fpx_replica_chosen_noop_range(self._h, slot_start, slot_end, C.byref(wm), C.byref(nc))
+        return st, wm.value, nc.value
+
     def replica_chosen_dev(self, slot, value, mask=None):
         st = self.L.fpx_replica_chosen_dev(self._h, slot.numel(), _dp(slot), _dp(value), _dp(mask))
         if st:

@@ -1045,6 +1045,34 @@ int32_t fpx_replica_chosen(fpx_ctx* ctx, int32_t n, const int32_t* slot, const i
   return fetch_status(ctx);
 }
 
+int32_t fpx_replica_chosen_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end, int32_t* executed_watermark,
+                                      int32_t* num_chosen) {
+  if (!ctx || slot_start < 0 || slot_end > ctx->g.S) return FPX_EINVAL;
+  const int stride = ctx->cfg.num_leader_groups;
+  const int count = slot_start < slot_end ? (slot_end - slot_start + stride - 1) / stride : 0;
+  int32_t first = count;
+  if (count > 0) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->st.log_scalars + LG_RANGE_FIRST, &first, 4, hipMemcpyHostToDevice, ctx->stream));
+    const int grid = std::max(1, std::min((count + 255) / 256, ctx->num_cus * 8));
+    hipLaunchKernelGGL(k_log_range_first, dim3(grid), dim3(256), 0, ctx->stream, ctx->st, slot_start, stride, count);
+    hipLaunchKernelGGL(k_log_range_fill, dim3(grid), dim3(256), 0, ctx->stream, ctx->st, slot_start, stride);
+    int rc = launch_check(ctx);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(&first, ctx->st.log_scalars + LG_RANGE_FIRST, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (first == count) {  // the handler ran to its end: executeLog (mencius/Replica.scala:485)
+    hipLaunchKernelGGL(k_log_prep, dim3(1), dim3(1), 0, ctx->stream, ctx->g, ctx->st);
+    hipLaunchKernelGGL(k_log_scan, dim3(ctx->num_cus * 4), dim3(256), 0, ctx->stream, ctx->g, ctx->st);
+    hipLaunchKernelGGL(k_log_commit, dim3(1), dim3(1), 0, ctx->stream, ctx->st);
+    int rc = launch_check(ctx);
+    if (rc) return rc;
+  }
+  int rc = fpx_replica_state(ctx, executed_watermark, num_chosen);
+  if (rc) return rc;
+  return fetch_status(ctx);
+}
+
 int32_t fpx_replica_read_log(fpx_ctx* ctx, int32_t first, int32_t count, int32_t* values, uint8_t* present) {
   if (!ctx || first < 0 || count < 0 || (int64_t)first + count > ctx->g.S) return FPX_EINVAL;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

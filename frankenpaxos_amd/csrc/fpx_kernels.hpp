@@ -1018,7 +1018,7 @@ __global__ void k_range_tally(const Geom g, const State st, int start, int end, 
 // already in the log is ignored, otherwise log.put + numChosen += 1; executeLog (:394-404) advances
 // executedWatermark over the contiguous prefix.
 // ------------------------------------------------------------------------------------------------
-enum { LG_WATERMARK = 0, LG_NUM_CHOSEN = 1, LG_LARGEST = 2, LG_FIRST_MISSING = 3 };
+enum { LG_WATERMARK = 0, LG_NUM_CHOSEN = 1, LG_LARGEST = 2, LG_FIRST_MISSING = 3, LG_RANGE_FIRST = 4 };
 
 __global__ void __launch_bounds__(256) k_log_ingest(const Geom g, const State st, const Batch b) {
   if (st.status[ST_CODE] != 0) return;
@@ -1072,6 +1072,38 @@ __global__ void k_log_commit(const State st) {
   if (st.status[ST_CODE] != 0) return;
   const int fm = st.log_scalars[LG_FIRST_MISSING];
   if (fm > st.log_scalars[LG_WATERMARK]) st.log_scalars[LG_WATERMARK] = fm;
+}
+
+// mencius Replica.handleChosenNoopRange (mencius/Replica.scala:464-485): the slots start, start + L, ...
+// below `end` get Noop in order UNTIL the first one that is already in the log -- there the reference
+// handler returns (the rest of the range is dropped and executeLog is not run).  Position k <-> slot
+// start + k * stride.  k_log_range_first: the smallest position already present (LG_RANGE_FIRST starts
+// at count); k_log_range_fill: put Noop at the positions before it.
+__global__ void __launch_bounds__(256) k_log_range_first(const State st, int start, int stride, int count) {
+  if (st.status[ST_CODE] != 0) return;
+  const int step = gridDim.x * blockDim.x;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += step) {
+    if (st.log_present[(size_t)start + (size_t)k * stride]) {
+      atomicMin(&st.log_scalars[LG_RANGE_FIRST], k);
+      break;  // later positions of this thread are larger
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_log_range_fill(const State st, int start, int stride) {
+  if (st.status[ST_CODE] != 0) return;
+  const int first = st.log_scalars[LG_RANGE_FIRST];
+  const int step = gridDim.x * blockDim.x;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < first; k += step) {
+    const size_t s = (size_t)start + (size_t)k * stride;
+    st.log_value[s] = -1;  // Noop
+    st.log_present[s] = 1;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && first > 0) {
+    st.log_scalars[LG_NUM_CHOSEN] += first;
+    const int top = start + (first - 1) * stride;  // BufferMap.largestKey
+    if (top > st.log_scalars[LG_LARGEST]) st.log_scalars[LG_LARGEST] = top;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

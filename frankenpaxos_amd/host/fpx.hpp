@@ -510,12 +510,25 @@ class NoopRangeEngine {
     return ChosenNoopRange{h.slotStartInclusive, h.slotEndExclusive};
   }
 
+  // mencius.Replica.handleChosenNoopRange (Replica.scala:464-485) at the replica whose log lives in this
+  // context: returns executedWatermark.  Like the reference it stops at the first slot of the range that
+  // is already chosen -- without filling the rest and without executing the log.
+  int replicaHandleChosenNoopRange(const ChosenNoopRange& m) {
+    int32_t wm = 0, nc = 0;
+    check(fpx_replica_chosen_noop_range(ctx_, m.slotStartInclusive, m.slotEndExclusive, &wm, &nc),
+          "Replica.handleChosenNoopRange");
+    numChosen_ = nc;
+    return wm;
+  }
+  int numChosen() const { return numChosen_; }
+
   fpx_ctx* context() { return ctx_; }
 
  private:
   Config config_;
   fpx_config fcfg_;
   fpx_ctx* ctx_ = nullptr;
+  int numChosen_ = 0;
 };
 
 }  // namespace mencius

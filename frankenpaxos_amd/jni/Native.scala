@@ -56,6 +56,8 @@ object Native {
                                 safeValue: Array[Int]): Int
   @native def replicaChosen(handle: Long, n: Int, slot: Array[Int], value: Array[Int],
                             mask: Array[Byte], state: Array[Int]): Int
+  @native def replicaChosenNoopRange(handle: Long, slotStart: Int, slotEnd: Int,
+                                     state: Array[Int]): Int
   @native def acceptorPhase2aNoopRange(handle: Long, slotStart: Int, slotEnd: Int, round: Int,
                                        numGroups: Int, targetMasks: Array[Long],
                                        bits: Array[Long], nackRound: Array[Int]): Int

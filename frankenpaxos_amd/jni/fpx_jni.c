@@ -168,6 +168,16 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_replicaChosen(JNIEnv* env, j
   return st;
 }
 
+/* mencius.Replica.handleChosenNoopRange: mencius/Replica.scala:464-485.  state = {executedWatermark, numChosen} */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_replicaChosenNoopRange(JNIEnv* env, jclass cls, jlong h,
+                                                                           jint slotStart, jint slotEnd,
+                                                                           jintArray state) {
+  jint* o = PIN(env, state);
+  int32_t st = fpx_replica_chosen_noop_range((fpx_ctx*)(intptr_t)h, slotStart, slotEnd, o, o ? o + 1 : NULL);
+  UNPIN(env, state, o, 0);
+  return st;
+}
+
 /* mencius noop ranges: mencius/Acceptor.scala:237-291, mencius/ProxyLeader.scala:255-303, 355-411.
  * bits: vote[numGroups x 4] then nack[numGroups x 4]; nackRound[0] */
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_acceptorPhase2aNoopRange(

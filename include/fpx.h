@@ -326,6 +326,12 @@ int32_t fpx_replica_chosen(fpx_ctx* ctx, int32_t n, const int32_t* slot, const i
 int32_t fpx_replica_chosen_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot,
                                const int32_t* d_value_id, const uint8_t* d_mask);
 int32_t fpx_replica_state(fpx_ctx* ctx, int32_t* executed_watermark, int32_t* num_chosen);
+/* mencius.Replica.handleChosenNoopRange (mencius/Replica.scala:464-485): the slots slot_start,
+ * slot_start + num_leader_groups, ... below slot_end are put as Noop in order until the first one that is
+ * ALREADY in the log -- there the reference handler returns: the rest of the range is dropped and
+ * executeLog does not run (kept as is).  Otherwise the contiguous prefix executes.  Synchronous. */
+int32_t fpx_replica_chosen_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end,
+                                      int32_t* executed_watermark, int32_t* num_chosen);
 /* log entries [first, first + count): value (-1 where absent) and present flag */
 int32_t fpx_replica_read_log(fpx_ctx* ctx, int32_t first, int32_t count, int32_t* values,
                              uint8_t* present);

@@ -1044,6 +1044,28 @@ int fpo_replica_chosen(fpo_sys* s, int32_t n, const int32_t* slot, const int32_t
   return FPO_OK;
 }
 
+int fpo_replica_chosen_noop_range(fpo_sys* s, int32_t slot_start, int32_t slot_end,
+                                  int32_t* executed_watermark, int32_t* num_chosen) {
+  if (slot_start < 0 || slot_end > s->cfg.num_slots) return FPO_EINVAL;
+  fpo_log* l = sys_log(s);
+  int returned_early = 0;
+  /* mencius/Replica.scala:471-484: for (slot <- start until end by config.numLeaderGroups) */
+  for (int slot = slot_start; slot < slot_end; slot += s->cfg.num_leader_groups) {
+    if (fpo_log_get(l, slot, NULL)) {
+      returned_early = 1; /* :475-479 `return`: leaves the handler, not just this iteration */
+      break;
+    }
+    fpo_log_put(l, slot, -1); /* :481, -1 = Noop */
+    l->num_chosen += 1;             /* :482 */
+  }
+  /* :485 executeLog() -- only reached when the loop ran to its end */
+  if (!returned_early)
+    while (fpo_log_get(l, l->executed_watermark, NULL)) l->executed_watermark += 1;
+  if (executed_watermark) *executed_watermark = l->executed_watermark;
+  if (num_chosen) *num_chosen = l->num_chosen;
+  return FPO_OK;
+}
+
 int fpo_replica_read_log(fpo_sys* s, int32_t first, int32_t count, int32_t* values, uint8_t* present) {
   fpo_log* l = sys_log(s);
   for (int i = 0; i < count; ++i) {

@@ -139,6 +139,9 @@ int fpo_proxy_phase2b_noop_range(fpo_sys* sys, int32_t slot_start, int32_t slot_
 /* f1: Replica.handleChosen per message (multipaxos/Replica.scala:572-590) on the system's replica log */
 int fpo_replica_chosen(fpo_sys* sys, int32_t n, const int32_t* slot, const int32_t* value_id,
                        const uint8_t* mask, int32_t* executed_watermark, int32_t* num_chosen);
+/* mencius.Replica.handleChosenNoopRange, mencius/Replica.scala:464-485 (early `return` kept) */
+int fpo_replica_chosen_noop_range(fpo_sys* sys, int32_t slot_start, int32_t slot_end,
+                                  int32_t* executed_watermark, int32_t* num_chosen);
 int fpo_replica_read_log(fpo_sys* sys, int32_t first, int32_t count, int32_t* values, uint8_t* present);
 /* f2: Leader.handlePhase1b recovery (multipaxos/Leader.scala:306-329 safeValue, :543-566) */
 int fpo_leader_phase1b_scan(fpo_sys* sys, int32_t chosen_watermark, const uint64_t* quorum_masks,

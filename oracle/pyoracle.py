@@ -118,6 +118,7 @@ def lib():
     L.fpo_proxy_open_noop_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, U8P]
     L.fpo_proxy_phase2b_noop_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, U64P, U8P]
     L.fpo_replica_chosen.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, U8P, I32P, I32P]
+    L.fpo_replica_chosen_noop_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32, I32P, I32P]
     L.fpo_replica_read_log.argtypes = [C.c_void_p, C.c_int32, C.c_int32, I32P, U8P]
     L.fpo_leader_phase1b_scan.argtypes = [C.c_void_p, C.c_int32, U64P, C.c_int32, I32P, I32P, I32P]
     L.fpo_error_detail.argtypes = [C.c_void_p, I32P, I32P, I32P]
@@ -384,6 +385,11 @@ class System:
         wm, nc = C.c_int32(), C.c_int32()
         st = lib().fpo_replica_chosen(self._h, len(slot), _p(slot, I32P), _p(value, I32P),
                                       _p(mask, U8P), C.byref(wm), C.byref(nc))
+        return st, wm.value, nc.value
+
+    def replica_chosen_noop_range(self, slot_start, slot_end):
+        wm, nc = C.c_int32(), C.c_int32()
+        st = lib().fpo_replica_chosen_noop_range(self._h, slot_start, slot_end, C.byref(wm), C.byref(nc))
         return st, wm.value, nc.value
 
     def replica_read_log(self, first, count):

@@ -284,6 +284,13 @@ static void menciusNoopRange() {
   SHOULD_BE(voteRound[4], 2); SHOULD_BE(voteValue[4], FPX_NOOP);    // slot 4 -> acceptor group (4 / 3) % 2 = 1
   SHOULD_BE(voteRound[10], 2); SHOULD_BE(voteRound[7], -1);         // slot 7 belongs to acceptor group 0
   SHOULD_BE(voteRound[16], -1);                                     // outside the range
+  // the replica: slots 4, 7, 10, 13 become Noop; nothing executes (hole at 0)
+  SHOULD_BE(engine.replicaHandleChosenNoopRange(*chosen), 0);
+  SHOULD_BE(engine.numChosen(), 4);
+  SHOULD_BE(engine.replicaHandleChosenNoopRange({4, 14}), 0);  // 4 is already chosen: returns at once
+  SHOULD_BE(engine.numChosen(), 4);
+  SHOULD_BE(engine.replicaHandleChosenNoopRange({0, 4}), 1);   // slots 0, 3: executes 0, hole at 1
+  SHOULD_BE(engine.numChosen(), 6);
 }
 
 // epaxos pre-accept, the two hand-worked ticks of tests/test_epaxos.py (Replica.scala:569-600, 633-729,

@@ -129,3 +129,52 @@ def test_noop_range_arguments(fa):
     assert gpu.proxy_open_noop_range(0, 4, -1)[0] == fa.FPX_EINVAL
     per_slot = fa.Context(fa.make_config(ballot_mode=1, **KW))
     assert per_slot.acceptor_phase2a_noop_range(0, 4, 0)[0] == fa.FPX_EINVAL
+
+
+# ------------------------------------------------ the receiver: Replica.handleChosenNoopRange ------
+def test_oracle_replica_chosen_noop_range_by_hand(oracle):
+    """mencius/Replica.scala:464-485, including its early `return` on a slot that is already chosen"""
+    s = oracle.System(oracle.make_config(**KW))            # 3 leader groups: stride 3
+    assert s.replica_chosen_noop_range(1, 11) == (0, 0, 4)  # slots 1, 4, 7, 10 <- Noop; hole at 0
+    vals, pres = s.replica_read_log(0, 12)
+    assert pres.tolist() == [0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1, 0] and (vals[pres == 1] == -1).all()
+    assert s.replica_chosen([0, 2, 3], [50, 52, 53])[1:] == (5, 7)   # prefix 0..4 executes
+    # leader group 2 skips 2, 5, 8, 11 -- but 2 is already chosen: the handler returns at once,
+    # nothing is put and executeLog does not run
+    assert s.replica_chosen_noop_range(2, 12) == (0, 5, 7)
+    assert s.replica_read_log(5, 1)[1].tolist() == [0]
+    # from 5 on: 5, 8, 11 are put; executeLog: 5 -> watermark 6 (6 is missing)
+    assert s.replica_chosen_noop_range(5, 12) == (0, 6, 10)
+    # a range that hits a chosen slot in the middle: 13 is put, 16 is present -> return; 19 is NOT put,
+    # and executeLog is skipped although nothing blocks it
+    assert s.replica_chosen([16, 6], [66, 56])[1:] == (9, 12)
+    assert s.replica_chosen([9], [59])[1:] == (12, 13)
+    assert s.replica_chosen([12], [62])[1:] == (13, 14)
+    assert s.replica_chosen_noop_range(13, 22) == (0, 13, 15)       # 13 put, watermark NOT advanced
+    assert s.replica_read_log(19, 1)[1].tolist() == [0]
+    assert s.replica_chosen_noop_range(30, 30) == (0, 14, 15)       # empty range: executeLog only
+    assert s.replica_chosen_noop_range(-1, 4)[0] == 1 and s.replica_chosen_noop_range(0, 257)[0] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stride", [1, 3])
+def test_replica_chosen_noop_range_matches_oracle(fa, oracle, stride):
+    kw = dict(KW, num_leader_groups=stride, num_slots=4096)
+    gpu = fa.Context(fa.make_config(**kw))
+    ref = oracle.System(oracle.make_config(**kw))
+    rng = np.random.default_rng(17 + stride)
+    S = kw["num_slots"]
+    for step in range(300):
+        if rng.random() < 0.5:
+            n = int(rng.integers(1, 40))
+            slot = rng.integers(0, min(S, 64 + step * 14), n).astype(np.int32)
+            val = rng.integers(0, 1000, n).astype(np.int32)
+            assert gpu.replica_chosen(slot, val) == ref.replica_chosen(slot, val)
+        else:
+            start = int(rng.integers(0, min(S - 1, 32 + step * 14)))
+            end = min(S, start + int(rng.integers(0, 200)))
+            assert gpu.replica_chosen_noop_range(start, end) == ref.replica_chosen_noop_range(start, end)
+    a, b = gpu.replica_read_log(0, S), ref.replica_read_log(0, S)
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(a[0][a[1] == 1], b[0][b[1] == 1])
+    assert gpu.replica_chosen_noop_range(0, S + 1)[0] == fa.FPX_EINVAL
