@@ -152,3 +152,31 @@ def test_mencius_slot_to_group_map(oracle):
     # multipaxos: slot % numAcceptorGroups (multipaxos/ProxyLeader.scala:190)
     s = oracle.System(oracle.make_config(num_slots=64, num_replicas=3, num_groups=5, f=1))
     assert [s.group_of_slot(x) for x in range(12)] == [x % 5 for x in range(12)]
+
+
+def test_flat_oracle_agrees_with_the_reference_shaped_restatement(oracle):
+    """Two independent restatements of the same handlers -- the flat-array oracle the parity tests use
+    and oracle/fpx_faithful.cpp, which keeps the reference's data-structure shapes (a sorted map per
+    acceptor, a hash map of Pending/Done keyed by (slot, round), one heap message per Phase2a / Phase2b
+    through a FIFO transport) -- must choose the same values on the steady stream."""
+    import ctypes as C
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "oracle", "libfpx_faithful.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "libfpx_faithful.so"],
+                              stdout=subprocess.DEVNULL)
+    L = C.CDLL(so)
+    L.fpo_faithful_run.restype = C.c_int64
+    L.fpo_faithful_run.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]
+    for S, R, f in ((500, 3, 1), (300, 7, 3), (64, 255, 127)):
+        slot, rnd, val = W.steady_stream(S)
+        cs = C.c_int64()
+        n = L.fpo_faithful_run(S, R, f, val.ctypes.data, C.byref(cs))
+        sys_ = oracle.System(oracle.make_config(num_slots=S, num_replicas=R, f=f))
+        assert sys_.acceptor_phase1a(0, 0)[0] == 0
+        st, ch, cr, cv, nr = sys_.phase2_fused(slot, rnd, val)
+        assert st == 0 and n == int(ch.sum()) == S
+        assert cs.value == int(cv[ch == 1].astype(np.int64).sum())
