@@ -44,6 +44,7 @@ struct EpxBatch {
   const int32_t* key;
   const uint8_t* is_set;
   const uint8_t* resp_mask;
+  const uint8_t* seen_mask;  // replicas that process the PreAccept (null = resp_mask)
   const int32_t* rank;   // [n][m]
   uint2* kv;             // [n][m] in the replica's delivery order: x = key | is_set << 27 | leader << 28
                          // (only the key bits are sorted on), y = message index
@@ -91,10 +92,12 @@ __global__ void __launch_bounds__(256) k_epx_keys(const EpxState st, const EpxBa
   const unsigned mask = b.resp_mask[i];
   bool ok = L >= 0 && L < n && b.number[i] >= 0 && k >= 0 && k < st.num_keys;
   ok = ok && !((mask >> (ok ? L : 0)) & 1u) && (mask >> n) == 0 && __popc(mask) == n - 2;
+  const unsigned seen = b.seen_mask ? b.seen_mask[i] : mask;
+  ok = ok && (mask & ~seen) == 0 && !((seen >> (ok ? L : 0)) & 1u) && (seen >> n) == 0;
   for (int r = 0; r < n; ++r) {
     const int p = b.rank[(size_t)r * b.m + i];
     ok = ok && p >= 0 && p < b.m;
-    const bool part = ok && (r == L || ((mask >> r) & 1u));
+    const bool part = ok && (r == L || ((seen >> r) & 1u));
     // rank is a permutation: scattering to position p lays the tick out in replica r's delivery order;
     // a stable sort by key alone then yields (key, delivery order).  Non-participants sort last.
     if (ok) {
@@ -372,7 +375,7 @@ struct fpx_epx {
   EpxState st;
   hipStream_t stream = nullptr, own_stream = nullptr;
   int last_hip = 0;
-  Buf kv, kv2, seg, conf, tmp, tick, h_leader, h_number, h_key, h_set, h_mask, h_rank, o_fast, o_deps, o_ldeps;
+  Buf kv, kv2, seg, conf, tmp, tick, h_leader, h_number, h_key, h_set, h_mask, h_seen, h_rank, o_fast, o_deps, o_ldeps;
 };
 
 namespace {
@@ -447,7 +450,7 @@ int32_t fpx_epx_destroy(fpx_epx* e) {
   for (void* p : ps)
     if (p) (void)hipFree(p);
   Buf* bs[] = {&e->kv, &e->kv2, &e->seg, &e->conf, &e->tmp, &e->tick, &e->h_leader, &e->h_number,
-               &e->h_key, &e->h_set, &e->h_mask, &e->h_rank, &e->o_fast, &e->o_deps, &e->o_ldeps};
+               &e->h_key, &e->h_set, &e->h_mask, &e->h_seen, &e->h_rank, &e->o_fast, &e->o_deps, &e->o_ldeps};
   for (Buf* b : bs)
     if (b->p) (void)hipFree(b->p);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -476,7 +479,8 @@ int32_t fpx_epx_sync(fpx_epx* e) {
 
 int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, const int32_t* d_number,
                               const int32_t* d_key, const uint8_t* d_is_set, const uint8_t* d_resp_mask,
-                              const int32_t* d_rank, uint8_t* d_fast, int32_t* d_deps, int32_t* d_leader_deps) {
+                              const uint8_t* d_seen_mask, const int32_t* d_rank, uint8_t* d_fast, int32_t* d_deps,
+                              int32_t* d_leader_deps) {
   if (!e || m < 0) return FPX_EINVAL;
   if (m == 0) return FPX_OK;
   const int n = e->st.n;
@@ -489,6 +493,7 @@ int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, co
   EpxBatch b;
   memset(&b, 0, sizeof(b));
   b.m = m, b.leader = d_leader, b.number = d_number, b.key = d_key, b.is_set = d_is_set, b.resp_mask = d_resp_mask;
+  b.seen_mask = d_seen_mask;
   b.rank = d_rank;
   b.kv = (uint2*)e->kv.p, b.kv_sorted = (uint2*)e->kv2.p;
   b.tick = (int32_t*)e->tick.p;
@@ -531,8 +536,8 @@ int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, co
 }
 
 int32_t fpx_epx_preaccept(fpx_epx* e, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* key,
-                          const uint8_t* is_set, const uint8_t* resp_mask, const int32_t* rank, uint8_t* fast,
-                          int32_t* deps, int32_t* leader_deps) {
+                          const uint8_t* is_set, const uint8_t* resp_mask, const uint8_t* seen_mask,
+                          const int32_t* rank, uint8_t* fast, int32_t* deps, int32_t* leader_deps) {
   if (!e || m < 0 || (m > 0 && (!leader || !number || !key || !is_set || !resp_mask || !rank))) return FPX_EINVAL;
   if (m == 0) return FPX_OK;
   const int n = e->st.n;
@@ -548,12 +553,14 @@ int32_t fpx_epx_preaccept(fpx_epx* e, int32_t m, const int32_t* leader, const in
   if ((rc = up(&e->h_key, key, (size_t)m * 4))) return rc;
   if ((rc = up(&e->h_set, is_set, (size_t)m))) return rc;
   if ((rc = up(&e->h_mask, resp_mask, (size_t)m))) return rc;
+  if (seen_mask && (rc = up(&e->h_seen, seen_mask, (size_t)m))) return rc;
   if ((rc = up(&e->h_rank, rank, (size_t)n * m * 4))) return rc;
   if ((rc = grow(e, &e->o_fast, (size_t)m))) return rc;
   if ((rc = grow(e, &e->o_deps, (size_t)m * n * 4))) return rc;
   if ((rc = grow(e, &e->o_ldeps, (size_t)m * n * 4))) return rc;
   rc = fpx_epx_preaccept_dev(e, m, (int32_t*)e->h_leader.p, (int32_t*)e->h_number.p, (int32_t*)e->h_key.p,
-                             (uint8_t*)e->h_set.p, (uint8_t*)e->h_mask.p, (int32_t*)e->h_rank.p, (uint8_t*)e->o_fast.p,
+                             (uint8_t*)e->h_set.p, (uint8_t*)e->h_mask.p, seen_mask ? (uint8_t*)e->h_seen.p : nullptr,
+                             (int32_t*)e->h_rank.p, (uint8_t*)e->o_fast.p,
                              (int32_t*)e->o_deps.p, (int32_t*)e->o_ldeps.p);
   if (rc) return rc;
   if (fast) EHIP(e, hipMemcpyAsync(fast, e->o_fast.p, (size_t)m, hipMemcpyDeviceToHost, e->stream));

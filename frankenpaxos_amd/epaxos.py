@@ -22,8 +22,7 @@ def _bind(L):
     L.fpx_epx_destroy.argtypes = [VP]
     L.fpx_epx_set_stream.argtypes = [VP, VP]
     L.fpx_epx_sync.argtypes = [VP]
-    L.fpx_epx_preaccept.argtypes = [VP, C.c_int32] + [VP] * 9
-    L.fpx_epx_preaccept_dev.argtypes = [VP, C.c_int32] + [VP] * 9
+    # fpx_epx_preaccept[_dev]: the table in _lib.SIGNATURES (one place, checked against the header)
     L.fpx_epx_read_index.argtypes = [VP, C.c_int32, C.c_int32, VP, VP]
     L._epx_bound = True
 
@@ -59,25 +58,28 @@ class EPaxos:
     def sync(self):
         return self.L.fpx_epx_sync(self._h)
 
-    def preaccept(self, leader, number, key, is_set, resp_mask, rank):
+    def preaccept(self, leader, number, key, is_set, resp_mask, rank, seen_mask=None):
+        """seen_mask: the other replicas that process the PreAccept (None = resp_mask, a thrifty
+        deployment; all n-1 others with the reference's default ThriftySystem.NotThrifty)"""
         a32 = lambda x: np.ascontiguousarray(x, dtype=np.int32)
         a8 = lambda x: np.ascontiguousarray(x, dtype=np.uint8)
         leader, number, key, rank = a32(leader), a32(number), a32(key), a32(rank)
         is_set, resp_mask = a8(is_set), a8(resp_mask)
+        seen_mask = None if seen_mask is None else a8(seen_mask)
         m = len(leader)
         fast = np.zeros(m, np.uint8)
         deps = np.zeros((m, self.n), np.int32)
         ldeps = np.zeros((m, self.n), np.int32)
-        p = lambda a: a.ctypes.data
+        p = lambda a: None if a is None else a.ctypes.data
         st = self.L.fpx_epx_preaccept(self._h, m, p(leader), p(number), p(key), p(is_set), p(resp_mask),
-                                      p(rank), p(fast), p(deps), p(ldeps))
+                                      p(seen_mask), p(rank), p(fast), p(deps), p(ldeps))
         return st, fast, deps, ldeps
 
     def preaccept_dev(self, leader, number, key, is_set, resp_mask, rank, fast=None, deps=None,
-                      leader_deps=None):
+                      leader_deps=None, seen_mask=None):
         d = lambda t: None if t is None else t.data_ptr()
         st = self.L.fpx_epx_preaccept_dev(self._h, leader.numel(), d(leader), d(number), d(key), d(is_set),
-                                          d(resp_mask), d(rank), d(fast), d(deps), d(leader_deps))
+                                          d(resp_mask), d(seen_mask), d(rank), d(fast), d(deps), d(leader_deps))
         if st:
             raise FpxError(st, "fpx_epx_preaccept_dev")
 

@@ -543,7 +543,10 @@ struct Command { int32_t key; bool isSet; };
 struct Proposal {
   Instance instance;
   Command command;
-  std::vector<int> fastQuorum;  // the n-2 other replicas the leader sends PreAccept to (Replica.scala:705-706)
+  std::vector<int> fastQuorum;  // the n-2 other replicas whose PreAcceptOk's the leader decides on: with a
+                                // thrifty system the only ones it sends to (Replica.scala:705-706)
+  std::vector<int> recipients;  // every other replica that receives the PreAccept; empty => fastQuorum.  With
+                                // the reference's default ThriftySystem.NotThrifty: all n-1 others.
 };
 // what the leader does with it after the PreAcceptOk's are in
 struct Decision {
@@ -576,7 +579,8 @@ class PreAcceptEngine {
                                    const std::vector<std::vector<int>>& deliveryOrder = {}) {
     const int m = (int)proposals.size();
     std::vector<int32_t> leader(m), number(m), key(m), rank((size_t)n_ * m);
-    std::vector<uint8_t> isSet(m), mask(m);
+    std::vector<uint8_t> isSet(m), mask(m), seen(m);
+    bool anyRecipients = false;
     for (int i = 0; i < m; ++i) {
       const Proposal& p = proposals[i];
       leader[i] = p.instance.replicaIndex, number[i] = p.instance.instanceNumber;
@@ -587,6 +591,13 @@ class PreAcceptEngine {
         b |= 1u << r;
       }
       mask[i] = (uint8_t)b;
+      unsigned sb = p.recipients.empty() ? b : 0;
+      for (int r : p.recipients) {
+        if (r < 0 || r >= n_) throw std::invalid_argument("replica index out of range");
+        sb |= 1u << r;
+      }
+      seen[i] = (uint8_t)sb;
+      anyRecipients = anyRecipients || !p.recipients.empty();
     }
     if (!deliveryOrder.empty() && (int)deliveryOrder.size() != n_)
       throw std::invalid_argument("one delivery order per replica");
@@ -606,8 +617,8 @@ class PreAcceptEngine {
     }
     std::vector<uint8_t> fast(m);
     std::vector<int32_t> deps((size_t)m * n_), ldeps((size_t)m * n_);
-    check(fpx_epx_preaccept(epx_, m, leader.data(), number.data(), key.data(), isSet.data(), mask.data(), rank.data(),
-                            fast.data(), deps.data(), ldeps.data()),
+    check(fpx_epx_preaccept(epx_, m, leader.data(), number.data(), key.data(), isSet.data(), mask.data(),
+                            anyRecipients ? seen.data() : nullptr, rank.data(), fast.data(), deps.data(), ldeps.data()),
           "Replica.handlePreAccept");
     std::vector<Decision> out(m);
     for (int i = 0; i < m; ++i) {

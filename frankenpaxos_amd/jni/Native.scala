@@ -69,7 +69,7 @@ object Native {
   @native def epxDestroy(handle: Long): Int
   @native def epxPreaccept(handle: Long, m: Int, leader: Array[Int], number: Array[Int],
                            key: Array[Int], isSet: Array[Byte], respMask: Array[Byte],
-                           rank: Array[Int], fast: Array[Byte], deps: Array[Int],
+                           seenMask: Array[Byte], rank: Array[Int], fast: Array[Byte], deps: Array[Int],
                            leaderDeps: Array[Int]): Int
 
   def check(status: Int, logger: Logger): Unit = status match {

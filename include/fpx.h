@@ -287,6 +287,11 @@ int32_t fpx_proxy_phase2b_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t s
  * leader takes the fast path iff the n-2 answers are identical (popularItems(..., n-2)), otherwise
  * the slow path proposes the union of all answers (preAcceptingSlowPath, :796-813).  After the tick
  * the commits reach every replica's conflict index (commit -> updateConflictIndex, :815-828).
+ * seen_mask (NULL = resp_mask, the thrifty deployment): the OTHER replicas that receive and process the
+ * PreAccept at all.  With the reference's default ThriftySystem.NotThrifty (Replica.scala:83, 556-562) that is
+ * every other replica (n-1 of them): all of them compute conflicts and update their index in their order,
+ * and the leader decides on the first n-2 answers to arrive (fastQuorumSize responses including its own,
+ * :1376) -- resp_mask, a subset of seen_mask.
  * Outputs (may be NULL): fast[i]; deps[i * n + l] = committed (fast) or Accept-phase (slow)
  * dependency watermark for leader l; leader_deps likewise for the PreAccept.  Sequence numbers are the
  * constant 0 the reference uses with top-k dependencies (:575-578). */
@@ -302,12 +307,13 @@ int32_t fpx_epx_destroy(fpx_epx* epx);
 int32_t fpx_epx_set_stream(fpx_epx* epx, void* hip_stream);
 int32_t fpx_epx_preaccept(fpx_epx* epx, int32_t m, const int32_t* leader, const int32_t* number,
                           const int32_t* key, const uint8_t* is_set, const uint8_t* resp_mask,
-                          const int32_t* rank, uint8_t* fast, int32_t* deps, int32_t* leader_deps);
+                          const uint8_t* seen_mask, const int32_t* rank, uint8_t* fast, int32_t* deps,
+                          int32_t* leader_deps);
 /* device-resident inputs / outputs, asynchronous; fpx_epx_sync returns the sticky status */
 int32_t fpx_epx_preaccept_dev(fpx_epx* epx, int32_t m, const int32_t* d_leader, const int32_t* d_number,
                               const int32_t* d_key, const uint8_t* d_is_set, const uint8_t* d_resp_mask,
-                              const int32_t* d_rank, uint8_t* d_fast, int32_t* d_deps,
-                              int32_t* d_leader_deps);
+                              const uint8_t* d_seen_mask, const int32_t* d_rank, uint8_t* d_fast,
+                              int32_t* d_deps, int32_t* d_leader_deps);
 int32_t fpx_epx_sync(fpx_epx* epx);
 /* replica's conflict-index entry of one key: gets[n], sets[n] (TopOne vectors) */
 int32_t fpx_epx_read_index(fpx_epx* epx, int32_t replica, int32_t key, int32_t* gets, int32_t* sets);

@@ -86,8 +86,8 @@ static int popcount8(unsigned x) { return __builtin_popcount(x & 0xffu); }
  * Returns 0, or 1 (EINVAL) on malformed input.
  */
 int fpo_epx_preaccept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* key,
-                      const uint8_t* is_set, const uint8_t* resp_mask, const int32_t* rank, uint8_t* fast,
-                      int32_t* deps, int32_t* leader_deps) {
+                      const uint8_t* is_set, const uint8_t* resp_mask, const uint8_t* seen_mask,
+                      const int32_t* rank, uint8_t* fast, int32_t* deps, int32_t* leader_deps) {
   const int n = e->n;
   if (m < 0) return 1;
   for (int i = 0; i < m; ++i) {
@@ -95,6 +95,10 @@ int fpo_epx_preaccept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_
     if ((resp_mask[i] >> leader[i]) & 1u) return 1;                     /* "other" replicas only */
     if (resp_mask[i] >> n) return 1;
     if (popcount8(resp_mask[i]) != n - 2) return 1;                     /* fastQuorumSize - 1, :705 */
+    /* the replicas the PreAccept is sent to: thriftyOtherReplicas(fastQuorumSize - 1), :556-562, 705 --
+     * exactly the n-2 with a thrifty system, every other replica with the default NotThrifty (:83) */
+    const unsigned seen = seen_mask ? seen_mask[i] : resp_mask[i];
+    if ((resp_mask[i] & ~seen) || ((seen >> leader[i]) & 1u) || (seen >> n)) return 1;
   }
   /* local conflicts seen by replica r for message i, in r's own processing order */
   int* conf = (int*)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1) * n * n);
@@ -110,7 +114,7 @@ int fpo_epx_preaccept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_
     }
     for (int p = 0; p < m; ++p) {
       const int i = order[p];
-      const int participates = r == leader[i] || ((resp_mask[i] >> r) & 1u);
+      const int participates = r == leader[i] || (((seen_mask ? seen_mask[i] : resp_mask[i]) >> r) & 1u);
       if (!participates) continue;
       /* Replica.scala:580-583: getTopOneConflicts then subtractOne(instance); the instance is fresh,
        * so it is not in the index yet and subtractOne changes nothing.  Then updateConflictIndex
@@ -141,8 +145,10 @@ int fpo_epx_preaccept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_
         all_equal = 0;
       }
     }
-    /* handlePreAcceptOk :1376-1410: with the leader's own response plus n-2 others the fast quorum
-     * (n-1) is reached; popularItems(others' (seq, deps), n-2) is non-empty iff all n-2 agree */
+    /* handlePreAcceptOk :1376-1410: with the leader's own response plus the first n-2 others to arrive
+     * (resp_mask) the fast quorum (n-1) is reached and the leader decides at once;
+     * popularItems(others' (seq, deps), n-2) is non-empty iff all n-2 agree.  A later answer of a further
+     * replica in seen_mask finds the instance committed / accepting and is ignored (:1308-1334). */
     const int is_fast = all_equal;
     if (fast) fast[i] = (uint8_t)is_fast;
     for (int l = 0; l < n; ++l) {

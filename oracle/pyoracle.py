@@ -485,7 +485,8 @@ class EPaxos:
         L.fpo_epx_new.argtypes = [C.c_int, C.c_int]
         L.fpo_epx_new.restype = C.c_void_p
         L.fpo_epx_free.argtypes = [C.c_void_p]
-        L.fpo_epx_preaccept.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, U8P, U8P, I32P, U8P, I32P, I32P]
+        L.fpo_epx_preaccept.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, U8P, U8P, U8P, I32P, U8P, I32P,
+                                        I32P]
         L.fpo_epx_read_index.argtypes = [C.c_void_p, C.c_int, C.c_int, I32P, I32P]
         self.n, self.num_keys = num_replicas, num_keys
         self._h = L.fpo_epx_new(num_replicas, num_keys)
@@ -498,16 +499,18 @@ class EPaxos:
         except Exception:
             pass
 
-    def preaccept(self, leader, number, key, is_set, resp_mask, rank):
+    def preaccept(self, leader, number, key, is_set, resp_mask, rank, seen_mask=None):
         a8 = lambda x: np.ascontiguousarray(x, dtype=np.uint8)
         leader, number, key, rank = _i32(leader), _i32(number), _i32(key), _i32(rank)
         is_set, resp_mask = a8(is_set), a8(resp_mask)
+        seen_mask = None if seen_mask is None else a8(seen_mask)
         m = len(leader)
         fast = np.zeros(m, np.uint8)
         deps = np.zeros((m, self.n), np.int32)
         ldeps = np.zeros((m, self.n), np.int32)
         st = lib().fpo_epx_preaccept(self._h, m, _p(leader, I32P), _p(number, I32P), _p(key, I32P),
-                                     _p(is_set, U8P), _p(resp_mask, U8P), _p(rank, I32P), _p(fast, U8P),
+                                     _p(is_set, U8P), _p(resp_mask, U8P), _p(seen_mask, U8P), _p(rank, I32P),
+                                     _p(fast, U8P),
                                      _p(deps, I32P), _p(ldeps, I32P))
         return st, fast, deps, ldeps
 

@@ -87,6 +87,29 @@ def test_oracle_slow_path_by_hand(oracle):
     assert e.preaccept([0], [0], [0], [1], [0b00111], np.zeros((5, 1), np.int32))[0] == 1  # asks itself
 
 
+def test_oracle_not_thrifty_by_hand(oracle):
+    """ThriftySystem.NotThrifty (the reference's default, Replica.scala:83, 556-562): the PreAccept goes to
+    EVERY other replica, each of them records the command in its conflict index, and the leader decides on
+    the first n-2 answers.  n = 3: A = set k1 by replica 0, B = get k1 by replica 2; both are answered by
+    replica 1; every replica processes A before B."""
+    leader, number, key, is_set = [0, 2], [0, 0], [1, 1], [1, 0]
+    resp, seen = [0b010, 0b010], [0b110, 0b011]
+    rank = np.array([[0, 1], [0, 1], [0, 1]])
+    e = oracle.EPaxos(3, 4)
+    st, fast, deps, ldeps = e.preaccept(leader, number, key, is_set, resp, rank, seen_mask=seen)
+    assert st == 0 and fast.tolist() == [1, 1]
+    # A reached replica 2 although its answer is not waited for: B's own leader already conflicts with it
+    assert ldeps[1].tolist() == [1, 0, 0] and deps[1].tolist() == [1, 0, 0]
+    assert ldeps[0].tolist() == [0, 0, 0] and deps[0].tolist() == [0, 0, 0]
+    # thrifty: replica 2 never sees A's PreAccept, B's PreAccept carries no dependency; replica 1 adds it
+    e = oracle.EPaxos(3, 4)
+    st, fast, deps, ldeps = e.preaccept(leader, number, key, is_set, resp, rank)
+    assert ldeps[1].tolist() == [0, 0, 0] and deps[1].tolist() == [1, 0, 0]
+    # the answers counted must come from replicas the PreAccept was sent to; never from the leader itself
+    assert e.preaccept([0], [5], [0], [1], [0b010], np.zeros((3, 1), np.int32), seen_mask=[0b100])[0] == 1
+    assert e.preaccept([0], [5], [0], [1], [0b010], np.zeros((3, 1), np.int32), seen_mask=[0b011])[0] == 1
+
+
 # ----------------------------------------------------------------------------- GPU parity -------
 def random_tick(rng, n, num_keys, m, next_number, skew):
     leader = rng.integers(0, n, m).astype(np.int32)
@@ -152,3 +175,35 @@ def test_epaxos_invalid_ticks(oracle):
     assert st == 0 and fast[0] == 1 and deps[0].tolist() == [0] * 5
     with pytest.raises(fa.FpxError):
         EPaxos(4, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,num_keys,m", [(3, 8, 700), (5, 64, 5000), (7, 16, 3000)])
+def test_epaxos_not_thrifty_ticks_match_oracle(oracle, n, num_keys, m):
+    """seen_mask: the PreAccept reaches every other replica (ThriftySystem.NotThrifty, the reference's
+    default) or a random superset of the n-2 that are waited for"""
+    from frankenpaxos_amd.epaxos import EPaxos
+    import frankenpaxos_amd as fa
+
+    gpu, ref = EPaxos(n, num_keys), oracle.EPaxos(n, num_keys)
+    rng = np.random.default_rng(n * 77 + num_keys)
+    nxt = [0] * n
+    for tick in range(4):
+        leader, number, key, is_set, mask, rank = random_tick(rng, n, num_keys, m, nxt, 8.0)
+        everyone = ((1 << n) - 1) & ~(1 << leader.astype(np.int64))
+        seen = np.where(rng.random(m) < 0.7, everyone, mask).astype(np.uint8)   # mixed deployments in one tick
+        a = gpu.preaccept(leader, number, key, is_set, mask, rank, seen_mask=seen)
+        b = ref.preaccept(leader, number, key, is_set, mask, rank, seen_mask=seen)
+        assert a[0] == b[0] == 0
+        for x, y in zip(a[1:], b[1:]):
+            np.testing.assert_array_equal(x, y)
+    for r in range(n):
+        for k in range(num_keys):
+            ga, sa = gpu.read_index(r, k)
+            gb, sb = ref.read_index(r, k)
+            assert ga.tolist() == gb.tolist() and sa.tolist() == sb.tolist()
+    z = np.zeros((n, 1), np.int32)
+    others = [r for r in range(1, n)]
+    resp = sum(1 << r for r in others[: n - 2])
+    assert gpu.preaccept([0], [0], [0], [1], [resp], z, seen_mask=[resp | 1])[0] == fa.FPX_EINVAL       # the leader
+    assert gpu.preaccept([0], [0], [0], [1], [resp], z, seen_mask=[resp & (resp - 1)])[0] == fa.FPX_EINVAL  # resp not in seen
