@@ -105,14 +105,39 @@ def cpu_baseline(ballot_mode):
         dtf = time.perf_counter() - t2
         assert n == Sf and cs.value == int(v.astype(np.int64).sum())
         faithful = Sf / dtf
+    # the flat port on all host cores, slots partitioned over threads exactly as acceptor groups partition
+    # over GPUs (SURVEY.md 8d "OpenMP over slots"): shared-nothing systems, ctypes releases the GIL
+    from concurrent.futures import ThreadPoolExecutor
+    T = max(1, min(os.cpu_count() or 1, 64))
+    St = 1 << 15
+    systems = []
+    for _ in range(T):
+        sy = pyoracle.System(pyoracle.make_config(num_slots=St, num_replicas=REPLICAS, f=F, ballot_mode=ballot_mode))
+        sy.acceptor_phase1a(0, 0)
+        systems.append(sy)
+    sl, rn, vl = slot[:St].copy(), rnd[:St].copy(), val[:St].copy()
+
+    def one(sy):
+        out = sy.phase2_fused(sl, rn, vl)
+        return int(out[1].sum())
+
+    with ThreadPoolExecutor(T) as pool:
+        t3 = time.perf_counter()
+        done = sum(pool.map(one, systems))
+        dta = time.perf_counter() - t3
+    assert done == T * St
+    all_cores = T * St / dta
+    del systems
     return {
         "value": S / dt, "unit": "slots/s", "cores": 1, "kind": "port",
+        "all_cores_value": all_cores, "all_cores_threads": T,
         "sample": "oracle/fpx_oracle.c fpo_phase2_fused (flat arrays), 2^19 slots x 256 acceptors, steady "
                   "stream, 1 thread (reference Transport is single-threaded); same handlers behind a FIFO "
                   "message pump on 2^15 slots: %.3e slots/s; with the reference's data-structure shapes "
                   "(oracle/fpx_faithful.cpp: std::map per acceptor, hash map of Pending, heap message per "
-                  "Phase2a/2b) on 2^14 slots: %s slots/s; C/C++ restatements, not the JVM; nproc=%d"
-                  % (Sp / dtp, ("%.3e" % faithful) if faithful else "n/a", os.cpu_count()),
+                  "Phase2a/2b) on 2^14 slots: %s slots/s; the flat port on %d threads (slots partitioned, 2^15 "
+                  "slots each): %.3e slots/s; C/C++ restatements, not the JVM; nproc=%d"
+                  % (Sp / dtp, ("%.3e" % faithful) if faithful else "n/a", T, all_cores, os.cpu_count()),
         "faithful_shapes_value": faithful,
     }
 
