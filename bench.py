@@ -53,6 +53,10 @@ def steady_values_torch(slot):
     return (splitmix64_torch(slot.to(torch.int64) + 0xF9A405) & 0x7FFFFFFF).to(torch.int32)
 
 
+# profiles/r01_hbm_mix.txt (1 x MI355X): pure read, pure write, copy, and this path's 1 read : 2 write mix
+MEASURED_STREAM_GBS = {"read": 5871.4, "write": 5868.0, "copy": 5140.2, "mix_1r_2w": 5068.0}
+
+
 def algorithmic_bytes_per_slot(ballot_mode):
     r = REPLICAS
     if ballot_mode == 1:  # SURVEY.md 8d generalised model
@@ -322,6 +326,10 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_slot": bps, "slots_per_launch": slots_per_launch,
                 "avg_kernel_ms": kernel_ms / max(launches, 1), "launches_timed": launches,
+                # what bare streaming kernels reach on this chip (profiles/microbench/hbm_mix.hip, best of the
+                # grid / unroll sweep in profiles/r01_hbm_mix.txt): the practical ceiling beside the spec peak
+                "measured_stream_GBs": MEASURED_STREAM_GBS,
+                "frac_of_measured_read_stream": (achieved / MEASURED_STREAM_GBS["read"]) if achieved else None,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
