@@ -123,6 +123,12 @@ struct RsArgs {
   uint2* dst;
   uint32_t* hist;  // [n][256][tiles] per-tile digit counts -> exclusive offsets within the digit
   uint32_t* tot;   // [n][256] digit totals
+  // first pass only (else null): rank[n][m] and the status words, to check that every replica's rank really is
+  // a permutation -- position p must hold a message i < m of THIS tick with rank[r][i] == p.  A position no
+  // message was scattered to still holds an older tick's pair, which fails one of the two tests (if its i had
+  // rank p now, i would have written p).
+  const int32_t* rank;
+  int32_t* status;
 };
 
 __global__ void __launch_bounds__(256) k_rs_hist(const RsArgs a) {
@@ -133,10 +139,27 @@ __global__ void __launch_bounds__(256) k_rs_hist(const RsArgs a) {
   if (tile >= a.tiles) return;
   const uint2* k = a.src + (size_t)r * a.m;
   uint32_t x[RS_ITEMS];
+  if (a.rank) {
+    uint32_t y[RS_ITEMS];
 #pragma unroll
-  for (int it = 0; it < RS_ITEMS; ++it) {  // all the tile's loads in flight before the first LDS atomic
-    const int idx = tile * RS_TILE + it * 64 + lane;
-    x[it] = idx < a.m ? k[idx].x : 0xffffffffu;
+    for (int it = 0; it < RS_ITEMS; ++it) {
+      const int idx = tile * RS_TILE + it * 64 + lane;
+      const uint2 e = idx < a.m ? k[idx] : make_uint2(0xffffffffu, 0u);
+      x[it] = e.x, y[it] = e.y;
+    }
+    int bad = -1;
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+      const int idx = tile * RS_TILE + it * 64 + lane;
+      if (idx < a.m && (y[it] >= (uint32_t)a.m || a.rank[(size_t)r * a.m + y[it]] != idx)) bad = idx;
+    }
+    if (bad >= 0) epx_report(a.status, FPX_EINVAL, -1);
+  } else {
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {  // all the tile's loads in flight before the first LDS atomic
+      const int idx = tile * RS_TILE + it * 64 + lane;
+      x[it] = idx < a.m ? k[idx].x : 0xffffffffu;
+    }
   }
 #pragma unroll
   for (int it = 0; it < RS_ITEMS; ++it)
@@ -511,6 +534,8 @@ int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, co
   int cur = 0;
   for (unsigned shift = 0; shift < bits; shift += 8, cur ^= 1) {
     a.shift = (int)shift;
+    a.rank = shift == 0 ? d_rank : nullptr;
+    a.status = e->st.status;
     a.src = buf[cur], a.dst = buf[cur ^ 1];
     const dim3 tg((a.tiles + 3) / 4, n);
     hipLaunchKernelGGL(k_rs_hist, tg, dim3(256), 0, e->stream, a);

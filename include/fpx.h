@@ -281,7 +281,8 @@ int32_t fpx_proxy_phase2b_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t s
  * SetRequest, 0: GetRequest); the leader sends PreAccept to the n-2 other replicas in resp_mask[i]
  * (thrifty fast quorum, Replica.scala:705-706).  rank is n x m: rank[r * m + i] = the position of
  * message i in replica r's processing order (a permutation of 0..m-1 per replica; only replicas that
- * take part in message i -- its leader and resp_mask[i] -- matter).  Every participating replica
+ * take part in message i -- its leader and resp_mask[i] -- matter; a rank row that is not a permutation
+ * is FPX_EINVAL and nothing is applied).  Every participating replica
  * computes the command's conflicts against ITS conflict index in ITS order (getTopOneConflicts), the
  * leader's become the PreAccept's dependencies, the others answer PreAcceptOk with the union; the
  * leader takes the fast path iff the n-2 answers are identical (popularItems(..., n-2)), otherwise

@@ -103,15 +103,21 @@ int fpo_epx_preaccept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_
   /* local conflicts seen by replica r for message i, in r's own processing order */
   int* conf = (int*)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1) * n * n);
   int* order = (int*)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+  /* every replica's rank must be a permutation of 0..m-1 (a delivery order); checked for all replicas before
+   * anything is applied */
   for (int r = 0; r < n; ++r) {
+    for (int p = 0; p < m; ++p) order[p] = -1;
     for (int i = 0; i < m; ++i) {
       int p = rank[(size_t)r * m + i];
-      if (p < 0 || p >= m) {
+      if (p < 0 || p >= m || order[p] != -1) {
         free(conf), free(order);
         return 1;
       }
       order[p] = i;
     }
+  }
+  for (int r = 0; r < n; ++r) {
+    for (int i = 0; i < m; ++i) order[rank[(size_t)r * m + i]] = i;
     for (int p = 0; p < m; ++p) {
       const int i = order[p];
       const int participates = r == leader[i] || (((seen_mask ? seen_mask[i] : resp_mask[i]) >> r) & 1u);

@@ -207,3 +207,42 @@ def test_epaxos_not_thrifty_ticks_match_oracle(oracle, n, num_keys, m):
     resp = sum(1 << r for r in others[: n - 2])
     assert gpu.preaccept([0], [0], [0], [1], [resp], z, seen_mask=[resp | 1])[0] == fa.FPX_EINVAL       # the leader
     assert gpu.preaccept([0], [0], [0], [1], [resp], z, seen_mask=[resp & (resp - 1)])[0] == fa.FPX_EINVAL  # resp not in seen
+
+
+def test_oracle_rejects_a_rank_that_is_not_a_permutation(oracle):
+    e = oracle.EPaxos(3, 4)
+    rank = np.array([[0, 1], [0, 0], [0, 1]])          # replica 1: two messages in position 0
+    assert e.preaccept([0, 1], [0, 0], [1, 1], [1, 1], [0b010, 0b100], rank)[0] == 1
+    assert e.read_index(0, 1)[1].tolist() == [0, 0, 0]  # nothing applied
+
+
+@pytest.mark.gpu
+def test_epaxos_rank_must_be_a_permutation_and_tick_sizes_may_vary(oracle):
+    """a malformed delivery order is FPX_EINVAL with nothing applied (positions nobody was scattered to would
+    otherwise be read with an older tick's contents); ticks of different sizes reuse the same buffers"""
+    from frankenpaxos_amd.epaxos import EPaxos
+    import frankenpaxos_amd as fa
+
+    n, K = 5, 32
+    gpu, ref = EPaxos(n, K), oracle.EPaxos(n, K)
+    rng = np.random.default_rng(3)
+    nxt = [0] * n
+    for m in (5000, 300, 2600, 64, 1, 5000, 1025):
+        args = random_tick(rng, n, K, m, nxt, 6.0)
+        a, b = gpu.preaccept(*args), ref.preaccept(*args)
+        assert a[0] == b[0] == 0
+        for x, y in zip(a[1:], b[1:]):
+            np.testing.assert_array_equal(x, y)
+        if m >= 64:
+            # break the permutation of one replica: two messages share a position, one position is empty
+            leader, number, key, is_set, mask, rank = random_tick(rng, n, K, m, list(nxt), 6.0)
+            bad = rank.copy()
+            bad[2, int(rng.integers(0, m))] = bad[2, int(rng.integers(0, m - 1)) + 1 if m > 1 else 0]
+            if not (np.sort(bad[2]) == np.arange(m)).all():
+                assert gpu.preaccept(leader, number, key, is_set, mask, bad)[0] == fa.FPX_EINVAL
+                assert ref.preaccept(leader, number, key, is_set, mask, bad)[0] == 1
+    for r in range(n):
+        for k in range(K):
+            ga, sa = gpu.read_index(r, k)
+            gb, sb = ref.read_index(r, k)
+            assert ga.tolist() == gb.tolist() and sa.tolist() == sb.tolist()
