@@ -16,8 +16,9 @@ chosen record 8).  `--ballot acceptor` runs the faithful per-acceptor scalar mod
 
 N > 1: one process per GPU, every rank owns its own acceptor groups (its own 2^20 x 256 grid per
 step): slot-partition sharding, no data-path collective; weak scaling.
-`--shard replica` instead splits the 256 acceptors of ONE grid across the ranks and all-reduces the
-per-slot vote bitmaps over RCCL; strong scaling of the replica axis.
+`--shard replica` instead splits the 256 acceptors of ONE grid across the ranks: K1 on every rank's
+acceptor columns, one RCCL reduce-scatter(sum) of the per-slot vote bitmaps (sum == OR, the bit ranges are
+disjoint), K2 on each rank's 1/N of the slots; strong scaling of the replica axis.
 """
 import argparse
 import json
@@ -227,7 +228,12 @@ def main():
     cr = torch.empty(SLOTS_PER_STEP, dtype=torch.int32, device=dev)
     cv = torch.empty(SLOTS_PER_STEP, dtype=torch.int32, device=dev)
     if replica_shard:
+        from frankenpaxos_amd import sharding
         vb = torch.empty((SLOTS_PER_STEP, 4), dtype=torch.int64, device=dev)
+        lo, hi = sharding.slot_slice(SLOTS_PER_STEP, world, rank)
+        vb_mine = torch.empty((hi - lo, 4), dtype=torch.int64, device=dev)
+    else:
+        lo, hi = 0, SLOTS_PER_STEP
 
     def step(i):
         slot, rnd, val, ch = steps[i]
@@ -239,11 +245,16 @@ def main():
         if not replica_shard:
             ctx.phase2_fused_dev(slot, rnd, val, None, ch, cr, cv)
         else:
-            # K1 on my acceptors -> all-reduce(sum) of the disjoint partial bitmaps over xGMI -> K2
-            ctx.proxy_open_dev(slot, rnd, val)
+            # K1 on my acceptors for every slot -> reduce-scatter(sum) of the disjoint partial bitmaps over
+            # xGMI (each rank receives the full bitmaps of ITS 1/N of the slots) -> K2 on that slice
             ctx.acceptor_phase2a_dev(slot, rnd, val, None, vb, None, None)
-            all_reduce(vb, dist.ReduceOp.SUM)
-            ctx.proxy_phase2b_dev(slot, rnd, vb, ch, cr, cv)
+            if backend == "nccl":
+                dist.reduce_scatter_tensor(vb_mine, vb, op=dist.ReduceOp.SUM)
+            else:
+                all_reduce(vb, dist.ReduceOp.SUM)
+                vb_mine.copy_(vb[lo:hi])
+            ctx.proxy_open_dev(slot[lo:hi], rnd[lo:hi], val[lo:hi])
+            ctx.proxy_phase2b_dev(slot[lo:hi], rnd[lo:hi], vb_mine, ch[lo:hi], cr[lo:hi], cv[lo:hi])
 
     def fence():
         torch.cuda.synchronize()
@@ -271,9 +282,9 @@ def main():
 
     # every timed step must have committed all of its slots, with the proposed value
     committed = sum(int(steps[i][3].sum().item()) for i in range(Wm, Wm + K))
-    assert committed == K * SLOTS_PER_STEP, (committed, K * SLOTS_PER_STEP)
-    assert bool((cv == steps[Wm + K - 1][2]).all())
-    if dist is not None and not replica_shard:
+    assert committed == K * (hi - lo), (committed, K * (hi - lo))   # replica sharding: my slice of the tally
+    assert bool((cv[lo:hi] == steps[Wm + K - 1][2][lo:hi]).all())
+    if dist is not None:
         t = torch.tensor([committed], dtype=torch.int64, device=dev)
         all_reduce(t, dist.ReduceOp.SUM)
         committed = int(t.item())

@@ -124,3 +124,44 @@ def test_replica_shard_geometry():
     s = np.arange(100)
     g = sharding.group_of_slot(s, 2, 5)   # mencius map
     assert (g == (s % 5) * 2 + (s // 5) % 2).all()
+
+
+def _replica_axis_reduce_scatter(rank):
+    from frankenpaxos_amd import sharding
+    from oracle import pyoracle as O
+
+    base, n = sharding.replica_shard(R, WORLD, rank)
+    shard = O.System(O.make_config(num_slots=S, num_replicas=n, f=127, replica_base=base,
+                                   replicas_total=R, tally_ways=8))
+    rng = np.random.default_rng(42)
+    slot, rnd, val = W.steady_stream(S)
+    tgt = W.bits_from_bool(W.random_subsets(rng, S, R, 135, 165))
+    shard.acceptor_phase1a(0, 3, 0, W.bits_from_bool((np.arange(R) % 7 == 0)[None, :])[0])
+    st, vb, nb, nr = shard.acceptor_phase2a(slot, rnd + 2, val, tgt)       # K1: all slots, my acceptors
+    mine = sharding.reduce_scatter_vote_bitmaps(torch.from_numpy(vb.view(np.int64).copy()))
+    lo, hi = sharding.slot_slice(S, WORLD, rank)
+    full = mine.numpy().view(np.uint64)
+    shard.proxy_open(slot[lo:hi], rnd[lo:hi] + 2, val[lo:hi])              # K2: my slice of the slots only
+    st, ch, cr, cv = shard.proxy_phase2b(slot[lo:hi], rnd[lo:hi] + 2, full)
+    return lo, hi, full.copy(), ch, cv
+
+
+def test_replica_axis_sharding_reduce_scatter_slices_the_tally():
+    from oracle import pyoracle as O
+
+    outs = _spawn(_replica_axis_reduce_scatter)
+    whole = O.System(O.make_config(num_slots=S, num_replicas=R, f=127, tally_ways=8))
+    rng = np.random.default_rng(42)
+    slot, rnd, val = W.steady_stream(S)
+    tgt = W.bits_from_bool(W.random_subsets(rng, S, R, 135, 165))
+    whole.acceptor_phase1a(0, 3, 0, W.bits_from_bool((np.arange(R) % 7 == 0)[None, :])[0])
+    whole.proxy_open(slot, rnd + 2, val)
+    st, vb, nb, nr = whole.acceptor_phase2a(slot, rnd + 2, val, tgt)
+    st, ch, cr, cv = whole.proxy_phase2b(slot, rnd + 2, vb)
+    covered = 0
+    for lo, hi, full, ch_r, cv_r in outs:
+        np.testing.assert_array_equal(full, vb[lo:hi])
+        np.testing.assert_array_equal(ch_r, ch[lo:hi])
+        np.testing.assert_array_equal(cv_r, cv[lo:hi])
+        covered += hi - lo
+    assert covered == S
