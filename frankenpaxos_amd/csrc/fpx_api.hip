@@ -995,7 +995,8 @@ int32_t fpx_replica_chosen_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, c
   b.n = n, b.slot = d_slot, b.value = d_value_id, b.mask = d_mask;
   int rc = enqueue_validate(ctx, b, false);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_log_ingest, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->g, ctx->st, b);
+  hipLaunchKernelGGL(k_log_ingest, dim3(std::max(1, std::min((n + 255) / 256, ctx->num_cus * 8))), dim3(256), 0, ctx->stream,
+                     ctx->g, ctx->st, b);
   hipLaunchKernelGGL(k_log_prep, dim3(1), dim3(1), 0, ctx->stream, ctx->g, ctx->st);
   hipLaunchKernelGGL(k_log_scan, dim3(ctx->num_cus * 4), dim3(256), 0, ctx->stream, ctx->g, ctx->st);
   hipLaunchKernelGGL(k_log_commit, dim3(1), dim3(1), 0, ctx->stream, ctx->st);

@@ -1022,27 +1022,41 @@ enum { LG_WATERMARK = 0, LG_NUM_CHOSEN = 1, LG_LARGEST = 2, LG_FIRST_MISSING = 3
 
 __global__ void __launch_bounds__(256) k_log_ingest(const Geom g, const State st, const Batch b) {
   if (st.status[ST_CODE] != 0) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool fresh = false;
-  int s = -1;
-  if (i < b.n && (!b.mask || b.mask[i])) {
-    s = b.slot[i];
+  // grid-stride, counts and the largest key accumulated per thread, then per workgroup: the two scalars see
+  // one atomic pair per workgroup (a pair per wavefront serialised 2^15 same-address atomics per 2^20 records)
+  __shared__ int w_cnt[4], w_top[4];
+  int cnt = 0, top = -1;  // BufferMap.largestKey
+  const int step = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < b.n; i += step) {
+    if (b.mask && !b.mask[i]) continue;
+    const int s = b.slot[i];
     if (!st.log_present[s]) {  // BufferMap.get == None
       st.log_value[s] = b.value[i];
       st.log_present[s] = 1;
-      fresh = true;
+      ++cnt;
+      top = s > top ? s : top;
     }
   }
-  const unsigned long long m = __ballot(fresh);
-  int top = fresh ? s : -1;  // BufferMap.largestKey
 #pragma unroll
   for (int k = 1; k < 64; k <<= 1) {
+    cnt += __shfl_xor(cnt, k);
     const int o = __shfl_xor(top, k);
     top = o > top ? o : top;
   }
-  if ((threadIdx.x & 63) == 0 && m) {
-    atomicAdd(&st.log_scalars[LG_NUM_CHOSEN], __popcll(m));
-    atomicMax(&st.log_scalars[LG_LARGEST], top);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) w_cnt[w] = cnt, w_top[w] = top;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    int c = 0, t = -1;
+    for (int j = 0; j < nw; ++j) {
+      c += w_cnt[j];
+      t = w_top[j] > t ? w_top[j] : t;
+    }
+    if (c) {
+      atomicAdd(&st.log_scalars[LG_NUM_CHOSEN], c);
+      atomicMax(&st.log_scalars[LG_LARGEST], t);
+    }
   }
 }
 
