@@ -828,7 +828,11 @@ __global__ void __launch_bounds__(256) k_phase1a_perslot(const Geom g, const Sta
     if (target && !((target[bit >> 6] >> (bit & 63)) & 1ull)) continue;
     const int cur = st.ballot[c];
     if (cur > round) {
-      atomicOr((unsigned long long*)&out[4 + (bit >> 6)], 1ull << (bit & 63));
+      // one bit per acceptor: test before the atomic, or a stale Phase1a that every cell Nacks would queue
+      // S x R same-address atomics
+      unsigned long long* word = (unsigned long long*)&out[4 + (bit >> 6)];
+      if (!((__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (bit & 63)) & 1ull))
+        atomicOr(word, 1ull << (bit & 63));
     } else if (cur != round) {
       st.ballot[c] = round;
     }
@@ -1018,6 +1022,18 @@ __global__ void k_range_tally(const Geom g, const State st, int start, int end, 
 // already in the log is ignored, otherwise log.put + numChosen += 1; executeLog (:394-404) advances
 // executedWatermark over the contiguous prefix.
 // ------------------------------------------------------------------------------------------------
+// one atomicMin per wavefront (and none when it cannot lower the target): a log full of holes would otherwise
+// send one same-address atomic per thread
+__device__ __forceinline__ void wave_atomic_min(int32_t* target, int v) {
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) {
+    const int o = __shfl_xor(v, k);
+    v = o < v ? o : v;
+  }
+  if ((threadIdx.x & 63) == 0 && v < __hip_atomic_load(target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMin(target, v);
+}
+
 enum { LG_WATERMARK = 0, LG_NUM_CHOSEN = 1, LG_LARGEST = 2, LG_FIRST_MISSING = 3, LG_RANGE_FIRST = 4 };
 
 __global__ void __launch_bounds__(256) k_log_ingest(const Geom g, const State st, const Batch b) {
@@ -1074,12 +1090,16 @@ __global__ void __launch_bounds__(256) k_log_scan(const Geom g, const State st) 
   const int hi0 = st.log_scalars[LG_LARGEST] + 1;
   const int hi = hi0 < g.S ? hi0 : g.S;
   const int stride = gridDim.x * blockDim.x;
+  int mine = 0x7fffffff;
   for (int s = lo + blockIdx.x * blockDim.x + threadIdx.x; s < hi; s += stride) {
+    // nothing at or above the smallest hole found so far matters any more
+    if (s >= __hip_atomic_load(&st.log_scalars[LG_FIRST_MISSING], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
     if (!st.log_present[s]) {
-      atomicMin(&st.log_scalars[LG_FIRST_MISSING], s);
+      mine = s;
       break;  // later slots of this thread are larger
     }
   }
+  wave_atomic_min(&st.log_scalars[LG_FIRST_MISSING], mine);
 }
 
 __global__ void k_log_commit(const State st) {
@@ -1096,12 +1116,15 @@ __global__ void k_log_commit(const State st) {
 __global__ void __launch_bounds__(256) k_log_range_first(const State st, int start, int stride, int count) {
   if (st.status[ST_CODE] != 0) return;
   const int step = gridDim.x * blockDim.x;
+  int mine = 0x7fffffff;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += step) {
+    if (k >= __hip_atomic_load(&st.log_scalars[LG_RANGE_FIRST], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
     if (st.log_present[(size_t)start + (size_t)k * stride]) {
-      atomicMin(&st.log_scalars[LG_RANGE_FIRST], k);
+      mine = k;
       break;  // later positions of this thread are larger
     }
   }
+  wave_atomic_min(&st.log_scalars[LG_RANGE_FIRST], mine);
 }
 
 __global__ void __launch_bounds__(256) k_log_range_fill(const State st, int start, int stride) {
