@@ -488,11 +488,14 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
   // 32 workgroups per CU: at 2^20 messages every wavefront gets exactly one FPX_CHUNK-message chunk and
   // the hardware dispatcher load-balances them (measured r01: +10 % over a 2048-workgroup persistent
   // grid, a further +8 % going from 64- to 32-message chunks)
-  ctx->max_grid = ctx->num_cus * 32;
-  if (const char* e = getenv("FPX_MAX_GRID")) ctx->max_grid = std::max(1, atoi(e));  // tuning aid
   int G = 1;
   while (G * 4 < ctx->g.R) G <<= 1;
   ctx->lanes_per_slot = G;
+  // small groups (R <= 16, the reference's everyday f = 1..3): a 64-slot chunk is three dependent round
+  // trips and a workgroup's fixed costs (LDS tables, the final reduction) dominate -- 4 workgroups per CU,
+  // each wave walking many chunks, measured 2x faster at R = 3 (profiles/r01_small_r.txt)
+  ctx->max_grid = ctx->num_cus * (G <= 4 ? 4 : 32);
+  if (const char* e = getenv("FPX_MAX_GRID")) ctx->max_grid = std::max(1, atoi(e));  // tuning aid
   ctx->vec = true;  // rows are padded to a multiple of 4 cells (Geom::RS)
   // big tables: fewer resident blocks so that the partial table stays small
   const int ntab = ctx->g.ngroups * ctx->g.R;

@@ -13,7 +13,7 @@ import frankenpaxos_amd as fa
 B, WINDOWS, STEPS = 1 << 22, 6, 5
 dev = torch.device("cuda:0")
 for ballot in (0, 1):
-    for R in (3, 5, 7, 16, 64):
+    for R in [int(x) for x in os.environ.get("SMALL_R", "3,5,7,16,64").split(",")]:
         f = (R - 1) // 2 if R % 2 else R // 2 - 1
         ctx = fa.Context(fa.make_config(num_slots=B * WINDOWS, num_replicas=R, f=f, ballot_mode=ballot,
                                         flags=fa.FPX_F_TRUSTED))
