@@ -246,3 +246,57 @@ def test_epaxos_rank_must_be_a_permutation_and_tick_sizes_may_vary(oracle):
             ga, sa = gpu.read_index(r, k)
             gb, sb = ref.read_index(r, k)
             assert ga.tolist() == gb.tolist() and sa.tolist() == sb.tolist()
+
+
+@pytest.mark.parametrize("n,not_thrifty", [(3, False), (5, False), (5, True), (7, False), (7, True)])
+def test_oracle_epaxos_safety_invariant(oracle, n, not_thrifty):
+    """EPaxos' dependency invariant, the property its execution order rests on: of two conflicting commands
+    (same key, at least one of them a set) at least one has the other in its committed dependencies -- fast
+    quorums intersect, and the replica in the intersection saw one of the two first.  Checked on the oracle
+    (the reference's own EPaxos tests are randomized simulations of the same property,
+    shared/src/test/scala/epaxos/EPaxosTest.scala), within a tick under skewed delivery orders and across
+    ticks; dependencies are TopOne watermarks: deps[leader] > number means "depends on (leader, number)"."""
+    num_keys, m = 6, 260
+    e = oracle.EPaxos(n, num_keys)
+    rng = np.random.default_rng(100 * n + int(not_thrifty))
+    nxt = [0] * n
+    history = []  # (leader, number, key, is_set, deps)
+    pairs = 0
+    for tick in range(4):
+        leader, number, key, is_set, mask, rank = random_tick(rng, n, num_keys, m, nxt, 25.0)
+        seen = None
+        if not_thrifty:
+            seen = (((1 << n) - 1) & ~(1 << leader.astype(np.int64))).astype(np.uint8)
+        st, fast, deps, ldeps = e.preaccept(leader, number, key, is_set, mask, rank, seen_mask=seen)
+        assert st == 0
+        cur = [(int(leader[i]), int(number[i]), int(key[i]), int(is_set[i]), deps[i]) for i in range(m)]
+        for i, (li, ni, ki, si, di) in enumerate(cur):
+            # every conflicting command of an EARLIER tick is committed everywhere: i must depend on it
+            for (lj, nj, kj, sj, dj) in history:
+                if ki == kj and (si or sj):
+                    assert di[lj] > nj, (tick, i, (lj, nj))
+            # within the tick: one of the two depends on the other
+            for (lj, nj, kj, sj, dj) in cur[:i]:
+                if ki == kj and (si or sj):
+                    pairs += 1
+                    assert di[lj] > nj or dj[li] > ni, (tick, (li, ni), (lj, nj))
+        history.extend(cur)
+    assert pairs > 1000
+
+
+def test_oracle_epaxos_safety_invariant_negative_control(oracle):
+    """the invariant test is not vacuous: the PreAccept's own dependencies (the leader's view alone, before
+    the fast quorum answered) do violate it under skewed delivery"""
+    n, num_keys, m = 5, 6, 260
+    e = oracle.EPaxos(n, num_keys)
+    rng = np.random.default_rng(9)
+    leader, number, key, is_set, mask, rank = random_tick(rng, n, num_keys, m, [0] * n, 25.0)
+    st, fast, deps, ldeps = e.preaccept(leader, number, key, is_set, mask, rank)
+    violations = 0
+    for i in range(m):
+        for j in range(i):
+            if key[i] == key[j] and (is_set[i] or is_set[j]):
+                if not (ldeps[i][leader[j]] > number[j] or ldeps[j][leader[i]] > number[i]):
+                    violations += 1
+                assert deps[i][leader[j]] > number[j] or deps[j][leader[i]] > number[i]
+    assert violations > 0
