@@ -54,6 +54,10 @@ def steady_values_torch(slot):
     return (splitmix64_torch(slot.to(torch.int64) + 0xF9A405) & 0x7FFFFFFF).to(torch.int32)
 
 
+# BASELINE.json's metric, verbatim (its "; 1/2/4/8-GPU scaling" clause describes the sweep the driver runs)
+METRIC = "committed log slots/sec at 1M slots \u00d7 256 replicas"
+
+
 # profiles/r01_hbm_mix.txt (1 x MI355X): pure read, pure write, copy, and this path's 1 read : 2 write mix
 MEASURED_STREAM_GBS = {"read": 5871.4, "write": 5868.0, "copy": 5140.2, "mix_1r_2w": 5068.0}
 
@@ -309,7 +313,7 @@ def main():
         kernel = "k_phase2<64,vec4,%s,%s>" % ("per_slot" if ballot_mode == 1 else "acceptor",
                                                "K1" if replica_shard else "fused")
         line = {
-            "metric": "committed log slots/sec at 1M slots x 256 replicas",
+            "metric": METRIC,
             "value": committed / elapsed,
             "unit": "slots/s",
             "n_gpus": world,
