@@ -1,0 +1,30 @@
+"""examples/phase2_demo.c: the C ABI used from plain C (no Python, no C++).  It must compile with -Wall -Werror
+as C11 and link against libfpx.so; without a device it reports FPX_ENODEVICE (exit 77), with one it runs
+BASELINE.json configs[0] (1000 commands, all chosen; a stale leader is Nacked) and exits 0."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_plain_c_caller_builds_links_and_fails_loudly_without_a_device():
+    import torch
+
+    import frankenpaxos_amd
+
+    if not os.path.exists(frankenpaxos_amd._lib.SO_PATH):
+        frankenpaxos_amd.build()
+    csrc = os.path.join(ROOT, "frankenpaxos_amd", "csrc")
+    out_dir = os.path.join(ROOT, "tests", "build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "phase2_demo")
+    subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "examples", "phase2_demo.c"),
+                           "-I" + os.path.join(ROOT, "include"), "-L" + csrc, "-lfpx", "-Wl,-rpath," + csrc,
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    if torch.cuda.is_available():
+        assert run.returncode == 0, run.stdout + run.stderr
+        assert "1000 of 1000 commands chosen" in run.stdout
+    else:
+        assert run.returncode == 77, run.stdout + run.stderr
+        assert "no usable gfx950 device" in run.stdout
