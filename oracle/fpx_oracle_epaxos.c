@@ -76,6 +76,15 @@ static void conflict_index_put(fpo_epx* e, int r, int key, int is_set, int leade
   fpo_top_one_put(idx(is_set ? e->sets : e->gets, e, r, key), leader, number);
 }
 
+/* the two conflict-index operations by themselves, so that the reference's known-answer test
+ * (statemachine/TopKConflictIndexTest.scala:281-329, k = 1) can be run against them */
+void fpo_epx_index_put(fpo_epx* e, int replica, int key, int is_set, int leader, int number) {
+  conflict_index_put(e, replica, key, is_set, leader, number);
+}
+void fpo_epx_index_conflicts(fpo_epx* e, int replica, int key, int is_set, int32_t* out) {
+  get_top_one_conflicts(e, replica, key, is_set, out);
+}
+
 static int popcount8(unsigned x) { return __builtin_popcount(x & 0xffu); }
 
 /*

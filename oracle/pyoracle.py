@@ -488,6 +488,8 @@ class EPaxos:
         L.fpo_epx_preaccept.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, U8P, U8P, U8P, I32P, U8P, I32P,
                                         I32P]
         L.fpo_epx_read_index.argtypes = [C.c_void_p, C.c_int, C.c_int, I32P, I32P]
+        L.fpo_epx_index_put.argtypes = [C.c_void_p] + [C.c_int] * 5
+        L.fpo_epx_index_conflicts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, I32P]
         self.n, self.num_keys = num_replicas, num_keys
         self._h = L.fpo_epx_new(num_replicas, num_keys)
         if not self._h:
@@ -513,6 +515,16 @@ class EPaxos:
                                      _p(fast, U8P),
                                      _p(deps, I32P), _p(ldeps, I32P))
         return st, fast, deps, ldeps
+
+    def index_put(self, replica, key, is_set, leader, number):
+        """KeyValueStore conflict index put of one single-key command (KeyValueStore.scala:232-253)"""
+        lib().fpo_epx_index_put(self._h, replica, key, int(is_set), leader, number)
+
+    def index_conflicts(self, replica, key, is_set):
+        """getTopOneConflicts of one single-key command (KeyValueStore.scala:259-302)"""
+        out = np.zeros(self.n, np.int32)
+        lib().fpo_epx_index_conflicts(self._h, replica, key, int(is_set), _p(out, I32P))
+        return out.tolist()
 
     def read_index(self, replica, key):
         g = np.zeros(self.n, np.int32)

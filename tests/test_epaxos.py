@@ -31,6 +31,32 @@ def test_popular_items_golden(oracle):
     assert p([(0, 1), (0, 1), (1, 0)], 2) == {(0, 1)}
 
 
+def test_key_value_store_top_one_conflict_index_golden(oracle):
+    """statemachine/TopKConflictIndexTest.scala:281-329 ("get complicated conflicts correctly", k = 1).  The
+    reference puts multi-key commands; a put of set(x, y) is the put of set x and of set y under the same
+    instance (KeyValueStore.scala:232-253 loops over the keys), and a multi-key query is the merge of the
+    single-key ones (:259-302), so the vector runs on the single-key index unchanged."""
+    X, Y, Z = 0, 1, 2
+    GET, SET = 0, 1
+    e = oracle.EPaxos(3, 3)
+    puts = [((0, 0), GET, [X]), ((1, 3), SET, [X, Y]), ((2, 20), GET, [Y, Z]), ((2, 10), GET, [Y, Z]),
+            ((0, 1), GET, [X]), ((0, 3), GET, [X]), ((0, 2), SET, [X]), ((1, 1), SET, [X, Y]),
+            ((2, 20), GET, [Y, Z])]
+    for (leader, number), kind, keys in puts:
+        for k in keys:
+            e.index_put(0, k, kind, leader, number)
+    assert e.index_conflicts(0, X, GET) == [3, 4, 0]
+    assert e.index_conflicts(0, Y, GET) == [0, 4, 0]
+    assert e.index_conflicts(0, Z, GET) == [0, 0, 0]
+    assert e.index_conflicts(0, X, SET) == [4, 4, 0]
+    assert e.index_conflicts(0, Y, SET) == [0, 4, 21]
+    assert e.index_conflicts(0, Z, SET) == [0, 0, 21]
+    merge = lambda *vs: [max(c) for c in zip(*vs)]
+    assert merge(*(e.index_conflicts(0, k, GET) for k in (X, Y, Z))) == [3, 4, 0]    # get("x", "y", "z")
+    assert merge(*(e.index_conflicts(0, k, SET) for k in (X, Y, Z))) == [4, 4, 21]   # set("x", "y", "z")
+    assert e.index_conflicts(1, X, SET) == [0, 0, 0]                                 # another replica's index
+
+
 # ------------------------------------------------------------------- a tick by hand (CPU) -------
 def test_oracle_tick_by_hand(oracle):
     """n = 3 (f = 1): fast quorum n-1 = 2, the leader asks ONE other replica (n-2 = 1), so every
