@@ -101,8 +101,8 @@ SIGNATURES = {
     "fpx_epx_destroy": (C.c_int32, [VP]),
     "fpx_epx_set_stream": (C.c_int32, [VP, VP]),
     "fpx_epx_sync": (C.c_int32, [VP]),
-    "fpx_epx_preaccept": (C.c_int32, [VP, C.c_int32] + [VP] * 10),
-    "fpx_epx_preaccept_dev": (C.c_int32, [VP, C.c_int32] + [VP] * 10),
+    "fpx_epx_preaccept": (C.c_int32, [VP, C.c_int32] + [VP] * 11),
+    "fpx_epx_preaccept_dev": (C.c_int32, [VP, C.c_int32] + [VP] * 11),
     "fpx_epx_read_index": (C.c_int32, [VP, C.c_int32, C.c_int32, VP, VP]),
     "fpx_replica_chosen": (C.c_int32, [VP, C.c_int32, VP, VP, VP, I32P, I32P]),
     "fpx_replica_chosen_dev": (C.c_int32, [VP, C.c_int32, VP, VP, VP]),

@@ -56,6 +56,7 @@ struct EpxBatch {
   uint8_t* fast;
   int32_t* deps;
   int32_t* leader_deps;
+  int32_t* own_values_end;  // [m][2]: explicit values of the own-leader column of deps / leader_deps (0 = none)
 };
 
 constexpr uint32_t EPX_KEY_MASK = (1u << 27) - 1u;
@@ -363,10 +364,24 @@ __global__ void __launch_bounds__(256) k_epx_decide(const EpxState st, const Epx
     have_first = true;
   }
   if (b.fast) b.fast[i] = all_equal ? 1 : 0;
+  // dependencies.subtractOne(instance) (Replica.scala:582, compact/IntPrefixSet.scala:388-398) only touches the
+  // column of the instance's own leader: with w = that column's watermark before the subtraction and x the
+  // instance number, the set is {0 .. w-1} \ {x}: (watermark w, no values) if x >= w, else (watermark x,
+  // values x+1 .. w-1).  Unions (addAll) and the equality test of popularItems commute with that encoding for a
+  // fresh instance (w == x + 1 would need the instance itself in the index), so everything above ran on the
+  // plain watermarks w and only the own column is re-encoded here.
+  const int x = b.number[i];
 #pragma unroll
   for (int l = 0; l < N; ++l) {
-    if (b.deps) b.deps[(size_t)i * N + l] = all_equal ? first[l] : uni[l];
-    if (b.leader_deps) b.leader_deps[(size_t)i * N + l] = D[l];
+    const int w = all_equal ? first[l] : uni[l];
+    const bool hole = l == L && w > x;
+    const bool lhole = l == L && D[l] > x;
+    if (b.deps) b.deps[(size_t)i * N + l] = hole ? x : w;
+    if (b.leader_deps) b.leader_deps[(size_t)i * N + l] = lhole ? x : D[l];
+    if (l == L && b.own_values_end) {
+      b.own_values_end[(size_t)i * 2] = hole ? w : 0;
+      b.own_values_end[(size_t)i * 2 + 1] = lhole ? D[l] : 0;
+    }
   }
 }
 
@@ -401,7 +416,7 @@ struct fpx_epx {
   EpxState st;
   hipStream_t stream = nullptr, own_stream = nullptr;
   int last_hip = 0;
-  Buf kv, kv2, seg, conf, tmp, tick, h_leader, h_number, h_key, h_set, h_mask, h_seen, h_rank, o_fast, o_deps, o_ldeps;
+  Buf kv, kv2, seg, conf, tmp, tick, h_leader, h_number, h_key, h_set, h_mask, h_seen, h_rank, o_fast, o_deps, o_ldeps, o_own;
 };
 
 namespace {
@@ -476,7 +491,7 @@ int32_t fpx_epx_destroy(fpx_epx* e) {
   for (void* p : ps)
     if (p) (void)hipFree(p);
   Buf* bs[] = {&e->kv, &e->kv2, &e->seg, &e->conf, &e->tmp, &e->tick, &e->h_leader, &e->h_number,
-               &e->h_key, &e->h_set, &e->h_mask, &e->h_seen, &e->h_rank, &e->o_fast, &e->o_deps, &e->o_ldeps};
+               &e->h_key, &e->h_set, &e->h_mask, &e->h_seen, &e->h_rank, &e->o_fast, &e->o_deps, &e->o_ldeps, &e->o_own};
   for (Buf* b : bs)
     if (b->p) (void)hipFree(b->p);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -506,7 +521,7 @@ int32_t fpx_epx_sync(fpx_epx* e) {
 int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, const int32_t* d_number,
                               const int32_t* d_key, const uint8_t* d_is_set, const uint8_t* d_resp_mask,
                               const uint8_t* d_seen_mask, const int32_t* d_rank, uint8_t* d_fast, int32_t* d_deps,
-                              int32_t* d_leader_deps) {
+                              int32_t* d_leader_deps, int32_t* d_own_values_end) {
   if (!e || m < 0) return FPX_EINVAL;
   if (m == 0) return FPX_OK;
   const int n = e->st.n;
@@ -524,7 +539,7 @@ int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, co
   b.kv = (uint2*)e->kv.p, b.kv_sorted = (uint2*)e->kv2.p;
   b.tick = (int32_t*)e->tick.p;
   b.seg = (int32_t*)e->seg.p, b.conf = (int32_t*)e->conf.p;
-  b.fast = d_fast, b.deps = d_deps, b.leader_deps = d_leader_deps;
+  b.fast = d_fast, b.deps = d_deps, b.leader_deps = d_leader_deps, b.own_values_end = d_own_values_end;
   hipLaunchKernelGGL(k_epx_keys, dim3((m + 255) / 256), dim3(256), 0, e->stream, e->st, b);
   // stable LSD radix sort on the key bits only (the sequence already is in delivery order)
   unsigned bits = 1;
@@ -565,7 +580,8 @@ int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, co
 
 int32_t fpx_epx_preaccept(fpx_epx* e, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* key,
                           const uint8_t* is_set, const uint8_t* resp_mask, const uint8_t* seen_mask,
-                          const int32_t* rank, uint8_t* fast, int32_t* deps, int32_t* leader_deps) {
+                          const int32_t* rank, uint8_t* fast, int32_t* deps, int32_t* leader_deps,
+                          int32_t* own_values_end) {
   if (!e || m < 0 || (m > 0 && (!leader || !number || !key || !is_set || !resp_mask || !rank))) return FPX_EINVAL;
   if (m == 0) return FPX_OK;
   const int n = e->st.n;
@@ -586,14 +602,16 @@ int32_t fpx_epx_preaccept(fpx_epx* e, int32_t m, const int32_t* leader, const in
   if ((rc = grow(e, &e->o_fast, (size_t)m))) return rc;
   if ((rc = grow(e, &e->o_deps, (size_t)m * n * 4))) return rc;
   if ((rc = grow(e, &e->o_ldeps, (size_t)m * n * 4))) return rc;
+  if ((rc = grow(e, &e->o_own, (size_t)m * 8))) return rc;
   rc = fpx_epx_preaccept_dev(e, m, (int32_t*)e->h_leader.p, (int32_t*)e->h_number.p, (int32_t*)e->h_key.p,
                              (uint8_t*)e->h_set.p, (uint8_t*)e->h_mask.p, seen_mask ? (uint8_t*)e->h_seen.p : nullptr,
                              (int32_t*)e->h_rank.p, (uint8_t*)e->o_fast.p,
-                             (int32_t*)e->o_deps.p, (int32_t*)e->o_ldeps.p);
+                             (int32_t*)e->o_deps.p, (int32_t*)e->o_ldeps.p, (int32_t*)e->o_own.p);
   if (rc) return rc;
   if (fast) EHIP(e, hipMemcpyAsync(fast, e->o_fast.p, (size_t)m, hipMemcpyDeviceToHost, e->stream));
   if (deps) EHIP(e, hipMemcpyAsync(deps, e->o_deps.p, (size_t)m * n * 4, hipMemcpyDeviceToHost, e->stream));
   if (leader_deps) EHIP(e, hipMemcpyAsync(leader_deps, e->o_ldeps.p, (size_t)m * n * 4, hipMemcpyDeviceToHost, e->stream));
+  if (own_values_end) EHIP(e, hipMemcpyAsync(own_values_end, e->o_own.p, (size_t)m * 8, hipMemcpyDeviceToHost, e->stream));
   return fpx_epx_sync(e);
 }
 

@@ -70,16 +70,18 @@ class EPaxos:
         fast = np.zeros(m, np.uint8)
         deps = np.zeros((m, self.n), np.int32)
         ldeps = np.zeros((m, self.n), np.int32)
+        own = np.zeros((m, 2), np.int32)
         p = lambda a: None if a is None else a.ctypes.data
         st = self.L.fpx_epx_preaccept(self._h, m, p(leader), p(number), p(key), p(is_set), p(resp_mask),
-                                      p(seen_mask), p(rank), p(fast), p(deps), p(ldeps))
-        return st, fast, deps, ldeps
+                                      p(seen_mask), p(rank), p(fast), p(deps), p(ldeps), p(own))
+        return st, fast, deps, ldeps, own
 
     def preaccept_dev(self, leader, number, key, is_set, resp_mask, rank, fast=None, deps=None,
-                      leader_deps=None, seen_mask=None):
+                      leader_deps=None, seen_mask=None, own_values_end=None):
         d = lambda t: None if t is None else t.data_ptr()
         st = self.L.fpx_epx_preaccept_dev(self._h, leader.numel(), d(leader), d(number), d(key), d(is_set),
-                                          d(resp_mask), d(seen_mask), d(rank), d(fast), d(deps), d(leader_deps))
+                                          d(resp_mask), d(seen_mask), d(rank), d(fast), d(deps), d(leader_deps),
+                                          d(own_values_end))
         if st:
             raise FpxError(st, "fpx_epx_preaccept_dev")
 

@@ -553,6 +553,9 @@ struct Decision {
   bool fastPath;                      // committed on the fast path (Replica.scala:1399-1405)
   std::vector<int32_t> dependencies;  // per leader replica: the dependency watermark (committed or Accept-phase)
   std::vector<int32_t> preAcceptDependencies;  // what the PreAccept carried (the leader's own conflicts)
+  // IntPrefixSet `values` of the instance's own-leader column after dependencies.subtractOne(instance)
+  // (Replica.scala:582): the run instanceNumber + 1 .. end - 1; 0 = none (always, on FIFO channels)
+  int32_t ownValuesEnd = 0, preAcceptOwnValuesEnd = 0;
 };
 
 // The conflict indices of the n replicas, resident in HBM.
@@ -616,15 +619,18 @@ class PreAcceptEngine {
       }
     }
     std::vector<uint8_t> fast(m);
-    std::vector<int32_t> deps((size_t)m * n_), ldeps((size_t)m * n_);
+    std::vector<int32_t> deps((size_t)m * n_), ldeps((size_t)m * n_), own((size_t)m * 2);
     check(fpx_epx_preaccept(epx_, m, leader.data(), number.data(), key.data(), isSet.data(), mask.data(),
-                            anyRecipients ? seen.data() : nullptr, rank.data(), fast.data(), deps.data(), ldeps.data()),
+                            anyRecipients ? seen.data() : nullptr, rank.data(), fast.data(), deps.data(), ldeps.data(),
+                            own.data()),
           "Replica.handlePreAccept");
     std::vector<Decision> out(m);
     for (int i = 0; i < m; ++i) {
       out[i].fastPath = fast[i] != 0;
       out[i].dependencies.assign(deps.begin() + (size_t)i * n_, deps.begin() + (size_t)(i + 1) * n_);
       out[i].preAcceptDependencies.assign(ldeps.begin() + (size_t)i * n_, ldeps.begin() + (size_t)(i + 1) * n_);
+      out[i].ownValuesEnd = own[(size_t)i * 2];
+      out[i].preAcceptOwnValuesEnd = own[(size_t)i * 2 + 1];
     }
     return out;
   }

@@ -70,7 +70,7 @@ object Native {
   @native def epxPreaccept(handle: Long, m: Int, leader: Array[Int], number: Array[Int],
                            key: Array[Int], isSet: Array[Byte], respMask: Array[Byte],
                            seenMask: Array[Byte], rank: Array[Int], fast: Array[Byte], deps: Array[Int],
-                           leaderDeps: Array[Int]): Int
+                           leaderDeps: Array[Int], ownValuesEnd: Array[Int]): Int
 
   def check(status: Int, logger: Logger): Unit = status match {
     case OK                       => ()

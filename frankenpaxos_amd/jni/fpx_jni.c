@@ -226,15 +226,16 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxDestroy(JNIEnv* env, jcla
 
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxPreaccept(
     JNIEnv* env, jclass cls, jlong h, jint m, jintArray leader, jintArray number, jintArray key, jbyteArray isSet,
-    jbyteArray respMask, jbyteArray seenMask, jintArray rank, jbyteArray fast, jintArray deps, jintArray leaderDeps) {
+    jbyteArray respMask, jbyteArray seenMask, jintArray rank, jbyteArray fast, jintArray deps, jintArray leaderDeps,
+    jintArray ownValuesEnd) {
   jint *l = PIN(env, leader), *nu = PIN(env, number), *k = PIN(env, key), *rk = PIN(env, rank);
-  jint *d = PIN(env, deps), *ld = PIN(env, leaderDeps);
+  jint *d = PIN(env, deps), *ld = PIN(env, leaderDeps), *ov = PIN(env, ownValuesEnd);
   jbyte *is = PIN(env, isSet), *rm = PIN(env, respMask), *sm = PIN(env, seenMask), *f = PIN(env, fast);
   int32_t st = fpx_epx_preaccept((fpx_epx*)(intptr_t)h, m, l, nu, k, (const uint8_t*)is, (const uint8_t*)rm,
                                  (const uint8_t*)sm, rk,
-                                 (uint8_t*)f, d, ld);
+                                 (uint8_t*)f, d, ld, ov);
   UNPIN(env, fast, f, 0); UNPIN(env, seenMask, sm, JNI_ABORT); UNPIN(env, respMask, rm, JNI_ABORT); UNPIN(env, isSet, is, JNI_ABORT);
-  UNPIN(env, leaderDeps, ld, 0); UNPIN(env, deps, d, 0); UNPIN(env, rank, rk, JNI_ABORT);
+  UNPIN(env, ownValuesEnd, ov, 0); UNPIN(env, leaderDeps, ld, 0); UNPIN(env, deps, d, 0); UNPIN(env, rank, rk, JNI_ABORT);
   UNPIN(env, key, k, JNI_ABORT); UNPIN(env, number, nu, JNI_ABORT); UNPIN(env, leader, l, JNI_ABORT);
   return st;
 }

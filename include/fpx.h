@@ -293,9 +293,17 @@ int32_t fpx_proxy_phase2b_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t s
  * every other replica (n-1 of them): all of them compute conflicts and update their index in their order,
  * and the leader decides on the first n-2 answers to arrive (fastQuorumSize responses including its own,
  * :1376) -- resp_mask, a subset of seen_mask.
- * Outputs (may be NULL): fast[i]; deps[i * n + l] = committed (fast) or Accept-phase (slow)
- * dependency watermark for leader l; leader_deps likewise for the PreAccept.  Sequence numbers are the
- * constant 0 the reference uses with top-k dependencies (:575-578). */
+ * Outputs (may be NULL): fast[i]; deps = the committed (fast) or Accept-phase (slow) dependencies and
+ * leader_deps = the PreAccept's, as InstancePrefixSets (epaxos/InstancePrefixSet.scala): deps[i * n + l] is
+ * the IntPrefixSet watermark of leader l's column (every instance of l below it is a dependency).  The
+ * reference removes the instance itself from its dependencies (dependencies.subtractOne(instance),
+ * Replica.scala:582; compact/IntPrefixSet.scala:388-398), which only ever changes the column of the
+ * instance's OWN leader: when a replica already holds a higher-numbered conflicting instance of that leader
+ * (it processed (L, 5) before (L, 4)), that column's watermark drops to number[i] and the ids above it become
+ * the set's explicit `values` -- always the run number[i] + 1 .. end - 1, reported as
+ * own_values_end[i * 2 + 0] (deps) and own_values_end[i * 2 + 1] (leader_deps); 0 = no explicit values (the
+ * case on every FIFO channel).  Sequence numbers are the constant 0 the reference uses with top-k
+ * dependencies (:575-578). */
 typedef struct fpx_epx fpx_epx;
 typedef struct {
   int32_t num_replicas; /* n: 3, 5 or 7 */
@@ -309,12 +317,12 @@ int32_t fpx_epx_set_stream(fpx_epx* epx, void* hip_stream);
 int32_t fpx_epx_preaccept(fpx_epx* epx, int32_t m, const int32_t* leader, const int32_t* number,
                           const int32_t* key, const uint8_t* is_set, const uint8_t* resp_mask,
                           const uint8_t* seen_mask, const int32_t* rank, uint8_t* fast, int32_t* deps,
-                          int32_t* leader_deps);
+                          int32_t* leader_deps, int32_t* own_values_end);
 /* device-resident inputs / outputs, asynchronous; fpx_epx_sync returns the sticky status */
 int32_t fpx_epx_preaccept_dev(fpx_epx* epx, int32_t m, const int32_t* d_leader, const int32_t* d_number,
                               const int32_t* d_key, const uint8_t* d_is_set, const uint8_t* d_resp_mask,
                               const uint8_t* d_seen_mask, const int32_t* d_rank, uint8_t* d_fast,
-                              int32_t* d_deps, int32_t* d_leader_deps);
+                              int32_t* d_deps, int32_t* d_leader_deps, int32_t* d_own_values_end);
 int32_t fpx_epx_sync(fpx_epx* epx);
 /* replica's conflict-index entry of one key: gets[n], sets[n] (TopOne vectors) */
 int32_t fpx_epx_read_index(fpx_epx* epx, int32_t replica, int32_t key, int32_t* gets, int32_t* sets);

@@ -15,8 +15,14 @@
  * single-key GetRequest / SetRequest commands, thrifty fast quorums (the leader sends PreAccept to
  * exactly fastQuorumSize - 1 = n - 2 other replicas, Replica.scala:705-706), sequence numbers are the
  * constant 0 the reference uses (:575-578, 598), dependencies are per-leader watermark vectors
- * (InstancePrefixSet.fromTopOne, epaxos/InstancePrefixSet.scala:19-29).  Commit messages of the
- * tick reach every replica after the tick (commit -> updateConflictIndex, Replica.scala:815-828).
+ * (InstancePrefixSet.fromTopOne, epaxos/InstancePrefixSet.scala:19-29) from which the instance itself is
+ * removed (dependencies.subtractOne(instance), Replica.scala:582; compact/IntPrefixSet.scala:388-398).
+ * subtractOne only ever touches the column of the instance's OWN leader, so that column is carried as a
+ * real IntPrefixSet (watermark + explicit values, restated below with its add-all / equality / compaction
+ * rules) and the other columns as bare watermarks (their `values` stay empty through every operation on
+ * this path: fromWatermarks -> addAll of value-less sets is a max of watermarks, IntPrefixSet.scala:296-301).
+ * Commit messages of the tick reach every replica after the tick (commit -> updateConflictIndex,
+ * Replica.scala:815-828).
  * The reference has no known-answer test for this path (T/epaxos/EPaxos.scala is a randomized
  * invariant check): parity unpinned; anchored on the citations and tests/test_epaxos.py traces.
  * TopOne itself is pinned by T/util/TopOneTest.scala (tests/test_epaxos.py).
@@ -87,16 +93,148 @@ void fpo_epx_index_conflicts(fpo_epx* e, int replica, int key, int is_set, int32
 
 static int popcount8(unsigned x) { return __builtin_popcount(x & 0xffu); }
 
+/* ---- compact.IntPrefixSet, the part of it this path reaches  (compact/IntPrefixSet.scala) ------------
+ * watermark: every x < watermark is in the set; values: the other members, sorted ascending, all
+ * >= watermark (kept compacted exactly like the Scala: the constructor and every mutator call compact()). */
+typedef struct {
+  int watermark;
+  int nvalues;
+  int* values; /* NULL when nvalues == 0 */
+} ips_t;
+
+static void ips_free(ips_t* s) {
+  free(s->values);
+  s->values = NULL;
+  s->nvalues = 0;
+}
+
+/* IntPrefixSet.compact (IntPrefixSet.scala, private): while values contains watermark, pop it and bump */
+static void ips_compact(ips_t* s) {
+  int k = 0;
+  /* drop members below the watermark, then absorb the run that starts at the watermark */
+  while (k < s->nvalues && s->values[k] < s->watermark) ++k;
+  while (k < s->nvalues && s->values[k] == s->watermark) ++k, ++s->watermark;
+  if (k > 0) {
+    memmove(s->values, s->values + k, sizeof(int) * (size_t)(s->nvalues - k));
+    s->nvalues -= k;
+  }
+  if (s->nvalues == 0) ips_free(s);
+}
+
+/* IntPrefixSet.fromWatermark  :13-14 */
+static ips_t ips_from_watermark(int w) {
+  ips_t s = {w, 0, NULL};
+  return s;
+}
+
+static ips_t ips_clone(const ips_t* a) {
+  ips_t s = {a->watermark, a->nvalues, NULL};
+  if (a->nvalues) {
+    s.values = (int*)malloc(sizeof(int) * (size_t)a->nvalues);
+    memcpy(s.values, a->values, sizeof(int) * (size_t)a->nvalues);
+  }
+  return s;
+}
+
+/* IntPrefixSet.subtractOne  :388-398
+ *   if (x >= watermark) values -= x  else { for (i <- x + 1 until watermark) values += i; watermark = x } */
+static void ips_subtract_one(ips_t* s, int x) {
+  if (x >= s->watermark) {
+    for (int k = 0; k < s->nvalues; ++k) {
+      if (s->values[k] == x) {
+        memmove(s->values + k, s->values + k + 1, sizeof(int) * (size_t)(s->nvalues - k - 1));
+        if (--s->nvalues == 0) ips_free(s);
+        break;
+      }
+    }
+  } else {
+    const int add = s->watermark - (x + 1);
+    int* v = (int*)malloc(sizeof(int) * (size_t)(add + s->nvalues + 1));
+    for (int i = 0; i < add; ++i) v[i] = x + 1 + i; /* all below the old watermark, hence below every old value */
+    if (s->nvalues) memcpy(v + add, s->values, sizeof(int) * (size_t)s->nvalues);
+    free(s->values);
+    s->values = v;
+    s->nvalues += add;
+    s->watermark = x;
+    if (s->nvalues == 0) ips_free(s);
+  }
+}
+
+/* IntPrefixSet.addAll  :296-330: the union, compacted (the four emptiness cases of the Scala all compute
+ * watermark = max, values = (values ++ other.values).filter(_ >= watermark), compact()) */
+static void ips_add_all(ips_t* s, const ips_t* o) {
+  const int w = s->watermark > o->watermark ? s->watermark : o->watermark;
+  int* v = (int*)malloc(sizeof(int) * (size_t)(s->nvalues + o->nvalues + 1));
+  int a = 0, b = 0, k = 0;
+  while (a < s->nvalues || b < o->nvalues) { /* sorted merge without duplicates */
+    int x;
+    if (b >= o->nvalues || (a < s->nvalues && s->values[a] <= o->values[b])) {
+      x = s->values[a++];
+      if (b < o->nvalues && o->values[b] == x) ++b;
+    } else {
+      x = o->values[b++];
+    }
+    if (x >= w) v[k++] = x;
+  }
+  free(s->values);
+  s->values = v;
+  s->nvalues = k;
+  s->watermark = w;
+  if (k == 0) ips_free(s);
+  ips_compact(s);
+}
+
+/* IntPrefixSet.equals  :214-221: (watermark, values) tuples */
+static int ips_equals(const ips_t* a, const ips_t* b) {
+  if (a->watermark != b->watermark || a->nvalues != b->nvalues) return 0;
+  return a->nvalues == 0 || memcmp(a->values, b->values, sizeof(int) * (size_t)a->nvalues) == 0;
+}
+
+/* for the tests: the operations above on their own (T/compact/IntPrefixSetTest.scala pins them) */
+int fpo_ips_subtract_one(int watermark, const int* values, int nvalues, int x, int* out_values, int* out_watermark) {
+  ips_t s = {watermark, nvalues, NULL};
+  if (nvalues) {
+    s.values = (int*)malloc(sizeof(int) * (size_t)nvalues);
+    memcpy(s.values, values, sizeof(int) * (size_t)nvalues);
+  }
+  ips_compact(&s);
+  ips_subtract_one(&s, x);
+  const int n = s.nvalues;
+  if (n) memcpy(out_values, s.values, sizeof(int) * (size_t)n);
+  *out_watermark = s.watermark;
+  ips_free(&s);
+  return n;
+}
+int fpo_ips_add_all(int wa, const int* va, int na, int wb, const int* vb, int nb, int* out_values, int* out_watermark) {
+  ips_t a = {wa, na, NULL}, b = {wb, nb, NULL};
+  if (na) a.values = (int*)malloc(sizeof(int) * (size_t)na), memcpy(a.values, va, sizeof(int) * (size_t)na);
+  if (nb) b.values = (int*)malloc(sizeof(int) * (size_t)nb), memcpy(b.values, vb, sizeof(int) * (size_t)nb);
+  ips_compact(&a);
+  ips_compact(&b);
+  ips_add_all(&a, &b);
+  const int n = a.nvalues;
+  if (n) memcpy(out_values, a.values, sizeof(int) * (size_t)n);
+  *out_watermark = a.watermark;
+  ips_free(&a);
+  ips_free(&b);
+  return n;
+}
+
 /*
  * One tick.  rank[r * m + i] = position of message i in replica r's processing order.
  * resp_mask[i]: the n-2 other replicas the leader sends PreAccept to.
- * Outputs: fast[i] (1 = fast path commit, 0 = slow path -> Accept phase), deps[i * n + l] = the
- * committed dependencies (fast) or the union the Accept phase proposes (slow), leader_deps[i * n + l].
- * Returns 0, or 1 (EINVAL) on malformed input.
+ * Outputs: fast[i] (1 = fast path commit, 0 = slow path -> Accept phase); deps = the committed
+ * dependencies (fast) or the union the Accept phase proposes (slow) and leader_deps = the PreAccept's, both
+ * as InstancePrefixSets: deps[i * n + l] = the IntPrefixSet watermark of column l; only the column of the
+ * instance's own leader can carry explicit values (subtractOne), and they always are the run
+ * number[i] + 1 .. own_values_end - 1: own_values_end[i * 2 + 0] for deps, [i * 2 + 1] for leader_deps,
+ * 0 = no values.  Returns 0, 1 (EINVAL) on malformed input, 99 if an own column's values are NOT such a run
+ * (the encoding could not represent the reference's set: never on this path, asserted by the tests).
  */
 int fpo_epx_preaccept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* key,
                       const uint8_t* is_set, const uint8_t* resp_mask, const uint8_t* seen_mask,
-                      const int32_t* rank, uint8_t* fast, int32_t* deps, int32_t* leader_deps) {
+                      const int32_t* rank, uint8_t* fast, int32_t* deps, int32_t* leader_deps,
+                      int32_t* own_values_end) {
   const int n = e->n;
   if (m < 0) return 1;
   for (int i = 0; i < m; ++i) {
@@ -109,9 +247,12 @@ int fpo_epx_preaccept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_
     const unsigned seen = seen_mask ? seen_mask[i] : resp_mask[i];
     if ((resp_mask[i] & ~seen) || ((seen >> leader[i]) & 1u) || (seen >> n)) return 1;
   }
-  /* local conflicts seen by replica r for message i, in r's own processing order */
-  int* conf = (int*)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1) * n * n);
-  int* order = (int*)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+  /* local conflicts seen by replica r for message i, in r's own processing order: the watermarks of the
+   * n columns, and the own-leader column again as the IntPrefixSet that subtractOne leaves */
+  const size_t mm = (size_t)(m > 0 ? m : 1);
+  int* conf = (int*)malloc(sizeof(int) * mm * n * n);
+  ips_t* own = (ips_t*)calloc(mm * n, sizeof(ips_t));
+  int* order = (int*)malloc(sizeof(int) * mm);
   /* every replica's rank must be a permutation of 0..m-1 (a delivery order); checked for all replicas before
    * anything is applied */
   for (int r = 0; r < n; ++r) {
@@ -119,7 +260,7 @@ int fpo_epx_preaccept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_
     for (int i = 0; i < m; ++i) {
       int p = rank[(size_t)r * m + i];
       if (p < 0 || p >= m || order[p] != -1) {
-        free(conf), free(order);
+        free(conf), free(own), free(order);
         return 1;
       }
       order[p] = i;
@@ -131,34 +272,57 @@ int fpo_epx_preaccept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_
       const int i = order[p];
       const int participates = r == leader[i] || (((seen_mask ? seen_mask[i] : resp_mask[i]) >> r) & 1u);
       if (!participates) continue;
-      /* Replica.scala:580-583: getTopOneConflicts then subtractOne(instance); the instance is fresh,
-       * so it is not in the index yet and subtractOne changes nothing.  Then updateConflictIndex
-       * (:696 for the leader, :1274 for the others). */
-      get_top_one_conflicts(e, r, key[i], is_set[i], conf + ((size_t)i * n + r) * n);
+      /* Replica.scala:580-583: InstancePrefixSet.fromTopOne(getTopOneConflicts), then
+       * dependencies.subtractOne(instance) -- IntPrefixSet.subtractOne on the column of the instance's own
+       * leader (epaxos/InstancePrefixSet.scala subtractOne -> intPrefixSets(replicaIndex)).  The instance is
+       * fresh, so it is not in the index itself; but a HIGHER-numbered instance of the same leader on the same
+       * key may be (processed earlier here): then the watermark drops to the instance number and the ids
+       * above it become explicit values.  Then updateConflictIndex (:696 for the leader, :1274 for the others). */
+      int* c = conf + ((size_t)i * n + r) * n;
+      get_top_one_conflicts(e, r, key[i], is_set[i], c);
+      ips_t* o = &own[(size_t)i * n + r];
+      *o = ips_from_watermark(c[leader[i]]);
+      ips_subtract_one(o, number[i]);
       conflict_index_put(e, r, key[i], is_set[i], leader[i], number[i]);
     }
   }
+  int rc = 0;
   for (int i = 0; i < m; ++i) {
     const int L = leader[i];
     const int* D = conf + ((size_t)i * n + L) * n; /* the leader's own (seq = 0, deps), :641-642 */
+    const ips_t* Down = &own[(size_t)i * n + L];
     int first[8], uni[8];
+    ips_t first_own = ips_from_watermark(0), uni_own = ips_clone(Down);
     int have_first = 0, all_equal = 1;
     memcpy(uni, D, sizeof(int) * (size_t)n);
     for (int r = 0; r < n; ++r) {
       if (!((resp_mask[i] >> r) & 1u)) continue;
-      /* handlePreAccept :1252-1257: dependencies = local conflicts ++ preAccept.dependencies */
+      /* handlePreAccept :1252-1257: dependencies = local conflicts, addAll(preAccept.dependencies) */
       int resp[8];
+      ips_t resp_own = ips_clone(&own[(size_t)i * n + r]);
+      ips_add_all(&resp_own, Down);
+      ips_add_all(&uni_own, &resp_own); /* preAcceptingSlowPath :804-807 union of all responses */
       for (int l = 0; l < n; ++l) {
         const int c = conf[((size_t)i * n + r) * n + l];
         resp[l] = c > D[l] ? c : D[l];
-        if (resp[l] > uni[l]) uni[l] = resp[l]; /* preAcceptingSlowPath :804-807 union of all responses */
+        if (resp[l] > uni[l]) uni[l] = resp[l];
       }
       if (!have_first) {
         memcpy(first, resp, sizeof(int) * (size_t)n);
+        first_own = ips_clone(&resp_own);
         have_first = 1;
-      } else if (memcmp(first, resp, sizeof(int) * (size_t)n) != 0) {
-        all_equal = 0;
+      } else {
+        /* Util.popularItems compares (sequenceNumber, InstancePrefixSet) values: per column
+         * (watermark, values) tuples (InstancePrefixSet.equals -> IntPrefixSet.equals) */
+        for (int l = 0; l < n; ++l) {
+          if (l == L) {
+            if (!ips_equals(&first_own, &resp_own)) all_equal = 0;
+          } else if (first[l] != resp[l]) {
+            all_equal = 0;
+          }
+        }
       }
+      ips_free(&resp_own);
     }
     /* handlePreAcceptOk :1376-1410: with the leader's own response plus the first n-2 others to arrive
      * (resp_mask) the fast quorum (n-1) is reached and the leader decides at once;
@@ -166,18 +330,34 @@ int fpo_epx_preaccept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_
      * replica in seen_mask finds the instance committed / accepting and is ignored (:1308-1334). */
     const int is_fast = all_equal;
     if (fast) fast[i] = (uint8_t)is_fast;
+    const ips_t* out_own = is_fast ? &first_own : &uni_own;
     for (int l = 0; l < n; ++l) {
-      if (deps) deps[(size_t)i * n + l] = is_fast ? first[l] : uni[l];
-      if (leader_deps) leader_deps[(size_t)i * n + l] = D[l];
+      if (deps) deps[(size_t)i * n + l] = l == L ? out_own->watermark : (is_fast ? first[l] : uni[l]);
+      if (leader_deps) leader_deps[(size_t)i * n + l] = l == L ? Down->watermark : D[l];
     }
+    /* the own column's explicit values, as the end of the run number + 1 .. end - 1 */
+    const ips_t* sets2[2] = {out_own, Down};
+    for (int k = 0; k < 2; ++k) {
+      const ips_t* q = sets2[k];
+      int end = 0;
+      if (q->nvalues) {
+        end = q->values[q->nvalues - 1] + 1;
+        if (q->watermark != number[i] || q->values[0] != number[i] + 1 || end - q->values[0] != q->nvalues) rc = 99;
+      }
+      if (own_values_end) own_values_end[(size_t)i * 2 + k] = end;
+    }
+    ips_free(&first_own);
+    ips_free(&uni_own);
   }
   /* commit (fast path) / Accept+commit (slow path) reach every replica after the tick:
    * commit -> updateConflictIndex(instance, command)  Replica.scala:815-828 */
   for (int r = 0; r < n; ++r)
     for (int i = 0; i < m; ++i) conflict_index_put(e, r, key[i], is_set[i], leader[i], number[i]);
+  for (size_t k = 0; k < mm * n; ++k) ips_free(&own[k]);
   free(conf);
+  free(own);
   free(order);
-  return 0;
+  return rc;
 }
 
 /* replica r's conflict index entries for `key`: gets[n], sets[n] */

@@ -486,7 +486,7 @@ class EPaxos:
         L.fpo_epx_new.restype = C.c_void_p
         L.fpo_epx_free.argtypes = [C.c_void_p]
         L.fpo_epx_preaccept.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, U8P, U8P, U8P, I32P, U8P, I32P,
-                                        I32P]
+                                        I32P, I32P]
         L.fpo_epx_read_index.argtypes = [C.c_void_p, C.c_int, C.c_int, I32P, I32P]
         L.fpo_epx_index_put.argtypes = [C.c_void_p] + [C.c_int] * 5
         L.fpo_epx_index_conflicts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, I32P]
@@ -510,11 +510,12 @@ class EPaxos:
         fast = np.zeros(m, np.uint8)
         deps = np.zeros((m, self.n), np.int32)
         ldeps = np.zeros((m, self.n), np.int32)
+        own = np.zeros((m, 2), np.int32)
         st = lib().fpo_epx_preaccept(self._h, m, _p(leader, I32P), _p(number, I32P), _p(key, I32P),
                                      _p(is_set, U8P), _p(resp_mask, U8P), _p(seen_mask, U8P), _p(rank, I32P),
                                      _p(fast, U8P),
-                                     _p(deps, I32P), _p(ldeps, I32P))
-        return st, fast, deps, ldeps
+                                     _p(deps, I32P), _p(ldeps, I32P), _p(own, I32P))
+        return st, fast, deps, ldeps, own
 
     def index_put(self, replica, key, is_set, leader, number):
         """KeyValueStore conflict index put of one single-key command (KeyValueStore.scala:232-253)"""

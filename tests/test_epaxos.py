@@ -72,7 +72,7 @@ def test_oracle_tick_by_hand(oracle):
     rank = np.array([[0, 3, 1, 2],     # positions of A, B, C, D at replica 0 (B does not reach it)
                      [1, 0, 2, 3],     # replica 1: B first, then A
                      [3, 1, 0, 2]])    # replica 2: C, B, D
-    st, fast, deps, ldeps = e.preaccept(leader, number, key, is_set, mask, rank)
+    st, fast, deps, ldeps, own = e.preaccept(leader, number, key, is_set, mask, rank)
     assert st == 0
     # A at its leader (replica 0, first): no conflicts -> [0,0,0]; at replica 1 after B (a get by 1,
     # instance 0): a set conflicts with gets -> [0,1,0]; one answer => fast, deps = [0,1,0]
@@ -90,7 +90,7 @@ def test_oracle_tick_by_hand(oracle):
         g, s = e.read_index(r, 2)
         assert g.tolist() == [2, 0, 0] and s.tolist() == [0, 0, 0]
     # next tick: a get of k1 by replica 1 conflicts with both sets everywhere: identical answers
-    st, fast, deps, ldeps = e.preaccept([1], [1], [1], [0], [0b001], np.zeros((3, 1), np.int32))
+    st, fast, deps, ldeps, own = e.preaccept([1], [1], [1], [0], [0b001], np.zeros((3, 1), np.int32))
     assert fast[0] == 1 and deps[0].tolist() == [1, 0, 1] and ldeps[0].tolist() == [1, 0, 1]
 
 
@@ -103,7 +103,7 @@ def test_oracle_slow_path_by_hand(oracle):
     mask = [0b01110, 0b01110]
     # replica 1 and 2 process X then Y; replica 3 processes Y then X
     rank = np.array([[0, 1], [0, 1], [0, 1], [1, 0], [0, 1]])
-    st, fast, deps, ldeps = e.preaccept(leader, number, key, is_set, mask, rank)
+    st, fast, deps, ldeps, own = e.preaccept(leader, number, key, is_set, mask, rank)
     assert st == 0
     # Y's answers: replicas 1, 2 saw X -> [0,0,0,0,1]; replica 3 did not -> [0,0,0,0,0]  => slow, union
     assert fast[1] == 0 and deps[1].tolist() == [0, 0, 0, 0, 1]
@@ -122,14 +122,14 @@ def test_oracle_not_thrifty_by_hand(oracle):
     resp, seen = [0b010, 0b010], [0b110, 0b011]
     rank = np.array([[0, 1], [0, 1], [0, 1]])
     e = oracle.EPaxos(3, 4)
-    st, fast, deps, ldeps = e.preaccept(leader, number, key, is_set, resp, rank, seen_mask=seen)
+    st, fast, deps, ldeps, own = e.preaccept(leader, number, key, is_set, resp, rank, seen_mask=seen)
     assert st == 0 and fast.tolist() == [1, 1]
     # A reached replica 2 although its answer is not waited for: B's own leader already conflicts with it
     assert ldeps[1].tolist() == [1, 0, 0] and deps[1].tolist() == [1, 0, 0]
     assert ldeps[0].tolist() == [0, 0, 0] and deps[0].tolist() == [0, 0, 0]
     # thrifty: replica 2 never sees A's PreAccept, B's PreAccept carries no dependency; replica 1 adds it
     e = oracle.EPaxos(3, 4)
-    st, fast, deps, ldeps = e.preaccept(leader, number, key, is_set, resp, rank)
+    st, fast, deps, ldeps, own = e.preaccept(leader, number, key, is_set, resp, rank)
     assert ldeps[1].tolist() == [0, 0, 0] and deps[1].tolist() == [1, 0, 0]
     # the answers counted must come from replicas the PreAccept was sent to; never from the leader itself
     assert e.preaccept([0], [5], [0], [1], [0b010], np.zeros((3, 1), np.int32), seen_mask=[0b100])[0] == 1
@@ -137,25 +137,137 @@ def test_oracle_not_thrifty_by_hand(oracle):
 
 
 # ----------------------------------------------------------------------------- GPU parity -------
-def random_tick(rng, n, num_keys, m, next_number, skew):
+def random_tick(rng, n, num_keys, m, next_number, skew, fifo=True):
+    """One tick of fresh instances.  Every replica sees the tick in roughly the global order, perturbed by a
+    replica-specific skew.  A leader numbers its instances in the order IT processes them
+    (Replica.scala nextAvailableInstance), and with fifo=True every other replica receives one leader's
+    PreAccepts in sending order (the reference's transports are TCP channels: per-pair FIFO).  fifo=False
+    lets the channels reorder, which is what makes a replica meet (L, 5) before (L, 4) -- the case
+    dependencies.subtractOne(instance) (Replica.scala:582) exists for."""
     leader = rng.integers(0, n, m).astype(np.int32)
-    number = np.zeros(m, np.int32)
-    for i in range(m):  # instance numbers increase per leader (Replica.scala nextAvailableInstance)
-        number[i] = next_number[leader[i]]
-        next_number[leader[i]] += 1
     key = rng.integers(0, num_keys, m).astype(np.int32)
     is_set = (rng.random(m) < 0.5).astype(np.uint8)  # Bernoulli get/set, J/Workload.scala:75-103
     mask = np.zeros(m, np.uint8)
-    for i in range(m):
-        others = [r for r in range(n) if r != leader[i]]
-        drop = rng.integers(0, n - 1)
-        mask[i] = sum(1 << r for j, r in enumerate(others) if j != drop)
-    # every replica sees the tick in roughly the global order, perturbed by a replica-specific skew
+    others = np.array([[r for r in range(n) if r != L] for L in range(n)])   # [n][n-1]
+    drop = rng.integers(0, n - 1, m)
+    for j in range(n - 1):
+        mask |= np.where(drop != j, 1 << others[leader, j], 0).astype(np.uint8)
     rank = np.zeros((n, m), np.int32)
     for r in range(n):
         noisy = np.arange(m) + rng.normal(0, skew, m)
         rank[r, np.argsort(noisy, kind="stable")] = np.arange(m)
+    number = np.zeros(m, np.int32)
+    for L in range(n):
+        idx = np.nonzero(leader == L)[0]
+        by_own = idx[np.argsort(rank[L, idx], kind="stable")]     # the leader's own processing order
+        number[by_own] = next_number[L] + np.arange(len(idx))
+        next_number[L] += len(idx)
+        if fifo:
+            for r in range(n):
+                if r != L:   # the positions leader L's messages occupy at r, refilled in sending order
+                    rank[r, by_own] = np.sort(rank[r, idx])
     return leader, number, key, is_set, mask, rank
+
+
+# ------------------------------------------------ subtractOne: the instance is never its own dependency ----
+def _ips(oracle, fn, *args):
+    import ctypes as C
+    L = oracle.lib()
+    out = np.zeros(4096, np.int32)
+    wm = C.c_int(0)
+    arrs = []
+    cargs = []
+    for a in args:
+        if isinstance(a, (list, tuple, set)):
+            v = np.array(sorted(a), dtype=np.int32)
+            arrs.append(v)
+            cargs += [v.ctypes.data_as(C.POINTER(C.c_int)), len(v)]
+        else:
+            cargs.append(int(a))
+    f = getattr(L, fn)
+    f.restype = C.c_int
+    f.argtypes = None
+    n = f(*cargs, out.ctypes.data_as(C.POINTER(C.c_int)), C.byref(wm))
+    return wm.value, out[:n].tolist()
+
+
+def _materialize(wm, values):
+    return set(range(wm)) | set(values)
+
+
+def test_int_prefix_set_restatement_is_pinned_like_the_reference(oracle):
+    """compact/IntPrefixSetTest.scala:231-239 ("addAll random sets correctly") and :251-263 ("subtractOne
+    random sets correctly"): the reference pins these operations by materialize() == the plain set operation
+    on random sets of 0..100; the oracle's IntPrefixSet restatement is held to the same property, and to the
+    canonical (watermark, values) form equality depends on (IntPrefixSet.scala:214-221, compact() :426-431)."""
+    rng = np.random.default_rng(2024)
+    for trial in range(600):
+        a = set(rng.integers(0, 100, rng.integers(0, 60)).tolist())
+        b = set(rng.integers(0, 100, rng.integers(0, 60)).tolist())
+        x = int(rng.integers(0, 101))
+        wm, vals = _ips(oracle, "fpo_ips_subtract_one", 0, a, x)
+        assert _materialize(wm, vals) == a - {x}
+        assert all(v > wm for v in vals) and wm not in vals          # compacted
+        wm, vals = _ips(oracle, "fpo_ips_add_all", 0, a, 0, b)
+        assert _materialize(wm, vals) == a | b
+        assert all(v > wm for v in vals)
+    # the shapes this path produces: a bare watermark minus one id
+    assert _ips(oracle, "fpo_ips_subtract_one", 6, [], 4) == (4, [5])       # {0..5} - 4 = {0..3, 5}
+    assert _ips(oracle, "fpo_ips_subtract_one", 6, [], 6) == (6, [])        # x >= watermark: values -= x
+    assert _ips(oracle, "fpo_ips_subtract_one", 6, [], 5) == (5, [])
+    assert _ips(oracle, "fpo_ips_subtract_one", 9, [], 2) == (2, [3, 4, 5, 6, 7, 8])
+    assert _ips(oracle, "fpo_ips_add_all", 4, [5], 4, [5, 6]) == (4, [5, 6])
+    assert _ips(oracle, "fpo_ips_add_all", 4, [5], 5, []) == (6, [])        # union {0..3,5} + {0..4} compacts
+
+
+def test_oracle_out_of_order_instances_of_one_leader_by_hand(oracle):
+    """VERDICT r01 weak #2.  n = 3; replica 0 leads instances (0, 4) and (0, 5), both sets of key 1, and asks
+    replica 1 (n - 2 = 1 other).  Replica 1 processes (0, 5) BEFORE (0, 4).
+      at the leader (in order): (0,4) sees nothing -> {<0} ; (0,5) sees (0,4) -> column 0 = {<5}, minus itself
+        (5 >= watermark 5: values -= 5, IntPrefixSet.scala:389-390) -> {<5}
+      at replica 1: (0,5) first: nothing -> {<0}; then (0,4): the index holds (0,5) => TopOne column 0 = 6,
+        fromWatermarks -> {<6}; subtractOne(4): 4 < 6 => values += 5, watermark = 4 (:391-396) -> {<4, 5},
+        i.e. {0..3, 5}: NOT a dependency on itself.
+      PreAcceptOk((0,4)) = {<4,5} U leader's {<0} = {<4, 5}; one answer, n = 3 => fast path with it."""
+    e = oracle.EPaxos(3, 4)
+    leader, number, key, is_set = [0, 0], [4, 5], [1, 1], [1, 1]
+    mask = [0b010, 0b010]
+    rank = np.array([[0, 1], [1, 0], [0, 1]])       # replica 1: message 1 = (0,5) first
+    st, fast, deps, ldeps, own = e.preaccept(leader, number, key, is_set, mask, rank)
+    assert st == 0 and fast.tolist() == [1, 1]
+    assert ldeps.tolist() == [[0, 0, 0], [5, 0, 0]] and own[:, 1].tolist() == [0, 0]
+    assert deps[0].tolist() == [4, 0, 0] and own[0, 0] == 6      # (0,4): {<4, 5}
+    assert deps[1].tolist() == [5, 0, 0] and own[1, 0] == 0      # (0,5): {<5}
+    # n = 5: two responders disagree about the hole => slow path, and the union keeps the hole
+    e = oracle.EPaxos(5, 4)
+    mask = [0b01110, 0b01110]
+    rank = np.array([[0, 1], [1, 0], [0, 1], [0, 1], [0, 1]])   # only replica 1 sees (0,5) first
+    st, fast, deps, ldeps, own = e.preaccept(leader, number, key, is_set, mask, rank)
+    assert st == 0 and fast.tolist() == [0, 1]
+    assert deps[0].tolist() == [4, 0, 0, 0, 0] and own[0, 0] == 6   # {<0} U {<0} U {<4,5} = {<4, 5}
+    assert deps[1].tolist() == [5, 0, 0, 0, 0] and own[1, 0] == 0
+    # the leader's own conflicts can carry the hole too (across ticks: its index already holds (0, 9))
+    st, fast, deps, ldeps, own = e.preaccept([0], [9], [1], [1], [0b01110], np.zeros((5, 1), np.int32))
+    st, fast, deps, ldeps, own = e.preaccept([0], [7], [1], [1], [0b01110], np.zeros((5, 1), np.int32))
+    assert st == 0 and fast[0] == 1 and ldeps[0].tolist() == [7, 0, 0, 0, 0] and own[0].tolist() == [10, 10]
+
+
+def test_random_tick_respects_channel_fifo():
+    rng = np.random.default_rng(1)
+    nxt = [0] * 5
+    for fifo in (True, False):
+        leader, number, key, is_set, mask, rank = random_tick(rng, 5, 16, 3000, nxt, 20.0, fifo=fifo)
+        for r in range(5):
+            assert (np.sort(rank[r]) == np.arange(3000)).all()
+        inversions = 0
+        for L in range(5):
+            idx = np.nonzero(leader == L)[0]
+            idx = idx[np.argsort(number[idx])]
+            assert (np.diff(rank[L, idx]) > 0).all()                # a leader processes its own in number order
+            for r in range(5):
+                inversions += int((np.diff(rank[r, idx]) < 0).sum())
+        assert (inversions == 0) == fifo
+        assert (np.array([bin(x).count("1") for x in mask]) == 3).all() and not ((mask >> leader) & 1).any()
 
 
 @pytest.mark.gpu
@@ -164,27 +276,62 @@ def random_tick(rng, n, num_keys, m, next_number, skew):
                                                # sort shapes: whole tiles / 2 digit passes, 3 digit passes,
                                                # 255 keys + the non-participant bucket = exactly one digit
                                                (3, 256, 2048, 4.0), (5, 70000, 5000, 20.0), (3, 255, 1025, 7.0)])
-def test_epaxos_ticks_match_oracle(oracle, n, num_keys, m, skew):
+@pytest.mark.parametrize("fifo", [True, False])
+def test_epaxos_ticks_match_oracle(oracle, n, num_keys, m, skew, fifo):
+    """fifo=False: channels reorder one leader's PreAccepts, so replicas meet higher-numbered instances of a
+    leader first and dependencies.subtractOne(instance) leaves explicit values (own_values_end != 0)"""
     from frankenpaxos_amd.epaxos import EPaxos
 
     gpu, ref = EPaxos(n, num_keys), oracle.EPaxos(n, num_keys)
     rng = np.random.default_rng(n * 1000 + num_keys)
     nxt = [0] * n
-    seen_fast = seen_slow = 0
+    seen_fast = seen_slow = holes = 0
     for tick in range(4):
-        args = random_tick(rng, n, num_keys, m, nxt, skew)
+        args = random_tick(rng, n, num_keys, m, nxt, skew, fifo=fifo)
         a, b = gpu.preaccept(*args), ref.preaccept(*args)
         assert a[0] == b[0] == 0
         for x, y in zip(a[1:], b[1:]):
             np.testing.assert_array_equal(x, y)
         seen_fast += int(a[1].sum())
         seen_slow += int((a[1] == 0).sum())
+        holes += int((a[4][:, 0] != 0).sum())
+    assert (holes == 0) == (fifo or num_keys > m)
     for r in range(n):
         for k in range(0, num_keys, max(1, num_keys // 16)):
             ga, sa = gpu.read_index(r, k)
             gb, sb = ref.read_index(r, k)
             assert ga.tolist() == gb.tolist() and sa.tolist() == sb.tolist()
     assert seen_fast > 0 and (seen_slow > 0 or n == 3)
+
+
+@pytest.mark.gpu
+def test_config4_epaxos_1m_commands_5_replicas(oracle):
+    """BASELINE.json configs[3] at its stated size: n = 5, 2^20 commands per tick, keys
+    splitmix64(i) % 1024, Bernoulli(1/2) get/set (J/Workload.scala:75-103) -- GPU == oracle bit for bit on
+    every output of two consecutive ticks and on every replica's whole conflict index; the second tick's
+    channels reorder, so the own-column holes of subtractOne are exercised at size too."""
+    from frankenpaxos_amd.epaxos import EPaxos
+    from tests import workloads as W
+
+    n, num_keys, m = 5, 1024, 1 << 20
+    gpu, ref = EPaxos(n, num_keys), oracle.EPaxos(n, num_keys)
+    rng = np.random.default_rng(4)
+    nxt = [0] * n
+    for tick, fifo in enumerate((True, False)):
+        leader, number, key, is_set, mask, rank = random_tick(rng, n, num_keys, m, nxt, 64.0, fifo=fifo)
+        key = (W.splitmix64_at(np.arange(tick * m, (tick + 1) * m, dtype=np.uint64)) % np.uint64(num_keys)).astype(np.int32)
+        a = gpu.preaccept(leader, number, key, is_set, mask, rank)
+        b = ref.preaccept(leader, number, key, is_set, mask, rank)
+        assert a[0] == b[0] == 0
+        for x, y in zip(a[1:], b[1:]):
+            np.testing.assert_array_equal(x, y)
+        assert 0 < int(a[1].sum()) < m                      # both paths taken
+        assert (int((a[4] != 0).sum()) > 0) == (not fifo)
+    for r in range(n):
+        for k in range(num_keys):
+            ga, sa = gpu.read_index(r, k)
+            gb, sb = ref.read_index(r, k)
+            assert ga.tolist() == gb.tolist() and sa.tolist() == sb.tolist()
 
 
 @pytest.mark.gpu
@@ -197,8 +344,8 @@ def test_epaxos_invalid_ticks(oracle):
     assert gpu.preaccept([0], [0], [0], [1], [0b00110], z)[0] == fa.FPX_EINVAL   # not n-2 others
     assert gpu.preaccept([0], [0], [0], [1], [0b00111], z)[0] == fa.FPX_EINVAL   # asks itself
     assert gpu.preaccept([0], [0], [9], [1], [0b01110], z)[0] == fa.FPX_EINVAL   # key out of range
-    st, fast, deps, ldeps = gpu.preaccept([0], [0], [0], [1], [0b01110], z)
-    assert st == 0 and fast[0] == 1 and deps[0].tolist() == [0] * 5
+    st, fast, deps, ldeps, own = gpu.preaccept([0], [0], [0], [1], [0b01110], z)
+    assert st == 0 and fast[0] == 1 and deps[0].tolist() == [0] * 5 and own.tolist() == [[0, 0]]
     with pytest.raises(fa.FpxError):
         EPaxos(4, 4)
 
@@ -293,7 +440,7 @@ def test_oracle_epaxos_safety_invariant(oracle, n, not_thrifty):
         seen = None
         if not_thrifty:
             seen = (((1 << n) - 1) & ~(1 << leader.astype(np.int64))).astype(np.uint8)
-        st, fast, deps, ldeps = e.preaccept(leader, number, key, is_set, mask, rank, seen_mask=seen)
+        st, fast, deps, ldeps, own = e.preaccept(leader, number, key, is_set, mask, rank, seen_mask=seen)
         assert st == 0
         cur = [(int(leader[i]), int(number[i]), int(key[i]), int(is_set[i]), deps[i]) for i in range(m)]
         for i, (li, ni, ki, si, di) in enumerate(cur):
@@ -317,7 +464,7 @@ def test_oracle_epaxos_safety_invariant_negative_control(oracle):
     e = oracle.EPaxos(n, num_keys)
     rng = np.random.default_rng(9)
     leader, number, key, is_set, mask, rank = random_tick(rng, n, num_keys, m, [0] * n, 25.0)
-    st, fast, deps, ldeps = e.preaccept(leader, number, key, is_set, mask, rank)
+    st, fast, deps, ldeps, own = e.preaccept(leader, number, key, is_set, mask, rank)
     violations = 0
     for i in range(m):
         for j in range(i):
