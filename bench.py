@@ -54,8 +54,8 @@ def steady_values_torch(slot):
     return (splitmix64_torch(slot.to(torch.int64) + 0xF9A405) & 0x7FFFFFFF).to(torch.int32)
 
 
-# BASELINE.json's metric, verbatim (its "; 1/2/4/8-GPU scaling" clause describes the sweep the driver runs)
-METRIC = "committed log slots/sec at 1M slots \u00d7 256 replicas"
+# BASELINE.json's metric, verbatim
+METRIC = "committed log slots/sec at 1M slots \u00d7 256 replicas; 1/2/4/8-GPU scaling"
 
 
 # profiles/r01_hbm_mix.txt (1 x MI355X): pure read, pure write, copy, and this path's 1 read : 2 write mix
@@ -151,6 +151,99 @@ def cpu_baseline(ballot_mode):
     }
 
 
+def setup_comm(fa, ctx, dist, backend, dev, rank, world):
+    """The RCCL communicator lives behind the C ABI (fpx_comm_create); its 128-byte id travels over
+    torch.distributed, which is control plane only here.  Under the gloo test hook the ranks share one GPU,
+    which RCCL refuses (duplicate device): no communicator, the caller falls back to a host exchange."""
+    if backend != "nccl":
+        return False
+    idt = torch.zeros(fa.FPX_COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        idt.copy_(torch.frombuffer(bytearray(fa.comm_unique_id()), dtype=torch.uint8))
+    dist.broadcast(idt, 0)
+    ctx.comm_create(idt.cpu().numpy().tobytes(), rank, world)
+    return True
+
+
+def replica_axis_row(fa, dist, backend, dev, rank, world, local_rank, ballot_mode, K, all_reduce):
+    """ONE 2^20-slot x 256-acceptor grid per step, its acceptor columns split over the
+    ranks; per step K1 on every rank, reduce-scatter(sum) of the per-slot vote bitmaps over xGMI, K2 on each
+    rank's slice.  Strong scaling of the acceptor axis; returns the row (rank 0) with the collective broken out."""
+    from frankenpaxos_amd import sharding
+    R_local = REPLICAS // world
+    windows = K + 1
+    ctx = fa.Context(fa.make_config(
+        num_slots=windows * SLOTS_PER_STEP, num_replicas=R_local, f=F, quorum_kind=fa.FPX_Q_THRESHOLD,
+        ballot_mode=ballot_mode, tally_ways=4, device=local_rank, flags=fa.FPX_F_TRUSTED,
+        replica_base=rank * R_local, replicas_total=REPLICAS))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    assert ctx.acceptor_phase1a(0, 0)[0] == 0
+    have_comm = setup_comm(fa, ctx, dist, backend, dev, rank, world)
+    lo, hi = sharding.slot_slice(SLOTS_PER_STEP, world, rank)
+    per = hi - lo
+    steps = []
+    for w in range(windows):
+        slot = torch.arange(w * SLOTS_PER_STEP, (w + 1) * SLOTS_PER_STEP, dtype=torch.int32, device=dev)
+        steps.append((slot, torch.zeros_like(slot), steady_values_torch(slot),
+                      torch.zeros(per, dtype=torch.uint8, device=dev),
+                      torch.full((per,), -7, dtype=torch.int32, device=dev),
+                      torch.full((per,), -7, dtype=torch.int32, device=dev)))
+    if not have_comm:
+        vb = torch.empty((SLOTS_PER_STEP, 4), dtype=torch.int64, device=dev)
+
+    def step(i):
+        slot, rnd, val, ch, cr, cv = steps[i]
+        if have_comm:
+            ctx.phase2_replica_sharded_dev(slot, rnd, val, None, ch, cr, cv)
+        else:
+            ctx.acceptor_phase2a_dev(slot, rnd, val, None, vb, None, None)
+            all_reduce(vb, dist.ReduceOp.SUM)
+            ctx.proxy_open_dev(slot[lo:hi], rnd[lo:hi], val[lo:hi])
+            ctx.proxy_phase2b_dev(slot[lo:hi], rnd[lo:hi], vb[lo:hi].contiguous(), ch, cr, cv)
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    step(0)
+    assert ctx.sync() == 0
+    ctx.profile_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(1, windows):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    k1_n, k1_ms = ctx.profile_read()
+    c_n, c_ms = ctx.profile_read_collective()
+    assert ctx.sync() == 0
+    committed = 0
+    for i in range(1, windows):
+        slot, rnd, val, ch, cr, cv = steps[i]
+        assert bool(ch.all()) and bool((cv == val[lo:hi]).all()) and bool((cr == 0).all()), "replica-axis step %d" % i
+        committed += int(ch.sum().item())
+    t = torch.tensor([elapsed, float(committed), c_ms / max(c_n, 1)], dtype=torch.float64, device=dev)
+    tm = t.clone()
+    all_reduce(tm, dist.ReduceOp.MAX)
+    all_reduce(t, dist.ReduceOp.SUM)
+    ctx.close()
+    if rank != 0:
+        return None
+    el = float(tm[0].item())
+    return {
+        "workload": "ONE 2^20 x 256 grid per step, acceptor columns split over the ranks (%d per GPU): K1 -> "
+                    "reduce-scatter(sum) of the vote bitmaps -> K2 on 1/N of the slots" % R_local,
+        "scaling": "strong", "steps": K, "value": float(t[1].item()) / el, "unit": "slots/s",
+        "ms_per_step": el / K * 1e3, "rccl_ranks": world if have_comm else 0,
+        "exchange": "ncclReduceScatter(ncclSum, ncclUint64) inside fpx_phase2_replica_sharded_dev" if have_comm
+                    else "all_reduce over gloo (single-GPU test hook)",
+        "collective_avg_ms_max_over_ranks": float(tm[2].item()) if c_n else None,
+        "k1_avg_ms_rank0": k1_ms / max(k1_n, 1),
+        "xgmi_bytes_per_gpu_per_step": (world - 1) * 32 * SLOTS_PER_STEP // world,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,11 +254,32 @@ def main():
     ap.add_argument("--validate", action="store_true",
                     help="keep the run-contract validation kernel in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--replica-row-steps", type=int, default=5,
+                    help="N > 1, --shard group: steps of the extra replica-axis row (0 = skip it)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: become N ranks (one per GPU) under torch.distributed.run.
+        # rank 0 of the children prints the one JSON line on the inherited stdout.
+        import socket
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        if os.environ.get("FPX_BENCH_DRY_SPAWN") == "1":   # test hook: show the launch instead of doing it
+            print(json.dumps({"spawn": cmd}))
+            return
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d -- refusing to report a %d-GPU number as a "
+                         "%d-GPU one" % (args.gpus, world, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libfpx has no CPU path)")
     # test hooks (tests/test_bench_distributed.py): run several ranks on ONE GPU over gloo, so that the
@@ -194,8 +308,6 @@ def main():
             c = t.cpu()
             dist.all_reduce(c, op=op)
             t.copy_(c)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
     import frankenpaxos_amd as fa
 
@@ -228,19 +340,22 @@ def main():
         rnd = torch.full((SLOTS_PER_STEP,), lap, dtype=torch.int32, device=dev)
         val = steady_values_torch(slot)
         ch = torch.zeros(SLOTS_PER_STEP, dtype=torch.uint8, device=dev)
-        steps.append((slot, rnd, val, ch))
-    cr = torch.empty(SLOTS_PER_STEP, dtype=torch.int32, device=dev)
-    cv = torch.empty(SLOTS_PER_STEP, dtype=torch.int32, device=dev)
+        # every step keeps its own Chosen records (round, value): all of them are verified after the timed region
+        cr = torch.full((SLOTS_PER_STEP,), -7, dtype=torch.int32, device=dev)
+        cv = torch.full((SLOTS_PER_STEP,), -7, dtype=torch.int32, device=dev)
+        steps.append((slot, rnd, val, ch, cr, cv))
+    lo, hi = 0, SLOTS_PER_STEP
+    have_comm = False
     if replica_shard:
         from frankenpaxos_amd import sharding
-        vb = torch.empty((SLOTS_PER_STEP, 4), dtype=torch.int64, device=dev)
         lo, hi = sharding.slot_slice(SLOTS_PER_STEP, world, rank)
-        vb_mine = torch.empty((hi - lo, 4), dtype=torch.int64, device=dev)
-    else:
-        lo, hi = 0, SLOTS_PER_STEP
+        have_comm = setup_comm(fa, ctx, dist, backend, dev, rank, world)
+        if not have_comm:   # gloo test hook only: the exchange through torch.distributed on the host
+            vb = torch.empty((SLOTS_PER_STEP, 4), dtype=torch.int64, device=dev)
+            vb_mine = torch.empty((hi - lo, 4), dtype=torch.int64, device=dev)
 
     def step(i):
-        slot, rnd, val, ch = steps[i]
+        slot, rnd, val, ch, cr, cv = steps[i]
         lap = i // windows
         if lap > 0 and lap % TALLY_WAYS == 0:
             # a window of the log is re-proposed once more than the proxy leader keeps tallies for:
@@ -248,15 +363,14 @@ def main():
             ctx.proxy_forget((i % windows) * SLOTS_PER_STEP, SLOTS_PER_STEP)
         if not replica_shard:
             ctx.phase2_fused_dev(slot, rnd, val, None, ch, cr, cv)
+        elif have_comm:
+            # ONE C-ABI call: K1 on my acceptors for every slot -> ncclReduceScatter(sum) of the disjoint partial
+            # bitmaps over xGMI (each rank receives the full bitmaps of ITS 1/N of the slots) -> open + K2 on that slice
+            ctx.phase2_replica_sharded_dev(slot, rnd, val, None, ch[lo:hi], cr[lo:hi], cv[lo:hi])
         else:
-            # K1 on my acceptors for every slot -> reduce-scatter(sum) of the disjoint partial bitmaps over
-            # xGMI (each rank receives the full bitmaps of ITS 1/N of the slots) -> K2 on that slice
             ctx.acceptor_phase2a_dev(slot, rnd, val, None, vb, None, None)
-            if backend == "nccl":
-                dist.reduce_scatter_tensor(vb_mine, vb, op=dist.ReduceOp.SUM)
-            else:
-                all_reduce(vb, dist.ReduceOp.SUM)
-                vb_mine.copy_(vb[lo:hi])
+            all_reduce(vb, dist.ReduceOp.SUM)
+            vb_mine.copy_(vb[lo:hi])
             ctx.proxy_open_dev(slot[lo:hi], rnd[lo:hi], val[lo:hi])
             ctx.proxy_phase2b_dev(slot[lo:hi], rnd[lo:hi], vb_mine, ch[lo:hi], cr[lo:hi], cv[lo:hi])
 
@@ -278,20 +392,34 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     launches, kernel_ms = ctx.profile_read()
+    coll_n, coll_ms = ctx.profile_read_collective()
     assert ctx.sync() == 0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         all_reduce(t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # every timed step must have committed all of its slots, with the proposed value
-    committed = sum(int(steps[i][3].sum().item()) for i in range(Wm, Wm + K))
-    assert committed == K * (hi - lo), (committed, K * (hi - lo))   # replica sharding: my slice of the tally
-    assert bool((cv[lo:hi] == steps[Wm + K - 1][2][lo:hi]).all())
+    # EVERY timed step must have committed all of its slots, in its round, with the proposed value
+    committed = 0
+    for i in range(Wm, Wm + K):
+        slot, rnd, val, ch, cr, cv = steps[i]
+        committed += int(ch.sum().item())
+        assert bool(ch[lo:hi].all()), "step %d: a slot was not chosen" % i    # replica sharding: my slice of the tally
+        assert bool((cv[lo:hi] == val[lo:hi]).all()), "step %d: chosen value != proposed value" % i
+        assert bool((cr[lo:hi] == rnd[lo:hi]).all()), "step %d: chosen round != proposing round" % i
+    assert committed == K * (hi - lo), (committed, K * (hi - lo))
     if dist is not None:
         t = torch.tensor([committed], dtype=torch.int64, device=dev)
         all_reduce(t, dist.ReduceOp.SUM)
         committed = int(t.item())
+
+    # SURVEY.md 8e asks for both sharding rows: with N > 1 the default (group-sharded) run appends the
+    # replica-axis row -- one 2^20 x 256 grid split over the N GPUs' acceptor columns, RCCL reduce-scatter of
+    # the vote bitmaps behind the C ABI, collective time broken out
+    replica_row = None
+    if world > 1 and not replica_shard and args.replica_row_steps > 0:
+        replica_row = replica_axis_row(fa, dist, backend, dev, rank, world, local_rank, ballot_mode,
+                                       args.replica_row_steps, all_reduce)
 
     if rank == 0:
         bps = algorithmic_bytes_per_slot(ballot_mode)
@@ -347,6 +475,16 @@ def main():
                 "frac_of_measured_read_stream": (achieved / MEASURED_STREAM_GBS["read"]) if achieved else None,
             },
         }
+        line["rccl_ranks"] = world if (have_comm or (replica_row or {}).get("rccl_ranks")) else 0
+        if replica_shard:
+            line["collective"] = {
+                "op": "ncclReduceScatter(ncclSum, ncclUint64) via fpx_phase2_replica_sharded_dev" if have_comm
+                      else "all_reduce over gloo (single-GPU test hook)",
+                "calls_timed": coll_n, "avg_ms": (coll_ms / coll_n) if coll_n else None,
+                "xgmi_bytes_per_gpu_per_step": (world - 1) * 32 * SLOTS_PER_STEP // world,
+            }
+        if replica_row is not None:
+            line["replica_axis"] = replica_row
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ballot_mode)
         print(json.dumps(line))

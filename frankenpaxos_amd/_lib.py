@@ -19,6 +19,8 @@ FPX_ENODEVICE = 4
 FPX_ECAPACITY = 5
 FPX_EORDER = 6
 FPX_ENOMEM = 7
+FPX_ERCCL = 8
+FPX_COMM_ID_BYTES = 128
 
 FPX_Q_THRESHOLD = 0
 FPX_Q_SIMPLE_MAJORITY = 1
@@ -114,6 +116,15 @@ SIGNATURES = {
     "fpx_read_state": (C.c_int32, [VP, VP, VP, VP]),
     "fpx_read_scalars": (C.c_int32, [VP, VP, VP]),
     "fpx_read_tally": (C.c_int32, [VP, C.c_int32, I32P, VP, VP, VP, VP]),
+    "fpx_state_digest": (C.c_int32, [VP, VP]),
+    "fpx_comm_unique_id": (C.c_int32, [VP]),
+    "fpx_comm_create": (C.c_int32, [VP, VP, C.c_int32, C.c_int32]),
+    "fpx_comm_destroy": (C.c_int32, [VP]),
+    "fpx_comm_info": (C.c_int32, [VP, I32P, I32P]),
+    "fpx_last_rccl_error": (C.c_int32, [VP]),
+    "fpx_phase2_replica_sharded_dev": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP, VP, VP, VP, VP]),
+    "fpx_comm_allgather_chosen_dev": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP, VP, VP]),
+    "fpx_profile_read_collective": (C.c_int32, [VP, I32P, C.POINTER(C.c_double)]),
 }
 
 

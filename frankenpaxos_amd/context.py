@@ -185,6 +185,48 @@ class Context:
         if st:
             raise FpxError(st, "fpx_phase2_fused_dev")
 
+    # ---- multi-GPU: RCCL communicator behind the C ABI (fpx_comm_*) ----------------------------------
+    def comm_create(self, unique_id, rank, world):
+        """collective over the `world` contexts (one per GPU): unique_id = comm_unique_id() of one rank"""
+        buf = (C.c_uint8 * _lib.FPX_COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        st = self.L.fpx_comm_create(self._h, buf, rank, world)
+        if st:
+            raise FpxError(st, "fpx_comm_create (rccl %d)" % self.L.fpx_last_rccl_error(self._h))
+
+    def comm_destroy(self):
+        st = self.L.fpx_comm_destroy(self._h)
+        if st:
+            raise FpxError(st, "fpx_comm_destroy")
+
+    def comm_info(self):
+        r, w = C.c_int32(), C.c_int32()
+        self.L.fpx_comm_info(self._h, C.byref(r), C.byref(w))
+        return r.value, w.value
+
+    def phase2_replica_sharded_dev(self, slot, round_, value, target_mask=None, chosen=None,
+                                   chosen_round=None, chosen_value=None, nack_round=None):
+        """replica-axis sharded fused step: K1 on my acceptors -> ncclReduceScatter(sum) of the partial vote
+        bitmaps -> open + K2 on my slice of the batch (outputs have n / world entries)"""
+        st = self.L.fpx_phase2_replica_sharded_dev(self._h, slot.numel(), _dp(slot), _dp(round_), _dp(value),
+                                                   _dp(target_mask), _dp(chosen), _dp(chosen_round),
+                                                   _dp(chosen_value), _dp(nack_round))
+        if st:
+            raise FpxError(st, "fpx_phase2_replica_sharded_dev (rccl %d)" % self.L.fpx_last_rccl_error(self._h))
+
+    def comm_allgather_chosen_dev(self, chosen, chosen_round, chosen_value, all_chosen, all_round, all_value):
+        n = (chosen if chosen is not None else chosen_value).numel()
+        st = self.L.fpx_comm_allgather_chosen_dev(self._h, n, _dp(chosen), _dp(chosen_round), _dp(chosen_value),
+                                                  _dp(all_chosen), _dp(all_round), _dp(all_value))
+        if st:
+            raise FpxError(st, "fpx_comm_allgather_chosen_dev")
+
+    def profile_read_collective(self):
+        n, ms = C.c_int32(), C.c_double()
+        st = self.L.fpx_profile_read_collective(self._h, C.byref(n), C.byref(ms))
+        if st:
+            raise FpxError(st, "fpx_profile_read_collective")
+        return n.value, ms.value
+
     def proxy_forget(self, first_slot, count):
         """GC of the proxy leader's tallies of a slot range (async on the context's stream)"""
         st = self.L.fpx_proxy_forget(self._h, first_slot, count)
@@ -287,6 +329,14 @@ class Context:
             raise FpxError(st, "fpx_read_scalars")
         return pr, mv
 
+    def state_digest(self):
+        """8 uint64 digests of the whole state (fpx_state_digest): two states are equal iff their digests are"""
+        out = np.zeros(8, np.uint64)
+        st = self.L.fpx_state_digest(self._h, _hp(out))
+        if st:
+            raise FpxError(st, "fpx_state_digest")
+        return out
+
     def read_tally(self, slot):
         n = C.c_int32()
         rounds = np.zeros(8, np.int32)
@@ -299,6 +349,15 @@ class Context:
             raise FpxError(st, "fpx_read_tally")
         return [(int(rounds[i]), int(states[i]), int(values[i]), tuple(int(x) for x in bits[i]))
                 for i in range(n.value)]
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the C ABI: 128 opaque bytes for fpx_comm_create on every rank"""
+    buf = (C.c_uint8 * _lib.FPX_COMM_ID_BYTES)()
+    st = _lib.lib().fpx_comm_unique_id(buf)
+    if st:
+        raise FpxError(st, "fpx_comm_unique_id")
+    return bytes(buf)
 
 
 # ---- a5 / a7 free functions ----------------------------------------------------------------------

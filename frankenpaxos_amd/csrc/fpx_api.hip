@@ -4,6 +4,8 @@
 // and fails with FPX_ENODEVICE / FPX_EHIP when no device is usable.
 #include "../../include/fpx.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -24,6 +26,25 @@ struct DevBuf {
 };
 
 }  // namespace
+
+// RCCL is bound at run time (dlopen), never at link time: a process that already carries an RCCL (PyTorch
+// bundles its own librccl.so) must keep using THAT copy -- two RCCLs in one address space do not share their
+// communicator state -- and a single-GPU caller needs no RCCL at all.  The handful of types below mirror
+// rccl.h (NCCL 2.x ABI: ncclUniqueId is 128 opaque bytes, ncclSum = 0, ncclUint64 = 5, ncclSuccess = 0).
+struct RcclUniqueId { char internal[128]; };
+typedef void* RcclComm;
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(RcclUniqueId*) = nullptr;
+  int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
+  int (*CommDestroy)(RcclComm) = nullptr;
+  int (*ReduceScatter)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+static_assert(sizeof(RcclUniqueId) == FPX_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+enum { RCCL_SUM = 0, RCCL_UINT8 = 1, RCCL_INT32 = 2, RCCL_UINT64 = 5 };
 
 struct fpx_ctx {
   fpx_config cfg;
@@ -54,6 +75,13 @@ struct fpx_ctx {
   bool profiling = false;
   std::vector<hipEvent_t> ev;  // start/stop pairs
   size_t ev_used = 0;
+  // multi-GPU (fpx_comm_*): one communicator per context, rank = this context's GPU
+  RcclComm comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  int last_rccl = 0;
+  DevBuf d_part, d_mine;       // partial vote bitmaps of my acceptors (all slots) / full bitmaps of my slots
+  std::vector<hipEvent_t> cev;  // start/stop pairs around the collective
+  size_t cev_used = 0;
 };
 
 namespace {
@@ -66,6 +94,27 @@ namespace {
       return _e == hipErrorOutOfMemory ? FPX_ENOMEM : FPX_EHIP; \
     }                                           \
   } while (0)
+
+// Every entry point runs with the context's device current and restores the caller's on return: allocations
+// (staging buffers, events) and launches otherwise land on whatever device the calling thread last selected --
+// two contexts on two GPUs in one process (or a torch.cuda.set_device elsewhere) would fault.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int device) { enter(device); }
+  explicit DeviceGuard(const fpx_ctx* ctx) {
+    if (ctx) enter(ctx->cfg.device);
+  }
+  void enter(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) switched = hipSetDevice(device) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (switched && prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 int check_config(const fpx_config* c) {
   if (!c) return FPX_EINVAL;
@@ -153,9 +202,18 @@ int grid_for(const fpx_ctx* ctx, int n) {
   return std::max(1, std::min(need, ctx->max_grid));
 }
 
+// dynamic LDS above the 64 KiB default needs an opt-in per kernel (gfx950 has 160 KiB per CU): the maxima
+// tables of a context with thousands of acceptors (num_groups * num_leader_groups * R up to 8192) reach 83 KiB
+template <typename K>
+void allow_lds(K kernel, size_t lds) {
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
 template <int G, bool RMW, bool PERSLOT>
 void launch_phase2_3(fpx_ctx* ctx, const Batch& b, bool fused, int grid) {
   const size_t lds = lds_bytes(ctx, fused);
+  if (fused) allow_lds(k_phase2<G, RMW, PERSLOT, true>, lds);
+  else allow_lds(k_phase2<G, RMW, PERSLOT, false>, lds);
   if (fused)
     hipLaunchKernelGGL((k_phase2<G, RMW, PERSLOT, true>), dim3(grid), dim3(256), lds, ctx->stream, ctx->g, ctx->st, b);
   else
@@ -318,6 +376,10 @@ void free_state(fpx_ctx* ctx) {
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
   ctx->ev.clear();
+  for (hipEvent_t e : ctx->cev) (void)hipEventDestroy(e);
+  ctx->cev.clear();
+  if (ctx->d_part.p) (void)hipFree(ctx->d_part.p);
+  if (ctx->d_mine.p) (void)hipFree(ctx->d_mine.p);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
 }
 
@@ -450,6 +512,7 @@ const char* fpx_strerror(int32_t s) {
     case FPX_ECAPACITY: return "more live (slot, round) tallies for one slot than tally_ways";
     case FPX_EORDER: return "device batch violates the run contract; nothing was applied";
     case FPX_ENOMEM: return "out of device memory";
+    case FPX_ERCCL: return "RCCL error (or RCCL could not be loaded)";
     default: return "unknown status";
   }
 }
@@ -479,6 +542,7 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
   if (!ctx->cfg.replicas_total) ctx->cfg.replicas_total = cfg->num_replicas;
   make_geom(ctx->cfg, &ctx->g);
   memset(&ctx->st, 0, sizeof(ctx->st));
+  DeviceGuard _dg(cfg->device);  // the caller's current device is restored on every return path
   if (hipSetDevice(cfg->device) != hipSuccess) {
     delete ctx;
     return FPX_ENODEVICE;
@@ -551,20 +615,23 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
 }
 
 int32_t fpx_destroy(fpx_ctx* ctx) {
+  DeviceGuard _dg(ctx);
   if (!ctx) return FPX_EINVAL;
-  (void)hipSetDevice(ctx->cfg.device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm) (void)fpx_comm_destroy(ctx);
   free_state(ctx);
   delete ctx;
   return FPX_OK;
 }
 
 int32_t fpx_reset(fpx_ctx* ctx) {
+  DeviceGuard _dg(ctx);
   if (!ctx) return FPX_EINVAL;
   return init_state(ctx);
 }
 
 int32_t fpx_set_stream(fpx_ctx* ctx, void* hip_stream) {
+  DeviceGuard _dg(ctx);
   if (!ctx) return FPX_EINVAL;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->stream = hip_stream == FPX_STREAM_OWN ? ctx->own_stream : (hipStream_t)hip_stream;
@@ -572,11 +639,13 @@ int32_t fpx_set_stream(fpx_ctx* ctx, void* hip_stream) {
 }
 
 int32_t fpx_sync(fpx_ctx* ctx) {
+  DeviceGuard _dg(ctx);
   if (!ctx) return FPX_EINVAL;
   return fetch_status(ctx);
 }
 
 int32_t fpx_error_detail(fpx_ctx* ctx, int32_t* index, int32_t* slot, int32_t* round) {
+  DeviceGuard _dg(ctx);
   if (!ctx) return FPX_EINVAL;
   if (index) *index = ctx->err_index;
   if (slot) *slot = ctx->err_slot;
@@ -585,17 +654,22 @@ int32_t fpx_error_detail(fpx_ctx* ctx, int32_t* index, int32_t* slot, int32_t* r
 }
 
 int32_t fpx_profile_enable(fpx_ctx* ctx, int32_t on) {
+  DeviceGuard _dg(ctx);
   if (!ctx) return FPX_EINVAL;
   if (on && ctx->ev.empty()) {
     ctx->ev.resize(2 * 1024);
     for (auto& e : ctx->ev) HIPCHK(ctx, hipEventCreate(&e));
+    ctx->cev.resize(2 * 1024);
+    for (auto& e : ctx->cev) HIPCHK(ctx, hipEventCreate(&e));
   }
   ctx->profiling = on != 0;
   ctx->ev_used = 0;
+  ctx->cev_used = 0;
   return FPX_OK;
 }
 
 int32_t fpx_profile_read(fpx_ctx* ctx, int32_t* launches, double* total_ms) {
+  DeviceGuard _dg(ctx);
   if (!ctx) return FPX_EINVAL;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   double sum = 0;
@@ -610,8 +684,10 @@ int32_t fpx_profile_read(fpx_ctx* ctx, int32_t* launches, double* total_ms) {
   return FPX_OK;
 }
 
-int32_t fpx_last_hip_error(fpx_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
-int64_t fpx_device_bytes(fpx_ctx* ctx) { return ctx ? ctx->bytes : 0; }
+int32_t fpx_last_hip_error(fpx_ctx* ctx) {
+  DeviceGuard _dg(ctx); return ctx ? ctx->last_hip : 0; }
+int64_t fpx_device_bytes(fpx_ctx* ctx) {
+  DeviceGuard _dg(ctx); return ctx ? ctx->bytes : 0; }
 
 int32_t fpx_host_alloc(int64_t bytes, void** out) {
   if (!out || bytes <= 0) return FPX_EINVAL;
@@ -647,6 +723,7 @@ static int32_t quorum_eval_impl(const fpx_config* cfg, int32_t n, const uint64_t
   if (n == 0) return FPX_OK;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FPX_ENODEVICE;
+  DeviceGuard _dg(c.device >= 0 && c.device < ndev ? c.device : 0);
   Geom g;
   make_geom(c, &g);
   uint64_t* d_nodes = nullptr;
@@ -683,6 +760,7 @@ int32_t fpx_is_write_quorum(const fpx_config* cfg, const uint64_t nodes[4], int3
 int32_t fpx_acceptor_phase2a_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,
                                  const int32_t* d_value_id, const uint64_t* d_target_mask, uint64_t* d_vote_bits,
                                  uint64_t* d_nack_bits, int32_t* d_nack_round) {
+  DeviceGuard _dg(ctx);
   if (!ctx || n < 0) return FPX_EINVAL;
   Batch b;
   memset(&b, 0, sizeof(b));
@@ -694,6 +772,7 @@ int32_t fpx_acceptor_phase2a_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot,
 int32_t fpx_phase2_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,
                              const int32_t* d_value_id, const uint64_t* d_target_mask, uint8_t* d_chosen,
                              int32_t* d_chosen_round, int32_t* d_chosen_value, int32_t* d_nack_round) {
+  DeviceGuard _dg(ctx);
   if (!ctx || n < 0) return FPX_EINVAL;
   Batch b;
   memset(&b, 0, sizeof(b));
@@ -704,6 +783,7 @@ int32_t fpx_phase2_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, con
 
 int32_t fpx_proxy_open_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,
                            const int32_t* d_value_id, uint8_t* d_is_new) {
+  DeviceGuard _dg(ctx);
   if (!ctx || n < 0) return FPX_EINVAL;
   Batch b;
   memset(&b, 0, sizeof(b));
@@ -714,6 +794,7 @@ int32_t fpx_proxy_open_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const
 int32_t fpx_proxy_phase2b_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,
                               const uint64_t* d_vote_bits, uint8_t* d_newly_chosen, int32_t* d_chosen_round,
                               int32_t* d_chosen_value) {
+  DeviceGuard _dg(ctx);
   if (!ctx || n < 0) return FPX_EINVAL;
   Batch b;
   memset(&b, 0, sizeof(b));
@@ -726,6 +807,7 @@ int32_t fpx_proxy_phase2b_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, co
 int32_t fpx_acceptor_phase2a(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round,
                              const int32_t* value_id, const uint64_t* target_mask, uint64_t* vote_bits,
                              uint64_t* nack_bits, int32_t* nack_round) {
+  DeviceGuard _dg(ctx);
   int rc = check_args(ctx, n, slot, round);
   if (rc) return rc;
   if (n == 0) return FPX_OK;
@@ -764,6 +846,7 @@ int32_t fpx_acceptor_phase2a(fpx_ctx* ctx, int32_t n, const int32_t* slot, const
 int32_t fpx_phase2_fused(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round, const int32_t* value_id,
                          const uint64_t* target_mask, uint8_t* chosen, int32_t* chosen_round, int32_t* chosen_value,
                          int32_t* nack_round) {
+  DeviceGuard _dg(ctx);
   int rc = check_args(ctx, n, slot, round);
   if (rc) return rc;
   if (n == 0) return FPX_OK;
@@ -823,6 +906,7 @@ int32_t fpx_phase2_fused(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int
 
 int32_t fpx_proxy_open(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round, const int32_t* value_id,
                        uint8_t* is_new) {
+  DeviceGuard _dg(ctx);
   int rc = check_args(ctx, n, slot, round);
   if (rc) return rc;
   if (n == 0) return FPX_OK;
@@ -847,6 +931,7 @@ int32_t fpx_proxy_open(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32
 
 int32_t fpx_proxy_phase2b(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round, const uint64_t* vote_bits,
                           uint8_t* newly_chosen, int32_t* chosen_round, int32_t* chosen_value) {
+  DeviceGuard _dg(ctx);
   int rc = check_args(ctx, n, slot, round);
   if (rc) return rc;
   if (n == 0) return FPX_OK;
@@ -876,6 +961,7 @@ int32_t fpx_proxy_phase2b(fpx_ctx* ctx, int32_t n, const int32_t* slot, const in
 
 int32_t fpx_acceptor_phase1a(fpx_ctx* ctx, int32_t group, int32_t round, int32_t chosen_watermark,
                              const uint64_t* target_mask, uint64_t* promised_bits, uint64_t* nack_bits) {
+  DeviceGuard _dg(ctx);
   if (!ctx || group < 0 || group >= ctx->g.ngroups || round < 0) return FPX_EINVAL;
   int rc;
   if ((rc = grow(ctx, &ctx->d_scratch, 128))) return rc;
@@ -906,6 +992,7 @@ int32_t fpx_acceptor_phase1a(fpx_ctx* ctx, int32_t group, int32_t round, int32_t
 }
 
 int32_t fpx_proxy_forget(fpx_ctx* ctx, int32_t first_slot, int32_t count) {
+  DeviceGuard _dg(ctx);
   if (!ctx || first_slot < 0 || count < 0 || (int64_t)first_slot + count > ctx->g.S) return FPX_EINVAL;
   if (count == 0) return FPX_OK;
   // an empty key word is all a tally entry needs to be free again (values / bitmaps are rewritten on open)
@@ -926,6 +1013,7 @@ static int32_t range_args_ok(fpx_ctx* ctx, int32_t start, int32_t end, int32_t r
 int32_t fpx_acceptor_phase2a_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end, int32_t round,
                                         const uint64_t* target_masks, uint64_t* vote_bits, uint64_t* nack_bits,
                                         int32_t* nack_round) {
+  DeviceGuard _dg(ctx);
   int rc = range_args_ok(ctx, slot_start, slot_end, round);
   if (rc) return rc;
   const int A = ctx->g.num_groups;
@@ -957,6 +1045,7 @@ int32_t fpx_acceptor_phase2a_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_
 }
 
 int32_t fpx_proxy_open_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end, int32_t round, uint8_t* is_new) {
+  DeviceGuard _dg(ctx);
   int rc = range_args_ok(ctx, slot_start, slot_end, round);
   if (rc) return rc;
   if ((rc = grow(ctx, &ctx->d_u8, 16))) return rc;
@@ -972,6 +1061,7 @@ int32_t fpx_proxy_open_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot
 
 int32_t fpx_proxy_phase2b_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end, int32_t round,
                                      const uint64_t* vote_bits, uint8_t* newly_chosen) {
+  DeviceGuard _dg(ctx);
   int rc = range_args_ok(ctx, slot_start, slot_end, round);
   if (rc) return rc;
   if (!vote_bits) return FPX_EINVAL;
@@ -991,6 +1081,7 @@ int32_t fpx_proxy_phase2b_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t s
 // ---- f1: replica log ------------------------------------------------------------------------------------
 int32_t fpx_replica_chosen_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_value_id,
                                const uint8_t* d_mask) {
+  DeviceGuard _dg(ctx);
   if (!ctx || n < 0) return FPX_EINVAL;
   if (n == 0) return FPX_OK;
   Batch b;
@@ -1007,6 +1098,7 @@ int32_t fpx_replica_chosen_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, c
 }
 
 int32_t fpx_replica_state(fpx_ctx* ctx, int32_t* executed_watermark, int32_t* num_chosen) {
+  DeviceGuard _dg(ctx);
   if (!ctx) return FPX_EINVAL;
   int32_t h[2] = {0, 0};
   HIPCHK(ctx, hipMemcpyAsync(h, ctx->st.log_scalars, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -1018,6 +1110,7 @@ int32_t fpx_replica_state(fpx_ctx* ctx, int32_t* executed_watermark, int32_t* nu
 
 int32_t fpx_replica_chosen(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* value_id, const uint8_t* mask,
                            int32_t* executed_watermark, int32_t* num_chosen) {
+  DeviceGuard _dg(ctx);
   if (!ctx || n < 0 || (n > 0 && (!slot || !value_id))) return FPX_EINVAL;
   for (int i = 0; i < n; ++i) {
     if ((!mask || mask[i]) && (slot[i] < 0 || slot[i] >= ctx->g.S)) {
@@ -1051,6 +1144,7 @@ int32_t fpx_replica_chosen(fpx_ctx* ctx, int32_t n, const int32_t* slot, const i
 
 int32_t fpx_replica_chosen_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end, int32_t* executed_watermark,
                                       int32_t* num_chosen) {
+  DeviceGuard _dg(ctx);
   if (!ctx || slot_start < 0 || slot_end > ctx->g.S) return FPX_EINVAL;
   const int stride = ctx->cfg.num_leader_groups;
   const int count = slot_start < slot_end ? (slot_end - slot_start + stride - 1) / stride : 0;
@@ -1078,6 +1172,7 @@ int32_t fpx_replica_chosen_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t 
 }
 
 int32_t fpx_replica_read_log(fpx_ctx* ctx, int32_t first, int32_t count, int32_t* values, uint8_t* present) {
+  DeviceGuard _dg(ctx);
   if (!ctx || first < 0 || count < 0 || (int64_t)first + count > ctx->g.S) return FPX_EINVAL;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (values && count) HIPCHK(ctx, hipMemcpy(values, ctx->st.log_value + first, (size_t)count * 4, hipMemcpyDeviceToHost));
@@ -1088,6 +1183,7 @@ int32_t fpx_replica_read_log(fpx_ctx* ctx, int32_t first, int32_t count, int32_t
 // ---- f2: Phase-1 recovery scan ------------------------------------------------------------------------
 int32_t fpx_leader_phase1b_scan(fpx_ctx* ctx, int32_t chosen_watermark, const uint64_t* quorum_masks, int32_t cap,
                                 int32_t* max_slot, int32_t* safe_round, int32_t* safe_value) {
+  DeviceGuard _dg(ctx);
   if (!ctx || !quorum_masks || chosen_watermark < 0 || cap < 0) return FPX_EINVAL;
   const int ng = ctx->g.ngroups;
   int rc;
@@ -1129,6 +1225,7 @@ int32_t fpx_leader_phase1b_scan(fpx_ctx* ctx, int32_t chosen_watermark, const ui
 
 // ---- readback ----------------------------------------------------------------------------------------
 int32_t fpx_read_state(fpx_ctx* ctx, int32_t* vote_round, int32_t* vote_value, int32_t* ballot) {
+  DeviceGuard _dg(ctx);
   if (!ctx) return FPX_EINVAL;
   const size_t S = (size_t)ctx->g.S, R = (size_t)ctx->g.R, RS = (size_t)ctx->g.RS;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1147,6 +1244,7 @@ int32_t fpx_read_state(fpx_ctx* ctx, int32_t* vote_round, int32_t* vote_value, i
 }
 
 int32_t fpx_read_scalars(fpx_ctx* ctx, int32_t* promised, int32_t* max_voted_slot) {
+  DeviceGuard _dg(ctx);
   if (!ctx) return FPX_EINVAL;
   const size_t nsc = (size_t)ctx->g.ngroups * ctx->g.R;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1157,6 +1255,7 @@ int32_t fpx_read_scalars(fpx_ctx* ctx, int32_t* promised, int32_t* max_voted_slo
 
 int32_t fpx_read_acceptor(fpx_ctx* ctx, int32_t group, int32_t replica, int32_t* promised, int32_t* max_voted_slot,
                           int32_t* vote_round, int32_t* vote_value, int32_t* ballot) {
+  DeviceGuard _dg(ctx);
   if (!ctx || group < 0 || group >= ctx->g.ngroups || replica < 0 || replica >= ctx->g.R) return FPX_EINVAL;
   const size_t e = (size_t)group * ctx->g.R + replica;
   const size_t S = (size_t)ctx->g.S;
@@ -1181,8 +1280,208 @@ int32_t fpx_read_acceptor(fpx_ctx* ctx, int32_t group, int32_t replica, int32_t*
   return FPX_OK;
 }
 
+// ---- multi-GPU: RCCL behind the C ABI ------------------------------------------------------------------
+static RcclApi* rccl() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return api.lib ? &api : nullptr;
+  tried = true;
+  void* h = nullptr;
+  const char* env = getenv("FPX_RCCL_LIB");
+  if (env && *env) h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+  // an RCCL that is already mapped (PyTorch's bundled copy) wins over loading a second one
+  const char* loaded[] = {"librccl.so", "librccl.so.1"};
+  for (size_t i = 0; !h && i < 2; ++i) h = dlopen(loaded[i], RTLD_NOW | RTLD_NOLOAD);
+  const char* fresh[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (size_t i = 0; !h && i < 3; ++i) h = dlopen(fresh[i], RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return nullptr;
+  auto sym = [&](const char* name) { return dlsym(h, name); };
+  api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+  api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+  api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+  api.ReduceScatter = reinterpret_cast<decltype(api.ReduceScatter)>(sym("ncclReduceScatter"));
+  api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+  api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+  api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.ReduceScatter || !api.AllGather) return nullptr;
+  api.lib = h;
+  return &api;
+}
+
+#define RCCLCHK(ctx, expr)                 \
+  do {                                     \
+    int _r = (expr);                       \
+    if (_r != 0) {                         \
+      if (ctx) (ctx)->last_rccl = _r;      \
+      return FPX_ERCCL;                    \
+    }                                      \
+  } while (0)
+
+int32_t fpx_comm_unique_id(uint8_t id[FPX_COMM_ID_BYTES]) {
+  if (!id) return FPX_EINVAL;
+  RcclApi* r = rccl();
+  if (!r) return FPX_ERCCL;
+  RcclUniqueId u;
+  if (r->GetUniqueId(&u) != 0) return FPX_ERCCL;
+  memcpy(id, u.internal, FPX_COMM_ID_BYTES);
+  return FPX_OK;
+}
+
+int32_t fpx_comm_create(fpx_ctx* ctx, const uint8_t id[FPX_COMM_ID_BYTES], int32_t rank, int32_t world) {
+  DeviceGuard _dg(ctx);
+  if (!ctx || !id || world < 1 || rank < 0 || rank >= world || ctx->comm) return FPX_EINVAL;
+  RcclApi* r = rccl();
+  if (!r) return FPX_ERCCL;
+  RcclUniqueId u;
+  memcpy(u.internal, id, FPX_COMM_ID_BYTES);
+  RcclComm c = nullptr;
+  RCCLCHK(ctx, r->CommInitRank(&c, world, u, rank));  // binds to the current device = the context's
+  ctx->comm = c;
+  ctx->comm_rank = rank;
+  ctx->comm_world = world;
+  return FPX_OK;
+}
+
+int32_t fpx_comm_destroy(fpx_ctx* ctx) {
+  DeviceGuard _dg(ctx);
+  if (!ctx) return FPX_EINVAL;
+  if (!ctx->comm) return FPX_OK;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  RcclApi* r = rccl();
+  if (r) RCCLCHK(ctx, r->CommDestroy(ctx->comm));
+  ctx->comm = nullptr;
+  ctx->comm_rank = 0, ctx->comm_world = 1;
+  return FPX_OK;
+}
+
+int32_t fpx_comm_info(fpx_ctx* ctx, int32_t* rank, int32_t* world) {
+  if (!ctx) return FPX_EINVAL;
+  if (rank) *rank = ctx->comm_rank;
+  if (world) *world = ctx->comm_world;
+  return FPX_OK;
+}
+
+int32_t fpx_last_rccl_error(fpx_ctx* ctx) { return ctx ? ctx->last_rccl : 0; }
+
+int32_t fpx_profile_read_collective(fpx_ctx* ctx, int32_t* launches, double* total_ms) {
+  DeviceGuard _dg(ctx);
+  if (!ctx) return FPX_EINVAL;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  double sum = 0;
+  for (size_t i = 0; i + 1 < ctx->cev_used; i += 2) {
+    float ms = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->cev[i], ctx->cev[i + 1]));
+    sum += ms;
+  }
+  if (launches) *launches = (int32_t)(ctx->cev_used / 2);
+  if (total_ms) *total_ms = sum;
+  ctx->cev_used = 0;
+  return FPX_OK;
+}
+
+int32_t fpx_phase2_replica_sharded_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,
+                                       const int32_t* d_value_id, const uint64_t* d_target_mask, uint8_t* d_chosen,
+                                       int32_t* d_chosen_round, int32_t* d_chosen_value, int32_t* d_nack_round) {
+  DeviceGuard _dg(ctx);
+  if (!ctx || n < 0) return FPX_EINVAL;
+  const int world = ctx->comm_world, rank = ctx->comm_rank;
+  if (n % world) return FPX_EINVAL;
+  if (n == 0) return FPX_OK;
+  const int per = n / world, lo = rank * per;
+  int rc;
+  if ((rc = grow(ctx, &ctx->d_part, (size_t)n * 32))) return rc;
+  if (world > 1 && (rc = grow(ctx, &ctx->d_mine, (size_t)per * 32))) return rc;
+  uint64_t* part = (uint64_t*)ctx->d_part.p;
+  // K1: my acceptor columns vote on every slot of the batch; partial bitmaps (bits in my range only) to HBM
+  Batch b;
+  memset(&b, 0, sizeof(b));
+  b.n = n, b.slot = d_slot, b.round = d_round, b.value = d_value_id, b.target = d_target_mask;
+  b.vote_bits = part, b.nack_round = d_nack_round;
+  if ((rc = enqueue_phase2(ctx, b, false))) return rc;
+  const uint64_t* mine = part + (size_t)lo * 4;
+  if (world > 1) {
+    // the exchange step: sum (== OR) of the partial bitmaps, scattered so that I receive my slots' rows
+    RcclApi* r = rccl();
+    if (!r || !ctx->comm) return FPX_ERCCL;
+    const bool prof = ctx->profiling && ctx->cev_used + 2 <= ctx->cev.size();
+    if (prof) HIPCHK(ctx, hipEventRecord(ctx->cev[ctx->cev_used], ctx->stream));
+    RCCLCHK(ctx, r->ReduceScatter(part, ctx->d_mine.p, (size_t)per * 4, RCCL_UINT64, RCCL_SUM, ctx->comm, ctx->stream));
+    if (prof) {
+      HIPCHK(ctx, hipEventRecord(ctx->cev[ctx->cev_used + 1], ctx->stream));
+      ctx->cev_used += 2;
+    }
+    mine = (const uint64_t*)ctx->d_mine.p;
+  }
+  // ProxyLeader.handlePhase2a bookkeeping + handlePhase2b for my slice of the slots; K1's validation pass
+  // covered the whole batch (slots distinct), so the slice needs none
+  HostRun trusted(ctx);
+  Batch o;
+  memset(&o, 0, sizeof(o));
+  o.n = per, o.slot = d_slot + lo, o.round = d_round + lo, o.value = d_value_id + lo;
+  if ((rc = enqueue_open(ctx, o))) return rc;
+  Batch t;
+  memset(&t, 0, sizeof(t));
+  t.n = per, t.slot = d_slot + lo, t.round = d_round + lo, t.vote_bits = const_cast<uint64_t*>(mine);
+  t.chosen = d_chosen, t.chosen_round = d_chosen_round, t.chosen_value = d_chosen_value;
+  return enqueue_tally(ctx, t);
+}
+
+int32_t fpx_comm_allgather_chosen_dev(fpx_ctx* ctx, int32_t n_local, const uint8_t* d_chosen,
+                                      const int32_t* d_chosen_round, const int32_t* d_chosen_value,
+                                      uint8_t* d_all_chosen, int32_t* d_all_round, int32_t* d_all_value) {
+  DeviceGuard _dg(ctx);
+  if (!ctx || n_local < 0) return FPX_EINVAL;
+  if (n_local == 0) return FPX_OK;
+  if (ctx->comm_world == 1) {  // degenerate: a device copy
+    if (d_chosen && d_all_chosen) HIPCHK(ctx, hipMemcpyAsync(d_all_chosen, d_chosen, (size_t)n_local, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_chosen_round && d_all_round) HIPCHK(ctx, hipMemcpyAsync(d_all_round, d_chosen_round, (size_t)n_local * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_chosen_value && d_all_value) HIPCHK(ctx, hipMemcpyAsync(d_all_value, d_chosen_value, (size_t)n_local * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    return FPX_OK;
+  }
+  RcclApi* r = rccl();
+  if (!r || !ctx->comm) return FPX_ERCCL;
+  const bool prof = ctx->profiling && ctx->cev_used + 2 <= ctx->cev.size();
+  if (prof) HIPCHK(ctx, hipEventRecord(ctx->cev[ctx->cev_used], ctx->stream));
+  if (d_chosen && d_all_chosen) RCCLCHK(ctx, r->AllGather(d_chosen, d_all_chosen, (size_t)n_local, RCCL_UINT8, ctx->comm, ctx->stream));
+  if (d_chosen_round && d_all_round) RCCLCHK(ctx, r->AllGather(d_chosen_round, d_all_round, (size_t)n_local, RCCL_INT32, ctx->comm, ctx->stream));
+  if (d_chosen_value && d_all_value) RCCLCHK(ctx, r->AllGather(d_chosen_value, d_all_value, (size_t)n_local, RCCL_INT32, ctx->comm, ctx->stream));
+  if (prof) {
+    HIPCHK(ctx, hipEventRecord(ctx->cev[ctx->cev_used + 1], ctx->stream));
+    ctx->cev_used += 2;
+  }
+  return FPX_OK;
+}
+
+int32_t fpx_state_digest(fpx_ctx* ctx, uint64_t out[8]) {
+  DeviceGuard _dg(ctx);
+  if (!ctx || !out) return FPX_EINVAL;
+  int rc;
+  if ((rc = grow(ctx, &ctx->d_scratch, 128))) return rc;
+  uint64_t* d = (uint64_t*)ctx->d_scratch.p;
+  HIPCHK(ctx, hipMemsetAsync(d, 0, 64, ctx->stream));
+  const Geom& g = ctx->g;
+  const int big = ctx->num_cus * 16;
+  const size_t n4 = (size_t)g.S * (size_t)(g.RS / 4);
+  const int gc = (int)std::max<size_t>(1, std::min<size_t>((n4 + 255) / 256, (size_t)big));
+  hipLaunchKernelGGL(k_digest_cells, dim3(gc), dim3(256), 0, ctx->stream, g, ctx->st.vote_round, d + 0);
+  hipLaunchKernelGGL(k_digest_cells, dim3(gc), dim3(256), 0, ctx->stream, g, ctx->st.vote_value, d + 1);
+  if (ctx->st.ballot) hipLaunchKernelGGL(k_digest_cells, dim3(gc), dim3(256), 0, ctx->stream, g, ctx->st.ballot, d + 2);
+  const int nsc = g.ngroups * g.R;
+  const int gs = std::max(1, std::min((nsc + 255) / 256, big));
+  hipLaunchKernelGGL(k_digest_1d, dim3(gs), dim3(256), 0, ctx->stream, ctx->st.promised, nsc, d + 3);
+  hipLaunchKernelGGL(k_digest_1d, dim3(gs), dim3(256), 0, ctx->stream, ctx->st.max_voted, nsc, d + 4);
+  const int gt = std::max(1, std::min((g.S + 255) / 256, big));
+  hipLaunchKernelGGL(k_digest_tally, dim3(gt), dim3(256), 0, ctx->stream, g, ctx->st, d + 5);
+  hipLaunchKernelGGL(k_digest_log, dim3(gt), dim3(256), 0, ctx->stream, g, ctx->st, d + 6);
+  if ((rc = launch_check(ctx))) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(out, d, 64, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FPX_OK;
+}
+
 int32_t fpx_read_tally(fpx_ctx* ctx, int32_t slot, int32_t* num_entries, int32_t* rounds, int32_t* states,
                        int32_t* values, uint64_t* vote_bits) {
+  DeviceGuard _dg(ctx);
   if (!ctx || slot < 0 || slot >= ctx->g.S) return FPX_EINVAL;
   const int wp = ctx->g.wp;
   uint32_t keys[8];

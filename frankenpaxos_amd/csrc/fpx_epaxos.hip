@@ -421,6 +421,19 @@ struct fpx_epx {
 
 namespace {
 
+// the context's device is current inside every entry point, the caller's is restored on return (see fpx_api.hip)
+struct EpxDeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit EpxDeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) switched = hipSetDevice(device) == hipSuccess;
+  }
+  ~EpxDeviceGuard() {
+    if (switched && prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
 #define EHIP(e, expr)                                            \
   do {                                                           \
     hipError_t _x = (expr);                                      \
@@ -468,6 +481,7 @@ int32_t fpx_epx_create(const fpx_epx_config* cfg, fpx_epx** out) {
     fpx_epx_destroy(e);
     return code;
   };
+  EpxDeviceGuard _dg(cfg->device);
   if (hipSetDevice(cfg->device) != hipSuccess) return fail(FPX_ENODEVICE);
   if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(FPX_EHIP);
   e->stream = e->own_stream;
@@ -486,6 +500,7 @@ int32_t fpx_epx_create(const fpx_epx_config* cfg, fpx_epx** out) {
 
 int32_t fpx_epx_destroy(fpx_epx* e) {
   if (!e) return FPX_EINVAL;
+  EpxDeviceGuard _dg(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   void* ps[] = {e->st.gets, e->st.sets, e->st.status};
   for (void* p : ps)
@@ -501,6 +516,7 @@ int32_t fpx_epx_destroy(fpx_epx* e) {
 
 int32_t fpx_epx_set_stream(fpx_epx* e, void* hip_stream) {
   if (!e) return FPX_EINVAL;
+  EpxDeviceGuard _dg(e->cfg.device);
   EHIP(e, hipStreamSynchronize(e->stream));
   e->stream = hip_stream == FPX_STREAM_OWN ? e->own_stream : (hipStream_t)hip_stream;
   return FPX_OK;
@@ -508,6 +524,7 @@ int32_t fpx_epx_set_stream(fpx_epx* e, void* hip_stream) {
 
 int32_t fpx_epx_sync(fpx_epx* e) {
   if (!e) return FPX_EINVAL;
+  EpxDeviceGuard _dg(e->cfg.device);
   int32_t h[2] = {0, 0};
   EHIP(e, hipMemcpyAsync(h, e->st.status, sizeof(h), hipMemcpyDeviceToHost, e->stream));
   EHIP(e, hipStreamSynchronize(e->stream));
@@ -523,6 +540,7 @@ int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, co
                               const uint8_t* d_seen_mask, const int32_t* d_rank, uint8_t* d_fast, int32_t* d_deps,
                               int32_t* d_leader_deps, int32_t* d_own_values_end) {
   if (!e || m < 0) return FPX_EINVAL;
+  EpxDeviceGuard _dg(e->cfg.device);
   if (m == 0) return FPX_OK;
   const int n = e->st.n;
   int rc;
@@ -583,6 +601,7 @@ int32_t fpx_epx_preaccept(fpx_epx* e, int32_t m, const int32_t* leader, const in
                           const int32_t* rank, uint8_t* fast, int32_t* deps, int32_t* leader_deps,
                           int32_t* own_values_end) {
   if (!e || m < 0 || (m > 0 && (!leader || !number || !key || !is_set || !resp_mask || !rank))) return FPX_EINVAL;
+  EpxDeviceGuard _dg(e->cfg.device);
   if (m == 0) return FPX_OK;
   const int n = e->st.n;
   int rc;
@@ -617,6 +636,7 @@ int32_t fpx_epx_preaccept(fpx_epx* e, int32_t m, const int32_t* leader, const in
 
 int32_t fpx_epx_read_index(fpx_epx* e, int32_t replica, int32_t key, int32_t* gets, int32_t* sets) {
   if (!e || replica < 0 || replica >= e->st.n || key < 0 || key >= e->st.num_keys) return FPX_EINVAL;
+  EpxDeviceGuard _dg(e->cfg.device);
   const size_t off = ((size_t)replica * e->st.num_keys + key) * e->st.n;
   EHIP(e, hipStreamSynchronize(e->stream));
   if (gets) EHIP(e, hipMemcpy(gets, e->st.gets + off, (size_t)e->st.n * 4, hipMemcpyDeviceToHost));

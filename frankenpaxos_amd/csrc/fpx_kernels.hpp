@@ -61,7 +61,10 @@ constexpr int RANGE_TALLIES = 1024;  // live Mencius noop-range tallies per cont
 constexpr int PART_ALL_STRIDE = 32;  // ints: one 128-byte line per shard of the whole-group maxima
 
 // status word layout in HBM (int32[8])
-enum { ST_CODE = 0, ST_INDEX = 1, ST_SLOT = 2, ST_ROUND = 3 };
+// ST_ABORT: set by k_validate only (FPX_EINVAL / FPX_EORDER on a _dev batch): every later kernel up to the next
+// fpx_sync applies nothing.  Errors raised while a batch is being applied (FPX_ECAPACITY,
+// FPX_EFATAL_UNKNOWN_SLOTROUND) concern single messages: they set the code and everything else goes on.
+enum { ST_CODE = 0, ST_INDEX = 1, ST_SLOT = 2, ST_ROUND = 3, ST_ABORT = 4 };
 
 struct Geom {
   int32_t S, R;
@@ -144,6 +147,11 @@ __device__ __forceinline__ void row_store(int4v v, int4v* p) {
 #else
   *p = v;
 #endif
+}
+
+__device__ __forceinline__ void report_abort(const State& st, int code, int index, int slot, int round) {
+  st.status[ST_ABORT] = 1;
+  report(st, code, index, slot, round);
 }
 
 __device__ __forceinline__ int popc256(const uint64_t x[4]) {
@@ -289,12 +297,12 @@ __global__ void __launch_bounds__(256) k_validate(const Geom g, const State st, 
   if (i >= b.n) return;
   const int s = b.slot[i], r = b.round ? b.round[i] : 0;
   if (s < 0 || s >= g.S || r < 0 || r > MAX_ROUND) {
-    report(st, 1 /*FPX_EINVAL*/, i, s, r);
+    report_abort(st, 1 /*FPX_EINVAL*/, i, s, r);
     return;
   }
   // (1) slots pairwise distinct within the run
   const uint32_t old = atomicExch(&st.stamp[s], b.run_id);
-  if (old == b.run_id) report(st, 6 /*FPX_EORDER*/, i, s, r);
+  if (old == b.run_id) report_abort(st, 6 /*FPX_EORDER*/, i, s, r);
   // (2) one round per acceptor group within the run
   if (b.check_round) {
     int* rr = &st.run_round[group_of_slot(g, s)];
@@ -303,7 +311,7 @@ __global__ void __launch_bounds__(256) k_validate(const Geom g, const State st, 
       cur = atomicCAS(rr, -1, r);
       if (cur == -1) cur = r;
     }
-    if (cur != r) report(st, 6, i, s, r);
+    if (cur != r) report_abort(st, 6, i, s, r);
   }
 }
 
@@ -342,7 +350,7 @@ __global__ void __launch_bounds__(256)
   constexpr int Q = 64 / G;           // slots per step
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  if (st.status[ST_CODE] != 0) return;  // a failed validation applies nothing
+  if (st.status[ST_ABORT] != 0) return;  // a failed validation applies nothing
 
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
@@ -678,7 +686,7 @@ __global__ void __launch_bounds__(256) k_finalize(const Geom g, const State st, 
     if (threadIdx.x < 128)
       st.part_all[((size_t)(par ^ 1) * 64 + (threadIdx.x >> 1)) * PART_ALL_STRIDE + (threadIdx.x & 1)] = -1;
   }
-  if (st.status[ST_CODE] != 0) return;
+  if (st.status[ST_ABORT] != 0) return;
   const int ntab = g.ngroups * g.R;
   const int nblocks = st.part_cnt[par] < g.part_rows ? st.part_cnt[par] : g.part_rows;
   const int e = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -718,7 +726,7 @@ __global__ void __launch_bounds__(256) k_finalize(const Geom g, const State st, 
 // k_open: ProxyLeader.handlePhase2a bookkeeping (ProxyLeader.scala:175-184, 213). Thread / message.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_open(const Geom g, const State st, const Batch b) {
-  if (st.status[ST_CODE] != 0) return;
+  if (st.status[ST_ABORT] != 0) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b.n) return;
   const int s = b.slot[i], rnd = b.round[i];
@@ -752,7 +760,7 @@ __global__ void __launch_bounds__(256) k_open(const Geom g, const State st, cons
 // of a run are distinct so a tally entry has exactly one writer.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_tally(const Geom g, const State st, const Batch b) {
-  if (st.status[ST_CODE] != 0) return;
+  if (st.status[ST_ABORT] != 0) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b.n) return;
   const int s = b.slot[i], rnd = b.round[i];
@@ -1037,7 +1045,7 @@ __device__ __forceinline__ void wave_atomic_min(int32_t* target, int v) {
 enum { LG_WATERMARK = 0, LG_NUM_CHOSEN = 1, LG_LARGEST = 2, LG_FIRST_MISSING = 3, LG_RANGE_FIRST = 4 };
 
 __global__ void __launch_bounds__(256) k_log_ingest(const Geom g, const State st, const Batch b) {
-  if (st.status[ST_CODE] != 0) return;
+  if (st.status[ST_ABORT] != 0) return;
   // grid-stride, counts and the largest key accumulated per thread, then per workgroup: the two scalars see
   // one atomic pair per workgroup (a pair per wavefront serialised 2^15 same-address atomics per 2^20 records)
   __shared__ int w_cnt[4], w_top[4];
@@ -1079,13 +1087,13 @@ __global__ void __launch_bounds__(256) k_log_ingest(const Geom g, const State st
 // scan range = [executedWatermark, min(S, largestKey + 1)): the slot after largestKey is absent by
 // definition, so LG_FIRST_MISSING starts at the end of the range and only ever decreases
 __global__ void k_log_prep(const Geom g, const State st) {
-  if (st.status[ST_CODE] != 0) return;
+  if (st.status[ST_ABORT] != 0) return;
   const int hi = st.log_scalars[LG_LARGEST] + 1;
   st.log_scalars[LG_FIRST_MISSING] = hi < g.S ? hi : g.S;
 }
 
 __global__ void __launch_bounds__(256) k_log_scan(const Geom g, const State st) {
-  if (st.status[ST_CODE] != 0) return;
+  if (st.status[ST_ABORT] != 0) return;
   const int lo = st.log_scalars[LG_WATERMARK];
   const int hi0 = st.log_scalars[LG_LARGEST] + 1;
   const int hi = hi0 < g.S ? hi0 : g.S;
@@ -1103,7 +1111,7 @@ __global__ void __launch_bounds__(256) k_log_scan(const Geom g, const State st) 
 }
 
 __global__ void k_log_commit(const State st) {
-  if (st.status[ST_CODE] != 0) return;
+  if (st.status[ST_ABORT] != 0) return;
   const int fm = st.log_scalars[LG_FIRST_MISSING];
   if (fm > st.log_scalars[LG_WATERMARK]) st.log_scalars[LG_WATERMARK] = fm;
 }
@@ -1114,7 +1122,7 @@ __global__ void k_log_commit(const State st) {
 // start + k * stride.  k_log_range_first: the smallest position already present (LG_RANGE_FIRST starts
 // at count); k_log_range_fill: put Noop at the positions before it.
 __global__ void __launch_bounds__(256) k_log_range_first(const State st, int start, int stride, int count) {
-  if (st.status[ST_CODE] != 0) return;
+  if (st.status[ST_ABORT] != 0) return;
   const int step = gridDim.x * blockDim.x;
   int mine = 0x7fffffff;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += step) {
@@ -1128,7 +1136,7 @@ __global__ void __launch_bounds__(256) k_log_range_first(const State st, int sta
 }
 
 __global__ void __launch_bounds__(256) k_log_range_fill(const State st, int start, int stride) {
-  if (st.status[ST_CODE] != 0) return;
+  if (st.status[ST_ABORT] != 0) return;
   const int first = st.log_scalars[LG_RANGE_FIRST];
   const int step = gridDim.x * blockDim.x;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < first; k += step) {
@@ -1205,6 +1213,88 @@ __global__ void __launch_bounds__(256)
       safe_value[idx] = best_round >= 0 ? best_val : -1;  // Noop when nobody voted (Leader.scala:323-325)
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// State digests (parity at full size): order-independent 64-bit sums of per-element hashes, so that
+// the whole acceptor / proxy-leader / replica state of a 2^20 x 256 context can be compared with another
+// implementation's (the formula is part of the ABI, include/fpx.h) without moving 3 GiB through PCIe.
+// Reads every cell once: HBM-bound.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finalizer
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ uint64_t digest_term(uint64_t idx, int32_t v) {
+  return mix64(idx * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)v + 1ull);
+}
+
+__device__ __forceinline__ void block_add_u64(uint64_t v, uint64_t* out) {
+  __shared__ uint64_t part[4];
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) v += shfl_xor64(v, k);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint64_t t = part[0] + part[1] + part[2] + part[3];
+    if (t) atomicAdd(reinterpret_cast<unsigned long long*>(out), (unsigned long long)t);
+  }
+}
+
+// a cell array [S][RS]: element (s, r), r < R, contributes digest_term(s * R + r, a[s][r])
+__global__ void __launch_bounds__(256) k_digest_cells(const Geom g, const int32_t* a, uint64_t* out) {
+  const size_t q = (size_t)(g.RS >> 2);  // int4's per row
+  const size_t n4 = (size_t)g.S * q;
+  uint64_t acc = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t s = i / q;
+    const int r0 = (int)(i - s * q) * 4;
+    const int4v v = *reinterpret_cast<const int4v*>(a + i * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (r0 + k < g.R) acc += digest_term(s * (size_t)g.R + (size_t)(r0 + k), v[k]);
+  }
+  block_add_u64(acc, out);
+}
+
+__global__ void __launch_bounds__(256) k_digest_1d(const int32_t* a, int n, uint64_t* out) {
+  uint64_t acc = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc += digest_term((uint64_t)i, a[i]);
+  block_add_u64(acc, out);
+}
+
+// ProxyLeader.states: every single-slot tally (slot, round) -> Done | Pending(value, votes); key order free
+__global__ void __launch_bounds__(256) k_digest_tally(const Geom g, const State st, uint64_t* out) {
+  uint64_t acc = 0;
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < g.S; s += gridDim.x * blockDim.x) {
+    for (int w = 0; w < g.ways; ++w) {
+      const size_t e = (size_t)s * g.wp + w;
+      const uint32_t k = st.pl_key[e];
+      if (k == 0 || (k & KEY_RANGE)) continue;
+      const uint32_t round = (k & KEY_ROUND_MASK) - 1u;
+      const uint64_t done = (k & KEY_DONE) ? 1ull : 0ull;
+      uint64_t t = mix64((((uint64_t)(uint32_t)s << 32) | round) * 0x9E3779B97F4A7C15ull + done);
+      if (!done) {  // a Done entry has dropped its payload (ProxyLeader.scala:256)
+        t = mix64(t ^ (uint64_t)(uint32_t)st.pl_value[e]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t = mix64(t ^ st.pl_bits[e * 4 + j]);
+      }
+      acc += t;
+    }
+  }
+  block_add_u64(acc, out);
+}
+
+// the replica's log: present entries (slot, value) + executedWatermark + numChosen
+__global__ void __launch_bounds__(256) k_digest_log(const Geom g, const State st, uint64_t* out) {
+  uint64_t acc = 0;
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < g.S; s += gridDim.x * blockDim.x)
+    if (st.log_present[s]) acc += digest_term((uint64_t)s, st.log_value[s]);
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    acc += mix64((uint64_t)(uint32_t)st.log_scalars[0] * 0x9E3779B97F4A7C15ull + 7ull) +
+           mix64((uint64_t)(uint32_t)st.log_scalars[1] * 0x9E3779B97F4A7C15ull + 11ull);
+  block_add_u64(acc, out);
 }
 
 }  // namespace fpx

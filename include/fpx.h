@@ -59,7 +59,19 @@ extern "C" {
 #define FPX_MASK_WORDS 4
 #define FPX_NOOP (-1)
 
-/* status codes */
+/* status codes.  What a non-OK status says about the state:
+ *   FPX_EINVAL / FPX_EORDER   raised by the validation pass BEFORE anything of the batch is applied: the
+ *                             batch -- and every later _dev call up to the next fpx_sync -- applied nothing.
+ *   FPX_ECAPACITY             per message: that message's tally could not be opened, so it was neither
+ *                             recorded nor forwarded to the acceptors (as if the proxy leader had never
+ *                             received it); every other message of the batch was applied in full, acceptor
+ *                             rounds and maxVotedSlot included.  The reference has no such limit
+ *                             (ProxyLeader.states grows forever): free ways with fpx_proxy_forget or raise
+ *                             tally_ways and resend the message.
+ *   FPX_EFATAL_UNKNOWN_SLOTROUND  per message (the reference process would have died in logger.fatal): that
+ *                             Phase2b was dropped, the others were applied.
+ *   FPX_EHIP / FPX_ENOMEM     the HIP runtime failed; the context should be destroyed.
+ * fpx_error_detail names the first offending message. */
 enum {
   FPX_OK = 0,
   FPX_EINVAL = 1,                   /* == Scala require(...) / IllegalArgumentException            */
@@ -68,7 +80,8 @@ enum {
   FPX_ENODEVICE = 4,                /* no gfx950 device / HIP runtime: there is NO CPU fallback      */
   FPX_ECAPACITY = 5,                /* more than tally_ways live (slot, round) tallies for one slot  */
   FPX_EORDER = 6,                   /* a _dev batch violated the run contract; nothing was applied   */
-  FPX_ENOMEM = 7
+  FPX_ENOMEM = 7,
+  FPX_ERCCL = 8                     /* an RCCL call failed / RCCL is not loadable (fpx_last_rccl_error)  */
 };
 
 typedef enum {
@@ -113,7 +126,9 @@ typedef struct {
                                 [replica_base, replica_base + num_replicas) of a group of
                                 replicas_total acceptors; multiple of 4; 0 when not sharded             */
   int32_t replicas_total;    /* 0 => num_replicas.  Quorum predicates are over replicas_total.          */
-  int32_t device;            /* HIP device ordinal                                                       */
+  int32_t device;            /* HIP device ordinal.  Every entry point makes it current for the duration
+                                of the call and restores the caller's device, so contexts on several GPUs
+                                can be driven from one thread                                              */
   uint32_t flags;            /* FPX_F_*                                                                  */
 } fpx_config;
 
@@ -377,6 +392,62 @@ int32_t fpx_read_scalars(fpx_ctx* ctx, int32_t* promised, int32_t* max_voted_slo
 /* proxy-leader tallies of one slot: up to tally_ways entries; state 0 = Pending, 1 = Done */
 int32_t fpx_read_tally(fpx_ctx* ctx, int32_t slot, int32_t* num_entries, int32_t* rounds,
                        int32_t* states, int32_t* values, uint64_t* vote_bits /* ways x 4 */);
+
+/* ---- multi-GPU: one context per GPU, one RCCL communicator over them ----------
+ *
+ * The Phase-2 path shards two ways.
+ * (1) By acceptor group -- no exchange step: slot -> group is fixed (multipaxos/ProxyLeader.scala:190,
+ *     mencius/ProxyLeader.scala:231-234) and groups never interact in Phase 2, so rank r simply owns the
+ *     groups g with g % world == r and runs the single-GPU entry points on its own slots.  Only Chosen
+ *     records leave a GPU; fpx_comm_allgather_chosen_dev hands every rank all of them when a device-side
+ *     replica log is kept on each GPU (13 B per slot per rank over xGMI).
+ * (2) By the acceptor axis of ONE big group (flexible mode: "the log is not partitioned",
+ *     multipaxos/Config.scala:16-21) -- one exchange step, replacing the fan-in of every acceptor's Phase2b
+ *     to one proxy leader (multipaxos/ProxyLeader.scala:217-258): the context of rank r is created with
+ *     replica_base = r * R / world, num_replicas = R / world, replicas_total = R;
+ *     fpx_phase2_replica_sharded_dev runs K1 on its acceptor columns for all n slots (partial 256-bit vote
+ *     bitmaps with bits only in its own range), ONE ncclReduceScatter(ncclSum, ncclUint64) of the 4 n words
+ *     (disjoint bit ranges: sum == OR and never carries) gives rank r the full bitmaps of ITS n / world
+ *     slots, and the proxy-leader open + tally (K2) runs on that slice.  xGMI traffic per GPU and call:
+ *     a ring reduce-scatter sends and receives (world - 1) / world x 32 B x n (28 MiB for n = 2^20 at
+ *     world = 8, ~0.2 ms at one 153 GB/s link); an all-reduce would move twice that and make every GPU tally
+ *     all n slots.
+ * RCCL is loaded at run time (an RCCL already in the process -- PyTorch's -- is reused; else librccl.so.1 /
+ * $FPX_RCCL_LIB): single-GPU callers never need it.  The id comes from fpx_comm_unique_id on one rank and
+ * reaches the others out of band (the JVM actors' own transport, MPI, a torch.distributed broadcast ...). */
+#define FPX_COMM_ID_BYTES 128
+int32_t fpx_comm_unique_id(uint8_t id[FPX_COMM_ID_BYTES]);
+/* collective: every rank calls it with the same id and world, its own rank; binds the communicator to ctx */
+int32_t fpx_comm_create(fpx_ctx* ctx, const uint8_t id[FPX_COMM_ID_BYTES], int32_t rank, int32_t world);
+int32_t fpx_comm_destroy(fpx_ctx* ctx);
+int32_t fpx_comm_info(fpx_ctx* ctx, int32_t* rank, int32_t* world); /* (0, 1) without a communicator */
+int32_t fpx_last_rccl_error(fpx_ctx* ctx);
+/* (2) above.  n must be a multiple of world; all ranks pass the same n messages (device pointers,
+ * asynchronous on the context's stream, run contract as for the other _dev calls).  d_target_mask: n x 4
+ * words over the WHOLE group (bit j = acceptor j of replicas_total) or NULL.  Outputs cover this rank's
+ * slice of the batch, messages [rank * n / world, (rank + 1) * n / world): d_chosen / d_chosen_round /
+ * d_chosen_value have n / world entries (as fpx_proxy_phase2b_dev); d_nack_round (n entries or NULL) is the
+ * largest round Nacked by THIS rank's acceptors.  Without a communicator (world 1) it is K1 + open + K2. */
+int32_t fpx_phase2_replica_sharded_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,
+                                       const int32_t* d_value_id, const uint64_t* d_target_mask,
+                                       uint8_t* d_chosen, int32_t* d_chosen_round, int32_t* d_chosen_value,
+                                       int32_t* d_nack_round);
+/* (1) above: all-gather of the Chosen records of n_local messages per rank; the d_all_* arrays have
+ * world x n_local entries, rank-major.  Any of the three pairs may be NULL. */
+int32_t fpx_comm_allgather_chosen_dev(fpx_ctx* ctx, int32_t n_local, const uint8_t* d_chosen,
+                                      const int32_t* d_chosen_round, const int32_t* d_chosen_value,
+                                      uint8_t* d_all_chosen, int32_t* d_all_round, int32_t* d_all_value);
+/* with fpx_profile_enable: number and summed duration of the collectives since the last read (HIP events
+ * on the context's stream around each RCCL call) */
+int32_t fpx_profile_read_collective(fpx_ctx* ctx, int32_t* launches, double* total_ms);
+
+/* Whole-state digests for parity checks at sizes where a readback is gigabytes: out[0..6] =
+ * vote_round cells, vote_value cells, ballot cells (0 in FPX_BALLOT_ACCEPTOR mode), acceptors' rounds,
+ * acceptors' maxVotedSlot, the proxy leader's single-slot tallies, the replica's log (+ executedWatermark,
+ * numChosen); out[7] = 0.  Each is an order-independent wrapping sum of a 64-bit hash per element (per cell
+ * (slot, acceptor): splitmix64-finalise((slot * R + acceptor) * 0x9E3779B97F4A7C15 + (uint32)value + 1)), so
+ * equal digests <=> equal state up to 2^-64.  Waits for the stream. */
+int32_t fpx_state_digest(fpx_ctx* ctx, uint64_t out[8]);
 
 #ifdef __cplusplus
 }

@@ -153,6 +153,8 @@ int fpo_read_acceptor(fpo_sys* sys, int32_t group, int32_t replica, int32_t* pro
                       int32_t* ballot);
 int fpo_read_state(fpo_sys* sys, int32_t* vote_round, int32_t* vote_value, int32_t* ballot);
 int fpo_read_scalars(fpo_sys* sys, int32_t* promised, int32_t* max_voted_slot);
+/* the CPU twin of fpx_state_digest (include/fpx.h) */
+int fpo_state_digest(fpo_sys* sys, uint64_t out[8]);
 int fpo_read_tally(fpo_sys* sys, int32_t slot, int32_t* num_entries, int32_t* rounds,
                    int32_t* states, int32_t* values, uint64_t* vote_bits);
 

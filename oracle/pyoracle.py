@@ -126,6 +126,7 @@ def lib():
     L.fpo_read_state.argtypes = [C.c_void_p, I32P, I32P, I32P]
     L.fpo_read_scalars.argtypes = [C.c_void_p, I32P, I32P]
     L.fpo_read_tally.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, I32P, U64P]
+    L.fpo_state_digest.argtypes = [C.c_void_p, U64P]
     _lib = L
     return L
 
@@ -437,6 +438,11 @@ class System:
         mv = np.zeros((self.ngroups, self.R), np.int32)
         lib().fpo_read_scalars(self._h, _p(pr, I32P), _p(mv, I32P))
         return pr, mv
+
+    def state_digest(self):
+        out = np.zeros(8, np.uint64)
+        lib().fpo_state_digest(self._h, _p(out, U64P))
+        return out
 
     def read_tally(self, slot):
         n = C.c_int32()

@@ -102,3 +102,26 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"\boracle\b|fpo_|pyoracle", txt):
                     bad.append(os.path.join(dirpath, fn))
     assert not bad, bad
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """bench.py --gpus N must never report another world size under the N-GPU label"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True,
+                         text=True, env=env, timeout=300)
+    assert out.returncode != 0 and "--gpus 4 but WORLD_SIZE is 1" in out.stderr
+    # ... and without a launcher around it, it launches its own ranks: one per GPU, 127.0.0.1 rendezvous
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["FPX_BENCH_DRY_SPAWN"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "5"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr
+    cmd = json.loads(out.stdout.strip().splitlines()[-1])["spawn"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "5"] and cmd[-5].endswith("bench.py")

@@ -34,8 +34,30 @@ def _run(extra):
     return json.loads(lines[0])
 
 
+def test_bench_spawns_its_own_ranks():
+    """VERDICT r01 missing #4: `python bench.py --gpus 2` with no torchrun around it must become 2 ranks
+    (here: sharing cuda:0 over gloo) and report n_gpus 2 -- not silently run one rank."""
+    env = dict(os.environ, FPX_BENCH_SHARE_GPU="1", FPX_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                          "--warmup", "1", "--replica-row-steps", "2"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2
+    # both rows of SURVEY.md 8e in one run: the group-sharded headline and the replica-axis row
+    r = d["replica_axis"]
+    assert r["scaling"] == "strong" and r["steps"] == 2 and r["value"] > 0
+    assert abs(r["value"] * r["ms_per_step"] * 1e-3 * 2 - 2 * (1 << 20)) < 1e-3 * 2 * (1 << 20)
+    assert r["xgmi_bytes_per_gpu_per_step"] == 16 << 20
+
+
 def test_group_sharded_bench_two_ranks():
-    d = _run([])
+    d = _run(["--replica-row-steps", "0"])
+    assert "replica_axis" not in d
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
     # every rank commits its own 2^20 slots per step: whole-job value counts both
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 * 3 - 2 * 3 * (1 << 20)) < 1e-3 * 2 * 3 * (1 << 20)
@@ -47,6 +69,7 @@ def test_replica_sharded_bench_two_ranks():
     d = _run(["--shard", "replica", "--ballot", "acceptor"])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert d["config"]["sharding"] == "replica"
+    assert d["collective"]["xgmi_bytes_per_gpu_per_step"] == 16 << 20 and d["rccl_ranks"] == 0   # gloo hook
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 * 3 - 3 * (1 << 20)) < 1e-3 * 3 * (1 << 20)
 
 

@@ -522,3 +522,66 @@ def test_scattered_targets_hint_changes_nothing(fa, oracle, R, ballot_mode):
     gpu.reset()
     ref.reset()
     check(gpu, ref, W.adversarial_script(S, R, q, 29 + R, epochs=16, fused=False), tally_slots=range(0, S, 61))
+
+
+def test_capacity_error_applies_everything_else(fa, oracle):
+    """a fused launch that hits FPX_ECAPACITY on some messages must still apply the others in
+    full -- votes AND the acceptors' round / maxVotedSlot (a vote in round r with promised < r would let a
+    later lower round be accepted).  The oracle has no capacity limit, so the expected state is the oracle's
+    after the same batch minus the over-capacity messages."""
+    import torch
+
+    S, R = 4096, 256
+    kw = dict(num_slots=S, num_replicas=R, f=127, tally_ways=2)
+    gpu, ref = both(fa, oracle, **kw)
+    slot, rnd, val = W.steady_stream(S)
+    none = np.zeros((S, 4), np.uint64)          # delivered to nobody: the tallies stay Pending
+    for r in (0, 1):
+        assert gpu.phase2_fused(slot, rnd + r, val, none)[0] == 0
+        assert ref.phase2_fused(slot, rnd + r, val, none)[0] == 0
+    gpu.proxy_forget(0, S // 2)                 # the lower half of the window has free ways again
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    ch = torch.zeros(S, dtype=torch.uint8, device=dev)
+    cv = torch.zeros(S, dtype=torch.int32, device=dev)
+    gpu.phase2_fused_dev(t(slot), t(rnd + 2), t(val), None, ch, None, cv)
+    assert gpu.sync() == fa.FPX_ECAPACITY
+    i, s, r = gpu.error_detail()
+    assert s >= S // 2 and r == 2
+    half = S // 2
+    st, ch_r, cr_r, cv_r, nr_r = ref.phase2_fused(slot[:half], rnd[:half] + 2, val[:half])
+    assert st == 0 and ch_r.all()
+    np.testing.assert_array_equal(ch.cpu().numpy()[:half], ch_r)
+    assert not ch.cpu().numpy()[half:].any()
+    W.assert_same_state(gpu, ref)               # cells, rounds (= 2 everywhere), maxVotedSlot (= S/2 - 1)
+    assert (gpu.read_scalars()[0] == 2).all() and (gpu.read_scalars()[1] == half - 1).all()
+    # a later lower round is Nacked, as it must be
+    st, chg, crg, cvg, nrg = gpu.phase2_fused(slot[:8] , rnd[:8] + 1, val[:8])
+    assert st == 0 and not chg.any() and (nrg == 2).all()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_eight_thousand_acceptors_in_one_context(fa, oracle, fused):
+    """num_groups * num_leader_groups * R up to 8192 puts 64+ KiB of maxima tables in LDS, above
+    the default dynamic-LDS limit: K1 and K3 opt in per kernel.  Mencius-shaped: 128 leader groups x 8
+    acceptor groups x 8 acceptors."""
+    S = 16384
+    kw = dict(num_slots=S, num_replicas=8, num_groups=8, num_leader_groups=128, f=3, tally_ways=8)
+    gpu, ref = both(fa, oracle, **kw)
+    check(gpu, ref, W.adversarial_script(S, 8, 4, 41, epochs=4, fused=fused, ngroups=1024,
+                                         subsets=W.fast_subsets), tally_slots=range(0, S, 1021))
+
+
+def test_two_contexts_keep_their_device(fa):
+    """entry points run on the context's device whatever the caller's current device is, and
+    restore the caller's.  (One GPU on this box: the guard must at least be transparent.)"""
+    import torch
+
+    gpu = fa.Context(fa.make_config(num_slots=64, num_replicas=3, f=1))
+    before = torch.cuda.current_device()
+    st, ch, *_ = gpu.phase2_fused(np.arange(8, dtype=np.int32), np.zeros(8, np.int32), np.arange(8, dtype=np.int32))
+    assert st == 0 and ch.all() and torch.cuda.current_device() == before
+    if torch.cuda.device_count() > 1:
+        other = fa.Context(fa.make_config(num_slots=64, num_replicas=3, f=1, device=1))
+        st, ch, *_ = other.phase2_fused(np.arange(8, dtype=np.int32), np.zeros(8, np.int32), np.arange(8, dtype=np.int32))
+        assert st == 0 and ch.all() and torch.cuda.current_device() == before

@@ -180,3 +180,28 @@ def test_flat_oracle_agrees_with_the_reference_shaped_restatement(oracle):
         st, ch, cr, cv, nr = sys_.phase2_fused(slot, rnd, val)
         assert st == 0 and n == int(ch.sum()) == S
         assert cs.value == int(cv[ch == 1].astype(np.int64).sum())
+
+
+def test_oracle_phase1a_loop_order_is_immaterial(oracle):
+    """the batch Phase1a of a big PER_SLOT window walks slots outside / acceptors inside; the per-acceptor
+    handler (Acceptor.scala:148-182 restated in fpo_acceptor_handle_phase1a) walks one acceptor's column.
+    Same cells, same rule, no shared state: identical results (checked on a window just over the switch)."""
+    import numpy as np
+    from tests import workloads as W
+
+    S, R = 4096, 9
+    kw = dict(num_slots=S, num_replicas=R, num_groups=2, f=4, ballot_mode=1)
+    a, b = oracle.System(oracle.make_config(**kw)), oracle.System(oracle.make_config(**kw))
+    rng = np.random.default_rng(5)
+    for step in range(12):
+        g, rnd, wm = int(rng.integers(0, 2)), int(rng.integers(0, 6)), int(rng.integers(0, S // 2))
+        tgt = W.bits_from_bool(rng.random((1, R)) < 0.6)[0]
+        sa, pa, na = a.acceptor_phase1a(g, rnd, wm, tgt)
+        pb, nb = [], []
+        for r in range(R):          # the per-message handler, acceptor by acceptor
+            if (int(tgt[0]) >> r) & 1:
+                ok, _ = b.acceptor_handle_phase1a(g, r, rnd, wm)
+                (pb if ok else nb).append(r)
+        assert oracle.indices_of(pa) == pb and oracle.indices_of(na) == nb
+        for x, y in zip(a.read_state(), b.read_state()):
+            np.testing.assert_array_equal(x, y)

@@ -76,6 +76,24 @@ def random_subsets(nprng, n, total, lo, hi):
     return rank < sizes[:, None]
 
 
+def fast_subsets(nprng, n, total, lo, hi):
+    """n pseudo-random subsets of [0, total) with sizes uniform in [lo, hi], in O(n * total) byte operations
+    (random_subsets sorts n x total keys: minutes at 2^20 x 256).  total must be a power of two <= 256: member j
+    of subset i is (a_i * j + b_i) mod total for j < size_i with a_i odd -- j -> a j + b is a permutation of
+    Z/total, so the size is exact.  Used by the full-size parity streams; which acceptors a Phase2a reaches is
+    the caller's choice in the reference too (an unseeded shuffle)."""
+    assert total & (total - 1) == 0 and total <= 256
+    sizes = nprng.integers(lo, hi + 1, size=n)
+    a = (nprng.integers(0, total // 2 if total > 1 else 1, size=n) * 2 + 1).astype(np.int64)
+    b = nprng.integers(0, total, size=n).astype(np.int64)
+    # position of element e in subset i's order: j = a^-1 (e - b) mod total ; member iff j < size
+    inv = np.array([pow(int(x), -1, total) if total > 1 else 0 for x in range(1, 2 * total, 2)], np.int64)
+    ainv = inv[(a - 1) // 2 % len(inv)]
+    e = np.arange(total, dtype=np.int64)[None, :]
+    j = (ainv[:, None] * (e - b[:, None])) & (total - 1)
+    return j < sizes[:, None]
+
+
 def next_classic_round(n, leader, rnd):
     if rnd < 0:
         return leader
@@ -85,7 +103,7 @@ def next_classic_round(n, leader, rnd):
 
 
 def adversarial_script(S, R, q, seed, epochs=64, num_leaders=2, fused=True, ngroups=1,
-                       group_of=None):
+                       group_of=None, subsets=None):
     """The parity / adversarial stream of SURVEY.md 8(d): delivery in `epochs` epochs of S/epochs
     slots; before an epoch, with probability 1/4, a leader change bumps the proposing round to
     nextClassicRound(leader = e % 2, round) and a random 25 % of the acceptors is pre-promised to the
@@ -93,6 +111,7 @@ def adversarial_script(S, R, q, seed, epochs=64, num_leaders=2, fused=True, ngro
     proposed slots are re-proposed in the new round with the same value; target_mask is a random
     subset of size U[q-8, R] (clamped to [1, R]); in the unfused pipeline 10 % of the vote messages
     are delivered twice.  Every epoch is one batch, so a batch carries one round per group."""
+    subsets = subsets or random_subsets
     rng = Rng(seed)
     ops = []
     rnd = 0
@@ -132,7 +151,7 @@ def adversarial_script(S, R, q, seed, epochs=64, num_leaders=2, fused=True, ngro
         slot = np.concatenate([reprop, np.arange(lo, hi)]).astype(np.int32)
         rr = np.full(len(slot), rnd, np.int32)
         val = values[slot]
-        tgt = bits_from_bool(random_subsets(nprng, len(slot), R, max(1, q - 8), R))
+        tgt = bits_from_bool(subsets(nprng, len(slot), R, max(1, q - 8), R))
         if fused:
             ops.append(("fused", slot, rr, val, tgt))
         else:
