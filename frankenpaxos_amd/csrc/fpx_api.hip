@@ -191,9 +191,9 @@ int dalloc(fpx_ctx* ctx, T** p, size_t count) {
   return FPX_OK;
 }
 
-size_t lds_bytes(const fpx_ctx* ctx, bool fused) {
+size_t lds_bytes(const fpx_ctx* ctx, bool fused, bool targets) {
   const size_t tab = (((size_t)ctx->g.ngroups * ctx->g.R * 8) + 16 + 15) & ~(size_t)15;  // tables + 4 workgroup words
-  return tab + 4 * (fused ? sizeof(WaveOut<true>) : sizeof(WaveOut<false>));
+  return tab + 4 * (fused ? sizeof(WaveOut<true>) : sizeof(WaveOut<false>)) + (targets ? 4 * 256 * sizeof(uint64_t) : 0);
 }
 
 int grid_for(const fpx_ctx* ctx, int n) {
@@ -209,27 +209,30 @@ void allow_lds(K kernel, size_t lds) {
   if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-template <int G, bool RMW, bool PERSLOT>
+template <int G, int MODE, bool PERSLOT>
 void launch_phase2_3(fpx_ctx* ctx, const Batch& b, bool fused, int grid) {
-  const size_t lds = lds_bytes(ctx, fused);
-  if (fused) allow_lds(k_phase2<G, RMW, PERSLOT, true>, lds);
-  else allow_lds(k_phase2<G, RMW, PERSLOT, false>, lds);
+  const size_t lds = lds_bytes(ctx, fused, MODE != 0);
+  if (fused) allow_lds(k_phase2<G, MODE, PERSLOT, true>, lds);
+  else allow_lds(k_phase2<G, MODE, PERSLOT, false>, lds);
   if (fused)
-    hipLaunchKernelGGL((k_phase2<G, RMW, PERSLOT, true>), dim3(grid), dim3(256), lds, ctx->stream, ctx->g, ctx->st, b);
+    hipLaunchKernelGGL((k_phase2<G, MODE, PERSLOT, true>), dim3(grid), dim3(256), lds, ctx->stream, ctx->g, ctx->st, b);
   else
-    hipLaunchKernelGGL((k_phase2<G, RMW, PERSLOT, false>), dim3(grid), dim3(256), lds, ctx->stream, ctx->g, ctx->st, b);
+    hipLaunchKernelGGL((k_phase2<G, MODE, PERSLOT, false>), dim3(grid), dim3(256), lds, ctx->stream, ctx->g, ctx->st, b);
 }
 
 template <int G>
 void launch_phase2_2(fpx_ctx* ctx, const Batch& b, bool fused, int grid) {
-  // rows are padded to a multiple of 4 cells (Geom::RS), so int4 accesses serve every R
-  const bool rmw = b.target && (ctx->cfg.flags & FPX_F_SCATTERED_TARGETS);
+  // rows are padded to a multiple of 4 cells (Geom::RS), so int4 accesses serve every R.
+  // mode 0: dense delivery (no target masks); 1: target masks; 2: target masks + FPX_F_SCATTERED_TARGETS
+  const int mode = !b.target ? 0 : ((ctx->cfg.flags & FPX_F_SCATTERED_TARGETS) ? 2 : 1);
   if (ctx->g.per_slot) {
-    if (rmw) launch_phase2_3<G, true, true>(ctx, b, fused, grid);
-    else launch_phase2_3<G, false, true>(ctx, b, fused, grid);
+    if (mode == 0) launch_phase2_3<G, 0, true>(ctx, b, fused, grid);
+    else if (mode == 1) launch_phase2_3<G, 1, true>(ctx, b, fused, grid);
+    else launch_phase2_3<G, 2, true>(ctx, b, fused, grid);
   } else {
-    if (rmw) launch_phase2_3<G, true, false>(ctx, b, fused, grid);
-    else launch_phase2_3<G, false, false>(ctx, b, fused, grid);
+    if (mode == 0) launch_phase2_3<G, 0, false>(ctx, b, fused, grid);
+    else if (mode == 1) launch_phase2_3<G, 1, false>(ctx, b, fused, grid);
+    else launch_phase2_3<G, 2, false>(ctx, b, fused, grid);
   }
 }
 
@@ -344,6 +347,7 @@ int init_state(fpx_ctx* ctx) {
   HIPCHK(ctx, hipMemsetAsync(st.pl_value, 0xFF, (size_t)g.S * g.wp * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.pl_bits, 0, (size_t)g.S * g.wp * 32, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.stamp, 0, (size_t)g.S * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.row_voted, 0, (size_t)g.S, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.run_round, 0xFF, (size_t)g.ngroups * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.status, 0, 8 * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.part_cnt, 0, 2 * 4, ctx->stream));
@@ -367,7 +371,8 @@ void free_state(fpx_ctx* ctx) {
   State& st = ctx->st;
   void* ps[] = {st.promised, st.max_voted, ctx->slab, st.pl_key, st.pl_value,
                 st.pl_bits,  st.stamp,     st.run_round,  st.status,     st.part,
-                st.log_value, st.log_present, st.log_scalars, st.rt_key, st.rt_bits, st.part_cnt, st.part_all};
+                st.log_value, st.log_present, st.log_scalars, st.rt_key, st.rt_bits, st.part_cnt, st.part_all,
+                st.row_voted};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   DevBuf* bs[] = {&ctx->d_slot,   &ctx->d_round, &ctx->d_value, &ctx->d_target, &ctx->d_bits_a, &ctx->d_bits_b,
@@ -597,6 +602,7 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
   if ((rc = dalloc(ctx, &st.pl_value, (size_t)g.S * g.wp))) return fail(rc);
   if ((rc = dalloc(ctx, &st.pl_bits, (size_t)g.S * g.wp * 4))) return fail(rc);
   if ((rc = dalloc(ctx, &st.stamp, (size_t)g.S))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.row_voted, (size_t)g.S))) return fail(rc);
   if ((rc = dalloc(ctx, &st.run_round, (size_t)g.ngroups))) return fail(rc);
   if ((rc = dalloc(ctx, &st.status, (size_t)8))) return fail(rc);
   ctx->g.part_rows = ctx->max_grid;
@@ -1390,7 +1396,7 @@ int32_t fpx_phase2_replica_sharded_dev(fpx_ctx* ctx, int32_t n, const int32_t* d
   const int per = n / world, lo = rank * per;
   int rc;
   if ((rc = grow(ctx, &ctx->d_part, (size_t)n * 32))) return rc;
-  if (world > 1 && (rc = grow(ctx, &ctx->d_mine, (size_t)per * 32))) return rc;
+  if (ctx->comm && (rc = grow(ctx, &ctx->d_mine, (size_t)per * 32))) return rc;
   uint64_t* part = (uint64_t*)ctx->d_part.p;
   // K1: my acceptor columns vote on every slot of the batch; partial bitmaps (bits in my range only) to HBM
   Batch b;
@@ -1399,10 +1405,10 @@ int32_t fpx_phase2_replica_sharded_dev(fpx_ctx* ctx, int32_t n, const int32_t* d
   b.vote_bits = part, b.nack_round = d_nack_round;
   if ((rc = enqueue_phase2(ctx, b, false))) return rc;
   const uint64_t* mine = part + (size_t)lo * 4;
-  if (world > 1) {
+  if (ctx->comm) {  // also on a communicator of one rank: the same call path, RCCL copies
     // the exchange step: sum (== OR) of the partial bitmaps, scattered so that I receive my slots' rows
     RcclApi* r = rccl();
-    if (!r || !ctx->comm) return FPX_ERCCL;
+    if (!r) return FPX_ERCCL;
     const bool prof = ctx->profiling && ctx->cev_used + 2 <= ctx->cev.size();
     if (prof) HIPCHK(ctx, hipEventRecord(ctx->cev[ctx->cev_used], ctx->stream));
     RCCLCHK(ctx, r->ReduceScatter(part, ctx->d_mine.p, (size_t)per * 4, RCCL_UINT64, RCCL_SUM, ctx->comm, ctx->stream));

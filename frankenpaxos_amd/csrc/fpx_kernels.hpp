@@ -89,6 +89,8 @@ struct State {
   uint32_t* pl_key;     // [S][wp]        0 = empty, else (round + 1) | KEY_DONE
   int32_t* pl_value;    // [S][wp]
   uint64_t* pl_bits;    // [S][wp][4]
+  uint8_t* row_voted;   // [S]            0 = no acceptor of the slot's group has ever voted in it (its cells
+                        //                are all -1): partially voted cells can then be written whole without a read
   uint32_t* stamp;      // [S]            run id of the last run that touched the slot
   int32_t* run_round;   // [ngroups]      the single round of the current run per group (-1 = none)
   int32_t* status;      // [8]
@@ -343,9 +345,14 @@ struct WaveOut<true> {     // K3: only the chosen flags are staged; bitmaps stay
   int32_t chosen[64];
 };
 
-template <int G, bool RMW, bool PERSLOT, bool FUSED>
+template <int G, int MODE, bool PERSLOT, bool FUSED>
 __global__ void __launch_bounds__(256)
     k_phase2(const Geom g, const State st, const Batch b) {
+  // MODE 0: no target masks (dense delivery) -- the lean kernel of the steady state; 1: target masks; 2: target
+  // masks + FPX_F_SCATTERED_TARGETS.  The target-mask code (LDS staging, fresh-row blend) costs 6-12 VGPRs = one
+  // wave per SIMD, which the dense stream would pay for nothing.
+  constexpr bool TGT = MODE != 0;
+  constexpr bool RMW = MODE == 2;
   constexpr bool VEC = true;  // 16-byte row accesses
   constexpr int Q = 64 / G;           // slots per step
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -362,6 +369,11 @@ __global__ void __launch_bounds__(256)
   // [0] this workgroup used the tables, [1] its partial-table row, [2] [3] whole-group maxima (round, slot)
   int32_t* blk_flag = tab_pr + 2 * ntab;
   WaveOut<FUSED>* wo = reinterpret_cast<WaveOut<FUSED>*>(smem + (((size_t)ntab * 8 + 16 + 15) & ~(size_t)15)) + wib;
+  // launches that carry target masks: the chunk's masks (64 x 32 B per wave) are staged here with one coalesced
+  // load, so that the walk has no global load of its own in the ACCEPTOR model (a dependent load per row made
+  // thrifty delivery latency-bound: 0.88 ms per 2^20 rows against 0.42 ms dense, profiles/r02_thrifty.txt)
+  uint64_t* wt = reinterpret_cast<uint64_t*>(smem + (((size_t)ntab * 8 + 16 + 15) & ~(size_t)15) + 4 * sizeof(WaveOut<FUSED>)) +
+                 (size_t)wib * 256;
 
   for (int i = threadIdx.x; i < 2 * ntab + 4; i += blockDim.x) tab_pr[i] = (i < 2 * ntab || i >= 2 * ntab + 2) ? -1 : 0;
   __syncthreads();
@@ -393,6 +405,11 @@ __global__ void __launch_bounds__(256)
     const int myslot = mv ? b.slot[m] : -1;
     const int myround = mv ? b.round[m] : 0;
     const int myvalue = mv ? b.value[m] : 0;
+    // a slot nobody has voted in yet (the common case: a first proposal) holds -1 in every cell, so a partial
+    // vote -- thrifty delivery to a random f+1 of the group (ProxyLeader.scala:190-191), or some acceptors
+    // Nacking -- can be stored as whole 16-byte cells blended with -1: full-line traffic, nothing read
+    bool myfresh = false;
+    if constexpr (TGT) myfresh = mv && st.row_voted[myslot] == 0;
     // ProxyLeader.handlePhase2a for 64 messages at once (ProxyLeader.scala:176-184): lane i reads the
     // tally-key row of its slot (one gathered 16-byte access per lane), detects a known (slot, round)
     // and picks the free way.  The key word is written back after the walk, one lane per message.
@@ -415,6 +432,14 @@ __global__ void __launch_bounds__(256)
       }
       mydeliver = !dup && myway >= 0;  // a known (slot, round) is ignored and NOT forwarded
       if (!dup && myway < 0) report(st, 5 /*FPX_ECAPACITY*/, m, myslot, myround);
+    }
+
+    if constexpr (TGT) {
+      const size_t w0 = (size_t)chunk * CH * 4, wend = (size_t)b.n * 4;
+#pragma unroll
+      for (int w = lane; w < CH * 4; w += 64)
+        if (w0 + w < wend) wt[w] = b.target[w0 + w];
+      wave_lds_sync();
     }
 
     // ---- walk the chunk, Q slots per step; the ballot row of the next step is already in flight ----
@@ -462,9 +487,13 @@ __global__ void __launch_bounds__(256)
       const int rnd = __shfl(myround, src);
       const int val = __shfl(myvalue, src);
       const bool deliver = __shfl((int)mydeliver, src) != 0 && s >= 0;
+      bool fresh = false;
+      if constexpr (TGT) fresh = __shfl((int)myfresh, src) != 0;
       const int4v thr = thr_cur;
       uint64_t tw = ~0ull;
-      if (b.target && own && s >= 0) tw = b.target[(size_t)(chunk * CH + src) * 4 + (bitpos >> 6)];
+      if constexpr (TGT) {
+        if (own && s >= 0) tw = wt[src * 4 + (bitpos >> 6)];
+      }
 
       // Acceptor.scala:192: phase2a.round < round -> Nack ; else vote
       const uint32_t tn = deliver ? (own & (uint32_t)((tw >> (bitpos & 63)) & 0xFull)) : 0u;
@@ -482,7 +511,30 @@ __global__ void __launch_bounds__(256)
       }
       // Acceptor.scala:204-208: round = phase2a.round; states(slot) = State(round, value)
       const bool full_cell = (acc | (~own & 0xFu)) == 0xFu;
-      if (acc) {
+      // does any acceptor of my 64-byte sector (4 lanes x 16 B) vote?  A fresh sector nobody votes in stays as it is
+      // (contiguous target runs would otherwise write twice the bytes); one somebody votes in is written whole
+      uint32_t sector_acc = 0;
+      if constexpr (TGT) {
+        sector_acc = acc | (uint32_t)__shfl_xor((int)acc, 1);
+        sector_acc |= (uint32_t)__shfl_xor((int)sector_acc, 2);
+      }
+      if (TGT && fresh && deliver && own && sector_acc) {
+        // first votes of the slot: cells whose acceptor does not vote hold -1 / -1.  ONE store path for the whole
+        // row (fully voted cells included): two half-masked store instructions per array cost the issue
+        // slots of two full ones
+        const size_t row = (size_t)s * (size_t)g.RS + (size_t)r0;
+        int4v rr, vv, nb = thr;
+        bool ballot_moves = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool a = (acc >> k) & 1u;
+          rr[k] = a ? rnd : -1, vv[k] = a ? val : -1;
+          if (a) ballot_moves = ballot_moves || thr[k] != rnd, nb[k] = rnd;
+        }
+        row_store(rr, reinterpret_cast<int4v*>(st.vote_round + row));
+        row_store(vv, reinterpret_cast<int4v*>(st.vote_value + row));
+        if (PERSLOT && ballot_moves) row_store(nb, reinterpret_cast<int4v*>(st.ballot + row));
+      } else if (acc) {
         const size_t row = (size_t)s * (size_t)g.RS + (size_t)r0;
         // whole-lane fast path: every acceptor this lane owns voted (padding cells may be overwritten)
         if (VEC && full_cell) {
@@ -603,6 +655,8 @@ __global__ void __launch_bounds__(256)
 
     // ---- outputs of the 64 messages leave as coalesced lines ------------------------------------
     wave_lds_sync();
+    // the slot's row is no longer known to be all -1 (marked even if every acceptor Nacked: that only costs the shortcut)
+    if (TGT ? (myfresh && mydeliver) : (mv && mydeliver)) st.row_voted[myslot] = 1;
     if (mv) {
       if constexpr (!FUSED) {
         if (b.vote_bits) {
@@ -944,6 +998,7 @@ __global__ void __launch_bounds__(256)
       const size_t cell = (size_t)s * g.RS + r;
       st.vote_round[cell] = round;  // :271-276 State(voteRound = round, voteValue = Noop)
       st.vote_value[cell] = -1;
+      if (st.row_voted[s] == 0) st.row_voted[s] = 1;
     }
   }
 }

@@ -15,6 +15,8 @@ S, R, F = 1 << 20, 255, 127
 dev = torch.device("cuda:0")
 ballot = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 scattered = len(sys.argv) > 2 and sys.argv[2] == "scattered"  # FPX_F_SCATTERED_TARGETS hint
+only = sys.argv[3] if len(sys.argv) > 3 else "all"      # random | rotating | dense | all
+phase = sys.argv[4] if len(sys.argv) > 4 else "both"    # first | both   (PMC runs: one kind of launch per process)
 windows = 6
 
 
@@ -45,6 +47,8 @@ def rotating_masks(n):
 
 
 for name, maker in (("random f+1 subsets", random_masks), ("rotating f+1 run", rotating_masks), ("dense", None)):
+    if only != "all" and not name.startswith(only):
+        continue
     ctx = fa.Context(fa.make_config(num_slots=windows * S, num_replicas=R, f=F, ballot_mode=ballot,
                                     flags=fa.FPX_F_TRUSTED | (fa.FPX_F_SCATTERED_TARGETS if scattered else 0)))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -66,5 +70,19 @@ for name, maker in (("random f+1 subsets", random_masks), ("rotating f+1 run", r
         ctx.phase2_fused_dev(*steps[w], tgt, ch, None, None)
     assert ctx.sync() == 0
     dt = (time.perf_counter() - t0) / (windows - 1)
-    print("ballot model %d  %-20s %.3f ms/step  %.3e slots/s" % (ballot, name, dt * 1e3, S / dt))
+    print("ballot model %d  %-20s first proposal  %.3f ms/step  %.3e slots/s" % (ballot, name, dt * 1e3, S / dt))
+    if phase == "first":
+        ctx.close()
+        continue
+    # the same windows re-proposed in round 1 to a DIFFERENT f+1: the rows now hold votes, partial cells take
+    # the 4-byte (or, with the scattered hint, load / blend / store) path
+    tgt2 = torch.roll(tgt, 12345, 0) if tgt is not None else None
+    one = torch.ones(S, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for w in range(1, windows):
+        ctx.phase2_fused_dev(steps[w][0], one, steps[w][2], tgt2, ch, None, None)
+    assert ctx.sync() == 0
+    dt = (time.perf_counter() - t0) / (windows - 1)
+    print("ballot model %d  %-20s re-proposal     %.3f ms/step  %.3e slots/s" % (ballot, name, dt * 1e3, S / dt))
     ctx.close()

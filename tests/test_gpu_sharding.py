@@ -72,3 +72,73 @@ def test_n_way_replica_shards(oracle, world, ballot_mode):
         assert a[1] == b[1]
         np.testing.assert_array_equal(a[2], b[2])
         np.testing.assert_array_equal(a[3], b[3])
+
+
+@pytest.mark.parametrize("with_comm", [False, True])
+@pytest.mark.parametrize("ballot_mode", [0, 1])
+def test_replica_sharded_entry_point_world_one(oracle, with_comm, ballot_mode):
+    """fpx_phase2_replica_sharded_dev on the degenerate world of one rank -- with a real RCCL communicator of
+    one rank created through the C ABI (fpx_comm_unique_id / fpx_comm_create) and without any -- is K1 ->
+    (reduce-scatter over one rank) -> open + K2, and must equal the oracle's unfused pipeline bit for bit."""
+    import torch
+    import frankenpaxos_amd as fa
+
+    S, R = 8192, 256
+    kw = dict(num_slots=S, num_replicas=R, f=127, ballot_mode=ballot_mode, tally_ways=8)
+    gpu, ref = fa.Context(fa.make_config(**kw)), oracle.System(oracle.make_config(**kw))
+    dev = torch.device("cuda:0")
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    if with_comm:
+        uid = fa.comm_unique_id()
+        assert len(uid) == fa.FPX_COMM_ID_BYTES
+        gpu.comm_create(uid, 0, 1)
+        assert gpu.comm_info() == (0, 1)
+    gpu.profile_enable(True)
+    rng = np.random.default_rng(9 + ballot_mode)
+    slot, rnd, val = W.steady_stream(S)
+    ahead = W.bits_from_bool(W.random_subsets(rng, 1, R, 100, 100))[0]
+    for be in (gpu, ref):
+        assert be.acceptor_phase1a(0, 0)[0] == 0
+        assert be.acceptor_phase1a(0, 4, 0, ahead)[0] == 0        # 100 acceptors are ahead: Nacks in round 2
+    for r in (2, 4):
+        rr = np.full(S, r, np.int32)
+        tgt = W.bits_from_bool(W.random_subsets(rng, S, R, 120, 256))
+        t = lambda a: torch.from_numpy(a).to(dev)
+        ch = torch.zeros(S, dtype=torch.uint8, device=dev)
+        cr = torch.zeros(S, dtype=torch.int32, device=dev)
+        cv = torch.zeros(S, dtype=torch.int32, device=dev)
+        nr = torch.zeros(S, dtype=torch.int32, device=dev)
+        gpu.phase2_replica_sharded_dev(t(slot), t(rr), t(val), t(tgt.view(np.int64)), ch, cr, cv, nr)
+        assert gpu.sync() == 0
+        ref.proxy_open(slot, rr, val)
+        st, vb_r, nb_r, nr_r = ref.acceptor_phase2a(slot, rr, val, tgt)
+        st, ch_r, cr_r, cv_r = ref.proxy_phase2b(slot, rr, vb_r)
+        np.testing.assert_array_equal(ch.cpu().numpy(), ch_r)
+        np.testing.assert_array_equal(cr.cpu().numpy(), cr_r)
+        np.testing.assert_array_equal(cv.cpu().numpy(), cv_r)
+        np.testing.assert_array_equal(nr.cpu().numpy(), nr_r)
+    assert 0 < int(ch_r.sum())
+    W.assert_same_state(gpu, ref, tally_slots=range(0, S, 257))
+    np.testing.assert_array_equal(gpu.state_digest(), ref.state_digest())
+    n_coll, ms = gpu.profile_read_collective()
+    assert n_coll == (2 if with_comm else 0)  # a communicator, even of one rank, goes through ncclReduceScatter
+    # the all-gather of Chosen records (group sharding) degenerates to a copy
+    allch = torch.zeros(S, dtype=torch.uint8, device=dev)
+    allcv = torch.zeros(S, dtype=torch.int32, device=dev)
+    gpu.comm_allgather_chosen_dev(ch, None, cv, allch, None, allcv)
+    assert gpu.sync() == 0 and bool((allch == ch).all()) and bool((allcv == cv).all())
+    if with_comm:
+        gpu.comm_destroy()
+        assert gpu.comm_info() == (0, 1)
+    gpu.set_stream(None)
+    gpu.close()
+
+
+def test_replica_sharded_entry_point_rejects_ragged_batches():
+    import torch
+    import frankenpaxos_amd as fa
+
+    gpu = fa.Context(fa.make_config(num_slots=64, num_replicas=4, f=1))
+    with pytest.raises(fa.FpxError):
+        gpu.comm_create(b"\0" * 128, 3, 2)        # rank outside the world: FPX_EINVAL before RCCL is touched
+    gpu.close()
