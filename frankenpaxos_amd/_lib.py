@@ -98,6 +98,12 @@ SIGNATURES = {
     "fpx_acceptor_phase2a_noop_range": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, VP, VP, VP, I32P]),
     "fpx_proxy_open_noop_range": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, U8P]),
     "fpx_proxy_phase2b_noop_range": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, VP, U8P]),
+    "fpx_acceptor_phase2a_noop_ranges": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP, VP, VP, VP]),
+    "fpx_proxy_open_noop_ranges": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP]),
+    "fpx_proxy_phase2b_noop_ranges": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP, VP]),
+    "fpx_noop_ranges_fused": (C.c_int32, [VP, C.c_int32] + [VP] * 9),
+    "fpx_noop_ranges_fused_dev": (C.c_int32, [VP, C.c_int32] + [VP] * 9),
+    "fpx_read_range_tally": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, I32P, VP]),
     "fpx_proxy_forget": (C.c_int32, [VP, C.c_int32, C.c_int32]),
     "fpx_epx_create": (C.c_int32, [VP, C.POINTER(VP)]),
     "fpx_epx_destroy": (C.c_int32, [VP]),

@@ -256,6 +256,64 @@ class Context:
                                                  C.byref(ch))
         return st, ch.value
 
+    # batched forms (n ranges per call; bitmaps n x num_groups x 4)
+    def _ranges(self, slot_start, slot_end, round_):
+        return _i32(np.atleast_1d(slot_start)), _i32(np.atleast_1d(slot_end)), _i32(np.atleast_1d(round_))
+
+    def acceptor_phase2a_noop_ranges(self, slot_start, slot_end, round_, target_masks=None):
+        s, e, r = self._ranges(slot_start, slot_end, round_)
+        n, A = len(s), self.cfg.num_groups
+        target_masks = _u64(target_masks)
+        vb = np.zeros((n, A, 4), np.uint64)
+        nb = np.zeros((n, A, 4), np.uint64)
+        nr = np.full(n, -1, np.int32)
+        st = self.L.fpx_acceptor_phase2a_noop_ranges(self._h, n, _hp(s), _hp(e), _hp(r), _hp(target_masks),
+                                                     _hp(vb), _hp(nb), _hp(nr))
+        return st, vb, nb, nr
+
+    def proxy_open_noop_ranges(self, slot_start, slot_end, round_):
+        s, e, r = self._ranges(slot_start, slot_end, round_)
+        new = np.zeros(len(s), np.uint8)
+        st = self.L.fpx_proxy_open_noop_ranges(self._h, len(s), _hp(s), _hp(e), _hp(r), _hp(new))
+        return st, new
+
+    def proxy_phase2b_noop_ranges(self, slot_start, slot_end, round_, vote_bits):
+        s, e, r = self._ranges(slot_start, slot_end, round_)
+        vote_bits = _u64(vote_bits)
+        ch = np.zeros(len(s), np.uint8)
+        st = self.L.fpx_proxy_phase2b_noop_ranges(self._h, len(s), _hp(s), _hp(e), _hp(r), _hp(vote_bits), _hp(ch))
+        return st, ch
+
+    def noop_ranges_fused(self, slot_start, slot_end, round_, target_masks=None):
+        """open + acceptors + tally for n ranges: (status, vote_bits, nack_bits, nack_round, is_new, chosen)"""
+        s, e, r = self._ranges(slot_start, slot_end, round_)
+        n, A = len(s), self.cfg.num_groups
+        target_masks = _u64(target_masks)
+        vb = np.zeros((n, A, 4), np.uint64)
+        nb = np.zeros((n, A, 4), np.uint64)
+        nr = np.full(n, -1, np.int32)
+        new = np.zeros(n, np.uint8)
+        ch = np.zeros(n, np.uint8)
+        st = self.L.fpx_noop_ranges_fused(self._h, n, _hp(s), _hp(e), _hp(r), _hp(target_masks), _hp(vb), _hp(nb),
+                                          _hp(nr), _hp(new), _hp(ch))
+        return st, vb, nb, nr, new, ch
+
+    def noop_ranges_fused_dev(self, slot_start, slot_end, round_, target_masks=None, vote_bits=None,
+                              nack_bits=None, nack_round=None, is_new=None, chosen=None):
+        st = self.L.fpx_noop_ranges_fused_dev(self._h, slot_start.numel(), _dp(slot_start), _dp(slot_end),
+                                              _dp(round_), _dp(target_masks), _dp(vote_bits), _dp(nack_bits),
+                                              _dp(nack_round), _dp(is_new), _dp(chosen))
+        if st:
+            raise FpxError(st, "fpx_noop_ranges_fused_dev")
+
+    def read_range_tally(self, slot_start, slot_end, round_):
+        state = C.c_int32()
+        bits = np.zeros((self.cfg.num_groups, 4), np.uint64)
+        st = self.L.fpx_read_range_tally(self._h, slot_start, slot_end, round_, C.byref(state), _hp(bits))
+        if st:
+            raise FpxError(st, "fpx_read_range_tally")
+        return state.value, bits
+
     # ---- f1: replica log / f2: Phase-1 recovery scan ----------------------------------------------
     def replica_chosen(self, slot, value, mask=None):
         slot, value = _i32(slot), _i32(value)

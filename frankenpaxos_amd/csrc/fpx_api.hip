@@ -12,9 +12,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <set>
 #include <vector>
 
 #include "fpx_kernels.hpp"
+#include "fpx_ranges.hpp"
 
 using namespace fpx;
 
@@ -75,6 +77,10 @@ struct fpx_ctx {
   bool profiling = false;
   std::vector<hipEvent_t> ev;  // start/stop pairs
   size_t ev_used = 0;
+  // K4: the proxy leader's noop-range tallies (two buffers: fpx_proxy_forget rehashes into the other one)
+  RangeTable rt[2];
+  int rt_cur = 0;
+  DevBuf d_rng;  // staging of range batches
   // multi-GPU (fpx_comm_*): one communicator per context, rank = this context's GPU
   RcclComm comm = nullptr;
   int comm_rank = 0, comm_world = 1;
@@ -334,6 +340,16 @@ int fetch_status(fpx_ctx* ctx) {
   return h[0];
 }
 
+int clear_range_table(fpx_ctx* ctx, const RangeTable& t) {
+  if (!t.key) return FPX_OK;
+  const size_t words = (size_t)ctx->g.num_groups * 4;
+  HIPCHK(ctx, hipMemsetAsync(t.key, 0, (size_t)t.cap * 16, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(t.bits, 0, (size_t)t.cap * words * 8, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(t.owner, 0x7F, (size_t)t.cap * 4, ctx->stream));  // 0x7f7f7f7f: above any message index
+  HIPCHK(ctx, hipMemsetAsync(t.count, 0, 4, ctx->stream));
+  return FPX_OK;
+}
+
 int init_state(fpx_ctx* ctx) {
   const Geom& g = ctx->g;
   State& st = ctx->st;
@@ -354,8 +370,11 @@ int init_state(fpx_ctx* ctx) {
   HIPCHK(ctx, hipMemsetAsync(st.part_all, 0xFF, (size_t)2 * 64 * PART_ALL_STRIDE * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.log_value, 0xFF, (size_t)g.S * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.log_present, 0, (size_t)g.S, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(st.rt_key, 0, (size_t)RANGE_TALLIES * 16, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(st.rt_bits, 0, (size_t)RANGE_TALLIES * 32, ctx->stream));
+  for (int k = 0; k < 2; ++k) {
+    int rc2 = clear_range_table(ctx, ctx->rt[k]);
+    if (rc2) return rc2;
+  }
+  ctx->rt_cur = 0;
   {
     // executedWatermark = 0, numChosen = 0, largestKey = -1, scan result = 0
     static const int32_t init[8] = {0, 0, -1, 0, 0, 0, 0, 0};
@@ -371,8 +390,10 @@ void free_state(fpx_ctx* ctx) {
   State& st = ctx->st;
   void* ps[] = {st.promised, st.max_voted, ctx->slab, st.pl_key, st.pl_value,
                 st.pl_bits,  st.stamp,     st.run_round,  st.status,     st.part,
-                st.log_value, st.log_present, st.log_scalars, st.rt_key, st.rt_bits, st.part_cnt, st.part_all,
-                st.row_voted};
+                st.log_value, st.log_present, st.log_scalars, st.part_cnt, st.part_all,
+                st.row_voted,
+                ctx->rt[0].key, ctx->rt[0].bits, ctx->rt[0].owner, ctx->rt[0].count,
+                ctx->rt[1].key, ctx->rt[1].bits, ctx->rt[1].owner, ctx->rt[1].count, ctx->d_rng.p};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   DevBuf* bs[] = {&ctx->d_slot,   &ctx->d_round, &ctx->d_value, &ctx->d_target, &ctx->d_bits_a, &ctx->d_bits_b,
@@ -547,6 +568,7 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
   if (!ctx->cfg.replicas_total) ctx->cfg.replicas_total = cfg->num_replicas;
   make_geom(ctx->cfg, &ctx->g);
   memset(&ctx->st, 0, sizeof(ctx->st));
+  memset(ctx->rt, 0, sizeof(ctx->rt));
   DeviceGuard _dg(cfg->device);  // the caller's current device is restored on every return path
   if (hipSetDevice(cfg->device) != hipSuccess) {
     delete ctx;
@@ -590,8 +612,58 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
     if (const char* e = getenv("FPX_STAGGER")) stagger = (size_t)atoll(e) & ~(size_t)15;
     const int narr = g.per_slot ? 3 : 2;
     const size_t stride = ncell * 4 + stagger;
+    // Placement: the very same kernel streams a slab at one of two speeds ~7 % apart depending on where the
+    // allocation landed (deterministic per allocation, profiles/r02_placement.txt).  A big context therefore
+    // allocates up to FPX_PLACEMENT_TRIES slabs (default 4, while free HBM allows), times the hot access pattern
+    // on each (k_probe, 3 x 0.5 ms) and keeps the fastest; the others are freed before anything else is allocated.
+    int tries = stride * narr >= ((size_t)2 << 30) && g.RS >= 64 ? 4 : 1;
+    if (const char* e = getenv("FPX_PLACEMENT_TRIES")) tries = std::max(1, std::min(8, atoi(e)));
     char* slab = nullptr;
-    if (hipMalloc((void**)&slab, stride * narr) != hipSuccess) return fail(FPX_ENOMEM);
+    float best_ms = 0;
+    std::vector<char*> losers;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (tries > 1 && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) tries = 1;
+    for (int t = 0; t < tries; ++t) {
+      if (t > 0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < stride * narr + ((size_t)8 << 30)) break;
+      }
+      char* cand = nullptr;
+      if (hipMalloc((void**)&cand, stride * narr) != hipSuccess) {
+        (void)hipGetLastError();
+        break;
+      }
+      float ms = 0;
+      if (tries > 1) {
+        // 2^20 rows in 16 runs spread evenly over the whole slab: placement quality varies WITHIN an allocation too
+        const int pieces = g.S >= (1 << 22) ? 16 : 1;
+        const int rows = (int)std::min<int64_t>(g.S, 1 << 20) / pieces * pieces, q4 = g.RS / 4;
+        const long long piece_stride = g.S / pieces;
+        const int grid = (rows + 127) / 128;
+        int32_t* a = g.per_slot ? (int32_t*)(cand + 2 * stride) : nullptr;
+        float tmin = 1e30f;
+        for (int rep = 0; rep < 4; ++rep) {
+          (void)hipEventRecord(e0, ctx->stream);
+          hipLaunchKernelGGL(k_probe, dim3(grid), dim3(256), 0, ctx->stream, a, (int32_t*)cand, (int32_t*)(cand + stride), rows, q4, pieces, piece_stride);
+          (void)hipEventRecord(e1, ctx->stream);
+          (void)hipEventSynchronize(e1);
+          float m = 0;
+          if (hipEventElapsedTime(&m, e0, e1) == hipSuccess && rep > 0) tmin = std::min(tmin, m);
+        }
+        ms = tmin;
+        if (getenv("FPX_DEBUG")) fprintf(stderr, "libfpx: slab placement %d at %p: probe %.4f ms\n", t, (void*)cand, ms);
+      }
+      if (!slab || ms < best_ms) {
+        if (slab) losers.push_back(slab);
+        slab = cand, best_ms = ms;
+      } else {
+        losers.push_back(cand);
+      }
+    }
+    for (char* l : losers) (void)hipFree(l);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (!slab) return fail(FPX_ENOMEM);
     ctx->bytes += (int64_t)(stride * narr);
     ctx->slab = slab;
     st.vote_round = (int32_t*)slab;
@@ -612,8 +684,23 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
   if ((rc = dalloc(ctx, &st.log_value, (size_t)g.S))) return fail(rc);
   if ((rc = dalloc(ctx, &st.log_present, (size_t)g.S))) return fail(rc);
   if ((rc = dalloc(ctx, &st.log_scalars, (size_t)8))) return fail(rc);
-  if ((rc = dalloc(ctx, &st.rt_key, (size_t)RANGE_TALLIES * 4))) return fail(rc);
-  if ((rc = dalloc(ctx, &st.rt_bits, (size_t)RANGE_TALLIES * 4))) return fail(rc);
+  if (!g.per_slot) {
+    // noop-range tallies: at most cap / 2 live entries; sized for a few hundred ranges in flight per leader group,
+    // bounded to 64 MiB of vote bitmaps per buffer (A x 32 B per entry)
+    int64_t want = std::max<int64_t>(4096, (int64_t)g.num_leader_groups * 64);
+    const int64_t by_mem = std::max<int64_t>(1024, ((int64_t)64 << 20) / ((int64_t)g.num_groups * 32));
+    want = std::min<int64_t>(std::min<int64_t>(want, by_mem), 1 << 18);
+    int cap = 1024;
+    while (cap < want) cap <<= 1;
+    for (int k = 0; k < 2; ++k) {
+      RangeTable& t = ctx->rt[k];
+      t.cap = cap;
+      if ((rc = dalloc(ctx, &t.key, (size_t)cap * 2))) return fail(rc);
+      if ((rc = dalloc(ctx, &t.bits, (size_t)cap * g.num_groups * 4))) return fail(rc);
+      if ((rc = dalloc(ctx, &t.owner, (size_t)cap))) return fail(rc);
+      if ((rc = dalloc(ctx, &t.count, (size_t)1))) return fail(rc);
+    }
+  }
   if ((rc = init_state(ctx))) return fail(rc);
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(FPX_EHIP);
   *out = ctx;
@@ -1004,84 +1091,254 @@ int32_t fpx_proxy_forget(fpx_ctx* ctx, int32_t first_slot, int32_t count) {
   // an empty key word is all a tally entry needs to be free again (values / bitmaps are rewritten on open)
   HIPCHK(ctx, hipMemsetAsync(ctx->st.pl_key + (size_t)first_slot * ctx->g.wp, 0, (size_t)count * ctx->g.wp * 4,
                              ctx->stream));
+  if (ctx->rt[0].key) {
+    // the noop-range tallies that lie inside the window go too: the survivors move to the other table buffer
+    const RangeTable& from = ctx->rt[ctx->rt_cur];
+    const RangeTable& to = ctx->rt[ctx->rt_cur ^ 1];
+    int rc = clear_range_table(ctx, to);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ranges_rehash, dim3((from.cap + 255) / 256), dim3(256), 0, ctx->stream, from, to,
+                       ctx->g.num_groups * 4, first_slot, count);
+    if ((rc = launch_check(ctx))) return rc;
+    ctx->rt_cur ^= 1;
+  }
   return FPX_OK;
 }
 
-// ---- K4: Mencius noop ranges ----------------------------------------------------------------------------
-static int32_t range_args_ok(fpx_ctx* ctx, int32_t start, int32_t end, int32_t round) {
-  if (!ctx) return FPX_EINVAL;
-  if (ctx->g.per_slot) return FPX_EINVAL;
-  if ((int64_t)ctx->g.num_groups * ctx->g.total > 256) return FPX_EINVAL;
-  if (start < 0 || end < start || end > ctx->g.S || round < 0 || round > MAX_ROUND) return FPX_EINVAL;
+// ---- K4: Mencius noop ranges (batched; kernels in fpx_ranges.hpp) -----------------------------------------
+static int32_t ranges_ctx_ok(fpx_ctx* ctx, int32_t n) {
+  if (!ctx || n < 0) return FPX_EINVAL;
+  if (ctx->g.per_slot) return FPX_EINVAL;  // ranges act on the acceptor's `round` scalar (mencius/Acceptor.scala:245-260)
   return FPX_OK;
 }
 
+enum { RANGES_FUSED = 0, RANGES_ACCEPTORS = 1, RANGES_OPEN = 2, RANGES_TALLY = 3 };
+
+// one device run of n ranges; vote_bits must be present for every mode but RANGES_OPEN
+static int enqueue_ranges(fpx_ctx* ctx, RangeBatch& b, int mode) {
+  if (b.n == 0) return FPX_OK;
+  const Geom& g = ctx->g;
+  const size_t words = (size_t)b.n * g.num_groups * 4;
+  b.run_id = ++ctx->run_id;
+  b.fused = mode == RANGES_FUSED;
+  b.quorum = ctx->cfg.f + 1;
+  const int gn = (b.n + 255) / 256;
+  const bool acceptors = mode == RANGES_FUSED || mode == RANGES_ACCEPTORS;
+  const bool validate = !(((ctx->cfg.flags & FPX_F_TRUSTED) && !ctx->force_validate) || ctx->host_validated);
+  if (validate) {
+    if (acceptors) HIPCHK(ctx, hipMemsetAsync(ctx->st.run_round, 0xFF, sizeof(int32_t) * (size_t)g.ngroups, ctx->stream));
+    hipLaunchKernelGGL(k_ranges_validate, dim3(gn), dim3(256), 0, ctx->stream, g, ctx->st, b, acceptors ? 1 : 0);
+  }
+  if (acceptors) {
+    HIPCHK(ctx, hipMemsetAsync(b.vote_bits, 0, words * 8, ctx->stream));
+    if (b.nack_bits) HIPCHK(ctx, hipMemsetAsync(b.nack_bits, 0, words * 8, ctx->stream));
+    if (b.nack_round) HIPCHK(ctx, hipMemsetAsync(b.nack_round, 0xFF, (size_t)b.n * 4, ctx->stream));
+  }
+  const RangeTable& rt = ctx->rt[ctx->rt_cur];
+  if (mode == RANGES_FUSED || mode == RANGES_OPEN) {
+    hipLaunchKernelGGL(k_ranges_open, dim3(gn), dim3(256), 0, ctx->stream, g, ctx->st, rt, b, 0);
+    hipLaunchKernelGGL(k_ranges_resolve, dim3(gn), dim3(256), 0, ctx->stream, g, ctx->st, rt, b);
+  }
+  if (acceptors) {
+    const long long threads = (long long)b.n * g.num_groups * g.R;
+    hipLaunchKernelGGL(k_ranges_acceptors, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, g, ctx->st, b);
+    const int gy = std::min(b.n, 4096);
+    const int gx = std::max(1, std::min(ctx->num_cus * 16 / gy, 64));
+    hipLaunchKernelGGL(k_ranges_fill, dim3(gx, gy), dim3(256), 0, ctx->stream, g, ctx->st, b);
+  }
+  if (mode == RANGES_TALLY) hipLaunchKernelGGL(k_ranges_open, dim3(gn), dim3(256), 0, ctx->stream, g, ctx->st, rt, b, 1);
+  if (mode == RANGES_FUSED || mode == RANGES_TALLY)
+    hipLaunchKernelGGL(k_ranges_tally, dim3(gn), dim3(256), 0, ctx->stream, g, ctx->st, rt, b);
+  return launch_check(ctx);
+}
+
+int32_t fpx_noop_ranges_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot_start, const int32_t* d_slot_end,
+                                  const int32_t* d_round, const uint64_t* d_target_masks, uint64_t* d_vote_bits,
+                                  uint64_t* d_nack_bits, int32_t* d_nack_round, uint8_t* d_is_new, uint8_t* d_chosen) {
+  DeviceGuard _dg(ctx);
+  int rc = ranges_ctx_ok(ctx, n);
+  if (rc) return rc;
+  if (n == 0) return FPX_OK;
+  const size_t words = (size_t)n * ctx->g.num_groups * 4;
+  // scratch: entry[n], and the vote bitmaps when the caller does not want them
+  if ((rc = grow(ctx, &ctx->d_rng, (size_t)n * 4 + 64 + (d_vote_bits ? 0 : words * 8)))) return rc;
+  RangeBatch b;
+  memset(&b, 0, sizeof(b));
+  b.n = n, b.start = d_slot_start, b.end = d_slot_end, b.round = d_round, b.target = d_target_masks;
+  b.entry = (int32_t*)ctx->d_rng.p;
+  b.vote_bits = d_vote_bits ? d_vote_bits : (uint64_t*)((char*)ctx->d_rng.p + (((size_t)n * 4 + 63) & ~(size_t)63));
+  b.nack_bits = d_nack_bits, b.nack_round = d_nack_round, b.is_new = d_is_new, b.chosen = d_chosen;
+  return enqueue_ranges(ctx, b, RANGES_FUSED);
+}
+
+namespace {
+struct RangeKey {
+  int32_t s, e, r;
+  bool operator<(const RangeKey& o) const { return s != o.s ? s < o.s : (e != o.e ? e < o.e : r < o.r); }
+};
+
+// host staging of a range batch: [start | end | round | entry | nack_round] int32, [is_new | chosen] u8, then the
+// bitmaps [target | votes | nacks] u64
+struct RangeStage {
+  int32_t *start, *end, *round, *entry, *nack_round;
+  uint8_t *is_new, *chosen;
+  uint64_t *target, *votes, *nacks;
+};
+
+int stage_ranges(fpx_ctx* ctx, int n, RangeStage* st) {
+  const size_t words = (size_t)n * ctx->g.num_groups * 4;
+  const size_t ints = ((size_t)n * 5 * 4 + 63) & ~(size_t)63, bytes = ((size_t)n * 2 + 63) & ~(size_t)63;
+  int rc = grow(ctx, &ctx->d_rng, ints + bytes + 3 * words * 8);
+  if (rc) return rc;
+  char* p = (char*)ctx->d_rng.p;
+  st->start = (int32_t*)p, st->end = st->start + n, st->round = st->end + n, st->entry = st->round + n;
+  st->nack_round = st->entry + n;
+  st->is_new = (uint8_t*)(p + ints), st->chosen = st->is_new + n;
+  st->target = (uint64_t*)(p + ints + bytes), st->votes = st->target + words, st->nacks = st->votes + words;
+  return FPX_OK;
+}
+
+// host batches: argument check (the first offender for fpx_error_detail) and the cuts that make every piece a run
+int check_ranges(fpx_ctx* ctx, int n, const int32_t* start, const int32_t* end, const int32_t* round) {
+  for (int i = 0; i < n; ++i)
+    if (start[i] < 0 || end[i] < start[i] || end[i] > ctx->g.S || round[i] < 0 || round[i] > MAX_ROUND) {
+      ctx->err_index = i, ctx->err_slot = start[i], ctx->err_round = round[i];
+      return FPX_EINVAL;
+    }
+  return FPX_OK;
+}
+
+void split_range_runs(fpx_ctx* ctx, int n, const int32_t* start, const int32_t* end, const int32_t* round,
+                      bool one_round_per_group, bool distinct_keys, std::vector<int>* cuts) {
+  cuts->clear();
+  cuts->push_back(0);
+  std::vector<int32_t> cur((size_t)ctx->g.num_leader_groups, -1);
+  std::vector<int> touched;
+  std::set<RangeKey> keys;
+  for (int i = 0; i < n; ++i) {
+    const int lg = start[i] % ctx->g.num_leader_groups;
+    bool cut = one_round_per_group && cur[lg] != -1 && cur[lg] != round[i];
+    const RangeKey k{start[i], end[i], round[i]};
+    if (distinct_keys && !cut) cut = keys.count(k) != 0;
+    if (cut) {
+      cuts->push_back(i);
+      for (int t : touched) cur[t] = -1;
+      touched.clear();
+      keys.clear();
+    }
+    if (cur[lg] == -1) touched.push_back(lg);
+    cur[lg] = round[i];
+    if (distinct_keys) keys.insert(k);
+  }
+  cuts->push_back(n);
+}
+}  // namespace
+
+// host-pointer driver shared by the four host entry points
+static int32_t host_ranges(fpx_ctx* ctx, int mode, int32_t n, const int32_t* start, const int32_t* end,
+                           const int32_t* round, const uint64_t* target_masks, const uint64_t* votes_in,
+                           uint64_t* vote_bits, uint64_t* nack_bits, int32_t* nack_round, uint8_t* is_new,
+                           uint8_t* chosen) {
+  int rc = ranges_ctx_ok(ctx, n);
+  if (rc) return rc;
+  if (n == 0) return FPX_OK;
+  if (!start || !end || !round || (mode == RANGES_TALLY && !votes_in)) return FPX_EINVAL;
+  if ((rc = check_ranges(ctx, n, start, end, round))) return rc;
+  const size_t words = (size_t)n * ctx->g.num_groups * 4, per = (size_t)ctx->g.num_groups * 4;
+  RangeStage sg;
+  if ((rc = stage_ranges(ctx, n, &sg))) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(sg.start, start, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(sg.end, end, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(sg.round, round, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (target_masks) HIPCHK(ctx, hipMemcpyAsync(sg.target, target_masks, words * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (mode == RANGES_TALLY) HIPCHK(ctx, hipMemcpyAsync(sg.votes, votes_in, words * 8, hipMemcpyHostToDevice, ctx->stream));
+  HostRun host_run(ctx);
+  std::vector<int> cuts;
+  split_range_runs(ctx, n, start, end, round, mode == RANGES_FUSED || mode == RANGES_ACCEPTORS, mode == RANGES_TALLY, &cuts);
+  for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+    const int lo = cuts[k], len = cuts[k + 1] - cuts[k];
+    RangeBatch b;
+    memset(&b, 0, sizeof(b));
+    b.n = len, b.start = sg.start + lo, b.end = sg.end + lo, b.round = sg.round + lo;
+    b.target = target_masks ? sg.target + (size_t)lo * per : nullptr;
+    b.entry = sg.entry + lo, b.nack_round = sg.nack_round + lo;
+    b.vote_bits = sg.votes + (size_t)lo * per, b.nack_bits = sg.nacks + (size_t)lo * per;
+    b.is_new = sg.is_new + lo, b.chosen = sg.chosen + lo;
+    if (mode == RANGES_TALLY) b.votes_in = sg.votes + (size_t)lo * per;
+    if ((rc = enqueue_ranges(ctx, b, mode))) return rc;
+  }
+  if (vote_bits) HIPCHK(ctx, hipMemcpyAsync(vote_bits, sg.votes, words * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (nack_bits) HIPCHK(ctx, hipMemcpyAsync(nack_bits, sg.nacks, words * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (nack_round) HIPCHK(ctx, hipMemcpyAsync(nack_round, sg.nack_round, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (is_new) HIPCHK(ctx, hipMemcpyAsync(is_new, sg.is_new, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  if (chosen) HIPCHK(ctx, hipMemcpyAsync(chosen, sg.chosen, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  return fetch_status(ctx);
+}
+
+int32_t fpx_noop_ranges_fused(fpx_ctx* ctx, int32_t n, const int32_t* slot_start, const int32_t* slot_end,
+                              const int32_t* round, const uint64_t* target_masks, uint64_t* vote_bits,
+                              uint64_t* nack_bits, int32_t* nack_round, uint8_t* is_new, uint8_t* chosen) {
+  DeviceGuard _dg(ctx);
+  return host_ranges(ctx, RANGES_FUSED, n, slot_start, slot_end, round, target_masks, nullptr, vote_bits, nack_bits,
+                     nack_round, is_new, chosen);
+}
+
+int32_t fpx_acceptor_phase2a_noop_ranges(fpx_ctx* ctx, int32_t n, const int32_t* slot_start, const int32_t* slot_end,
+                                         const int32_t* round, const uint64_t* target_masks, uint64_t* vote_bits,
+                                         uint64_t* nack_bits, int32_t* nack_round) {
+  DeviceGuard _dg(ctx);
+  return host_ranges(ctx, RANGES_ACCEPTORS, n, slot_start, slot_end, round, target_masks, nullptr, vote_bits, nack_bits,
+                     nack_round, nullptr, nullptr);
+}
+
+int32_t fpx_proxy_open_noop_ranges(fpx_ctx* ctx, int32_t n, const int32_t* slot_start, const int32_t* slot_end,
+                                   const int32_t* round, uint8_t* is_new) {
+  DeviceGuard _dg(ctx);
+  return host_ranges(ctx, RANGES_OPEN, n, slot_start, slot_end, round, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     is_new, nullptr);
+}
+
+int32_t fpx_proxy_phase2b_noop_ranges(fpx_ctx* ctx, int32_t n, const int32_t* slot_start, const int32_t* slot_end,
+                                      const int32_t* round, const uint64_t* vote_bits, uint8_t* newly_chosen) {
+  DeviceGuard _dg(ctx);
+  return host_ranges(ctx, RANGES_TALLY, n, slot_start, slot_end, round, nullptr, vote_bits, nullptr, nullptr, nullptr,
+                     nullptr, newly_chosen);
+}
+
+// the single-range entry points: batches of one
 int32_t fpx_acceptor_phase2a_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end, int32_t round,
                                         const uint64_t* target_masks, uint64_t* vote_bits, uint64_t* nack_bits,
                                         int32_t* nack_round) {
-  DeviceGuard _dg(ctx);
-  int rc = range_args_ok(ctx, slot_start, slot_end, round);
-  if (rc) return rc;
-  const int A = ctx->g.num_groups;
-  const size_t words = (size_t)A * 4;
-  if ((rc = grow(ctx, &ctx->d_scratch, (3 * words + 1) * 8))) return rc;
-  uint64_t* d_out = (uint64_t*)ctx->d_scratch.p;  // [A][4] votes, [A][4] nacks, nack_round
-  uint64_t* d_tgt = target_masks ? d_out + 2 * words + 1 : nullptr;
-  HIPCHK(ctx, hipMemsetAsync(d_out, 0, 2 * words * 8, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(d_out + 2 * words, 0xFF, 8, ctx->stream));
-  if (target_masks) HIPCHK(ctx, hipMemcpyAsync(d_tgt, target_masks, words * 8, hipMemcpyHostToDevice, ctx->stream));
-  const int nacc = A * ctx->g.R;
-  hipLaunchKernelGGL(k_noop_scalar, dim3((nacc + 255) / 256), dim3(256), 0, ctx->stream, ctx->g, ctx->st, slot_start,
-                     slot_end, round, d_tgt, d_out);
-  const long long rows = ((long long)slot_end - slot_start + ctx->g.num_leader_groups - 1) / ctx->g.num_leader_groups;
-  if (rows > 0) {
-    const long long cells = rows * ctx->g.R;
-    const int grid = (int)std::max<long long>(1, std::min<long long>((cells + 255) / 256, ctx->num_cus * 16));
-    hipLaunchKernelGGL(k_noop_fill, dim3(grid), dim3(256), 0, ctx->stream, ctx->g, ctx->st, slot_start, slot_end, round,
-                       d_out);
-  }
-  if ((rc = launch_check(ctx))) return rc;
-  std::vector<uint64_t> h(2 * words + 1);
-  HIPCHK(ctx, hipMemcpyAsync(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  if (vote_bits) memcpy(vote_bits, h.data(), words * 8);
-  if (nack_bits) memcpy(nack_bits, h.data() + words, words * 8);
-  if (nack_round) memcpy(nack_round, h.data() + 2 * words, 4);
-  return FPX_OK;
+  return fpx_acceptor_phase2a_noop_ranges(ctx, 1, &slot_start, &slot_end, &round, target_masks, vote_bits, nack_bits,
+                                          nack_round);
 }
 
 int32_t fpx_proxy_open_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end, int32_t round, uint8_t* is_new) {
-  DeviceGuard _dg(ctx);
-  int rc = range_args_ok(ctx, slot_start, slot_end, round);
-  if (rc) return rc;
-  if ((rc = grow(ctx, &ctx->d_u8, 16))) return rc;
-  hipLaunchKernelGGL(k_range_open, dim3(1), dim3(64), 0, ctx->stream, ctx->g, ctx->st, slot_start, slot_end, round,
-                     (uint8_t*)ctx->d_u8.p);
-  if ((rc = launch_check(ctx))) return rc;
-  uint8_t h = 0;
-  HIPCHK(ctx, hipMemcpyAsync(&h, ctx->d_u8.p, 1, hipMemcpyDeviceToHost, ctx->stream));
-  rc = fetch_status(ctx);
-  if (is_new) *is_new = h;
-  return rc;
+  return fpx_proxy_open_noop_ranges(ctx, 1, &slot_start, &slot_end, &round, is_new);
 }
 
 int32_t fpx_proxy_phase2b_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end, int32_t round,
                                      const uint64_t* vote_bits, uint8_t* newly_chosen) {
+  return fpx_proxy_phase2b_noop_ranges(ctx, 1, &slot_start, &slot_end, &round, vote_bits, newly_chosen);
+}
+
+// the proxy leader's tally of one range (parity): state 0 = unknown, 1 = Pending, 2 = Done; votes num_groups x 4 words
+int32_t fpx_read_range_tally(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end, int32_t round, int32_t* state,
+                             uint64_t* vote_bits) {
   DeviceGuard _dg(ctx);
-  int rc = range_args_ok(ctx, slot_start, slot_end, round);
+  int rc = ranges_ctx_ok(ctx, 0);
   if (rc) return rc;
-  if (!vote_bits) return FPX_EINVAL;
   const size_t words = (size_t)ctx->g.num_groups * 4;
-  if ((rc = grow(ctx, &ctx->d_u8, 16))) return rc;
-  if ((rc = h2d(ctx, &ctx->d_bits_a, vote_bits, words))) return rc;
-  hipLaunchKernelGGL(k_range_tally, dim3(1), dim3(64), 0, ctx->stream, ctx->g, ctx->st, slot_start, slot_end, round,
-                     ctx->cfg.f + 1, (const uint64_t*)ctx->d_bits_a.p, (uint8_t*)ctx->d_u8.p);
+  if ((rc = grow(ctx, &ctx->d_scratch, (words + 1) * 8))) return rc;
+  hipLaunchKernelGGL(k_ranges_read, dim3(1), dim3(64), 0, ctx->stream, ctx->g, ctx->rt[ctx->rt_cur], slot_start, slot_end,
+                     round, (uint64_t*)ctx->d_scratch.p);
   if ((rc = launch_check(ctx))) return rc;
-  uint8_t h = 0;
-  HIPCHK(ctx, hipMemcpyAsync(&h, ctx->d_u8.p, 1, hipMemcpyDeviceToHost, ctx->stream));
-  rc = fetch_status(ctx);
-  if (newly_chosen) *newly_chosen = h;
-  return rc;
+  std::vector<uint64_t> h(words + 1);
+  HIPCHK(ctx, hipMemcpyAsync(h.data(), ctx->d_scratch.p, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (state) *state = (int32_t)h[0];
+  if (vote_bits) memcpy(vote_bits, h.data() + 1, words * 8);
+  return FPX_OK;
 }
 
 // ---- f1: replica log ------------------------------------------------------------------------------------
@@ -1479,6 +1736,11 @@ int32_t fpx_state_digest(fpx_ctx* ctx, uint64_t out[8]) {
   const int gt = std::max(1, std::min((g.S + 255) / 256, big));
   hipLaunchKernelGGL(k_digest_tally, dim3(gt), dim3(256), 0, ctx->stream, g, ctx->st, d + 5);
   hipLaunchKernelGGL(k_digest_log, dim3(gt), dim3(256), 0, ctx->stream, g, ctx->st, d + 6);
+  if (ctx->rt[0].key) {
+    const RangeTable& rt = ctx->rt[ctx->rt_cur];
+    hipLaunchKernelGGL(k_digest_ranges, dim3(std::max(1, std::min((rt.cap + 255) / 256, big))), dim3(256), 0, ctx->stream, rt,
+                       g.num_groups * 4, d + 7);
+  }
   if ((rc = launch_check(ctx))) return rc;
   HIPCHK(ctx, hipMemcpyAsync(out, d, 64, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -57,7 +57,6 @@ typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 // single-slot key, mencius/ProxyLeader.scala:86-90).
 enum : uint32_t { KEY_DONE = 0x80000000u, KEY_RANGE = 0x40000000u, KEY_ROUND_MASK = 0x3fffffffu };
 constexpr int MAX_ROUND = 0x3ffffffe;
-constexpr int RANGE_TALLIES = 1024;  // live Mencius noop-range tallies per context
 constexpr int PART_ALL_STRIDE = 32;  // ints: one 128-byte line per shard of the whole-group maxima
 
 // status word layout in HBM (int32[8])
@@ -100,8 +99,6 @@ struct State {
   int32_t* log_value;   // [S]  the replica's log (BufferMap), -1 where absent
   uint8_t* log_present; // [S]
   int32_t* log_scalars; // [8]  LG_*: executedWatermark, numChosen, largestKey, scan result
-  int32_t* rt_key;      // [RANGE_TALLIES][4]  start, end, round, state (0 empty, 1 Pending, 2 Done)
-  uint64_t* rt_bits;    // [RANGE_TALLIES][4]  Phase2bNoopRange votes, bit = acceptorGroup * R + acceptor
 };
 
 struct Batch {
@@ -948,139 +945,6 @@ __global__ void __launch_bounds__(256) k_gather_acceptor(const Geom g, const Sta
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: Mencius noop ranges.
-//   k_noop_scalar  mencius/Acceptor.scala:245-260: per acceptor of the leader group: Nack or round := round
-//   k_noop_fill    mencius/Acceptor.scala:262-277: every slot of [start, end) owned by the leader group
-//                  (slot = start + k * L) gets (round, Noop) from the voting acceptors of its acceptor group
-//   k_range_open   mencius/ProxyLeader.scala:255-303 bookkeeping
-//   k_range_tally  mencius/ProxyLeader.scala:355-411
-// out layout: [A][4] vote bits, [A][4] nack bits, then one int32 nack_round
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-    k_noop_scalar(const Geom g, const State st, int start, int end, int round, const uint64_t* target, uint64_t* out) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int A = g.num_groups, L = g.num_leader_groups;
-  if (e >= A * g.R) return;
-  const int ag = e / g.R, r = e % g.R, bit = g.base + r;
-  if (target && !((target[(size_t)ag * 4 + (bit >> 6)] >> (bit & 63)) & 1ull)) return;
-  const int lg = start % L;  // slotSystem.leader(slotStartInclusive)
-  const size_t acc = (size_t)(lg * A + ag) * g.R + r;
-  const int pr = st.promised[acc];
-  if (round < pr) {  // :245-256 Nack(round = my round)
-    atomicOr((unsigned long long*)&out[(size_t)(A + ag) * 4 + (bit >> 6)], 1ull << (bit & 63));
-    atomicMax(reinterpret_cast<int*>(out + (size_t)2 * A * 4), pr);
-    return;
-  }
-  st.promised[acc] = round;  // :260
-  atomicOr((unsigned long long*)&out[(size_t)ag * 4 + (bit >> 6)], 1ull << (bit & 63));
-  // the largest slot of the range owned by my acceptor group (for maxVotedSlot)
-  const int rows = (end - start + L - 1) / L;
-  for (int j = rows - 1; j >= 0 && j >= rows - A; --j) {
-    const int s = start + j * L;
-    if ((s / L) % A == ag) {
-      if (s > st.max_voted[acc]) st.max_voted[acc] = s;
-      break;
-    }
-  }
-}
-
-__global__ void __launch_bounds__(256)
-    k_noop_fill(const Geom g, const State st, int start, int end, int round, const uint64_t* votes) {
-  const int A = g.num_groups, L = g.num_leader_groups;
-  const long long rows = ((long long)end - start + L - 1) / L;
-  const long long total = rows * g.R;
-  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total;
-       c += (long long)gridDim.x * blockDim.x) {
-    const int s = start + (int)(c / g.R) * L;
-    const int r = (int)(c % g.R);
-    const int ag = (s / L) % A, bit = g.base + r;
-    if ((votes[(size_t)ag * 4 + (bit >> 6)] >> (bit & 63)) & 1ull) {
-      const size_t cell = (size_t)s * g.RS + r;
-      st.vote_round[cell] = round;  // :271-276 State(voteRound = round, voteValue = Noop)
-      st.vote_value[cell] = -1;
-      if (st.row_voted[s] == 0) st.row_voted[s] = 1;
-    }
-  }
-}
-
-__global__ void k_range_open(const Geom g, const State st, int start, int end, int round, uint8_t* is_new) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  *is_new = 0;
-  int free_e = -1;
-  for (int i = 0; i < RANGE_TALLIES; ++i) {
-    const int32_t* k = st.rt_key + (size_t)i * 4;
-    if (k[3] == 0) {
-      if (free_e < 0) free_e = i;
-    } else if (k[0] == start && k[1] == end && k[2] == round) {
-      return;  // :259-266 already known: ignored
-    }
-  }
-  int way = -1;
-  if (end == start + 1) {  // the key collides with the single-slot key (slot, slot + 1, round)
-    const uint32_t* kr = st.pl_key + (size_t)start * g.wp;
-    for (int w = g.ways - 1; w >= 0; --w) {
-      if ((kr[w] & KEY_ROUND_MASK) == (uint32_t)round + 1u) return;
-      if (kr[w] == 0) way = w;
-    }
-    if (way < 0) {
-      report(st, 5, 0, start, round);
-      return;
-    }
-  }
-  if (free_e < 0) {
-    report(st, 5, 0, start, round);
-    return;
-  }
-  int32_t* k = st.rt_key + (size_t)free_e * 4;
-  k[0] = start, k[1] = end, k[2] = round, k[3] = 1;
-  for (int w = 0; w < 4; ++w) st.rt_bits[(size_t)free_e * 4 + w] = 0ull;
-  if (way >= 0) st.pl_key[(size_t)start * g.wp + way] = ((uint32_t)round + 1u) | KEY_RANGE;
-  *is_new = 1;
-}
-
-// votes: [A][4] (bit = acceptor index within the group); quorum = f + 1 from EVERY acceptor group
-__global__ void k_range_tally(const Geom g, const State st, int start, int end, int round, int quorum,
-                              const uint64_t* votes, uint8_t* chosen) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  *chosen = 0;
-  int e = -1;
-  for (int i = 0; i < RANGE_TALLIES && e < 0; ++i) {
-    const int32_t* k = st.rt_key + (size_t)i * 4;
-    if (k[3] != 0 && k[0] == start && k[1] == end && k[2] == round) e = i;
-  }
-  if (e < 0) {
-    // a single-slot tally under the same key swallows the message (:378-385); otherwise fatal (:361-368)
-    if (end == start + 1) {
-      const uint32_t* kr = st.pl_key + (size_t)start * g.wp;
-      for (int w = 0; w < g.ways; ++w)
-        if ((kr[w] & KEY_ROUND_MASK) == (uint32_t)round + 1u) return;
-    }
-    report(st, 2, 0, start, round);
-    return;
-  }
-  int32_t* k = st.rt_key + (size_t)e * 4;
-  if (k[3] == 2) return;  // Done: ignored (:370-376)
-  uint64_t x[4];
-  for (int w = 0; w < 4; ++w) x[w] = st.rt_bits[(size_t)e * 4 + w];
-  const int A = g.num_groups, T = g.total;
-  bool all = true;
-  for (int ag = 0; ag < A; ++ag) {
-    int c = 0;
-    for (int r = 0; r < T; ++r) {
-      const int bit = ag * T + r;
-      if ((votes[(size_t)ag * 4 + (r >> 6)] >> (r & 63)) & 1ull) x[bit >> 6] |= 1ull << (bit & 63);  // :389-390
-      c += (int)((x[bit >> 6] >> (bit & 63)) & 1ull);
-    }
-    all = all && c >= quorum;  // :391
-  }
-  for (int w = 0; w < 4; ++w) st.rt_bits[(size_t)e * 4 + w] = x[w];
-  if (all) {
-    k[3] = 2;  // :410 ; ChosenNoopRange(start, end) :395-407
-    *chosen = 1;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // f1: the replica's log.  Replica.handleChosen (multipaxos/Replica.scala:572-590): a slot that is
 // already in the log is ignored, otherwise log.put + numChosen += 1; executeLog (:394-404) advances
 // executedWatermark over the contiguous prefix.
@@ -1267,6 +1131,29 @@ __global__ void __launch_bounds__(256)
       safe_round[idx] = best_round;
       safe_value[idx] = best_round >= 0 ? best_val : -1;  // Noop when nobody voted (Leader.scala:323-325)
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_probe: the hot kernel's HBM access pattern and nothing else (one wavefront per 32 consecutive rows: read the
+// ballot row, write the two vote rows, 16 B per lane), run by fpx_create on a freshly allocated slab BEFORE it is
+// initialised.  The same kernel on the same box runs 7 % apart depending on where the slab happened to be
+// placed (profiles/r02_placement.txt); create times a few placements and keeps the fastest.
+// ------------------------------------------------------------------------------------------------
+// rows = number of rows touched, in `pieces` equal runs spread evenly over the S rows of the arrays
+__global__ void __launch_bounds__(256) k_probe(int32_t* a_read, int32_t* b_write, int32_t* c_write, int rows, int q4,
+                                               int pieces, long long piece_stride) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int first = wave * 32;
+  const int per_piece = rows / pieces;
+  for (int i = first; i < first + 32 && i < rows; ++i) {
+    if (lane >= q4) continue;
+    const long long r = (long long)(i / per_piece) * piece_stride + i % per_piece;
+    const size_t o = ((size_t)r * q4 + lane) * 4;
+    int4v v = {i, i, i, i};
+    if (a_read) v = *reinterpret_cast<const int4v*>(a_read + o);
+    row_store(v, reinterpret_cast<int4v*>(b_write + o));
+    row_store(v, reinterpret_cast<int4v*>(c_write + o));
   }
 }
 

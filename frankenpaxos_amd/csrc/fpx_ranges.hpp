@@ -1,0 +1,321 @@
+// fpx_ranges.hpp -- K4: Mencius noop ranges as batched gfx950 kernels.
+//
+//   mencius.Acceptor.handlePhase2aNoopRange      mencius/Acceptor.scala:237-291
+//   mencius.ProxyLeader.handlePhase2aNoopRange   mencius/ProxyLeader.scala:255-303
+//   mencius.ProxyLeader.handlePhase2bNoopRange   mencius/ProxyLeader.scala:355-411
+//
+// A Mencius leader that has nothing to propose skips its slots with ONE message per lagging stretch of the
+// log: Phase2aNoopRange(slotStart, slotEnd, round) stands for Noop in every slot of [slotStart, slotEnd) that
+// its leader group owns (slotStart + k * numLeaderGroups).  With 256 leader groups (BASELINE.json configs[4])
+// every tick carries hundreds of such ranges, so they are processed n at a time:
+//
+//   k_ranges_validate   argument ranges; one round per leader group within the launch (the run contract of the
+//                       per-acceptor `round` scalar, as for Phase2a batches)
+//   k_ranges_open       the proxy leader's states map for ranges: an open-addressing hash table keyed by
+//                       (slotStart, slotEnd) + round, claimed with one 64-bit CAS; a key seen twice in one launch
+//                       is the reference's "already received this Phase2aNoopRange: ignoring" for every copy but
+//                       the one with the lowest index
+//   k_ranges_resolve    who opened what (is_new), the per-slot shadow of a length-1 range (its key collides with
+//                       the single-slot tally's, mencius/ProxyLeader.scala:86-90)
+//   k_ranges_acceptors  one thread per (range, acceptor group, acceptor): Nack, or round := round and a vote
+//   k_ranges_fill       (round, Noop) into every owned slot of the range for the voting acceptors
+//   k_ranges_tally      Phase2bNoopRange votes: a quorum f+1 from EVERY acceptor group -> ChosenNoopRange, Done
+//   k_ranges_rehash     garbage collection (fpx_proxy_forget): live entries outside the forgotten window move to
+//                       the other table buffer; nothing is ever deleted in place, so probing needs no tombstones
+//
+// HBM-write-bound where it moves data at all (8 B per voted cell); the rest is a few bytes per range.
+#pragma once
+
+#include "fpx_kernels.hpp"
+
+namespace fpx {
+
+constexpr uint32_t RT_PENDING = 1, RT_DONE = 2;
+
+struct RangeTable {
+  uint64_t* key;    // [cap][2]  k0 = (start + 1) << 32 | end (0 = empty); k1 = stamp << 32 | round << 2 | state
+  uint64_t* bits;   // [cap][A * 4]  Phase2bNoopRange votes per acceptor group (bit = acceptor index)
+  int32_t* owner;   // [cap]  lowest index of the message that inserted the entry in launch `stamp`
+  int32_t* count;   // [1]    entries in use
+  int32_t cap;      // power of two
+};
+
+struct RangeBatch {
+  int32_t n;
+  const int32_t* start;
+  const int32_t* end;
+  const int32_t* round;
+  const uint64_t* target;  // [n][A][4] or null
+  uint64_t* vote_bits;     // [n][A][4]
+  uint64_t* nack_bits;     // [n][A][4]
+  int32_t* nack_round;     // [n]
+  int32_t* entry;          // [n] scratch: table entry of the range, -1 = ignored / invalid
+  uint8_t* is_new;         // [n]
+  uint8_t* chosen;         // [n]
+  const uint64_t* votes_in;  // tally input [n][A][4] (the unfused Phase2bNoopRange entry point)
+  uint32_t run_id;
+  int32_t fused;           // acceptors / fill / tally act only on ranges this launch opened
+  int32_t quorum;          // f + 1
+};
+
+__device__ __forceinline__ uint64_t range_k0(int start, int end) {
+  return ((uint64_t)(uint32_t)(start + 1) << 32) | (uint64_t)(uint32_t)end;
+}
+__device__ __forceinline__ uint32_t range_hash(uint64_t k0) { return (uint32_t)(mix64(k0) >> 20); }
+
+__global__ void __launch_bounds__(256) k_ranges_validate(const Geom g, const State st, const RangeBatch b, int check_round) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.n) return;
+  const int s = b.start[i], e = b.end[i], r = b.round[i];
+  if (s < 0 || e < s || e > g.S || r < 0 || r > MAX_ROUND) {
+    report_abort(st, 1 /*FPX_EINVAL*/, i, s, r);
+    return;
+  }
+  if (check_round) {  // one round per leader group within the launch
+    int* rr = &st.run_round[(s % g.num_leader_groups) * g.num_groups];
+    int cur = __hip_atomic_load(rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == -1) {
+      cur = atomicCAS(rr, -1, r);
+      if (cur == -1) cur = r;
+    }
+    if (cur != r) report_abort(st, 6 /*FPX_EORDER*/, i, s, r);
+  }
+}
+
+// mencius/ProxyLeader.scala:255-303.  lookup = 1: find only (the Phase2bNoopRange entry point).
+__global__ void __launch_bounds__(256) k_ranges_open(const Geom g, const State st, const RangeTable rt, const RangeBatch b, int lookup) {
+  if (st.status[ST_ABORT] != 0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.n) return;
+  const int s = b.start[i], e = b.end[i], rnd = b.round[i];
+  b.entry[i] = -1;
+  const uint32_t want = (uint32_t)rnd + 1u;
+  if (e == s + 1) {
+    // the key (slot, slot + 1, round) is also the key of the single-slot tally: if that one exists -- Pending or
+    // Done -- the range message is swallowed (:259-266 on open, :370-385 on Phase2bNoopRange)
+    const uint32_t* kr = st.pl_key + (size_t)s * g.wp;
+    for (int w = 0; w < g.ways; ++w)
+      if ((kr[w] & KEY_ROUND_MASK) == want && !(kr[w] & KEY_RANGE)) {
+        b.entry[i] = -2;  // swallowed
+        return;
+      }
+  }
+  const uint64_t k0 = range_k0(s, e);
+  const uint32_t mask = (uint32_t)rt.cap - 1u;
+  uint32_t p = range_hash(k0) & mask;
+  for (int probes = 0; probes < rt.cap; ++probes, p = (p + 1) & mask) {
+    uint64_t cur = __hip_atomic_load(&rt.key[(size_t)p * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == 0) {
+      if (lookup) return;  // unknown key
+      if (__hip_atomic_load(rt.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= rt.cap / 2) {
+        report(st, 5 /*FPX_ECAPACITY*/, i, s, rnd);
+        return;
+      }
+      const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&rt.key[(size_t)p * 2]), 0ull, (unsigned long long)k0);
+      if (prev == 0) {  // mine: :295-301 PendingPhase2aNoopRange(phase2a, no votes) -- bits and owner were initialised
+                        // when the table buffer was (entries are never reused in place)
+        rt.key[(size_t)p * 2 + 1] = ((uint64_t)b.run_id << 32) | ((uint64_t)(uint32_t)rnd << 2) | RT_PENDING;
+        atomicAdd(rt.count, 1);
+        atomicMin(&rt.owner[p], i);
+        b.entry[i] = (int)p;
+        return;
+      }
+      cur = prev;  // somebody else claimed the slot between the load and the CAS: look at what is there now
+    }
+    if (cur == k0) {
+      const uint64_t k1 = __hip_atomic_load(&rt.key[(size_t)p * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // k1 == 0: being inserted by another message of THIS launch -- same (start, end), hence (run contract: one
+      // round per leader group) the same round: the same key.  Its stamp says the same once it is written.
+      const bool this_launch = k1 == 0 || (uint32_t)(k1 >> 32) == b.run_id;
+      if (this_launch || (uint32_t)((k1 >> 2) & 0x3fffffffu) == (uint32_t)rnd) {
+        if (this_launch && !lookup) atomicMin(&rt.owner[p], i);
+        b.entry[i] = (int)p;
+        return;
+      }
+      // the same range in another round: a different key, keep probing
+    }
+  }
+  if (!lookup) report(st, 5, i, s, rnd);
+}
+
+// after k_ranges_open: is_new[i] <=> this launch inserted the entry and i is its lowest index; the owner of a
+// new length-1 range also claims the per-slot shadow way
+__global__ void __launch_bounds__(256) k_ranges_resolve(const Geom g, const State st, const RangeTable rt, const RangeBatch b) {
+  if (st.status[ST_ABORT] != 0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.n) return;
+  const int e = b.entry[i];
+  bool fresh = false;
+  if (e >= 0) {
+    const uint64_t k1 = rt.key[(size_t)e * 2 + 1];
+    fresh = (uint32_t)(k1 >> 32) == b.run_id && rt.owner[e] == i;
+  }
+  if (fresh && b.end[i] == b.start[i] + 1) {
+    uint32_t* kr = st.pl_key + (size_t)b.start[i] * g.wp;
+    int way = -1;
+    for (int w = g.ways - 1; w >= 0; --w)
+      if (kr[w] == 0) way = w;
+    if (way < 0) report(st, 5, i, b.start[i], b.round[i]);
+    else kr[way] = ((uint32_t)b.round[i] + 1u) | KEY_RANGE;
+  }
+  if (b.is_new) b.is_new[i] = fresh ? 1 : 0;
+  if (!fresh && b.fused) b.entry[i] = e >= 0 ? -3 - e : e;  // not mine to drive: acceptors / fill / tally skip it
+}
+
+// mencius/Acceptor.scala:237-260, 279-290: one thread per (range, acceptor group, acceptor)
+__global__ void __launch_bounds__(256) k_ranges_acceptors(const Geom g, const State st, const RangeBatch b) {
+  if (st.status[ST_ABORT] != 0) return;
+  const int A = g.num_groups, L = g.num_leader_groups;
+  const long long per = (long long)A * g.R;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= per * b.n) return;
+  const int i = (int)(idx / per), rem = (int)(idx % per);
+  if (b.fused && b.entry[i] < 0) return;
+  const int ag = rem / g.R, r = rem % g.R, bit = g.base + r;
+  const size_t row = ((size_t)i * A + ag) * 4;
+  if (b.target && !((b.target[row + (bit >> 6)] >> (bit & 63)) & 1ull)) return;
+  const int start = b.start[i], end = b.end[i], round = b.round[i];
+  const int lg = start % L;  // slotSystem.leader(slotStartInclusive)
+  const size_t acc = (size_t)(lg * A + ag) * g.R + r;
+  const int pr = st.promised[acc];
+  if (round < pr) {  // :245-256 Nack(round = my round)
+    if (b.nack_bits) atomicOr((unsigned long long*)&b.nack_bits[row + (bit >> 6)], 1ull << (bit & 63));
+    if (b.nack_round) atomicMax(&b.nack_round[i], pr);
+    return;
+  }
+  if (pr != round) st.promised[acc] = round;  // :260 (every message of this leader group carries this round)
+  atomicOr((unsigned long long*)&b.vote_bits[row + (bit >> 6)], 1ull << (bit & 63));
+  // the largest slot of the range owned by my acceptor group (maxVotedSlot)
+  const int rows = (end - start + L - 1) / L;
+  for (int j = rows - 1; j >= 0 && j >= rows - A; --j) {
+    const int s = start + j * L;
+    if ((s / L) % A == ag) {
+      if (s > st.max_voted[acc]) atomicMax(&st.max_voted[acc], s);
+      break;
+    }
+  }
+}
+
+// mencius/Acceptor.scala:262-277: blockIdx.y strides over the ranges, x over the cells of one range
+__global__ void __launch_bounds__(256) k_ranges_fill(const Geom g, const State st, const RangeBatch b) {
+  if (st.status[ST_ABORT] != 0) return;
+  const int A = g.num_groups, L = g.num_leader_groups;
+  for (int i = blockIdx.y; i < b.n; i += gridDim.y) {
+    if (b.fused && b.entry[i] < 0) continue;
+    const int start = b.start[i], end = b.end[i], round = b.round[i];
+    const long long rows = ((long long)end - start + L - 1) / L;
+    const long long total = rows * g.R;
+    const uint64_t* votes = b.vote_bits + (size_t)i * A * 4;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long long)gridDim.x * blockDim.x) {
+      const int s = start + (int)(c / g.R) * L;
+      const int r = (int)(c % g.R);
+      const int ag = (s / L) % A, bit = g.base + r;
+      if ((votes[(size_t)ag * 4 + (bit >> 6)] >> (bit & 63)) & 1ull) {
+        const size_t cell = (size_t)s * g.RS + r;
+        st.vote_round[cell] = round;  // :271-276 State(voteRound = round, voteValue = Noop)
+        st.vote_value[cell] = -1;
+        if (st.row_voted[s] == 0) st.row_voted[s] = 1;
+      }
+    }
+  }
+}
+
+// mencius/ProxyLeader.scala:355-411: one thread per range
+__global__ void __launch_bounds__(256) k_ranges_tally(const Geom g, const State st, const RangeTable rt, const RangeBatch b) {
+  if (st.status[ST_ABORT] != 0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.n) return;
+  uint8_t ch = 0;
+  const int e = b.entry[i];
+  const int A = g.num_groups;
+  const uint64_t* in = (b.votes_in ? b.votes_in : b.vote_bits) + (size_t)i * A * 4;
+  if (e == -1 && !b.fused) {
+    // never opened: fatal (:361-368) -- unless the message carries no vote at all ("no message")
+    bool any = false;
+    for (int w = 0; w < A * 4; ++w) any = any || in[w] != 0;
+    if (any) report(st, 2 /*FPX_EFATAL_UNKNOWN_SLOTROUND*/, i, b.start[i], b.round[i]);
+  } else if (e >= 0) {
+    uint64_t* k1p = &rt.key[(size_t)e * 2 + 1];
+    if ((uint32_t)(*k1p & 3u) == RT_PENDING) {  // Done: ignored (:370-376)
+      uint64_t* bits = rt.bits + (size_t)e * A * 4;
+      bool all = true;
+      for (int ag = 0; ag < A; ++ag) {
+        int c = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const uint64_t x = bits[ag * 4 + w] | (in[ag * 4 + w] & g.member[w]);  // :389-390
+          bits[ag * 4 + w] = x;
+          c += __popcll(x);
+        }
+        all = all && c >= b.quorum;  // :391
+      }
+      if (all) {
+        *k1p = (*k1p & ~3ull) | RT_DONE;  // :410 ; ChosenNoopRange(start, end) :395-407
+        ch = 1;
+      }
+    }
+  }
+  if (b.chosen) b.chosen[i] = ch;
+}
+
+// fpx_proxy_forget: live entries that do not lie inside [first, first + count) move to the other buffer
+__global__ void __launch_bounds__(256) k_ranges_rehash(const RangeTable from, const RangeTable to, int words, int first, int count) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= from.cap) return;
+  const uint64_t k0 = from.key[(size_t)p * 2];
+  if (k0 == 0) return;
+  const int start = (int)(uint32_t)(k0 >> 32) - 1, end = (int)(uint32_t)k0;
+  if (start >= first && (long long)end <= (long long)first + count) return;  // forgotten
+  const uint32_t mask = (uint32_t)to.cap - 1u;
+  uint32_t q = range_hash(k0) & mask;
+  for (int probes = 0; probes < to.cap; ++probes, q = (q + 1) & mask) {
+    if (atomicCAS(reinterpret_cast<unsigned long long*>(&to.key[(size_t)q * 2]), 0ull, (unsigned long long)k0) == 0) {
+      to.key[(size_t)q * 2 + 1] = from.key[(size_t)p * 2 + 1];
+      to.owner[q] = from.owner[p];
+      for (int w = 0; w < words; ++w) to.bits[(size_t)q * words + w] = from.bits[(size_t)p * words + w];
+      atomicAdd(to.count, 1);
+      return;
+    }
+  }
+}
+
+// readback of one range tally (parity): out[0] = state (0 unknown, 1 Pending, 2 Done), then A * 4 words of votes
+__global__ void k_ranges_read(const Geom g, const RangeTable rt, int start, int end, int round, uint64_t* out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const int words = g.num_groups * 4;
+  out[0] = 0;
+  for (int w = 0; w < words; ++w) out[1 + w] = 0;
+  const uint64_t k0 = range_k0(start, end);
+  const uint32_t mask = (uint32_t)rt.cap - 1u;
+  uint32_t p = range_hash(k0) & mask;
+  for (int probes = 0; probes < rt.cap; ++probes, p = (p + 1) & mask) {
+    const uint64_t cur = rt.key[(size_t)p * 2];
+    if (cur == 0) return;
+    const uint64_t k1 = rt.key[(size_t)p * 2 + 1];
+    if (cur == k0 && (uint32_t)((k1 >> 2) & 0x3fffffffu) == (uint32_t)round) {
+      out[0] = k1 & 3u;
+      if ((k1 & 3u) == RT_PENDING)
+        for (int w = 0; w < words; ++w) out[1 + w] = rt.bits[(size_t)p * words + w];
+      return;
+    }
+  }
+}
+
+// digest of the range tallies (fpx_state_digest out[7]): order-independent sum over the live entries
+__global__ void __launch_bounds__(256) k_digest_ranges(const RangeTable rt, int words, uint64_t* out) {
+  uint64_t acc = 0;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < rt.cap; p += gridDim.x * blockDim.x) {
+    const uint64_t k0 = rt.key[(size_t)p * 2];
+    if (k0 == 0) continue;
+    const uint64_t k1 = rt.key[(size_t)p * 2 + 1];
+    const uint64_t done = (k1 & 3u) == RT_DONE ? 1ull : 0ull;
+    // (start, end, round, Done?) then the votes of a Pending entry
+    uint64_t t = mix64((k0 - (1ull << 32)) * 0x9E3779B97F4A7C15ull + (((k1 >> 2) & 0x3fffffffull) << 1) + done);
+    if (!done)
+      for (int w = 0; w < words; ++w) t = mix64(t ^ rt.bits[(size_t)p * words + w]);
+    acc += t;
+  }
+  block_add_u64(acc, out);
+}
+
+}  // namespace fpx

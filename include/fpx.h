@@ -244,7 +244,7 @@ int32_t fpx_proxy_phase2b_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, co
 
 /* Garbage collection of the proxy leader (NOT in the reference, whose ProxyLeader.states grows forever,
  * ProxyLeader.scala:135): forgets every tally -- Pending or Done -- of the slots
- * [first_slot, first_slot + count), so that a long-running simulation can re-propose a chosen-and-executed
+ * [first_slot, first_slot + count) and every noop-range tally whose range lies inside that window, so that a long-running simulation can re-propose a chosen-and-executed
  * window of the log in further rounds without exhausting tally_ways.  Acceptor state is untouched.
  * Asynchronous on the context's stream.  After it, a Phase2b for a forgotten (slot, round) is "unknown". */
 int32_t fpx_proxy_forget(fpx_ctx* ctx, int32_t first_slot, int32_t count);
@@ -263,29 +263,59 @@ int32_t fpx_phase2_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, con
                              int32_t* d_nack_round);
 
 /* ---- a2/a4 (K4): Mencius noop ranges -----------------------------------------------------------------
- * Needs FPX_BALLOT_ACCEPTOR and num_groups * replicas_total <= 256.  Rounds must be < 2^30 - 1
- * everywhere (one key bit marks the per-slot shadow of a length-1 range).
+ * Needs FPX_BALLOT_ACCEPTOR.  Rounds must be < 2^30 - 1 everywhere (one key bit marks the per-slot shadow of
+ * a length-1 range).  A leader with nothing to propose skips a stretch of its slots with ONE message per
+ * stretch; with hundreds of leader groups a tick carries hundreds of them, so every entry point takes n
+ * ranges (slot_start[i], slot_end[i], round[i]), processed as if delivered in array order.  Bitmaps are
+ * num_groups x 4 words PER RANGE (bit = acceptor index within its acceptor group), so a batch's are
+ * n x num_groups x 4.
  *
- * mencius.Acceptor.handlePhase2aNoopRange (mencius/Acceptor.scala:237-291) delivered to the acceptors
- * of EVERY acceptor group of the leader group that owns slot_start (the proxy leader relays a range to
- * each group, mencius/ProxyLeader.scala:276-291), selected by target_masks (num_groups x 4 words,
- * NULL = all).  An acceptor with round > `round` Nacks; otherwise round := `round` and every slot of
- * [slot_start, slot_end) owned by its acceptor group (slot = slot_start + k * num_leader_groups with
- * (slot / num_leader_groups) % num_groups == its group) votes (round, Noop).  Outputs (may be NULL):
- * vote_bits / nack_bits num_groups x 4 words, nack_round = largest round carried by a Nack or -1. */
+ * mencius.Acceptor.handlePhase2aNoopRange (mencius/Acceptor.scala:237-291) delivered to the acceptors of
+ * EVERY acceptor group of the leader group that owns slot_start (the proxy leader relays a range to each
+ * group, mencius/ProxyLeader.scala:276-291), selected by target_masks (NULL = all).  An acceptor with
+ * round > `round` Nacks; otherwise round := `round` and every slot of [slot_start, slot_end) owned by its
+ * acceptor group (slot = slot_start + k * num_leader_groups with (slot / num_leader_groups) % num_groups ==
+ * its group) votes (round, Noop).  Outputs (may be NULL): vote_bits / nack_bits, nack_round[i] = largest round
+ * carried by a Nack for range i or -1. */
+int32_t fpx_acceptor_phase2a_noop_ranges(fpx_ctx* ctx, int32_t n, const int32_t* slot_start,
+                                         const int32_t* slot_end, const int32_t* round,
+                                         const uint64_t* target_masks, uint64_t* vote_bits,
+                                         uint64_t* nack_bits, int32_t* nack_round);
+/* mencius.ProxyLeader.handlePhase2aNoopRange bookkeeping (mencius/ProxyLeader.scala:255-303): opens
+ * PendingPhase2aNoopRange for (slot_start, slot_end, round); a known key -- also an earlier message of the
+ * same batch -- is ignored (is_new = 0).  The tallies live in a hash table of the context (capacity: a few
+ * hundred ranges in flight per leader group; FPX_ECAPACITY beyond it); fpx_proxy_forget reclaims those of
+ * a slot window, Pending and Done alike. */
+int32_t fpx_proxy_open_noop_ranges(fpx_ctx* ctx, int32_t n, const int32_t* slot_start, const int32_t* slot_end,
+                                   const int32_t* round, uint8_t* is_new);
+/* mencius.ProxyLeader.handlePhase2bNoopRange (mencius/ProxyLeader.scala:355-411).  Unknown key ->
+ * FPX_EFATAL_UNKNOWN_SLOTROUND; Done or a single-slot tally under the same key -> ignored; ChosenNoopRange
+ * (newly_chosen = 1) once every acceptor group has f+1 votes. */
+int32_t fpx_proxy_phase2b_noop_ranges(fpx_ctx* ctx, int32_t n, const int32_t* slot_start, const int32_t* slot_end,
+                                      const int32_t* round, const uint64_t* vote_bits, uint8_t* newly_chosen);
+/* The fused step for ranges = open + acceptors + tally (the K3 of noop ranges): a range that is already
+ * known is neither forwarded nor tallied again.  Outputs may be NULL.  The _dev form takes device pointers,
+ * enqueues on the context's stream and needs one round per leader group within the batch (the run contract;
+ * FPX_EORDER otherwise, nothing applied); the host form cuts any batch into such runs itself. */
+int32_t fpx_noop_ranges_fused(fpx_ctx* ctx, int32_t n, const int32_t* slot_start, const int32_t* slot_end,
+                              const int32_t* round, const uint64_t* target_masks, uint64_t* vote_bits,
+                              uint64_t* nack_bits, int32_t* nack_round, uint8_t* is_new, uint8_t* chosen);
+int32_t fpx_noop_ranges_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot_start,
+                                  const int32_t* d_slot_end, const int32_t* d_round,
+                                  const uint64_t* d_target_masks, uint64_t* d_vote_bits, uint64_t* d_nack_bits,
+                                  int32_t* d_nack_round, uint8_t* d_is_new, uint8_t* d_chosen);
+/* batches of one (bitmaps num_groups x 4 words) */
 int32_t fpx_acceptor_phase2a_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end,
                                         int32_t round, const uint64_t* target_masks,
                                         uint64_t* vote_bits, uint64_t* nack_bits, int32_t* nack_round);
-/* mencius.ProxyLeader.handlePhase2aNoopRange bookkeeping (mencius/ProxyLeader.scala:255-303): opens
- * PendingPhase2aNoopRange for (slot_start, slot_end, round); a known key is ignored (is_new = 0). */
 int32_t fpx_proxy_open_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end, int32_t round,
                                   uint8_t* is_new);
-/* mencius.ProxyLeader.handlePhase2bNoopRange (mencius/ProxyLeader.scala:355-411): vote_bits is
- * num_groups x 4 words (bit = acceptor index in its group).  Unknown key -> FPX_EFATAL_UNKNOWN_SLOTROUND;
- * Done or a single-slot tally under the same key -> ignored; ChosenNoopRange (newly_chosen = 1) once
- * every acceptor group has f+1 votes. */
 int32_t fpx_proxy_phase2b_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end, int32_t round,
                                      const uint64_t* vote_bits, uint8_t* newly_chosen);
+/* readback (parity): state 0 = unknown key, 1 = Pending, 2 = Done; vote_bits num_groups x 4 words (zero
+ * unless Pending) */
+int32_t fpx_read_range_tally(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end, int32_t round, int32_t* state,
+                             uint64_t* vote_bits);
 
 /* ---- a9 (K5): EPaxos pre-accept fast path -------------------------------------------------------------
  * One tick of FRESH instances through the pre-accept phase of n = 2f+1 EPaxos replicas with the
@@ -444,7 +474,7 @@ int32_t fpx_profile_read_collective(fpx_ctx* ctx, int32_t* launches, double* tot
 /* Whole-state digests for parity checks at sizes where a readback is gigabytes: out[0..6] =
  * vote_round cells, vote_value cells, ballot cells (0 in FPX_BALLOT_ACCEPTOR mode), acceptors' rounds,
  * acceptors' maxVotedSlot, the proxy leader's single-slot tallies, the replica's log (+ executedWatermark,
- * numChosen); out[7] = 0.  Each is an order-independent wrapping sum of a 64-bit hash per element (per cell
+ * numChosen), the proxy leader's noop-range tallies.  Each is an order-independent wrapping sum of a 64-bit hash per element (per cell
  * (slot, acceptor): splitmix64-finalise((slot * R + acceptor) * 0x9E3779B97F4A7C15 + (uint32)value + 1)), so
  * equal digests <=> equal state up to 2^-64.  Waits for the stream. */
 int32_t fpx_state_digest(fpx_ctx* ctx, uint64_t out[8]);

@@ -349,6 +349,8 @@ typedef struct {
   int state;     /* 0 empty, 1 Pending, 2 Done */
   int value;     /* pending.phase2a.commandBatchOrNoop */
   uint64_t v[4]; /* phase2bs.keys as a set of acceptor bits */
+  uint64_t* rv;  /* PendingPhase2aNoopRange.phase2bNoopRanges: one 256-bit set of acceptor indices per acceptor
+                    group (num_groups x 4 words), mencius/ProxyLeader.scala:99-104, 295-301 */
   int seq;       /* insertion order (for fpo_read_tally) */
 } tally_t;
 
@@ -416,6 +418,7 @@ void fpo_sys_reset(fpo_sys* s) {
   for (size_t i = 0; i < nc; ++i) s->vote_round[i] = -1, s->vote_value[i] = -1;
   if (s->ballot)
     for (size_t i = 0; i < nc; ++i) s->ballot[i] = -1;
+  for (size_t i = 0; i < s->tab_cap; ++i) free(s->tab[i].rv);
   memset(s->tab, 0, sizeof(tally_t) * s->tab_cap);
   s->tab_n = 0;
   s->seq = 0;
@@ -450,6 +453,7 @@ void fpo_sys_free(fpo_sys* s) {
   free(s->vote_round);
   free(s->vote_value);
   free(s->ballot);
+  for (size_t i = 0; i < s->tab_cap; ++i) free(s->tab[i].rv);
   free(s->tab);
   if (s->log) fpo_log_free(s->log);
   free(s);
@@ -649,7 +653,7 @@ static tally_t* tab_insert(fpo_sys* s, uint64_t key) {
 }
 
 /* GC extension of fpx.h (fpx_proxy_forget; not in the reference): drop every single-slot tally of the
- * slots [first_slot, first_slot + count) */
+ * slots [first_slot, first_slot + count) and every noop-range tally whose range lies inside that window */
 int fpo_proxy_forget(fpo_sys* s, int32_t first_slot, int32_t count) {
   if (first_slot < 0 || count < 0 || (int64_t)first_slot + count > s->cfg.num_slots) return FPO_EINVAL;
   tally_t* old = s->tab;
@@ -661,6 +665,10 @@ int fpo_proxy_forget(fpo_sys* s, int32_t first_slot, int32_t count) {
     if (old[i].state == 0) continue;
     int slot = (int)(old[i].key >> 32);
     if (!old[i].is_range && slot >= first_slot && slot < first_slot + count) continue;
+    if (old[i].is_range && slot >= first_slot && (int64_t)old[i].end <= (int64_t)first_slot + count) {
+      free(old[i].rv);
+      continue;
+    }
     size_t j = thash(old[i].key) & mask;
     while (s->tab[j].state != 0) j = (j + 1) & mask;
     s->tab[j] = old[i];
@@ -738,6 +746,7 @@ int fpo_proxy_handle_phase2a_noop_range(fpo_sys* s, int slot_start, int slot_end
   t->is_range = 1;
   t->state = 1;
   t->value = -1;
+  t->rv = (uint64_t*)calloc((size_t)s->cfg.num_groups * 4, sizeof(uint64_t)); /* :295-301 Buffer.fill(groups)(Map()) */
   return 1;
 }
 
@@ -752,12 +761,11 @@ int fpo_proxy_handle_phase2b_noop_range(fpo_sys* s, int acceptor_group, int acce
   if (t->state == 2) return 2;       /* :370-376 */
   if (!t->is_range) return 2;        /* :378-385 PendingPhase2a => ignored */
   /* :389-390  phase2bs(acceptorGroupIndex)(acceptorIndex) = phase2b */
-  int bit = acceptor_group * R + acceptor_index;
-  t->v[bit >> 6] |= 1ull << (bit & 63);
+  t->rv[(size_t)acceptor_group * 4 + (acceptor_index >> 6)] |= 1ull << (acceptor_index & 63);
   /* :391  if (phase2bs.exists(_.size < config.quorumSize)) return */
   for (int ag = 0; ag < A; ++ag) {
     int c = 0;
-    for (int r = 0; r < R; ++r) c += test_bit(t->v, ag * R + r);
+    for (int r = 0; r < R; ++r) c += test_bit(t->rv + (size_t)ag * 4, r);
     if (c < s->cfg.f + 1) return 0;
   }
   t->state = 2; /* :410 ; ChosenNoopRange(start, end) :395-407 */
@@ -817,6 +825,95 @@ int fpo_proxy_phase2b_noop_range(fpo_sys* s, int32_t slot_start, int32_t slot_en
     }
   if (newly_chosen) *newly_chosen = (uint8_t)chosen;
   return status;
+}
+
+/* batches of n ranges, delivered in array order (fpx_*_noop_ranges of fpx.h); bitmaps n x num_groups x 4 */
+int fpo_acceptor_phase2a_noop_ranges(fpo_sys* s, int32_t n, const int32_t* start, const int32_t* end,
+                                     const int32_t* round, const uint64_t* target_masks, uint64_t* vote_bits,
+                                     uint64_t* nack_bits, int32_t* nack_round) {
+  const size_t per = (size_t)s->cfg.num_groups * 4;
+  for (int i = 0; i < n; ++i)
+    if (start[i] < 0 || end[i] < start[i] || end[i] > s->cfg.num_slots || round[i] < 0) {
+      s->err_index = i, s->err_slot = start[i], s->err_round = round[i];
+      return FPO_EINVAL;
+    }
+  for (int i = 0; i < n; ++i) {
+    int rc = fpo_acceptor_phase2a_noop_range(s, start[i], end[i], round[i], target_masks ? target_masks + i * per : NULL,
+                                             vote_bits ? vote_bits + i * per : NULL,
+                                             nack_bits ? nack_bits + i * per : NULL, nack_round ? nack_round + i : NULL);
+    if (rc) return rc;
+  }
+  return FPO_OK;
+}
+
+int fpo_proxy_open_noop_ranges(fpo_sys* s, int32_t n, const int32_t* start, const int32_t* end, const int32_t* round,
+                               uint8_t* is_new) {
+  for (int i = 0; i < n; ++i) {
+    int rc = fpo_proxy_open_noop_range(s, start[i], end[i], round[i], is_new ? is_new + i : NULL);
+    if (rc) return rc;
+  }
+  return FPO_OK;
+}
+
+int fpo_proxy_phase2b_noop_ranges(fpo_sys* s, int32_t n, const int32_t* start, const int32_t* end,
+                                  const int32_t* round, const uint64_t* vote_bits, uint8_t* newly_chosen) {
+  const size_t per = (size_t)s->cfg.num_groups * 4;
+  int status = FPO_OK;
+  for (int i = 0; i < n; ++i) {
+    int rc = fpo_proxy_phase2b_noop_range(s, start[i], end[i], round[i], vote_bits + i * per,
+                                          newly_chosen ? newly_chosen + i : NULL);
+    if (rc && status == FPO_OK) {
+      status = rc;
+      s->err_index = i;
+    }
+  }
+  return status;
+}
+
+/* the fused step for ranges: per range, in order, ProxyLeader.handlePhase2aNoopRange (a known key: the message is
+ * ignored, not forwarded), the acceptors, then their Phase2bNoopRange's back to the proxy leader */
+int fpo_noop_ranges_fused(fpo_sys* s, int32_t n, const int32_t* start, const int32_t* end, const int32_t* round,
+                          const uint64_t* target_masks, uint64_t* vote_bits, uint64_t* nack_bits, int32_t* nack_round,
+                          uint8_t* is_new, uint8_t* chosen) {
+  const size_t per = (size_t)s->cfg.num_groups * 4;
+  if (s->cfg.ballot_mode != 0) return FPO_EINVAL;
+  for (int i = 0; i < n; ++i)
+    if (start[i] < 0 || end[i] < start[i] || end[i] > s->cfg.num_slots || round[i] < 0) {
+      s->err_index = i, s->err_slot = start[i], s->err_round = round[i];
+      return FPO_EINVAL;
+    }
+  uint64_t* vb = (uint64_t*)malloc(sizeof(uint64_t) * per);
+  for (int i = 0; i < n; ++i) {
+    uint8_t fresh = 0, ch = 0;
+    memset(vb, 0, sizeof(uint64_t) * per);
+    if (nack_bits) memset(nack_bits + i * per, 0, sizeof(uint64_t) * per);
+    if (nack_round) nack_round[i] = -1;
+    fpo_proxy_open_noop_range(s, start[i], end[i], round[i], &fresh);
+    if (fresh) {
+      fpo_acceptor_phase2a_noop_range(s, start[i], end[i], round[i], target_masks ? target_masks + i * per : NULL, vb,
+                                      nack_bits ? nack_bits + i * per : NULL, nack_round ? nack_round + i : NULL);
+      fpo_proxy_phase2b_noop_range(s, start[i], end[i], round[i], vb, &ch);
+    }
+    if (vote_bits) memcpy(vote_bits + i * per, vb, sizeof(uint64_t) * per);
+    if (is_new) is_new[i] = fresh;
+    if (chosen) chosen[i] = ch;
+  }
+  free(vb);
+  return FPO_OK;
+}
+
+/* state 0 = unknown key, 1 = Pending, 2 = Done; votes (num_groups x 4 words) of a Pending range */
+int fpo_read_range_tally(fpo_sys* s, int32_t start, int32_t end, int32_t round, int32_t* state, uint64_t* vote_bits) {
+  const size_t per = (size_t)s->cfg.num_groups * 4;
+  tally_t* t = tab_find2(s, tkey(start, round), end);
+  if (vote_bits) memset(vote_bits, 0, sizeof(uint64_t) * per);
+  if (!t || !t->is_range) {
+    if (state) *state = 0;
+    return FPO_OK;
+  }
+  if (state) *state = t->state;
+  if (vote_bits && t->state == 1) memcpy(vote_bits, t->rv, sizeof(uint64_t) * per);
+  return FPO_OK;
 }
 
 /* ---- batch entry points (same semantics as fpx.h host entry points) --------------------------- */
@@ -1222,6 +1319,16 @@ int fpo_state_digest(fpo_sys* s, uint64_t out[8]) {
     }
     out[6] += dg_mix64((uint64_t)(uint32_t)wm * 0x9E3779B97F4A7C15ull + 7ull) +
               dg_mix64((uint64_t)(uint32_t)nch * 0x9E3779B97F4A7C15ull + 11ull);
+  }
+  for (size_t i = 0; i < s->tab_cap; ++i) { /* the noop-range tallies */
+    const tally_t* t = &s->tab[i];
+    if (t->state == 0 || !t->is_range) continue;
+    const uint64_t done = t->state == 2 ? 1ull : 0ull;
+    const uint64_t start = t->key >> 32, round = (uint32_t)t->key;
+    uint64_t h = dg_mix64(((start << 32) | (uint32_t)t->end) * 0x9E3779B97F4A7C15ull + (round << 1) + done);
+    if (!done)
+      for (int w = 0; w < s->cfg.num_groups * 4; ++w) h = dg_mix64(h ^ t->rv[w]);
+    out[7] += h;
   }
   return FPO_OK;
 }

@@ -136,6 +136,20 @@ int fpo_proxy_open_noop_range(fpo_sys* sys, int32_t slot_start, int32_t slot_end
 int fpo_proxy_phase2b_noop_range(fpo_sys* sys, int32_t slot_start, int32_t slot_end, int32_t round,
                                  const uint64_t* vote_bits, uint8_t* newly_chosen);
 
+/* batched / fused forms (fpx_*_noop_ranges, fpx_noop_ranges_fused of fpx.h): n ranges in array order */
+int fpo_acceptor_phase2a_noop_ranges(fpo_sys* sys, int32_t n, const int32_t* start, const int32_t* end,
+                                     const int32_t* round, const uint64_t* target_masks, uint64_t* vote_bits,
+                                     uint64_t* nack_bits, int32_t* nack_round);
+int fpo_proxy_open_noop_ranges(fpo_sys* sys, int32_t n, const int32_t* start, const int32_t* end,
+                               const int32_t* round, uint8_t* is_new);
+int fpo_proxy_phase2b_noop_ranges(fpo_sys* sys, int32_t n, const int32_t* start, const int32_t* end,
+                                  const int32_t* round, const uint64_t* vote_bits, uint8_t* newly_chosen);
+int fpo_noop_ranges_fused(fpo_sys* sys, int32_t n, const int32_t* start, const int32_t* end, const int32_t* round,
+                          const uint64_t* target_masks, uint64_t* vote_bits, uint64_t* nack_bits, int32_t* nack_round,
+                          uint8_t* is_new, uint8_t* chosen);
+int fpo_read_range_tally(fpo_sys* sys, int32_t start, int32_t end, int32_t round, int32_t* state, uint64_t* vote_bits);
+int fpo_proxy_forget(fpo_sys* sys, int32_t first_slot, int32_t count);
+
 /* f1: Replica.handleChosen per message (multipaxos/Replica.scala:572-590) on the system's replica log */
 int fpo_replica_chosen(fpo_sys* sys, int32_t n, const int32_t* slot, const int32_t* value_id,
                        const uint8_t* mask, int32_t* executed_watermark, int32_t* num_chosen);

@@ -117,6 +117,12 @@ def lib():
                                                   U64P, I32P]
     L.fpo_proxy_open_noop_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, U8P]
     L.fpo_proxy_phase2b_noop_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, U64P, U8P]
+    L.fpo_acceptor_phase2a_noop_ranges.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, U64P, U64P, U64P, I32P]
+    L.fpo_proxy_open_noop_ranges.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, U8P]
+    L.fpo_proxy_phase2b_noop_ranges.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, U64P, U8P]
+    L.fpo_noop_ranges_fused.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, U64P, U64P, U64P, I32P, U8P, U8P]
+    L.fpo_read_range_tally.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, I32P, U64P]
+    L.fpo_proxy_forget.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     L.fpo_replica_chosen.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, U8P, I32P, I32P]
     L.fpo_replica_chosen_noop_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32, I32P, I32P]
     L.fpo_replica_read_log.argtypes = [C.c_void_p, C.c_int32, C.c_int32, I32P, U8P]
@@ -379,6 +385,58 @@ class System:
         st = lib().fpo_proxy_phase2b_noop_range(self._h, slot_start, slot_end, round_,
                                                 _p(vote_bits, U64P), C.byref(ch))
         return st, ch.value
+
+    def _ranges(self, slot_start, slot_end, round_):
+        return _i32(np.atleast_1d(slot_start)), _i32(np.atleast_1d(slot_end)), _i32(np.atleast_1d(round_))
+
+    def acceptor_phase2a_noop_ranges(self, slot_start, slot_end, round_, target_masks=None):
+        s, e, r = self._ranges(slot_start, slot_end, round_)
+        n, A = len(s), self.cfg.num_groups
+        target_masks = _u64(target_masks)
+        vb = np.zeros((n, A, 4), np.uint64)
+        nb = np.zeros((n, A, 4), np.uint64)
+        nr = np.full(n, -1, np.int32)
+        st = lib().fpo_acceptor_phase2a_noop_ranges(self._h, n, _p(s, I32P), _p(e, I32P), _p(r, I32P),
+                                                    _p(target_masks, U64P), _p(vb, U64P), _p(nb, U64P), _p(nr, I32P))
+        return st, vb, nb, nr
+
+    def proxy_open_noop_ranges(self, slot_start, slot_end, round_):
+        s, e, r = self._ranges(slot_start, slot_end, round_)
+        new = np.zeros(len(s), np.uint8)
+        st = lib().fpo_proxy_open_noop_ranges(self._h, len(s), _p(s, I32P), _p(e, I32P), _p(r, I32P), _p(new, U8P))
+        return st, new
+
+    def proxy_phase2b_noop_ranges(self, slot_start, slot_end, round_, vote_bits):
+        s, e, r = self._ranges(slot_start, slot_end, round_)
+        vote_bits = _u64(vote_bits)
+        ch = np.zeros(len(s), np.uint8)
+        st = lib().fpo_proxy_phase2b_noop_ranges(self._h, len(s), _p(s, I32P), _p(e, I32P), _p(r, I32P),
+                                                 _p(vote_bits, U64P), _p(ch, U8P))
+        return st, ch
+
+    def noop_ranges_fused(self, slot_start, slot_end, round_, target_masks=None):
+        s, e, r = self._ranges(slot_start, slot_end, round_)
+        n, A = len(s), self.cfg.num_groups
+        target_masks = _u64(target_masks)
+        vb = np.zeros((n, A, 4), np.uint64)
+        nb = np.zeros((n, A, 4), np.uint64)
+        nr = np.full(n, -1, np.int32)
+        new = np.zeros(n, np.uint8)
+        ch = np.zeros(n, np.uint8)
+        st = lib().fpo_noop_ranges_fused(self._h, n, _p(s, I32P), _p(e, I32P), _p(r, I32P), _p(target_masks, U64P),
+                                         _p(vb, U64P), _p(nb, U64P), _p(nr, I32P), _p(new, U8P), _p(ch, U8P))
+        return st, vb, nb, nr, new, ch
+
+    def read_range_tally(self, slot_start, slot_end, round_):
+        state = C.c_int32()
+        bits = np.zeros((self.cfg.num_groups, 4), np.uint64)
+        lib().fpo_read_range_tally(self._h, slot_start, slot_end, round_, C.byref(state), _p(bits, U64P))
+        return state.value, bits
+
+    def proxy_forget(self, first_slot, count):
+        st = lib().fpo_proxy_forget(self._h, first_slot, count)
+        if st:
+            raise ValueError("FPX_EINVAL")
 
     def replica_chosen(self, slot, value, mask=None):
         slot, value = _i32(slot), _i32(value)

@@ -83,3 +83,96 @@ def test_config2_64k_slots_3_acceptors_adversarial(fa, oracle):
     for fused in (True, False):
         script = W.adversarial_script(S, 3, 2, 17, epochs=64, fused=fused)
         run_both(fa, oracle, script, range(0, S, 4099), num_slots=S, num_replicas=3, f=1, tally_ways=8)
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4]: Mencius, 256 rotating leader groups, 4M slots, 3 acceptors per group (f = 1)
+# ---------------------------------------------------------------------------------------------------
+def mencius_stream(S, L, R, epochs, seed):
+    """A Mencius-shaped stream (mencius/Leader.scala:342-345, 455; ProxyLeader.scala:231-234): slot s belongs to
+    leader group s % L.  Per epoch (a band of rows of the log) about half of the leader groups have commands and
+    propose them in their own slots; the others have nothing to say and skip their slots of the band with noop
+    ranges (one or two Phase2aNoopRange per group and epoch).  Leader groups move through rounds independently:
+    now and then a competing leader of a group pre-promises some acceptors (its Phase2a's of that epoch get
+    Nacked by them), then takes over in the next epoch.  Yields ops for either backend."""
+    rng = W.Rng(seed)
+    rows_per = (S // L) // epochs
+    rounds = np.zeros(L, np.int64)
+    pending = {}
+    for e in range(epochs):
+        nprng = rng.np_rng()
+        for lg, rnd in pending.items():            # the challengers of the last epoch finish Phase 1 and take over
+            rounds[lg] = rnd
+            yield ("phase1a", int(lg), int(rnd), 0, None)
+        pending = {}
+        for lg in nprng.choice(L, size=6, replace=False):
+            rnd = W.next_classic_round(2, (e + 1) % 2, int(rounds[lg]))
+            pending[int(lg)] = rnd
+            pre = W.bits_from_bool(W.random_subsets(nprng, 1, R, 1, 1))[0]
+            yield ("phase1a", int(lg), int(rnd), 0, pre)
+        active = nprng.random(L) < 0.5
+        rows = np.arange(e * rows_per, (e + 1) * rows_per, dtype=np.int64)
+        slot = (rows[:, None] * L + np.nonzero(active)[0][None, :]).reshape(-1).astype(np.int32)   # ascending
+        rr = rounds[slot % L].astype(np.int32)
+        tgt = W.bits_from_bool(W.random_subsets(nprng, len(slot), R, 2, R))
+        yield ("fused", slot, rr, W.steady_values(slot), tgt)
+        starts, ends, rnds = [], [], []
+        for lg in np.nonzero(~active)[0]:
+            lo, hi = e * rows_per, (e + 1) * rows_per
+            cut = int(nprng.integers(lo, hi + 1))
+            for a, b in ((lo, cut), (cut, hi)):
+                if a < b or nprng.random() < 0.1:   # now and then an empty range, too
+                    starts.append(a * L + lg)
+                    ends.append(min(S, (b - 1) * L + lg + 1) if b > a else a * L + lg)
+                    rnds.append(rounds[lg])
+        order = nprng.permutation(len(starts))
+        i32 = lambda x: np.asarray(x, np.int32)[order]
+        tm = W.bits_from_bool(W.random_subsets(nprng, len(starts), R, 2, R)).reshape(len(starts), 1, 4)
+        yield ("ranges", i32(starts), i32(ends), i32(rnds), tm)
+
+
+def test_config5_mencius_256_leader_groups_4m_slots(fa, oracle):
+    S, L, R = 1 << 22, 256, 3
+    kw = dict(num_slots=S, num_replicas=R, num_groups=1, num_leader_groups=L, f=1, tally_ways=4)
+    gpu, ref = fa.Context(fa.make_config(**kw)), oracle.System(oracle.make_config(**kw))
+    n_ranges = n_chosen_ranges = n_chosen = n_nacks = 0
+    for op in mencius_stream(S, L, R, epochs=16, seed=5):
+        if op[0] == "phase1a":
+            a, b = gpu.acceptor_phase1a(*op[1:]), ref.acceptor_phase1a(*op[1:])
+            assert a[0] == b[0] == 0
+            np.testing.assert_array_equal(a[1], b[1])
+            np.testing.assert_array_equal(a[2], b[2])
+        elif op[0] == "fused":
+            a, b = gpu.phase2_fused(*op[1:]), ref.phase2_fused(*op[1:])
+            assert a[0] == b[0] == 0
+            for x, y in zip(a[1:], b[1:]):
+                np.testing.assert_array_equal(x, y)
+            ch = a[1].astype(bool)
+            n_chosen += int(ch.sum())
+            n_nacks += int((a[4] >= 0).sum())
+            # the replicas learn the Chosen commands (Replica.handleChosen + executeLog)
+            assert gpu.replica_chosen(op[1][ch], a[3][ch]) == ref.replica_chosen(op[1][ch], a[3][ch])
+        else:
+            a, b = gpu.noop_ranges_fused(*op[1:]), ref.noop_ranges_fused(*op[1:])
+            assert a[0] == b[0] == 0
+            for x, y in zip(a[1:], b[1:]):
+                np.testing.assert_array_equal(x, y)
+            n_ranges += len(op[1])
+            n_chosen_ranges += int(a[5].sum())
+            for i in np.nonzero(a[5])[0][:48]:      # ChosenNoopRange -> Replica.handleChosenNoopRange (a sample)
+                s, e = int(op[1][i]), int(op[2][i])
+                assert gpu.replica_chosen_noop_range(s, e) == ref.replica_chosen_noop_range(s, e)
+    assert n_ranges > 1024 and 0 < n_chosen_ranges < n_ranges and n_chosen > S // 4 and n_nacks > 0
+    np.testing.assert_array_equal(gpu.state_digest(), ref.state_digest())
+    pg, mg = gpu.read_scalars()
+    pr, mr = ref.read_scalars()
+    np.testing.assert_array_equal(pg, pr)
+    np.testing.assert_array_equal(mg, mr)
+    assert gpu.replica_state() == tuple(ref.replica_chosen([], [])[1:])
+    for s in range(0, S, 262147):
+        assert gpu.read_tally(s) == ref.read_tally(s)
+    for lg in (0, 255):
+        a, b = gpu.read_acceptor(lg, 2), ref.read_acceptor(lg, 2)
+        assert a[:2] == b[:2]
+        for x, y in zip(a[2:], b[2:]):
+            np.testing.assert_array_equal(x, y)
