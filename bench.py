@@ -178,6 +178,7 @@ def replica_axis_row(fa, dist, backend, dev, rank, world, local_rank, ballot_mod
         replica_base=rank * R_local, replicas_total=REPLICAS))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     assert ctx.acceptor_phase1a(0, 0)[0] == 0
+    ctx.flush_promises()
     have_comm = setup_comm(fa, ctx, dist, backend, dev, rank, world)
     lo, hi = sharding.slot_slice(SLOTS_PER_STEP, world, rank)
     per = hi - lo
@@ -254,9 +255,6 @@ def main():
     ap.add_argument("--validate", action="store_true",
                     help="keep the run-contract validation kernel in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--spinup-ms", type=float, default=500.0,
-                    help="untimed device-to-device copies before the warmup steps: the first process on a cold "
-                         "box otherwise measures the GPU's clock ramp (0.60 vs 0.565 ms per step, r02)")
     ap.add_argument("--replica-row-steps", type=int, default=5,
                     help="N > 1, --shard group: steps of the extra replica-axis row (0 = skip it)")
     args = ap.parse_args()
@@ -333,6 +331,7 @@ def main():
     # the leader's Phase 1 in round 0 (once, before any Phase 2): every acceptor promises round 0
     st, pb, nb = ctx.acceptor_phase1a(0, 0)
     assert st == 0
+    ctx.flush_promises()  # PER_SLOT: the promise is in the cells before the steady stretch starts (setup, untimed)
 
     # synthetic command stream, resident in HBM
     steps = []
@@ -383,16 +382,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.spinup_ms > 0:
-        # part of the setup, like generating the command stream: keep HBM busy until the clocks are up
-        a = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
-        c = torch.empty_like(a)
-        t_spin = time.perf_counter()
-        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
-            for _ in range(8):
-                c.copy_(a)
-            torch.cuda.synchronize()
-        del a, c
     for i in range(Wm):
         step(i)
     assert ctx.sync() == 0

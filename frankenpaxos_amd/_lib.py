@@ -89,6 +89,8 @@ SIGNATURES = {
     "fpx_acceptor_phase2a": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP, VP, VP, VP]),
     "fpx_acceptor_phase2a_dev": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP, VP, VP, VP]),
     "fpx_acceptor_phase1a": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, VP, VP, VP]),
+    "fpx_acceptor_phase1a_dev": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, VP, VP, VP]),
+    "fpx_acceptor_flush_promises": (C.c_int32, [VP]),
     "fpx_proxy_open": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP]),
     "fpx_proxy_open_dev": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP]),
     "fpx_proxy_phase2b": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP, VP, VP]),

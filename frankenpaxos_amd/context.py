@@ -126,6 +126,19 @@ class Context:
                                          _hp(pb), _hp(nb))
         return st, pb, nb
 
+    def acceptor_phase1a_dev(self, group, round_, watermark=0, target_mask=None, promised_bits=None,
+                             nack_bits=None):
+        """asynchronous Phase1a: torch CUDA tensors of 4 int64 words each (or None)"""
+        st = self.L.fpx_acceptor_phase1a_dev(self._h, group, round_, watermark, _dp(target_mask),
+                                             _dp(promised_bits), _dp(nack_bits))
+        if st:
+            raise FpxError(st, "fpx_acceptor_phase1a_dev")
+
+    def flush_promises(self):
+        st = self.L.fpx_acceptor_flush_promises(self._h)
+        if st:
+            raise FpxError(st, "fpx_acceptor_flush_promises")
+
     def proxy_open(self, slot, round_, value):
         slot, round_, value = _i32(slot), _i32(round_), _i32(value)
         n = len(slot)

@@ -77,6 +77,7 @@ struct fpx_ctx {
   bool profiling = false;
   std::vector<hipEvent_t> ev;  // start/stop pairs
   size_t ev_used = 0;
+  bool lazy_active = false;  // PER_SLOT: lazy Phase1a promises may be outstanding (k_phase2 runs its lazy-aware form)
   // K4: the proxy leader's noop-range tallies (two buffers: fpx_proxy_forget rehashes into the other one)
   RangeTable rt[2];
   int rt_cur = 0;
@@ -202,8 +203,19 @@ size_t lds_bytes(const fpx_ctx* ctx, bool fused, bool targets) {
   return tab + 4 * (fused ? sizeof(WaveOut<true>) : sizeof(WaveOut<false>)) + (targets ? 4 * 256 * sizeof(uint64_t) : 0);
 }
 
+// messages per wavefront at G = 64: FPX_CHUNK for batches that fill the chip anyway, fewer (down to 4) for small
+// ones -- a wave walks its chunk one row at a time, so a 20 k-message epoch in 32-message chunks is 670 waves
+// walking 32 dependent steps each on a machine with room for 6000
+int chunk_for(const fpx_ctx* ctx, int n) {
+  if (ctx->lanes_per_slot != 64) return 64;
+  const long long want_waves = (long long)ctx->num_cus * 16;
+  int ch = FPX_CHUNK;
+  while (ch > 4 && (long long)(n + ch - 1) / ch < want_waves) ch >>= 1;
+  return ch;
+}
+
 int grid_for(const fpx_ctx* ctx, int n) {
-  const int per_block = 4 * (ctx->lanes_per_slot == 64 ? FPX_CHUNK : 64);
+  const int per_block = 4 * chunk_for(ctx, n);
   const int need = (n + per_block - 1) / per_block;
   return std::max(1, std::min(need, ctx->max_grid));
 }
@@ -215,15 +227,23 @@ void allow_lds(K kernel, size_t lds) {
   if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-template <int G, int MODE, bool PERSLOT>
+template <int G, int MODE, int PS>
 void launch_phase2_3(fpx_ctx* ctx, const Batch& b, bool fused, int grid) {
   const size_t lds = lds_bytes(ctx, fused, MODE != 0);
-  if (fused) allow_lds(k_phase2<G, MODE, PERSLOT, true>, lds);
-  else allow_lds(k_phase2<G, MODE, PERSLOT, false>, lds);
+  if (fused) allow_lds(k_phase2<G, MODE, PS, true>, lds);
+  else allow_lds(k_phase2<G, MODE, PS, false>, lds);
   if (fused)
-    hipLaunchKernelGGL((k_phase2<G, MODE, PERSLOT, true>), dim3(grid), dim3(256), lds, ctx->stream, ctx->g, ctx->st, b);
+    hipLaunchKernelGGL((k_phase2<G, MODE, PS, true>), dim3(grid), dim3(256), lds, ctx->stream, ctx->g, ctx->st, b);
   else
-    hipLaunchKernelGGL((k_phase2<G, MODE, PERSLOT, false>), dim3(grid), dim3(256), lds, ctx->stream, ctx->g, ctx->st, b);
+    hipLaunchKernelGGL((k_phase2<G, MODE, PS, false>), dim3(grid), dim3(256), lds, ctx->stream, ctx->g, ctx->st, b);
+}
+
+template <int G, int MODE>
+void launch_phase2_2b(fpx_ctx* ctx, const Batch& b, bool fused, int grid) {
+  // ballot model: 0 = per-acceptor scalar, 1 = per cell, 2 = per cell with lazy Phase1a promises outstanding
+  if (!ctx->g.per_slot) launch_phase2_3<G, MODE, 0>(ctx, b, fused, grid);
+  else if (!ctx->lazy_active) launch_phase2_3<G, MODE, 1>(ctx, b, fused, grid);
+  else launch_phase2_3<G, MODE, 2>(ctx, b, fused, grid);
 }
 
 template <int G>
@@ -231,15 +251,9 @@ void launch_phase2_2(fpx_ctx* ctx, const Batch& b, bool fused, int grid) {
   // rows are padded to a multiple of 4 cells (Geom::RS), so int4 accesses serve every R.
   // mode 0: dense delivery (no target masks); 1: target masks; 2: target masks + FPX_F_SCATTERED_TARGETS
   const int mode = !b.target ? 0 : ((ctx->cfg.flags & FPX_F_SCATTERED_TARGETS) ? 2 : 1);
-  if (ctx->g.per_slot) {
-    if (mode == 0) launch_phase2_3<G, 0, true>(ctx, b, fused, grid);
-    else if (mode == 1) launch_phase2_3<G, 1, true>(ctx, b, fused, grid);
-    else launch_phase2_3<G, 2, true>(ctx, b, fused, grid);
-  } else {
-    if (mode == 0) launch_phase2_3<G, 0, false>(ctx, b, fused, grid);
-    else if (mode == 1) launch_phase2_3<G, 1, false>(ctx, b, fused, grid);
-    else launch_phase2_3<G, 2, false>(ctx, b, fused, grid);
-  }
+  if (mode == 0) launch_phase2_2b<G, 0>(ctx, b, fused, grid);
+  else if (mode == 1) launch_phase2_2b<G, 1>(ctx, b, fused, grid);
+  else launch_phase2_2b<G, 2>(ctx, b, fused, grid);
 }
 
 void launch_phase2(fpx_ctx* ctx, const Batch& b, bool fused, int grid) {
@@ -252,6 +266,13 @@ void launch_phase2(fpx_ctx* ctx, const Batch& b, bool fused, int grid) {
     case 32: launch_phase2_2<32>(ctx, b, fused, grid); break;
     default: launch_phase2_2<64>(ctx, b, fused, grid); break;
   }
+}
+
+// fill n int32 words on the stream with a kernel (see k_fill32)
+void fill32(fpx_ctx* ctx, void* p, int32_t v, size_t n) {
+  if (n == 0) return;
+  const int grid = (int)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cus * 8));
+  hipLaunchKernelGGL(k_fill32, dim3(grid), dim3(256), 0, ctx->stream, (int32_t*)p, v, n);
 }
 
 int launch_check(fpx_ctx* ctx) {
@@ -281,8 +302,7 @@ int enqueue_validate(fpx_ctx* ctx, Batch& b, bool check_round) {
   }
   if (((ctx->cfg.flags & FPX_F_TRUSTED) && !ctx->force_validate) || ctx->host_validated) return FPX_OK;
   b.check_round = check_round && !ctx->g.per_slot;
-  if (b.check_round)
-    HIPCHK(ctx, hipMemsetAsync(ctx->st.run_round, 0xFF, sizeof(int32_t) * (size_t)ctx->g.ngroups, ctx->stream));
+  if (b.check_round) fill32(ctx, ctx->st.run_round, -1, (size_t)ctx->g.ngroups);
   hipLaunchKernelGGL(k_validate, dim3((b.n + 255) / 256), dim3(256), 0, ctx->stream, ctx->g, ctx->st, b);
   return launch_check(ctx);
 }
@@ -293,6 +313,7 @@ int enqueue_phase2(fpx_ctx* ctx, Batch& b, bool fused) {
   int rc = enqueue_validate(ctx, b, true);
   if (rc) return rc;
   const int grid = grid_for(ctx, b.n);
+  b.chunk = chunk_for(ctx, b.n);
   b.parity = (int32_t)(ctx->phase2_launches++ & 1u);  // every K1 / K3 launch is followed by its k_finalize
   const bool prof = ctx->profiling && ctx->ev_used + 2 <= ctx->ev.size();
   if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[ctx->ev_used], ctx->stream));
@@ -364,6 +385,11 @@ int init_state(fpx_ctx* ctx) {
   HIPCHK(ctx, hipMemsetAsync(st.pl_bits, 0, (size_t)g.S * g.wp * 32, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.stamp, 0, (size_t)g.S * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.row_voted, 0, (size_t)g.S, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.lz_round, 0xFF, (nsc + 4) * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.lz_from, 0, (nsc + 4) * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.max_ballot, 0xFF, (nsc + 4) * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.p1, 0, ((size_t)4 * g.R + 4) * 4, ctx->stream));
+  ctx->lazy_active = false;
   HIPCHK(ctx, hipMemsetAsync(st.run_round, 0xFF, (size_t)g.ngroups * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.status, 0, 8 * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.part_cnt, 0, 2 * 4, ctx->stream));
@@ -391,7 +417,7 @@ void free_state(fpx_ctx* ctx) {
   void* ps[] = {st.promised, st.max_voted, ctx->slab, st.pl_key, st.pl_value,
                 st.pl_bits,  st.stamp,     st.run_round,  st.status,     st.part,
                 st.log_value, st.log_present, st.log_scalars, st.part_cnt, st.part_all,
-                st.row_voted,
+                st.row_voted, st.lz_round, st.lz_from, st.max_ballot, st.p1,
                 ctx->rt[0].key, ctx->rt[0].bits, ctx->rt[0].owner, ctx->rt[0].count,
                 ctx->rt[1].key, ctx->rt[1].bits, ctx->rt[1].owner, ctx->rt[1].count, ctx->d_rng.p};
   for (void* p : ps)
@@ -675,6 +701,10 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
   if ((rc = dalloc(ctx, &st.pl_bits, (size_t)g.S * g.wp * 4))) return fail(rc);
   if ((rc = dalloc(ctx, &st.stamp, (size_t)g.S))) return fail(rc);
   if ((rc = dalloc(ctx, &st.row_voted, (size_t)g.S))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.lz_round, nsc + 4))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.lz_from, nsc + 4))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.max_ballot, nsc + 4))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.p1, (size_t)4 * g.R + 4))) return fail(rc);
   if ((rc = dalloc(ctx, &st.run_round, (size_t)g.ngroups))) return fail(rc);
   if ((rc = dalloc(ctx, &st.status, (size_t)8))) return fail(rc);
   ctx->g.part_rows = ctx->max_grid;
@@ -1052,36 +1082,75 @@ int32_t fpx_proxy_phase2b(fpx_ctx* ctx, int32_t n, const int32_t* slot, const in
   return fetch_status(ctx);
 }
 
+// Phase1a on device-resident arguments, asynchronous: d_target_mask 4 words or NULL, d_out 8 words = promised
+// bits then nack bits (zeroed here)
+static int enqueue_phase1a(fpx_ctx* ctx, int group, int round, int watermark, const uint64_t* d_tgt, uint64_t* d_out) {
+  int rc;
+  const dim3 gr(1), blk(256);  // R <= 256: one block, which also initialises d_out
+  if (!ctx->g.per_slot) {
+    hipLaunchKernelGGL(k_phase1a_scalar, gr, blk, 0, ctx->stream, ctx->g, ctx->st, group, round, d_tgt, d_out);
+  } else {
+    // O(R) unless the Phase1a is stale for some acceptor or an older lazy promise has to be made explicit below
+    // the new watermark: k_p1a_sweep returns at once in the common case
+    hipLaunchKernelGGL(k_p1a_decide, gr, blk, 0, ctx->stream, ctx->g, ctx->st, group, round, watermark, d_tgt, d_out);
+    hipLaunchKernelGGL(k_p1a_sweep, dim3(ctx->num_cus * 2), dim3(256), 0, ctx->stream, ctx->g, ctx->st, group, round,
+                       watermark, d_out);
+    // promised = the targeted acceptors none of whose cells was ahead
+    hipLaunchKernelGGL(k_phase1a_perslot_finish, gr, blk, 0, ctx->stream, ctx->g, ctx->st, d_tgt, d_out);
+    ctx->lazy_active = true;
+  }
+  if ((rc = launch_check(ctx))) return rc;
+  return FPX_OK;
+}
+
+int32_t fpx_acceptor_phase1a_dev(fpx_ctx* ctx, int32_t group, int32_t round, int32_t chosen_watermark,
+                                 const uint64_t* d_target_mask, uint64_t* d_promised_bits, uint64_t* d_nack_bits) {
+  DeviceGuard _dg(ctx);
+  if (!ctx || group < 0 || group >= ctx->g.ngroups || round < 0 || round > MAX_ROUND) return FPX_EINVAL;
+  int rc;
+  if ((rc = grow(ctx, &ctx->d_scratch, 128))) return rc;
+  uint64_t* d_out = (uint64_t*)ctx->d_scratch.p;  // [8]: promised bits, nack bits
+  if ((rc = enqueue_phase1a(ctx, group, round, chosen_watermark, d_target_mask, d_out))) return rc;
+  if (d_promised_bits) HIPCHK(ctx, hipMemcpyAsync(d_promised_bits, d_out, 32, hipMemcpyDeviceToDevice, ctx->stream));
+  if (d_nack_bits) HIPCHK(ctx, hipMemcpyAsync(d_nack_bits, d_out + 4, 32, hipMemcpyDeviceToDevice, ctx->stream));
+  return FPX_OK;
+}
+
 int32_t fpx_acceptor_phase1a(fpx_ctx* ctx, int32_t group, int32_t round, int32_t chosen_watermark,
                              const uint64_t* target_mask, uint64_t* promised_bits, uint64_t* nack_bits) {
   DeviceGuard _dg(ctx);
-  if (!ctx || group < 0 || group >= ctx->g.ngroups || round < 0) return FPX_EINVAL;
+  if (!ctx || group < 0 || group >= ctx->g.ngroups || round < 0 || round > MAX_ROUND) return FPX_EINVAL;
   int rc;
   if ((rc = grow(ctx, &ctx->d_scratch, 128))) return rc;
   uint64_t* d_out = (uint64_t*)ctx->d_scratch.p;       // [8]: promised bits, nack bits
   uint64_t* d_tgt = target_mask ? d_out + 8 : nullptr;  // [4]
-  HIPCHK(ctx, hipMemsetAsync(d_out, 0, 64, ctx->stream));
   if (target_mask) HIPCHK(ctx, hipMemcpyAsync(d_tgt, target_mask, 32, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = enqueue_phase1a(ctx, group, round, chosen_watermark, d_tgt, d_out))) return rc;
   uint64_t h[8];
-  if (!ctx->g.per_slot) {
-    hipLaunchKernelGGL(k_phase1a_scalar, dim3((ctx->g.R + 63) / 64), dim3(64), 0, ctx->stream, ctx->g, ctx->st, group,
-                       round, d_tgt, d_out);
-    if ((rc = launch_check(ctx))) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(h, d_out, 64, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  } else {
-    hipLaunchKernelGGL(k_phase1a_perslot, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, ctx->g, ctx->st, group,
-                       round, chosen_watermark, d_tgt, d_out);
-    // promised = the targeted acceptors none of whose cells was ahead (second, tiny kernel)
-    hipLaunchKernelGGL(k_phase1a_perslot_finish, dim3((ctx->g.R + 63) / 64), dim3(64), 0, ctx->stream, ctx->g, d_tgt,
-                       d_out);
-    if ((rc = launch_check(ctx))) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(h, d_out, 64, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  }
+  HIPCHK(ctx, hipMemcpyAsync(h, d_out, 64, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (promised_bits) memcpy(promised_bits, h, 32);
   if (nack_bits) memcpy(nack_bits, h + 4, 32);
   return FPX_OK;
+}
+
+// PER_SLOT: every outstanding lazy promise is written into the cells it covers (one sweep over the ballot array)
+// and forgotten; k_phase2 goes back to its lean form.  Readback and digests do this implicitly.
+static int flush_promises(fpx_ctx* ctx) {
+  if (!ctx->g.per_slot || !ctx->lazy_active) return FPX_OK;
+  hipLaunchKernelGGL(k_lazy_flush, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, ctx->g, ctx->st);
+  const int nsc = ctx->g.ngroups * ctx->g.R;
+  hipLaunchKernelGGL(k_lazy_clear, dim3((nsc + 255) / 256), dim3(256), 0, ctx->stream, ctx->g, ctx->st);
+  int rc = launch_check(ctx);
+  if (rc) return rc;
+  ctx->lazy_active = false;
+  return FPX_OK;
+}
+
+int32_t fpx_acceptor_flush_promises(fpx_ctx* ctx) {
+  DeviceGuard _dg(ctx);
+  if (!ctx) return FPX_EINVAL;
+  return flush_promises(ctx);
 }
 
 int32_t fpx_proxy_forget(fpx_ctx* ctx, int32_t first_slot, int32_t count) {
@@ -1126,13 +1195,13 @@ static int enqueue_ranges(fpx_ctx* ctx, RangeBatch& b, int mode) {
   const bool acceptors = mode == RANGES_FUSED || mode == RANGES_ACCEPTORS;
   const bool validate = !(((ctx->cfg.flags & FPX_F_TRUSTED) && !ctx->force_validate) || ctx->host_validated);
   if (validate) {
-    if (acceptors) HIPCHK(ctx, hipMemsetAsync(ctx->st.run_round, 0xFF, sizeof(int32_t) * (size_t)g.ngroups, ctx->stream));
+    if (acceptors) fill32(ctx, ctx->st.run_round, -1, (size_t)g.ngroups);
     hipLaunchKernelGGL(k_ranges_validate, dim3(gn), dim3(256), 0, ctx->stream, g, ctx->st, b, acceptors ? 1 : 0);
   }
   if (acceptors) {
-    HIPCHK(ctx, hipMemsetAsync(b.vote_bits, 0, words * 8, ctx->stream));
-    if (b.nack_bits) HIPCHK(ctx, hipMemsetAsync(b.nack_bits, 0, words * 8, ctx->stream));
-    if (b.nack_round) HIPCHK(ctx, hipMemsetAsync(b.nack_round, 0xFF, (size_t)b.n * 4, ctx->stream));
+    fill32(ctx, b.vote_bits, 0, words * 2);
+    if (b.nack_bits) fill32(ctx, b.nack_bits, 0, words * 2);
+    if (b.nack_round) fill32(ctx, b.nack_round, -1, (size_t)b.n);
   }
   const RangeTable& rt = ctx->rt[ctx->rt_cur];
   if (mode == RANGES_FUSED || mode == RANGES_OPEN) {
@@ -1254,7 +1323,9 @@ static int32_t host_ranges(fpx_ctx* ctx, int mode, int32_t n, const int32_t* sta
   if (mode == RANGES_TALLY) HIPCHK(ctx, hipMemcpyAsync(sg.votes, votes_in, words * 8, hipMemcpyHostToDevice, ctx->stream));
   HostRun host_run(ctx);
   std::vector<int> cuts;
-  split_range_runs(ctx, n, start, end, round, mode == RANGES_FUSED || mode == RANGES_ACCEPTORS, mode == RANGES_TALLY, &cuts);
+  // one round per leader group in every run: the acceptors' scalar needs it, and the table insert relies on
+  // "same (start, end) in one launch => same key"
+  split_range_runs(ctx, n, start, end, round, true, mode == RANGES_TALLY, &cuts);
   for (size_t k = 0; k + 1 < cuts.size(); ++k) {
     const int lo = cuts[k], len = cuts[k + 1] - cuts[k];
     RangeBatch b;
@@ -1491,6 +1562,10 @@ int32_t fpx_read_state(fpx_ctx* ctx, int32_t* vote_round, int32_t* vote_value, i
   DeviceGuard _dg(ctx);
   if (!ctx) return FPX_EINVAL;
   const size_t S = (size_t)ctx->g.S, R = (size_t)ctx->g.R, RS = (size_t)ctx->g.RS;
+  if (ballot) {
+    int rcf = flush_promises(ctx);
+    if (rcf) return rcf;
+  }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   // device rows are RS cells long, the caller's are R
   if (vote_round)
@@ -1523,6 +1598,7 @@ int32_t fpx_read_acceptor(fpx_ctx* ctx, int32_t group, int32_t replica, int32_t*
   const size_t e = (size_t)group * ctx->g.R + replica;
   const size_t S = (size_t)ctx->g.S;
   int rc;
+  if (ballot && (rc = flush_promises(ctx))) return rc;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (promised) {
     if (ctx->g.per_slot) *promised = -1;
@@ -1721,6 +1797,7 @@ int32_t fpx_state_digest(fpx_ctx* ctx, uint64_t out[8]) {
   int rc;
   if ((rc = grow(ctx, &ctx->d_scratch, 128))) return rc;
   uint64_t* d = (uint64_t*)ctx->d_scratch.p;
+  if ((rc = flush_promises(ctx))) return rc;
   HIPCHK(ctx, hipMemsetAsync(d, 0, 64, ctx->stream));
   const Geom& g = ctx->g;
   const int big = ctx->num_cus * 16;

@@ -88,6 +88,12 @@ struct State {
   uint32_t* pl_key;     // [S][wp]        0 = empty, else (round + 1) | KEY_DONE
   int32_t* pl_value;    // [S][wp]
   uint64_t* pl_bits;    // [S][wp][4]
+  // FPX_BALLOT_PER_SLOT: a Phase1a that nothing is ahead of is recorded per acceptor instead of being written into
+  // every cell (k_p1a_*): the effective ballot of cell (s, a) is max(ballot[s][a], s >= lz_from[a] ? lz_round[a] : -1)
+  int32_t* lz_round;    // [ngroups][R]   -1 = none
+  int32_t* lz_from;     // [ngroups][R]   first slot the lazy promise covers (the Phase1a's chosenWatermark)
+  int32_t* max_ballot;  // [ngroups][R]   an upper bound of the acceptor's effective ballots
+  int32_t* p1;          // [4][R] + 1     scratch of one Phase1a: mode / a / b / c per acceptor, then the "sweep needed" flag
   uint8_t* row_voted;   // [S]            0 = no acceptor of the slot's group has ever voted in it (its cells
                         //                are all -1): partially voted cells can then be written whole without a read
   uint32_t* stamp;      // [S]            run id of the last run that touched the slot
@@ -118,6 +124,7 @@ struct Batch {
   uint32_t run_id;
   int32_t parity;          // K1 / K3 launch counter & 1: which half of part_cnt / part_all this launch uses
   int32_t check_round;     // validate: enforce one round per group (ACCEPTOR ballot mode)
+  int32_t chunk;           // K1 / K3 at G = 64: messages per wavefront (4 .. FPX_CHUNK)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -288,6 +295,12 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// small device fills on the context's stream (hipMemsetAsync of a few bytes measured ~170 us per call between
+// kernels on this stack, a kernel launch ~5 us: profiles/r02_adversarial.txt)
+__global__ void __launch_bounds__(256) k_fill32(int32_t* p, int32_t v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_validate: run contract of a device batch.  One thread per message.
 // ------------------------------------------------------------------------------------------------
@@ -304,13 +317,24 @@ __global__ void __launch_bounds__(256) k_validate(const Geom g, const State st, 
   if (old == b.run_id) report_abort(st, 6 /*FPX_EORDER*/, i, s, r);
   // (2) one round per acceptor group within the run
   if (b.check_round) {
+    // every message of a group looks at the same word, and same-address requests serialise in one L2 channel
+    // (170 us for a 20 k-message epoch when every thread asked).  One acceptor group: the wavefront agrees on its
+    // round among itself and sends ONE lane.
     int* rr = &st.run_round[group_of_slot(g, s)];
-    int cur = __hip_atomic_load(rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cur == -1) {
-      cur = atomicCAS(rr, -1, r);
-      if (cur == -1) cur = r;
+    bool ask = true;
+    if (g.ngroups == 1) {
+      const int r0 = __builtin_amdgcn_readfirstlane(r);
+      if (r != r0) report_abort(st, 6, i, s, r);
+      ask = __builtin_amdgcn_readfirstlane(i) == i;  // the first active lane
     }
-    if (cur != r) report_abort(st, 6, i, s, r);
+    if (ask) {
+      int cur = __hip_atomic_load(rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == -1) {
+        cur = atomicCAS(rr, -1, r);
+        if (cur == -1) cur = r;
+      }
+      if (cur != r) report_abort(st, 6, i, s, r);
+    }
   }
 }
 
@@ -342,9 +366,13 @@ struct WaveOut<true> {     // K3: only the chosen flags are staged; bitmaps stay
   int32_t chosen[64];
 };
 
-template <int G, int MODE, bool PERSLOT, bool FUSED>
+template <int G, int MODE, int PS, bool FUSED>
 __global__ void __launch_bounds__(256)
     k_phase2(const Geom g, const State st, const Batch b) {
+  // PS 0: the acceptor's round is a scalar (FPX_BALLOT_ACCEPTOR); 1: ballot[S][R] in HBM; 2: the same with lazy
+  // Phase1a promises to honour (only while some are outstanding: 8 VGPRs the steady state does not pay)
+  constexpr bool PERSLOT = PS != 0;
+  constexpr bool LAZY = PS == 2;
   // MODE 0: no target masks (dense delivery) -- the lean kernel of the steady state; 1: target masks; 2: target
   // masks + FPX_F_SCATTERED_TARGETS.  The target-mask code (LDS staging, fresh-row blend) costs 6-12 VGPRs = one
   // wave per SIMD, which the dense stream would pay for nothing.
@@ -393,7 +421,16 @@ __global__ void __launch_bounds__(256)
       if (own >> k & 1) init_thr[k] = st.promised[r0 + k];
   }
 
-  constexpr int CH = (G == 64) ? FPX_CHUNK : 64;  // messages per wavefront chunk
+  int lzr[4] = {-1, -1, -1, -1}, lzf[4] = {0, 0, 0, 0};
+  if (LAZY && one_group) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (own >> k & 1) lzr[k] = st.lz_round[r0 + k], lzf[k] = st.lz_from[r0 + k];
+  }
+
+  // messages per wavefront chunk: 64, or at G = 64 the launch's choice (32 for big batches, fewer when the batch
+  // would not otherwise fill the chip: a wave walks its chunk one row at a time)
+  const int CH = (G == 64) ? b.chunk : 64;
   const int nchunks = (b.n + CH - 1) / CH;
   for (int chunk = blockIdx.x * 4 + wib; chunk < nchunks; chunk += gridDim.x * 4) {
     // ---- stage the chunk: lane i owns message i -------------------------------------------------
@@ -433,7 +470,6 @@ __global__ void __launch_bounds__(256)
 
     if constexpr (TGT) {
       const size_t w0 = (size_t)chunk * CH * 4, wend = (size_t)b.n * 4;
-#pragma unroll
       for (int w = lane; w < CH * 4; w += 64)
         if (w0 + w < wend) wt[w] = b.target[w0 + w];
       wave_lds_sync();
@@ -466,6 +502,24 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
           for (int k = 0; k < 4; ++k)
             if (own >> k & 1) thr[k] = pr[k];
+        }
+        if constexpr (LAZY) {
+          if (one_group) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int lz = s >= lzf[k] ? lzr[k] : -1;
+              thr[k] = lz > thr[k] ? lz : thr[k];
+            }
+          } else {
+            const size_t e = (size_t)grp_out * g.R + r0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (own >> k & 1) {
+                const int lz = s >= st.lz_from[e + k] ? st.lz_round[e + k] : -1;
+                thr[k] = lz > thr[k] ? lz : thr[k];
+              }
+            }
+          }
         }
       }
       return thr;
@@ -768,7 +822,9 @@ __global__ void __launch_bounds__(256) k_finalize(const Geom g, const State st, 
       pr = red[0][k][threadIdx.x] > pr ? red[0][k][threadIdx.x] : pr;
       mvs = red[1][k][threadIdx.x] > mvs ? red[1][k][threadIdx.x] : mvs;
     }
-    if (!g.per_slot && pr > st.promised[e]) atomicMax(&st.promised[e], pr);
+    // the accepted rounds raise Acceptor.round -- or, with a ballot per cell, the bound on the acceptor's ballots
+    int32_t* top = g.per_slot ? st.max_ballot : st.promised;
+    if (pr > top[e]) atomicMax(&top[e], pr);
     if (mvs > st.max_voted[e]) atomicMax(&st.max_voted[e], mvs);
   }
 }
@@ -857,49 +913,117 @@ __global__ void __launch_bounds__(256) k_tally(const Geom g, const State st, con
 // ------------------------------------------------------------------------------------------------
 // Phase1a (Acceptor.scala:148-182)
 // ------------------------------------------------------------------------------------------------
-// ACCEPTOR mode: one thread per acceptor of the group.  out[0..3] promised bits, out[4..7] nack bits
-__global__ void k_phase1a_scalar(const Geom g, const State st, int group, int round, const uint64_t* target,
-                                 uint64_t* out) {
+// ACCEPTOR mode: ONE block, one thread per acceptor of the group (R <= 256).  out[0..3] promised bits,
+// out[4..7] nack bits, assembled in LDS and written whole (no zeroing pass before the launch)
+__global__ void __launch_bounds__(256) k_phase1a_scalar(const Geom g, const State st, int group, int round,
+                                                        const uint64_t* target, uint64_t* out) {
+  __shared__ unsigned long long bits[8];
+  const int r = threadIdx.x;
+  if (r < 8) bits[r] = 0ull;
+  __syncthreads();
+  if (r < g.R) {
+    const int bit = g.base + r;
+    if (!target || ((target[bit >> 6] >> (bit & 63)) & 1ull)) {
+      int* pr = &st.promised[(size_t)group * g.R + r];
+      if (round < *pr) {  // :155 Nack
+        atomicOr(&bits[4 + (bit >> 6)], 1ull << (bit & 63));
+      } else {            // :166 round = phase1a.round
+        *pr = round;
+        atomicOr(&bits[bit >> 6], 1ull << (bit & 63));
+      }
+    }
+  }
+  __syncthreads();
+  if (r < 8) out[r] = bits[r];
+}
+
+// PER_SLOT mode, Acceptor.handlePhase1a generalised to a ballot per cell: every cell of the group at or above the
+// watermark becomes max(old, round), and the acceptor Nacks iff one of them was ahead (old > round).
+// k_p1a_decide (one thread per acceptor): if nothing of this acceptor can be ahead (max_ballot <= round) the whole
+// Phase1a is ONE lazy record (round, watermark) -- O(R) instead of a sweep over S x R cells; an older record whose
+// range starts below the new watermark is first written into the cells it alone covers (mode 1).  Otherwise
+// (a stale Phase1a) the acceptor's column is checked cell by cell (mode 2).  k_p1a_sweep does that work and
+// returns at once when no acceptor asked for any.
+enum { P1_MODE = 0, P1_A = 1, P1_B = 2, P1_C = 3 };
+__global__ void k_p1a_decide(const Geom g, const State st, int group, int round, int watermark, const uint64_t* target,
+                             uint64_t* out) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < 8) out[r] = 0ull;  // (one block: R <= 256) the sweep ORs nack bits in, the finish kernel the promises
   if (r >= g.R) return;
+  int32_t* mode = st.p1 + P1_MODE * g.R;
+  mode[r] = 0;
   const int bit = g.base + r;
   if (target && !((target[bit >> 6] >> (bit & 63)) & 1ull)) return;
-  int* pr = &st.promised[(size_t)group * g.R + r];
-  if (round < *pr) {  // :155 Nack
-    atomicOr((unsigned long long*)&out[4 + (bit >> 6)], 1ull << (bit & 63));
-  } else {            // :166 round = phase1a.round
-    *pr = round;
-    atomicOr((unsigned long long*)&out[bit >> 6], 1ull << (bit & 63));
+  const size_t e = (size_t)group * g.R + r;
+  const int wm = watermark < 0 ? 0 : watermark;
+  const int lr = st.lz_round[e], lf = st.lz_from[e];
+  if (st.max_ballot[e] <= round) {
+    if (lr >= 0 && wm > lf) {  // the cells of [lf, wm) keep the older promise: make it explicit there
+      mode[r] = 1;
+      st.p1[P1_A * g.R + r] = lf, st.p1[P1_B * g.R + r] = wm, st.p1[P1_C * g.R + r] = lr;
+      st.p1[4 * g.R] = 1;
+    }
+    st.lz_round[e] = round, st.lz_from[e] = wm;
+    st.max_ballot[e] = round;
+  } else {
+    mode[r] = 2;
+    st.p1[4 * g.R] = 1;
   }
 }
 
-// PER_SLOT mode: one thread per cell, grid-stride; a cell ahead of the leader keeps its ballot and
-// marks its acceptor as nacking.
-__global__ void __launch_bounds__(256) k_phase1a_perslot(const Geom g, const State st, int group, int round,
-                                                         int watermark, const uint64_t* target, uint64_t* out) {
+__global__ void __launch_bounds__(256) k_p1a_sweep(const Geom g, const State st, int group, int round, int watermark,
+                                                   uint64_t* out) {
+  if (st.p1[4 * g.R] == 0) return;
+  const int32_t* mode = st.p1 + P1_MODE * g.R;
+  const int wm = watermark < 0 ? 0 : watermark;
   const size_t ncell = (size_t)g.S * g.RS;
-  const size_t first = (size_t)(watermark < 0 ? 0 : watermark) * g.RS;
-  for (size_t c = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncell;
-       c += (size_t)gridDim.x * blockDim.x) {
+  for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += (size_t)gridDim.x * blockDim.x) {
     const int s = (int)(c / g.RS), r = (int)(c % g.RS);
-    if (r >= g.R || group_of_slot(g, s) != group) continue;
-    const int bit = g.base + r;
-    if (target && !((target[bit >> 6] >> (bit & 63)) & 1ull)) continue;
+    if (r >= g.R) continue;
+    const int m = mode[r];
+    if (m == 0 || group_of_slot(g, s) != group) continue;
     const int cur = st.ballot[c];
-    if (cur > round) {
-      // one bit per acceptor: test before the atomic, or a stale Phase1a that every cell Nacks would queue
-      // S x R same-address atomics
-      unsigned long long* word = (unsigned long long*)&out[4 + (bit >> 6)];
-      if (!((__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (bit & 63)) & 1ull))
-        atomicOr(word, 1ull << (bit & 63));
-    } else if (cur != round) {
-      st.ballot[c] = round;
+    if (m == 1) {
+      if (s >= st.p1[P1_A * g.R + r] && s < st.p1[P1_B * g.R + r] && st.p1[P1_C * g.R + r] > cur)
+        st.ballot[c] = st.p1[P1_C * g.R + r];
+    } else if (s >= wm) {
+      const size_t e = (size_t)group * g.R + r;
+      const int lz = s >= st.lz_from[e] ? st.lz_round[e] : -1;
+      const int eff = lz > cur ? lz : cur;
+      if (eff > round) {
+        // one bit per acceptor: test before the atomic, or a stale Phase1a that every cell Nacks would queue
+        // S x R same-address atomics
+        const int bit = g.base + r;
+        unsigned long long* word = (unsigned long long*)&out[4 + (bit >> 6)];
+        if (!((__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (bit & 63)) & 1ull))
+          atomicOr(word, 1ull << (bit & 63));
+      } else if (cur != round) {
+        st.ballot[c] = round;
+      }
     }
   }
 }
 
-__global__ void k_phase1a_perslot_finish(const Geom g, const uint64_t* target, uint64_t* out) {
+// every outstanding lazy promise written into the cells it covers, the records cleared (readback / digests /
+// fpx_acceptor_flush_promises)
+__global__ void __launch_bounds__(256) k_lazy_flush(const Geom g, const State st) {
+  const size_t ncell = (size_t)g.S * g.RS;
+  for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += (size_t)gridDim.x * blockDim.x) {
+    const int s = (int)(c / g.RS), r = (int)(c % g.RS);
+    if (r >= g.R) continue;
+    const size_t e = (size_t)group_of_slot(g, s) * g.R + r;
+    const int lr = st.lz_round[e];
+    if (lr >= 0 && s >= st.lz_from[e] && lr > st.ballot[c]) st.ballot[c] = lr;
+  }
+}
+__global__ void k_lazy_clear(const Geom g, const State st) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < g.ngroups * g.R) st.lz_round[e] = -1, st.lz_from[e] = 0;
+}
+
+__global__ void k_phase1a_perslot_finish(const Geom g, const State st, const uint64_t* target, uint64_t* out) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r == 0) st.p1[4 * g.R] = 0;
   if (r >= g.R) return;
   const int bit = g.base + r;
   const bool tgt = !target || ((target[bit >> 6] >> (bit & 63)) & 1ull);

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) k_ranges_validate(const Geom g, const Sta
   }
   if (check_round) {  // one round per leader group within the launch
     int* rr = &st.run_round[(s % g.num_leader_groups) * g.num_groups];
-    int cur = __hip_atomic_load(rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int cur = *reinterpret_cast<volatile int*>(rr);  // ordinary load first (see k_validate)
     if (cur == -1) {
       cur = atomicCAS(rr, -1, r);
       if (cur == -1) cur = r;

@@ -216,6 +216,17 @@ int32_t fpx_acceptor_phase2a_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot,
 int32_t fpx_acceptor_phase1a(fpx_ctx* ctx, int32_t group, int32_t round, int32_t chosen_watermark,
                              const uint64_t* target_mask, uint64_t* promised_bits,
                              uint64_t* nack_bits);
+/* the same on device-resident arguments (each 4 words in HBM, may be NULL), asynchronous on the context's
+ * stream: a leader change in the middle of a device-resident stream costs no host round trip. */
+int32_t fpx_acceptor_phase1a_dev(fpx_ctx* ctx, int32_t group, int32_t round, int32_t chosen_watermark,
+                                 const uint64_t* d_target_mask, uint64_t* d_promised_bits,
+                                 uint64_t* d_nack_bits);
+/* FPX_BALLOT_PER_SLOT keeps a Phase1a that no cell is ahead of as ONE record per acceptor ("every cell from
+ * the watermark on is at least `round`") instead of rewriting S x R ballots, and honours the records in the
+ * vote kernels; results are identical.  This writes all outstanding records into the cells (one sweep over the
+ * ballot array) and drops them, which puts the vote kernels back into their leanest form -- worth calling once
+ * after the last Phase1a before a long steady stretch.  Readback and digests do it implicitly.  Asynchronous. */
+int32_t fpx_acceptor_flush_promises(fpx_ctx* ctx);
 
 /* ---- a6: ProxyLeader.handlePhase2a bookkeeping ---------------------------------------------------
  * Opens the tally Pending(phase2a, {}) for (slot[i], round[i]) (ProxyLeader.scala:213).  A (slot,

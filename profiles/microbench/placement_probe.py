@@ -20,6 +20,7 @@ def one(tag):
                                     flags=fa.FPX_F_TRUSTED))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.acceptor_phase1a(0, 0)
+    ctx.flush_promises()
     ch = torch.zeros(S, dtype=torch.uint8, device=dev)
     steps = []
     for w in range(W):

@@ -53,6 +53,7 @@ for name, maker in (("random f+1 subsets", random_masks), ("rotating f+1 run", r
                                     flags=fa.FPX_F_TRUSTED | (fa.FPX_F_SCATTERED_TARGETS if scattered else 0)))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.acceptor_phase1a(0, 0)
+    ctx.flush_promises()
     print('ctx ok', name, flush=True)
     tgt = maker(S) if maker else None
     torch.cuda.synchronize(); print('masks ok', flush=True)

@@ -585,3 +585,82 @@ def test_two_contexts_keep_their_device(fa):
         other = fa.Context(fa.make_config(num_slots=64, num_replicas=3, f=1, device=1))
         st, ch, *_ = other.phase2_fused(np.arange(8, dtype=np.int32), np.zeros(8, np.int32), np.arange(8, dtype=np.int32))
         assert st == 0 and ch.all() and torch.cuda.current_device() == before
+
+
+@pytest.mark.parametrize("R,ngroups", [(256, 1), (7, 1), (5, 3), (33, 2)])
+def test_lazy_phase1a_promises_equal_the_sweep(fa, oracle, R, ngroups):
+    """PER_SLOT Phase1a is O(R) on the device (one lazy record per acceptor) where the oracle rewrites every cell
+    from the watermark on.  Random sequences of Phase1a's -- rising and stale rounds, rising and falling
+    watermarks, partial target sets, several groups -- interleaved with votes that must see the promises
+    (Nacks, nack rounds), checked on every output, and on the whole state before and after an explicit flush."""
+    S = 2048
+    q = R // 2 + 1
+    kw = dict(num_slots=S, num_replicas=R, num_groups=ngroups, quorum_kind=1, ballot_mode=1, tally_ways=8)
+    gpu, ref = both(fa, oracle, **kw)
+    rng = np.random.default_rng(R * 10 + ngroups)
+    rounds = [0] * ngroups
+    slots_done = 0
+    for step in range(60):
+        k = rng.integers(0, 10)
+        g = int(rng.integers(0, ngroups))
+        if k < 4:
+            # Phase1a: mostly ahead of everything (the lazy path), sometimes stale (the checked sweep)
+            rnd = rounds[g] + int(rng.integers(1, 4)) if rng.random() < 0.7 else max(0, rounds[g] - int(rng.integers(0, 3)))
+            wm = int(rng.integers(0, S)) if rng.random() < 0.7 else 0
+            tgt = None if rng.random() < 0.4 else W.bits_from_bool(W.random_subsets(rng, 1, R, 1, R))[0]
+            a, b = gpu.acceptor_phase1a(g, rnd, wm, tgt), ref.acceptor_phase1a(g, rnd, wm, tgt)
+            assert a[0] == b[0] == 0
+            np.testing.assert_array_equal(a[1], b[1], err_msg="promised bits, step %d" % step)
+            np.testing.assert_array_equal(a[2], b[2], err_msg="nack bits, step %d" % step)
+            if tgt is None and not b[2].any():
+                rounds[g] = max(rounds[g], rnd)
+        elif k < 9:
+            n = int(rng.integers(1, 300))
+            slot = np.sort(rng.choice(S, size=n, replace=False)).astype(np.int32)
+            grp = slot % ngroups
+            rr = np.array([max(0, rounds[int(x)] - (1 if rng.random() < 0.2 else 0)) for x in grp], np.int32)
+            if ngroups == 1:
+                rr[:] = rr[0]
+            val = rng.integers(0, 1 << 30, n).astype(np.int32)
+            tgt = None if rng.random() < 0.5 else W.bits_from_bool(W.random_subsets(rng, n, R, 1, R))
+            op = [("fused", slot, rr, val, tgt)] if rng.random() < 0.6 else [("phase2a", slot, rr, val, tgt)]
+            W.assert_same_outputs(W.run_script(gpu, op), W.run_script(ref, op))
+        else:
+            if rng.random() < 0.5:
+                gpu.flush_promises()
+            W.assert_same_state(gpu, ref)
+    W.assert_same_state(gpu, ref, tally_slots=range(0, S, 97))
+    np.testing.assert_array_equal(gpu.state_digest(), ref.state_digest())
+
+
+def test_phase1a_dev_is_asynchronous_and_equal(fa, oracle):
+    import torch
+
+    S, R = 4096, 256
+    dev = torch.device("cuda:0")
+    for ballot_mode in (0, 1):
+        gpu, ref = both(fa, oracle, num_slots=S, num_replicas=R, f=127, ballot_mode=ballot_mode, tally_ways=8)
+        gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+        rng = np.random.default_rng(3)
+        slot, rnd, val = W.steady_stream(S)
+        t = lambda a: torch.from_numpy(a).to(dev)
+        outs = []
+        for rr, frac in ((0, None), (3, 0.3), (2, None), (3, None)):
+            tgt = None if frac is None else W.bits_from_bool(rng.random((1, R)) < frac)[0]
+            pb = torch.zeros(4, dtype=torch.int64, device=dev)
+            nb = torch.zeros(4, dtype=torch.int64, device=dev)
+            gpu.acceptor_phase1a_dev(0, rr, 0, None if tgt is None else t(tgt.view(np.int64)), pb, nb)
+            ch = torch.zeros(S, dtype=torch.uint8, device=dev)
+            nr = torch.zeros(S, dtype=torch.int32, device=dev)
+            gpu.phase2_fused_dev(t(slot), t(np.full(S, rr, np.int32)), t(val), None, ch, None, None, nr)
+            outs.append((pb, nb, ch, nr, rr, tgt))          # nothing synchronised so far
+        assert gpu.sync() == 0
+        for pb, nb, ch, nr, rr, tgt in outs:
+            st, pb_r, nb_r = ref.acceptor_phase1a(0, rr, 0, tgt)
+            st, ch_r, cr_r, cv_r, nr_r = ref.phase2_fused(slot, np.full(S, rr, np.int32), val)
+            np.testing.assert_array_equal(pb.cpu().numpy().view(np.uint64), pb_r)
+            np.testing.assert_array_equal(nb.cpu().numpy().view(np.uint64), nb_r)
+            np.testing.assert_array_equal(ch.cpu().numpy(), ch_r)
+            np.testing.assert_array_equal(nr.cpu().numpy(), nr_r)
+        W.assert_same_state(gpu, ref, tally_slots=range(0, S, 211))
+        gpu.set_stream(None)
