@@ -255,6 +255,9 @@ def main():
     ap.add_argument("--validate", action="store_true",
                     help="keep the run-contract validation kernel in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", choices=["headline", "2", "3", "4", "5"], default="headline",
+                    help="headline = BASELINE.json's metric grid (2^20 slots x 256 acceptors); 2..5 = the other "
+                         "BASELINE.json configs as bench lines of the same schema (bench_configs.py)")
     ap.add_argument("--replica-row-steps", type=int, default=5,
                     help="N > 1, --shard group: steps of the extra replica-axis row (0 = skip it)")
     args = ap.parse_args()
@@ -311,6 +314,16 @@ def main():
             t.copy_(c)
 
     import frankenpaxos_amd as fa
+
+    if args.config != "headline":
+        import bench_configs
+        line = bench_configs.run(args, fa, dist, dev, rank, world, local_rank, all_reduce)
+        if rank == 0:
+            print(json.dumps(line))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     ballot_mode = fa.FPX_BALLOT_PER_SLOT if args.ballot == "per_slot" else fa.FPX_BALLOT_ACCEPTOR
     K, Wm = args.steps, args.warmup
@@ -469,6 +482,8 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                 "traffic": traffic,
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command in an earlier profiled run "
+                                  "(profiles/traffic.json, profiles/r01_pmc_summary.md) -- not measured in this run",
                 "algorithmic_bytes_per_slot": bps, "slots_per_launch": slots_per_launch,
                 "avg_kernel_ms": kernel_ms / max(launches, 1), "launches_timed": launches,
                 # what bare streaming kernels reach on this chip (profiles/microbench/hbm_mix.hip, best of the

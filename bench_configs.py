@@ -1,0 +1,337 @@
+"""bench.py --config {2,3,4,5}: the other BASELINE.json configs as bench lines (same JSON schema as the headline:
+roofline with that workload's algorithmic bytes, cpu_baseline from the oracle).  The headline metric's grid
+(2^20 slots x 256 acceptors) is bench.py's default and lives there.
+
+  2  MultiPaxos f=1, 64k slots x 3 acceptors               fused K3, one step = 65 536 fresh slots
+  3  Compartmentalized MultiPaxos, 16 groups of 2x2 grids   fused K3, one step = 2^20 fresh slots (slot % 16 -> group)
+  4  EPaxos, 5 replicas                                     K5, one step = one tick of 2^20 fresh commands, 1024 keys
+  5  Mencius, 256 leader groups x 3 acceptors, 4M slots     one step = a band of 2^22 slots: the leader groups that have
+                                                            commands propose them (fused K3), the others skip their
+                                                            slots with one noop range each (fused K4); N > 1: leader
+                                                            groups are sharded over the ranks (strong scaling)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+HBM_PEAK_GBS = 8000.0
+
+
+def _splitmix_values(slot):
+    from bench import steady_values_torch
+    return steady_values_torch(slot)
+
+
+class Timer:
+    """HIP events on the stream the library launches on (the torch current stream, handed to the context)"""
+
+    def __init__(self, n):
+        self.ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        self.k = 0
+
+    def __enter__(self):
+        self.ev[self.k][0].record()
+
+    def __exit__(self, *a):
+        self.ev[self.k][1].record()
+        self.k += 1
+
+    def avg_ms(self):
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.ev[:self.k]) / max(self.k, 1)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# configs 2, 3: the fused MultiPaxos step on other shapes
+# ------------------------------------------------------------------------------------------------------------------
+def multipaxos_setup(fa, dev, local_rank, ballot_mode, cfg, K, Wm):
+    shapes = {
+        "2": dict(slots=65536, R=3, groups=1, kw=dict(f=1, quorum_kind=fa.FPX_Q_THRESHOLD),
+                  name="MultiPaxos f=1: fused Phase-2 step, 65 536 fresh slots x 3 acceptors per step"),
+        "3": dict(slots=1 << 20, R=4, groups=16, kw=dict(quorum_kind=fa.FPX_Q_GRID, grid_rows=2, grid_cols=2),
+                  name="Compartmentalized MultiPaxos: 16 acceptor groups of 2x2 grids (slot % 16 -> group), fused "
+                       "Phase-2 step, 2^20 fresh slots per step"),
+    }[cfg]
+    n, R, G = shapes["slots"], shapes["R"], shapes["groups"]
+    windows = K + Wm
+    ctx = fa.Context(fa.make_config(num_slots=windows * n, num_replicas=R, num_groups=G, ballot_mode=ballot_mode,
+                                    tally_ways=4, device=local_rank, flags=fa.FPX_F_TRUSTED, **shapes["kw"]))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    for g in range(G):
+        assert ctx.acceptor_phase1a(g, 0)[0] == 0
+    ctx.flush_promises()
+    steps = []
+    for w in range(windows):
+        slot = torch.arange(w * n, (w + 1) * n, dtype=torch.int32, device=dev)
+        steps.append((slot, torch.zeros_like(slot), _splitmix_values(slot), torch.zeros(n, dtype=torch.uint8, device=dev),
+                      torch.full((n,), -7, dtype=torch.int32, device=dev), torch.full((n,), -7, dtype=torch.int32, device=dev)))
+
+    def step(i):
+        slot, rnd, val, ch, cr, cv = steps[i]
+        ctx.phase2_fused_dev(slot, rnd, val, None, ch, cr, cv)
+
+    def verify(lo, hi):
+        done = 0
+        for i in range(lo, hi):
+            slot, rnd, val, ch, cr, cv = steps[i]
+            assert bool(ch.all()) and bool((cv == val).all()) and bool((cr == 0).all()), "step %d" % i
+            done += int(ch.sum().item())
+        return done
+
+    cells = (3 if ballot_mode == 1 else 2) * 4 * R        # ballot read (per_slot) + voteRound + voteValue written
+    bps = cells + 12 + 9 + 20                             # + proposal, chosen record, tally key row (16 read + 4 written)
+
+    def cpu(fa_cfg_mode=ballot_mode):
+        from oracle import pyoracle
+        from tests import workloads as W
+        pyoracle.build()
+        S = min(n, 1 << 18)
+        ref = pyoracle.System(pyoracle.make_config(num_slots=S, num_replicas=R, num_groups=G, ballot_mode=ballot_mode,
+                                                   **shapes["kw"]))
+        for g in range(G):
+            ref.acceptor_phase1a(g, 0)
+        slot, rnd, val = W.steady_stream(S)
+        t0 = time.perf_counter()
+        out = ref.phase2_fused(slot, rnd, val)
+        dt = time.perf_counter() - t0
+        assert out[0] == 0 and int(out[1].sum()) == S
+        return {"value": S / dt, "unit": "slots/s", "cores": 1, "kind": "port",
+                "sample": "oracle/fpx_oracle.c fpo_phase2_fused, %d slots of the same workload, 1 thread" % S}
+
+    return dict(ctx=ctx, step=step, verify=verify, units=n, unit="slots/s", bytes_per_unit=bps,
+                workload=shapes["name"], kernel="k_phase2 (fused K3)", profile=lambda: ctx.profile_read(),
+                metric="committed log slots/sec (BASELINE.json configs[%d])" % (int(cfg) - 1), cpu=cpu,
+                extra={"slots_per_step": n, "replicas": R, "acceptor_groups": G,
+                       "ballot_model": "per_slot" if ballot_mode == 1 else "acceptor"})
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# config 4: EPaxos pre-accept ticks
+# ------------------------------------------------------------------------------------------------------------------
+def epaxos_setup(fa, dev, local_rank, K, Wm):
+    from frankenpaxos_amd.epaxos import EPaxos
+    from tests.test_epaxos import random_tick
+    from tests import workloads as W
+
+    n, num_keys, m = 5, 1024, 1 << 20
+    epx = EPaxos(n, num_keys, device=local_rank)
+    epx.set_stream(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(4)
+    nxt = [0] * n
+    ticks = []
+    for t in range(K + Wm):
+        leader, number, key, is_set, mask, rank = random_tick(rng, n, num_keys, m, nxt, 64.0)
+        key = (W.splitmix64_at(np.arange(t * m, (t + 1) * m, dtype=np.uint64)) % np.uint64(num_keys)).astype(np.int32)
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        ticks.append((d(leader), d(number), d(key), d(is_set), d(mask), d(rank),
+                      torch.zeros(m, dtype=torch.uint8, device=dev), torch.zeros((m, n), dtype=torch.int32, device=dev),
+                      torch.zeros((m, n), dtype=torch.int32, device=dev), torch.zeros((m, 2), dtype=torch.int32, device=dev)))
+    timer = Timer(K)
+    state = {"timing": False}
+
+    def step(i):
+        leader, number, key, is_set, mask, rank, fast, deps, ldeps, own = ticks[i]
+        if state["timing"]:
+            with timer:
+                epx.preaccept_dev(leader, number, key, is_set, mask, rank, fast, deps, ldeps, own_values_end=own)
+        else:
+            epx.preaccept_dev(leader, number, key, is_set, mask, rank, fast, deps, ldeps, own_values_end=own)
+
+    def verify(lo, hi):
+        assert epx.sync() == 0
+        done = 0
+        for i in range(lo, hi):
+            fast = ticks[i][6]
+            nf = int(fast.sum().item())
+            assert 0 < nf <= m, "tick %d: %d fast-path commits" % (i, nf)
+            assert bool((ticks[i][9] == 0).all())       # FIFO channels: no own-column holes
+            done += m                                   # every command is decided (fast commit or Accept phase)
+        return done
+
+    def profile():
+        state["timing"] = False
+        return timer.k, timer.avg_ms() * timer.k
+
+    def cpu():
+        from oracle import pyoracle
+        pyoracle.build()
+        mm = 1 << 18
+        ref = pyoracle.EPaxos(n, num_keys)
+        args = random_tick(np.random.default_rng(5), n, num_keys, mm, [0] * n, 64.0)
+        t0 = time.perf_counter()
+        out = ref.preaccept(*args)
+        dt = time.perf_counter() - t0
+        assert out[0] == 0
+        return {"value": mm / dt, "unit": "commands/s", "cores": 1, "kind": "port",
+                "sample": "oracle/fpx_oracle_epaxos.c fpo_epx_preaccept, one tick of 2^18 commands, 1 thread"}
+
+    # per command: inputs (leader, number, key 12 B, is_set + mask 2 B, rank 5 x 4 B) read; the n-1 = 4 PreAcceptOk
+    # dependency rows (n x 4 B each) written by the scans and read by the decision; fast + deps + leader_deps +
+    # own_values_end written
+    bpc = 34 + 4 * 20 * 2 + (1 + 20 + 20 + 8)
+    return dict(ctx=epx, step=step, verify=verify, units=m, unit="commands/s", bytes_per_unit=bpc,
+                workload="EPaxos n = 5: one tick = 2^20 fresh single-key commands (1024 keys, Bernoulli get/set) through "
+                         "the pre-accept phase of all replicas: conflict scan in every replica's delivery order, "
+                         "fast-path test, slow-path union, commit into every conflict index",
+                kernel="K5 tick (k_epx_keys, radix sort, k_epx_scan, k_epx_decide, k_epx_commit)", profile=profile,
+                metric="EPaxos commands decided/sec (BASELINE.json configs[3])", cpu=cpu,
+                extra={"commands_per_tick": m, "replicas": n, "keys": num_keys}, start_timing=lambda: state.update(timing=True))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# config 5: Mencius bands -- commands from half of the leader groups, noop ranges from the other half
+# ------------------------------------------------------------------------------------------------------------------
+def mencius_setup(fa, dev, local_rank, rank, world, K, Wm):
+    L_total, R, band_total = 256, 3, 1 << 22
+    if L_total % world:
+        raise SystemExit("--config 5 shards 256 leader groups: --gpus must divide 256")
+    L = L_total // world                 # this rank's leader groups (a Mencius deployment of its own: slot % L)
+    band = band_total // world           # its slots per step
+    rows = band // L
+    windows = K + Wm
+    ctx = fa.Context(fa.make_config(num_slots=windows * band, num_replicas=R, num_groups=1, num_leader_groups=L, f=1,
+                                    tally_ways=4, device=local_rank, flags=fa.FPX_F_TRUSTED))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    for lg in range(L):
+        assert ctx.acceptor_phase1a(lg, 0)[0] == 0
+    steps = []
+    lgs = torch.arange(L, device=dev)
+    for w in range(windows):
+        active = (lgs + w) % 2 == 0                       # the leader groups with commands alternate
+        base = w * band
+        r = torch.arange(rows, device=dev, dtype=torch.int64)
+        slot = (base + r[:, None] * L + lgs[active][None, :]).reshape(-1).to(torch.int32)
+        idle = lgs[~active]
+        start = (base + idle).to(torch.int32)
+        end = (base + (rows - 1) * L + idle + 1).to(torch.int32)
+        steps.append((slot, torch.zeros_like(slot), _splitmix_values(slot),
+                      torch.zeros(slot.numel(), dtype=torch.uint8, device=dev),
+                      torch.full((slot.numel(),), -7, dtype=torch.int32, device=dev),
+                      start.contiguous(), end.contiguous(), torch.zeros_like(start),
+                      torch.zeros(start.numel(), dtype=torch.uint8, device=dev)))
+    timer = Timer(K)
+    state = {"timing": False}
+
+    def step(i):
+        slot, rnd, val, ch, cv, start, end, rr, rch = steps[i]
+        ctx.phase2_fused_dev(slot, rnd, val, None, ch, None, cv)
+        if state["timing"]:
+            with timer:
+                ctx.noop_ranges_fused_dev(start, end, rr, None, None, None, None, None, rch)
+        else:
+            ctx.noop_ranges_fused_dev(start, end, rr, None, None, None, None, None, rch)
+
+    def verify(lo, hi):
+        done = 0
+        for i in range(lo, hi):
+            slot, rnd, val, ch, cv, start, end, rr, rch = steps[i]
+            assert bool(ch.all()) and bool((cv == val).all()), "step %d: commands" % i
+            assert bool(rch.all()), "step %d: noop ranges" % i
+            done += int(ch.sum().item()) + int(rch.sum().item()) * rows     # a chosen range commits its `rows` slots
+        return done
+
+    def profile():
+        n2, ms2 = ctx.profile_read()
+        return n2, ms2 + timer.avg_ms() * timer.k        # both kernels of the step: k_phase2 + the K4 chain
+
+    def cpu():
+        from oracle import pyoracle
+        from tests import workloads as W
+        pyoracle.build()
+        S = 1 << 19
+        ref = pyoracle.System(pyoracle.make_config(num_slots=S, num_replicas=R, num_groups=1, num_leader_groups=256, f=1))
+        for lg in range(256):
+            ref.acceptor_phase1a(lg, 0)
+        lg = np.arange(256)
+        rws = S // 256
+        slot = (np.arange(rws)[:, None] * 256 + lg[lg % 2 == 0][None, :]).reshape(-1).astype(np.int32)
+        idle = lg[lg % 2 == 1]
+        t0 = time.perf_counter()
+        a = ref.phase2_fused(slot, np.zeros(len(slot), np.int32), W.steady_values(slot))
+        b = ref.noop_ranges_fused(idle.astype(np.int32), ((rws - 1) * 256 + idle + 1).astype(np.int32), np.zeros(128, np.int32))
+        dt = time.perf_counter() - t0
+        assert a[0] == 0 and b[0] == 0 and a[1].all() and b[5].all()
+        return {"value": S / dt, "unit": "slots/s", "cores": 1, "kind": "port",
+                "sample": "oracle/fpx_oracle.c: one band of 2^19 slots, 256 leader groups (128 propose commands through "
+                          "fpo_phase2_fused, 128 skip through fpo_noop_ranges_fused), 1 thread"}
+
+    # per slot: voteRound + voteValue of 3 acceptors written (24 B); command slots add proposal 12 + chosen 5 + tally key
+    # row 20 B (half of the slots): 24 + 18.5
+    bps = 24 + 0.5 * (12 + 5 + 20)
+    return dict(ctx=ctx, step=step, verify=verify, units=band, unit="slots/s", bytes_per_unit=bps,
+                workload="Mencius: %d leader groups x 3 acceptors on this GPU (256 in the job), one step = a band of "
+                         "%d slots: half of the leader groups propose commands in their slots (fused K3), the others "
+                         "skip theirs with one noop range each (fused K4)" % (L, band),
+                kernel="k_phase2 (fused K3) + K4 chain (k_ranges_open .. k_ranges_tally)", profile=profile,
+                metric="committed log slots/sec (BASELINE.json configs[4])", cpu=cpu,
+                extra={"slots_per_step_per_gpu": band, "leader_groups_per_gpu": L, "replicas": R,
+                       "ranges_per_step_per_gpu": L // 2},
+                start_timing=lambda: state.update(timing=True), scaling="strong")
+
+
+def run(args, fa, dist, dev, rank, world, local_rank, all_reduce):
+    K, Wm = args.steps, args.warmup
+    ballot_mode = fa.FPX_BALLOT_PER_SLOT if args.ballot == "per_slot" else fa.FPX_BALLOT_ACCEPTOR
+    if args.config in ("2", "3"):
+        w = multipaxos_setup(fa, dev, local_rank, ballot_mode, args.config, K, Wm)
+    elif args.config == "4":
+        w = epaxos_setup(fa, dev, local_rank, K, Wm)
+    else:
+        w = mencius_setup(fa, dev, local_rank, rank, world, K, Wm)
+    ctx = w["ctx"]
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(Wm):
+        w["step"](i)
+    assert ctx.sync() == 0
+    if hasattr(ctx, "profile_enable"):
+        ctx.profile_enable(True)
+    if "start_timing" in w:
+        w["start_timing"]()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(Wm, Wm + K):
+        w["step"](i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    launches, kernel_ms = w["profile"]()
+    assert ctx.sync() == 0
+    done = w["verify"](Wm, Wm + K)
+    assert done == K * w["units"], (done, K * w["units"])
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        all_reduce(t, dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        t = torch.tensor([done], dtype=torch.int64, device=dev)
+        all_reduce(t, dist.ReduceOp.SUM)
+        done = int(t.item())
+    if rank != 0:
+        return None
+    avg_kernel_s = (kernel_ms / max(launches, 1)) * 1e-3
+    achieved = w["bytes_per_unit"] * w["units"] / avg_kernel_s / 1e9 if launches else None
+    line = {
+        "metric": w["metric"], "value": done / elapsed, "unit": w["unit"], "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": w.get("scaling", "weak"),
+        "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": dict({"workload": w["workload"], "baseline_config": int(args.config)}, **w["extra"]),
+        "roofline": {
+            "bound": "hbm", "kernel": w["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+            "algorithmic_bytes_per_unit": w["bytes_per_unit"], "units_per_launch": w["units"],
+            "avg_kernel_ms": kernel_ms / max(launches, 1), "launches_timed": launches,
+            "note": "small-row workloads are bound by request rate and dependent-step latency, not HBM bytes: the "
+                    "fraction of the HBM peak is reported for the contract, the absolute rate is the figure of merit",
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = w["cpu"]()
+    return line

@@ -84,3 +84,16 @@ def test_single_gpu_bench_contract():
     assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "int32"
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
     assert "workload" in d["config"]
+
+
+@pytest.mark.parametrize("config", ["2", "3", "4", "5"])
+def test_bench_lines_of_the_other_configs(config):
+    """every BASELINE.json config has a bench line of the headline's schema"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "3",
+                          "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "config", "roofline"):
+        assert key in d
+    assert d["config"]["baseline_config"] == int(config) and d["value"] > 0 and d["steps"] == 3
+    assert d["roofline"]["launches_timed"] == 3 and d["roofline"]["achieved"] > 0
