@@ -33,11 +33,17 @@ def test_library_exports_every_declared_symbol(fa):
         assert hasattr(lib, name), "libfpx.so does not export %s" % name
     # and the python binding binds exactly the header's surface
     assert sorted(fa._lib.SIGNATURES) == names
+    # the wire adapter's header (include/fpx_wire.h) is part of the same library
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "fpx_wire.h")).read(), flags=re.S)
+    wire = sorted(set(re.findall(r"\b(fpx_wire_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(wire) >= 11
+    for name in wire:
+        assert hasattr(lib, name), "libfpx.so does not export %s" % name
 
 
 def test_header_compiles_as_c_and_cxx(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "fpx.h"\nint main(void){fpx_config c; (void)c; return FPX_OK;}\n')
+    src.write_text('#include "fpx.h"\n#include "fpx_wire.h"\nint main(void){fpx_config c; (void)c; return FPX_OK + FPX_WIRE_OTHER;}\n')
     inc = os.path.join(ROOT, "include")
     assert os.system("gcc -std=c99 -Wall -Werror -I%s -c %s -o %s" % (inc, src, tmp_path / "t.o")) == 0
     assert os.system("g++ -std=c++17 -Wall -Werror -I%s -x c++ -c %s -o %s" % (inc, src, tmp_path / "t2.o")) == 0
