@@ -49,28 +49,46 @@ object Native {
                                 nackRound: java.nio.ByteBuffer): Int
 
   // the rows around the fused step
+  @native def roundLeader(numLeaders: Int, round: Int): Int // < 0: -status (numLeaders < 1)
   @native def acceptorPhase1a(handle: Long, group: Int, round: Int, chosenWatermark: Int,
                               targetMask: Array[Long], bits: Array[Long]): Int
-  @native def leaderPhase1bScan(handle: Long, chosenWatermark: Int, quorumMasks: Array[Long],
-                                cap: Int, maxSlot: Array[Int], safeRound: Array[Int],
-                                safeValue: Array[Int]): Int
+  @native def leaderPhase1bScan(handle: Long, chosenWatermark: Int, numGroups: Int,
+                                quorumMasks: Array[Long], cap: Int, maxSlot: Array[Int],
+                                safeRound: Array[Int], safeValue: Array[Int]): Int
   @native def replicaChosen(handle: Long, n: Int, slot: Array[Int], value: Array[Int],
                             mask: Array[Byte], state: Array[Int]): Int
   @native def replicaChosenNoopRange(handle: Long, slotStart: Int, slotEnd: Int,
                                      state: Array[Int]): Int
+  // Mencius noop ranges: n per call (the fused step), and the unfused pieces for one range
+  @native def noopRangesFused(handle: Long, n: Int, numGroups: Int, slotStart: Array[Int],
+                              slotEnd: Array[Int], round: Array[Int], targetMasks: Array[Long],
+                              voteBits: Array[Long], nackBits: Array[Long], nackRound: Array[Int],
+                              isNew: Array[Byte], chosen: Array[Byte]): Int
   @native def acceptorPhase2aNoopRange(handle: Long, slotStart: Int, slotEnd: Int, round: Int,
                                        numGroups: Int, targetMasks: Array[Long],
                                        bits: Array[Long], nackRound: Array[Int]): Int
   @native def proxyOpenNoopRange(handle: Long, slotStart: Int, slotEnd: Int, round: Int,
                                  isNew: Array[Byte]): Int
   @native def proxyPhase2bNoopRange(handle: Long, slotStart: Int, slotEnd: Int, round: Int,
-                                    voteBits: Array[Long], newlyChosen: Array[Byte]): Int
+                                    numGroups: Int, voteBits: Array[Long],
+                                    newlyChosen: Array[Byte]): Int
   @native def epxCreate(numReplicas: Int, numKeys: Int, device: Int): Long // < 0: -status
   @native def epxDestroy(handle: Long): Int
-  @native def epxPreaccept(handle: Long, m: Int, leader: Array[Int], number: Array[Int],
-                           key: Array[Int], isSet: Array[Byte], respMask: Array[Byte],
-                           seenMask: Array[Byte], rank: Array[Int], fast: Array[Byte], deps: Array[Int],
-                           leaderDeps: Array[Int], ownValuesEnd: Array[Int]): Int
+  @native def epxPreaccept(handle: Long, m: Int, numReplicas: Int, leader: Array[Int],
+                           number: Array[Int], key: Array[Int], isSet: Array[Byte],
+                           respMask: Array[Byte], seenMask: Array[Byte], rank: Array[Int],
+                           fast: Array[Byte], deps: Array[Int], leaderDeps: Array[Int],
+                           ownValuesEnd: Array[Int]): Int
+  // multi-GPU: one context per GPU, one RCCL communicator over them (fpx_comm_*); the 128-byte id of
+  // commUniqueId travels to the other ranks over the actors' own transport
+  @native def commUniqueId(id: Array[Byte]): Int
+  @native def commCreate(handle: Long, id: Array[Byte], rank: Int, world: Int): Int
+  @native def commDestroy(handle: Long): Int
+  // wire adapter: a tick of ProxyLeaderInbound byte arrays packed into one direct buffer + n + 1
+  // offsets -> fields = kind | slot | round | isNoop | valueLen | groupIndex | acceptorIndex (7 x n)
+  @native def wireDecodeProxyLeaderInbound(buf: java.nio.ByteBuffer, offsets: Array[Long], n: Int,
+                                           fields: Array[Int], valueOff: Array[Long],
+                                           badIndex: Array[Int]): Int
 
   def check(status: Int, logger: Logger): Unit = status match {
     case OK                       => ()

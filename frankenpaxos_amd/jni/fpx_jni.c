@@ -1,52 +1,111 @@
 /*
- * fpx_jni.c -- the JNI shim between the reference's JVM actors and the C ABI of include/fpx.h.
+ * fpx_jni.c -- the JNI shim between the reference's JVM actors and the C ABI of include/fpx.h / fpx_wire.h.
  *
- * Source only: this image has no JDK (no jni.h), so the shim cannot be compiled or run here; build it
- * on a machine with a JDK via `make -C frankenpaxos_amd/jni JAVA_HOME=/path/to/jdk`.  It is
- * deliberately thin: every function pins the primitive arrays of one SoA batch and forwards to one
- * entry point of libfpx.  Scala side: frankenpaxos_amd/jni/Native.scala.
+ * Class: frankenpaxos.gpu.Native (frankenpaxos_amd/jni/Native.scala; all methods static native returning the
+ * int32 status).  Build on a machine with a JDK: `make -C frankenpaxos_amd/jni JAVA_HOME=/path/to/jdk`.  This
+ * image has no JDK; tests/jni_stub/ carries a small mock of the JNI function table the shim uses, against which
+ * the shim is compiled AND RUN by tests/test_jni_shim.py (argument checking on the CPU, a fused tick on the GPU).
  *
- * Class: frankenpaxos.gpu.Native (all methods static native, returning the int32 status).
+ * Rules the shim keeps (JNI specification):
+ *   - no blocking call ever runs inside a Get/ReleasePrimitiveArrayCritical region: libfpx entry points allocate,
+ *     copy over PCIe and synchronise the GPU stream, and a critical region stalls the garbage collector for all
+ *     of it.  Primitive arrays are COPIED in and out with Get/Set<Type>ArrayRegion (a memcpy each; the payload
+ *     crosses PCIe anyway); the zero-copy path is the *Direct natives over direct ByteBuffers (page-locked
+ *     memory from hostAlloc), which is also what the reference's Netty transport hands out.
+ *   - every array is checked against the batch size before native code touches it: a short array is FPX_EINVAL
+ *     (the IllegalArgumentException of a require(...)), never an out-of-bounds read or write.
  */
 #include <jni.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "../../include/fpx.h"
+#include "../../include/fpx_wire.h"
 
-#define PIN(env, arr) ((arr) ? (*(env))->GetPrimitiveArrayCritical((env), (arr), NULL) : NULL)
-#define UNPIN(env, arr, p, mode) \
-  do { if (arr) (*(env))->ReleasePrimitiveArrayCritical((env), (arr), (p), (mode)); } while (0)
+#define CTX(h) ((fpx_ctx*)(intptr_t)(h))
 
-/* long create(int[] cfg /* the 15 fpx_config fields in order *\/) -> handle or -status */
+/* ---- checked copies between Java arrays and native buffers ------------------------------------------------ */
+static int has(JNIEnv* env, jarray a, jlong need) { return a != NULL && (jlong)(*env)->GetArrayLength(env, a) >= need; }
+/* an optional array: absent, or long enough */
+static int opt(JNIEnv* env, jarray a, jlong need) { return a == NULL || has(env, a, need); }
+
+static jint* in_ints(JNIEnv* env, jintArray a, jlong n) {
+  if (!a || n <= 0) return NULL;
+  jint* p = (jint*)malloc((size_t)n * sizeof(jint));
+  if (p) (*env)->GetIntArrayRegion(env, a, 0, (jsize)n, p);
+  return p;
+}
+static jlong* in_longs(JNIEnv* env, jlongArray a, jlong n) {
+  if (!a || n <= 0) return NULL;
+  jlong* p = (jlong*)malloc((size_t)n * sizeof(jlong));
+  if (p) (*env)->GetLongArrayRegion(env, a, 0, (jsize)n, p);
+  return p;
+}
+static jbyte* in_bytes(JNIEnv* env, jbyteArray a, jlong n) {
+  if (!a || n <= 0) return NULL;
+  jbyte* p = (jbyte*)malloc((size_t)n);
+  if (p) (*env)->GetByteArrayRegion(env, a, 0, (jsize)n, p);
+  return p;
+}
+static void* out_buf(jarray a, jlong n, size_t elem) { return (a && n > 0) ? calloc((size_t)n, elem) : NULL; }
+static void put_ints(JNIEnv* env, jintArray a, jlong n, const jint* p) {
+  if (a && p && n > 0) (*env)->SetIntArrayRegion(env, a, 0, (jsize)n, p);
+}
+static void put_longs(JNIEnv* env, jlongArray a, jlong n, const jlong* p) {
+  if (a && p && n > 0) (*env)->SetLongArrayRegion(env, a, 0, (jsize)n, p);
+}
+static void put_bytes(JNIEnv* env, jbyteArray a, jlong n, const jbyte* p) {
+  if (a && p && n > 0) (*env)->SetByteArrayRegion(env, a, 0, (jsize)n, p);
+}
+
+static int read_config(JNIEnv* env, jintArray jcfg, fpx_config* cfg) {
+  jint c[15];
+  if (!has(env, jcfg, 15)) return FPX_EINVAL;
+  (*env)->GetIntArrayRegion(env, jcfg, 0, 15, c);
+  cfg->num_slots = c[0]; cfg->num_replicas = c[1]; cfg->num_groups = c[2]; cfg->num_leader_groups = c[3];
+  cfg->f = c[4]; cfg->quorum_kind = c[5]; cfg->grid_rows = c[6]; cfg->grid_cols = c[7]; cfg->num_leaders = c[8];
+  cfg->ballot_mode = c[9]; cfg->tally_ways = c[10]; cfg->replica_base = c[11]; cfg->replicas_total = c[12];
+  cfg->device = c[13]; cfg->flags = (uint32_t)c[14];
+  return FPX_OK;
+}
+
+/* long create(int[] cfg: the 15 fpx_config fields in order) -> handle, or -status */
 JNIEXPORT jlong JNICALL Java_frankenpaxos_gpu_Native_create(JNIEnv* env, jclass cls, jintArray jcfg) {
   fpx_config cfg;
-  jint* c = (jint*)PIN(env, jcfg);
-  cfg.num_slots = c[0]; cfg.num_replicas = c[1]; cfg.num_groups = c[2]; cfg.num_leader_groups = c[3];
-  cfg.f = c[4]; cfg.quorum_kind = c[5]; cfg.grid_rows = c[6]; cfg.grid_cols = c[7]; cfg.num_leaders = c[8];
-  cfg.ballot_mode = c[9]; cfg.tally_ways = c[10]; cfg.replica_base = c[11]; cfg.replicas_total = c[12];
-  cfg.device = c[13]; cfg.flags = (uint32_t)c[14];
-  UNPIN(env, jcfg, c, JNI_ABORT);
+  int32_t st = read_config(env, jcfg, &cfg);
+  if (st) return -(jlong)st;
   fpx_ctx* ctx = NULL;
-  int32_t st = fpx_create(&cfg, &ctx);
+  st = fpx_create(&cfg, &ctx);
   return st == FPX_OK ? (jlong)(intptr_t)ctx : -(jlong)st;
 }
 
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_destroy(JNIEnv* env, jclass cls, jlong h) {
-  return fpx_destroy((fpx_ctx*)(intptr_t)h);
+  return fpx_destroy(CTX(h));
+}
+
+/* ClassicRoundRobin (roundsystem/RoundSystem.scala:60-87); numLeaders < 1 is the require() of :61 */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_roundLeader(JNIEnv* env, jclass cls, jint numLeaders, jint round) {
+  return numLeaders < 1 ? -FPX_EINVAL : fpx_round_leader(numLeaders, round);
 }
 
 /* Acceptor.handlePhase2a for one tick: multipaxos/Acceptor.scala:184-220 */
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_acceptorPhase2a(
     JNIEnv* env, jclass cls, jlong h, jint n, jintArray slot, jintArray round, jintArray value,
     jlongArray targetMask, jlongArray voteBits, jlongArray nackBits, jintArray nackRound) {
-  jint *s = PIN(env, slot), *r = PIN(env, round), *v = PIN(env, value), *nr = PIN(env, nackRound);
-  jlong *t = PIN(env, targetMask), *vb = PIN(env, voteBits), *nb = PIN(env, nackBits);
-  int32_t st = fpx_acceptor_phase2a((fpx_ctx*)(intptr_t)h, n, s, r, v, (const uint64_t*)t, (uint64_t*)vb,
-                                    (uint64_t*)nb, nr);
-  UNPIN(env, nackBits, nb, 0); UNPIN(env, voteBits, vb, 0); UNPIN(env, targetMask, t, JNI_ABORT);
-  UNPIN(env, nackRound, nr, 0); UNPIN(env, value, v, JNI_ABORT); UNPIN(env, round, r, JNI_ABORT);
-  UNPIN(env, slot, s, JNI_ABORT);
+  if (n < 0) return FPX_EINVAL;
+  if (n == 0) return FPX_OK;
+  if (!has(env, slot, n) || !has(env, round, n) || !has(env, value, n) || !opt(env, targetMask, 4 * (jlong)n) ||
+      !opt(env, voteBits, 4 * (jlong)n) || !opt(env, nackBits, 4 * (jlong)n) || !opt(env, nackRound, n))
+    return FPX_EINVAL;
+  jint *s = in_ints(env, slot, n), *r = in_ints(env, round, n), *v = in_ints(env, value, n);
+  jlong* t = in_longs(env, targetMask, 4 * (jlong)n);
+  jlong *vb = out_buf(voteBits, 4 * (jlong)n, 8), *nb = out_buf(nackBits, 4 * (jlong)n, 8);
+  jint* nr = out_buf(nackRound, n, 4);
+  int32_t st = fpx_acceptor_phase2a(CTX(h), n, s, r, v, (const uint64_t*)t, (uint64_t*)vb, (uint64_t*)nb, nr);
+  put_longs(env, voteBits, 4 * (jlong)n, vb); put_longs(env, nackBits, 4 * (jlong)n, nb); put_ints(env, nackRound, n, nr);
+  free(s); free(r); free(v); free(t); free(vb); free(nb); free(nr);
   return st;
 }
 
@@ -54,11 +113,14 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_acceptorPhase2a(
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_proxyOpen(JNIEnv* env, jclass cls, jlong h, jint n,
                                                               jintArray slot, jintArray round, jintArray value,
                                                               jbyteArray isNew) {
-  jint *s = PIN(env, slot), *r = PIN(env, round), *v = PIN(env, value);
-  jbyte* f = PIN(env, isNew);
-  int32_t st = fpx_proxy_open((fpx_ctx*)(intptr_t)h, n, s, r, v, (uint8_t*)f);
-  UNPIN(env, isNew, f, 0); UNPIN(env, value, v, JNI_ABORT); UNPIN(env, round, r, JNI_ABORT);
-  UNPIN(env, slot, s, JNI_ABORT);
+  if (n < 0) return FPX_EINVAL;
+  if (n == 0) return FPX_OK;
+  if (!has(env, slot, n) || !has(env, round, n) || !has(env, value, n) || !opt(env, isNew, n)) return FPX_EINVAL;
+  jint *s = in_ints(env, slot, n), *r = in_ints(env, round, n), *v = in_ints(env, value, n);
+  jbyte* f = out_buf(isNew, n, 1);
+  int32_t st = fpx_proxy_open(CTX(h), n, s, r, v, (uint8_t*)f);
+  put_bytes(env, isNew, n, f);
+  free(s); free(r); free(v); free(f);
   return st;
 }
 
@@ -67,12 +129,18 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_proxyPhase2b(JNIEnv* env, jc
                                                                  jintArray slot, jintArray round, jlongArray voteBits,
                                                                  jbyteArray newlyChosen, jintArray chosenRound,
                                                                  jintArray chosenValue) {
-  jint *s = PIN(env, slot), *r = PIN(env, round), *cr = PIN(env, chosenRound), *cv = PIN(env, chosenValue);
-  jlong* vb = PIN(env, voteBits);
-  jbyte* ch = PIN(env, newlyChosen);
-  int32_t st = fpx_proxy_phase2b((fpx_ctx*)(intptr_t)h, n, s, r, (const uint64_t*)vb, (uint8_t*)ch, cr, cv);
-  UNPIN(env, newlyChosen, ch, 0); UNPIN(env, voteBits, vb, JNI_ABORT); UNPIN(env, chosenValue, cv, 0);
-  UNPIN(env, chosenRound, cr, 0); UNPIN(env, round, r, JNI_ABORT); UNPIN(env, slot, s, JNI_ABORT);
+  if (n < 0) return FPX_EINVAL;
+  if (n == 0) return FPX_OK;
+  if (!has(env, slot, n) || !has(env, round, n) || !has(env, voteBits, 4 * (jlong)n) || !opt(env, newlyChosen, n) ||
+      !opt(env, chosenRound, n) || !opt(env, chosenValue, n))
+    return FPX_EINVAL;
+  jint *s = in_ints(env, slot, n), *r = in_ints(env, round, n);
+  jlong* vb = in_longs(env, voteBits, 4 * (jlong)n);
+  jbyte* ch = out_buf(newlyChosen, n, 1);
+  jint *cr = out_buf(chosenRound, n, 4), *cv = out_buf(chosenValue, n, 4);
+  int32_t st = fpx_proxy_phase2b(CTX(h), n, s, r, (const uint64_t*)vb, (uint8_t*)ch, cr, cv);
+  put_bytes(env, newlyChosen, n, ch); put_ints(env, chosenRound, n, cr); put_ints(env, chosenValue, n, cv);
+  free(s); free(r); free(vb); free(ch); free(cr); free(cv);
   return st;
 }
 
@@ -80,36 +148,42 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_proxyPhase2b(JNIEnv* env, jc
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_phase2Fused(
     JNIEnv* env, jclass cls, jlong h, jint n, jintArray slot, jintArray round, jintArray value,
     jlongArray targetMask, jbyteArray chosen, jintArray chosenRound, jintArray chosenValue, jintArray nackRound) {
-  jint *s = PIN(env, slot), *r = PIN(env, round), *v = PIN(env, value);
-  jint *cr = PIN(env, chosenRound), *cv = PIN(env, chosenValue), *nr = PIN(env, nackRound);
-  jlong* t = PIN(env, targetMask);
-  jbyte* ch = PIN(env, chosen);
-  int32_t st = fpx_phase2_fused((fpx_ctx*)(intptr_t)h, n, s, r, v, (const uint64_t*)t, (uint8_t*)ch, cr, cv, nr);
-  UNPIN(env, chosen, ch, 0); UNPIN(env, targetMask, t, JNI_ABORT); UNPIN(env, nackRound, nr, 0);
-  UNPIN(env, chosenValue, cv, 0); UNPIN(env, chosenRound, cr, 0); UNPIN(env, value, v, JNI_ABORT);
-  UNPIN(env, round, r, JNI_ABORT); UNPIN(env, slot, s, JNI_ABORT);
+  if (n < 0) return FPX_EINVAL;
+  if (n == 0) return FPX_OK;
+  if (!has(env, slot, n) || !has(env, round, n) || !has(env, value, n) || !opt(env, targetMask, 4 * (jlong)n) ||
+      !opt(env, chosen, n) || !opt(env, chosenRound, n) || !opt(env, chosenValue, n) || !opt(env, nackRound, n))
+    return FPX_EINVAL;
+  jint *s = in_ints(env, slot, n), *r = in_ints(env, round, n), *v = in_ints(env, value, n);
+  jlong* t = in_longs(env, targetMask, 4 * (jlong)n);
+  jbyte* ch = out_buf(chosen, n, 1);
+  jint *cr = out_buf(chosenRound, n, 4), *cv = out_buf(chosenValue, n, 4), *nr = out_buf(nackRound, n, 4);
+  int32_t st = fpx_phase2_fused(CTX(h), n, s, r, v, (const uint64_t*)t, (uint8_t*)ch, cr, cv, nr);
+  put_bytes(env, chosen, n, ch); put_ints(env, chosenRound, n, cr); put_ints(env, chosenValue, n, cv);
+  put_ints(env, nackRound, n, nr);
+  free(s); free(r); free(v); free(t); free(ch); free(cr); free(cv); free(nr);
   return st;
 }
 
 /* quorums.*.isWriteQuorum / isSuperSetOfWriteQuorum on bitmaps: quorums/QuorumSystem.scala:21,24 */
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_quorumEval(JNIEnv* env, jclass cls, jintArray jcfg, jint n,
                                                                jlongArray nodes, jint strict, jbyteArray out) {
-  fpx_config cfg = {0};
-  jint* c = (jint*)PIN(env, jcfg);
-  cfg.num_slots = 1; cfg.num_replicas = c[1]; cfg.num_groups = 1; cfg.num_leader_groups = 1; cfg.f = c[4];
-  cfg.quorum_kind = c[5]; cfg.grid_rows = c[6]; cfg.grid_cols = c[7]; cfg.num_leaders = 1; cfg.tally_ways = 1;
-  UNPIN(env, jcfg, c, JNI_ABORT);
-  jlong* nd = PIN(env, nodes);
-  jbyte* o = PIN(env, out);
-  int32_t st = fpx_quorum_eval(&cfg, n, (const uint64_t*)nd, strict, (uint8_t*)o);
-  UNPIN(env, out, o, 0); UNPIN(env, nodes, nd, JNI_ABORT);
+  fpx_config cfg;
+  int32_t st = read_config(env, jcfg, &cfg);
+  if (st) return st;
+  if (n < 0 || (n > 0 && (!has(env, nodes, 4 * (jlong)n) || !has(env, out, n)))) return FPX_EINVAL;
+  if (n == 0) return FPX_OK;
+  jlong* nd = in_longs(env, nodes, 4 * (jlong)n);
+  jbyte* o = out_buf(out, n, 1);
+  st = fpx_quorum_eval(&cfg, n, (const uint64_t*)nd, strict, (uint8_t*)o);
+  put_bytes(env, out, n, o);
+  free(nd); free(o);
   return st;
 }
 
 /* ---- page-locked batches: direct ByteBuffers over fpx_host_alloc memory ------------------------------
  * A tick's SoA batch lives in direct buffers the JVM fills in place (IntBuffer / LongBuffer views, native
  * byte order), the counterpart of the Netty direct buffers the reference's transport decodes from: no
- * array pinning, no copy, DMA straight out of the buffer. */
+ * copy, DMA straight out of the buffer. */
 JNIEXPORT jobject JNICALL Java_frankenpaxos_gpu_Native_hostAlloc(JNIEnv* env, jclass cls, jlong bytes) {
   void* p = NULL;
   if (fpx_host_alloc(bytes, &p) != FPX_OK) return NULL;
@@ -120,15 +194,29 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_hostFree(JNIEnv* env, jclass
   return fpx_host_free(buffer ? (*env)->GetDirectBufferAddress(env, buffer) : NULL);
 }
 
-#define ADDR(env, buf) ((buf) ? (*(env))->GetDirectBufferAddress((env), (buf)) : NULL)
+/* address of a direct buffer that must hold `need` bytes; *bad is set when it is present but too small or not direct */
+static void* direct(JNIEnv* env, jobject buf, jlong need, int* bad) {
+  if (!buf) return NULL;
+  void* p = (*env)->GetDirectBufferAddress(env, buf);
+  if (!p || (*env)->GetDirectBufferCapacity(env, buf) < need) *bad = 1;
+  return p;
+}
 
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_phase2FusedDirect(
     JNIEnv* env, jclass cls, jlong h, jint n, jobject slot, jobject round, jobject value, jobject targetMask,
     jobject chosen, jobject chosenRound, jobject chosenValue, jobject nackRound) {
-  return fpx_phase2_fused((fpx_ctx*)(intptr_t)h, n, (const int32_t*)ADDR(env, slot), (const int32_t*)ADDR(env, round),
-                          (const int32_t*)ADDR(env, value), (const uint64_t*)ADDR(env, targetMask),
-                          (uint8_t*)ADDR(env, chosen), (int32_t*)ADDR(env, chosenRound),
-                          (int32_t*)ADDR(env, chosenValue), (int32_t*)ADDR(env, nackRound));
+  if (n < 0) return FPX_EINVAL;
+  int bad = 0;
+  const jlong n4 = 4 * (jlong)n, n32 = 32 * (jlong)n;
+  const int32_t* s = direct(env, slot, n4, &bad);
+  const int32_t* r = direct(env, round, n4, &bad);
+  const int32_t* v = direct(env, value, n4, &bad);
+  const uint64_t* t = direct(env, targetMask, n32, &bad);
+  uint8_t* ch = direct(env, chosen, n, &bad);
+  int32_t *cr = direct(env, chosenRound, n4, &bad), *cv = direct(env, chosenValue, n4, &bad);
+  int32_t* nr = direct(env, nackRound, n4, &bad);
+  if (bad || (n > 0 && (!s || !r || !v))) return FPX_EINVAL;
+  return fpx_phase2_fused(CTX(h), n, s, r, v, t, ch, cr, cv, nr);
 }
 
 /* ---- the rows around the fused step ---------------------------------------------------------------------- */
@@ -136,23 +224,30 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_phase2FusedDirect(
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_acceptorPhase1a(JNIEnv* env, jclass cls, jlong h, jint group,
                                                                     jint round, jint chosenWatermark,
                                                                     jlongArray targetMask, jlongArray bits) {
-  jlong *t = PIN(env, targetMask), *b = PIN(env, bits);
-  int32_t st = fpx_acceptor_phase1a((fpx_ctx*)(intptr_t)h, group, round, chosenWatermark, (const uint64_t*)t,
-                                    (uint64_t*)b, b ? (uint64_t*)b + 4 : NULL);
-  UNPIN(env, bits, b, 0); UNPIN(env, targetMask, t, JNI_ABORT);
+  if (!opt(env, targetMask, 4) || !opt(env, bits, 8)) return FPX_EINVAL;
+  jlong t[4], b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (targetMask) (*env)->GetLongArrayRegion(env, targetMask, 0, 4, t);
+  int32_t st = fpx_acceptor_phase1a(CTX(h), group, round, chosenWatermark, targetMask ? (const uint64_t*)t : NULL,
+                                    (uint64_t*)b, (uint64_t*)b + 4);
+  put_longs(env, bits, 8, b);
   return st;
 }
 
-/* Leader.handlePhase1b safe values: multipaxos/Leader.scala:306-329, 543-566.  out[0] = maxSlot */
+/* Leader.handlePhase1b safe values: multipaxos/Leader.scala:306-329, 543-566.  maxSlot[0] */
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_leaderPhase1bScan(JNIEnv* env, jclass cls, jlong h,
-                                                                      jint chosenWatermark, jlongArray quorumMasks,
-                                                                      jint cap, jintArray maxSlot,
-                                                                      jintArray safeRound, jintArray safeValue) {
-  jlong* q = PIN(env, quorumMasks);
-  jint *mx = PIN(env, maxSlot), *sr = PIN(env, safeRound), *sv = PIN(env, safeValue);
-  int32_t st = fpx_leader_phase1b_scan((fpx_ctx*)(intptr_t)h, chosenWatermark, (const uint64_t*)q, cap, mx, sr, sv);
-  UNPIN(env, safeValue, sv, 0); UNPIN(env, safeRound, sr, 0); UNPIN(env, maxSlot, mx, 0);
-  UNPIN(env, quorumMasks, q, JNI_ABORT);
+                                                                      jint chosenWatermark, jint numGroups,
+                                                                      jlongArray quorumMasks, jint cap,
+                                                                      jintArray maxSlot, jintArray safeRound,
+                                                                      jintArray safeValue) {
+  if (cap < 0 || numGroups < 1 || !has(env, quorumMasks, 4 * (jlong)numGroups) || !opt(env, maxSlot, 1) ||
+      !opt(env, safeRound, cap) || !opt(env, safeValue, cap))
+    return FPX_EINVAL;
+  jlong* q = in_longs(env, quorumMasks, 4 * (jlong)numGroups);
+  jint mx = -1;
+  jint *sr = out_buf(safeRound, cap, 4), *sv = out_buf(safeValue, cap, 4);
+  int32_t st = fpx_leader_phase1b_scan(CTX(h), chosenWatermark, (const uint64_t*)q, cap, &mx, sr, sv);
+  put_ints(env, maxSlot, 1, &mx); put_ints(env, safeRound, cap, sr); put_ints(env, safeValue, cap, sv);
+  free(q); free(sr); free(sv);
   return st;
 }
 
@@ -160,11 +255,13 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_leaderPhase1bScan(JNIEnv* en
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_replicaChosen(JNIEnv* env, jclass cls, jlong h, jint n,
                                                                   jintArray slot, jintArray value, jbyteArray mask,
                                                                   jintArray state) {
-  jint *s = PIN(env, slot), *v = PIN(env, value), *o = PIN(env, state);
-  jbyte* m = PIN(env, mask);
-  int32_t st = fpx_replica_chosen((fpx_ctx*)(intptr_t)h, n, s, v, (const uint8_t*)m, o, o ? o + 1 : NULL);
-  UNPIN(env, mask, m, JNI_ABORT); UNPIN(env, state, o, 0); UNPIN(env, value, v, JNI_ABORT);
-  UNPIN(env, slot, s, JNI_ABORT);
+  if (n < 0 || (n > 0 && (!has(env, slot, n) || !has(env, value, n))) || !opt(env, mask, n) || !opt(env, state, 2))
+    return FPX_EINVAL;
+  jint *s = in_ints(env, slot, n), *v = in_ints(env, value, n), o[2] = {0, 0};
+  jbyte* m = in_bytes(env, mask, n);
+  int32_t st = fpx_replica_chosen(CTX(h), n, s, v, (const uint8_t*)m, &o[0], &o[1]);
+  put_ints(env, state, 2, o);
+  free(s); free(v); free(m);
   return st;
 }
 
@@ -172,46 +269,80 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_replicaChosen(JNIEnv* env, j
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_replicaChosenNoopRange(JNIEnv* env, jclass cls, jlong h,
                                                                            jint slotStart, jint slotEnd,
                                                                            jintArray state) {
-  jint* o = PIN(env, state);
-  int32_t st = fpx_replica_chosen_noop_range((fpx_ctx*)(intptr_t)h, slotStart, slotEnd, o, o ? o + 1 : NULL);
-  UNPIN(env, state, o, 0);
+  if (!opt(env, state, 2)) return FPX_EINVAL;
+  jint o[2] = {0, 0};
+  int32_t st = fpx_replica_chosen_noop_range(CTX(h), slotStart, slotEnd, &o[0], &o[1]);
+  put_ints(env, state, 2, o);
   return st;
 }
 
-/* mencius noop ranges: mencius/Acceptor.scala:237-291, mencius/ProxyLeader.scala:255-303, 355-411.
- * bits: vote[numGroups x 4] then nack[numGroups x 4]; nackRound[0] */
+/* Mencius noop ranges, n per call (mencius/Acceptor.scala:237-291, mencius/ProxyLeader.scala:255-303, 355-411): the
+ * fused step = open + acceptors + tally.  Bitmaps are n x numGroups x 4 longs. */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_noopRangesFused(
+    JNIEnv* env, jclass cls, jlong h, jint n, jint numGroups, jintArray slotStart, jintArray slotEnd, jintArray round,
+    jlongArray targetMasks, jlongArray voteBits, jlongArray nackBits, jintArray nackRound, jbyteArray isNew,
+    jbyteArray chosen) {
+  if (n < 0 || numGroups < 1) return FPX_EINVAL;
+  if (n == 0) return FPX_OK;
+  const jlong w = 4 * (jlong)n * numGroups;
+  if (!has(env, slotStart, n) || !has(env, slotEnd, n) || !has(env, round, n) || !opt(env, targetMasks, w) ||
+      !opt(env, voteBits, w) || !opt(env, nackBits, w) || !opt(env, nackRound, n) || !opt(env, isNew, n) ||
+      !opt(env, chosen, n))
+    return FPX_EINVAL;
+  jint *s = in_ints(env, slotStart, n), *e = in_ints(env, slotEnd, n), *r = in_ints(env, round, n);
+  jlong* t = in_longs(env, targetMasks, w);
+  jlong *vb = out_buf(voteBits, w, 8), *nb = out_buf(nackBits, w, 8);
+  jint* nr = out_buf(nackRound, n, 4);
+  jbyte *nw = out_buf(isNew, n, 1), *ch = out_buf(chosen, n, 1);
+  int32_t st = fpx_noop_ranges_fused(CTX(h), n, s, e, r, (const uint64_t*)t, (uint64_t*)vb, (uint64_t*)nb, nr,
+                                     (uint8_t*)nw, (uint8_t*)ch);
+  put_longs(env, voteBits, w, vb); put_longs(env, nackBits, w, nb); put_ints(env, nackRound, n, nr);
+  put_bytes(env, isNew, n, nw); put_bytes(env, chosen, n, ch);
+  free(s); free(e); free(r); free(t); free(vb); free(nb); free(nr); free(nw); free(ch);
+  return st;
+}
+
+/* the unfused pieces for one range: bits = vote[numGroups x 4] then nack[numGroups x 4]; nackRound[0] */
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_acceptorPhase2aNoopRange(
     JNIEnv* env, jclass cls, jlong h, jint slotStart, jint slotEnd, jint round, jint numGroups, jlongArray targetMasks,
     jlongArray bits, jintArray nackRound) {
-  jlong *t = PIN(env, targetMasks), *b = PIN(env, bits);
-  jint* nr = PIN(env, nackRound);
-  int32_t st = fpx_acceptor_phase2a_noop_range((fpx_ctx*)(intptr_t)h, slotStart, slotEnd, round, (const uint64_t*)t,
-                                               (uint64_t*)b, b ? (uint64_t*)b + (size_t)numGroups * 4 : NULL, nr);
-  UNPIN(env, nackRound, nr, 0); UNPIN(env, bits, b, 0); UNPIN(env, targetMasks, t, JNI_ABORT);
+  if (numGroups < 1) return FPX_EINVAL;
+  const jlong w = 4 * (jlong)numGroups;
+  if (!opt(env, targetMasks, w) || !opt(env, bits, 2 * w) || !opt(env, nackRound, 1)) return FPX_EINVAL;
+  jlong* t = in_longs(env, targetMasks, w);
+  jlong* b = out_buf(bits, 2 * w, 8);
+  jint nr = -1;
+  int32_t st = fpx_acceptor_phase2a_noop_range(CTX(h), slotStart, slotEnd, round, (const uint64_t*)t, (uint64_t*)b,
+                                               b ? (uint64_t*)b + w : NULL, &nr);
+  put_longs(env, bits, 2 * w, b); put_ints(env, nackRound, 1, &nr);
+  free(t); free(b);
   return st;
 }
 
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_proxyOpenNoopRange(JNIEnv* env, jclass cls, jlong h,
                                                                        jint slotStart, jint slotEnd, jint round,
                                                                        jbyteArray isNew) {
-  jbyte* f = PIN(env, isNew);
-  int32_t st = fpx_proxy_open_noop_range((fpx_ctx*)(intptr_t)h, slotStart, slotEnd, round, (uint8_t*)f);
-  UNPIN(env, isNew, f, 0);
+  if (!opt(env, isNew, 1)) return FPX_EINVAL;
+  jbyte f = 0;
+  int32_t st = fpx_proxy_open_noop_range(CTX(h), slotStart, slotEnd, round, (uint8_t*)&f);
+  put_bytes(env, isNew, 1, &f);
   return st;
 }
 
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_proxyPhase2bNoopRange(JNIEnv* env, jclass cls, jlong h,
                                                                           jint slotStart, jint slotEnd, jint round,
-                                                                          jlongArray voteBits, jbyteArray newlyChosen) {
-  jlong* vb = PIN(env, voteBits);
-  jbyte* c = PIN(env, newlyChosen);
-  int32_t st = fpx_proxy_phase2b_noop_range((fpx_ctx*)(intptr_t)h, slotStart, slotEnd, round, (const uint64_t*)vb,
-                                            (uint8_t*)c);
-  UNPIN(env, newlyChosen, c, 0); UNPIN(env, voteBits, vb, JNI_ABORT);
+                                                                          jint numGroups, jlongArray voteBits,
+                                                                          jbyteArray newlyChosen) {
+  if (numGroups < 1 || !has(env, voteBits, 4 * (jlong)numGroups) || !opt(env, newlyChosen, 1)) return FPX_EINVAL;
+  jlong* vb = in_longs(env, voteBits, 4 * (jlong)numGroups);
+  jbyte c = 0;
+  int32_t st = fpx_proxy_phase2b_noop_range(CTX(h), slotStart, slotEnd, round, (const uint64_t*)vb, (uint8_t*)&c);
+  put_bytes(env, newlyChosen, 1, &c);
+  free(vb);
   return st;
 }
 
-/* EPaxos pre-accept fast path: epaxos/Replica.scala:569-600, 633-729, 1159-1419 */
+/* ---- EPaxos pre-accept fast path: epaxos/Replica.scala:569-600, 633-729, 1159-1419 ------------------------- */
 JNIEXPORT jlong JNICALL Java_frankenpaxos_gpu_Native_epxCreate(JNIEnv* env, jclass cls, jint numReplicas,
                                                                jint numKeys, jint device) {
   fpx_epx_config cfg = {numReplicas, numKeys, device, 0};
@@ -224,18 +355,75 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxDestroy(JNIEnv* env, jcla
   return fpx_epx_destroy((fpx_epx*)(intptr_t)h);
 }
 
+/* numReplicas = n of the context (the shim cannot ask the handle): sizes rank (n x m) and the deps (m x n) */
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxPreaccept(
-    JNIEnv* env, jclass cls, jlong h, jint m, jintArray leader, jintArray number, jintArray key, jbyteArray isSet,
-    jbyteArray respMask, jbyteArray seenMask, jintArray rank, jbyteArray fast, jintArray deps, jintArray leaderDeps,
-    jintArray ownValuesEnd) {
-  jint *l = PIN(env, leader), *nu = PIN(env, number), *k = PIN(env, key), *rk = PIN(env, rank);
-  jint *d = PIN(env, deps), *ld = PIN(env, leaderDeps), *ov = PIN(env, ownValuesEnd);
-  jbyte *is = PIN(env, isSet), *rm = PIN(env, respMask), *sm = PIN(env, seenMask), *f = PIN(env, fast);
+    JNIEnv* env, jclass cls, jlong h, jint m, jint numReplicas, jintArray leader, jintArray number, jintArray key,
+    jbyteArray isSet, jbyteArray respMask, jbyteArray seenMask, jintArray rank, jbyteArray fast, jintArray deps,
+    jintArray leaderDeps, jintArray ownValuesEnd) {
+  if (m < 0 || numReplicas < 3) return FPX_EINVAL;
+  if (m == 0) return FPX_OK;
+  const jlong mn = (jlong)m * numReplicas;
+  if (!has(env, leader, m) || !has(env, number, m) || !has(env, key, m) || !has(env, isSet, m) ||
+      !has(env, respMask, m) || !opt(env, seenMask, m) || !has(env, rank, mn) || !opt(env, fast, m) ||
+      !opt(env, deps, mn) || !opt(env, leaderDeps, mn) || !opt(env, ownValuesEnd, 2 * (jlong)m))
+    return FPX_EINVAL;
+  jint *l = in_ints(env, leader, m), *nu = in_ints(env, number, m), *k = in_ints(env, key, m), *rk = in_ints(env, rank, mn);
+  jbyte *is = in_bytes(env, isSet, m), *rm = in_bytes(env, respMask, m), *sm = in_bytes(env, seenMask, m);
+  jbyte* f = out_buf(fast, m, 1);
+  jint *d = out_buf(deps, mn, 4), *ld = out_buf(leaderDeps, mn, 4), *ov = out_buf(ownValuesEnd, 2 * (jlong)m, 4);
   int32_t st = fpx_epx_preaccept((fpx_epx*)(intptr_t)h, m, l, nu, k, (const uint8_t*)is, (const uint8_t*)rm,
-                                 (const uint8_t*)sm, rk,
-                                 (uint8_t*)f, d, ld, ov);
-  UNPIN(env, fast, f, 0); UNPIN(env, seenMask, sm, JNI_ABORT); UNPIN(env, respMask, rm, JNI_ABORT); UNPIN(env, isSet, is, JNI_ABORT);
-  UNPIN(env, ownValuesEnd, ov, 0); UNPIN(env, leaderDeps, ld, 0); UNPIN(env, deps, d, 0); UNPIN(env, rank, rk, JNI_ABORT);
-  UNPIN(env, key, k, JNI_ABORT); UNPIN(env, number, nu, JNI_ABORT); UNPIN(env, leader, l, JNI_ABORT);
+                                 (const uint8_t*)sm, rk, (uint8_t*)f, d, ld, ov);
+  put_bytes(env, fast, m, f); put_ints(env, deps, mn, d); put_ints(env, leaderDeps, mn, ld);
+  put_ints(env, ownValuesEnd, 2 * (jlong)m, ov);
+  free(l); free(nu); free(k); free(rk); free(is); free(rm); free(sm); free(f); free(d); free(ld); free(ov);
+  return st;
+}
+
+/* ---- multi-GPU: the RCCL communicator behind the C ABI (fpx_comm_*) ---------------------------------------- */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_commUniqueId(JNIEnv* env, jclass cls, jbyteArray id) {
+  if (!has(env, id, FPX_COMM_ID_BYTES)) return FPX_EINVAL;
+  uint8_t b[FPX_COMM_ID_BYTES];
+  int32_t st = fpx_comm_unique_id(b);
+  if (st == FPX_OK) put_bytes(env, id, FPX_COMM_ID_BYTES, (const jbyte*)b);
+  return st;
+}
+
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_commCreate(JNIEnv* env, jclass cls, jlong h, jbyteArray id,
+                                                               jint rank, jint world) {
+  if (!has(env, id, FPX_COMM_ID_BYTES)) return FPX_EINVAL;
+  uint8_t b[FPX_COMM_ID_BYTES];
+  (*env)->GetByteArrayRegion(env, id, 0, FPX_COMM_ID_BYTES, (jbyte*)b);
+  return fpx_comm_create(CTX(h), b, rank, world);
+}
+
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_commDestroy(JNIEnv* env, jclass cls, jlong h) {
+  return fpx_comm_destroy(CTX(h));
+}
+
+/* ---- wire adapter (include/fpx_wire.h): a tick of ProxyLeaderInbound byte arrays, packed into one direct buffer
+ * with n + 1 offsets, decoded straight into the SoA arrays of a batch.  fields = kind, slot, round, isNoop,
+ * valueLen, groupIndex, acceptorIndex (7 x n ints); valueOff n longs; returns the status, badIndex[0] on error */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_wireDecodeProxyLeaderInbound(
+    JNIEnv* env, jclass cls, jobject buf, jlongArray offsets, jint n, jintArray fields, jlongArray valueOff,
+    jintArray badIndex) {
+  if (n < 0 || !has(env, offsets, (jlong)n + 1) || !has(env, fields, 7 * (jlong)n) || !opt(env, valueOff, n) ||
+      !opt(env, badIndex, 1))
+    return FPX_EINVAL;
+  if (n == 0) return FPX_OK;
+  jlong* off = in_longs(env, offsets, (jlong)n + 1);
+  int bad = 0;
+  const uint8_t* b = direct(env, buf, off ? off[n] : 0, &bad);
+  if (bad || !b || !off) {
+    free(off);
+    return FPX_EINVAL;
+  }
+  jint* f = out_buf(fields, 7 * (jlong)n, 4);
+  jlong* vo = (jlong*)calloc((size_t)n, 8);
+  jint bi = -1;
+  int32_t st = fpx_wire_decode_proxy_leader_inbound(b, (const int64_t*)off, n, f, f + n, f + 2 * (size_t)n,
+                                                    f + 3 * (size_t)n, (int64_t*)vo, f + 4 * (size_t)n,
+                                                    f + 5 * (size_t)n, f + 6 * (size_t)n, &bi);
+  put_ints(env, fields, 7 * (jlong)n, f); put_longs(env, valueOff, n, vo); put_ints(env, badIndex, 1, &bi);
+  free(off); free(f); free(vo);
   return st;
 }
