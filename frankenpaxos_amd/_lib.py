@@ -20,6 +20,7 @@ FPX_ECAPACITY = 5
 FPX_EORDER = 6
 FPX_ENOMEM = 7
 FPX_ERCCL = 8
+FPX_EFATAL_PROTOCOL = 9
 FPX_COMM_ID_BYTES = 128
 
 FPX_Q_THRESHOLD = 0
@@ -111,8 +112,11 @@ SIGNATURES = {
     "fpx_epx_destroy": (C.c_int32, [VP]),
     "fpx_epx_set_stream": (C.c_int32, [VP, VP]),
     "fpx_epx_sync": (C.c_int32, [VP]),
-    "fpx_epx_preaccept": (C.c_int32, [VP, C.c_int32] + [VP] * 11),
-    "fpx_epx_preaccept_dev": (C.c_int32, [VP, C.c_int32] + [VP] * 11),
+    "fpx_epx_preaccept": (C.c_int32, [VP, C.c_int32] + [VP] * 12),
+    "fpx_epx_preaccept_dev": (C.c_int32, [VP, C.c_int32] + [VP] * 12),
+    "fpx_epx_prepare": (C.c_int32, [VP, C.c_int32] + [VP] * 12),
+    "fpx_epx_accept": (C.c_int32, [VP, C.c_int32] + [VP] * 11),
+    "fpx_epx_read_cmdlog": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, VP]),
     "fpx_epx_read_index": (C.c_int32, [VP, C.c_int32, C.c_int32, VP, VP]),
     "fpx_replica_chosen": (C.c_int32, [VP, C.c_int32, VP, VP, VP, I32P, I32P]),
     "fpx_replica_chosen_dev": (C.c_int32, [VP, C.c_int32, VP, VP, VP]),

@@ -565,6 +565,7 @@ const char* fpx_strerror(int32_t s) {
     case FPX_EORDER: return "device batch violates the run contract; nothing was applied";
     case FPX_ENOMEM: return "out of device memory";
     case FPX_ERCCL: return "RCCL error (or RCCL could not be loaded)";
+    case FPX_EFATAL_PROTOCOL: return "a logger.fatal / logger.check of the reference would have fired; the message was skipped";
     default: return "unknown status";
   }
 }

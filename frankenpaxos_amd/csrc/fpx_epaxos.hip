@@ -30,11 +30,23 @@
 
 namespace {
 
+// cmdLog entry kinds (epaxos/Replica.scala:303-330)
+enum { CL_NONE = 0, CL_NO_COMMAND = 1, CL_PRE_ACCEPTED = 2, CL_ACCEPTED = 3, CL_COMMITTED = 4 };
+
 struct EpxState {
   int n, num_keys;
   int32_t* gets;  // [n][num_keys][n]
   int32_t* sets;  // [n][num_keys][n]
   int32_t* status;
+  // the command log of every replica (Replica.scala:440 cmdLog) for the instances (leader, number < num_instances):
+  // entry kind, ballot, voteBallot (ballots encoded ordering * 8 + replicaIndex, nullBallot = -1), triple id
+  int num_instances;
+  uint8_t* cl_status;   // [n][n * num_instances]
+  int32_t* cl_ballot;
+  int32_t* cl_vote;
+  int32_t* cl_triple;
+  int32_t* largest;     // [n]  Replica.largestBallot, encoded
+  uint32_t* cl_stamp;   // [n * num_instances]  run id: instances of one batch must be distinct
 };
 
 struct EpxBatch {
@@ -46,6 +58,7 @@ struct EpxBatch {
   const uint8_t* resp_mask;
   const uint8_t* seen_mask;  // replicas that process the PreAccept (null = resp_mask)
   const int32_t* rank;   // [n][m]
+  const int32_t* triple; // [m] or null: the CommandTriple's id, recorded in the command log
   uint2* kv;             // [n][m] in the replica's delivery order: x = key | is_set << 27 | leader << 28
                          // (only the key bits are sorted on), y = message index
   uint2* kv_sorted;      // [n][m]
@@ -105,6 +118,14 @@ __global__ void __launch_bounds__(256) k_epx_keys(const EpxState st, const EpxBa
       const uint32_t flags = ((uint32_t)(b.is_set[i] ? 1 : 0) << EPX_SET_SHIFT) | ((uint32_t)L << EPX_LEADER_SHIFT);
       b.kv[(size_t)r * b.m + p] = make_uint2((part ? (uint32_t)k : (uint32_t)st.num_keys) | flags, (uint32_t)i);
     }
+  }
+  if (ok && st.num_instances > 0) {
+    // this tick-at-once form covers handlePreAccept's `cmdLog.get(instance) == None` branch only: an instance a
+    // participating replica already knows is rejected (nothing of the tick is applied)
+    ok = b.number[i] < st.num_instances;
+    const unsigned part = (b.seen_mask ? b.seen_mask[i] : mask) | (1u << L);
+    for (int r = 0; ok && r < n; ++r)
+      if (((part >> r) & 1u) && st.cl_status[((size_t)r * n + L) * st.num_instances + b.number[i]] != CL_NONE) ok = false;
   }
   if (!ok) {
     epx_report(st.status, FPX_EINVAL, i);
@@ -370,6 +391,21 @@ __global__ void __launch_bounds__(256) k_epx_decide(const EpxState st, const Epx
   // values x+1 .. w-1).  Unions (addAll) and the equality test of popularItems commute with that encoding for a
   // fresh instance (w == x + 1 would need the instance itself in the index), so everything above ran on the
   // plain watermarks w and only the own column is re-encoded here.
+  if (st.num_instances > 0) {
+    // the command log: a fast-path commit is a CommittedEntry at every replica (commit :815-823, Commit to the
+    // others); otherwise every replica that processed the PreAccept holds PreAcceptedEntry(Ballot(0, leader),
+    // Ballot(0, leader), triple) (:688-696, :1259-1271) for the Accept phase to find
+    const unsigned seen = (b.seen_mask ? b.seen_mask[i] : mask) | (1u << L);
+    const int tr = b.triple ? b.triple[i] : -1;
+    for (int r = 0; r < N; ++r) {
+      const size_t c = ((size_t)r * N + L) * st.num_instances + b.number[i];
+      if (all_equal) {
+        st.cl_status[c] = CL_COMMITTED, st.cl_ballot[c] = -1, st.cl_vote[c] = -1, st.cl_triple[c] = tr;
+      } else if ((seen >> r) & 1u) {
+        st.cl_status[c] = CL_PRE_ACCEPTED, st.cl_ballot[c] = L, st.cl_vote[c] = L, st.cl_triple[c] = tr;  // 0 * 8 + L
+      }
+    }
+  }
   const int x = b.number[i];
 #pragma unroll
   for (int l = 0; l < N; ++l) {
@@ -404,6 +440,188 @@ __global__ void __launch_bounds__(256) k_epx_commit(const EpxState st, const Epx
   if (ts > *s2) *s2 = ts;
 }
 
+// ---- the per-instance Paxos of EPaxos on the command log: Prepare (phase 1) and Accept (phase 2) ---------------
+// Messages are delivered in array order to the replicas of target[i]; the instances of a batch are pairwise
+// distinct, so every command-log cell has one writer and the only order-dependent quantity is each replica's
+// running largestBallot (Replica.scala:458), which only Nacks report: an inclusive prefix max per replica over the
+// ballots the replica took in (k_cl_tilemax / k_cl_tilescan / k_cl_nacks).
+struct ClBatch {
+  int m, accept;           // accept = 0: Prepare
+  const int32_t* leader;
+  const int32_t* number;
+  const int32_t* b_ord;
+  const int32_t* b_rep;
+  const int32_t* triple;   // Accept
+  const uint8_t* target;
+  uint8_t* ok_bits;
+  uint8_t* nack_bits;
+  uint8_t* commit_bits;
+  int32_t* nack_ballot;
+  uint8_t* committed;      // Accept
+  int32_t* reply_status;   // Prepare: [m][n]
+  int32_t* reply_vote;
+  int32_t* reply_triple;
+  int32_t* contrib;        // [n][m] scratch: the ballot replica r took in with message i, or -1
+  uint8_t* nackflag;       // [n][m] scratch
+  int32_t* tilemax;        // [n][tiles] scratch
+  uint8_t* skip;           // [m] scratch: Accept whose proposer refused it (logger.fatal / checkLe)
+  uint32_t run_id;
+};
+constexpr int CL_TILE = 1024;
+
+__global__ void __launch_bounds__(256) k_cl_validate(const EpxState st, const ClBatch b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.m) return;
+  const int n = st.n, L = b.leader[i], x = b.number[i], bo = b.b_ord[i], br = b.b_rep[i];
+  bool ok = L >= 0 && L < n && x >= 0 && x < st.num_instances && bo >= 0 && bo < (1 << 27) && br >= 0 && br < n &&
+            (b.target[i] >> n) == 0;
+  if (ok && b.accept) ok = !((b.target[i] >> br) & 1u);  // thriftyOtherReplicas: never the proposer itself (:774)
+  if (ok) ok = atomicExch(&st.cl_stamp[(size_t)L * st.num_instances + x], b.run_id) != b.run_id;
+  if (!ok) epx_report(st.status, FPX_EINVAL, i);
+}
+
+// Accept: transitionToAcceptPhase at the proposer (Replica.scala:732-792), one thread per message
+__global__ void __launch_bounds__(256) k_cl_propose(const EpxState st, const ClBatch b) {
+  if (st.status[0] == FPX_EINVAL) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.m) return;
+  const int n = st.n, P = b.b_rep[i], ballot = b.b_ord[i] * 8 + P;
+  const size_t c = ((size_t)P * n + b.leader[i]) * st.num_instances + b.number[i];
+  const int kind = st.cl_status[c];
+  // :740-744 a CommittedEntry is logger.fatal; :749-757 logger.checkLe(entry.ballot / voteBallot, ballot)
+  const bool refuse = kind == CL_COMMITTED || (kind != CL_NONE && st.cl_ballot[c] > ballot) ||
+                      (kind >= CL_PRE_ACCEPTED && st.cl_vote[c] > ballot);
+  b.skip[i] = refuse ? 1 : 0;
+  if (refuse) {
+    if (atomicCAS(&st.status[0], 0, FPX_EFATAL_PROTOCOL) == 0) st.status[1] = i;
+    return;
+  }
+  st.cl_status[c] = CL_ACCEPTED, st.cl_ballot[c] = ballot, st.cl_vote[c] = ballot, st.cl_triple[c] = b.triple[i];  // :759-762
+}
+
+// handlePrepare (:1632-1757) / handleAccept (:1421-1511) at replica r for message i: one thread per (i, r)
+__global__ void __launch_bounds__(256) k_cl_handle(const EpxState st, const ClBatch b) {
+  if (st.status[0] == FPX_EINVAL) return;
+  const int n = st.n;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)b.m * n) return;
+  const int r = (int)(t / b.m), i = (int)(t % b.m);  // replica-major: the scratch rows are contiguous per replica
+  const int ballot = b.b_ord[i] * 8 + b.b_rep[i];
+  int contrib = -1, rs = -1, rv = -1, rt = -1;
+  uint8_t nack = 0;
+  const bool live = ((b.target[i] >> r) & 1u) && !(b.accept && b.skip[i]);
+  if (live) {
+    const size_t c = ((size_t)r * n + b.leader[i]) * st.num_instances + b.number[i];
+    const int kind = st.cl_status[c];
+    if (!b.accept) contrib = ballot;  // :1637 largestBallot = max(.., prepare.ballot) before anything else
+    if (kind == CL_COMMITTED) {
+      atomicOr(reinterpret_cast<unsigned int*>(b.commit_bits) + (i >> 2), (1u << r) << (8 * (i & 3)));
+    } else if (kind != CL_NONE && ballot < st.cl_ballot[c]) {
+      nack = 1;  // Nack(instance, largestBallot): the value comes from the scan
+      atomicOr(reinterpret_cast<unsigned int*>(b.nack_bits) + (i >> 2), (1u << r) << (8 * (i & 3)));
+    } else {
+      atomicOr(reinterpret_cast<unsigned int*>(b.ok_bits) + (i >> 2), (1u << r) << (8 * (i & 3)));
+      if (!b.accept) {
+        if (kind == CL_NONE || kind == CL_NO_COMMAND) {  // :1654-1669, :1686-1701
+          rs = 0;
+          st.cl_status[c] = CL_NO_COMMAND, st.cl_vote[c] = -1, st.cl_triple[c] = -1;
+        } else {  // :1711-1743 the entry keeps its vote, only `ballot` moves
+          rs = kind, rv = st.cl_vote[c], rt = st.cl_triple[c];
+        }
+        st.cl_ballot[c] = ballot;
+      } else if (!(kind == CL_ACCEPTED && ballot == st.cl_vote[c])) {  // (:1451-1461: already answered, re-send only)
+        contrib = ballot;  // :1487
+        st.cl_status[c] = CL_ACCEPTED, st.cl_ballot[c] = ballot, st.cl_vote[c] = ballot, st.cl_triple[c] = b.triple[i];
+      }
+    }
+  }
+  b.contrib[(size_t)r * b.m + i] = contrib;
+  b.nackflag[(size_t)r * b.m + i] = nack;
+  if (!b.accept) {
+    if (b.reply_status) b.reply_status[(size_t)i * n + r] = rs;
+    if (b.reply_vote) b.reply_vote[(size_t)i * n + r] = rv;
+    if (b.reply_triple) b.reply_triple[(size_t)i * n + r] = rt;
+  }
+}
+
+__device__ __forceinline__ int block_max_256(int v, int* sh) {
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) v = imax(v, __shfl_xor(v, k));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const int out = imax(imax(sh[0], sh[1]), imax(sh[2], sh[3]));
+  __syncthreads();
+  return out;
+}
+
+__global__ void __launch_bounds__(256) k_cl_tilemax(const ClBatch b, int tiles) {
+  __shared__ int sh[4];
+  const int r = blockIdx.y, t = blockIdx.x;
+  int v = -1;
+  for (int k = threadIdx.x; k < CL_TILE; k += 256) {
+    const int i = t * CL_TILE + k;
+    if (i < b.m) v = imax(v, b.contrib[(size_t)r * b.m + i]);
+  }
+  v = block_max_256(v, sh);
+  if (threadIdx.x == 0) b.tilemax[(size_t)r * tiles + t] = v;
+}
+
+// one block per replica: tilemax -> what the replica had seen BEFORE each tile; the replica's new largestBallot
+__global__ void __launch_bounds__(256) k_cl_tilescan(const EpxState st, const ClBatch b, int tiles) {
+  if (st.status[0] == FPX_EINVAL) return;
+  const int r = blockIdx.x;
+  if (threadIdx.x != 0) return;  // tiles <= a few thousand: a serial walk of one thread is microseconds
+  int run = st.largest[r];
+  for (int t = 0; t < tiles; ++t) {
+    const int v = b.tilemax[(size_t)r * tiles + t];
+    b.tilemax[(size_t)r * tiles + t] = run;
+    run = imax(run, v);
+  }
+  st.largest[r] = run;
+}
+
+// the largestBallot a Nack of (i, r) carries = max(before the tile, inclusive prefix inside the tile)
+__global__ void __launch_bounds__(256) k_cl_nacks(const ClBatch b, int tiles) {
+  __shared__ int wmax[4];
+  const int r = blockIdx.y, t = blockIdx.x;
+  int carry = b.tilemax[(size_t)r * tiles + t];
+  for (int k0 = 0; k0 < CL_TILE; k0 += 256) {
+    const int i = t * CL_TILE + k0 + threadIdx.x;
+    const int v = i < b.m ? b.contrib[(size_t)r * b.m + i] : -1;
+    int inc = wave_incl_max(v + 1) - 1;  // the DPP scan's identity is 0: shift ballots (>= -1) up by one
+    if ((threadIdx.x & 63) == 63) wmax[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int before = carry;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before = imax(before, wmax[w]);
+    const int total = imax(imax(wmax[0], wmax[1]), imax(wmax[2], wmax[3]));
+    inc = imax(inc, before);
+    if (i < b.m && b.nackflag[(size_t)r * b.m + i] && b.nack_ballot) atomicMax(&b.nack_ballot[i], inc);
+    carry = imax(carry, total);
+    __syncthreads();
+  }
+}
+
+// handleAcceptOk (:1513-1565): f + 1 responses, the proposer's own included -> commit (:815-860) at every replica
+__global__ void __launch_bounds__(256) k_cl_commit(const EpxState st, const ClBatch b) {
+  if (st.status[0] == FPX_EINVAL) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.m) return;
+  const int n = st.n, f = (n - 1) / 2;
+  uint8_t done = 0;
+  if (!b.skip[i]) {
+    const unsigned ok = b.ok_bits[i] | (1u << b.b_rep[i]);  // :780-789 the proposer's own AcceptOk
+    b.ok_bits[i] = (uint8_t)ok;
+    if (__popc(ok) >= f + 1) {
+      done = 1;
+      for (int r = 0; r < n; ++r) {
+        const size_t c = ((size_t)r * n + b.leader[i]) * st.num_instances + b.number[i];
+        st.cl_status[c] = CL_COMMITTED, st.cl_ballot[c] = -1, st.cl_vote[c] = -1, st.cl_triple[c] = b.triple[i];
+      }
+    }
+  }
+  if (b.committed) b.committed[i] = done;
+}
+
 struct Buf {
   void* p = nullptr;
   size_t cap = 0;
@@ -416,7 +634,8 @@ struct fpx_epx {
   EpxState st;
   hipStream_t stream = nullptr, own_stream = nullptr;
   int last_hip = 0;
-  Buf kv, kv2, seg, conf, tmp, tick, h_leader, h_number, h_key, h_set, h_mask, h_seen, h_rank, o_fast, o_deps, o_ldeps, o_own;
+  Buf kv, kv2, seg, conf, tmp, tick, h_leader, h_number, h_key, h_set, h_mask, h_seen, h_rank, h_triple, o_fast, o_deps, o_ldeps, o_own, cl;
+  uint32_t cl_run = 0;
 };
 
 namespace {
@@ -467,7 +686,9 @@ int32_t fpx_epx_create(const fpx_epx_config* cfg, fpx_epx** out) {
   if (!cfg || !out) return FPX_EINVAL;
   *out = nullptr;
   const int n = cfg->num_replicas;
-  if (!(n == 3 || n == 5 || n == 7) || cfg->num_keys < 1 || cfg->num_keys > (1 << 24)) return FPX_EINVAL;
+  if (!(n == 3 || n == 5 || n == 7) || cfg->num_keys < 1 || cfg->num_keys > (1 << 24) || cfg->num_instances < 0 ||
+      (int64_t)cfg->num_instances * n > (int64_t)1 << 30)
+    return FPX_EINVAL;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
     return FPX_ENODEVICE;
@@ -477,6 +698,8 @@ int32_t fpx_epx_create(const fpx_epx_config* cfg, fpx_epx** out) {
   e->st.n = n;
   e->st.num_keys = cfg->num_keys;
   e->st.gets = e->st.sets = e->st.status = nullptr;
+  e->st.num_instances = cfg->num_instances;
+  e->st.cl_status = nullptr, e->st.cl_ballot = e->st.cl_vote = e->st.cl_triple = e->st.largest = nullptr, e->st.cl_stamp = nullptr;
   auto fail = [&](int code) {
     fpx_epx_destroy(e);
     return code;
@@ -493,6 +716,25 @@ int32_t fpx_epx_create(const fpx_epx_config* cfg, fpx_epx** out) {
   if (hipMemsetAsync(e->st.gets, 0, cells * 4, e->stream) != hipSuccess) return fail(FPX_EHIP);
   if (hipMemsetAsync(e->st.sets, 0, cells * 4, e->stream) != hipSuccess) return fail(FPX_EHIP);
   if (hipMemsetAsync(e->st.status, 0, 32, e->stream) != hipSuccess) return fail(FPX_EHIP);
+  {
+    // Replica.scala:458  largestBallot = Ballot(0, index)  (encoded 0 * 8 + index)
+    int32_t init[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+    if (hipMalloc((void**)&e->st.largest, 32) != hipSuccess) return fail(FPX_ENOMEM);
+    if (hipMemcpy(e->st.largest, init, 32, hipMemcpyHostToDevice) != hipSuccess) return fail(FPX_EHIP);
+  }
+  if (cfg->num_instances > 0) {
+    const size_t ce = (size_t)n * n * cfg->num_instances;
+    if (hipMalloc((void**)&e->st.cl_status, ce) != hipSuccess) return fail(FPX_ENOMEM);
+    if (hipMalloc((void**)&e->st.cl_ballot, ce * 4) != hipSuccess) return fail(FPX_ENOMEM);
+    if (hipMalloc((void**)&e->st.cl_vote, ce * 4) != hipSuccess) return fail(FPX_ENOMEM);
+    if (hipMalloc((void**)&e->st.cl_triple, ce * 4) != hipSuccess) return fail(FPX_ENOMEM);
+    if (hipMalloc((void**)&e->st.cl_stamp, (size_t)n * cfg->num_instances * 4) != hipSuccess) return fail(FPX_ENOMEM);
+    if (hipMemsetAsync(e->st.cl_status, 0, ce, e->stream) != hipSuccess) return fail(FPX_EHIP);
+    if (hipMemsetAsync(e->st.cl_ballot, 0xFF, ce * 4, e->stream) != hipSuccess) return fail(FPX_EHIP);
+    if (hipMemsetAsync(e->st.cl_vote, 0xFF, ce * 4, e->stream) != hipSuccess) return fail(FPX_EHIP);
+    if (hipMemsetAsync(e->st.cl_triple, 0xFF, ce * 4, e->stream) != hipSuccess) return fail(FPX_EHIP);
+    if (hipMemsetAsync(e->st.cl_stamp, 0, (size_t)n * cfg->num_instances * 4, e->stream) != hipSuccess) return fail(FPX_EHIP);
+  }
   if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(FPX_EHIP);
   *out = e;
   return FPX_OK;
@@ -502,11 +744,13 @@ int32_t fpx_epx_destroy(fpx_epx* e) {
   if (!e) return FPX_EINVAL;
   EpxDeviceGuard _dg(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  void* ps[] = {e->st.gets, e->st.sets, e->st.status};
+  void* ps[] = {e->st.gets, e->st.sets, e->st.status, e->st.cl_status, e->st.cl_ballot, e->st.cl_vote, e->st.cl_triple,
+                e->st.largest, e->st.cl_stamp};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   Buf* bs[] = {&e->kv, &e->kv2, &e->seg, &e->conf, &e->tmp, &e->tick, &e->h_leader, &e->h_number,
-               &e->h_key, &e->h_set, &e->h_mask, &e->h_seen, &e->h_rank, &e->o_fast, &e->o_deps, &e->o_ldeps, &e->o_own};
+               &e->h_key, &e->h_set, &e->h_mask, &e->h_seen, &e->h_rank, &e->h_triple, &e->o_fast, &e->o_deps, &e->o_ldeps,
+               &e->o_own, &e->cl};
   for (Buf* b : bs)
     if (b->p) (void)hipFree(b->p);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -537,8 +781,8 @@ int32_t fpx_epx_sync(fpx_epx* e) {
 
 int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, const int32_t* d_number,
                               const int32_t* d_key, const uint8_t* d_is_set, const uint8_t* d_resp_mask,
-                              const uint8_t* d_seen_mask, const int32_t* d_rank, uint8_t* d_fast, int32_t* d_deps,
-                              int32_t* d_leader_deps, int32_t* d_own_values_end) {
+                              const uint8_t* d_seen_mask, const int32_t* d_rank, const int32_t* d_triple_id,
+                              uint8_t* d_fast, int32_t* d_deps, int32_t* d_leader_deps, int32_t* d_own_values_end) {
   if (!e || m < 0) return FPX_EINVAL;
   EpxDeviceGuard _dg(e->cfg.device);
   if (m == 0) return FPX_OK;
@@ -554,6 +798,7 @@ int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, co
   b.m = m, b.leader = d_leader, b.number = d_number, b.key = d_key, b.is_set = d_is_set, b.resp_mask = d_resp_mask;
   b.seen_mask = d_seen_mask;
   b.rank = d_rank;
+  b.triple = d_triple_id;
   b.kv = (uint2*)e->kv.p, b.kv_sorted = (uint2*)e->kv2.p;
   b.tick = (int32_t*)e->tick.p;
   b.seg = (int32_t*)e->seg.p, b.conf = (int32_t*)e->conf.p;
@@ -598,8 +843,8 @@ int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, co
 
 int32_t fpx_epx_preaccept(fpx_epx* e, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* key,
                           const uint8_t* is_set, const uint8_t* resp_mask, const uint8_t* seen_mask,
-                          const int32_t* rank, uint8_t* fast, int32_t* deps, int32_t* leader_deps,
-                          int32_t* own_values_end) {
+                          const int32_t* rank, const int32_t* triple_id, uint8_t* fast, int32_t* deps,
+                          int32_t* leader_deps, int32_t* own_values_end) {
   if (!e || m < 0 || (m > 0 && (!leader || !number || !key || !is_set || !resp_mask || !rank))) return FPX_EINVAL;
   EpxDeviceGuard _dg(e->cfg.device);
   if (m == 0) return FPX_OK;
@@ -618,13 +863,14 @@ int32_t fpx_epx_preaccept(fpx_epx* e, int32_t m, const int32_t* leader, const in
   if ((rc = up(&e->h_mask, resp_mask, (size_t)m))) return rc;
   if (seen_mask && (rc = up(&e->h_seen, seen_mask, (size_t)m))) return rc;
   if ((rc = up(&e->h_rank, rank, (size_t)n * m * 4))) return rc;
+  if (triple_id && (rc = up(&e->h_triple, triple_id, (size_t)m * 4))) return rc;
   if ((rc = grow(e, &e->o_fast, (size_t)m))) return rc;
   if ((rc = grow(e, &e->o_deps, (size_t)m * n * 4))) return rc;
   if ((rc = grow(e, &e->o_ldeps, (size_t)m * n * 4))) return rc;
   if ((rc = grow(e, &e->o_own, (size_t)m * 8))) return rc;
   rc = fpx_epx_preaccept_dev(e, m, (int32_t*)e->h_leader.p, (int32_t*)e->h_number.p, (int32_t*)e->h_key.p,
                              (uint8_t*)e->h_set.p, (uint8_t*)e->h_mask.p, seen_mask ? (uint8_t*)e->h_seen.p : nullptr,
-                             (int32_t*)e->h_rank.p, (uint8_t*)e->o_fast.p,
+                             (int32_t*)e->h_rank.p, triple_id ? (int32_t*)e->h_triple.p : nullptr, (uint8_t*)e->o_fast.p,
                              (int32_t*)e->o_deps.p, (int32_t*)e->o_ldeps.p, (int32_t*)e->o_own.p);
   if (rc) return rc;
   if (fast) EHIP(e, hipMemcpyAsync(fast, e->o_fast.p, (size_t)m, hipMemcpyDeviceToHost, e->stream));
@@ -632,6 +878,111 @@ int32_t fpx_epx_preaccept(fpx_epx* e, int32_t m, const int32_t* leader, const in
   if (leader_deps) EHIP(e, hipMemcpyAsync(leader_deps, e->o_ldeps.p, (size_t)m * n * 4, hipMemcpyDeviceToHost, e->stream));
   if (own_values_end) EHIP(e, hipMemcpyAsync(own_values_end, e->o_own.p, (size_t)m * 8, hipMemcpyDeviceToHost, e->stream));
   return fpx_epx_sync(e);
+}
+
+// Prepare / Accept on the command log: stage, validate, handle, scan the largestBallot's, (Accept) tally + commit
+static int32_t cl_run(fpx_epx* e, int accept, int32_t m, const int32_t* leader, const int32_t* number,
+                      const int32_t* b_ord, const int32_t* b_rep, const int32_t* triple, const uint8_t* target,
+                      uint8_t* ok_bits, uint8_t* nack_bits, uint8_t* commit_bits, int32_t* nack_ballot,
+                      uint8_t* committed, int32_t* reply_status, int32_t* reply_vote, int32_t* reply_triple) {
+  if (!e || m < 0) return FPX_EINVAL;
+  EpxDeviceGuard _dg(e->cfg.device);
+  if (e->st.num_instances <= 0) return FPX_EINVAL;
+  if (m == 0) return FPX_OK;
+  if (!leader || !number || !b_ord || !b_rep || !target || (accept && !triple)) return FPX_EINVAL;
+  const int n = e->st.n;
+  const int tiles = (m + CL_TILE - 1) / CL_TILE;
+  const size_t mp = ((size_t)m + 63) & ~(size_t)63;
+  // staging: 5 int32 inputs, target, 3 reply bit arrays, skip, committed, nack_ballot, 3 reply int arrays [m][n],
+  // contrib [n][m], nackflag [n][m], tilemax [n][tiles]
+  const size_t bytes = mp * 4 * 5 + mp * 6 + mp * 4 + (size_t)m * n * 4 * 3 + (size_t)n * mp * 4 + (size_t)n * mp +
+                       (size_t)n * tiles * 4 + 1024;
+  int rc;
+  if ((rc = grow(e, &e->cl, bytes))) return rc;
+  char* p = (char*)e->cl.p;
+  auto take = [&](size_t sz) { char* q = p; p += (sz + 63) & ~(size_t)63; return q; };
+  int32_t* d_leader = (int32_t*)take(mp * 4); int32_t* d_number = (int32_t*)take(mp * 4);
+  int32_t* d_bo = (int32_t*)take(mp * 4); int32_t* d_br = (int32_t*)take(mp * 4); int32_t* d_tr = (int32_t*)take(mp * 4);
+  uint8_t* d_tgt = (uint8_t*)take(mp); uint8_t* d_ok = (uint8_t*)take(mp); uint8_t* d_nack = (uint8_t*)take(mp);
+  uint8_t* d_com = (uint8_t*)take(mp); uint8_t* d_skip = (uint8_t*)take(mp); uint8_t* d_done = (uint8_t*)take(mp);
+  int32_t* d_nb = (int32_t*)take(mp * 4);
+  int32_t* d_rs = (int32_t*)take((size_t)m * n * 4); int32_t* d_rv = (int32_t*)take((size_t)m * n * 4);
+  int32_t* d_rt = (int32_t*)take((size_t)m * n * 4);
+  int32_t* d_contrib = (int32_t*)take((size_t)n * m * 4); uint8_t* d_flag = (uint8_t*)take((size_t)n * m);
+  int32_t* d_tm = (int32_t*)take((size_t)n * tiles * 4);
+  EHIP(e, hipMemcpyAsync(d_leader, leader, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+  EHIP(e, hipMemcpyAsync(d_number, number, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+  EHIP(e, hipMemcpyAsync(d_bo, b_ord, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+  EHIP(e, hipMemcpyAsync(d_br, b_rep, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+  if (accept) EHIP(e, hipMemcpyAsync(d_tr, triple, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+  EHIP(e, hipMemcpyAsync(d_tgt, target, (size_t)m, hipMemcpyHostToDevice, e->stream));
+  EHIP(e, hipMemsetAsync(d_ok, 0, mp * 5, e->stream));  // ok, nack, commit, skip, committed are contiguous
+  EHIP(e, hipMemsetAsync(d_nb, 0xFF, mp * 4, e->stream));
+  ClBatch b;
+  memset(&b, 0, sizeof(b));
+  b.m = m, b.accept = accept, b.leader = d_leader, b.number = d_number, b.b_ord = d_bo, b.b_rep = d_br, b.triple = d_tr;
+  b.target = d_tgt, b.ok_bits = d_ok, b.nack_bits = d_nack, b.commit_bits = d_com, b.nack_ballot = d_nb;
+  b.committed = d_done, b.reply_status = d_rs, b.reply_vote = d_rv, b.reply_triple = d_rt;
+  b.contrib = d_contrib, b.nackflag = d_flag, b.tilemax = d_tm, b.skip = d_skip;
+  if (++e->cl_run == 0) {  // stamp space exhausted: start over
+    EHIP(e, hipMemsetAsync(e->st.cl_stamp, 0, (size_t)n * e->st.num_instances * 4, e->stream));
+    e->cl_run = 1;
+  }
+  b.run_id = e->cl_run;
+  const dim3 gm((m + 255) / 256), blk(256);
+  hipLaunchKernelGGL(k_cl_validate, gm, blk, 0, e->stream, e->st, b);
+  if (accept) hipLaunchKernelGGL(k_cl_propose, gm, blk, 0, e->stream, e->st, b);
+  hipLaunchKernelGGL(k_cl_handle, dim3((unsigned)(((long long)m * n + 255) / 256)), blk, 0, e->stream, e->st, b);
+  hipLaunchKernelGGL(k_cl_tilemax, dim3(tiles, n), blk, 0, e->stream, b, tiles);
+  hipLaunchKernelGGL(k_cl_tilescan, dim3(n), blk, 0, e->stream, e->st, b, tiles);
+  hipLaunchKernelGGL(k_cl_nacks, dim3(tiles, n), blk, 0, e->stream, b, tiles);
+  if (accept) hipLaunchKernelGGL(k_cl_commit, gm, blk, 0, e->stream, e->st, b);
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) {
+    e->last_hip = (int)le;
+    return FPX_EHIP;
+  }
+  if (ok_bits) EHIP(e, hipMemcpyAsync(ok_bits, d_ok, (size_t)m, hipMemcpyDeviceToHost, e->stream));
+  if (nack_bits) EHIP(e, hipMemcpyAsync(nack_bits, d_nack, (size_t)m, hipMemcpyDeviceToHost, e->stream));
+  if (commit_bits) EHIP(e, hipMemcpyAsync(commit_bits, d_com, (size_t)m, hipMemcpyDeviceToHost, e->stream));
+  if (nack_ballot) EHIP(e, hipMemcpyAsync(nack_ballot, d_nb, (size_t)m * 4, hipMemcpyDeviceToHost, e->stream));
+  if (committed) EHIP(e, hipMemcpyAsync(committed, d_done, (size_t)m, hipMemcpyDeviceToHost, e->stream));
+  if (reply_status) EHIP(e, hipMemcpyAsync(reply_status, d_rs, (size_t)m * n * 4, hipMemcpyDeviceToHost, e->stream));
+  if (reply_vote) EHIP(e, hipMemcpyAsync(reply_vote, d_rv, (size_t)m * n * 4, hipMemcpyDeviceToHost, e->stream));
+  if (reply_triple) EHIP(e, hipMemcpyAsync(reply_triple, d_rt, (size_t)m * n * 4, hipMemcpyDeviceToHost, e->stream));
+  return fpx_epx_sync(e);
+}
+
+int32_t fpx_epx_prepare(fpx_epx* e, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* ballot_ordering,
+                        const int32_t* ballot_replica, const uint8_t* target_mask, uint8_t* ok_bits, uint8_t* nack_bits,
+                        uint8_t* commit_bits, int32_t* nack_ballot, int32_t* reply_status, int32_t* reply_vote_ballot,
+                        int32_t* reply_triple) {
+  return cl_run(e, 0, m, leader, number, ballot_ordering, ballot_replica, nullptr, target_mask, ok_bits, nack_bits,
+                commit_bits, nack_ballot, nullptr, reply_status, reply_vote_ballot, reply_triple);
+}
+
+int32_t fpx_epx_accept(fpx_epx* e, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* ballot_ordering,
+                       const int32_t* ballot_replica, const int32_t* triple_id, const uint8_t* target_mask, uint8_t* ok_bits,
+                       uint8_t* nack_bits, uint8_t* commit_bits, int32_t* nack_ballot, uint8_t* committed) {
+  return cl_run(e, 1, m, leader, number, ballot_ordering, ballot_replica, triple_id, target_mask, ok_bits, nack_bits,
+                commit_bits, nack_ballot, committed, nullptr, nullptr, nullptr);
+}
+
+int32_t fpx_epx_read_cmdlog(fpx_epx* e, int32_t replica, int32_t leader, int32_t number, int32_t out[5]) {
+  if (!e || !out || e->st.num_instances <= 0 || replica < 0 || replica >= e->st.n || leader < 0 || leader >= e->st.n ||
+      number < 0 || number >= e->st.num_instances)
+    return FPX_EINVAL;
+  EpxDeviceGuard _dg(e->cfg.device);
+  const size_t c = ((size_t)replica * e->st.n + leader) * e->st.num_instances + number;
+  uint8_t kind = 0;
+  EHIP(e, hipStreamSynchronize(e->stream));
+  EHIP(e, hipMemcpy(&kind, e->st.cl_status + c, 1, hipMemcpyDeviceToHost));
+  out[0] = kind;
+  EHIP(e, hipMemcpy(&out[1], e->st.cl_ballot + c, 4, hipMemcpyDeviceToHost));
+  EHIP(e, hipMemcpy(&out[2], e->st.cl_vote + c, 4, hipMemcpyDeviceToHost));
+  EHIP(e, hipMemcpy(&out[3], e->st.cl_triple + c, 4, hipMemcpyDeviceToHost));
+  EHIP(e, hipMemcpy(&out[4], e->st.largest + replica, 4, hipMemcpyDeviceToHost));
+  return FPX_OK;
 }
 
 int32_t fpx_epx_read_index(fpx_epx* e, int32_t replica, int32_t key, int32_t* gets, int32_t* sets) {

@@ -11,7 +11,7 @@ from ._lib import FpxError
 
 class FpxEpxConfig(C.Structure):
     _fields_ = [("num_replicas", C.c_int32), ("num_keys", C.c_int32), ("device", C.c_int32),
-                ("flags", C.c_uint32)]
+                ("flags", C.c_uint32), ("num_instances", C.c_int32)]
 
 
 def _bind(L):
@@ -28,11 +28,13 @@ def _bind(L):
 
 
 class EPaxos:
-    def __init__(self, num_replicas, num_keys, device=0):
+    def __init__(self, num_replicas, num_keys, device=0, num_instances=0):
+        """num_instances > 0: every replica keeps its command log for instances (leader, number < num_instances):
+        pre-accept records it, prepare() / accept() run the per-instance Paxos on it"""
         self.L = _lib.lib()
         _bind(self.L)
         self.n, self.num_keys = num_replicas, num_keys
-        cfg = FpxEpxConfig(num_replicas, num_keys, device, 0)
+        cfg = FpxEpxConfig(num_replicas, num_keys, device, 0, num_instances)
         h = C.c_void_p()
         st = self.L.fpx_epx_create(C.byref(cfg), C.byref(h))
         if st:
@@ -58,7 +60,7 @@ class EPaxos:
     def sync(self):
         return self.L.fpx_epx_sync(self._h)
 
-    def preaccept(self, leader, number, key, is_set, resp_mask, rank, seen_mask=None):
+    def preaccept(self, leader, number, key, is_set, resp_mask, rank, seen_mask=None, triple_id=None):
         """seen_mask: the other replicas that process the PreAccept (None = resp_mask, a thrifty
         deployment; all n-1 others with the reference's default ThriftySystem.NotThrifty)"""
         a32 = lambda x: np.ascontiguousarray(x, dtype=np.int32)
@@ -66,6 +68,7 @@ class EPaxos:
         leader, number, key, rank = a32(leader), a32(number), a32(key), a32(rank)
         is_set, resp_mask = a8(is_set), a8(resp_mask)
         seen_mask = None if seen_mask is None else a8(seen_mask)
+        triple_id = None if triple_id is None else a32(triple_id)
         m = len(leader)
         fast = np.zeros(m, np.uint8)
         deps = np.zeros((m, self.n), np.int32)
@@ -73,15 +76,51 @@ class EPaxos:
         own = np.zeros((m, 2), np.int32)
         p = lambda a: None if a is None else a.ctypes.data
         st = self.L.fpx_epx_preaccept(self._h, m, p(leader), p(number), p(key), p(is_set), p(resp_mask),
-                                      p(seen_mask), p(rank), p(fast), p(deps), p(ldeps), p(own))
+                                      p(seen_mask), p(rank), p(triple_id), p(fast), p(deps), p(ldeps), p(own))
         return st, fast, deps, ldeps, own
 
+    def prepare(self, leader, number, ballot_ordering, ballot_replica, target_mask):
+        """Replica.handlePrepare at the replicas of target_mask: (status, ok_bits, nack_bits, commit_bits,
+        nack_ballot, reply_status[m, n], reply_vote[m, n], reply_triple[m, n])"""
+        a32 = lambda x: np.ascontiguousarray(x, dtype=np.int32)
+        leader, number, bo, br = a32(leader), a32(number), a32(ballot_ordering), a32(ballot_replica)
+        tgt = np.ascontiguousarray(target_mask, dtype=np.uint8)
+        m = len(leader)
+        ok, nack, com = (np.zeros(m, np.uint8) for _ in range(3))
+        nb = np.full(m, -1, np.int32)
+        rs, rv, rt = (np.full((m, self.n), -1, np.int32) for _ in range(3))
+        p = lambda a: a.ctypes.data
+        st = self.L.fpx_epx_prepare(self._h, m, p(leader), p(number), p(bo), p(br), p(tgt), p(ok), p(nack), p(com),
+                                    p(nb), p(rs), p(rv), p(rt))
+        return st, ok, nack, com, nb, rs, rv, rt
+
+    def accept(self, leader, number, ballot_ordering, ballot_replica, triple_id, target_mask):
+        """the Accept phase: (status, ok_bits, nack_bits, commit_bits, nack_ballot, committed)"""
+        a32 = lambda x: np.ascontiguousarray(x, dtype=np.int32)
+        leader, number, bo, br, tr = a32(leader), a32(number), a32(ballot_ordering), a32(ballot_replica), a32(triple_id)
+        tgt = np.ascontiguousarray(target_mask, dtype=np.uint8)
+        m = len(leader)
+        ok, nack, com, done = (np.zeros(m, np.uint8) for _ in range(4))
+        nb = np.full(m, -1, np.int32)
+        p = lambda a: a.ctypes.data
+        st = self.L.fpx_epx_accept(self._h, m, p(leader), p(number), p(bo), p(br), p(tr), p(tgt), p(ok), p(nack),
+                                   p(com), p(nb), p(done))
+        return st, ok, nack, com, nb, done
+
+    def read_cmdlog(self, replica, leader, number):
+        """(kind, ballot, voteBallot, triple id, the replica's largestBallot); ballots encoded ordering * 8 + index"""
+        out = np.zeros(5, np.int32)
+        st = self.L.fpx_epx_read_cmdlog(self._h, replica, leader, number, out.ctypes.data)
+        if st:
+            raise FpxError(st, "fpx_epx_read_cmdlog")
+        return tuple(int(x) for x in out)
+
     def preaccept_dev(self, leader, number, key, is_set, resp_mask, rank, fast=None, deps=None,
-                      leader_deps=None, seen_mask=None, own_values_end=None):
+                      leader_deps=None, seen_mask=None, own_values_end=None, triple_id=None):
         d = lambda t: None if t is None else t.data_ptr()
         st = self.L.fpx_epx_preaccept_dev(self._h, leader.numel(), d(leader), d(number), d(key), d(is_set),
-                                          d(resp_mask), d(seen_mask), d(rank), d(fast), d(deps), d(leader_deps),
-                                          d(own_values_end))
+                                          d(resp_mask), d(seen_mask), d(rank), d(triple_id), d(fast), d(deps),
+                                          d(leader_deps), d(own_values_end))
         if st:
             raise FpxError(st, "fpx_epx_preaccept_dev")
 

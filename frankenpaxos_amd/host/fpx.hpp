@@ -621,7 +621,7 @@ class PreAcceptEngine {
     std::vector<uint8_t> fast(m);
     std::vector<int32_t> deps((size_t)m * n_), ldeps((size_t)m * n_), own((size_t)m * 2);
     check(fpx_epx_preaccept(epx_, m, leader.data(), number.data(), key.data(), isSet.data(), mask.data(),
-                            anyRecipients ? seen.data() : nullptr, rank.data(), fast.data(), deps.data(), ldeps.data(),
+                            anyRecipients ? seen.data() : nullptr, rank.data(), nullptr, fast.data(), deps.data(), ldeps.data(),
                             own.data()),
           "Replica.handlePreAccept");
     std::vector<Decision> out(m);

@@ -372,7 +372,7 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxPreaccept(
   jbyte* f = out_buf(fast, m, 1);
   jint *d = out_buf(deps, mn, 4), *ld = out_buf(leaderDeps, mn, 4), *ov = out_buf(ownValuesEnd, 2 * (jlong)m, 4);
   int32_t st = fpx_epx_preaccept((fpx_epx*)(intptr_t)h, m, l, nu, k, (const uint8_t*)is, (const uint8_t*)rm,
-                                 (const uint8_t*)sm, rk, (uint8_t*)f, d, ld, ov);
+                                 (const uint8_t*)sm, rk, NULL, (uint8_t*)f, d, ld, ov);
   put_bytes(env, fast, m, f); put_ints(env, deps, mn, d); put_ints(env, leaderDeps, mn, ld);
   put_ints(env, ownValuesEnd, 2 * (jlong)m, ov);
   free(l); free(nu); free(k); free(rk); free(is); free(rm); free(sm); free(f); free(d); free(ld); free(ov);

@@ -81,7 +81,11 @@ enum {
   FPX_ECAPACITY = 5,                /* more than tally_ways live (slot, round) tallies for one slot  */
   FPX_EORDER = 6,                   /* a _dev batch violated the run contract; nothing was applied   */
   FPX_ENOMEM = 7,
-  FPX_ERCCL = 8                     /* an RCCL call failed / RCCL is not loadable (fpx_last_rccl_error)  */
+  FPX_ERCCL = 8,                    /* an RCCL call failed / RCCL is not loadable (fpx_last_rccl_error)  */
+  FPX_EFATAL_PROTOCOL = 9           /* a logger.fatal / logger.check of the reference would have fired for a
+                                       message (EPaxos: transitionToAcceptPhase on a committed instance or
+                                       below an entry's ballot, Replica.scala:740-757): that message was not
+                                       applied, the others were                                             */
 };
 
 typedef enum {
@@ -366,20 +370,61 @@ typedef struct {
   int32_t num_keys;
   int32_t device;
   uint32_t flags;
+  int32_t num_instances; /* > 0: every replica keeps its command log (Replica.cmdLog) for the instances
+                            (leader, number < num_instances): fpx_epx_preaccept records and checks it,
+                            fpx_epx_prepare / fpx_epx_accept run on it.  0: no command log (pre-accept only) */
 } fpx_epx_config;
 int32_t fpx_epx_create(const fpx_epx_config* cfg, fpx_epx** out);
 int32_t fpx_epx_destroy(fpx_epx* epx);
 int32_t fpx_epx_set_stream(fpx_epx* epx, void* hip_stream);
 int32_t fpx_epx_preaccept(fpx_epx* epx, int32_t m, const int32_t* leader, const int32_t* number,
                           const int32_t* key, const uint8_t* is_set, const uint8_t* resp_mask,
-                          const uint8_t* seen_mask, const int32_t* rank, uint8_t* fast, int32_t* deps,
-                          int32_t* leader_deps, int32_t* own_values_end);
+                          const uint8_t* seen_mask, const int32_t* rank, const int32_t* triple_id,
+                          uint8_t* fast, int32_t* deps, int32_t* leader_deps, int32_t* own_values_end);
 /* device-resident inputs / outputs, asynchronous; fpx_epx_sync returns the sticky status */
 int32_t fpx_epx_preaccept_dev(fpx_epx* epx, int32_t m, const int32_t* d_leader, const int32_t* d_number,
                               const int32_t* d_key, const uint8_t* d_is_set, const uint8_t* d_resp_mask,
-                              const uint8_t* d_seen_mask, const int32_t* d_rank, uint8_t* d_fast,
-                              int32_t* d_deps, int32_t* d_leader_deps, int32_t* d_own_values_end);
+                              const uint8_t* d_seen_mask, const int32_t* d_rank, const int32_t* d_triple_id,
+                              uint8_t* d_fast, int32_t* d_deps, int32_t* d_leader_deps,
+                              int32_t* d_own_values_end);
 int32_t fpx_epx_sync(fpx_epx* epx);
+
+/* ---- EPaxos beyond fresh instances: the per-instance Paxos on the command log (num_instances > 0) --------------
+ * Ballots are (ordering, replicaIndex), compared lexicographically (epaxos/BallotHelpers.scala:11-21); where one
+ * int32 carries a ballot it is ordering * 8 + replicaIndex, the null ballot (-1, -1) (Replica.scala:256) is -1.
+ * Command-log entry kinds: 0 none, 1 NoCommandEntry, 2 PreAcceptedEntry, 3 AcceptedEntry, 4 CommittedEntry
+ * (Replica.scala:303-330).  A CommandTriple travels as the caller's int32 triple_id (pre-accept: the optional
+ * triple_id argument; the dependencies themselves are the pre-accept's outputs and stay with the caller).
+ * fpx_epx_preaccept with a command log: every participating replica must not know the instance yet (the
+ * `cmdLog.get == None` branch of handlePreAccept, Replica.scala:1169-1172; anything else is FPX_EINVAL, nothing
+ * applied); it records PreAcceptedEntry(Ballot(0, leader), Ballot(0, leader), triple) at the participants, and a
+ * fast-path commit turns the entry into CommittedEntry at every replica.
+ *
+ * Both calls below deliver message i, in array order, to the replicas in target_mask[i] (bit r); the instances
+ * (leader[i], number[i]) of one call must be pairwise distinct (FPX_EINVAL otherwise, nothing applied).  Replies
+ * per message (host pointers, may be NULL): ok_bits / nack_bits / commit_bits (the replica answered with the Commit
+ * it already holds), nack_ballot = the largest `largestBallot` carried by a Nack (Nack(instance, largestBallot),
+ * Replica.scala:1424, 1652), -1 if none.
+ *
+ * fpx_epx_prepare: Replica.handlePrepare (Replica.scala:1632-1757) -- phase 1 of an instance's recovery.  reply_*
+ *   are m x n: the PrepareOk of replica r = (status: 0 NotSeen / 2 PreAccepted / 3 Accepted, voteBallot, triple id);
+ *   -1 where r sent no PrepareOk.
+ * fpx_epx_accept: the Accept phase of message i proposed by replica ballot_replica[i] in ballot
+ *   (ballot_ordering[i], ballot_replica[i]): transitionToAcceptPhase at the proposer (:732-792; target_mask must
+ *   not contain it), handleAccept at the targets (:1421-1511), handleAcceptOk (:1513-1565): with f + 1 responses,
+ *   the proposer's own included, the instance is committed -- CommittedEntry at every replica (commit :815-860 and
+ *   Commit to the others).  A proposer that holds a CommittedEntry, or an entry with a larger ballot, would have
+ *   died in logger.fatal / logger.check: FPX_EFATAL_PROTOCOL, that message is skipped. */
+int32_t fpx_epx_prepare(fpx_epx* epx, int32_t m, const int32_t* leader, const int32_t* number,
+                        const int32_t* ballot_ordering, const int32_t* ballot_replica, const uint8_t* target_mask,
+                        uint8_t* ok_bits, uint8_t* nack_bits, uint8_t* commit_bits, int32_t* nack_ballot,
+                        int32_t* reply_status, int32_t* reply_vote_ballot, int32_t* reply_triple);
+int32_t fpx_epx_accept(fpx_epx* epx, int32_t m, const int32_t* leader, const int32_t* number,
+                       const int32_t* ballot_ordering, const int32_t* ballot_replica, const int32_t* triple_id,
+                       const uint8_t* target_mask, uint8_t* ok_bits, uint8_t* nack_bits, uint8_t* commit_bits,
+                       int32_t* nack_ballot, uint8_t* committed);
+/* one command-log entry: out[0..4] = kind, ballot, voteBallot, triple id, the replica's largestBallot */
+int32_t fpx_epx_read_cmdlog(fpx_epx* epx, int32_t replica, int32_t leader, int32_t number, int32_t out[5]);
 /* replica's conflict-index entry of one key: gets[n], sets[n] (TopOne vectors) */
 int32_t fpx_epx_read_index(fpx_epx* epx, int32_t replica, int32_t key, int32_t* gets, int32_t* sets);
 

@@ -31,27 +31,59 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* cmdLog entry kinds (epaxos/Replica.scala:303-330) */
+enum { CL_NONE = 0, CL_NO_COMMAND = 1, CL_PRE_ACCEPTED = 2, CL_ACCEPTED = 3, CL_COMMITTED = 4 };
+
 typedef struct {
   int n, num_keys;
   int* gets; /* [n][num_keys][n]  replica r's conflict index: gets(key) TopOne */
   int* sets; /* [n][num_keys][n] */
+  /* cmdLog: mutable.Map[Instance, CmdLogEntry] per replica (Replica.scala:440), for the instances
+   * (leader, number < num_instances); ballots are (ordering, replicaIndex) compared lexicographically
+   * (BallotHelpers.scala:11-21), kept as ordering * 8 + replicaIndex; nullBallot (-1, -1) (Replica.scala:256) = -1 */
+  int num_instances;
+  unsigned char* cl_status; /* [n][n * num_instances] */
+  int* cl_ballot;
+  int* cl_vote;
+  int* cl_triple;            /* the CommandTriple, by the caller's id */
+  int* largest_ballot;       /* [n]  Replica.scala:458  var largestBallot = Ballot(0, index) */
 } fpo_epx;
 
-fpo_epx* fpo_epx_new(int n, int num_keys) {
-  if (n < 3 || n > 8 || !(n & 1) || num_keys < 1) return NULL;
+static int enc_ballot(int ordering, int replica) { return (ordering < 0 || replica < 0) ? -1 : ordering * 8 + replica; }
+
+fpo_epx* fpo_epx_new2(int n, int num_keys, int num_instances) {
+  if (n < 3 || n > 8 || !(n & 1) || num_keys < 1 || num_instances < 0) return NULL;
   fpo_epx* e = (fpo_epx*)calloc(1, sizeof(fpo_epx));
   e->n = n;
   e->num_keys = num_keys;
   /* TopOne.scala:10 topOnes = Buffer.fill(numLeaders)(0) */
   e->gets = (int*)calloc((size_t)n * num_keys * n, sizeof(int));
   e->sets = (int*)calloc((size_t)n * num_keys * n, sizeof(int));
+  e->num_instances = num_instances;
+  if (num_instances > 0) {
+    const size_t cells = (size_t)n * n * num_instances;
+    e->cl_status = (unsigned char*)calloc(cells, 1);
+    e->cl_ballot = (int*)malloc(sizeof(int) * cells);
+    e->cl_vote = (int*)malloc(sizeof(int) * cells);
+    e->cl_triple = (int*)malloc(sizeof(int) * cells);
+    for (size_t i = 0; i < cells; ++i) e->cl_ballot[i] = e->cl_vote[i] = e->cl_triple[i] = -1;
+  }
+  e->largest_ballot = (int*)malloc(sizeof(int) * (size_t)n);
+  for (int r = 0; r < n; ++r) e->largest_ballot[r] = enc_ballot(0, r);
   return e;
 }
+
+fpo_epx* fpo_epx_new(int n, int num_keys) { return fpo_epx_new2(n, num_keys, 0); }
 
 void fpo_epx_free(fpo_epx* e) {
   if (!e) return;
   free(e->gets);
   free(e->sets);
+  free(e->cl_status);
+  free(e->cl_ballot);
+  free(e->cl_vote);
+  free(e->cl_triple);
+  free(e->largest_ballot);
   free(e);
 }
 
@@ -220,6 +252,11 @@ int fpo_ips_add_all(int wa, const int* va, int na, int wb, const int* vb, int nb
   return n;
 }
 
+int fpo_epx_preaccept2(fpo_epx* e, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* key,
+                       const uint8_t* is_set, const uint8_t* resp_mask, const uint8_t* seen_mask,
+                       const int32_t* rank, const int32_t* triple_id, uint8_t* fast, int32_t* deps,
+                       int32_t* leader_deps, int32_t* own_values_end);
+
 /*
  * One tick.  rank[r * m + i] = position of message i in replica r's processing order.
  * resp_mask[i]: the n-2 other replicas the leader sends PreAccept to.
@@ -235,8 +272,31 @@ int fpo_epx_preaccept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_
                       const uint8_t* is_set, const uint8_t* resp_mask, const uint8_t* seen_mask,
                       const int32_t* rank, uint8_t* fast, int32_t* deps, int32_t* leader_deps,
                       int32_t* own_values_end) {
+  return fpo_epx_preaccept2(e, m, leader, number, key, is_set, resp_mask, seen_mask, rank, NULL, fast, deps, leader_deps,
+                            own_values_end);
+}
+
+/* the same with the command log kept (num_instances > 0): triple_id[i] (NULL = -1) names the CommandTriple of
+ * message i; every participating replica must not have seen the instance (cmdLog.get == None, the only branch of
+ * handlePreAccept this tick-at-once form covers -- anything else is EINVAL 1 and nothing is applied) and records
+ * PreAcceptedEntry(ballot = voteBallot = Ballot(0, leader), triple) (:688-696, :1259-1271); a fast-path commit
+ * makes it CommittedEntry at every replica (commit :815-823 + Commit to the others, handleCommit), a slow-path
+ * decision leaves the entries for the Accept phase (fpo_epx_accept) */
+int fpo_epx_preaccept2(fpo_epx* e, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* key,
+                       const uint8_t* is_set, const uint8_t* resp_mask, const uint8_t* seen_mask,
+                       const int32_t* rank, const int32_t* triple_id, uint8_t* fast, int32_t* deps,
+                       int32_t* leader_deps, int32_t* own_values_end) {
   const int n = e->n;
   if (m < 0) return 1;
+  if (e->num_instances > 0) {
+    for (int i = 0; i < m; ++i) {
+      if (leader[i] < 0 || leader[i] >= n || number[i] < 0 || number[i] >= e->num_instances) return 1;
+      const unsigned part = (seen_mask ? seen_mask[i] : resp_mask[i]) | (1u << leader[i]);
+      for (int r = 0; r < n; ++r)
+        if (((part >> r) & 1u) && e->cl_status[((size_t)r * n + leader[i]) * e->num_instances + number[i]] != CL_NONE)
+          return 1;
+    }
+  }
   for (int i = 0; i < m; ++i) {
     if (leader[i] < 0 || leader[i] >= n || number[i] < 0 || key[i] < 0 || key[i] >= e->num_keys) return 1;
     if ((resp_mask[i] >> leader[i]) & 1u) return 1;                     /* "other" replicas only */
@@ -330,6 +390,19 @@ int fpo_epx_preaccept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_
      * replica in seen_mask finds the instance committed / accepting and is ignored (:1308-1334). */
     const int is_fast = all_equal;
     if (fast) fast[i] = (uint8_t)is_fast;
+    if (e->num_instances > 0) {
+      const unsigned part = (seen_mask ? seen_mask[i] : resp_mask[i]) | (1u << L);
+      for (int r = 0; r < n; ++r) {
+        const size_t c = ((size_t)r * n + L) * e->num_instances + number[i];
+        if (is_fast) {
+          e->cl_status[c] = CL_COMMITTED, e->cl_ballot[c] = e->cl_vote[c] = -1;
+          e->cl_triple[c] = triple_id ? triple_id[i] : -1;
+        } else if ((part >> r) & 1u) {
+          e->cl_status[c] = CL_PRE_ACCEPTED, e->cl_ballot[c] = e->cl_vote[c] = enc_ballot(0, L);
+          e->cl_triple[c] = triple_id ? triple_id[i] : -1;
+        }
+      }
+    }
     const ips_t* out_own = is_fast ? &first_own : &uni_own;
     for (int l = 0; l < n; ++l) {
       if (deps) deps[(size_t)i * n + l] = l == L ? out_own->watermark : (is_fast ? first[l] : uni[l]);
@@ -358,6 +431,156 @@ int fpo_epx_preaccept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_
   free(own);
   free(order);
   return rc;
+}
+
+/* ---- the per-instance Paxos of EPaxos: Prepare (phase 1) and Accept (phase 2) on the command log ---------------
+ * Messages are delivered in array order, each to the replicas of its target_mask (bit r); the instances of one
+ * call must be pairwise distinct (EINVAL 1 otherwise: the GPU evaluates a batch at once).  Per message the replies:
+ * ok_bits / nack_bits / commit_bits (the replica answered with the Commit it already has), nack_ballot = the largest
+ * `largestBallot` a Nack carried (encoded ordering * 8 + replicaIndex; -1 = none). */
+static int instances_ok(const fpo_epx* e, int m, const int32_t* leader, const int32_t* number, const int32_t* b_ord,
+                        const int32_t* b_rep, const uint8_t* target) {
+  if (e->num_instances <= 0 || m < 0) return 0;
+  unsigned char* seen = (unsigned char*)calloc((size_t)e->n * e->num_instances, 1);
+  int ok = 1;
+  for (int i = 0; i < m && ok; ++i) {
+    if (leader[i] < 0 || leader[i] >= e->n || number[i] < 0 || number[i] >= e->num_instances || b_ord[i] < 0 ||
+        b_ord[i] >= (1 << 27) || b_rep[i] < 0 || b_rep[i] >= e->n || (target[i] >> e->n))
+      ok = 0;
+    else if (seen[(size_t)leader[i] * e->num_instances + number[i]]++)
+      ok = 0;
+  }
+  free(seen);
+  return ok;
+}
+
+/* Replica.handlePrepare  epaxos/Replica.scala:1632-1757, at every replica of target_mask.  Per (message, replica):
+ * reply_status = the PrepareOk's CommandStatus as the entry kind (0 NotSeen, 2 PreAccepted, 3 Accepted; -1 when the
+ * replica did not answer PrepareOk), reply_vote = its voteBallot (encoded), reply_triple = its triple id. */
+int fpo_epx_prepare(fpo_epx* e, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* b_ord,
+                    const int32_t* b_rep, const uint8_t* target, uint8_t* ok_bits, uint8_t* nack_bits,
+                    uint8_t* commit_bits, int32_t* nack_ballot, int32_t* reply_status, int32_t* reply_vote,
+                    int32_t* reply_triple) {
+  const int n = e->n;
+  if (!instances_ok(e, m, leader, number, b_ord, b_rep, target)) return 1;
+  for (int i = 0; i < m; ++i) {
+    const int ballot = enc_ballot(b_ord[i], b_rep[i]);
+    unsigned ok = 0, nack = 0, com = 0;
+    int nb = -1;
+    for (int r = 0; r < n; ++r) {
+      int rs = -1, rv = -1, rt = -1;
+      if ((target[i] >> r) & 1u) {
+        /* :1637 largestBallot = max(largestBallot, prepare.ballot) -- before anything else */
+        if (ballot > e->largest_ballot[r]) e->largest_ballot[r] = ballot;
+        const size_t c = ((size_t)r * n + leader[i]) * e->num_instances + number[i];
+        const int st = e->cl_status[c];
+        if (st == CL_COMMITTED) {
+          com |= 1u << r; /* :1744-1755 */
+        } else if (st != CL_NONE && ballot < e->cl_ballot[c]) {
+          nack |= 1u << r; /* :1681-1684, :1706-1709, :1726-1729  Nack(instance, largestBallot) */
+          if (e->largest_ballot[r] > nb) nb = e->largest_ballot[r];
+        } else {
+          ok |= 1u << r;
+          if (st == CL_NONE || st == CL_NO_COMMAND) { /* :1654-1669, :1686-1701 */
+            rs = 0, rv = -1, rt = -1;
+            e->cl_status[c] = CL_NO_COMMAND, e->cl_vote[c] = -1, e->cl_triple[c] = -1;
+          } else { /* :1711-1724, :1731-1743: the entry keeps its vote, only `ballot` moves */
+            rs = st, rv = e->cl_vote[c], rt = e->cl_triple[c];
+          }
+          e->cl_ballot[c] = ballot;
+        }
+      }
+      if (reply_status) reply_status[(size_t)i * n + r] = rs;
+      if (reply_vote) reply_vote[(size_t)i * n + r] = rv;
+      if (reply_triple) reply_triple[(size_t)i * n + r] = rt;
+    }
+    if (ok_bits) ok_bits[i] = (uint8_t)ok;
+    if (nack_bits) nack_bits[i] = (uint8_t)nack;
+    if (commit_bits) commit_bits[i] = (uint8_t)com;
+    if (nack_ballot) nack_ballot[i] = nb;
+  }
+  return 0;
+}
+
+/* The Accept phase of message i, proposed by replica b_rep[i] in ballot (b_ord[i], b_rep[i]):
+ *   transitionToAcceptPhase at the proposer (:732-792): its own entry becomes AcceptedEntry(ballot, ballot, triple)
+ *     -- a CommittedEntry there is logger.fatal (:740-744), an entry with a larger ballot a failed logger.checkLe
+ *     (:749-757): both return 9 = FPX_EFATAL_PROTOCOL (nothing of message i is applied; the other messages are) -- and its own
+ *     AcceptOk is the first response (:780-789);
+ *   handleAccept at every replica of target_mask (:1421-1511), the proposer excluded;
+ *   handleAcceptOk at the proposer (:1513-1565): slowQuorumSize = f + 1 responses (Config.scala:9) -> commit;
+ *   commit (:815-860) with informOthers: CommittedEntry at every replica once the tick is over.
+ * committed[i] = 1 if the instance got committed by this message. */
+int fpo_epx_accept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* b_ord,
+                   const int32_t* b_rep, const int32_t* triple_id, const uint8_t* target, uint8_t* ok_bits,
+                   uint8_t* nack_bits, uint8_t* commit_bits, int32_t* nack_ballot, uint8_t* committed) {
+  const int n = e->n, f = (n - 1) / 2;
+  if (!instances_ok(e, m, leader, number, b_ord, b_rep, target)) return 1;
+  for (int i = 0; i < m; ++i)
+    if ((target[i] >> b_rep[i]) & 1u) return 1; /* thriftyOtherReplicas: never the proposer itself (:774) */
+  int status = 0;
+  for (int i = 0; i < m; ++i) {
+    const int ballot = enc_ballot(b_ord[i], b_rep[i]), P = b_rep[i];
+    unsigned ok = 0, nack = 0, com = 0;
+    int nb = -1;
+    if (ok_bits) ok_bits[i] = 0;
+    if (nack_bits) nack_bits[i] = 0;
+    if (commit_bits) commit_bits[i] = 0;
+    if (nack_ballot) nack_ballot[i] = -1;
+    if (committed) committed[i] = 0;
+    const size_t cp = ((size_t)P * n + leader[i]) * e->num_instances + number[i];
+    if (e->cl_status[cp] == CL_COMMITTED || (e->cl_status[cp] != CL_NONE && e->cl_ballot[cp] > ballot) ||
+        (e->cl_status[cp] >= CL_PRE_ACCEPTED && e->cl_vote[cp] > ballot)) {
+      if (!status) status = 9; /* FPX_EFATAL_PROTOCOL */
+      continue;
+    }
+    e->cl_status[cp] = CL_ACCEPTED, e->cl_ballot[cp] = e->cl_vote[cp] = ballot, e->cl_triple[cp] = triple_id[i];
+    ok |= 1u << P;
+    for (int r = 0; r < n; ++r) {
+      if (!((target[i] >> r) & 1u)) continue;
+      const size_t c = ((size_t)r * n + leader[i]) * e->num_instances + number[i];
+      const int st = e->cl_status[c];
+      if (st == CL_COMMITTED) {
+        com |= 1u << r; /* :1463-1474 */
+        continue;
+      }
+      if (st != CL_NONE && ballot < e->cl_ballot[c]) { /* :1432-1449 Nack(instance, largestBallot) */
+        nack |= 1u << r;
+        if (e->largest_ballot[r] > nb) nb = e->largest_ballot[r];
+        continue;
+      }
+      if (st == CL_ACCEPTED && ballot == e->cl_vote[c]) { /* :1451-1461 already answered: re-send the AcceptOk */
+        ok |= 1u << r;
+        continue;
+      }
+      if (ballot > e->largest_ballot[r]) e->largest_ballot[r] = ballot; /* :1487 */
+      e->cl_status[c] = CL_ACCEPTED, e->cl_ballot[c] = e->cl_vote[c] = ballot, e->cl_triple[c] = triple_id[i]; /* :1493-1502 */
+      ok |= 1u << r;
+    }
+    if (ok_bits) ok_bits[i] = (uint8_t)ok;
+    if (nack_bits) nack_bits[i] = (uint8_t)nack;
+    if (commit_bits) commit_bits[i] = (uint8_t)com;
+    if (nack_ballot) nack_ballot[i] = nb;
+    if (popcount8(ok) >= f + 1) { /* :1557-1563 */
+      if (committed) committed[i] = 1;
+      for (int r = 0; r < n; ++r) {
+        const size_t c = ((size_t)r * n + leader[i]) * e->num_instances + number[i];
+        e->cl_status[c] = CL_COMMITTED, e->cl_ballot[c] = e->cl_vote[c] = -1, e->cl_triple[c] = triple_id[i];
+      }
+    }
+  }
+  return status;
+}
+
+/* one command-log entry: kind, ballot, voteBallot (encoded), triple id; and the replica's largestBallot */
+int fpo_epx_read_cmdlog(fpo_epx* e, int replica, int leader, int number, int32_t* out5) {
+  if (e->num_instances <= 0 || replica < 0 || replica >= e->n || leader < 0 || leader >= e->n || number < 0 ||
+      number >= e->num_instances)
+    return 1;
+  const size_t c = ((size_t)replica * e->n + leader) * e->num_instances + number;
+  out5[0] = e->cl_status[c], out5[1] = e->cl_ballot[c], out5[2] = e->cl_vote[c], out5[3] = e->cl_triple[c];
+  out5[4] = e->largest_ballot[replica];
+  return 0;
 }
 
 /* replica r's conflict index entries for `key`: gets[n], sets[n] */

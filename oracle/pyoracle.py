@@ -544,10 +544,15 @@ def indices_of(words):
 class EPaxos:
     """oracle twin of frankenpaxos_amd.epaxos.EPaxos (fpx_oracle_epaxos.c)"""
 
-    def __init__(self, num_replicas, num_keys):
+    def __init__(self, num_replicas, num_keys, num_instances=0):
         L = lib()
-        L.fpo_epx_new.argtypes = [C.c_int, C.c_int]
-        L.fpo_epx_new.restype = C.c_void_p
+        L.fpo_epx_new2.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.fpo_epx_new2.restype = C.c_void_p
+        L.fpo_epx_preaccept2.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, U8P, U8P, U8P, I32P, I32P, U8P, I32P,
+                                         I32P, I32P]
+        L.fpo_epx_prepare.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, I32P, U8P, U8P, U8P, U8P, I32P, I32P, I32P, I32P]
+        L.fpo_epx_accept.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, I32P, I32P, U8P, U8P, U8P, U8P, I32P, U8P]
+        L.fpo_epx_read_cmdlog.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, I32P]
         L.fpo_epx_free.argtypes = [C.c_void_p]
         L.fpo_epx_preaccept.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, U8P, U8P, U8P, I32P, U8P, I32P,
                                         I32P, I32P]
@@ -555,7 +560,7 @@ class EPaxos:
         L.fpo_epx_index_put.argtypes = [C.c_void_p] + [C.c_int] * 5
         L.fpo_epx_index_conflicts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, I32P]
         self.n, self.num_keys = num_replicas, num_keys
-        self._h = L.fpo_epx_new(num_replicas, num_keys)
+        self._h = L.fpo_epx_new2(num_replicas, num_keys, num_instances)
         if not self._h:
             raise ValueError("FPX_EINVAL")
 
@@ -565,7 +570,35 @@ class EPaxos:
         except Exception:
             pass
 
-    def preaccept(self, leader, number, key, is_set, resp_mask, rank, seen_mask=None):
+    def prepare(self, leader, number, ballot_ordering, ballot_replica, target_mask):
+        leader, number, bo, br = _i32(leader), _i32(number), _i32(ballot_ordering), _i32(ballot_replica)
+        tgt = np.ascontiguousarray(target_mask, dtype=np.uint8)
+        m = len(leader)
+        ok, nack, com = (np.zeros(m, np.uint8) for _ in range(3))
+        nb = np.full(m, -1, np.int32)
+        rs, rv, rt = (np.full((m, self.n), -1, np.int32) for _ in range(3))
+        st = lib().fpo_epx_prepare(self._h, m, _p(leader, I32P), _p(number, I32P), _p(bo, I32P), _p(br, I32P), _p(tgt, U8P),
+                                   _p(ok, U8P), _p(nack, U8P), _p(com, U8P), _p(nb, I32P), _p(rs, I32P), _p(rv, I32P),
+                                   _p(rt, I32P))
+        return st, ok, nack, com, nb, rs, rv, rt
+
+    def accept(self, leader, number, ballot_ordering, ballot_replica, triple_id, target_mask):
+        leader, number, bo, br, tr = _i32(leader), _i32(number), _i32(ballot_ordering), _i32(ballot_replica), _i32(triple_id)
+        tgt = np.ascontiguousarray(target_mask, dtype=np.uint8)
+        m = len(leader)
+        ok, nack, com, done = (np.zeros(m, np.uint8) for _ in range(4))
+        nb = np.full(m, -1, np.int32)
+        st = lib().fpo_epx_accept(self._h, m, _p(leader, I32P), _p(number, I32P), _p(bo, I32P), _p(br, I32P), _p(tr, I32P),
+                                  _p(tgt, U8P), _p(ok, U8P), _p(nack, U8P), _p(com, U8P), _p(nb, I32P), _p(done, U8P))
+        return st, ok, nack, com, nb, done
+
+    def read_cmdlog(self, replica, leader, number):
+        out = np.zeros(5, np.int32)
+        if lib().fpo_epx_read_cmdlog(self._h, replica, leader, number, _p(out, I32P)):
+            raise ValueError("FPX_EINVAL")
+        return tuple(int(x) for x in out)
+
+    def preaccept(self, leader, number, key, is_set, resp_mask, rank, seen_mask=None, triple_id=None):
         a8 = lambda x: np.ascontiguousarray(x, dtype=np.uint8)
         leader, number, key, rank = _i32(leader), _i32(number), _i32(key), _i32(rank)
         is_set, resp_mask = a8(is_set), a8(resp_mask)
@@ -575,10 +608,11 @@ class EPaxos:
         deps = np.zeros((m, self.n), np.int32)
         ldeps = np.zeros((m, self.n), np.int32)
         own = np.zeros((m, 2), np.int32)
-        st = lib().fpo_epx_preaccept(self._h, m, _p(leader, I32P), _p(number, I32P), _p(key, I32P),
-                                     _p(is_set, U8P), _p(resp_mask, U8P), _p(seen_mask, U8P), _p(rank, I32P),
-                                     _p(fast, U8P),
-                                     _p(deps, I32P), _p(ldeps, I32P), _p(own, I32P))
+        triple_id = None if triple_id is None else _i32(triple_id)
+        st = lib().fpo_epx_preaccept2(self._h, m, _p(leader, I32P), _p(number, I32P), _p(key, I32P),
+                                      _p(is_set, U8P), _p(resp_mask, U8P), _p(seen_mask, U8P), _p(rank, I32P),
+                                      _p(triple_id, I32P), _p(fast, U8P),
+                                      _p(deps, I32P), _p(ldeps, I32P), _p(own, I32P))
         return st, fast, deps, ldeps, own
 
     def index_put(self, replica, key, is_set, leader, number):

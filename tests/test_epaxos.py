@@ -473,3 +473,137 @@ def test_oracle_epaxos_safety_invariant_negative_control(oracle):
                     violations += 1
                 assert deps[i][leader[j]] > number[j] or deps[j][leader[i]] > number[i]
     assert violations > 0
+
+
+# ------------------------------------------------ beyond fresh instances: command log, Prepare, Accept ------------
+def enc(ordering, replica):
+    return ordering * 8 + replica
+
+
+def test_oracle_accept_phase_by_hand(oracle):
+    """n = 5 (f = 2: slow quorum 3, the proposer included).  X = set k0 by replica 4 (instance (4,0)), Y = set k0 by
+    replica 0 (instance (0,7)); both pre-accept on the slow path (test_oracle_slow_path_by_hand), then:
+      the command log after the pre-accept: PreAcceptedEntry(Ballot(0, leader), Ballot(0, leader), triple) at the
+        leader and its three responders (Replica.scala:688-696, 1259-1271), nothing at the fifth replica;
+      Accept X by 4 in Ballot(0,4) to {1, 2}: 0 < entry ballot? no -> AcceptedEntry, AcceptOk; with 4's own that is
+        3 = f + 1 responses -> commit: CommittedEntry at ALL five replicas (handleAcceptOk :1557-1563, commit);
+      replica 2 starts recovering Y: Prepare(Y, Ballot(1,2)) to {1, 3}: PreAcceptedEntry -> PrepareOk(PreAccepted,
+        voteBallot (0,0), triple), the entries' ballot moves to (1,2), largestBallot of 1 and 3 too (:1637, 1711-1724);
+      the old leader 0 still sends Accept(Y, Ballot(0,0)) to {1, 3}: (0,0) < (1,2) -> Nack(largestBallot = (1,2))
+        from both (:1432-1439); 0's own AcceptOk alone is no quorum;
+      replica 2 finishes: Accept(Y, Ballot(1,2)) to {1, 3}: equal ballot is not smaller -> accepted; 3 responses ->
+        committed everywhere, replica 0 included;
+      0 tries once more: its own entry is Committed -> logger.fatal in transitionToAcceptPhase (:740-744)."""
+    e = oracle.EPaxos(5, 2, num_instances=16)
+    leader, number, key, is_set = [4, 0], [0, 7], [0, 0], [1, 1]
+    rank = np.array([[0, 1], [0, 1], [0, 1], [1, 0], [0, 1]])
+    st, fast, deps, ldeps, own = e.preaccept(leader, number, key, is_set, [0b01110, 0b01110], rank, triple_id=[100, 107])
+    assert st == 0 and fast.tolist() == [0, 0]
+    for r, want in ((4, (2, enc(0, 4), enc(0, 4), 100)), (1, (2, enc(0, 4), enc(0, 4), 100)), (0, (0, -1, -1, -1))):
+        assert e.read_cmdlog(r, 4, 0)[:4] == want
+    assert e.read_cmdlog(0, 0, 7)[:4] == (2, enc(0, 0), enc(0, 0), 107) and e.read_cmdlog(4, 0, 7)[0] == 0
+    st, ok, nack, com, nb, done = e.accept([4], [0], [0], [4], [100], [0b00110])
+    assert st == 0 and ok[0] == 0b10110 and nack[0] == 0 and done[0] == 1
+    assert all(e.read_cmdlog(r, 4, 0)[:4] == (4, -1, -1, 100) for r in range(5))
+    st, ok, nack, com, nb, rs, rv, rt = e.prepare([0], [7], [1], [2], [0b01010])
+    assert st == 0 and ok[0] == 0b01010 and nack[0] == 0
+    assert rs[0].tolist() == [-1, 2, -1, 2, -1] and rv[0].tolist() == [-1, 0, -1, 0, -1] and rt[0].tolist() == [-1, 107, -1, 107, -1]
+    assert e.read_cmdlog(1, 0, 7) == (2, enc(1, 2), enc(0, 0), 107, enc(1, 2))
+    st, ok, nack, com, nb, done = e.accept([0], [7], [0], [0], [107], [0b01010])
+    assert st == 0 and ok[0] == 0b00001 and nack[0] == 0b01010 and nb[0] == enc(1, 2) and done[0] == 0
+    assert e.read_cmdlog(0, 0, 7)[:4] == (3, enc(0, 0), enc(0, 0), 107)
+    st, ok, nack, com, nb, done = e.accept([0], [7], [1], [2], [107], [0b01010])
+    assert st == 0 and ok[0] == 0b01110 and nack[0] == 0 and done[0] == 1
+    assert all(e.read_cmdlog(r, 0, 7)[:4] == (4, -1, -1, 107) for r in range(5))
+    st, ok, nack, com, nb, done = e.accept([0], [7], [0], [0], [107], [0b01010])
+    assert st == 9 and done[0] == 0                      # FPX_EFATAL_PROTOCOL: the proposer holds a CommittedEntry
+    # a Prepare and an Accept that reach committed replicas are answered with the Commit (:1744-1755, :1463-1474)
+    st, ok, nack, com, nb, rs, rv, rt = e.prepare([0], [7], [2], [3], [0b10111])
+    assert com[0] == 0b10111 and ok[0] == 0 and e.read_cmdlog(4, 0, 7)[4] == enc(2, 3)   # largestBallot moved all the same
+    # an instance nobody has heard of: Prepare leaves NoCommandEntry(ballot), a smaller Accept is then Nacked,
+    # an equal one accepted; re-sending the Accept is answered again without changing anything (:1451-1461)
+    st, ok, nack, com, nb, rs, rv, rt = e.prepare([3], [5], [4], [1], [0b00101])
+    assert ok[0] == 0b00101 and rs[0].tolist() == [0, -1, 0, -1, -1] and e.read_cmdlog(2, 3, 5)[:4] == (1, enc(4, 1), -1, -1)
+    st, ok, nack, com, nb, done = e.accept([3], [5], [3], [3], [55], [0b00101])
+    assert ok[0] == 0b01000 and nack[0] == 0b00101 and nb[0] == enc(4, 1)
+    st, ok, nack, com, nb, done = e.accept([3], [5], [4], [1], [56], [0b00101])
+    assert ok[0] == 0b00111 and done[0] == 1
+    # the instances of one call must be distinct; the proposer is never among its own targets
+    assert e.accept([1, 1], [2, 2], [0, 0], [1, 1], [1, 1], [0b00101, 0b00101])[0] == 1
+    assert e.accept([1], [3], [0], [1], [1], [0b00011])[0] == 1
+    assert oracle.EPaxos(5, 2).accept([1], [3], [0], [1], [1], [0b00101])[0] == 1   # no command log configured
+
+
+def _cl_batch(rng, n, NI, m, nxt):
+    """m distinct instances, random ballots and target sets.  Instances come from the upper half of every leader's
+    numbers and from those the pre-accept ticks have already used (nxt): the numbers the NEXT pre-accept tick will
+    take stay untouched, so that its instances are fresh"""
+    pool = np.array([L * NI + x for L in range(n) for x in list(range(nxt[L])) + list(range(NI // 2, NI))])
+    m = min(m, len(pool))
+    inst = rng.choice(pool, size=m, replace=False)
+    leader, number = (inst // NI).astype(np.int32), (inst % NI).astype(np.int32)
+    b_ord = rng.integers(0, 4, m).astype(np.int32)
+    b_rep = rng.integers(0, n, m).astype(np.int32)
+    tgt = rng.integers(0, 1 << n, m).astype(np.uint8)
+    return leader, number, b_ord, b_rep, tgt
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,NI,m", [(3, 64, 40), (5, 512, 700), (7, 300, 1500), (5, 4096, 5000)])
+def test_epaxos_prepare_accept_match_oracle(oracle, n, NI, m):
+    """random Prepare / Accept batches on the command log (ballots going up and down, arbitrary target sets, instances
+    in every state incl. committed, re-sent Accepts, proposers that must refuse), interleaved with pre-accept ticks
+    that create PreAccepted / Committed entries: every reply and the whole command log, GPU == oracle"""
+    from frankenpaxos_amd.epaxos import EPaxos
+    import frankenpaxos_amd as fa
+
+    gpu, ref = EPaxos(n, 8, num_instances=NI), oracle.EPaxos(n, 8, num_instances=NI)
+    rng = np.random.default_rng(n * 31 + NI)
+    nxt = [0] * n
+    fatal = nacks = commits = 0
+    for step in range(14):
+        kind = step % 4
+        if kind == 0 and max(nxt) + min(m, 200) // 2 + 8 < NI // 2:
+            mm = min(m, 200)
+            leader, number, key, is_set, mask, rank = random_tick(rng, n, 8, mm, nxt, 3.0)
+            tr = rng.integers(0, 1 << 20, mm).astype(np.int32)
+            a = gpu.preaccept(leader, number, key, is_set, mask, rank, triple_id=tr)
+            b = ref.preaccept(leader, number, key, is_set, mask, rank, triple_id=tr)
+            assert a[0] == b[0] == 0
+            for x, y in zip(a[1:], b[1:]):
+                np.testing.assert_array_equal(x, y)
+            # the same tick again: the instances are no longer fresh -> FPX_EINVAL on both, nothing applied
+            assert gpu.preaccept(leader, number, key, is_set, mask, rank)[0] == fa.FPX_EINVAL
+            assert ref.preaccept(leader, number, key, is_set, mask, rank)[0] == 1
+        elif kind in (1, 3):
+            leader, number, b_ord, b_rep, tgt = _cl_batch(rng, n, NI, m, nxt)
+            tgt = (tgt & ~(1 << b_rep)).astype(np.uint8)          # an Accept never targets its proposer
+            tr = rng.integers(0, 1 << 20, len(leader)).astype(np.int32)
+            a, b = gpu.accept(leader, number, b_ord, b_rep, tr, tgt), ref.accept(leader, number, b_ord, b_rep, tr, tgt)
+            assert a[0] == b[0] and a[0] in (0, fa.FPX_EFATAL_PROTOCOL)
+            fatal += a[0] != 0
+            for x, y in zip(a[1:], b[1:]):
+                np.testing.assert_array_equal(x, y)
+            nacks += int((a[2] != 0).sum())
+            commits += int(a[5].sum())
+            if kind == 3:     # re-send the very same Accepts: answered again (or refused by now-committed proposers)
+                a, b = gpu.accept(leader, number, b_ord, b_rep, tr, tgt), ref.accept(leader, number, b_ord, b_rep, tr, tgt)
+                assert a[0] == b[0]
+                for x, y in zip(a[1:], b[1:]):
+                    np.testing.assert_array_equal(x, y)
+        else:
+            leader, number, b_ord, b_rep, tgt = _cl_batch(rng, n, NI, m, nxt)
+            a, b = gpu.prepare(leader, number, b_ord, b_rep, tgt), ref.prepare(leader, number, b_ord, b_rep, tgt)
+            assert a[0] == b[0] == 0
+            for x, y in zip(a[1:], b[1:]):
+                np.testing.assert_array_equal(x, y)
+            nacks += int((a[2] != 0).sum())
+    assert fatal > 0 and nacks > 0 and commits > 0
+    for r in range(n):
+        for inst in rng.choice(n * NI, size=min(200, n * NI), replace=False):
+            assert gpu.read_cmdlog(r, int(inst) // NI, int(inst) % NI) == ref.read_cmdlog(r, int(inst) // NI, int(inst) % NI)
+    # malformed batches: duplicate instance, proposer among its targets, no command log configured
+    one = np.zeros(2, np.int32)
+    assert gpu.accept(one, one, one, one, one, np.zeros(2, np.uint8))[0] == fa.FPX_EINVAL
+    assert gpu.accept([1], [1], [0], [1], [0], [0b010])[0] == fa.FPX_EINVAL
+    assert EPaxos(n, 8).accept([1], [1], [0], [1], [0], [0b001])[0] == fa.FPX_EINVAL
