@@ -58,7 +58,7 @@ def steady_values_torch(slot):
 METRIC = "committed log slots/sec at 1M slots \u00d7 256 replicas; 1/2/4/8-GPU scaling"
 
 
-# profiles/r01_hbm_mix.txt (1 x MI355X): pure read, pure write, copy, and this path's 1 read : 2 write mix
+# profiles/r01_hbm_mix.txt (1 x MI355X, bare streaming kernels): pure read, pure write, copy, and this path's 1 read : 2 write mix
 MEASURED_STREAM_GBS = {"read": 5871.4, "write": 5868.0, "copy": 5140.2, "mix_1r_2w": 5068.0}
 
 
@@ -483,7 +483,7 @@ def main():
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                 "traffic": traffic,
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command in an earlier profiled run "
-                                  "(profiles/traffic.json, profiles/r01_pmc_summary.md) -- not measured in this run",
+                                  "(profiles/traffic.json, profiles/r02_pmc_summary.md) -- not measured in this run",
                 "algorithmic_bytes_per_slot": bps, "slots_per_launch": slots_per_launch,
                 "avg_kernel_ms": kernel_ms / max(launches, 1), "launches_timed": launches,
                 # what bare streaming kernels reach on this chip (profiles/microbench/hbm_mix.hip, best of the
