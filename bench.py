@@ -433,8 +433,11 @@ def main():
     # the vote bitmaps behind the C ABI, collective time broken out
     replica_row = None
     if world > 1 and not replica_shard and args.replica_row_steps > 0:
-        replica_row = replica_axis_row(fa, dist, backend, dev, rank, world, local_rank, ballot_mode,
-                                       args.replica_row_steps, all_reduce)
+        try:
+            replica_row = replica_axis_row(fa, dist, backend, dev, rank, world, local_rank, ballot_mode,
+                                           args.replica_row_steps, all_reduce)
+        except Exception as e:  # the headline line must not be lost to a failure of the extra row
+            replica_row = {"error": "%s: %s" % (type(e).__name__, e)} if rank == 0 else None
 
     if rank == 0:
         bps = algorithmic_bytes_per_slot(ballot_mode)

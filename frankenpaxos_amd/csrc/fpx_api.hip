@@ -77,6 +77,10 @@ struct fpx_ctx {
   bool profiling = false;
   std::vector<hipEvent_t> ev;  // start/stop pairs
   size_t ev_used = 0;
+  // host-pointer K3 on big batches: upload / K3 / download of consecutive pieces overlap on three streams
+  hipStream_t up_stream = nullptr, down_stream = nullptr;
+  std::vector<hipEvent_t> pipe_ev;  // [2 * pieces]: uploaded, computed
+  int32_t index_base = 0;           // message index of the piece being launched (error reports are batch-relative)
   bool lazy_active = false;  // PER_SLOT: lazy Phase1a promises may be outstanding (k_phase2 runs its lazy-aware form)
   // K4: the proxy leader's noop-range tallies (two buffers: fpx_proxy_forget rehashes into the other one)
   RangeTable rt[2];
@@ -310,10 +314,12 @@ int enqueue_validate(fpx_ctx* ctx, Batch& b, bool check_round) {
 // K1 / K3 on one device run
 int enqueue_phase2(fpx_ctx* ctx, Batch& b, bool fused) {
   if (b.n == 0) return FPX_OK;
+  b.index_base = ctx->index_base;
   int rc = enqueue_validate(ctx, b, true);
   if (rc) return rc;
   const int grid = grid_for(ctx, b.n);
   b.chunk = chunk_for(ctx, b.n);
+  b.index_base = ctx->index_base;
   b.parity = (int32_t)(ctx->phase2_launches++ & 1u);  // every K1 / K3 launch is followed by its k_finalize
   const bool prof = ctx->profiling && ctx->ev_used + 2 <= ctx->ev.size();
   if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[ctx->ev_used], ctx->stream));
@@ -430,6 +436,10 @@ void free_state(fpx_ctx* ctx) {
   ctx->ev.clear();
   for (hipEvent_t e : ctx->cev) (void)hipEventDestroy(e);
   ctx->cev.clear();
+  for (hipEvent_t e : ctx->pipe_ev) (void)hipEventDestroy(e);
+  ctx->pipe_ev.clear();
+  if (ctx->up_stream) (void)hipStreamDestroy(ctx->up_stream);
+  if (ctx->down_stream) (void)hipStreamDestroy(ctx->down_stream);
   if (ctx->d_part.p) (void)hipFree(ctx->d_part.p);
   if (ctx->d_mine.p) (void)hipFree(ctx->d_mine.p);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -543,6 +553,127 @@ template <typename T>
 int d2h(fpx_ctx* ctx, T* dst, const DevBuf& b, size_t count) {
   if (dst && count) HIPCHK(ctx, hipMemcpyAsync(dst, b.p, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
   return FPX_OK;
+}
+
+
+// ---- host-pointer K3 helpers --------------------------------------------------------------------------------
+// the host-split replay of [from, n) of a staged batch (the slices are still in the staging buffers): cut into
+// runs on the host, launch them back to back, download that part of the outputs
+int host_fused_replay(fpx_ctx* ctx, int n, const int32_t* slot, const int32_t* round, bool has_target, int from,
+                      uint8_t* chosen, int32_t* chosen_round, int32_t* chosen_value, int32_t* nack_round) {
+  int32_t *d_slot = (int32_t*)ctx->d_slot.p, *d_round = (int32_t*)ctx->d_round.p, *d_value = (int32_t*)ctx->d_value.p;
+  uint64_t* d_target = has_target ? (uint64_t*)ctx->d_target.p : nullptr;
+  uint8_t* d_ch = (uint8_t*)ctx->d_u8.p;
+  int32_t *d_cr = (int32_t*)ctx->d_i32_a.p, *d_cv = (int32_t*)ctx->d_i32_b.p, *d_nr = (int32_t*)ctx->d_i32_c.p;
+  const int len_all = n - from;
+  int rc;
+  if ((rc = check_inputs(ctx, len_all, slot + from, round + from))) {
+    ctx->err_index += from;
+    return rc;
+  }
+  HostRun host_run(ctx);
+  std::vector<int> cuts;
+  split_runs(ctx, len_all, slot + from, round + from, true, &cuts);
+  for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+    const int lo = from + cuts[k], len = cuts[k + 1] - cuts[k];
+    ctx->index_base = lo;
+    rc = fpx_phase2_fused_dev(ctx, len, d_slot + lo, d_round + lo, d_value + lo,
+                              d_target ? d_target + (size_t)lo * 4 : nullptr, d_ch + lo, d_cr + lo, d_cv + lo, d_nr + lo);
+    ctx->index_base = 0;
+    if (rc) {
+      (void)hipStreamSynchronize(ctx->stream);
+      return rc;
+    }
+  }
+  const size_t cnt = (size_t)len_all;
+  if (chosen) HIPCHK(ctx, hipMemcpyAsync(chosen + from, d_ch + from, cnt, hipMemcpyDeviceToHost, ctx->stream));
+  if (chosen_round) HIPCHK(ctx, hipMemcpyAsync(chosen_round + from, d_cr + from, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (chosen_value) HIPCHK(ctx, hipMemcpyAsync(chosen_value + from, d_cv + from, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (nack_round) HIPCHK(ctx, hipMemcpyAsync(nack_round + from, d_nr + from, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+  return fetch_status(ctx);
+}
+
+// piece size of the pipelined host path.  OFF unless FPX_HOST_PIECE is set: measured on two boxes
+// (profiles/r02_host_path.txt) the three-stream pipeline buys nothing over upload -> K3 -> download in sequence --
+// 1.90-2.07 ms against 1.96 ms per 2^20 messages on the slow-PCIe box -- as in round 1: the host copies do not
+// overlap a kernel that saturates HBM on this stack.  At most 64 pieces.
+int host_piece(const fpx_ctx* ctx, int n) {
+  (void)ctx;
+  const char* e = getenv("FPX_HOST_PIECE");
+  if (!e || !*e) return n > 0 ? n : 1;
+  int piece = std::max(1024, atoi(e));
+  while ((long long)piece * 64 < n) piece <<= 1;
+  return piece;
+}
+
+// Big host batches: the three stages of the host-pointer K3 -- upload (12 B per message), the fused step, download
+// (13 B per message) -- run as a pipeline over pieces on three streams (opt-in, see host_piece).  Pieces are
+// separate device runs, launched in order on the context's stream: sequential semantics across pieces for free.
+// Range errors are found on the host BEFORE anything is launched (FPX_EINVAL => nothing applied, as ever); a run
+// -contract violation inside a piece aborts that piece and everything after it on the device, and the host-split
+// replay takes over from that piece's first message.
+int host_fused_pipelined(fpx_ctx* ctx, int n, const int32_t* slot, const int32_t* round, const int32_t* value_id,
+                         const uint64_t* target_mask, uint8_t* chosen, int32_t* chosen_round, int32_t* chosen_value,
+                         int32_t* nack_round) {
+  int rc;
+  if ((rc = check_inputs(ctx, n, slot, round))) return rc;
+  ctx->batch_increasing = ctx->batch_one_round = false;
+  if ((rc = grow(ctx, &ctx->d_slot, (size_t)n * 4))) return rc;
+  if ((rc = grow(ctx, &ctx->d_round, (size_t)n * 4))) return rc;
+  if ((rc = grow(ctx, &ctx->d_value, (size_t)n * 4))) return rc;
+  if (target_mask && (rc = grow(ctx, &ctx->d_target, (size_t)n * 32))) return rc;
+  const int piece = host_piece(ctx, n), pieces = (n + piece - 1) / piece;
+  if (!ctx->up_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+  if (!ctx->down_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
+  while (ctx->pipe_ev.size() < (size_t)2 * pieces) {
+    hipEvent_t e;
+    HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->pipe_ev.push_back(e);
+  }
+  int32_t *d_slot = (int32_t*)ctx->d_slot.p, *d_round = (int32_t*)ctx->d_round.p, *d_value = (int32_t*)ctx->d_value.p;
+  uint64_t* d_target = target_mask ? (uint64_t*)ctx->d_target.p : nullptr;
+  uint8_t* d_ch = (uint8_t*)ctx->d_u8.p;
+  int32_t *d_cr = (int32_t*)ctx->d_i32_a.p, *d_cv = (int32_t*)ctx->d_i32_b.p, *d_nr = (int32_t*)ctx->d_i32_c.p;
+  ctx->force_validate = true;
+  for (int k = 0; k < pieces && rc == FPX_OK; ++k) {
+    const int lo = k * piece, len = std::min(piece, n - lo);
+    const size_t c = (size_t)len;
+    hipEvent_t up = ctx->pipe_ev[2 * k], done = ctx->pipe_ev[2 * k + 1];
+    HIPCHK(ctx, hipMemcpyAsync(d_slot + lo, slot + lo, c * 4, hipMemcpyHostToDevice, ctx->up_stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_round + lo, round + lo, c * 4, hipMemcpyHostToDevice, ctx->up_stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_value + lo, value_id + lo, c * 4, hipMemcpyHostToDevice, ctx->up_stream));
+    if (target_mask)
+      HIPCHK(ctx, hipMemcpyAsync(d_target + (size_t)lo * 4, target_mask + (size_t)lo * 4, c * 32, hipMemcpyHostToDevice, ctx->up_stream));
+    HIPCHK(ctx, hipEventRecord(up, ctx->up_stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, up, 0));
+    ctx->index_base = lo;
+    rc = fpx_phase2_fused_dev(ctx, len, d_slot + lo, d_round + lo, d_value + lo, d_target ? d_target + (size_t)lo * 4 : nullptr,
+                              d_ch + lo, d_cr + lo, d_cv + lo, d_nr + lo);
+    ctx->index_base = 0;
+    if (rc) break;
+    HIPCHK(ctx, hipEventRecord(done, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->down_stream, done, 0));
+    if (chosen) HIPCHK(ctx, hipMemcpyAsync(chosen + lo, d_ch + lo, c, hipMemcpyDeviceToHost, ctx->down_stream));
+    if (chosen_round) HIPCHK(ctx, hipMemcpyAsync(chosen_round + lo, d_cr + lo, c * 4, hipMemcpyDeviceToHost, ctx->down_stream));
+    if (chosen_value) HIPCHK(ctx, hipMemcpyAsync(chosen_value + lo, d_cv + lo, c * 4, hipMemcpyDeviceToHost, ctx->down_stream));
+    if (nack_round) HIPCHK(ctx, hipMemcpyAsync(nack_round + lo, d_nr + lo, c * 4, hipMemcpyDeviceToHost, ctx->down_stream));
+  }
+  ctx->force_validate = false;
+  (void)hipStreamSynchronize(ctx->up_stream);
+  const hipError_t dsync = hipStreamSynchronize(ctx->down_stream);
+  if (rc) {
+    (void)hipStreamSynchronize(ctx->stream);
+    return rc;
+  }
+  rc = fetch_status(ctx);
+  if (dsync != hipSuccess) {
+    ctx->last_hip = (int)dsync;
+    return FPX_EHIP;
+  }
+  if (rc != FPX_EORDER) return rc;
+  // the piece that holds the first offender and everything after it applied nothing: replay from its first message
+  const int from = (ctx->err_index / piece) * piece;
+  return host_fused_replay(ctx, n, slot, round, target_mask != nullptr, from, chosen, chosen_round, chosen_value, nack_round);
 }
 
 }  // namespace
@@ -979,6 +1110,8 @@ int32_t fpx_phase2_fused(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int
   if ((rc = grow(ctx, &ctx->d_i32_a, (size_t)n * 4))) return rc;
   if ((rc = grow(ctx, &ctx->d_i32_b, (size_t)n * 4))) return rc;
   if ((rc = grow(ctx, &ctx->d_i32_c, (size_t)n * 4))) return rc;
+  if (n >= 2 * host_piece(ctx, n))
+    return host_fused_pipelined(ctx, n, slot, round, value_id, target_mask, chosen, chosen_round, chosen_value, nack_round);
   if ((rc = h2d(ctx, &ctx->d_slot, slot, n))) return rc;
   if ((rc = h2d(ctx, &ctx->d_round, round, n))) return rc;
   if ((rc = h2d(ctx, &ctx->d_value, value_id, n))) return rc;
@@ -994,6 +1127,7 @@ int32_t fpx_phase2_fused(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int
     if ((r2 = d2h(ctx, chosen_value, ctx->d_i32_b, (size_t)n))) return r2;
     return d2h(ctx, nack_round, ctx->d_i32_c, (size_t)n);
   };
+  int replay_from = 0;  // the host-split replay below covers [replay_from, n)
   {
     ctx->force_validate = true;  // also under FPX_F_TRUSTED: that flag is a promise about _dev batches only
     rc = fpx_phase2_fused_dev(ctx, n, d_slot, d_round, d_value, d_target, d_ch, d_cr, d_cv, d_nr);
@@ -1007,25 +1141,8 @@ int32_t fpx_phase2_fused(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int
     if (rc == FPX_EINVAL) return check_inputs(ctx, n, slot, round);  // the FIRST offender, for fpx_error_detail
     if (rc != FPX_EORDER) return rc;
   }
-  // the batch is not a single run: cut it on the host and replay (the staged copies are still there)
-  if ((rc = check_inputs(ctx, n, slot, round))) return rc;
-  HostRun host_run(ctx);
-  std::vector<int> cuts;
-  split_runs(ctx, n, slot, round, true, &cuts);
-  for (size_t k = 0; k + 1 < cuts.size(); ++k) {
-    const int lo = cuts[k], len = cuts[k + 1] - cuts[k];
-    rc = fpx_phase2_fused_dev(ctx, len, d_slot + lo, d_round + lo, d_value + lo,
-                              d_target ? d_target + (size_t)lo * 4 : nullptr, d_ch + lo, d_cr + lo, d_cv + lo, d_nr + lo);
-    if (rc) {
-      (void)hipStreamSynchronize(ctx->stream);
-      return rc;
-    }
-  }
-  if ((rc = download())) {
-    (void)hipStreamSynchronize(ctx->stream);
-    return rc;
-  }
-  return fetch_status(ctx);
+  return host_fused_replay(ctx, n, slot, round, target_mask != nullptr, replay_from, chosen, chosen_round, chosen_value,
+                           nack_round);
 }
 
 int32_t fpx_proxy_open(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round, const int32_t* value_id,

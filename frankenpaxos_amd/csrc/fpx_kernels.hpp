@@ -125,6 +125,7 @@ struct Batch {
   int32_t parity;          // K1 / K3 launch counter & 1: which half of part_cnt / part_all this launch uses
   int32_t check_round;     // validate: enforce one round per group (ACCEPTOR ballot mode)
   int32_t chunk;           // K1 / K3 at G = 64: messages per wavefront (4 .. FPX_CHUNK)
+  int32_t index_base;      // added to the message index an error reports (host batches launched in pieces)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -309,12 +310,12 @@ __global__ void __launch_bounds__(256) k_validate(const Geom g, const State st, 
   if (i >= b.n) return;
   const int s = b.slot[i], r = b.round ? b.round[i] : 0;
   if (s < 0 || s >= g.S || r < 0 || r > MAX_ROUND) {
-    report_abort(st, 1 /*FPX_EINVAL*/, i, s, r);
+    report_abort(st, 1 /*FPX_EINVAL*/, i + b.index_base, s, r);
     return;
   }
   // (1) slots pairwise distinct within the run
   const uint32_t old = atomicExch(&st.stamp[s], b.run_id);
-  if (old == b.run_id) report_abort(st, 6 /*FPX_EORDER*/, i, s, r);
+  if (old == b.run_id) report_abort(st, 6 /*FPX_EORDER*/, i + b.index_base, s, r);
   // (2) one round per acceptor group within the run
   if (b.check_round) {
     // every message of a group looks at the same word, and same-address requests serialise in one L2 channel
@@ -324,7 +325,7 @@ __global__ void __launch_bounds__(256) k_validate(const Geom g, const State st, 
     bool ask = true;
     if (g.ngroups == 1) {
       const int r0 = __builtin_amdgcn_readfirstlane(r);
-      if (r != r0) report_abort(st, 6, i, s, r);
+      if (r != r0) report_abort(st, 6, i + b.index_base, s, r);
       ask = __builtin_amdgcn_readfirstlane(i) == i;  // the first active lane
     }
     if (ask) {
@@ -333,7 +334,7 @@ __global__ void __launch_bounds__(256) k_validate(const Geom g, const State st, 
         cur = atomicCAS(rr, -1, r);
         if (cur == -1) cur = r;
       }
-      if (cur != r) report_abort(st, 6, i, s, r);
+      if (cur != r) report_abort(st, 6, i + b.index_base, s, r);
     }
   }
 }
@@ -465,7 +466,7 @@ __global__ void __launch_bounds__(256)
         }
       }
       mydeliver = !dup && myway >= 0;  // a known (slot, round) is ignored and NOT forwarded
-      if (!dup && myway < 0) report(st, 5 /*FPX_ECAPACITY*/, m, myslot, myround);
+      if (!dup && myway < 0) report(st, 5 /*FPX_ECAPACITY*/, m + b.index_base, myslot, myround);
     }
 
     if constexpr (TGT) {

@@ -664,3 +664,34 @@ def test_phase1a_dev_is_asynchronous_and_equal(fa, oracle):
             np.testing.assert_array_equal(nr.cpu().numpy(), nr_r)
         W.assert_same_state(gpu, ref, tally_slots=range(0, S, 211))
         gpu.set_stream(None)
+
+
+@pytest.mark.parametrize("ballot_mode", [0, 1])
+def test_pipelined_host_batches(fa, oracle, ballot_mode, monkeypatch):
+    """big host batches run as a 3-stream pipeline over pieces (upload / K3 / download overlap).  Forced here at a
+    small piece size: a well-formed batch, a batch with range errors (FPX_EINVAL: nothing applied), and batches
+    that break the run contract in a LATER piece (duplicate slots, a round change) -- the pieces before it stay
+    applied, the host-split replay takes over from the offending piece, results equal message-at-a-time delivery"""
+    monkeypatch.setenv("FPX_HOST_PIECE", "1024")
+    S, R = 1 << 15, 256
+    gpu, ref = both(fa, oracle, num_slots=S, num_replicas=R, f=127, ballot_mode=ballot_mode, tally_ways=8)
+    rng = np.random.default_rng(17 + ballot_mode)
+    n = 9000
+    slot = rng.permutation(S)[:n].astype(np.int32)
+    rnd = np.zeros(n, np.int32)
+    val = rng.integers(0, 1 << 30, n).astype(np.int32)
+    tgt = W.bits_from_bool(W.random_subsets(rng, n, R, 100, R))
+    check(gpu, ref, [("phase1a", 0, 0, 0, None), ("fused", slot, rnd, val, tgt)], tally_slots=range(0, S, 997))
+    bad = slot.copy()
+    bad[7000] = S + 5
+    before = gpu.state_digest()
+    a, b = gpu.phase2_fused(bad, rnd + 1, val), ref.phase2_fused(bad, rnd + 1, val)
+    assert a[0] == b[0] == fa.FPX_EINVAL and gpu.error_detail() == ref.error_detail() == (7000, S + 5, 1)
+    np.testing.assert_array_equal(gpu.state_digest(), before)
+    dup = slot.copy()
+    dup[5000:5050] = dup[4000:4050]                      # duplicates inside piece 4, and of piece-3 slots
+    r2 = rnd + 1
+    r2[8000:] = 2                                         # and a round change further on
+    check(gpu, ref, [("fused", dup, r2, val, None), ("fused", slot[::-1].copy(), rnd + 3, val, tgt)],
+          tally_slots=range(0, S, 997))
+    monkeypatch.delenv("FPX_HOST_PIECE")
