@@ -1,6 +1,9 @@
-"""Committed golden fixtures (tests/golden/*.npz, generated by tests/golden/make_golden.py from the
-CPU oracle -- the JVM reference cannot run here): the oracle must keep reproducing them (CPU), and
-the HIP path must match them bit for bit (GPU)."""
+"""Committed regression fixtures (tests/golden/*.npz): OUTPUTS OF THE CPU ORACLE frozen by
+tests/golden/make_golden.py -- NOT reference vectors (the JVM reference cannot run here, and it holds no
+known-answer test for the vote / tally: SURVEY.md F9).  The oracle must keep reproducing them (CPU), and the
+HIP path must match them bit for bit (GPU).  The vectors that DO come from the reference are in
+tests/test_oracle_golden.py (quorums, round system, BufferMap, TopOne, popularItems, conflict index),
+tests/test_epaxos.py (IntPrefixSet properties) and tests/golden/wire_vectors.json (protobuf bytes)."""
 import os
 
 import numpy as np
