@@ -394,7 +394,7 @@ int init_state(fpx_ctx* ctx) {
   HIPCHK(ctx, hipMemsetAsync(st.lz_round, 0xFF, (nsc + 4) * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.lz_from, 0, (nsc + 4) * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.max_ballot, 0xFF, (nsc + 4) * 4, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(st.p1, 0, ((size_t)4 * g.R + 4) * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.p1, 0, ((size_t)4 * g.R + 8) * 4, ctx->stream));
   ctx->lazy_active = false;
   HIPCHK(ctx, hipMemsetAsync(st.run_round, 0xFF, (size_t)g.ngroups * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.status, 0, 8 * 4, ctx->stream));
@@ -836,7 +836,7 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
   if ((rc = dalloc(ctx, &st.lz_round, nsc + 4))) return fail(rc);
   if ((rc = dalloc(ctx, &st.lz_from, nsc + 4))) return fail(rc);
   if ((rc = dalloc(ctx, &st.max_ballot, nsc + 4))) return fail(rc);
-  if ((rc = dalloc(ctx, &st.p1, (size_t)4 * g.R + 4))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.p1, (size_t)4 * g.R + 8))) return fail(rc);
   if ((rc = dalloc(ctx, &st.run_round, (size_t)g.ngroups))) return fail(rc);
   if ((rc = dalloc(ctx, &st.status, (size_t)8))) return fail(rc);
   ctx->g.part_rows = ctx->max_grid;
@@ -1209,12 +1209,11 @@ static int enqueue_phase1a(fpx_ctx* ctx, int group, int round, int watermark, co
     hipLaunchKernelGGL(k_phase1a_scalar, gr, blk, 0, ctx->stream, ctx->g, ctx->st, group, round, d_tgt, d_out);
   } else {
     // O(R) unless the Phase1a is stale for some acceptor or an older lazy promise has to be made explicit below
-    // the new watermark: k_p1a_sweep returns at once in the common case
+    // the new watermark: k_p1a_sweep returns at once in the common case; when it does sweep, its last block writes
+    // the swept acceptors' promises (those none of whose cells was ahead)
     hipLaunchKernelGGL(k_p1a_decide, gr, blk, 0, ctx->stream, ctx->g, ctx->st, group, round, watermark, d_tgt, d_out);
     hipLaunchKernelGGL(k_p1a_sweep, dim3(ctx->num_cus * 2), dim3(256), 0, ctx->stream, ctx->g, ctx->st, group, round,
                        watermark, d_out);
-    // promised = the targeted acceptors none of whose cells was ahead
-    hipLaunchKernelGGL(k_phase1a_perslot_finish, gr, blk, 0, ctx->stream, ctx->g, ctx->st, d_tgt, d_out);
     ctx->lazy_active = true;
   }
   if ((rc = launch_check(ctx))) return rc;

@@ -946,35 +946,44 @@ __global__ void __launch_bounds__(256) k_phase1a_scalar(const Geom g, const Stat
 // (a stale Phase1a) the acceptor's column is checked cell by cell (mode 2).  k_p1a_sweep does that work and
 // returns at once when no acceptor asked for any.
 enum { P1_MODE = 0, P1_A = 1, P1_B = 2, P1_C = 3 };
-__global__ void k_p1a_decide(const Geom g, const State st, int group, int round, int watermark, const uint64_t* target,
-                             uint64_t* out) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < 8) out[r] = 0ull;  // (one block: R <= 256) the sweep ORs nack bits in, the finish kernel the promises
-  if (r >= g.R) return;
-  int32_t* mode = st.p1 + P1_MODE * g.R;
-  mode[r] = 0;
-  const int bit = g.base + r;
-  if (target && !((target[bit >> 6] >> (bit & 63)) & 1ull)) return;
-  const size_t e = (size_t)group * g.R + r;
-  const int wm = watermark < 0 ? 0 : watermark;
-  const int lr = st.lz_round[e], lf = st.lz_from[e];
-  if (st.max_ballot[e] <= round) {
-    if (lr >= 0 && wm > lf) {  // the cells of [lf, wm) keep the older promise: make it explicit there
-      mode[r] = 1;
-      st.p1[P1_A * g.R + r] = lf, st.p1[P1_B * g.R + r] = wm, st.p1[P1_C * g.R + r] = lr;
-      st.p1[4 * g.R] = 1;
+// ONE block (R <= 256).  Writes the reply bitmaps itself for every acceptor that needs no sweep: out[0..3] promised
+// bits, out[4..7] nack bits (zero here; a stale Phase1a's Nacks and promises come from the tail of k_p1a_sweep).
+__global__ void __launch_bounds__(256) k_p1a_decide(const Geom g, const State st, int group, int round, int watermark,
+                                                    const uint64_t* target, uint64_t* out) {
+  __shared__ unsigned long long bits[4];
+  const int r = threadIdx.x;
+  if (r < 4) bits[r] = 0ull;
+  __syncthreads();
+  if (r < g.R) {
+    int32_t* mode = st.p1 + P1_MODE * g.R;
+    mode[r] = 0;
+    const int bit = g.base + r;
+    if (!target || ((target[bit >> 6] >> (bit & 63)) & 1ull)) {
+      const size_t e = (size_t)group * g.R + r;
+      const int wm = watermark < 0 ? 0 : watermark;
+      const int lr = st.lz_round[e], lf = st.lz_from[e];
+      if (st.max_ballot[e] <= round) {
+        if (lr >= 0 && wm > lf) {  // the cells of [lf, wm) keep the older promise: make it explicit there
+          mode[r] = 1;
+          st.p1[P1_A * g.R + r] = lf, st.p1[P1_B * g.R + r] = wm, st.p1[P1_C * g.R + r] = lr;
+          st.p1[4 * g.R] = 1;
+        }
+        st.lz_round[e] = round, st.lz_from[e] = wm;
+        st.max_ballot[e] = round;
+        atomicOr(&bits[bit >> 6], 1ull << (bit & 63));  // promised: nothing of this acceptor was ahead
+      } else {
+        mode[r] = 2;  // possibly stale: its column is checked cell by cell
+        st.p1[4 * g.R] = 1;
+      }
     }
-    st.lz_round[e] = round, st.lz_from[e] = wm;
-    st.max_ballot[e] = round;
-  } else {
-    mode[r] = 2;
-    st.p1[4 * g.R] = 1;
   }
+  __syncthreads();
+  if (r < 4) out[r] = bits[r], out[4 + r] = 0ull;
 }
 
 __global__ void __launch_bounds__(256) k_p1a_sweep(const Geom g, const State st, int group, int round, int watermark,
                                                    uint64_t* out) {
-  if (st.p1[4 * g.R] == 0) return;
+  if (st.p1[4 * g.R] == 0) return;  // the common case: nothing to sweep
   const int32_t* mode = st.p1 + P1_MODE * g.R;
   const int wm = watermark < 0 ? 0 : watermark;
   const size_t ncell = (size_t)g.S * g.RS;
@@ -1003,6 +1012,21 @@ __global__ void __launch_bounds__(256) k_p1a_sweep(const Geom g, const State st,
       }
     }
   }
+  // the block that finishes last: the swept acceptors promise unless one of their cells was ahead; re-arm the flag
+  __shared__ int last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(&st.p1[4 * g.R + 1], 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  const int r = threadIdx.x;
+  if (r < g.R && mode[r] == 2) {
+    const int bit = g.base + r;
+    const unsigned long long nack = __hip_atomic_load((unsigned long long*)&out[4 + (bit >> 6)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!((nack >> (bit & 63)) & 1ull)) atomicOr((unsigned long long*)&out[bit >> 6], 1ull << (bit & 63));
+  }
+  if (r == 0) st.p1[4 * g.R] = 0, st.p1[4 * g.R + 1] = 0;
 }
 
 // every outstanding lazy promise written into the cells it covers, the records cleared (readback / digests /
@@ -1020,16 +1044,6 @@ __global__ void __launch_bounds__(256) k_lazy_flush(const Geom g, const State st
 __global__ void k_lazy_clear(const Geom g, const State st) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < g.ngroups * g.R) st.lz_round[e] = -1, st.lz_from[e] = 0;
-}
-
-__global__ void k_phase1a_perslot_finish(const Geom g, const State st, const uint64_t* target, uint64_t* out) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r == 0) st.p1[4 * g.R] = 0;
-  if (r >= g.R) return;
-  const int bit = g.base + r;
-  const bool tgt = !target || ((target[bit >> 6] >> (bit & 63)) & 1ull);
-  const bool nck = (out[4 + (bit >> 6)] >> (bit & 63)) & 1ull;
-  if (tgt && !nck) atomicOr((unsigned long long*)&out[bit >> 6], 1ull << (bit & 63));
 }
 
 // ------------------------------------------------------------------------------------------------
