@@ -49,6 +49,11 @@ struct EpxState {
   uint32_t* cl_stamp;   // [n * num_instances]  run id: instances of one batch must be distinct
 };
 
+#ifndef FPX_RS_ITEMS
+#define FPX_RS_ITEMS 16  // 64-element steps per wavefront tile; 8 / 16 / 32 / 64 measured 0.390 / 0.380 / 0.379 / 0.418 ms per tick
+#endif
+#define FPX_RS_ITEMS_V FPX_RS_ITEMS
+
 struct EpxBatch {
   int m;
   const int32_t* leader;
@@ -136,14 +141,12 @@ __global__ void __launch_bounds__(256) k_epx_keys(const EpxState st, const EpxBa
 // ---- stable LSD radix sort, 8-bit digits, all replicas in one launch (blockIdx.y = replica) ------------
 // A wavefront owns a tile of RS_TILE consecutive elements, so walking the tile 64 at a time in lane order
 // is the input order: ranking equal digits by (tile, step, lane) keeps the sort stable.
-#ifndef FPX_RS_ITEMS
-#define FPX_RS_ITEMS 16  // 64-element steps per wavefront tile; 8 / 16 / 32 / 64 measured 0.390 / 0.380 / 0.379 / 0.418 ms per tick
-#endif
 constexpr int RS_ITEMS = FPX_RS_ITEMS;
 constexpr int RS_TILE = 64 * RS_ITEMS;
 
 struct RsArgs {
   int m, tiles, shift;
+  int width;       // digit bits of this pass (<= 8): the key bits are split evenly over the passes, fewer buckets = longer runs
   const uint2* src;  // [n][m] (key word, payload)
   uint2* dst;
   uint32_t* hist;  // [n][256][tiles] per-tile digit counts -> exclusive offsets within the digit
@@ -188,7 +191,7 @@ __global__ void __launch_bounds__(256) k_rs_hist(const RsArgs a) {
   }
 #pragma unroll
   for (int it = 0; it < RS_ITEMS; ++it)
-    if (tile * RS_TILE + it * 64 + lane < a.m) atomicAdd(&h[w][(x[it] >> a.shift) & 255u], 1u);
+    if (tile * RS_TILE + it * 64 + lane < a.m) atomicAdd(&h[w][(x[it] >> a.shift) & ((1u << a.width) - 1u)], 1u);
   for (int j = lane; j < 256; j += 64) a.hist[((size_t)r * 256 + j) * a.tiles + tile] = h[w][j];
 }
 
@@ -250,14 +253,22 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const RsArgs a) {
   const uint2* src = a.src + (size_t)r * a.m;
   uint2* dst = a.dst + (size_t)r * a.m;
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  // all the tile's loads in flight before the ranking starts (the ranking loop is a chain of ballots, LDS updates
+  // and wave barriers: a load inside it is a full memory round trip per 64 elements)
+  uint2 kvs[RS_ITEMS];
+#pragma unroll
+  for (int it = 0; it < RS_ITEMS; ++it) {
+    const int idx = tile * RS_TILE + it * 64 + lane;
+    kvs[it] = idx < a.m ? src[idx] : make_uint2(0u, 0u);
+  }
+#pragma unroll
   for (int it = 0; it < RS_ITEMS; ++it) {
     const int idx = tile * RS_TILE + it * 64 + lane;
     const bool valid = idx < a.m;
-    const uint2 kv = valid ? src[idx] : make_uint2(0u, 0u);
-    const uint32_t dg = (kv.x >> a.shift) & 255u;
+    const uint2 kv = kvs[it];
+    const uint32_t dg = (kv.x >> a.shift) & ((1u << a.width) - 1u);
     unsigned long long peers = __ballot(valid);
-#pragma unroll
-    for (int bit = 0; bit < 8; ++bit) {
+    for (int bit = 0; bit < a.width; ++bit) {
       const bool on = (dg >> bit) & 1u;
       const unsigned long long bb = __ballot(on);
       peers &= on ? bb : ~bb;
@@ -306,14 +317,23 @@ __global__ void __launch_bounds__(256) k_epx_scan(const EpxState st, const EpxBa
   int ng[N], ns[N];  // this tick's puts alone: what the commit teaches the other replicas
 #pragma unroll
   for (int l = 0; l < N; ++l) ng[l] = 0, ns[l] = 0;
+  // the next chunk's sort pair and instance number are requested before this chunk is scanned: a segment is ~13
+  // dependent round trips otherwise (pair -> number gather -> row store)
+  uint2 kv_next = (lo + lane < hi) ? kvs[lo + lane] : make_uint2(0u, 0u);
+  int num_next = (lo + lane < hi) ? b.number[kv_next.y] : 0;
   for (int base = lo; base < hi; base += 64) {
     const int p = base + lane;
     const bool valid = p < hi;
-    const uint2 kv = valid ? kvs[p] : make_uint2(0u, 0u);
+    const uint2 kv = kv_next;
+    const int id1 = num_next + 1;  // TopOne.put: max(.., id + 1), util/TopOne.scala:12-15
+    if (base + 64 < hi) {
+      const int pn = base + 64 + lane;
+      kv_next = pn < hi ? kvs[pn] : make_uint2(0u, 0u);
+      num_next = pn < hi ? b.number[kv_next.y] : 0;
+    }
     const int i = (int)kv.y;
     const int L = (int)(kv.x >> EPX_LEADER_SHIFT);
     const bool t = (kv.x >> EPX_SET_SHIFT) & 1u;
-    const int id1 = b.number[i] + 1;  // TopOne.put: max(.., id + 1), util/TopOne.scala:12-15
     int dep[NP];
 #pragma unroll
     for (int l = 0; l < NP; ++l) dep[l] = 0;
@@ -345,10 +365,29 @@ __global__ void __launch_bounds__(256) k_epx_scan(const EpxState st, const EpxBa
 }
 
 template <int N>
+__device__ __forceinline__ void epx_decide_one(const EpxState& st, const EpxBatch& b, int i, int* out_deps, int* out_ldeps);
+
+// one thread per command; the n-wide dependency rows leave through LDS as contiguous lines (m x n ints written
+// by 256 threads with a stride of n ints were 5 strided store instructions per wave)
+template <int N>
 __global__ void __launch_bounds__(256) k_epx_decide(const EpxState st, const EpxBatch b) {
+  __shared__ int out_deps[256 * N], out_ldeps[256 * N];
   if (st.status[0] != 0) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= b.m) return;
+  if (i < b.m) epx_decide_one<N>(st, b, i, out_deps, out_ldeps);
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * blockDim.x * N;
+  const size_t end = (size_t)b.m * N;
+  for (int k = threadIdx.x; k < 256 * N; k += 256) {
+    if (base + k < end) {
+      if (b.deps) b.deps[base + k] = out_deps[k];
+      if (b.leader_deps) b.leader_deps[base + k] = out_ldeps[k];
+    }
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void epx_decide_one(const EpxState& st, const EpxBatch& b, int i, int* out_deps, int* out_ldeps) {
   const int L = b.leader[i];
   const unsigned mask = b.resp_mask[i];
   constexpr int NP = ConfRow<N>::NP;
@@ -412,8 +451,8 @@ __global__ void __launch_bounds__(256) k_epx_decide(const EpxState st, const Epx
     const int w = all_equal ? first[l] : uni[l];
     const bool hole = l == L && w > x;
     const bool lhole = l == L && D[l] > x;
-    if (b.deps) b.deps[(size_t)i * N + l] = hole ? x : w;
-    if (b.leader_deps) b.leader_deps[(size_t)i * N + l] = lhole ? x : D[l];
+    out_deps[threadIdx.x * N + l] = hole ? x : w;
+    out_ldeps[threadIdx.x * N + l] = lhole ? x : D[l];
     if (l == L && b.own_values_end) {
       b.own_values_end[(size_t)i * 2] = hole ? w : 0;
       b.own_values_end[(size_t)i * 2 + 1] = lhole ? D[l] : 0;
@@ -803,18 +842,22 @@ int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, co
   b.tick = (int32_t*)e->tick.p;
   b.seg = (int32_t*)e->seg.p, b.conf = (int32_t*)e->conf.p;
   b.fast = d_fast, b.deps = d_deps, b.leader_deps = d_leader_deps, b.own_values_end = d_own_values_end;
-  hipLaunchKernelGGL(k_epx_keys, dim3((m + 255) / 256), dim3(256), 0, e->stream, e->st, b);
   // stable LSD radix sort on the key bits only (the sequence already is in delivery order)
   unsigned bits = 1;
   while ((1u << bits) <= (unsigned)e->st.num_keys) ++bits;
+  const unsigned passes = (bits + 7) / 8, width = (bits + passes - 1) / passes;
   RsArgs a;
   a.m = m, a.tiles = (m + RS_TILE - 1) / RS_TILE;
   if ((rc = grow(e, &e->tmp, ((size_t)n * 256 * a.tiles + (size_t)n * 256) * 4))) return rc;
   a.hist = (uint32_t*)e->tmp.p, a.tot = a.hist + (size_t)n * 256 * a.tiles;
+  // (counting the first pass's histogram in k_epx_keys with global atomics was tried: 5 M atomics on 327 k counters
+  // took 450 us against 22 us for the histogram kernel)
+  hipLaunchKernelGGL(k_epx_keys, dim3((m + 255) / 256), dim3(256), 0, e->stream, e->st, b);
   uint2* buf[2] = {b.kv, b.kv_sorted};
   int cur = 0;
-  for (unsigned shift = 0; shift < bits; shift += 8, cur ^= 1) {
+  for (unsigned shift = 0; shift < bits; shift += width, cur ^= 1) {
     a.shift = (int)shift;
+    a.width = (int)width;
     a.rank = shift == 0 ? d_rank : nullptr;
     a.status = e->st.status;
     a.src = buf[cur], a.dst = buf[cur ^ 1];
