@@ -71,6 +71,7 @@ struct fpx_ctx {
   // kernel timing (fpx_profile_*)
   void* slab = nullptr;  // vote_round | vote_value | ballot
   uint32_t phase2_launches = 0;
+  uint32_t launch_seq = 0;  // stamps the partial-maxima rows of a K1 / K3 launch (never 0 in a row that counts)
   bool batch_increasing = false, batch_one_round = false;  // check_inputs' findings about the current host batch
   bool force_validate = false;  // host-pointer K3's optimistic whole-batch run is validated even under FPX_F_TRUSTED
   bool host_validated = false;  // set while a host entry point drives runs it cut itself (split_runs)
@@ -321,6 +322,8 @@ int enqueue_phase2(fpx_ctx* ctx, Batch& b, bool fused) {
   b.chunk = chunk_for(ctx, b.n);
   b.index_base = ctx->index_base;
   b.parity = (int32_t)(ctx->phase2_launches++ & 1u);  // every K1 / K3 launch is followed by its k_finalize
+  if (++ctx->launch_seq == 0) ctx->launch_seq = 1;
+  b.launch_seq = ctx->launch_seq;
   const bool prof = ctx->profiling && ctx->ev_used + 2 <= ctx->ev.size();
   if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[ctx->ev_used], ctx->stream));
   launch_phase2(ctx, b, fused, grid);
@@ -331,8 +334,9 @@ int enqueue_phase2(fpx_ctx* ctx, Batch& b, bool fused) {
     ctx->ev_used += 2;
   }
   const int ntab = ctx->g.ngroups * ctx->g.R;
-  hipLaunchKernelGGL(k_finalize, dim3((ntab + 63) / 64, FINALIZE_SLICES), dim3(256), 0, ctx->stream, ctx->g, ctx->st,
-                     (int)b.parity);
+  const int slices = std::max(FINALIZE_SLICES, std::min(256, grid / 32));  // ~8 partial rows per wavefront
+  hipLaunchKernelGGL(k_finalize, dim3((ntab + 63) / 64, slices), dim3(256), 0, ctx->stream, ctx->g, ctx->st,
+                     (int)b.parity, grid, b.launch_seq);
   return launch_check(ctx);
 }
 
@@ -398,7 +402,7 @@ int init_state(fpx_ctx* ctx) {
   ctx->lazy_active = false;
   HIPCHK(ctx, hipMemsetAsync(st.run_round, 0xFF, (size_t)g.ngroups * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.status, 0, 8 * 4, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(st.part_cnt, 0, 2 * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.part_stamp, 0, (size_t)ctx->max_grid * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.part_all, 0xFF, (size_t)2 * 64 * PART_ALL_STRIDE * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.log_value, 0xFF, (size_t)g.S * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.log_present, 0, (size_t)g.S, ctx->stream));
@@ -422,7 +426,7 @@ void free_state(fpx_ctx* ctx) {
   State& st = ctx->st;
   void* ps[] = {st.promised, st.max_voted, ctx->slab, st.pl_key, st.pl_value,
                 st.pl_bits,  st.stamp,     st.run_round,  st.status,     st.part,
-                st.log_value, st.log_present, st.log_scalars, st.part_cnt, st.part_all,
+                st.log_value, st.log_present, st.log_scalars, st.part_stamp, st.part_all,
                 st.row_voted, st.lz_round, st.lz_from, st.max_ballot, st.p1,
                 ctx->rt[0].key, ctx->rt[0].bits, ctx->rt[0].owner, ctx->rt[0].count,
                 ctx->rt[1].key, ctx->rt[1].bits, ctx->rt[1].owner, ctx->rt[1].count, ctx->d_rng.p};
@@ -841,7 +845,7 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
   if ((rc = dalloc(ctx, &st.status, (size_t)8))) return fail(rc);
   ctx->g.part_rows = ctx->max_grid;
   if ((rc = dalloc(ctx, &st.part, (size_t)ctx->max_grid * 2 * ntab))) return fail(rc);
-  if ((rc = dalloc(ctx, &st.part_cnt, (size_t)2))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.part_stamp, (size_t)ctx->max_grid))) return fail(rc);
   if ((rc = dalloc(ctx, &st.part_all, (size_t)2 * 64 * PART_ALL_STRIDE))) return fail(rc);
   if ((rc = dalloc(ctx, &st.log_value, (size_t)g.S))) return fail(rc);
   if ((rc = dalloc(ctx, &st.log_present, (size_t)g.S))) return fail(rc);

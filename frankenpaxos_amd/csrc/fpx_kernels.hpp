@@ -100,7 +100,8 @@ struct State {
   int32_t* run_round;   // [ngroups]      the single round of the current run per group (-1 = none)
   int32_t* status;      // [8]
   int32_t* part;        // [grid][2][ngroups*R] per-workgroup maxima rows (accepted round, voted slot)
-  int32_t* part_cnt;    // [2]   rows of `part` claimed by the current launch, per launch parity
+  uint32_t* part_stamp; // [grid] the launch (Batch::launch_seq) that wrote row b of `part`: a workgroup that used the
+                        //        tables writes row blockIdx.x -- no claiming counter (8192 same-address atomics were 65 us)
   int32_t* part_all;    // [2][64][PART_ALL_STRIDE] whole-group maxima (round, slot), 64 lines, per launch parity
   int32_t* log_value;   // [S]  the replica's log (BufferMap), -1 where absent
   uint8_t* log_present; // [S]
@@ -122,7 +123,8 @@ struct Batch {
   uint8_t* is_new;         // k_open
   const uint8_t* mask;     // k_log_ingest: which messages are Chosen (null = all)
   uint32_t run_id;
-  int32_t parity;          // K1 / K3 launch counter & 1: which half of part_cnt / part_all this launch uses
+  int32_t parity;          // K1 / K3 launch counter & 1: which half of part_all this launch uses
+  uint32_t launch_seq;     // K1 / K3 launch counter (never 0): stamps the rows of `part` this launch writes
   int32_t check_round;     // validate: enforce one round per group (ACCEPTOR ballot mode)
   int32_t chunk;           // K1 / K3 at G = 64: messages per wavefront (4 .. FPX_CHUNK)
   int32_t index_base;      // added to the message index an error reports (host batches launched in pieces)
@@ -767,13 +769,10 @@ __global__ void __launch_bounds__(256)
     atomicMax(&pa[0], blk_flag[2]);
     atomicMax(&pa[1], blk_flag[3]);
   }
-  if (blk_flag[0]) {
-    if (threadIdx.x == 0) blk_flag[1] = atomicAdd(&st.part_cnt[par], 1);
-    __syncthreads();
-    if (blk_flag[1] < g.part_rows) {  // always true unless a finalize launch was lost: never write out of bounds
-      int32_t* prow = st.part + (size_t)blk_flag[1] * 2 * ntab;
-      for (int i = threadIdx.x; i < 2 * ntab; i += blockDim.x) prow[i] = tab_pr[i];
-    }
+  if (blk_flag[0] && (int)blockIdx.x < g.part_rows) {  // (the grid never exceeds part_rows: never write out of bounds)
+    int32_t* prow = st.part + (size_t)blockIdx.x * 2 * ntab;
+    for (int i = threadIdx.x; i < 2 * ntab; i += blockDim.x) prow[i] = tab_pr[i];
+    if (threadIdx.x == 0) st.part_stamp[blockIdx.x] = b.launch_seq;
   }
 }
 
@@ -783,18 +782,17 @@ __global__ void __launch_bounds__(256)
 // ------------------------------------------------------------------------------------------------
 // grid = (ceil(ntab / 64), FINALIZE_SLICES): blockIdx.y strides over the rows of the partial table,
 // the 4 waves of a block stride within that; one atomicMax per (entry, blockIdx.y) that improves.
-constexpr int FINALIZE_SLICES = 8;
-__global__ void __launch_bounds__(256) k_finalize(const Geom g, const State st, int par) {
+constexpr int FINALIZE_SLICES = 8;  // at least; the launch uses more for big grids (about 8 rows per wavefront)
+__global__ void __launch_bounds__(256) k_finalize(const Geom g, const State st, int par, int grid, uint32_t seq) {
   __shared__ int32_t red[2][4][64];
   // the buffers of the OTHER parity are used by the next launch: clear them here, whatever happens
   if (blockIdx.x == 0 && blockIdx.y == 0) {
-    if (threadIdx.x == 0) st.part_cnt[par ^ 1] = 0;
     if (threadIdx.x < 128)
       st.part_all[((size_t)(par ^ 1) * 64 + (threadIdx.x >> 1)) * PART_ALL_STRIDE + (threadIdx.x & 1)] = -1;
   }
   if (st.status[ST_ABORT] != 0) return;
   const int ntab = g.ngroups * g.R;
-  const int nblocks = st.part_cnt[par] < g.part_rows ? st.part_cnt[par] : g.part_rows;
+  const int nblocks = grid < g.part_rows ? grid : g.part_rows;
   const int e = blockIdx.x * 64 + (threadIdx.x & 63);
   const int slice = threadIdx.x >> 6;
   int pr = -1, mvs = -1;
@@ -808,11 +806,13 @@ __global__ void __launch_bounds__(256) k_finalize(const Geom g, const State st, 
   }
   if (e < ntab) {
 #pragma unroll 4
-    for (int bl = blockIdx.y * 4 + slice; bl < nblocks; bl += 4 * FINALIZE_SLICES) {
+    for (int bl = blockIdx.y * 4 + slice; bl < nblocks; bl += 4 * (int)gridDim.y) {
+      // stamp and row are loaded together (no dependent chain); a row of another launch is simply not used
+      const bool mine = st.part_stamp[bl] == seq;  // that workgroup of THIS launch used the tables
       const int32_t* prow = st.part + (size_t)bl * 2 * ntab;
       const int a = prow[e], c = prow[ntab + e];
-      pr = a > pr ? a : pr;
-      mvs = c > mvs ? c : mvs;
+      pr = (mine && a > pr) ? a : pr;
+      mvs = (mine && c > mvs) ? c : mvs;
     }
   }
   red[0][slice][threadIdx.x & 63] = pr;
