@@ -117,6 +117,8 @@ SIGNATURES = {
     "fpx_epx_prepare": (C.c_int32, [VP, C.c_int32] + [VP] * 12),
     "fpx_epx_accept": (C.c_int32, [VP, C.c_int32] + [VP] * 11),
     "fpx_epx_read_cmdlog": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, VP]),
+    "fpx_epx_read_cmdlog_deps": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, VP, VP]),
+    "fpx_epx_handle_preaccept": (C.c_int32, [VP, C.c_int32] + [VP] * 18),
     "fpx_epx_read_index": (C.c_int32, [VP, C.c_int32, C.c_int32, VP, VP]),
     "fpx_replica_chosen": (C.c_int32, [VP, C.c_int32, VP, VP, VP, I32P, I32P]),
     "fpx_replica_chosen_dev": (C.c_int32, [VP, C.c_int32, VP, VP, VP]),

@@ -45,6 +45,9 @@ struct EpxState {
   int32_t* cl_ballot;
   int32_t* cl_vote;
   int32_t* cl_triple;
+  int32_t* cl_deps;     // [n * n * num_instances][n] the triple's dependencies as watermarks (column 0 = -1: the entry
+                        // was written by an Accept, which names its triple by id only)
+  int32_t* cl_dend;     // [n * n * num_instances] end of the explicit values number + 1 .. end - 1 of the own-leader column
   int32_t* largest;     // [n]  Replica.largestBallot, encoded
   uint32_t* cl_stamp;   // [n * num_instances]  run id: instances of one batch must be distinct
 };
@@ -88,6 +91,13 @@ __device__ __forceinline__ int dpp0(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false);
 }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+// The own-leader column of an instance (leader L, number x) is {0 .. cover-1} \ {x} (dependencies.subtractOne(instance),
+// Replica.scala:582): an IntPrefixSet with (watermark cover, no values) if cover <= x, (watermark x, no values) if
+// cover == x + 1, else (watermark x, values x+1 .. cover-1), reported as values_end = cover.  Unions are max of covers.
+__device__ __forceinline__ void own_column(int cover, int x, int* watermark, int* values_end) {
+  *watermark = cover <= x ? cover : x;
+  *values_end = cover > x + 1 ? cover : 0;
+}
 __device__ __forceinline__ int wave_incl_max(int v) {
   v = imax(v, dpp0<0x111, 0xF>(v));  // row_shr:1
   v = imax(v, dpp0<0x112, 0xF>(v));  // row_shr:2
@@ -436,11 +446,35 @@ __device__ __forceinline__ void epx_decide_one(const EpxState& st, const EpxBatc
     // Ballot(0, leader), triple) (:688-696, :1259-1271) for the Accept phase to find
     const unsigned seen = (b.seen_mask ? b.seen_mask[i] : mask) | (1u << L);
     const int tr = b.triple ? b.triple[i] : -1;
+    const int xi = b.number[i];
     for (int r = 0; r < N; ++r) {
-      const size_t c = ((size_t)r * N + L) * st.num_instances + b.number[i];
+      const size_t c = ((size_t)r * N + L) * st.num_instances + xi;
+      if (!all_equal && !((seen >> r) & 1u)) continue;
+      // the triple's dependencies: the agreed ones (fast path, committed everywhere), else what THIS replica
+      // answered (its conflicts U the PreAccept's, :1257-1271) / what the leader proposed (:688-696)
+      int t[N];
+      if (all_equal) {
+#pragma unroll
+        for (int l = 0; l < N; ++l) t[l] = first[l];
+      } else if (r == L) {
+#pragma unroll
+        for (int l = 0; l < N; ++l) t[l] = D[l];
+      } else {
+        int cr[N];
+        load_row(r, cr);
+#pragma unroll
+        for (int l = 0; l < N; ++l) t[l] = cr[l] > D[l] ? cr[l] : D[l];
+      }
+      int wm = 0, end = 0;
+#pragma unroll
+      for (int l = 0; l < N; ++l)
+        if (l == L) own_column(t[l], xi, &wm, &end);
+#pragma unroll
+      for (int l = 0; l < N; ++l) st.cl_deps[c * N + l] = l == L ? wm : t[l];
+      st.cl_dend[c] = end;
       if (all_equal) {
         st.cl_status[c] = CL_COMMITTED, st.cl_ballot[c] = -1, st.cl_vote[c] = -1, st.cl_triple[c] = tr;
-      } else if ((seen >> r) & 1u) {
+      } else {
         st.cl_status[c] = CL_PRE_ACCEPTED, st.cl_ballot[c] = L, st.cl_vote[c] = L, st.cl_triple[c] = tr;  // 0 * 8 + L
       }
     }
@@ -449,13 +483,13 @@ __device__ __forceinline__ void epx_decide_one(const EpxState& st, const EpxBatc
 #pragma unroll
   for (int l = 0; l < N; ++l) {
     const int w = all_equal ? first[l] : uni[l];
-    const bool hole = l == L && w > x;
-    const bool lhole = l == L && D[l] > x;
-    out_deps[threadIdx.x * N + l] = hole ? x : w;
-    out_ldeps[threadIdx.x * N + l] = lhole ? x : D[l];
+    int ow = w, oe = 0, lw = D[l], le = 0;
+    if (l == L) own_column(w, x, &ow, &oe), own_column(D[l], x, &lw, &le);
+    out_deps[threadIdx.x * N + l] = ow;
+    out_ldeps[threadIdx.x * N + l] = lw;
     if (l == L && b.own_values_end) {
-      b.own_values_end[(size_t)i * 2] = hole ? w : 0;
-      b.own_values_end[(size_t)i * 2 + 1] = lhole ? D[l] : 0;
+      b.own_values_end[(size_t)i * 2] = oe;
+      b.own_values_end[(size_t)i * 2 + 1] = le;
     }
   }
 }
@@ -508,6 +542,12 @@ struct ClBatch {
 };
 constexpr int CL_TILE = 1024;
 
+// an Accept names its triple by the caller's id alone: the stored dependencies are marked unknown
+__device__ __forceinline__ void deps_by_id(const EpxState& st, size_t cell) {
+  for (int l = 0; l < st.n; ++l) st.cl_deps[cell * st.n + l] = -1;
+  st.cl_dend[cell] = 0;
+}
+
 __global__ void __launch_bounds__(256) k_cl_validate(const EpxState st, const ClBatch b) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b.m) return;
@@ -536,6 +576,7 @@ __global__ void __launch_bounds__(256) k_cl_propose(const EpxState st, const ClB
     return;
   }
   st.cl_status[c] = CL_ACCEPTED, st.cl_ballot[c] = ballot, st.cl_vote[c] = ballot, st.cl_triple[c] = b.triple[i];  // :759-762
+  deps_by_id(st, c);
 }
 
 // handlePrepare (:1632-1757) / handleAccept (:1421-1511) at replica r for message i: one thread per (i, r)
@@ -571,6 +612,7 @@ __global__ void __launch_bounds__(256) k_cl_handle(const EpxState st, const ClBa
       } else if (!(kind == CL_ACCEPTED && ballot == st.cl_vote[c])) {  // (:1451-1461: already answered, re-send only)
         contrib = ballot;  // :1487
         st.cl_status[c] = CL_ACCEPTED, st.cl_ballot[c] = ballot, st.cl_vote[c] = ballot, st.cl_triple[c] = b.triple[i];
+        deps_by_id(st, c);
       }
     }
   }
@@ -655,10 +697,165 @@ __global__ void __launch_bounds__(256) k_cl_commit(const EpxState st, const ClBa
       for (int r = 0; r < n; ++r) {
         const size_t c = ((size_t)r * n + b.leader[i]) * st.num_instances + b.number[i];
         st.cl_status[c] = CL_COMMITTED, st.cl_ballot[c] = -1, st.cl_vote[c] = -1, st.cl_triple[c] = b.triple[i];
+        deps_by_id(st, c);
       }
     }
   }
   if (b.committed) b.committed[i] = done;
+}
+
+// ---- handlePreAccept in full (Replica.scala:1159-1289): ballots, Nacks, re-sent replies ------------------------
+// Like Prepare / Accept above: messages delivered in array order to the replicas of target[i], instances pairwise
+// distinct per batch -- so what a replica does with a message (process / Nack / answer again / ignore / answer with
+// the Commit) follows from its command-log entry alone (k_hp_gate); the messages a replica processes run through
+// K5's conflict scan in array order (sort by key, segmented prefix max) and k_hp_reply forms the PreAcceptOk's.
+enum { HP_NONE = 0, HP_PROCESS = 1, HP_NACK = 2, HP_RESEND = 3, HP_IGNORE = 4, HP_COMMIT = 5 };
+struct HpBatch {
+  int m;
+  const int32_t* leader;
+  const int32_t* number;
+  const int32_t* b_ord;
+  const int32_t* b_rep;
+  const int32_t* key;       // -1 = Noop
+  const uint8_t* is_set;
+  const int32_t* triple;    // may be null
+  const int32_t* deps_in;   // [m][n]
+  const int32_t* dend_in;   // [m] or null
+  const uint8_t* target;
+  uint8_t* ok_bits;
+  uint8_t* resend_bits;
+  uint8_t* nack_bits;
+  uint8_t* commit_bits;
+  int32_t* reply_deps;      // [m][n][n]
+  int32_t* reply_end;       // [m][n]
+  int32_t* reply_triple;    // [m][n]
+  uint8_t* act;             // [n][m] scratch
+  int32_t* contrib;         // [n][m] scratch (k_cl_tilemax / k_cl_nacks)
+  uint8_t* nackflag;        // [n][m] scratch
+  uint2* kv;                // [n][m] sort pairs
+  const int32_t* conf;      // [m][n][NP] from k_epx_scan
+  const int32_t* tick;      // [n][num_keys][2][n] from k_epx_scan
+  uint32_t run_id;
+};
+
+__global__ void __launch_bounds__(256) k_hp_validate(const EpxState st, const HpBatch b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.m) return;
+  const int n = st.n, L = b.leader[i], x = b.number[i], bo = b.b_ord[i], br = b.b_rep[i], k = b.key[i];
+  bool ok = L >= 0 && L < n && x >= 0 && x < st.num_instances && bo >= 0 && bo < (1 << 27) && br >= 0 && br < n &&
+            (b.target[i] >> n) == 0 && k >= -1 && k < st.num_keys;
+  if (ok) {
+    for (int l = 0; l < n; ++l) ok = ok && b.deps_in[(size_t)i * n + l] >= 0;
+    // a PreAccept never depends on its own instance (:582); explicit values are the run number + 1 .. end - 1
+    const int w = b.deps_in[(size_t)i * n + L], end = b.dend_in ? b.dend_in[i] : 0;
+    ok = ok && (end == 0 ? w <= x : (w == x && end >= x + 2));
+  }
+  if (ok) ok = atomicExch(&st.cl_stamp[(size_t)L * st.num_instances + x], b.run_id) != b.run_id;
+  if (!ok) epx_report(st.status, FPX_EINVAL, i);
+}
+
+// one thread per (replica, message), replica-major
+__global__ void __launch_bounds__(256) k_hp_gate(const EpxState st, const HpBatch b) {
+  const int n = st.n;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)b.m * n) return;
+  const int r = (int)(t / b.m), i = (int)(t % b.m);
+  int act = HP_NONE;
+  const int L = b.leader[i], ballot = b.b_ord[i] * 8 + b.b_rep[i], k = b.key[i];
+  // (a malformed message is reported by k_hp_validate; here it only must not index out of bounds)
+  if (((b.target[i] >> r) & 1u) && L >= 0 && L < n && b.number[i] >= 0 && b.number[i] < st.num_instances) {
+    const size_t c = ((size_t)r * n + L) * st.num_instances + b.number[i];
+    const int kind = st.cl_status[c];
+    if (kind == CL_COMMITTED) act = HP_COMMIT;                                        // :1227-1238
+    else if (kind != CL_NONE && ballot < st.cl_ballot[c]) act = HP_NACK;              // :1180-1184, 1189-1192, 1215-1218
+    else if (kind == CL_PRE_ACCEPTED && ballot == st.cl_vote[c]) act = HP_RESEND;     // :1196-1210
+    else if (kind == CL_ACCEPTED && ballot == st.cl_vote[c]) act = HP_IGNORE;         // :1222-1224
+    else act = HP_PROCESS;
+  }
+  const size_t o = (size_t)r * b.m + i;
+  b.act[o] = (uint8_t)act;
+  b.contrib[o] = act == HP_PROCESS ? ballot : -1;   // :1251 largestBallot = max(largestBallot, preAccept.ballot)
+  b.nackflag[o] = act == HP_NACK ? 1 : 0;
+  // only what the replica processes takes part in its conflict scan; the rest (and Noops, :592-593) sorts last
+  const bool scanned = act == HP_PROCESS && k >= 0 && k < st.num_keys;
+  const uint32_t flags = ((uint32_t)(b.is_set[i] ? 1 : 0) << EPX_SET_SHIFT) | ((uint32_t)(L & 7) << EPX_LEADER_SHIFT);
+  b.kv[o] = make_uint2((scanned ? (uint32_t)k : (uint32_t)st.num_keys) | flags, (uint32_t)i);
+}
+
+// one thread per (message, replica): the reply and the new command-log entry
+template <int N>
+__global__ void __launch_bounds__(256) k_hp_reply(const EpxState st, const HpBatch b) {
+  if (st.status[0] == FPX_EINVAL) return;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)b.m * N) return;
+  const int i = (int)(t / N), r = (int)(t % N);
+  constexpr int NP = ConfRow<N>::NP;
+  const int act = b.act[(size_t)r * b.m + i];
+  const int L = b.leader[i], x = b.number[i];
+  const size_t c = ((size_t)r * N + L) * st.num_instances + x;
+  int out[N], end = 0, tr = -1;
+#pragma unroll
+  for (int l = 0; l < N; ++l) out[l] = 0;
+  uint8_t* bits = nullptr;
+  if (act == HP_PROCESS) {
+    const int ballot = b.b_ord[i] * 8 + b.b_rep[i];
+    int row[N];
+#pragma unroll
+    for (int l = 0; l < N; ++l) row[l] = 0;
+    if (b.key[i] >= 0) {  // computeSequenceNumberAndDependencies :569-600: the conflicts the scan found
+      const int32_t* cr = b.conf + ((size_t)i * N + r) * NP;
+#pragma unroll
+      for (int l = 0; l < N; ++l) row[l] = cr[l];
+    }
+    const int in_end = b.dend_in ? b.dend_in[i] : 0;
+#pragma unroll
+    for (int l = 0; l < N; ++l) {
+      const int in = b.deps_in[(size_t)i * N + l];
+      if (l == L) {
+        // local {0 .. row-1} \ {x}  U  the message's own column (cover in_end, or its plain watermark): :582, :1257-1262
+        const int cover = imax(row[l], in_end ? in_end : in);
+        own_column(cover, x, &out[l], &end);
+      } else {
+        out[l] = imax(row[l], in);
+      }
+    }
+    tr = b.triple ? b.triple[i] : -1;
+    st.cl_status[c] = CL_PRE_ACCEPTED, st.cl_ballot[c] = ballot, st.cl_vote[c] = ballot, st.cl_triple[c] = tr;  // :1265-1276
+#pragma unroll
+    for (int l = 0; l < N; ++l) st.cl_deps[c * N + l] = out[l];
+    st.cl_dend[c] = end;
+    bits = b.ok_bits;
+  } else if (act == HP_RESEND || act == HP_COMMIT) {
+#pragma unroll
+    for (int l = 0; l < N; ++l) out[l] = st.cl_deps[c * N + l];
+    end = st.cl_dend[c], tr = st.cl_triple[c];
+    bits = act == HP_RESEND ? b.resend_bits : b.commit_bits;
+  } else if (act == HP_NACK) {
+    bits = b.nack_bits;
+  }
+  if (bits) atomicOr(reinterpret_cast<unsigned int*>(bits) + (i >> 2), (1u << r) << (8 * (i & 3)));
+  if (b.reply_deps) {
+#pragma unroll
+    for (int l = 0; l < N; ++l) b.reply_deps[((size_t)i * N + r) * N + l] = out[l];
+  }
+  if (b.reply_end) b.reply_end[(size_t)i * N + r] = end;
+  if (b.reply_triple) b.reply_triple[(size_t)i * N + r] = tr;
+}
+
+// updateConflictIndex (:1279) at the replicas that processed: replica r's index learns what ITS scan saw
+__global__ void __launch_bounds__(256) k_hp_commit(const EpxState st, const HpBatch b) {
+  if (st.status[0] == FPX_EINVAL) return;
+  const long long per = (long long)st.num_keys * st.n;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= per * st.n) return;
+  const int r = (int)(t / per);
+  const long long e = t % per;
+  const int k = (int)(e / st.n), l = (int)(e % st.n);
+  const int32_t* seen = b.tick + (((size_t)r * st.num_keys + k) * 2) * st.n;
+  int32_t* g = &st.gets[(size_t)r * per + e];
+  int32_t* s2 = &st.sets[(size_t)r * per + e];
+  if (seen[l] > *g) *g = seen[l];
+  if (seen[st.n + l] > *s2) *s2 = seen[st.n + l];
 }
 
 struct Buf {
@@ -673,7 +870,7 @@ struct fpx_epx {
   EpxState st;
   hipStream_t stream = nullptr, own_stream = nullptr;
   int last_hip = 0;
-  Buf kv, kv2, seg, conf, tmp, tick, h_leader, h_number, h_key, h_set, h_mask, h_seen, h_rank, h_triple, o_fast, o_deps, o_ldeps, o_own, cl;
+  Buf kv, kv2, seg, conf, tmp, tick, h_leader, h_number, h_key, h_set, h_mask, h_seen, h_rank, h_triple, o_fast, o_deps, o_ldeps, o_own, cl, hp;
   uint32_t cl_run = 0;
 };
 
@@ -717,6 +914,40 @@ void launch_scan_decide(fpx_epx* e, const EpxBatch& b) {
   hipLaunchKernelGGL((k_epx_decide<N>), dim3((b.m + 255) / 256), dim3(256), 0, e->stream, e->st, b);
 }
 
+template <int N>
+void launch_hp(fpx_epx* e, const EpxBatch& sb, const HpBatch& hb) {
+  const int segs = N * e->st.num_keys;
+  hipLaunchKernelGGL((k_epx_scan<N>), dim3((segs + 3) / 4), dim3(256), 0, e->stream, e->st, sb);
+  hipLaunchKernelGGL((k_hp_reply<N>), dim3((unsigned)(((long long)hb.m * N + 255) / 256)), dim3(256), 0, e->stream, e->st, hb);
+}
+
+// stable LSD radix sort of the n sequences of m pairs on the key bits; returns the buffer that holds the result
+uint2* sort_by_key(fpx_epx* e, int m, uint2* a_buf, uint2* b_buf, const int32_t* check_rank, int* rc_out) {
+  const int n = e->st.n;
+  unsigned bits = 1;
+  while ((1u << bits) <= (unsigned)e->st.num_keys) ++bits;
+  const unsigned passes = (bits + 7) / 8, width = (bits + passes - 1) / passes;
+  RsArgs a;
+  a.m = m, a.tiles = (m + RS_TILE - 1) / RS_TILE;
+  *rc_out = grow(e, &e->tmp, ((size_t)n * 256 * a.tiles + (size_t)n * 256) * 4);
+  if (*rc_out) return nullptr;
+  a.hist = (uint32_t*)e->tmp.p, a.tot = a.hist + (size_t)n * 256 * a.tiles;
+  uint2* buf[2] = {a_buf, b_buf};
+  int cur = 0;
+  for (unsigned shift = 0; shift < bits; shift += width, cur ^= 1) {
+    a.shift = (int)shift;
+    a.width = (int)width;
+    a.rank = shift == 0 ? check_rank : nullptr;
+    a.status = e->st.status;
+    a.src = buf[cur], a.dst = buf[cur ^ 1];
+    const dim3 tg((a.tiles + 3) / 4, n);
+    hipLaunchKernelGGL(k_rs_hist, tg, dim3(256), 0, e->stream, a);
+    hipLaunchKernelGGL(k_rs_scan, dim3(256, n), dim3(256), 0, e->stream, a);
+    hipLaunchKernelGGL(k_rs_scatter, tg, dim3(256), 0, e->stream, a);
+  }
+  return buf[cur];  // where the last pass left the sequence
+}
+
 }  // namespace
 
 extern "C" {
@@ -739,6 +970,7 @@ int32_t fpx_epx_create(const fpx_epx_config* cfg, fpx_epx** out) {
   e->st.gets = e->st.sets = e->st.status = nullptr;
   e->st.num_instances = cfg->num_instances;
   e->st.cl_status = nullptr, e->st.cl_ballot = e->st.cl_vote = e->st.cl_triple = e->st.largest = nullptr, e->st.cl_stamp = nullptr;
+  e->st.cl_deps = e->st.cl_dend = nullptr;
   auto fail = [&](int code) {
     fpx_epx_destroy(e);
     return code;
@@ -768,6 +1000,10 @@ int32_t fpx_epx_create(const fpx_epx_config* cfg, fpx_epx** out) {
     if (hipMalloc((void**)&e->st.cl_vote, ce * 4) != hipSuccess) return fail(FPX_ENOMEM);
     if (hipMalloc((void**)&e->st.cl_triple, ce * 4) != hipSuccess) return fail(FPX_ENOMEM);
     if (hipMalloc((void**)&e->st.cl_stamp, (size_t)n * cfg->num_instances * 4) != hipSuccess) return fail(FPX_ENOMEM);
+    if (hipMalloc((void**)&e->st.cl_deps, ce * n * 4) != hipSuccess) return fail(FPX_ENOMEM);
+    if (hipMalloc((void**)&e->st.cl_dend, ce * 4) != hipSuccess) return fail(FPX_ENOMEM);
+    if (hipMemsetAsync(e->st.cl_deps, 0, ce * n * 4, e->stream) != hipSuccess) return fail(FPX_EHIP);
+    if (hipMemsetAsync(e->st.cl_dend, 0, ce * 4, e->stream) != hipSuccess) return fail(FPX_EHIP);
     if (hipMemsetAsync(e->st.cl_status, 0, ce, e->stream) != hipSuccess) return fail(FPX_EHIP);
     if (hipMemsetAsync(e->st.cl_ballot, 0xFF, ce * 4, e->stream) != hipSuccess) return fail(FPX_EHIP);
     if (hipMemsetAsync(e->st.cl_vote, 0xFF, ce * 4, e->stream) != hipSuccess) return fail(FPX_EHIP);
@@ -784,12 +1020,12 @@ int32_t fpx_epx_destroy(fpx_epx* e) {
   EpxDeviceGuard _dg(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   void* ps[] = {e->st.gets, e->st.sets, e->st.status, e->st.cl_status, e->st.cl_ballot, e->st.cl_vote, e->st.cl_triple,
-                e->st.largest, e->st.cl_stamp};
+                e->st.largest, e->st.cl_stamp, e->st.cl_deps, e->st.cl_dend};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   Buf* bs[] = {&e->kv, &e->kv2, &e->seg, &e->conf, &e->tmp, &e->tick, &e->h_leader, &e->h_number,
                &e->h_key, &e->h_set, &e->h_mask, &e->h_seen, &e->h_rank, &e->h_triple, &e->o_fast, &e->o_deps, &e->o_ldeps,
-               &e->o_own, &e->cl};
+               &e->o_own, &e->cl, &e->hp};
   for (Buf* b : bs)
     if (b->p) (void)hipFree(b->p);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -842,31 +1078,12 @@ int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, co
   b.tick = (int32_t*)e->tick.p;
   b.seg = (int32_t*)e->seg.p, b.conf = (int32_t*)e->conf.p;
   b.fast = d_fast, b.deps = d_deps, b.leader_deps = d_leader_deps, b.own_values_end = d_own_values_end;
-  // stable LSD radix sort on the key bits only (the sequence already is in delivery order)
-  unsigned bits = 1;
-  while ((1u << bits) <= (unsigned)e->st.num_keys) ++bits;
-  const unsigned passes = (bits + 7) / 8, width = (bits + passes - 1) / passes;
-  RsArgs a;
-  a.m = m, a.tiles = (m + RS_TILE - 1) / RS_TILE;
-  if ((rc = grow(e, &e->tmp, ((size_t)n * 256 * a.tiles + (size_t)n * 256) * 4))) return rc;
-  a.hist = (uint32_t*)e->tmp.p, a.tot = a.hist + (size_t)n * 256 * a.tiles;
   // (counting the first pass's histogram in k_epx_keys with global atomics was tried: 5 M atomics on 327 k counters
   // took 450 us against 22 us for the histogram kernel)
   hipLaunchKernelGGL(k_epx_keys, dim3((m + 255) / 256), dim3(256), 0, e->stream, e->st, b);
-  uint2* buf[2] = {b.kv, b.kv_sorted};
-  int cur = 0;
-  for (unsigned shift = 0; shift < bits; shift += width, cur ^= 1) {
-    a.shift = (int)shift;
-    a.width = (int)width;
-    a.rank = shift == 0 ? d_rank : nullptr;
-    a.status = e->st.status;
-    a.src = buf[cur], a.dst = buf[cur ^ 1];
-    const dim3 tg((a.tiles + 3) / 4, n);
-    hipLaunchKernelGGL(k_rs_hist, tg, dim3(256), 0, e->stream, a);
-    hipLaunchKernelGGL(k_rs_scan, dim3(256, n), dim3(256), 0, e->stream, a);
-    hipLaunchKernelGGL(k_rs_scatter, tg, dim3(256), 0, e->stream, a);
-  }
-  b.kv_sorted = buf[cur];  // where the last pass left the sequence
+  // stable LSD radix sort on the key bits only (the sequence already is in delivery order)
+  b.kv_sorted = sort_by_key(e, m, b.kv, b.kv_sorted, d_rank, &rc);
+  if (rc) return rc;
   const int segs = n * e->st.num_keys;
   hipLaunchKernelGGL(k_epx_segments, dim3((segs + 255) / 256), dim3(256), 0, e->stream, e->st, b);
   switch (n) {
@@ -1009,6 +1226,127 @@ int32_t fpx_epx_accept(fpx_epx* e, int32_t m, const int32_t* leader, const int32
                        uint8_t* nack_bits, uint8_t* commit_bits, int32_t* nack_ballot, uint8_t* committed) {
   return cl_run(e, 1, m, leader, number, ballot_ordering, ballot_replica, triple_id, target_mask, ok_bits, nack_bits,
                 commit_bits, nack_ballot, committed, nullptr, nullptr, nullptr);
+}
+
+int32_t fpx_epx_handle_preaccept(fpx_epx* e, int32_t m, const int32_t* leader, const int32_t* number,
+                                 const int32_t* ballot_ordering, const int32_t* ballot_replica, const int32_t* key,
+                                 const uint8_t* is_set, const int32_t* triple_id, const int32_t* deps_in,
+                                 const int32_t* deps_in_values_end, const uint8_t* target_mask, uint8_t* ok_bits,
+                                 uint8_t* resend_bits, uint8_t* nack_bits, uint8_t* commit_bits, int32_t* nack_ballot,
+                                 int32_t* reply_deps, int32_t* reply_values_end, int32_t* reply_triple) {
+  if (!e || m < 0) return FPX_EINVAL;
+  EpxDeviceGuard _dg(e->cfg.device);
+  if (e->st.num_instances <= 0) return FPX_EINVAL;
+  if (m == 0) return FPX_OK;
+  if (!leader || !number || !ballot_ordering || !ballot_replica || !key || !is_set || !deps_in || !target_mask)
+    return FPX_EINVAL;
+  const int n = e->st.n;
+  const int tiles = (m + CL_TILE - 1) / CL_TILE;
+  const size_t mp = ((size_t)m + 63) & ~(size_t)63;
+  int rc;
+  if ((rc = grow(e, &e->kv, (size_t)n * m * 8))) return rc;
+  if ((rc = grow(e, &e->kv2, (size_t)n * m * 8))) return rc;
+  if ((rc = grow(e, &e->tick, (size_t)n * e->st.num_keys * 2 * n * 4))) return rc;
+  if ((rc = grow(e, &e->seg, (size_t)n * e->st.num_keys * 8))) return rc;
+  if ((rc = grow(e, &e->conf, (size_t)m * n * (n <= 4 ? 4 : 8) * 4))) return rc;
+  // staging: 7 int32 inputs + deps_in [m][n], is_set, target, 4 reply bit arrays, nack_ballot, reply_deps [m][n][n],
+  // reply_end / reply_triple [m][n], act / nackflag [n][m], contrib [n][m], tilemax [n][tiles]
+  const size_t bytes = mp * 4 * 7 + (size_t)m * n * 4 + mp * 6 + mp * 4 + (size_t)m * n * n * 4 + (size_t)m * n * 4 * 2 +
+                       (size_t)n * mp * 2 + (size_t)n * mp * 4 + (size_t)n * tiles * 4 + 2048;
+  if ((rc = grow(e, &e->hp, bytes))) return rc;
+  char* p = (char*)e->hp.p;
+  auto take = [&](size_t sz) { char* q = p; p += (sz + 63) & ~(size_t)63; return q; };
+  int32_t* d_leader = (int32_t*)take(mp * 4); int32_t* d_number = (int32_t*)take(mp * 4);
+  int32_t* d_bo = (int32_t*)take(mp * 4); int32_t* d_br = (int32_t*)take(mp * 4); int32_t* d_key = (int32_t*)take(mp * 4);
+  int32_t* d_tr = (int32_t*)take(mp * 4); int32_t* d_dend = (int32_t*)take(mp * 4);
+  int32_t* d_din = (int32_t*)take((size_t)m * n * 4);
+  uint8_t* d_set = (uint8_t*)take(mp); uint8_t* d_tgt = (uint8_t*)take(mp);
+  uint8_t* d_ok = (uint8_t*)take(mp); uint8_t* d_resend = (uint8_t*)take(mp); uint8_t* d_nack = (uint8_t*)take(mp);
+  uint8_t* d_com = (uint8_t*)take(mp);
+  int32_t* d_nb = (int32_t*)take(mp * 4);
+  int32_t* d_rd = (int32_t*)take((size_t)m * n * n * 4); int32_t* d_re = (int32_t*)take((size_t)m * n * 4);
+  int32_t* d_rt = (int32_t*)take((size_t)m * n * 4);
+  uint8_t* d_act = (uint8_t*)take((size_t)n * m); uint8_t* d_flag = (uint8_t*)take((size_t)n * m);
+  int32_t* d_contrib = (int32_t*)take((size_t)n * m * 4); int32_t* d_tm = (int32_t*)take((size_t)n * tiles * 4);
+  auto up = [&](void* dst, const void* src, size_t sz) { return hipMemcpyAsync(dst, src, sz, hipMemcpyHostToDevice, e->stream); };
+  EHIP(e, up(d_leader, leader, (size_t)m * 4));
+  EHIP(e, up(d_number, number, (size_t)m * 4));
+  EHIP(e, up(d_bo, ballot_ordering, (size_t)m * 4));
+  EHIP(e, up(d_br, ballot_replica, (size_t)m * 4));
+  EHIP(e, up(d_key, key, (size_t)m * 4));
+  if (triple_id) EHIP(e, up(d_tr, triple_id, (size_t)m * 4));
+  if (deps_in_values_end) EHIP(e, up(d_dend, deps_in_values_end, (size_t)m * 4));
+  EHIP(e, up(d_din, deps_in, (size_t)m * n * 4));
+  EHIP(e, up(d_set, is_set, (size_t)m));
+  EHIP(e, up(d_tgt, target_mask, (size_t)m));
+  EHIP(e, hipMemsetAsync(d_ok, 0, mp * 4, e->stream));  // ok, resend, nack, commit are contiguous
+  EHIP(e, hipMemsetAsync(d_nb, 0xFF, mp * 4, e->stream));
+  HpBatch hb;
+  memset(&hb, 0, sizeof(hb));
+  hb.m = m, hb.leader = d_leader, hb.number = d_number, hb.b_ord = d_bo, hb.b_rep = d_br, hb.key = d_key, hb.is_set = d_set;
+  hb.triple = triple_id ? d_tr : nullptr, hb.deps_in = d_din, hb.dend_in = deps_in_values_end ? d_dend : nullptr;
+  hb.target = d_tgt, hb.ok_bits = d_ok, hb.resend_bits = d_resend, hb.nack_bits = d_nack, hb.commit_bits = d_com;
+  hb.reply_deps = d_rd, hb.reply_end = d_re, hb.reply_triple = d_rt;
+  hb.act = d_act, hb.contrib = d_contrib, hb.nackflag = d_flag, hb.kv = (uint2*)e->kv.p;
+  hb.conf = (int32_t*)e->conf.p, hb.tick = (int32_t*)e->tick.p;
+  if (++e->cl_run == 0) {  // stamp space exhausted: start over
+    EHIP(e, hipMemsetAsync(e->st.cl_stamp, 0, (size_t)n * e->st.num_instances * 4, e->stream));
+    e->cl_run = 1;
+  }
+  hb.run_id = e->cl_run;
+  const dim3 gm((m + 255) / 256), gmn((unsigned)(((long long)m * n + 255) / 256)), blk(256);
+  hipLaunchKernelGGL(k_hp_validate, gm, blk, 0, e->stream, e->st, hb);
+  hipLaunchKernelGGL(k_hp_gate, gmn, blk, 0, e->stream, e->st, hb);
+  // the conflict scan of what each replica processes, in array order: K5's sort / segments / scan
+  EpxBatch sb;
+  memset(&sb, 0, sizeof(sb));
+  sb.m = m, sb.number = d_number, sb.kv = hb.kv;
+  sb.kv_sorted = sort_by_key(e, m, hb.kv, (uint2*)e->kv2.p, nullptr, &rc);
+  if (rc) return rc;
+  sb.tick = (int32_t*)e->tick.p, sb.seg = (int32_t*)e->seg.p, sb.conf = (int32_t*)e->conf.p;
+  hipLaunchKernelGGL(k_epx_segments, dim3((n * e->st.num_keys + 255) / 256), blk, 0, e->stream, e->st, sb);
+  // the largestBallot every Nack carries: prefix max per replica over the ballots it took in (as for Prepare / Accept)
+  ClBatch cb;
+  memset(&cb, 0, sizeof(cb));
+  cb.m = m, cb.contrib = d_contrib, cb.nackflag = d_flag, cb.tilemax = d_tm, cb.nack_ballot = d_nb;
+  hipLaunchKernelGGL(k_cl_tilemax, dim3(tiles, n), blk, 0, e->stream, cb, tiles);
+  hipLaunchKernelGGL(k_cl_tilescan, dim3(n), blk, 0, e->stream, e->st, cb, tiles);
+  hipLaunchKernelGGL(k_cl_nacks, dim3(tiles, n), blk, 0, e->stream, cb, tiles);
+  switch (n) {
+    case 3: launch_hp<3>(e, sb, hb); break;
+    case 5: launch_hp<5>(e, sb, hb); break;
+    default: launch_hp<7>(e, sb, hb); break;
+  }
+  const long long tot = (long long)e->st.num_keys * n * n;
+  hipLaunchKernelGGL(k_hp_commit, dim3((unsigned)((tot + 255) / 256)), blk, 0, e->stream, e->st, hb);
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) {
+    e->last_hip = (int)le;
+    return FPX_EHIP;
+  }
+  auto down = [&](void* dst, const void* src, size_t sz) { return hipMemcpyAsync(dst, src, sz, hipMemcpyDeviceToHost, e->stream); };
+  if (ok_bits) EHIP(e, down(ok_bits, d_ok, (size_t)m));
+  if (resend_bits) EHIP(e, down(resend_bits, d_resend, (size_t)m));
+  if (nack_bits) EHIP(e, down(nack_bits, d_nack, (size_t)m));
+  if (commit_bits) EHIP(e, down(commit_bits, d_com, (size_t)m));
+  if (nack_ballot) EHIP(e, down(nack_ballot, d_nb, (size_t)m * 4));
+  if (reply_deps) EHIP(e, down(reply_deps, d_rd, (size_t)m * n * n * 4));
+  if (reply_values_end) EHIP(e, down(reply_values_end, d_re, (size_t)m * n * 4));
+  if (reply_triple) EHIP(e, down(reply_triple, d_rt, (size_t)m * n * 4));
+  return fpx_epx_sync(e);
+}
+
+int32_t fpx_epx_read_cmdlog_deps(fpx_epx* e, int32_t replica, int32_t leader, int32_t number, int32_t* deps,
+                                 int32_t* values_end) {
+  if (!e || !deps || !values_end || e->st.num_instances <= 0 || replica < 0 || replica >= e->st.n || leader < 0 ||
+      leader >= e->st.n || number < 0 || number >= e->st.num_instances)
+    return FPX_EINVAL;
+  EpxDeviceGuard _dg(e->cfg.device);
+  const size_t c = ((size_t)replica * e->st.n + leader) * e->st.num_instances + number;
+  EHIP(e, hipStreamSynchronize(e->stream));
+  EHIP(e, hipMemcpy(deps, e->st.cl_deps + c * e->st.n, (size_t)e->st.n * 4, hipMemcpyDeviceToHost));
+  EHIP(e, hipMemcpy(values_end, e->st.cl_dend + c, 4, hipMemcpyDeviceToHost));
+  return FPX_OK;
 }
 
 int32_t fpx_epx_read_cmdlog(fpx_epx* e, int32_t replica, int32_t leader, int32_t number, int32_t out[5]) {

@@ -107,6 +107,36 @@ class EPaxos:
                                    p(com), p(nb), p(done))
         return st, ok, nack, com, nb, done
 
+    def handle_preaccept(self, leader, number, ballot_ordering, ballot_replica, key, is_set, triple_id, deps_in,
+                         deps_in_values_end, target_mask):
+        """Replica.handlePreAccept in full at the replicas of target_mask (key -1 = Noop): (status, ok_bits,
+        resend_bits, nack_bits, commit_bits, nack_ballot, reply_deps[m, n, n], reply_values_end[m, n],
+        reply_triple[m, n])"""
+        a32 = lambda x: None if x is None else np.ascontiguousarray(x, dtype=np.int32)
+        leader, number, bo, br, key = a32(leader), a32(number), a32(ballot_ordering), a32(ballot_replica), a32(key)
+        is_set = np.ascontiguousarray(is_set, dtype=np.uint8)
+        tr, din, dend = a32(triple_id), a32(deps_in), a32(deps_in_values_end)
+        tgt = np.ascontiguousarray(target_mask, dtype=np.uint8)
+        m = len(leader)
+        ok, resend, nack, com = (np.zeros(m, np.uint8) for _ in range(4))
+        nb = np.full(m, -1, np.int32)
+        rd = np.zeros((m, self.n, self.n), np.int32)
+        re = np.zeros((m, self.n), np.int32)
+        rt = np.full((m, self.n), -1, np.int32)
+        p = lambda a: None if a is None else a.ctypes.data
+        st = self.L.fpx_epx_handle_preaccept(self._h, m, p(leader), p(number), p(bo), p(br), p(key), p(is_set), p(tr),
+                                             p(din), p(dend), p(tgt), p(ok), p(resend), p(nack), p(com), p(nb), p(rd),
+                                             p(re), p(rt))
+        return st, ok, resend, nack, com, nb, rd, re, rt
+
+    def read_cmdlog_deps(self, replica, leader, number):
+        """the dependencies kept with a command-log entry: (watermarks[n], values_end)"""
+        deps, end = np.zeros(self.n, np.int32), np.zeros(1, np.int32)
+        st = self.L.fpx_epx_read_cmdlog_deps(self._h, replica, leader, number, deps.ctypes.data, end.ctypes.data)
+        if st:
+            raise FpxError(st, "fpx_epx_read_cmdlog_deps")
+        return deps, int(end[0])
+
     def read_cmdlog(self, replica, leader, number):
         """(kind, ballot, voteBallot, triple id, the replica's largestBallot); ballots encoded ordering * 8 + index"""
         out = np.zeros(5, np.int32)

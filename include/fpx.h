@@ -393,8 +393,11 @@ int32_t fpx_epx_sync(fpx_epx* epx);
  * Ballots are (ordering, replicaIndex), compared lexicographically (epaxos/BallotHelpers.scala:11-21); where one
  * int32 carries a ballot it is ordering * 8 + replicaIndex, the null ballot (-1, -1) (Replica.scala:256) is -1.
  * Command-log entry kinds: 0 none, 1 NoCommandEntry, 2 PreAcceptedEntry, 3 AcceptedEntry, 4 CommittedEntry
- * (Replica.scala:303-330).  A CommandTriple travels as the caller's int32 triple_id (pre-accept: the optional
- * triple_id argument; the dependencies themselves are the pre-accept's outputs and stay with the caller).
+ * (Replica.scala:303-330).  A CommandTriple is the caller's int32 triple_id (the command; pre-accept: the optional
+ * triple_id argument) plus its dependencies, which the command log keeps with every entry a pre-accept wrote (what
+ * THAT replica answered, :1259-1271; the agreed dependencies after a fast-path commit): n watermarks + the end of
+ * the own-leader column's explicit values (fpx_epx_read_cmdlog_deps).  An Accept names its triple by id alone:
+ * the entries it writes have dependency column 0 = -1 ("look the triple up by its id").
  * fpx_epx_preaccept with a command log: every participating replica must not know the instance yet (the
  * `cmdLog.get == None` branch of handlePreAccept, Replica.scala:1169-1172; anything else is FPX_EINVAL, nothing
  * applied); it records PreAcceptedEntry(Ballot(0, leader), Ballot(0, leader), triple) at the participants, and a
@@ -423,8 +426,39 @@ int32_t fpx_epx_accept(fpx_epx* epx, int32_t m, const int32_t* leader, const int
                        const int32_t* ballot_ordering, const int32_t* ballot_replica, const int32_t* triple_id,
                        const uint8_t* target_mask, uint8_t* ok_bits, uint8_t* nack_bits, uint8_t* commit_bits,
                        int32_t* nack_ballot, uint8_t* committed);
+/* K7: Replica.handlePreAccept in full (epaxos/Replica.scala:1159-1289) -- what fpx_epx_preaccept's tick-at-once form
+ * leaves out: PreAccepts for instances a replica already knows (a leader's re-sent PreAccept, a recovering replica
+ * pre-accepting again in a higher ballot).  Message i = PreAccept(instance (leader, number), ballot
+ * (ballot_ordering, ballot_replica), single-key get / set on key[i] or Noop (key[i] = -1), sequenceNumber 0,
+ * dependencies deps_in[i * n ..] = n watermarks + deps_in_values_end[i] (explicit values number + 1 .. end - 1 of
+ * the instance's own-leader column, 0 = none; the array may be NULL; a PreAccept that depends on its own instance is
+ * FPX_EINVAL)), delivered in array order to the replicas of target_mask[i]; instances pairwise distinct per call.
+ * At each replica, cmdLog.get(instance) decides (:1169-1238):
+ *   none                                            -> processed
+ *   NoCommandEntry(b):       ballot < b             -> Nack(instance, largestBallot)
+ *   PreAcceptedEntry(b, vb): ballot < b -> Nack;  ballot == vb -> the PreAcceptOk again, from the stored triple
+ *   AcceptedEntry(b, vb):    ballot < b -> Nack;  ballot == vb -> ignored
+ *   CommittedEntry(triple)                          -> the Commit back
+ *   otherwise processed: largestBallot = max(largestBallot, ballot) (:1251); dependencies = the command's conflicts
+ *   in THIS replica's index minus the instance itself (computeSequenceNumberAndDependencies :569-600; none for a
+ *   Noop) U deps_in (:1257-1262); PreAcceptedEntry(ballot, ballot, triple) (:1265-1276); updateConflictIndex (:1279,
+ *   a Noop leaves the index alone); PreAcceptOk(dependencies).  (The leaderStates / timer bookkeeping of :1243-1254
+ *   is leader-side state outside this path.)
+ * Replies (host pointers, may be NULL): ok_bits (processed), resend_bits, nack_bits, commit_bits -- the other replicas
+ * of target_mask ignored the message; nack_ballot as above; reply_deps (m x n x n) / reply_values_end (m x n) /
+ * reply_triple (m x n): the dependencies and triple id of the PreAcceptOk or Commit replica r sent (zeros / 0 / -1
+ * where it sent neither). */
+int32_t fpx_epx_handle_preaccept(fpx_epx* epx, int32_t m, const int32_t* leader, const int32_t* number,
+                                 const int32_t* ballot_ordering, const int32_t* ballot_replica, const int32_t* key,
+                                 const uint8_t* is_set, const int32_t* triple_id, const int32_t* deps_in,
+                                 const int32_t* deps_in_values_end, const uint8_t* target_mask, uint8_t* ok_bits,
+                                 uint8_t* resend_bits, uint8_t* nack_bits, uint8_t* commit_bits, int32_t* nack_ballot,
+                                 int32_t* reply_deps, int32_t* reply_values_end, int32_t* reply_triple);
 /* one command-log entry: out[0..4] = kind, ballot, voteBallot, triple id, the replica's largestBallot */
 int32_t fpx_epx_read_cmdlog(fpx_epx* epx, int32_t replica, int32_t leader, int32_t number, int32_t out[5]);
+/* the dependencies kept with that entry: deps[n] watermarks (deps[0] = -1: known by triple id only), *values_end */
+int32_t fpx_epx_read_cmdlog_deps(fpx_epx* epx, int32_t replica, int32_t leader, int32_t number, int32_t* deps,
+                                 int32_t* values_end);
 /* replica's conflict-index entry of one key: gets[n], sets[n] (TopOne vectors) */
 int32_t fpx_epx_read_index(fpx_epx* epx, int32_t replica, int32_t key, int32_t* gets, int32_t* sets);
 

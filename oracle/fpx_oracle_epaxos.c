@@ -6,7 +6,8 @@
  *   statemachine/KeyValueStore.scala:225-302                 top-one conflict index of the key-value store
  *   epaxos/Replica.scala:569-600   computeSequenceNumberAndDependencies (topKDependencies == 1)
  *   epaxos/Replica.scala:633-729   transitionToPreAcceptPhase (the leader's own pre-accept)
- *   epaxos/Replica.scala:1159-1289 handlePreAccept (fresh instance: cmdLog.get == None)
+ *   epaxos/Replica.scala:1159-1289 handlePreAccept (the tick-at-once form: fresh instances, cmdLog.get == None;
+ *                                  fpo_epx_handle_preaccept: every branch)
  *   epaxos/Replica.scala:1291-1419 handlePreAcceptOk (fast path test) ; :796-813 preAcceptingSlowPath
  *   Util.scala:7-21                histogram / popularItems
  *   epaxos/Config.scala:7-9        n = 2f+1, fastQuorumSize = n-1, slowQuorumSize = f+1
@@ -46,6 +47,9 @@ typedef struct {
   int* cl_ballot;
   int* cl_vote;
   int* cl_triple;            /* the CommandTriple, by the caller's id */
+  int* cl_deps;              /* [cells][n] the triple's dependencies as watermarks (column 0 = -1: the entry was written
+                              * by an Accept, which names its triple by id only) */
+  int* cl_dend;              /* [cells] end of the explicit values number + 1 .. end - 1 of the own-leader column, 0 = none */
   int* largest_ballot;       /* [n]  Replica.scala:458  var largestBallot = Ballot(0, index) */
 } fpo_epx;
 
@@ -66,6 +70,8 @@ fpo_epx* fpo_epx_new2(int n, int num_keys, int num_instances) {
     e->cl_ballot = (int*)malloc(sizeof(int) * cells);
     e->cl_vote = (int*)malloc(sizeof(int) * cells);
     e->cl_triple = (int*)malloc(sizeof(int) * cells);
+    e->cl_deps = (int*)calloc(cells * (size_t)n, sizeof(int));
+    e->cl_dend = (int*)calloc(cells, sizeof(int));
     for (size_t i = 0; i < cells; ++i) e->cl_ballot[i] = e->cl_vote[i] = e->cl_triple[i] = -1;
   }
   e->largest_ballot = (int*)malloc(sizeof(int) * (size_t)n);
@@ -83,6 +89,8 @@ void fpo_epx_free(fpo_epx* e) {
   free(e->cl_ballot);
   free(e->cl_vote);
   free(e->cl_triple);
+  free(e->cl_deps);
+  free(e->cl_dend);
   free(e->largest_ballot);
   free(e);
 }
@@ -257,6 +265,13 @@ int fpo_epx_preaccept2(fpo_epx* e, int32_t m, const int32_t* leader, const int32
                        const int32_t* rank, const int32_t* triple_id, uint8_t* fast, int32_t* deps,
                        int32_t* leader_deps, int32_t* own_values_end);
 
+/* the dependencies of a command-log triple: watermarks of the n columns, the own-leader column from its
+ * IntPrefixSet (its explicit values are a run that ends at cl_dend - 1; the callers check that) */
+static void store_deps(fpo_epx* e, size_t cell, int own_leader, const int* watermarks, const ips_t* own) {
+  for (int l = 0; l < e->n; ++l) e->cl_deps[cell * (size_t)e->n + l] = l == own_leader ? own->watermark : watermarks[l];
+  e->cl_dend[cell] = own->nvalues ? own->values[own->nvalues - 1] + 1 : 0;
+}
+
 /*
  * One tick.  rank[r * m + i] = position of message i in replica r's processing order.
  * resp_mask[i]: the n-2 other replicas the leader sends PreAccept to.
@@ -390,20 +405,35 @@ int fpo_epx_preaccept2(fpo_epx* e, int32_t m, const int32_t* leader, const int32
      * replica in seen_mask finds the instance committed / accepting and is ignored (:1308-1334). */
     const int is_fast = all_equal;
     if (fast) fast[i] = (uint8_t)is_fast;
+    const ips_t* out_own = is_fast ? &first_own : &uni_own;
     if (e->num_instances > 0) {
       const unsigned part = (seen_mask ? seen_mask[i] : resp_mask[i]) | (1u << L);
       for (int r = 0; r < n; ++r) {
         const size_t c = ((size_t)r * n + L) * e->num_instances + number[i];
         if (is_fast) {
+          /* the committed triple: (seq, deps) of the fast-path agreement (:1399-1408 -> commit) */
           e->cl_status[c] = CL_COMMITTED, e->cl_ballot[c] = e->cl_vote[c] = -1;
           e->cl_triple[c] = triple_id ? triple_id[i] : -1;
+          int wm[8];
+          memcpy(wm, first, sizeof(int) * (size_t)n);
+          store_deps(e, c, L, wm, out_own);
         } else if ((part >> r) & 1u) {
+          /* every replica that processed the PreAccept keeps ITS answer as the triple (:1259-1271); the leader
+           * the dependencies it proposed (:688-696) */
           e->cl_status[c] = CL_PRE_ACCEPTED, e->cl_ballot[c] = e->cl_vote[c] = enc_ballot(0, L);
           e->cl_triple[c] = triple_id ? triple_id[i] : -1;
+          int wm[8];
+          ips_t mine = ips_clone(&own[(size_t)i * n + r]);
+          if (r != L) ips_add_all(&mine, Down);
+          for (int l = 0; l < n; ++l) {
+            const int cl = conf[((size_t)i * n + r) * n + l];
+            wm[l] = (r != L && D[l] > cl) ? D[l] : cl;
+          }
+          store_deps(e, c, L, wm, &mine);
+          ips_free(&mine);
         }
       }
     }
-    const ips_t* out_own = is_fast ? &first_own : &uni_own;
     for (int l = 0; l < n; ++l) {
       if (deps) deps[(size_t)i * n + l] = l == L ? out_own->watermark : (is_fast ? first[l] : uni[l]);
       if (leader_deps) leader_deps[(size_t)i * n + l] = l == L ? Down->watermark : D[l];
@@ -438,6 +468,12 @@ int fpo_epx_preaccept2(fpo_epx* e, int32_t m, const int32_t* leader, const int32
  * call must be pairwise distinct (EINVAL 1 otherwise: the GPU evaluates a batch at once).  Per message the replies:
  * ok_bits / nack_bits / commit_bits (the replica answered with the Commit it already has), nack_ballot = the largest
  * `largestBallot` a Nack carried (encoded ordering * 8 + replicaIndex; -1 = none). */
+/* an Accept names its triple by the caller's id alone: the stored dependencies are marked unknown */
+static void deps_by_id(fpo_epx* e, size_t cell) {
+  for (int l = 0; l < e->n; ++l) e->cl_deps[cell * (size_t)e->n + l] = -1;
+  e->cl_dend[cell] = 0;
+}
+
 static int instances_ok(const fpo_epx* e, int m, const int32_t* leader, const int32_t* number, const int32_t* b_ord,
                         const int32_t* b_rep, const uint8_t* target) {
   if (e->num_instances <= 0 || m < 0) return 0;
@@ -535,6 +571,7 @@ int fpo_epx_accept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_t* 
       continue;
     }
     e->cl_status[cp] = CL_ACCEPTED, e->cl_ballot[cp] = e->cl_vote[cp] = ballot, e->cl_triple[cp] = triple_id[i];
+    deps_by_id(e, cp);
     ok |= 1u << P;
     for (int r = 0; r < n; ++r) {
       if (!((target[i] >> r) & 1u)) continue;
@@ -555,6 +592,7 @@ int fpo_epx_accept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_t* 
       }
       if (ballot > e->largest_ballot[r]) e->largest_ballot[r] = ballot; /* :1487 */
       e->cl_status[c] = CL_ACCEPTED, e->cl_ballot[c] = e->cl_vote[c] = ballot, e->cl_triple[c] = triple_id[i]; /* :1493-1502 */
+      deps_by_id(e, c);
       ok |= 1u << r;
     }
     if (ok_bits) ok_bits[i] = (uint8_t)ok;
@@ -566,10 +604,134 @@ int fpo_epx_accept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_t* 
       for (int r = 0; r < n; ++r) {
         const size_t c = ((size_t)r * n + leader[i]) * e->num_instances + number[i];
         e->cl_status[c] = CL_COMMITTED, e->cl_ballot[c] = e->cl_vote[c] = -1, e->cl_triple[c] = triple_id[i];
+        deps_by_id(e, c);
       }
     }
   }
   return status;
+}
+
+/* Replica.handlePreAccept in full (epaxos/Replica.scala:1159-1289) at every replica of target_mask, messages delivered
+ * in array order; the instances of one call are pairwise distinct.  Message i = PreAccept(instance (leader, number),
+ * ballot (b_ord, b_rep), commandOrNoop = single-key get / set on key[i] or Noop (key[i] == -1), sequenceNumber 0,
+ * dependencies deps_in[i] = n watermarks + deps_in_end[i] (the explicit values number + 1 .. end - 1 of the instance's
+ * own-leader column, 0 = none; NULL = none anywhere)).  Per (message, replica):
+ *   cmdLog.get(instance)                                                      :1169
+ *     None                                     -> process
+ *     NoCommandEntry(b):  ballot < b           -> Nack(instance, largestBallot)       :1174-1185
+ *     PreAcceptedEntry(b, vb, triple): ballot < b -> Nack ; ballot == vb -> the PreAcceptOk again, from the stored
+ *                                                 triple                                :1187-1211
+ *     AcceptedEntry(b, vb, _): ballot < b -> Nack ; ballot == vb -> ignored             :1213-1225
+ *     CommittedEntry(triple)                   -> Commit(triple) back                   :1227-1238
+ *   process: largestBallot = max(largestBallot, ballot) :1251; dependencies = computeSequenceNumberAndDependencies
+ *     (conflicts of the command in this replica's index minus the instance itself; empty for a Noop, :569-600)
+ *     addAll preAccept.dependencies :1257-1262; cmdLog.put(PreAcceptedEntry(ballot, ballot, triple)) :1265-1276;
+ *     updateConflictIndex (a Noop leaves the index alone, :602-614) :1279; PreAcceptOk(dependencies) :1282-1293.
+ * (The leaderStates / timer bookkeeping of :1243-1254 is leader-side state outside this path.)
+ * Outputs per message: ok_bits (processed), resend_bits (PreAcceptOk sent again), nack_bits, commit_bits; the other
+ * replicas of target_mask ignored it.  nack_ballot = the largest `largestBallot` a Nack carried.  reply_deps[i][r] /
+ * reply_end[i][r] / reply_triple[i][r]: the dependencies (and triple id) of the PreAcceptOk or Commit replica r sent,
+ * zeros / 0 / -1 where it sent neither.  Returns 0, 1 (EINVAL), 99 if a set is not representable (never: asserted). */
+int fpo_epx_handle_preaccept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* b_ord,
+                             const int32_t* b_rep, const int32_t* key, const uint8_t* is_set, const int32_t* triple_id,
+                             const int32_t* deps_in, const int32_t* deps_in_end, const uint8_t* target,
+                             uint8_t* ok_bits, uint8_t* resend_bits, uint8_t* nack_bits, uint8_t* commit_bits,
+                             int32_t* nack_ballot, int32_t* reply_deps, int32_t* reply_end, int32_t* reply_triple) {
+  const int n = e->n;
+  if (!instances_ok(e, m, leader, number, b_ord, b_rep, target)) return 1;
+  for (int i = 0; i < m; ++i) {
+    if (key[i] < -1 || key[i] >= e->num_keys) return 1;
+    const int x = number[i], end = deps_in_end ? deps_in_end[i] : 0;
+    for (int l = 0; l < n; ++l)
+      if (deps_in[(size_t)i * n + l] < 0) return 1;
+    /* a PreAccept never depends on its own instance (:582), and the only explicit values this path produces are
+     * the run number + 1 .. end - 1 above a watermark equal to the instance number */
+    const int w = deps_in[(size_t)i * n + leader[i]];
+    if (end == 0 ? w > x : (w != x || end < x + 2)) return 1;
+  }
+  int rc = 0;
+  for (int i = 0; i < m; ++i) {
+    const int L = leader[i], x = number[i], ballot = enc_ballot(b_ord[i], b_rep[i]);
+    unsigned ok = 0, resend = 0, nack = 0, com = 0;
+    int nb = -1;
+    for (int r = 0; r < n; ++r) {
+      int* rd = reply_deps ? reply_deps + ((size_t)i * n + r) * n : NULL;
+      if (rd) memset(rd, 0, sizeof(int) * (size_t)n);
+      if (reply_end) reply_end[(size_t)i * n + r] = 0;
+      if (reply_triple) reply_triple[(size_t)i * n + r] = -1;
+      if (!((target[i] >> r) & 1u)) continue;
+      const size_t c = ((size_t)r * n + L) * e->num_instances + x;
+      const int st = e->cl_status[c];
+      int stored = 0;
+      if (st == CL_COMMITTED) {
+        com |= 1u << r, stored = 1;
+      } else if (st != CL_NONE && ballot < e->cl_ballot[c]) {
+        nack |= 1u << r;
+        if (e->largest_ballot[r] > nb) nb = e->largest_ballot[r];
+        continue;
+      } else if (st == CL_PRE_ACCEPTED && ballot == e->cl_vote[c]) {
+        resend |= 1u << r, stored = 1;
+      } else if (st == CL_ACCEPTED && ballot == e->cl_vote[c]) {
+        continue;
+      }
+      if (stored) {
+        if (rd) memcpy(rd, e->cl_deps + c * (size_t)n, sizeof(int) * (size_t)n);
+        if (reply_end) reply_end[(size_t)i * n + r] = e->cl_dend[c];
+        if (reply_triple) reply_triple[(size_t)i * n + r] = e->cl_triple[c];
+        continue;
+      }
+      if (ballot > e->largest_ballot[r]) e->largest_ballot[r] = ballot;
+      int wm[8];
+      memset(wm, 0, sizeof(wm));
+      ips_t own = ips_from_watermark(0);
+      if (key[i] >= 0) {
+        get_top_one_conflicts(e, r, key[i], is_set[i], wm);
+        own = ips_from_watermark(wm[L]);
+        ips_subtract_one(&own, x);
+      }
+      ips_t in = ips_from_watermark(deps_in[(size_t)i * n + L]);
+      const int end = deps_in_end ? deps_in_end[i] : 0;
+      if (end) {
+        in.nvalues = end - (x + 1);
+        in.values = (int*)malloc(sizeof(int) * (size_t)in.nvalues);
+        for (int k = 0; k < in.nvalues; ++k) in.values[k] = x + 1 + k;
+      }
+      ips_add_all(&own, &in);
+      ips_free(&in);
+      for (int l = 0; l < n; ++l)
+        if (deps_in[(size_t)i * n + l] > wm[l]) wm[l] = deps_in[(size_t)i * n + l];
+      if (own.nvalues && (own.watermark != x || own.values[0] != x + 1 ||
+                          own.values[own.nvalues - 1] + 1 - own.values[0] != own.nvalues))
+        rc = 99;
+      e->cl_status[c] = CL_PRE_ACCEPTED, e->cl_ballot[c] = e->cl_vote[c] = ballot;
+      e->cl_triple[c] = triple_id ? triple_id[i] : -1;
+      store_deps(e, c, L, wm, &own);
+      if (key[i] >= 0) conflict_index_put(e, r, key[i], is_set[i], L, x);
+      ok |= 1u << r;
+      if (rd) memcpy(rd, e->cl_deps + c * (size_t)n, sizeof(int) * (size_t)n);
+      if (reply_end) reply_end[(size_t)i * n + r] = e->cl_dend[c];
+      if (reply_triple) reply_triple[(size_t)i * n + r] = e->cl_triple[c];
+      ips_free(&own);
+    }
+    if (ok_bits) ok_bits[i] = (uint8_t)ok;
+    if (resend_bits) resend_bits[i] = (uint8_t)resend;
+    if (nack_bits) nack_bits[i] = (uint8_t)nack;
+    if (commit_bits) commit_bits[i] = (uint8_t)com;
+    if (nack_ballot) nack_ballot[i] = nb;
+  }
+  return rc;
+}
+
+/* the dependencies stored with one command-log entry: n watermarks (column 0 = -1: known by triple id only) and
+ * the end of the own-leader column's explicit values */
+int fpo_epx_read_cmdlog_deps(fpo_epx* e, int replica, int leader, int number, int32_t* deps, int32_t* values_end) {
+  if (e->num_instances <= 0 || replica < 0 || replica >= e->n || leader < 0 || leader >= e->n || number < 0 ||
+      number >= e->num_instances)
+    return 1;
+  const size_t c = ((size_t)replica * e->n + leader) * e->num_instances + number;
+  memcpy(deps, e->cl_deps + c * (size_t)e->n, sizeof(int) * (size_t)e->n);
+  *values_end = e->cl_dend[c];
+  return 0;
 }
 
 /* one command-log entry: kind, ballot, voteBallot (encoded), triple id; and the replica's largestBallot */

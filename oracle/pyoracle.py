@@ -553,6 +553,9 @@ class EPaxos:
         L.fpo_epx_prepare.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, I32P, U8P, U8P, U8P, U8P, I32P, I32P, I32P, I32P]
         L.fpo_epx_accept.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, I32P, I32P, U8P, U8P, U8P, U8P, I32P, U8P]
         L.fpo_epx_read_cmdlog.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, I32P]
+        L.fpo_epx_read_cmdlog_deps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, I32P, I32P]
+        L.fpo_epx_handle_preaccept.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, I32P, I32P, U8P, I32P, I32P, I32P,
+                                               U8P, U8P, U8P, U8P, U8P, I32P, I32P, I32P, I32P]
         L.fpo_epx_free.argtypes = [C.c_void_p]
         L.fpo_epx_preaccept.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, U8P, U8P, U8P, I32P, U8P, I32P,
                                         I32P, I32P]
@@ -597,6 +600,32 @@ class EPaxos:
         if lib().fpo_epx_read_cmdlog(self._h, replica, leader, number, _p(out, I32P)):
             raise ValueError("FPX_EINVAL")
         return tuple(int(x) for x in out)
+
+    def read_cmdlog_deps(self, replica, leader, number):
+        deps, end = np.zeros(self.n, np.int32), np.zeros(1, np.int32)
+        if lib().fpo_epx_read_cmdlog_deps(self._h, replica, leader, number, _p(deps, I32P), _p(end, I32P)):
+            raise ValueError("FPX_EINVAL")
+        return deps, int(end[0])
+
+    def handle_preaccept(self, leader, number, ballot_ordering, ballot_replica, key, is_set, triple_id, deps_in,
+                         deps_in_values_end, target_mask):
+        leader, number, bo, br, key = _i32(leader), _i32(number), _i32(ballot_ordering), _i32(ballot_replica), _i32(key)
+        is_set = np.ascontiguousarray(is_set, dtype=np.uint8)
+        tr = None if triple_id is None else _i32(triple_id)
+        din = np.ascontiguousarray(deps_in, dtype=np.int32)
+        dend = None if deps_in_values_end is None else _i32(deps_in_values_end)
+        tgt = np.ascontiguousarray(target_mask, dtype=np.uint8)
+        m = len(leader)
+        ok, resend, nack, com = (np.zeros(m, np.uint8) for _ in range(4))
+        nb = np.full(m, -1, np.int32)
+        rd = np.zeros((m, self.n, self.n), np.int32)
+        re = np.zeros((m, self.n), np.int32)
+        rt = np.full((m, self.n), -1, np.int32)
+        st = lib().fpo_epx_handle_preaccept(self._h, m, _p(leader, I32P), _p(number, I32P), _p(bo, I32P), _p(br, I32P),
+                                            _p(key, I32P), _p(is_set, U8P), _p(tr, I32P), _p(din, I32P), _p(dend, I32P),
+                                            _p(tgt, U8P), _p(ok, U8P), _p(resend, U8P), _p(nack, U8P), _p(com, U8P),
+                                            _p(nb, I32P), _p(rd, I32P), _p(re, I32P), _p(rt, I32P))
+        return st, ok, resend, nack, com, nb, rd, re, rt
 
     def preaccept(self, leader, number, key, is_set, resp_mask, rank, seen_mask=None, triple_id=None):
         a8 = lambda x: np.ascontiguousarray(x, dtype=np.uint8)

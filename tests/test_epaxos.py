@@ -607,3 +607,199 @@ def test_epaxos_prepare_accept_match_oracle(oracle, n, NI, m):
     assert gpu.accept(one, one, one, one, one, np.zeros(2, np.uint8))[0] == fa.FPX_EINVAL
     assert gpu.accept([1], [1], [0], [1], [0], [0b010])[0] == fa.FPX_EINVAL
     assert EPaxos(n, 8).accept([1], [1], [0], [1], [0], [0b001])[0] == fa.FPX_EINVAL
+
+
+# ------------------------------------------------ handlePreAccept in full: ballots, Nacks, re-sent replies ----
+def test_oracle_handle_preaccept_every_branch_by_hand(oracle):
+    """n = 5, instance X = (0, 0): set k1 led by replica 0.  Replica 1 already knows the conflicting instance (2, 6).
+      tick: X pre-accepts at {1, 2, 3}: replica 1 answers [0,0,7,0,0], 2 and 3 answer zeros -> slow path; the command log
+        holds PreAcceptedEntry(Ballot(0,0), Ballot(0,0), triple = ITS OWN answer) at 0, 1, 2, 3 (Replica.scala:688-696,
+        1259-1271); after the tick every index knows X (commit, :815-828);
+      a) replica 0 re-sends PreAccept(X, Ballot(0,0)) to {1, 2, 4}: 1 and 2 have voted in that ballot -> the
+        PreAcceptOk again with the stored dependencies (:1196-1210); 4 has no entry -> processes it (:1170-1172): its
+        index holds X itself, subtractOne(X) takes it out again -> no dependencies;
+      b) replica 2 starts a recovery: Prepare(X, Ballot(1,2)) at 1; the old PreAccept(X, Ballot(0,0)) at 1 is now
+        Nacked with largestBallot (1,2) (:1188-1192);
+      c) PreAccept(X, Ballot(2,3), deps [0,0,0,2,0]) at {1, 2}: larger than every ballot, not the vote ballot ->
+        processed afresh: local conflicts (with X itself removed) U the message's dependencies;
+      d) Accept(X, Ballot(3,4)) by 4 at 1, then PreAccept(X, Ballot(3,4)) at {1, 4}: accepted in that very ballot ->
+        ignored (:1219-1224); PreAccept(X, Ballot(4,0)) at 1: a larger ballot pre-accepts again;
+      e) Accept(X, Ballot(5,2)) at {0, 1, 3} commits X; any PreAccept(X) is answered with the Commit (:1227-1238)."""
+    e = oracle.EPaxos(5, 4, num_instances=16)
+    e.index_put(1, 1, 1, 2, 6)
+    st, fast, deps, ldeps, own = e.preaccept([0], [0], [1], [1], [0b01110], np.zeros((5, 1), np.int32), triple_id=[42])
+    assert st == 0 and fast[0] == 0 and deps[0].tolist() == [0, 0, 7, 0, 0] and ldeps[0].tolist() == [0] * 5
+    assert e.read_cmdlog(1, 0, 0)[:4] == (2, enc(0, 0), enc(0, 0), 42) and e.read_cmdlog(4, 0, 0)[0] == 0
+    assert e.read_cmdlog_deps(1, 0, 0)[0].tolist() == [0, 0, 7, 0, 0] and e.read_cmdlog_deps(0, 0, 0)[0].tolist() == [0] * 5
+    zeros = np.zeros((1, 5), np.int32)
+    # a)
+    st, ok, resend, nack, com, nb, rd, re, rt = e.handle_preaccept([0], [0], [0], [0], [1], [1], [42], zeros, None, [0b10110])
+    assert (st, ok[0], resend[0], nack[0], com[0], nb[0]) == (0, 0b10000, 0b00110, 0, 0, -1)
+    assert rd[0].tolist() == [[0] * 5, [0, 0, 7, 0, 0], [0] * 5, [0] * 5, [0] * 5] and re[0].tolist() == [0] * 5
+    assert rt[0].tolist() == [-1, 42, 42, -1, 42]
+    assert e.read_cmdlog(4, 0, 0) == (2, enc(0, 0), enc(0, 0), 42, enc(0, 4))       # largestBallot stays (0,4) > (0,0)
+    # b)
+    assert e.prepare([0], [0], [1], [2], [0b00010])[1][0] == 0b00010
+    st, ok, resend, nack, com, nb, rd, re, rt = e.handle_preaccept([0], [0], [0], [0], [1], [1], [42], zeros, None, [0b00010])
+    assert (st, ok[0], resend[0], nack[0], com[0], nb[0]) == (0, 0, 0, 0b00010, 0, enc(1, 2))
+    assert rd[0].tolist() == [[0] * 5] * 5 and rt[0].tolist() == [-1] * 5
+    # c)
+    st, ok, resend, nack, com, nb, rd, re, rt = e.handle_preaccept([0], [0], [2], [3], [1], [1], [43], [[0, 0, 0, 2, 0]], None,
+                                                                    [0b00110])
+    assert (st, ok[0], resend[0], nack[0], com[0]) == (0, 0b00110, 0, 0, 0)
+    assert rd[0][1].tolist() == [0, 0, 7, 2, 0] and rd[0][2].tolist() == [0, 0, 0, 2, 0] and re[0].tolist() == [0] * 5
+    assert e.read_cmdlog(1, 0, 0) == (2, enc(2, 3), enc(2, 3), 43, enc(2, 3))
+    assert e.read_cmdlog_deps(1, 0, 0)[0].tolist() == [0, 0, 7, 2, 0]
+    # d)
+    st, ok, nack, com, nb, done = e.accept([0], [0], [3], [4], [44], [0b00010])
+    assert st == 0 and ok[0] == 0b10010 and done[0] == 0
+    st, ok, resend, nack, com, nb, rd, re, rt = e.handle_preaccept([0], [0], [3], [4], [1], [1], [44], zeros, None, [0b10010])
+    assert (st, ok[0], resend[0], nack[0], com[0]) == (0, 0, 0, 0, 0)
+    st, ok, resend, nack, com, nb, rd, re, rt = e.handle_preaccept([0], [0], [4], [0], [1], [1], [45], zeros, None, [0b00010])
+    assert ok[0] == 0b00010 and e.read_cmdlog(1, 0, 0)[:4] == (2, enc(4, 0), enc(4, 0), 45)
+    # e)
+    st, ok, nack, com, nb, done = e.accept([0], [0], [5], [2], [46], [0b01011])
+    assert st == 0 and done[0] == 1
+    st, ok, resend, nack, com, nb, rd, re, rt = e.handle_preaccept([0], [0], [0], [1], [1], [1], [47], zeros, None, [0b11111])
+    assert (st, ok[0], resend[0], nack[0], com[0]) == (0, 0, 0, 0, 0b11111)
+    assert rt[0].tolist() == [46] * 5 and rd[0][:, 0].tolist() == [-1] * 5        # an Accept names its triple by id only
+    # a Noop (key -1) has no conflicts and leaves the index alone (:592-593, 602-614); a fresh instance of leader 3
+    g0, s0 = e.read_index(2, 1)
+    st, ok, resend, nack, com, nb, rd, re, rt = e.handle_preaccept([3], [2], [0], [3], [-1], [0], [50], [[4, 0, 0, 0, 1]], None,
+                                                                    [0b00100])
+    assert ok[0] == 0b00100 and rd[0][2].tolist() == [4, 0, 0, 0, 1]
+    g1, s1 = e.read_index(2, 1)
+    assert g0.tolist() == g1.tolist() and s0.tolist() == s1.tolist()
+    # the hole: replica 3 met (1, 5) on k2 before PreAccept((1, 3)) arrives: dependencies {0,1,2,4,5} of leader 1 =
+    # watermark 3 + explicit values 4 .. 5 (values_end 6); a message that already carries a hole up to 8 widens it
+    e.index_put(3, 2, 1, 1, 5)
+    st, ok, resend, nack, com, nb, rd, re, rt = e.handle_preaccept([1, 1], [3, 2], [0, 0], [1, 1], [2, 2], [0, 0], [60, 61],
+                                                                    [[0, 1, 0, 0, 0], [0, 2, 0, 0, 0]], [0, 9], [0b01000, 0b01000])
+    assert st == 0 and ok.tolist() == [0b01000, 0b01000]
+    assert rd[0][3].tolist() == [0, 3, 0, 0, 0] and re[0][3] == 6
+    assert rd[1][3].tolist() == [0, 2, 0, 0, 0] and re[1][3] == 9
+    # malformed: a PreAccept that depends on its own instance; duplicate instances in one batch; no command log
+    assert e.handle_preaccept([1], [7], [0], [1], [2], [0], [1], [[0, 8, 0, 0, 0]], None, [0b00001])[0] == 1
+    assert e.handle_preaccept([1, 1], [7, 7], [0, 0], [1, 1], [2, 2], [0, 0], [1, 1], np.zeros((2, 5)), None, [1, 1])[0] == 1
+    assert oracle.EPaxos(5, 4).handle_preaccept([1], [7], [0], [1], [2], [0], [1], zeros, None, [1])[0] == 1
+
+
+def _same(a, b):
+    assert a[0] == b[0], (a[0], b[0])
+    for x, y in zip(a[1:], b[1:]):
+        np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.gpu
+def test_epaxos_handle_preaccept_hand_trace_matches_oracle(oracle):
+    """the calls of test_oracle_handle_preaccept_every_branch_by_hand, GPU beside oracle: every reply, the command log
+    with its stored dependencies and the conflict indexes after each step"""
+    from frankenpaxos_amd.epaxos import EPaxos
+    import frankenpaxos_amd as fa
+
+    gpu, ref = EPaxos(5, 4, num_instances=16), oracle.EPaxos(5, 4, num_instances=16)
+    zeros = np.zeros((1, 5), np.int32)
+
+    def state():
+        for r in range(5):
+            for (L, x) in ((0, 0), (3, 2), (1, 3), (1, 2)):
+                assert gpu.read_cmdlog(r, L, x) == ref.read_cmdlog(r, L, x)
+                a, b = gpu.read_cmdlog_deps(r, L, x), ref.read_cmdlog_deps(r, L, x)
+                assert a[0].tolist() == b[0].tolist() and a[1] == b[1]
+            for k in range(4):
+                for x, y in zip(gpu.read_index(r, k), ref.read_index(r, k)):
+                    np.testing.assert_array_equal(x, y)
+
+    # replica 1 alone knows (2, 6) on k1 before anything else
+    for e in (gpu, ref):
+        assert e.handle_preaccept([2], [6], [0], [2], [1], [1], [7], zeros, None, [0b00010])[1][0] == 0b00010
+    tick = ([0], [0], [1], [1], [0b01110], np.zeros((5, 1), np.int32))
+    _same(gpu.preaccept(*tick, triple_id=[42]), ref.preaccept(*tick, triple_id=[42]))
+    state()
+    calls = [
+        ("hp", ([0], [0], [0], [0], [1], [1], [42], zeros, None, [0b10110])),
+        ("prepare", ([0], [0], [1], [2], [0b00010])),
+        ("hp", ([0], [0], [0], [0], [1], [1], [42], zeros, None, [0b00010])),
+        ("hp", ([0], [0], [2], [3], [1], [1], [43], [[0, 0, 0, 2, 0]], None, [0b00110])),
+        ("accept", ([0], [0], [3], [4], [44], [0b00010])),
+        ("hp", ([0], [0], [3], [4], [1], [1], [44], zeros, None, [0b10010])),
+        ("hp", ([0], [0], [4], [0], [1], [1], [45], zeros, None, [0b00010])),
+        ("accept", ([0], [0], [5], [2], [46], [0b01011])),
+        ("hp", ([0], [0], [0], [1], [1], [1], [47], zeros, None, [0b11111])),
+        ("hp", ([3], [2], [0], [3], [-1], [0], [50], [[4, 0, 0, 0, 1]], None, [0b00100])),
+        ("hp", ([1, 1], [3, 2], [0, 0], [1, 1], [2, 2], [0, 0], [60, 61], [[0, 1, 0, 0, 0], [0, 2, 0, 0, 0]], [0, 9],
+                [0b01000, 0b01000])),
+    ]
+    for kind, args in calls:
+        fn = {"hp": "handle_preaccept", "prepare": "prepare", "accept": "accept"}[kind]
+        _same(getattr(gpu, fn)(*args), getattr(ref, fn)(*args))
+        state()
+    assert gpu.handle_preaccept([1], [7], [0], [1], [2], [0], [1], [[0, 8, 0, 0, 0]], None, [0b00001])[0] == fa.FPX_EINVAL
+    assert gpu.handle_preaccept([1, 1], [7, 7], [0, 0], [1, 1], [2, 2], [0, 0], [1, 1], np.zeros((2, 5)), None, [1, 1])[0] == fa.FPX_EINVAL
+    assert EPaxos(5, 4).handle_preaccept([1], [7], [0], [1], [2], [0], [1], zeros, None, [1])[0] == fa.FPX_EINVAL
+    state()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,NI,m,num_keys", [(3, 64, 40, 4), (5, 512, 700, 8), (7, 300, 1500, 3), (5, 4096, 5000, 64)])
+def test_epaxos_handle_preaccept_matches_oracle(oracle, n, NI, m, num_keys):
+    """random PreAccept batches (ballots up and down, arbitrary targets, instances in every command-log state, Noops,
+    dependencies with and without holes) between pre-accept ticks, Prepares and Accepts: every reply, then the whole
+    command log with the stored dependencies and every conflict index, GPU == oracle"""
+    from frankenpaxos_amd.epaxos import EPaxos
+
+    gpu, ref = EPaxos(n, num_keys, num_instances=NI), oracle.EPaxos(n, num_keys, num_instances=NI)
+    rng = np.random.default_rng(n * 131 + NI)
+    nxt = [0] * n
+    seen = {k: 0 for k in ("ok", "resend", "nack", "commit", "ignored", "holes")}
+    for step in range(16):
+        kind = step % 4
+        if kind == 0 and max(nxt) + min(m, 200) // 2 + 8 < NI // 2:
+            mm = min(m, 200)
+            leader, number, key, is_set, mask, rank = random_tick(rng, n, num_keys, mm, nxt, 3.0, fifo=bool(step & 4))
+            tr = rng.integers(0, 1 << 20, mm).astype(np.int32)
+            _same(gpu.preaccept(leader, number, key, is_set, mask, rank, triple_id=tr),
+                  ref.preaccept(leader, number, key, is_set, mask, rank, triple_id=tr))
+            continue
+        leader, number, b_ord, b_rep, tgt = _cl_batch(rng, n, NI, m, nxt)
+        mm = len(leader)
+        if kind == 2 and step % 8 == 2:
+            _same(gpu.prepare(leader, number, b_ord, b_rep, tgt), ref.prepare(leader, number, b_ord, b_rep, tgt))
+            continue
+        if kind == 2:
+            tgt = (tgt & ~(1 << b_rep)).astype(np.uint8)
+            tr = rng.integers(0, 1 << 20, mm).astype(np.int32)
+            a, b = gpu.accept(leader, number, b_ord, b_rep, tr, tgt), ref.accept(leader, number, b_ord, b_rep, tr, tgt)
+            _same(a, b)
+            continue
+        key = rng.integers(-1, num_keys, mm).astype(np.int32)           # -1: Noop
+        is_set = (rng.random(mm) < 0.5).astype(np.uint8)
+        tr = rng.integers(0, 1 << 20, mm).astype(np.int32)
+        din = rng.integers(0, NI, (mm, n)).astype(np.int32)
+        dend = np.zeros(mm, np.int32)
+        own = din[np.arange(mm), leader]
+        hole = rng.random(mm) < 0.3
+        # the own-leader column: a plain watermark <= the instance number, or watermark == number with values above
+        din[np.arange(mm), leader] = np.where(hole, number, np.minimum(own, number))
+        dend[:] = np.where(hole, number + 2 + rng.integers(0, 5, mm), 0)
+        if step % 8 == 5:    # the old leaders' original PreAccepts once more: Ballot(0, leader)
+            b_ord[:], b_rep[:] = 0, leader
+        a = gpu.handle_preaccept(leader, number, b_ord, b_rep, key, is_set, tr, din, dend, tgt)
+        b = ref.handle_preaccept(leader, number, b_ord, b_rep, key, is_set, tr, din, dend, tgt)
+        _same(a, b)
+        st, ok, resend, nack, com, nb, rd, re, rt = a
+        assert st == 0
+        for name, bits in (("ok", ok), ("resend", resend), ("nack", nack), ("commit", com)):
+            seen[name] += int(np.unpackbits(bits).sum())
+        seen["ignored"] += int(np.unpackbits(tgt & ~(ok | resend | nack | com)).sum())
+        seen["holes"] += int((re != 0).sum())
+    assert seen["ok"] > 0 and seen["nack"] > 0 and (m < 500 or all(v > 0 for v in seen.values())), seen
+    for r in range(n):
+        for inst in rng.choice(n * NI, size=min(300, n * NI), replace=False):
+            L, x = int(inst) // NI, int(inst) % NI
+            assert gpu.read_cmdlog(r, L, x) == ref.read_cmdlog(r, L, x)
+            a, b = gpu.read_cmdlog_deps(r, L, x), ref.read_cmdlog_deps(r, L, x)
+            assert a[0].tolist() == b[0].tolist() and a[1] == b[1]
+        for k in range(num_keys):
+            for x, y in zip(gpu.read_index(r, k), ref.read_index(r, k)):
+                np.testing.assert_array_equal(x, y)
