@@ -8,11 +8,14 @@
 //                      at once, on the key bits only (stable => (key, delivery order)); one wavefront owns a
 //                      tile of 1024 consecutive elements and ranks equal digits with 8 ballots per 64 elements
 //   3. k_epx_segments  [lo, hi) of every (replica, key) segment by binary search
-//   4. k_epx_scan<N>   one wavefront per (replica, key): 64 commands per step, wave-level max-scan of the
+//   4. k_epx_key<N>    one workgroup per key, for every key whose commands fit its LDS tables: the scans of all
+//                      replicas' segments of the key (steps 4a / 5a below in one kernel, the conflict rows never
+//                      leave the chip); the other keys go through
+//   4a. k_epx_scan<N>  one wavefront per (replica, key): 64 commands per step, wave-level max-scan of the
 //                      2N watermark columns on the DPP network (row_shr / row_bcast), carry in registers;
 //                      leader and get/set travel in the sort key's spare bits, the answer row is one aligned
 //                      16- / 32-byte store
-//   5. k_epx_decide<N> one thread per command: PreAcceptOk = local conflicts U leader's deps; fast path iff
+//   5a. k_epx_decide<N> one thread per command: PreAcceptOk = local conflicts U leader's deps; fast path iff
 //                      the n-2 answers agree (Util.popularItems), else the union (preAcceptingSlowPath)
 //   6. k_epx_commit    every replica's conflict index learns the tick's instances (commit ->
 //                      updateConflictIndex): elementwise max with what the scans saw of this tick (every
@@ -22,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -78,6 +82,8 @@ struct EpxBatch {
   int32_t* deps;
   int32_t* leader_deps;
   int32_t* own_values_end;  // [m][2]: explicit values of the own-leader column of deps / leader_deps (0 = none)
+  uint8_t* fused;           // [num_keys] or null: 1 = k_epx_key did the key's scan and decisions on chip
+  int32_t* unfused;         // number of keys left to k_epx_scan / k_epx_decide (null: all of them)
 };
 
 constexpr uint32_t EPX_KEY_MASK = (1u << 27) - 1u;
@@ -116,6 +122,7 @@ __device__ __forceinline__ void epx_report(int32_t* status, int code, int index)
 __global__ void __launch_bounds__(256) k_epx_keys(const EpxState st, const EpxBatch b) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b.m) return;
+  if (i == 0 && b.unfused) *b.unfused = 0;
   const int n = st.n;
   const int L = b.leader[i], k = b.key[i];
   const unsigned mask = b.resp_mask[i];
@@ -309,6 +316,27 @@ __global__ void __launch_bounds__(256) k_epx_segments(const EpxState st, const E
   b.seg[(size_t)t * 2 + 1] = lower((uint32_t)(k + 1));
 }
 
+// One chunk of 64 consecutive commands of a (replica, key) segment, one per lane: dep[l] = what the command's
+// conflict lookup returns in column l (exclusive prefix over the chunk + carry), and the carries cg / cs (the
+// replica's TopOne vectors for the key, KeyValueStore.scala:229-230) and ng / ns (this tick's puts alone) move on.
+template <int N>
+__device__ __forceinline__ void scan_chunk(bool valid, bool t, int L, int id1, int* cg, int* cs, int* ng, int* ns, int* dep) {
+#pragma unroll
+  for (int l = 0; l < N; ++l) {
+    // inclusive prefix maxima of this chunk's puts into column l
+    const int ig = wave_incl_max((valid && !t && L == l) ? id1 : 0);
+    const int is = wave_incl_max((valid && t && L == l) ? id1 : 0);
+    // exclusive prefix (the command's own put comes after its conflict lookup) + carry
+    const int eg = imax(wave_shr1(ig), cg[l]);
+    const int es = imax(wave_shr1(is), cs[l]);
+    // KeyValueStore.scala:259-302: a get conflicts with sets, a set with sets and gets
+    dep[l] = t ? imax(es, eg) : es;
+    const int tg = __builtin_amdgcn_readlane(ig, 63), ts = __builtin_amdgcn_readlane(is, 63);
+    cg[l] = imax(cg[l], tg), cs[l] = imax(cs[l], ts);
+    ng[l] = imax(ng[l], tg), ns[l] = imax(ns[l], ts);
+  }
+}
+
 // one wavefront per (replica, key) segment
 template <int N>
 __global__ void __launch_bounds__(256) k_epx_scan(const EpxState st, const EpxBatch b) {
@@ -317,6 +345,7 @@ __global__ void __launch_bounds__(256) k_epx_scan(const EpxState st, const EpxBa
   const int seg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (seg >= N * st.num_keys) return;
   const int r = seg / st.num_keys, k = seg % st.num_keys;
+  if (b.unfused && (*b.unfused == 0 || b.fused[k])) return;  // k_epx_key did this key on chip
   const int lo = b.seg[(size_t)seg * 2], hi = b.seg[(size_t)seg * 2 + 1];
   const uint2* kvs = b.kv_sorted + (size_t)r * b.m;
   constexpr int NP = ConfRow<N>::NP;
@@ -347,20 +376,7 @@ __global__ void __launch_bounds__(256) k_epx_scan(const EpxState st, const EpxBa
     int dep[NP];
 #pragma unroll
     for (int l = 0; l < NP; ++l) dep[l] = 0;
-#pragma unroll
-    for (int l = 0; l < N; ++l) {
-      // inclusive prefix maxima of this chunk's puts into column l
-      const int ig = wave_incl_max((valid && !t && L == l) ? id1 : 0);
-      const int is = wave_incl_max((valid && t && L == l) ? id1 : 0);
-      // exclusive prefix (the command's own put comes after its conflict lookup) + carry
-      const int eg = imax(wave_shr1(ig), cg[l]);
-      const int es = imax(wave_shr1(is), cs[l]);
-      // KeyValueStore.scala:259-302: a get conflicts with sets, a set with sets and gets
-      dep[l] = t ? imax(es, eg) : es;
-      const int tg = __builtin_amdgcn_readlane(ig, 63), ts = __builtin_amdgcn_readlane(is, 63);
-      cg[l] = imax(cg[l], tg), cs[l] = imax(cs[l], ts);
-      ng[l] = imax(ng[l], tg), ns[l] = imax(ns[l], ts);
-    }
+    scan_chunk<N>(valid, t, L, id1, cg, cs, ng, ns, dep);
     if (valid) {
       int4* row = reinterpret_cast<int4*>(b.conf + ((size_t)i * N + r) * NP);
       row[0] = make_int4(dep[0], dep[1], dep[2], dep[3]);
@@ -374,45 +390,15 @@ __global__ void __launch_bounds__(256) k_epx_scan(const EpxState st, const EpxBa
   }
 }
 
-template <int N>
-__device__ __forceinline__ void epx_decide_one(const EpxState& st, const EpxBatch& b, int i, int* out_deps, int* out_ldeps);
-
-// one thread per command; the n-wide dependency rows leave through LDS as contiguous lines (m x n ints written
-// by 256 threads with a stride of n ints were 5 strided store instructions per wave)
-template <int N>
-__global__ void __launch_bounds__(256) k_epx_decide(const EpxState st, const EpxBatch b) {
-  __shared__ int out_deps[256 * N], out_ldeps[256 * N];
-  if (st.status[0] != 0) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < b.m) epx_decide_one<N>(st, b, i, out_deps, out_ldeps);
-  __syncthreads();
-  const size_t base = (size_t)blockIdx.x * blockDim.x * N;
-  const size_t end = (size_t)b.m * N;
-  for (int k = threadIdx.x; k < 256 * N; k += 256) {
-    if (base + k < end) {
-      if (b.deps) b.deps[base + k] = out_deps[k];
-      if (b.leader_deps) b.leader_deps[base + k] = out_ldeps[k];
-    }
-  }
-}
-
-template <int N>
-__device__ __forceinline__ void epx_decide_one(const EpxState& st, const EpxBatch& b, int i, int* out_deps, int* out_ldeps) {
-  const int L = b.leader[i];
-  const unsigned mask = b.resp_mask[i];
-  constexpr int NP = ConfRow<N>::NP;
-  const int32_t* c = b.conf + (size_t)i * N * NP;
-  auto load_row = [&](int r, int* out) {
-    const int4* row = reinterpret_cast<const int4*>(c + r * NP);
-    const int4 a = row[0];
-    int tmp[8] = {a.x, a.y, a.z, a.w, 0, 0, 0, 0};
-    if constexpr (NP == 8) {
-      const int4 b2 = row[1];
-      tmp[4] = b2.x, tmp[5] = b2.y, tmp[6] = b2.z, tmp[7] = b2.w;
-    }
-#pragma unroll
-    for (int l = 0; l < N; ++l) out[l] = tmp[l];
-  };
+// handlePreAcceptOk for one command (Replica.scala:1291-1419): the leader's own conflicts D become the PreAccept's
+// dependencies, every responder answers its conflicts U D (handlePreAccept :1257-1262), the fast path needs the n-2
+// answers identical (popularItems), the slow path proposes their union (preAcceptingSlowPath :796-813).
+// load_row(r, out[N]) yields replica r's conflicts for the command.  Writes the command log (if kept); returns the
+// decision in o_deps / o_ldeps (watermarks, own column re-encoded) and o_end[2].
+template <int N, typename Rows>
+__device__ __forceinline__ bool epx_decide_core(const EpxState& st, const EpxBatch& b, int i, int L, unsigned mask,
+                                                unsigned seen_in, int x, Rows&& load_row, int* o_deps, int* o_ldeps,
+                                                int* o_end) {
   int D[N], uni[N], first[N];
   load_row(L, D);
 #pragma unroll
@@ -433,7 +419,6 @@ __device__ __forceinline__ void epx_decide_one(const EpxState& st, const EpxBatc
     if (have_first) all_equal = all_equal && same;
     have_first = true;
   }
-  if (b.fast) b.fast[i] = all_equal ? 1 : 0;
   // dependencies.subtractOne(instance) (Replica.scala:582, compact/IntPrefixSet.scala:388-398) only touches the
   // column of the instance's own leader: with w = that column's watermark before the subtraction and x the
   // instance number, the set is {0 .. w-1} \ {x}: (watermark w, no values) if x >= w, else (watermark x,
@@ -444,11 +429,10 @@ __device__ __forceinline__ void epx_decide_one(const EpxState& st, const EpxBatc
     // the command log: a fast-path commit is a CommittedEntry at every replica (commit :815-823, Commit to the
     // others); otherwise every replica that processed the PreAccept holds PreAcceptedEntry(Ballot(0, leader),
     // Ballot(0, leader), triple) (:688-696, :1259-1271) for the Accept phase to find
-    const unsigned seen = (b.seen_mask ? b.seen_mask[i] : mask) | (1u << L);
+    const unsigned seen = seen_in | (1u << L);
     const int tr = b.triple ? b.triple[i] : -1;
-    const int xi = b.number[i];
     for (int r = 0; r < N; ++r) {
-      const size_t c = ((size_t)r * N + L) * st.num_instances + xi;
+      const size_t c = ((size_t)r * N + L) * st.num_instances + x;
       if (!all_equal && !((seen >> r) & 1u)) continue;
       // the triple's dependencies: the agreed ones (fast path, committed everywhere), else what THIS replica
       // answered (its conflicts U the PreAccept's, :1257-1271) / what the leader proposed (:688-696)
@@ -468,7 +452,7 @@ __device__ __forceinline__ void epx_decide_one(const EpxState& st, const EpxBatc
       int wm = 0, end = 0;
 #pragma unroll
       for (int l = 0; l < N; ++l)
-        if (l == L) own_column(t[l], xi, &wm, &end);
+        if (l == L) own_column(t[l], x, &wm, &end);
 #pragma unroll
       for (int l = 0; l < N; ++l) st.cl_deps[c * N + l] = l == L ? wm : t[l];
       st.cl_dend[c] = end;
@@ -479,19 +463,249 @@ __device__ __forceinline__ void epx_decide_one(const EpxState& st, const EpxBatc
       }
     }
   }
-  const int x = b.number[i];
+  o_end[0] = 0, o_end[1] = 0;
 #pragma unroll
   for (int l = 0; l < N; ++l) {
     const int w = all_equal ? first[l] : uni[l];
     int ow = w, oe = 0, lw = D[l], le = 0;
-    if (l == L) own_column(w, x, &ow, &oe), own_column(D[l], x, &lw, &le);
-    out_deps[threadIdx.x * N + l] = ow;
-    out_ldeps[threadIdx.x * N + l] = lw;
-    if (l == L && b.own_values_end) {
-      b.own_values_end[(size_t)i * 2] = oe;
-      b.own_values_end[(size_t)i * 2 + 1] = le;
+    if (l == L) {
+      own_column(w, x, &ow, &oe), own_column(D[l], x, &lw, &le);
+      o_end[0] = oe, o_end[1] = le;
+    }
+    o_deps[l] = ow;
+    o_ldeps[l] = lw;
+  }
+  return all_equal;
+}
+
+// one thread per command; the n-wide dependency rows leave through LDS as contiguous lines (m x n ints written
+// by 256 threads with a stride of n ints were 5 strided store instructions per wave)
+template <int N>
+__global__ void __launch_bounds__(256) k_epx_decide(const EpxState st, const EpxBatch b) {
+  __shared__ int out_deps[256 * N], out_ldeps[256 * N];
+  __shared__ uint8_t did[256];
+  if (st.status[0] != 0) return;
+  if (b.unfused && *b.unfused == 0) return;  // k_epx_key decided every key on chip
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool mine = i < b.m && !(b.unfused && b.fused[b.key[i]]);
+  did[threadIdx.x] = mine ? 1 : 0;
+  if (mine) {
+    constexpr int NP = ConfRow<N>::NP;
+    const int32_t* c = b.conf + (size_t)i * N * NP;
+    auto load_row = [&](int r, int* out) {
+      const int4* row = reinterpret_cast<const int4*>(c + r * NP);
+      const int4 a = row[0];
+      int tmp[8] = {a.x, a.y, a.z, a.w, 0, 0, 0, 0};
+      if constexpr (NP == 8) {
+        const int4 b2 = row[1];
+        tmp[4] = b2.x, tmp[5] = b2.y, tmp[6] = b2.z, tmp[7] = b2.w;
+      }
+#pragma unroll
+      for (int l = 0; l < N; ++l) out[l] = tmp[l];
+    };
+    int od[N], ol[N], oe[2];
+    const unsigned mask = b.resp_mask[i];
+    const bool fast = epx_decide_core<N>(st, b, i, b.leader[i], mask, b.seen_mask ? b.seen_mask[i] : mask, b.number[i],
+                                         load_row, od, ol, oe);
+    if (b.fast) b.fast[i] = fast ? 1 : 0;
+    if (b.own_values_end) b.own_values_end[(size_t)i * 2] = oe[0], b.own_values_end[(size_t)i * 2 + 1] = oe[1];
+#pragma unroll
+    for (int l = 0; l < N; ++l) out_deps[threadIdx.x * N + l] = od[l], out_ldeps[threadIdx.x * N + l] = ol[l];
+  }
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * blockDim.x * N;
+  for (int k = threadIdx.x; k < 256 * N; k += 256) {
+    if (did[k / N]) {
+      if (b.deps) b.deps[base + k] = out_deps[k];
+      if (b.leader_deps) b.leader_deps[base + k] = out_ldeps[k];
     }
   }
+}
+
+// ---- scan + decide of ONE key on chip ------------------------------------------------------------------------
+// k_epx_scan hands every (command, replica) conflict row to k_epx_decide through HBM at [command][replica]: n * m
+// rows written in (key, delivery order), i.e. at random -- 5 M random row writes are ~70 us on this GPU whatever
+// their size (profiles/r02_random_rows.txt).  Here one workgroup owns a key: wavefront r scans replica r's segment
+// of the key, the rows stay in LDS ([command of the key][replica][column]), and the same workgroup decides the
+// key's commands; only the decisions cross to message-index order.  A command gets its slot in the LDS tables from
+// the wavefront of its LEADER's replica (every command is in its leader's segment exactly once); the other
+// wavefronts find the slot through an LDS hash table on the message index.  A key with more commands than the
+// tables hold (KeyTile<N>::TC) is left to k_epx_scan / k_epx_decide (b.fused[k] = 0), so skewed workloads stay
+// correct and merely lose the shortcut on their hot keys.
+template <int N> struct KeyTile {
+  static constexpr int TC = N <= 3 ? 2048 : N <= 5 ? 1152 : 576;   // commands of one key held on chip
+  static constexpr int HC = N <= 3 ? 4096 : N <= 5 ? 2048 : 1024;  // hash slots: a power of two, load <= 0.57
+  static constexpr int W = N <= 3 ? 4 : N <= 5 ? 3 : 2;             // wavefronts per replica segment
+  static constexpr int MAXC = (TC + 63) / 64;                       // 64-command chunks of one segment
+  static constexpr int CPW = (MAXC + W - 1) / W;                    // chunks per wavefront
+  static constexpr int THREADS = 64 * N * W;
+  static constexpr int IDX_BITS = 11;                               // TC <= 2048
+  static constexpr size_t BYTES =
+      (size_t)TC * N * N * 4 + (size_t)HC * 4 + (size_t)TC * 4 * 3 + (size_t)N * TC * 2 + (size_t)N * W * 2 * N * 4 + 64;
+};
+
+template <int N>
+__global__ void __launch_bounds__(KeyTile<N>::THREADS) k_epx_key(const EpxState st, const EpxBatch b) {
+  using T = KeyTile<N>;
+  extern __shared__ __align__(16) unsigned char smem[];
+  int* rows = reinterpret_cast<int*>(smem);                                   // [TC][N replicas][N columns]
+  uint32_t* hk = reinterpret_cast<uint32_t*>(rows + (size_t)T::TC * N * N);   // (message index + 1) << 11 | slot
+  int* list_i = reinterpret_cast<int*>(hk + T::HC);                           // slot -> message index
+  int* num = list_i + T::TC;                                                  // slot -> instance number
+  uint32_t* msk = reinterpret_cast<uint32_t*>(num + T::TC);                   // slot -> resp_mask | seen << 8 | leader << 16
+  uint16_t* stage = reinterpret_cast<uint16_t*>(msk + T::TC);                 // [N][TC] slot | is_set << 11 | leader << 12
+  int* tot = reinterpret_cast<int*>(stage + (size_t)N * T::TC);               // [N][W][2N] puts of a wavefront's chunks
+  int* ctl = tot + N * T::W * 2 * N;                                          // [0] slots handed out, [1] give up
+  if (st.status[0] != 0) return;
+  const int k = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = wave / T::W, w = wave - r * T::W;  // replica, part of its segment
+  const int seg = r * st.num_keys + k;
+  const int lo = b.seg[(size_t)seg * 2], hi = b.seg[(size_t)seg * 2 + 1], len = hi - lo;
+  const int cpw = ((len + 63) / 64 + T::W - 1) / T::W;  // chunks per wavefront of THIS segment
+  const int first = w * cpw * 64;                       // where this wavefront's part starts
+  // the replica's TopOne vectors for this key: requested now, needed in the scan
+  int cg[N], cs[N];
+  {
+    const size_t ib = ((size_t)r * st.num_keys + k) * N;
+#pragma unroll
+    for (int l = 0; l < N; ++l) cg[l] = st.gets[ib + l], cs[l] = st.sets[ib + l];
+  }
+  for (int j = threadIdx.x; j < T::HC; j += T::THREADS) hk[j] = 0;
+  for (int j = threadIdx.x; j < N * T::W * 2 * N + 2; j += T::THREADS) tot[j] = 0;  // tot and ctl
+  __syncthreads();
+  if (len > T::MAXC * 64 && lane == 0) ctl[1] = 1;
+  // this wavefront's sort pairs in one go (one memory round trip, not one per chunk)
+  const uint2* kvs = b.kv_sorted + (size_t)r * b.m + lo;
+  uint2 kvq[T::CPW];
+  bool have[T::CPW];
+#pragma unroll
+  for (int c = 0; c < T::CPW; ++c) {
+    const int p = first + c * 64 + lane;
+    have[c] = c < cpw && p < len;
+    kvq[c] = have[c] ? kvs[p] : make_uint2(0u, 0u);
+  }
+  // the wavefronts of the leader's replica hand out the slots of the commands it leads
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  int myslot[T::CPW];
+#pragma unroll
+  for (int c = 0; c < T::CPW; ++c) {
+    const bool own = have[c] && (int)(kvq[c].x >> EPX_LEADER_SHIFT) == r;
+    const unsigned long long bal = __ballot(own);
+    int base = 0;
+    if (bal) {
+      if (lane == 0) base = atomicAdd(&ctl[0], (int)__popcll(bal));
+      base = __builtin_amdgcn_readfirstlane(base);
+    }
+    myslot[c] = own ? base + (int)__popcll(bal & lt) : -1;
+  }
+  // what the decisions need of each led command, gathered by message index: all requests go out before the first
+  // one is used (a gather inside the insert loop below would be one memory round trip per chunk)
+  int gnum[T::CPW];
+  unsigned gmask[T::CPW];
+#pragma unroll
+  for (int c = 0; c < T::CPW; ++c) {
+    gnum[c] = 0, gmask[c] = 0;
+    if (myslot[c] >= 0) {
+      const int i = (int)kvq[c].y;
+      const unsigned mask = b.resp_mask[i];
+      gnum[c] = b.number[i];
+      gmask[c] = mask | ((b.seen_mask ? (unsigned)b.seen_mask[i] : mask) << 8);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < T::CPW; ++c) {
+    const int sl = myslot[c];
+    if (sl >= T::TC) ctl[1] = 1;
+    if (sl >= 0 && sl < T::TC) {
+      const int i = (int)kvq[c].y;
+      list_i[sl] = i;
+      num[sl] = gnum[c];
+      msk[sl] = gmask[c] | ((unsigned)r << 16);
+      const uint32_t word = ((uint32_t)(i + 1) << T::IDX_BITS) | (uint32_t)sl;
+      uint32_t h = ((uint32_t)i * 2654435761u >> 12) & (T::HC - 1);
+      while (atomicCAS(&hk[h], 0u, word) != 0u) h = (h + 1) & (T::HC - 1);
+    }
+  }
+  __syncthreads();
+  if (ctl[1]) {  // more commands than the tables hold: the key goes the long way
+    if (threadIdx.x == 0) b.fused[k] = 0, atomicAdd(b.unfused, 1);
+    return;
+  }
+  // every command finds its slot; the scan below only needs (slot, is_set, leader) per lane.  The puts of this
+  // wavefront's part (per column the largest id + 1) are the carry of the parts behind it.
+  uint16_t* mystage = stage + (size_t)r * T::TC + first;
+  int* mytot = tot + (r * T::W + w) * 2 * N;
+#pragma unroll
+  for (int c = 0; c < T::CPW; ++c) {
+    if (have[c]) {
+      const uint32_t want = kvq[c].y + 1u;
+      uint32_t h = (kvq[c].y * 2654435761u >> 12) & (T::HC - 1);
+      uint32_t wd = hk[h];
+      while ((wd >> T::IDX_BITS) != want) h = (h + 1) & (T::HC - 1), wd = hk[h];
+      const uint32_t sl = wd & ((1u << T::IDX_BITS) - 1u);
+      const uint32_t flags = kvq[c].x >> EPX_SET_SHIFT;  // bit 0 is_set, bits 1.. leader
+      mystage[c * 64 + lane] = (uint16_t)(sl | (flags << T::IDX_BITS));
+      atomicMax(&mytot[(flags & 1u) * N + (flags >> 1)], num[sl] + 1);
+    }
+  }
+  __syncthreads();
+  for (int w2 = 0; w2 < w; ++w2) {
+    const int* o = tot + (r * T::W + w2) * 2 * N;
+#pragma unroll
+    for (int l = 0; l < N; ++l) cg[l] = imax(cg[l], o[l]), cs[l] = imax(cs[l], o[N + l]);
+  }
+  if (w == 0 && lane == 0) {  // what the commit teaches the other replicas: this tick's puts alone
+    int32_t* out = b.tick + (size_t)seg * 2 * N;
+    for (int l = 0; l < 2 * N; ++l) {
+      int v = 0;
+      for (int w2 = 0; w2 < T::W; ++w2) v = imax(v, tot[(r * T::W + w2) * 2 * N + l]);
+      out[l] = v;
+    }
+  }
+  int ng[N], ns[N];
+#pragma unroll
+  for (int l = 0; l < N; ++l) ng[l] = 0, ns[l] = 0;
+  for (int base = 0; base < cpw * 64 && first + base < len; base += 64) {
+    const bool valid = first + base + lane < len;
+    const unsigned code = valid ? mystage[base + lane] : 0u;
+    const int sl = (int)(code & ((1u << T::IDX_BITS) - 1u));
+    const bool t = (code >> T::IDX_BITS) & 1u;
+    const int L = (int)(code >> (T::IDX_BITS + 1));
+    const int id1 = valid ? num[sl] + 1 : 0;  // TopOne.put: max(.., id + 1), util/TopOne.scala:12-15
+    int dep[N];
+    scan_chunk<N>(valid, t, L, id1, cg, cs, ng, ns, dep);
+    if (valid) {
+#pragma unroll
+      for (int l = 0; l < N; ++l) rows[((size_t)sl * N + r) * N + l] = dep[l];
+    }
+  }
+  __syncthreads();
+  const int count = ctl[0];
+  for (int sl = threadIdx.x; sl < count; sl += T::THREADS) {
+    const int i = list_i[sl];
+    const unsigned mw = msk[sl];
+    auto load_row = [&](int rr, int* out) {
+#pragma unroll
+      for (int l = 0; l < N; ++l) out[l] = rows[((size_t)sl * N + rr) * N + l];
+    };
+    int od[N], ol[N], oe[2];
+    const bool fast = epx_decide_core<N>(st, b, i, (int)(mw >> 16), mw & 0xffu, (mw >> 8) & 0xffu, num[sl], load_row, od,
+                                         ol, oe);
+    if (b.fast) b.fast[i] = fast ? 1 : 0;
+    if (b.own_values_end) *reinterpret_cast<int2*>(b.own_values_end + (size_t)i * 2) = make_int2(oe[0], oe[1]);
+    // the command's rows are spent: its decision takes their place, to leave below as whole n-int lines (one store
+    // instruction per column and thread here would touch 64 different lines each)
+#pragma unroll
+    for (int l = 0; l < N; ++l) rows[((size_t)sl * N + 0) * N + l] = od[l], rows[((size_t)sl * N + 1) * N + l] = ol[l];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < count * N; t += T::THREADS) {
+    const int sl = t / N, l = t - sl * N;
+    const size_t o = (size_t)list_i[sl] * N + l;
+    if (b.deps) b.deps[o] = rows[((size_t)sl * N + 0) * N + l];
+    if (b.leader_deps) b.leader_deps[o] = rows[((size_t)sl * N + 1) * N + l];
+  }
+  if (threadIdx.x == 0) b.fused[k] = 1;
 }
 
 __global__ void __launch_bounds__(256) k_epx_commit(const EpxState st, const EpxBatch b) {
@@ -870,7 +1084,7 @@ struct fpx_epx {
   EpxState st;
   hipStream_t stream = nullptr, own_stream = nullptr;
   int last_hip = 0;
-  Buf kv, kv2, seg, conf, tmp, tick, h_leader, h_number, h_key, h_set, h_mask, h_seen, h_rank, h_triple, o_fast, o_deps, o_ldeps, o_own, cl, hp;
+  Buf kv, kv2, seg, conf, tmp, tick, h_leader, h_number, h_key, h_set, h_mask, h_seen, h_rank, h_triple, o_fast, o_deps, o_ldeps, o_own, cl, hp, fusedb;
   uint32_t cl_run = 0;
 };
 
@@ -910,6 +1124,17 @@ int grow(fpx_epx* e, Buf* b, size_t bytes) {
 template <int N>
 void launch_scan_decide(fpx_epx* e, const EpxBatch& b) {
   const int segs = N * e->st.num_keys;
+  if (b.fused) {
+    // keys whose commands fit the on-chip tables are scanned and decided by one workgroup each; the two kernels
+    // below then only see what is left (usually nothing: they return at once)
+    static bool allowed = false;  // per instantiation
+    if (!allowed) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_epx_key<N>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)KeyTile<N>::BYTES);
+      allowed = true;
+    }
+    hipLaunchKernelGGL((k_epx_key<N>), dim3(e->st.num_keys), dim3(KeyTile<N>::THREADS), KeyTile<N>::BYTES, e->stream, e->st, b);
+  }
   hipLaunchKernelGGL((k_epx_scan<N>), dim3((segs + 3) / 4), dim3(256), 0, e->stream, e->st, b);
   hipLaunchKernelGGL((k_epx_decide<N>), dim3((b.m + 255) / 256), dim3(256), 0, e->stream, e->st, b);
 }
@@ -1025,7 +1250,7 @@ int32_t fpx_epx_destroy(fpx_epx* e) {
     if (p) (void)hipFree(p);
   Buf* bs[] = {&e->kv, &e->kv2, &e->seg, &e->conf, &e->tmp, &e->tick, &e->h_leader, &e->h_number,
                &e->h_key, &e->h_set, &e->h_mask, &e->h_seen, &e->h_rank, &e->h_triple, &e->o_fast, &e->o_deps, &e->o_ldeps,
-               &e->o_own, &e->cl, &e->hp};
+               &e->o_own, &e->cl, &e->hp, &e->fusedb};
   for (Buf* b : bs)
     if (b->p) (void)hipFree(b->p);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -1078,6 +1303,12 @@ int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, co
   b.tick = (int32_t*)e->tick.p;
   b.seg = (int32_t*)e->seg.p, b.conf = (int32_t*)e->conf.p;
   b.fast = d_fast, b.deps = d_deps, b.leader_deps = d_leader_deps, b.own_values_end = d_own_values_end;
+  // the per-key on-chip path (k_epx_key): message indices must fit its 21-bit hash words, one workgroup per key
+  if (m < (1 << 21) - 1 && e->st.num_keys <= (1 << 16) && !getenv("FPX_EPX_NO_KEY_TILES")) {
+    if ((rc = grow(e, &e->fusedb, (size_t)e->st.num_keys + 64))) return rc;
+    b.unfused = (int32_t*)e->fusedb.p;
+    b.fused = (uint8_t*)e->fusedb.p + 64;
+  }
   // (counting the first pass's histogram in k_epx_keys with global atomics was tried: 5 M atomics on 327 k counters
   // took 450 us against 22 us for the histogram kernel)
   hipLaunchKernelGGL(k_epx_keys, dim3((m + 255) / 256), dim3(256), 0, e->stream, e->st, b);

@@ -803,3 +803,39 @@ def test_epaxos_handle_preaccept_matches_oracle(oracle, n, NI, m, num_keys):
         for k in range(num_keys):
             for x, y in zip(gpu.read_index(r, k), ref.read_index(r, k)):
                 np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,hot,NI", [(5, 6000, 0.5, 0), (5, 6000, 0.5, 4096), (3, 9000, 0.4, 0), (7, 4000, 0.3, 2048),
+                                         (5, 3000, 0.0, 2048)])
+def test_epaxos_hot_keys_take_the_long_way(oracle, n, m, hot, NI):
+    """a key with more commands per tick than the on-chip tables of k_epx_key hold (1152 at n = 5) is left to
+    k_epx_scan / k_epx_decide while the other keys of the same tick are scanned and decided on chip: a hot key that
+    draws `hot` of the tick beside 63 cold ones, with and without the command log -- every output, the stored
+    dependencies and the conflict indexes, GPU == oracle"""
+    from frankenpaxos_amd.epaxos import EPaxos
+
+    num_keys = 64
+    gpu, ref = EPaxos(n, num_keys, num_instances=NI), oracle.EPaxos(n, num_keys, num_instances=NI)
+    rng = np.random.default_rng(n * 77 + m)
+    nxt = [0] * n
+    for tick in range(3):
+        leader, number, key, is_set, mask, rank = random_tick(rng, n, num_keys, m, nxt, 8.0, fifo=bool(tick & 1))
+        key = np.where(rng.random(m) < hot, 5, key).astype(np.int32)
+        if NI and max(nxt) >= NI:
+            break
+        tr = rng.integers(0, 1 << 20, m).astype(np.int32) if NI else None
+        a = gpu.preaccept(leader, number, key, is_set, mask, rank, triple_id=tr)
+        b = ref.preaccept(leader, number, key, is_set, mask, rank, triple_id=tr)
+        _same(a, b)
+        assert a[0] == 0
+    for r in range(n):
+        for k in range(num_keys):
+            for x, y in zip(gpu.read_index(r, k), ref.read_index(r, k)):
+                np.testing.assert_array_equal(x, y)
+        if NI:
+            for inst in rng.choice(n * NI, size=400, replace=False):
+                L, x = int(inst) // NI, int(inst) % NI
+                assert gpu.read_cmdlog(r, L, x) == ref.read_cmdlog(r, L, x)
+                c, d = gpu.read_cmdlog_deps(r, L, x), ref.read_cmdlog_deps(r, L, x)
+                assert c[0].tolist() == d[0].tolist() and c[1] == d[1]
