@@ -1086,6 +1086,7 @@ struct fpx_epx {
   int last_hip = 0;
   Buf kv, kv2, seg, conf, tmp, tick, h_leader, h_number, h_key, h_set, h_mask, h_seen, h_rank, h_triple, o_fast, o_deps, o_ldeps, o_own, cl, hp, fusedb;
   uint32_t cl_run = 0;
+  bool lds_allowed = false;
 };
 
 namespace {
@@ -1127,11 +1128,10 @@ void launch_scan_decide(fpx_epx* e, const EpxBatch& b) {
   if (b.fused) {
     // keys whose commands fit the on-chip tables are scanned and decided by one workgroup each; the two kernels
     // below then only see what is left (usually nothing: they return at once)
-    static bool allowed = false;  // per instantiation
-    if (!allowed) {
+    if (!e->lds_allowed) {  // more than the default 64 KiB of LDS needs an opt-in, per device: once per context
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_epx_key<N>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)KeyTile<N>::BYTES);
-      allowed = true;
+      e->lds_allowed = true;
     }
     hipLaunchKernelGGL((k_epx_key<N>), dim3(e->st.num_keys), dim3(KeyTile<N>::THREADS), KeyTile<N>::BYTES, e->stream, e->st, b);
   }

@@ -79,6 +79,23 @@ object Native {
                            respMask: Array[Byte], seenMask: Array[Byte], rank: Array[Int],
                            fast: Array[Byte], deps: Array[Int], leaderDeps: Array[Int],
                            ownValuesEnd: Array[Int]): Int
+  // EPaxos on the command log (Replica.cmdLog): Prepare, Accept, handlePreAccept with ballots / Nacks / re-sent
+  // replies.  replies packs the per-message reply bit sets back to back (m bytes each), see fpx_jni.c
+  @native def epxCreateWithLog(numReplicas: Int, numKeys: Int, device: Int, numInstances: Int): Long
+  @native def epxPrepare(handle: Long, m: Int, numReplicas: Int, leader: Array[Int], number: Array[Int],
+                         ballotOrdering: Array[Int], ballotReplica: Array[Int], targetMask: Array[Byte],
+                         replies: Array[Byte], nackBallot: Array[Int], prepareOk: Array[Int]): Int
+  @native def epxAccept(handle: Long, m: Int, leader: Array[Int], number: Array[Int],
+                        ballotOrdering: Array[Int], ballotReplica: Array[Int], tripleId: Array[Int],
+                        targetMask: Array[Byte], replies: Array[Byte], nackBallot: Array[Int]): Int
+  @native def epxHandlePreaccept(handle: Long, m: Int, numReplicas: Int, leader: Array[Int],
+                                 number: Array[Int], ballotOrdering: Array[Int],
+                                 ballotReplica: Array[Int], key: Array[Int], isSet: Array[Byte],
+                                 tripleId: Array[Int], depsIn: Array[Int], depsInValuesEnd: Array[Int],
+                                 targetMask: Array[Byte], replies: Array[Byte], nackBallot: Array[Int],
+                                 replyDeps: Array[Int], replyEndTriple: Array[Int]): Int
+  @native def epxReadCmdlog(handle: Long, numReplicas: Int, replica: Int, leader: Int, number: Int,
+                            entry: Array[Int]): Int
   // multi-GPU: one context per GPU, one RCCL communicator over them (fpx_comm_*); the 128-byte id of
   // commUniqueId travels to the other ranks over the actors' own transport
   @native def commUniqueId(id: Array[Byte]): Int

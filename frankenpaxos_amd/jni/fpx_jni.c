@@ -379,6 +379,111 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxPreaccept(
   return st;
 }
 
+/* ---- EPaxos on the command log: Prepare / Accept / handlePreAccept in full (epaxos/Replica.scala:732-860,
+ * 1159-1289, 1421-1565, 1632-1757); a context with a command log of numInstances instances per leader */
+JNIEXPORT jlong JNICALL Java_frankenpaxos_gpu_Native_epxCreateWithLog(JNIEnv* env, jclass cls, jint numReplicas,
+                                                                      jint numKeys, jint device, jint numInstances) {
+  fpx_epx_config cfg = {numReplicas, numKeys, device, 0, numInstances};
+  fpx_epx* e = NULL;
+  int32_t st = fpx_epx_create(&cfg, &e);
+  return st == FPX_OK ? (jlong)(intptr_t)e : -(jlong)st;
+}
+
+/* replies = okBits | nackBits | commitBits (3 x m bytes); nackBallot m ints; prepareOk = status | voteBallot |
+ * triple (3 x m x n ints) */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxPrepare(JNIEnv* env, jclass cls, jlong h, jint m,
+                                                               jint numReplicas, jintArray leader, jintArray number,
+                                                               jintArray ballotOrdering, jintArray ballotReplica,
+                                                               jbyteArray targetMask, jbyteArray replies,
+                                                               jintArray nackBallot, jintArray prepareOk) {
+  if (m < 0 || numReplicas < 3) return FPX_EINVAL;
+  if (m == 0) return FPX_OK;
+  const jlong mn = (jlong)m * numReplicas;
+  if (!has(env, leader, m) || !has(env, number, m) || !has(env, ballotOrdering, m) || !has(env, ballotReplica, m) ||
+      !has(env, targetMask, m) || !opt(env, replies, 3 * (jlong)m) || !opt(env, nackBallot, m) || !opt(env, prepareOk, 3 * mn))
+    return FPX_EINVAL;
+  jint *l = in_ints(env, leader, m), *nu = in_ints(env, number, m), *bo = in_ints(env, ballotOrdering, m),
+       *br = in_ints(env, ballotReplica, m);
+  jbyte* tg = in_bytes(env, targetMask, m);
+  jbyte* rp = out_buf(replies, 3 * (jlong)m, 1);
+  jint *nb = out_buf(nackBallot, m, 4), *po = out_buf(prepareOk, 3 * mn, 4);
+  uint8_t* r8 = (uint8_t*)rp;
+  int32_t st = fpx_epx_prepare((fpx_epx*)(intptr_t)h, m, l, nu, bo, br, (const uint8_t*)tg, r8, r8 ? r8 + m : NULL,
+                               r8 ? r8 + 2 * (size_t)m : NULL, nb, po, po ? po + mn : NULL, po ? po + 2 * mn : NULL);
+  put_bytes(env, replies, 3 * (jlong)m, rp); put_ints(env, nackBallot, m, nb); put_ints(env, prepareOk, 3 * mn, po);
+  free(l); free(nu); free(bo); free(br); free(tg); free(rp); free(nb); free(po);
+  return st;
+}
+
+/* replies = okBits | nackBits | commitBits | committed (4 x m bytes) */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxAccept(JNIEnv* env, jclass cls, jlong h, jint m, jintArray leader,
+                                                              jintArray number, jintArray ballotOrdering,
+                                                              jintArray ballotReplica, jintArray tripleId,
+                                                              jbyteArray targetMask, jbyteArray replies,
+                                                              jintArray nackBallot) {
+  if (m < 0) return FPX_EINVAL;
+  if (m == 0) return FPX_OK;
+  if (!has(env, leader, m) || !has(env, number, m) || !has(env, ballotOrdering, m) || !has(env, ballotReplica, m) ||
+      !has(env, tripleId, m) || !has(env, targetMask, m) || !opt(env, replies, 4 * (jlong)m) || !opt(env, nackBallot, m))
+    return FPX_EINVAL;
+  jint *l = in_ints(env, leader, m), *nu = in_ints(env, number, m), *bo = in_ints(env, ballotOrdering, m),
+       *br = in_ints(env, ballotReplica, m), *tr = in_ints(env, tripleId, m);
+  jbyte* tg = in_bytes(env, targetMask, m);
+  jbyte* rp = out_buf(replies, 4 * (jlong)m, 1);
+  jint* nb = out_buf(nackBallot, m, 4);
+  uint8_t* r8 = (uint8_t*)rp;
+  int32_t st = fpx_epx_accept((fpx_epx*)(intptr_t)h, m, l, nu, bo, br, tr, (const uint8_t*)tg, r8, r8 ? r8 + m : NULL,
+                              r8 ? r8 + 2 * (size_t)m : NULL, nb, r8 ? r8 + 3 * (size_t)m : NULL);
+  put_bytes(env, replies, 4 * (jlong)m, rp); put_ints(env, nackBallot, m, nb);
+  free(l); free(nu); free(bo); free(br); free(tr); free(tg); free(rp); free(nb);
+  return st;
+}
+
+/* key -1 = Noop; depsIn m x n, depsInValuesEnd m (may be null); replies = okBits | resendBits | nackBits | commitBits
+ * (4 x m bytes); replyDeps m x n x n, replyEndTriple = valuesEnd | tripleId (2 x m x n ints) */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxHandlePreaccept(
+    JNIEnv* env, jclass cls, jlong h, jint m, jint numReplicas, jintArray leader, jintArray number,
+    jintArray ballotOrdering, jintArray ballotReplica, jintArray key, jbyteArray isSet, jintArray tripleId,
+    jintArray depsIn, jintArray depsInValuesEnd, jbyteArray targetMask, jbyteArray replies, jintArray nackBallot,
+    jintArray replyDeps, jintArray replyEndTriple) {
+  if (m < 0 || numReplicas < 3) return FPX_EINVAL;
+  if (m == 0) return FPX_OK;
+  const jlong mn = (jlong)m * numReplicas;
+  if (!has(env, leader, m) || !has(env, number, m) || !has(env, ballotOrdering, m) || !has(env, ballotReplica, m) ||
+      !has(env, key, m) || !has(env, isSet, m) || !opt(env, tripleId, m) || !has(env, depsIn, mn) ||
+      !opt(env, depsInValuesEnd, m) || !has(env, targetMask, m) || !opt(env, replies, 4 * (jlong)m) ||
+      !opt(env, nackBallot, m) || !opt(env, replyDeps, mn * numReplicas) || !opt(env, replyEndTriple, 2 * mn))
+    return FPX_EINVAL;
+  jint *l = in_ints(env, leader, m), *nu = in_ints(env, number, m), *bo = in_ints(env, ballotOrdering, m),
+       *br = in_ints(env, ballotReplica, m), *k = in_ints(env, key, m), *tr = in_ints(env, tripleId, m),
+       *di = in_ints(env, depsIn, mn), *de = in_ints(env, depsInValuesEnd, m);
+  jbyte *is = in_bytes(env, isSet, m), *tg = in_bytes(env, targetMask, m);
+  jbyte* rp = out_buf(replies, 4 * (jlong)m, 1);
+  jint *nb = out_buf(nackBallot, m, 4), *rd = out_buf(replyDeps, mn * numReplicas, 4), *re = out_buf(replyEndTriple, 2 * mn, 4);
+  uint8_t* r8 = (uint8_t*)rp;
+  int32_t st = fpx_epx_handle_preaccept((fpx_epx*)(intptr_t)h, m, l, nu, bo, br, k, (const uint8_t*)is, tr, di, de,
+                                        (const uint8_t*)tg, r8, r8 ? r8 + m : NULL, r8 ? r8 + 2 * (size_t)m : NULL,
+                                        r8 ? r8 + 3 * (size_t)m : NULL, nb, rd, re, re ? re + mn : NULL);
+  put_bytes(env, replies, 4 * (jlong)m, rp); put_ints(env, nackBallot, m, nb);
+  put_ints(env, replyDeps, mn * numReplicas, rd); put_ints(env, replyEndTriple, 2 * mn, re);
+  free(l); free(nu); free(bo); free(br); free(k); free(tr); free(di); free(de); free(is); free(tg); free(rp); free(nb);
+  free(rd); free(re);
+  return st;
+}
+
+/* entry = kind, ballot, voteBallot, triple id, the replica's largestBallot, then the n stored dependency watermarks
+ * and the own column's values end (5 + n + 1 ints) */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxReadCmdlog(JNIEnv* env, jclass cls, jlong h, jint numReplicas,
+                                                                  jint replica, jint leader, jint number,
+                                                                  jintArray entry) {
+  if (numReplicas < 3 || numReplicas > 7 || !has(env, entry, 6 + (jlong)numReplicas)) return FPX_EINVAL;
+  jint out[5 + 7 + 1];
+  int32_t st = fpx_epx_read_cmdlog((fpx_epx*)(intptr_t)h, replica, leader, number, out);
+  if (st == FPX_OK) st = fpx_epx_read_cmdlog_deps((fpx_epx*)(intptr_t)h, replica, leader, number, out + 5, out + 5 + numReplicas);
+  if (st == FPX_OK) (*env)->SetIntArrayRegion(env, entry, 0, 6 + numReplicas, out);
+  return st;
+}
+
 /* ---- multi-GPU: the RCCL communicator behind the C ABI (fpx_comm_*) ---------------------------------------- */
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_commUniqueId(JNIEnv* env, jclass cls, jbyteArray id) {
   if (!has(env, id, FPX_COMM_ID_BYTES)) return FPX_EINVAL;

@@ -130,6 +130,16 @@ def test_short_arrays_are_rejected_before_native_code_touches_them(jvm):
     assert jvm.call("noopRangesFused", C.c_int32, 0, n, 2, i32(n), i32(n), i32(n), None, i64(8 * n - 1), None, None, None, None) == EINVAL
     assert jvm.call("proxyPhase2bNoopRange", C.c_int32, 0, 0, 4, 0, 2, i64(7), i8(1)) == EINVAL
     assert jvm.call("epxPreaccept", C.c_int32, 0, n, 5, i32(n), i32(n), i32(n), i8(n), i8(n), None, i32(5 * n - 1), None, None, None, None) == EINVAL
+    assert jvm.call("epxPrepare", C.c_int32, 0, n, 5, i32(n), i32(n), i32(n), i32(n), i8(n), i8(3 * n - 1), None, None) == EINVAL
+    assert jvm.call("epxPrepare", C.c_int32, 0, n, 5, i32(n), i32(n), i32(n), i32(n), i8(n), None, None, i32(15 * n - 1)) == EINVAL
+    assert jvm.call("epxAccept", C.c_int32, 0, n, i32(n), i32(n), i32(n), i32(n), i32(n - 1), i8(n), None, None) == EINVAL
+    assert jvm.call("epxAccept", C.c_int32, 0, n, i32(n), i32(n), i32(n), i32(n), i32(n), i8(n), i8(4 * n - 1), None) == EINVAL
+    hp = lambda **kw: jvm.call("epxHandlePreaccept", C.c_int32, 0, n, 5, i32(n), i32(n), i32(n), i32(n), i32(n), i8(n),
+                               kw.get("tr"), kw.get("din", i32(5 * n)), kw.get("dend"), i8(n), kw.get("rep"), None,
+                               kw.get("rd"), kw.get("re"))
+    assert hp(din=i32(5 * n - 1)) == EINVAL and hp(dend=i32(n - 1)) == EINVAL and hp(rep=i8(4 * n - 1)) == EINVAL
+    assert hp(rd=i32(25 * n - 1)) == EINVAL and hp(re=i32(10 * n - 1)) == EINVAL and hp(tr=i32(n - 1)) == EINVAL
+    assert jvm.call("epxReadCmdlog", C.c_int32, 0, 5, 0, 0, 0, i32(10)) == EINVAL      # 5 + n + 1 ints
     assert jvm.call("commUniqueId", C.c_int32, i8(127)) == EINVAL
     assert jvm.call("commCreate", C.c_int32, 0, i8(64), 0, 1) == EINVAL
     assert jvm.call("roundLeader", C.c_int32, 0, 5) == -EINVAL and jvm.call("roundLeader", C.c_int32, 3, 5) == 2
@@ -213,3 +223,53 @@ def test_fused_tick_and_ranges_through_the_shim(jvm, oracle):
     np.testing.assert_array_equal(jvm.read(nw, np.int8, 5), b[4].astype(np.int8))
     np.testing.assert_array_equal(jvm.read(rch, np.int8, 5), b[5].astype(np.int8))
     assert jvm.call("destroy", C.c_int32, h) == 0
+
+
+@pytest.mark.gpu
+def test_epaxos_command_log_through_the_shim(jvm, oracle):
+    """epxCreateWithLog / epxHandlePreaccept / epxPrepare / epxAccept / epxReadCmdlog on the mock JVM, against the
+    oracle: a PreAccept processed at three replicas, the same one again (re-sent replies), a Prepare that moves the
+    ballots, the stale PreAccept Nacked, an Accept that commits"""
+    n, NI = 5, 32
+    h = jvm.call("epxCreateWithLog", C.c_int64, n, 4, 0, NI)
+    assert h > 0
+    ref = oracle.EPaxos(n, 4, num_instances=NI)
+    i32 = lambda a: jvm.arr(np.asarray(a, np.int32))
+    i8 = lambda a: jvm.arr(np.asarray(a, np.int8))
+
+    def hp(bo, br, tgt, tr, din):
+        rep, nb = jvm.arr(np.zeros(4, np.int8)), jvm.arr(np.zeros(1, np.int32))
+        rd, ret = jvm.arr(np.zeros(n * n, np.int32)), jvm.arr(np.zeros(2 * n, np.int32))
+        st = jvm.call("epxHandlePreaccept", C.c_int32, h, 1, n, i32([1]), i32([3]), i32([bo]), i32([br]), i32([2]), i8([1]),
+                      i32([tr]), i32(din), None, i8([tgt]), rep, nb, rd, ret)
+        want = ref.handle_preaccept([1], [3], [bo], [br], [2], [1], [tr], [din], None, [tgt])
+        assert st == want[0] == 0
+        bits = jvm.read(rep, np.int8, 4).view(np.uint8)
+        assert bits.tolist() == [int(want[k][0]) for k in (1, 2, 3, 4)]
+        assert int(jvm.read(nb, np.int32, 1)[0]) == int(want[5][0])
+        np.testing.assert_array_equal(jvm.read(rd, np.int32, n * n).reshape(n, n), want[6][0])
+        got = jvm.read(ret, np.int32, 2 * n)
+        np.testing.assert_array_equal(got[:n], want[7][0])
+        np.testing.assert_array_equal(got[n:], want[8][0])
+        return bits
+
+    assert hp(0, 1, 0b01101, 70, [0, 1, 0, 4, 0]).tolist() == [0b01101, 0, 0, 0]
+    assert hp(0, 1, 0b01111, 70, [0, 1, 0, 4, 0]).tolist() == [0b00010, 0b01101, 0, 0]
+    rep, nb, po = jvm.arr(np.zeros(3, np.int8)), jvm.arr(np.zeros(1, np.int32)), jvm.arr(np.zeros(3 * n, np.int32))
+    assert jvm.call("epxPrepare", C.c_int32, h, 1, n, i32([1]), i32([3]), i32([2]), i32([4]), i8([0b00100]), rep, nb, po) == 0
+    want = ref.prepare([1], [3], [2], [4], [0b00100])
+    assert jvm.read(rep, np.int8, 3).tolist() == [int(want[1][0]), int(want[2][0]), int(want[3][0])]
+    np.testing.assert_array_equal(jvm.read(po, np.int32, 3 * n), np.concatenate([want[5][0], want[6][0], want[7][0]]))
+    assert hp(0, 1, 0b00100, 70, [0, 1, 0, 4, 0]).tolist() == [0, 0, 0b00100, 0]
+    rep4, nb = jvm.arr(np.zeros(4, np.int8)), jvm.arr(np.zeros(1, np.int32))
+    assert jvm.call("epxAccept", C.c_int32, h, 1, i32([1]), i32([3]), i32([2]), i32([4]), i32([71]), i8([0b00101]), rep4, nb) == 0
+    want = ref.accept([1], [3], [2], [4], [71], [0b00101])
+    assert jvm.read(rep4, np.int8, 4).view(np.uint8).tolist() == [int(want[k][0]) for k in (1, 2, 3, 5)]
+    entry = jvm.arr(np.zeros(6 + n, np.int32))
+    for r in range(n):
+        assert jvm.call("epxReadCmdlog", C.c_int32, h, n, r, 1, 3, entry) == 0
+        got = jvm.read(entry, np.int32, 6 + n)
+        assert tuple(got[:5]) == ref.read_cmdlog(r, 1, 3)
+        deps, end = ref.read_cmdlog_deps(r, 1, 3)
+        assert got[5:5 + n].tolist() == deps.tolist() and got[5 + n] == end
+    assert jvm.call("epxDestroy", C.c_int32, h) == 0
