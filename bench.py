@@ -245,6 +245,30 @@ def replica_axis_row(fa, dist, backend, dev, rank, world, local_rank, ballot_mod
     }
 
 
+def run_with_deadline(fn, seconds, dev):
+    """fn() on a worker thread: (result, False), ({"error": ...}, False) if it raised, or ({"error": ...}, True) if it
+    has not returned within `seconds` (the thread is left behind; the caller must end the process with os._exit)"""
+    import threading
+    box = {}
+
+    def target():
+        try:
+            if dev is not None and getattr(dev, "type", "") == "cuda":
+                torch.cuda.set_device(dev)
+            box["value"] = fn()
+        except BaseException as e:  # noqa: BLE001 -- reported, not swallowed
+            box["error"] = "%s: %s" % (type(e).__name__, e)
+
+    th = threading.Thread(target=target, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        return {"error": "no answer within %d s" % seconds}, True
+    if "error" in box:
+        return {"error": box["error"]}, False
+    return box.get("value"), False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -258,6 +282,8 @@ def main():
     ap.add_argument("--config", choices=["headline", "2", "3", "4", "5"], default="headline",
                     help="headline = BASELINE.json's metric grid (2^20 slots x 256 acceptors); 2..5 = the other "
                          "BASELINE.json configs as bench lines of the same schema (bench_configs.py)")
+    ap.add_argument("--replica-row-deadline", type=int, default=120,
+                    help="seconds the extra replica-axis row may take before the line is printed without it")
     ap.add_argument("--replica-row-steps", type=int, default=5,
                     help="N > 1, --shard group: steps of the extra replica-axis row (0 = skip it)")
     args = ap.parse_args()
@@ -431,13 +457,19 @@ def main():
     # SURVEY.md 8e asks for both sharding rows: with N > 1 the default (group-sharded) run appends the
     # replica-axis row -- one 2^20 x 256 grid split over the N GPUs' acceptor columns, RCCL reduce-scatter of
     # the vote bitmaps behind the C ABI, collective time broken out
-    replica_row = None
+    replica_row, hung, replica_row_tried = None, False, False
     if world > 1 and not replica_shard and args.replica_row_steps > 0:
-        try:
-            replica_row = replica_axis_row(fa, dist, backend, dev, rank, world, local_rank, ballot_mode,
-                                           args.replica_row_steps, all_reduce)
-        except Exception as e:  # the headline line must not be lost to a failure of the extra row
-            replica_row = {"error": "%s: %s" % (type(e).__name__, e)} if rank == 0 else None
+        replica_row_tried = True
+        # the headline line must not be lost to the extra row: an exception becomes an "error" field, and a
+        # collective that never returns (RCCL between real GPUs runs for the first time in the driver's own
+        # multi-GPU job) is given a deadline -- the line is printed without the row and the process leaves
+        # without waiting for the stuck thread
+        replica_row, hung = run_with_deadline(
+            lambda: replica_axis_row(fa, dist, backend, dev, rank, world, local_rank, ballot_mode,
+                                     args.replica_row_steps, all_reduce),
+            args.replica_row_deadline, dev)
+        if rank != 0 and not hung:
+            replica_row = None
 
     if rank == 0:
         bps = algorithmic_bytes_per_slot(ballot_mode)
@@ -507,10 +539,20 @@ def main():
             line["replica_axis"] = replica_row
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ballot_mode)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+    if hung:  # a collective of the extra row never returned: no barrier, no teardown that could wait for it
+        sys.stderr.write("bench.py: rank %d: the replica-axis row did not finish; exiting without it\n" % rank)
+        sys.stderr.flush()
+        os._exit(0)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        if replica_row_tried:
+            # another rank may have left without the row (see above): the closing barrier gets a deadline too
+            _, stuck = run_with_deadline(lambda: (dist.barrier(), dist.destroy_process_group()), 60, dev)
+            if stuck:
+                os._exit(0)
+        else:
+            dist.barrier()
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

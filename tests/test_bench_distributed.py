@@ -97,3 +97,12 @@ def test_bench_lines_of_the_other_configs(config):
         assert key in d
     assert d["config"]["baseline_config"] == int(config) and d["value"] > 0 and d["steps"] == 3
     assert d["roofline"]["launches_timed"] == 3 and d["roofline"]["achieved"] > 0
+
+
+def test_headline_line_survives_an_extra_row_that_never_finishes():
+    """the replica-axis row runs RCCL between real GPUs for the first time in the driver's own multi-GPU job: if a
+    collective in it never returns, the headline line is still printed (with the row marked) and every rank leaves
+    with status 0.  A deadline of 0 s makes the row 'never finish' here."""
+    d = _run(["--replica-row-steps", "2", "--replica-row-deadline", "0"])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert "no answer" in d["replica_axis"]["error"]
