@@ -839,3 +839,26 @@ def test_epaxos_hot_keys_take_the_long_way(oracle, n, m, hot, NI):
                 assert gpu.read_cmdlog(r, L, x) == ref.read_cmdlog(r, L, x)
                 c, d = gpu.read_cmdlog_deps(r, L, x), ref.read_cmdlog_deps(r, L, x)
                 assert c[0].tolist() == d[0].tolist() and c[1] == d[1]
+
+
+@pytest.mark.gpu
+def test_epaxos_ticks_without_the_per_key_workgroups(oracle, monkeypatch):
+    """k_epx_scan / k_epx_decide alone (what a tick of 2^21 or more commands, or more than 65536 keys, uses):
+    FPX_EPX_NO_KEY_TILES switches k_epx_key off; same answers"""
+    from frankenpaxos_amd.epaxos import EPaxos
+
+    monkeypatch.setenv("FPX_EPX_NO_KEY_TILES", "1")
+    n, num_keys, m = 5, 16, 3000
+    gpu, ref = EPaxos(n, num_keys, num_instances=2048), oracle.EPaxos(n, num_keys, num_instances=2048)
+    rng = np.random.default_rng(99)
+    nxt = [0] * n
+    for tick in range(2):
+        args = random_tick(rng, n, num_keys, m, nxt, 6.0, fifo=False)
+        tr = rng.integers(0, 1 << 20, m).astype(np.int32)
+        _same(gpu.preaccept(*args, triple_id=tr), ref.preaccept(*args, triple_id=tr))
+    for r in range(n):
+        for inst in rng.choice(n * 2048, size=300, replace=False):
+            L, x = int(inst) // 2048, int(inst) % 2048
+            assert gpu.read_cmdlog(r, L, x) == ref.read_cmdlog(r, L, x)
+            a, b = gpu.read_cmdlog_deps(r, L, x), ref.read_cmdlog_deps(r, L, x)
+            assert a[0].tolist() == b[0].tolist() and a[1] == b[1]
