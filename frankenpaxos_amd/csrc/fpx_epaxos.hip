@@ -4,9 +4,10 @@
 // in that replica's delivery order, on n-wide watermark vectors (util/TopOne.scala): data-parallel as
 //   1. k_epx_keys      scatter every command to its position in the replica's delivery order (rank is a
 //                      permutation)
-//   2. k_rs_hist / k_rs_scan / k_rs_scatter   stable LSD radix sort (8-bit digits) of all replicas' sequences
-//                      at once, on the key bits only (stable => (key, delivery order)); one wavefront owns a
-//                      tile of 1024 consecutive elements and ranks equal digits with 8 ballots per 64 elements
+//   2. k_rs_hist / k_rs_scan / k_rs_scatter   stable LSD radix sort (digits of up to 11 bits: 1024 keys are one pass)
+//                      of all replicas' sequences at once, on the key bits only (stable => (key, delivery
+//                      order)); a workgroup sorts its tile of 4096 elements into LDS (equal digits ranked with
+//                      one ballot per digit bit and 64 elements) and writes it out as runs per digit
 //   3. k_epx_segments  [lo, hi) of every (replica, key) segment by binary search
 //   4. k_epx_key<N>    one workgroup per key, for every key whose commands fit its LDS tables: the scans of all
 //                      replicas' segments of the key (steps 4a / 5a below in one kernel, the conflict rows never
@@ -57,7 +58,7 @@ struct EpxState {
 };
 
 #ifndef FPX_RS_ITEMS
-#define FPX_RS_ITEMS 16  // 64-element steps per wavefront tile; 8 / 16 / 32 / 64 measured 0.390 / 0.380 / 0.379 / 0.418 ms per tick
+#define FPX_RS_ITEMS 16  // 64-element steps per wavefront (tile = 4 x that); 8 / 16 / 32 measured 0.317 / 0.302 / 0.322 ms per tick
 #endif
 #define FPX_RS_ITEMS_V FPX_RS_ITEMS
 
@@ -155,19 +156,25 @@ __global__ void __launch_bounds__(256) k_epx_keys(const EpxState st, const EpxBa
   }
 }
 
-// ---- stable LSD radix sort, 8-bit digits, all replicas in one launch (blockIdx.y = replica) ------------
-// A wavefront owns a tile of RS_TILE consecutive elements, so walking the tile 64 at a time in lane order
-// is the input order: ranking equal digits by (tile, step, lane) keeps the sort stable.
-constexpr int RS_ITEMS = FPX_RS_ITEMS;
-constexpr int RS_TILE = 64 * RS_ITEMS;
+// ---- stable LSD radix sort, digits of up to 11 bits, all replicas in one launch (blockIdx.y = replica) --------
+// 1024 keys (+ the non-participants' bucket) are ONE pass.  A workgroup owns a tile of RS_TILE consecutive elements,
+// wavefront w the w-th quarter of it, walked 64 at a time in lane order: ranking equal digits by (tile, wavefront,
+// step, lane) is the input order, so the sort is stable.  The tile is first sorted into LDS and leaves as runs of
+// consecutive elements per digit (a scatter straight from the ranking loop wrote 8 bytes per lane and instruction
+// to 64 different places: two such passes were 66 us for 5 M pairs, profiles/r02_epaxos_kernel_stats.csv).
+constexpr int RS_ITEMS = FPX_RS_ITEMS;      // 64-element steps per wavefront
+constexpr int RS_TILE = 256 * RS_ITEMS;     // elements per workgroup tile
+constexpr int RS_MAXW = 11;                 // widest digit
+constexpr int RS_MAXB = 1 << RS_MAXW;
+constexpr size_t RS_SCATTER_LDS = (size_t)RS_TILE * 8 + (size_t)4 * RS_MAXB * 4 + (size_t)RS_MAXB * 4 + 64;
 
 struct RsArgs {
   int m, tiles, shift;
-  int width;       // digit bits of this pass (<= 8): the key bits are split evenly over the passes, fewer buckets = longer runs
+  int width;       // digit bits of this pass (<= 11): the key bits are split evenly over the passes
   const uint2* src;  // [n][m] (key word, payload)
   uint2* dst;
-  uint32_t* hist;  // [n][256][tiles] per-tile digit counts -> exclusive offsets within the digit
-  uint32_t* tot;   // [n][256] digit totals
+  uint32_t* hist;  // [n][tiles][B] per-tile digit counts -> exclusive offsets of the tile within the digit
+  uint32_t* tot;   // [n][B] digit totals
   // first pass only (else null): rank[n][m] and the status words, to check that every replica's rank really is
   // a permutation -- position p must hold a message i < m of THIS tick with rank[r][i] == p.  A position no
   // message was scattered to still holds an older tick's pair, which fails one of the two tests (if its i had
@@ -177,113 +184,160 @@ struct RsArgs {
 };
 
 __global__ void __launch_bounds__(256) k_rs_hist(const RsArgs a) {
-  __shared__ uint32_t h[4][256];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = blockIdx.y;
-  const int tile = blockIdx.x * 4 + w;
-  for (int j = lane; j < 256; j += 64) h[w][j] = 0;
-  if (tile >= a.tiles) return;
+  __shared__ uint32_t h[RS_MAXB];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = blockIdx.y, tile = blockIdx.x;
+  const int B = 1 << a.width;
+  for (int j = threadIdx.x; j < B; j += 256) h[j] = 0;
+  __syncthreads();
   const uint2* k = a.src + (size_t)r * a.m;
+  const int first = tile * RS_TILE + w * (RS_TILE / 4);
   uint32_t x[RS_ITEMS];
   if (a.rank) {
     uint32_t y[RS_ITEMS];
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
-      const int idx = tile * RS_TILE + it * 64 + lane;
+      const int idx = first + it * 64 + lane;
       const uint2 e = idx < a.m ? k[idx] : make_uint2(0xffffffffu, 0u);
       x[it] = e.x, y[it] = e.y;
     }
     int bad = -1;
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
-      const int idx = tile * RS_TILE + it * 64 + lane;
+      const int idx = first + it * 64 + lane;
       if (idx < a.m && (y[it] >= (uint32_t)a.m || a.rank[(size_t)r * a.m + y[it]] != idx)) bad = idx;
     }
     if (bad >= 0) epx_report(a.status, FPX_EINVAL, -1);
   } else {
 #pragma unroll
-    for (int it = 0; it < RS_ITEMS; ++it) {  // all the tile's loads in flight before the first LDS atomic
-      const int idx = tile * RS_TILE + it * 64 + lane;
+    for (int it = 0; it < RS_ITEMS; ++it) {  // all the loads in flight before the first LDS atomic
+      const int idx = first + it * 64 + lane;
       x[it] = idx < a.m ? k[idx].x : 0xffffffffu;
     }
   }
 #pragma unroll
   for (int it = 0; it < RS_ITEMS; ++it)
-    if (tile * RS_TILE + it * 64 + lane < a.m) atomicAdd(&h[w][(x[it] >> a.shift) & ((1u << a.width) - 1u)], 1u);
-  for (int j = lane; j < 256; j += 64) a.hist[((size_t)r * 256 + j) * a.tiles + tile] = h[w][j];
+    if (first + it * 64 + lane < a.m) atomicAdd(&h[(x[it] >> a.shift) & (B - 1)], 1u);
+  __syncthreads();
+  uint32_t* out = a.hist + ((size_t)r * a.tiles + tile) * B;
+  for (int j = threadIdx.x; j < B; j += 256) out[j] = h[j];
 }
 
-// one workgroup per (replica, digit): exclusive scan of that digit's per-tile counts, in place
+// exclusive scan of every digit's per-tile counts, in place: 64 digits x 4 parts of the tiles per workgroup (the 64
+// lanes of a wavefront read neighbouring digits of one tile: coalesced); a part sums its tiles, the parts' sums are
+// combined through LDS, then each part rewrites its tiles (second read: L2)
 __global__ void __launch_bounds__(256) k_rs_scan(const RsArgs a) {
-  __shared__ uint32_t wsum[4];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  uint32_t* row = a.hist + ((size_t)blockIdx.y * 256 + blockIdx.x) * a.tiles;
-  uint32_t carry = 0;
-  for (int c = 0; c < a.tiles; c += 256) {
-    const int t = c + threadIdx.x;
-    const uint32_t x = t < a.tiles ? row[t] : 0u;
-    uint32_t inc = x;
+  __shared__ uint32_t part_sum[4][64];
+  const int B = 1 << a.width, lane = threadIdx.x & 63, part = threadIdx.x >> 6, r = blockIdx.y;
+  const int d = blockIdx.x * 64 + lane;
+  const int per = (a.tiles + 3) / 4, t0 = part * per, t1 = min(a.tiles, t0 + per);
+  uint32_t* col = a.hist + (size_t)r * a.tiles * B + d;
+  uint32_t sum = 0;
+  if (d < B) {
+    int t = t0;
+    for (; t + 8 <= t1; t += 8) {
+      uint32_t v[8];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = __shfl_up(inc, d);
-      if (lane >= d) inc += o;
-    }
-    __syncthreads();
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    uint32_t before = 0, total = 0;
+      for (int j = 0; j < 8; ++j) v[j] = col[(size_t)(t + j) * B];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      before += j < w ? wsum[j] : 0u;
-      total += wsum[j];
+      for (int j = 0; j < 8; ++j) sum += v[j];
     }
-    if (t < a.tiles) row[t] = carry + before + inc - x;
-    carry += total;
+    for (; t < t1; ++t) sum += col[(size_t)t * B];
   }
-  if (threadIdx.x == 0) a.tot[blockIdx.y * 256 + blockIdx.x] = carry;
+  part_sum[part][lane] = sum;
+  __syncthreads();
+  if (d >= B) return;
+  uint32_t run = 0;
+  for (int p2 = 0; p2 < part; ++p2) run += part_sum[p2][lane];
+  if (part == 3) a.tot[r * B + d] = run + sum;
+  int t = t0;
+  for (; t + 8 <= t1; t += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = col[(size_t)(t + j) * B];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) col[(size_t)(t + j) * B] = run, run += v[j];
+  }
+  for (; t < t1; ++t) {
+    const uint32_t v = col[(size_t)t * B];
+    col[(size_t)t * B] = run, run += v;
+  }
+}
+
+// exclusive prefix of one value per thread over the 256 threads of the workgroup (sh: 4 words of LDS)
+__device__ __forceinline__ uint32_t block_excl_sum_256(uint32_t v, uint32_t* sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(inc, d);
+    if (lane >= d) inc += o;
+  }
+  __syncthreads();
+  if (lane == 63) sh[w] = inc;
+  __syncthreads();
+  uint32_t before = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) before += j < w ? sh[j] : 0u;
+  return before + inc - v;
 }
 
 __global__ void __launch_bounds__(256) k_rs_scatter(const RsArgs a) {
-  __shared__ uint32_t cnt[4][256];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = blockIdx.y;
-  const int tile = blockIdx.x * 4 + w;
-  if (tile >= a.tiles) return;
-  {
-    // where each digit starts (exclusive scan of the 256 totals across the wave, 4 digits per lane) plus
-    // this tile's offset within the digit
-    uint32_t t4[4], s = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) t4[j] = a.tot[r * 256 + lane * 4 + j], s += t4[j];
-    uint32_t inc = s;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = __shfl_up(inc, d);
-      if (lane >= d) inc += o;
-    }
-    uint32_t base = inc - s;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int dg = lane * 4 + j;
-      cnt[w][dg] = base + a.hist[((size_t)r * 256 + dg) * a.tiles + tile];
-      base += t4[j];
-    }
-  }
+  extern __shared__ __align__(16) unsigned char rs_smem[];
+  uint2* sorted = reinterpret_cast<uint2*>(rs_smem);                       // the tile in digit order
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(sorted + RS_TILE);           // [4][B] per wavefront: count, then cursor
+  int32_t* gpos = reinterpret_cast<int32_t*>(cnt + 4 * RS_MAXB);           // digit -> (global position - position in tile)
+  uint32_t* sh = reinterpret_cast<uint32_t*>(gpos + RS_MAXB);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = blockIdx.y, tile = blockIdx.x;
+  const int B = 1 << a.width;
+  for (int j = threadIdx.x; j < 4 * B; j += 256) cnt[(j / B) * RS_MAXB + (j % B)] = 0;
   const uint2* src = a.src + (size_t)r * a.m;
   uint2* dst = a.dst + (size_t)r * a.m;
-  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  // all the tile's loads in flight before the ranking starts (the ranking loop is a chain of ballots, LDS updates
-  // and wave barriers: a load inside it is a full memory round trip per 64 elements)
+  const int first = tile * RS_TILE + w * (RS_TILE / 4);
   uint2 kvs[RS_ITEMS];
 #pragma unroll
   for (int it = 0; it < RS_ITEMS; ++it) {
-    const int idx = tile * RS_TILE + it * 64 + lane;
+    const int idx = first + it * 64 + lane;
     kvs[it] = idx < a.m ? src[idx] : make_uint2(0u, 0u);
   }
+  __syncthreads();
+  uint32_t* mycnt = cnt + w * RS_MAXB;
+#pragma unroll
+  for (int it = 0; it < RS_ITEMS; ++it)
+    if (first + it * 64 + lane < a.m) atomicAdd(&mycnt[(kvs[it].x >> a.shift) & (B - 1)], 1u);
+  __syncthreads();
+  // thread j owns the digits [j * per, (j + 1) * per): where each starts in the tile, where in the whole sequence
+  {
+    const int per = B >= 256 ? B / 256 : 1;
+    const int d0 = threadIdx.x * per;
+    uint32_t mine = 0, all = 0;
+    for (int j = 0; j < per; ++j) {
+      const int d = d0 + j;
+      if (d < B) {
+        mine += cnt[d] + cnt[RS_MAXB + d] + cnt[2 * RS_MAXB + d] + cnt[3 * RS_MAXB + d];
+        all += a.tot[r * B + d];
+      }
+    }
+    uint32_t tstart = block_excl_sum_256(mine, sh);
+    uint32_t gstart = block_excl_sum_256(all, sh);
+    for (int j = 0; j < per; ++j) {
+      const int d = d0 + j;
+      if (d < B) {
+        const uint32_t c0 = cnt[d], c1 = cnt[RS_MAXB + d], c2 = cnt[2 * RS_MAXB + d], c3 = cnt[3 * RS_MAXB + d];
+        gpos[d] = (int32_t)(gstart + a.hist[((size_t)r * a.tiles + tile) * B + d]) - (int32_t)tstart;
+        cnt[d] = tstart, cnt[RS_MAXB + d] = tstart + c0, cnt[2 * RS_MAXB + d] = tstart + c0 + c1;
+        cnt[3 * RS_MAXB + d] = tstart + c0 + c1 + c2;
+        tstart += c0 + c1 + c2 + c3;
+        gstart += a.tot[r * B + d];
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
   for (int it = 0; it < RS_ITEMS; ++it) {
-    const int idx = tile * RS_TILE + it * 64 + lane;
-    const bool valid = idx < a.m;
+    const bool valid = first + it * 64 + lane < a.m;
     const uint2 kv = kvs[it];
-    const uint32_t dg = (kv.x >> a.shift) & ((1u << a.width) - 1u);
+    const uint32_t dg = (kv.x >> a.shift) & (B - 1);
     unsigned long long peers = __ballot(valid);
     for (int bit = 0; bit < a.width; ++bit) {
       const bool on = (dg >> bit) & 1u;
@@ -291,11 +345,17 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const RsArgs a) {
       peers &= on ? bb : ~bb;
     }
     const uint32_t before = __popcll(peers & lt);
-    const uint32_t at = cnt[w][dg];
+    const uint32_t at = mycnt[dg];
     __builtin_amdgcn_wave_barrier();
-    if (valid && before == 0) cnt[w][dg] = at + (uint32_t)__popcll(peers);
+    if (valid && before == 0) mycnt[dg] = at + (uint32_t)__popcll(peers);
     __builtin_amdgcn_wave_barrier();
-    if (valid) dst[at + before] = kv;
+    if (valid) sorted[at + before] = kv;
+  }
+  __syncthreads();
+  const int have = min(RS_TILE, a.m - tile * RS_TILE);
+  for (int j = threadIdx.x; j < have; j += 256) {
+    const uint2 kv = sorted[j];
+    dst[gpos[(kv.x >> a.shift) & (B - 1)] + j] = kv;
   }
 }
 
@@ -1086,7 +1146,7 @@ struct fpx_epx {
   int last_hip = 0;
   Buf kv, kv2, seg, conf, tmp, tick, h_leader, h_number, h_key, h_set, h_mask, h_seen, h_rank, h_triple, o_fast, o_deps, o_ldeps, o_own, cl, hp, fusedb;
   uint32_t cl_run = 0;
-  bool lds_allowed = false;
+  bool lds_allowed = false, sort_lds_allowed = false;
 };
 
 namespace {
@@ -1151,12 +1211,18 @@ uint2* sort_by_key(fpx_epx* e, int m, uint2* a_buf, uint2* b_buf, const int32_t*
   const int n = e->st.n;
   unsigned bits = 1;
   while ((1u << bits) <= (unsigned)e->st.num_keys) ++bits;
-  const unsigned passes = (bits + 7) / 8, width = (bits + passes - 1) / passes;
+  const unsigned passes = (bits + RS_MAXW - 1) / RS_MAXW, width = (bits + passes - 1) / passes;
+  const unsigned B = 1u << width;
   RsArgs a;
   a.m = m, a.tiles = (m + RS_TILE - 1) / RS_TILE;
-  *rc_out = grow(e, &e->tmp, ((size_t)n * 256 * a.tiles + (size_t)n * 256) * 4);
+  *rc_out = grow(e, &e->tmp, ((size_t)n * a.tiles * B + (size_t)n * B) * 4);
   if (*rc_out) return nullptr;
-  a.hist = (uint32_t*)e->tmp.p, a.tot = a.hist + (size_t)n * 256 * a.tiles;
+  a.hist = (uint32_t*)e->tmp.p, a.tot = a.hist + (size_t)n * a.tiles * B;
+  if (!e->sort_lds_allowed) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)RS_SCATTER_LDS);
+    e->sort_lds_allowed = true;
+  }
   uint2* buf[2] = {a_buf, b_buf};
   int cur = 0;
   for (unsigned shift = 0; shift < bits; shift += width, cur ^= 1) {
@@ -1165,10 +1231,10 @@ uint2* sort_by_key(fpx_epx* e, int m, uint2* a_buf, uint2* b_buf, const int32_t*
     a.rank = shift == 0 ? check_rank : nullptr;
     a.status = e->st.status;
     a.src = buf[cur], a.dst = buf[cur ^ 1];
-    const dim3 tg((a.tiles + 3) / 4, n);
+    const dim3 tg(a.tiles, n);
     hipLaunchKernelGGL(k_rs_hist, tg, dim3(256), 0, e->stream, a);
-    hipLaunchKernelGGL(k_rs_scan, dim3(256, n), dim3(256), 0, e->stream, a);
-    hipLaunchKernelGGL(k_rs_scatter, tg, dim3(256), 0, e->stream, a);
+    hipLaunchKernelGGL(k_rs_scan, dim3((B + 63) / 64, n), dim3(256), 0, e->stream, a);
+    hipLaunchKernelGGL(k_rs_scatter, tg, dim3(256), RS_SCATTER_LDS, e->stream, a);
   }
   return buf[cur];  // where the last pass left the sequence
 }
