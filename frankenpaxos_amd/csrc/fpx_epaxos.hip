@@ -376,6 +376,29 @@ __global__ void __launch_bounds__(256) k_epx_segments(const EpxState st, const E
   b.seg[(size_t)t * 2 + 1] = lower((uint32_t)(k + 1));
 }
 
+// the same from the sort's digit totals when the whole key was ONE digit (digit == key): the segment of key k starts
+// where the digits below k end -- an exclusive scan of B totals per replica instead of 2 binary searches per segment
+__global__ void __launch_bounds__(256) k_epx_segments_from_totals(const EpxState st, const EpxBatch b, const uint32_t* tot,
+                                                                  int B) {
+  __shared__ uint32_t sh[4];
+  const int r = blockIdx.x, per = B >= 256 ? B / 256 : 1, d0 = threadIdx.x * per;
+  uint32_t mine = 0;
+  for (int j = 0; j < per; ++j)
+    if (d0 + j < B) mine += tot[r * B + d0 + j];
+  uint32_t start = block_excl_sum_256(mine, sh);
+  for (int j = 0; j < per; ++j) {
+    const int k = d0 + j;
+    if (k < B) {
+      const uint32_t c = tot[r * B + k];
+      if (k < st.num_keys) {
+        b.seg[((size_t)r * st.num_keys + k) * 2] = (int32_t)start;
+        b.seg[((size_t)r * st.num_keys + k) * 2 + 1] = (int32_t)(start + c);
+      }
+      start += c;
+    }
+  }
+}
+
 // One chunk of 64 consecutive commands of a (replica, key) segment, one per lane: dep[l] = what the command's
 // conflict lookup returns in column l (exclusive prefix over the chunk + carry), and the carries cg / cs (the
 // replica's TopOne vectors for the key, KeyValueStore.scala:229-230) and ng / ns (this tick's puts alone) move on.
@@ -1206,8 +1229,16 @@ void launch_hp(fpx_epx* e, const EpxBatch& sb, const HpBatch& hb) {
   hipLaunchKernelGGL((k_hp_reply<N>), dim3((unsigned)(((long long)hb.m * N + 255) / 256)), dim3(256), 0, e->stream, e->st, hb);
 }
 
+void launch_segments(fpx_epx* e, const EpxBatch& b, const uint32_t* key_totals, int key_buckets) {
+  if (key_totals)
+    hipLaunchKernelGGL(k_epx_segments_from_totals, dim3(e->st.n), dim3(256), 0, e->stream, e->st, b, key_totals, key_buckets);
+  else
+    hipLaunchKernelGGL(k_epx_segments, dim3((e->st.n * e->st.num_keys + 255) / 256), dim3(256), 0, e->stream, e->st, b);
+}
+
 // stable LSD radix sort of the n sequences of m pairs on the key bits; returns the buffer that holds the result
-uint2* sort_by_key(fpx_epx* e, int m, uint2* a_buf, uint2* b_buf, const int32_t* check_rank, int* rc_out) {
+uint2* sort_by_key(fpx_epx* e, int m, uint2* a_buf, uint2* b_buf, const int32_t* check_rank, int* rc_out,
+                   const uint32_t** key_totals, int* key_buckets) {
   const int n = e->st.n;
   unsigned bits = 1;
   while ((1u << bits) <= (unsigned)e->st.num_keys) ++bits;
@@ -1236,6 +1267,8 @@ uint2* sort_by_key(fpx_epx* e, int m, uint2* a_buf, uint2* b_buf, const int32_t*
     hipLaunchKernelGGL(k_rs_scan, dim3((B + 63) / 64, n), dim3(256), 0, e->stream, a);
     hipLaunchKernelGGL(k_rs_scatter, tg, dim3(256), RS_SCATTER_LDS, e->stream, a);
   }
+  // one pass: the digit was the whole key, its totals are the sizes of the (replica, key) segments
+  *key_totals = passes == 1 ? a.tot : nullptr, *key_buckets = (int)B;
   return buf[cur];  // where the last pass left the sequence
 }
 
@@ -1379,10 +1412,11 @@ int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, co
   // took 450 us against 22 us for the histogram kernel)
   hipLaunchKernelGGL(k_epx_keys, dim3((m + 255) / 256), dim3(256), 0, e->stream, e->st, b);
   // stable LSD radix sort on the key bits only (the sequence already is in delivery order)
-  b.kv_sorted = sort_by_key(e, m, b.kv, b.kv_sorted, d_rank, &rc);
+  const uint32_t* key_totals = nullptr;
+  int key_buckets = 0;
+  b.kv_sorted = sort_by_key(e, m, b.kv, b.kv_sorted, d_rank, &rc, &key_totals, &key_buckets);
   if (rc) return rc;
-  const int segs = n * e->st.num_keys;
-  hipLaunchKernelGGL(k_epx_segments, dim3((segs + 255) / 256), dim3(256), 0, e->stream, e->st, b);
+  launch_segments(e, b, key_totals, key_buckets);
   switch (n) {
     case 3: launch_scan_decide<3>(e, b); break;
     case 5: launch_scan_decide<5>(e, b); break;
@@ -1598,10 +1632,12 @@ int32_t fpx_epx_handle_preaccept(fpx_epx* e, int32_t m, const int32_t* leader, c
   EpxBatch sb;
   memset(&sb, 0, sizeof(sb));
   sb.m = m, sb.number = d_number, sb.kv = hb.kv;
-  sb.kv_sorted = sort_by_key(e, m, hb.kv, (uint2*)e->kv2.p, nullptr, &rc);
+  const uint32_t* key_totals = nullptr;
+  int key_buckets = 0;
+  sb.kv_sorted = sort_by_key(e, m, hb.kv, (uint2*)e->kv2.p, nullptr, &rc, &key_totals, &key_buckets);
   if (rc) return rc;
   sb.tick = (int32_t*)e->tick.p, sb.seg = (int32_t*)e->seg.p, sb.conf = (int32_t*)e->conf.p;
-  hipLaunchKernelGGL(k_epx_segments, dim3((n * e->st.num_keys + 255) / 256), blk, 0, e->stream, e->st, sb);
+  launch_segments(e, sb, key_totals, key_buckets);
   // the largestBallot every Nack carries: prefix max per replica over the ballots it took in (as for Prepare / Accept)
   ClBatch cb;
   memset(&cb, 0, sizeof(cb));
