@@ -640,155 +640,184 @@ __global__ void __launch_bounds__(KeyTile<N>::THREADS) k_epx_key(const EpxState 
   int* tot = reinterpret_cast<int*>(stage + (size_t)N * T::TC);               // [N][W][2N] puts of a wavefront's chunks
   int* ctl = tot + N * T::W * 2 * N;                                          // [0] slots handed out, [1] give up
   if (st.status[0] != 0) return;
-  const int k = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = wave / T::W, w = wave - r * T::W;  // replica, part of its segment
-  const int seg = r * st.num_keys + k;
-  const int lo = b.seg[(size_t)seg * 2], hi = b.seg[(size_t)seg * 2 + 1], len = hi - lo;
-  const int cpw = ((len + 63) / 64 + T::W - 1) / T::W;  // chunks per wavefront of THIS segment
-  const int first = w * cpw * 64;                       // where this wavefront's part starts
-  // the replica's TopOne vectors for this key: requested now, needed in the scan
-  int cg[N], cs[N];
-  {
-    const size_t ib = ((size_t)r * st.num_keys + k) * N;
-#pragma unroll
-    for (int l = 0; l < N; ++l) cg[l] = st.gets[ib + l], cs[l] = st.sets[ib + l];
-  }
-  for (int j = threadIdx.x; j < T::HC; j += T::THREADS) hk[j] = 0;
-  for (int j = threadIdx.x; j < N * T::W * 2 * N + 2; j += T::THREADS) tot[j] = 0;  // tot and ctl
-  __syncthreads();
-  if (len > T::MAXC * 64 && lane == 0) ctl[1] = 1;
-  // this wavefront's sort pairs in one go (one memory round trip, not one per chunk)
-  const uint2* kvs = b.kv_sorted + (size_t)r * b.m + lo;
-  uint2 kvq[T::CPW];
-  bool have[T::CPW];
-#pragma unroll
-  for (int c = 0; c < T::CPW; ++c) {
-    const int p = first + c * 64 + lane;
-    have[c] = c < cpw && p < len;
-    kvq[c] = have[c] ? kvs[p] : make_uint2(0u, 0u);
-  }
-  // the wavefronts of the leader's replica hand out the slots of the commands it leads
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  int myslot[T::CPW];
+
+  // A workgroup works through the keys blockIdx.x, + gridDim.x, ...  With 149 KB of LDS it is alone on its CU, so
+  // nothing else hides its memory round trips: what the NEXT key needs from memory -- segment bounds and the
+  // replica's TopOne vectors (A), the sort pairs of this wavefront's part (B), number / masks of the commands it
+  // leads (C), each addressed with the one before -- is requested while the current key is worked on.
+  struct SegA {
+    int lo, len, cpw, first;
+    int cg[N], cs[N];
+  };
+  auto fetch_a = [&](int k, SegA& s) {
+    const int seg = r * st.num_keys + k;
+    s.lo = b.seg[(size_t)seg * 2];
+    s.len = b.seg[(size_t)seg * 2 + 1] - s.lo;
+    s.cpw = ((s.len + 63) / 64 + T::W - 1) / T::W;  // chunks per wavefront of THIS segment
+    s.first = w * s.cpw * 64;                       // where this wavefront's part starts
+    const size_t ib = (size_t)seg * N;
 #pragma unroll
-  for (int c = 0; c < T::CPW; ++c) {
-    const bool own = have[c] && (int)(kvq[c].x >> EPX_LEADER_SHIFT) == r;
-    const unsigned long long bal = __ballot(own);
-    int base = 0;
-    if (bal) {
-      if (lane == 0) base = atomicAdd(&ctl[0], (int)__popcll(bal));
-      base = __builtin_amdgcn_readfirstlane(base);
+    for (int l = 0; l < N; ++l) s.cg[l] = st.gets[ib + l], s.cs[l] = st.sets[ib + l];
+  };
+  auto fetch_b = [&](const SegA& s, uint2* kv, bool* have) {
+    const uint2* kvs = b.kv_sorted + (size_t)r * b.m + s.lo;
+#pragma unroll
+    for (int c = 0; c < T::CPW; ++c) {
+      const int p = s.first + c * 64 + lane;
+      have[c] = c < s.cpw && p < s.len && s.len <= T::MAXC * 64;
+      kv[c] = have[c] ? kvs[p] : make_uint2(0u, 0u);
     }
-    myslot[c] = own ? base + (int)__popcll(bal & lt) : -1;
-  }
-  // what the decisions need of each led command, gathered by message index: all requests go out before the first
-  // one is used (a gather inside the insert loop below would be one memory round trip per chunk)
-  int gnum[T::CPW];
-  unsigned gmask[T::CPW];
+  };
+  auto fetch_c = [&](const uint2* kv, const bool* have, int* gnum, unsigned* gmask) {
 #pragma unroll
-  for (int c = 0; c < T::CPW; ++c) {
-    gnum[c] = 0, gmask[c] = 0;
-    if (myslot[c] >= 0) {
-      const int i = (int)kvq[c].y;
-      const unsigned mask = b.resp_mask[i];
-      gnum[c] = b.number[i];
-      gmask[c] = mask | ((b.seen_mask ? (unsigned)b.seen_mask[i] : mask) << 8);
+    for (int c = 0; c < T::CPW; ++c) {
+      gnum[c] = 0, gmask[c] = 0;
+      if (have[c] && (int)(kv[c].x >> EPX_LEADER_SHIFT) == r) {
+        const int i = (int)kv[c].y;
+        const unsigned mask = b.resp_mask[i];
+        gnum[c] = b.number[i];
+        gmask[c] = mask | ((b.seen_mask ? (unsigned)b.seen_mask[i] : mask) << 8);
+      }
     }
-  }
+  };
+
+  SegA cur, nxt;
+  uint2 kvq[T::CPW], kvn[T::CPW];
+  bool have[T::CPW], haven[T::CPW];
+  int gnum[T::CPW], gnumn[T::CPW];
+  unsigned gmask[T::CPW], gmaskn[T::CPW];
+  int k = blockIdx.x;
+  if (k >= st.num_keys) return;
+  fetch_a(k, cur);
+  fetch_b(cur, kvq, have);
+  fetch_c(kvq, have, gnum, gmask);
+  for (; k < st.num_keys; k += gridDim.x) {
+    const int kn = k + gridDim.x;
+    const bool more = kn < st.num_keys;
+    if (more) fetch_a(kn, nxt);
+    for (int j = threadIdx.x; j < T::HC; j += T::THREADS) hk[j] = 0;
+    for (int j = threadIdx.x; j < N * T::W * 2 * N + 2; j += T::THREADS) tot[j] = 0;  // tot and ctl
+    __syncthreads();
+    if (cur.len > T::MAXC * 64 && lane == 0) ctl[1] = 1;
+    // the wavefronts of the leader's replica hand out the slots of the commands it leads
 #pragma unroll
-  for (int c = 0; c < T::CPW; ++c) {
-    const int sl = myslot[c];
-    if (sl >= T::TC) ctl[1] = 1;
-    if (sl >= 0 && sl < T::TC) {
-      const int i = (int)kvq[c].y;
-      list_i[sl] = i;
-      num[sl] = gnum[c];
-      msk[sl] = gmask[c] | ((unsigned)r << 16);
-      const uint32_t word = ((uint32_t)(i + 1) << T::IDX_BITS) | (uint32_t)sl;
-      uint32_t h = ((uint32_t)i * 2654435761u >> 12) & (T::HC - 1);
-      while (atomicCAS(&hk[h], 0u, word) != 0u) h = (h + 1) & (T::HC - 1);
+    for (int c = 0; c < T::CPW; ++c) {
+      const bool own = have[c] && (int)(kvq[c].x >> EPX_LEADER_SHIFT) == r;
+      const unsigned long long bal = __ballot(own);
+      int base = 0;
+      if (bal) {
+        if (lane == 0) base = atomicAdd(&ctl[0], (int)__popcll(bal));
+        base = __builtin_amdgcn_readfirstlane(base);
+      }
+      const int sl = own ? base + (int)__popcll(bal & lt) : -1;
+      if (sl >= T::TC) ctl[1] = 1;
+      if (sl >= 0 && sl < T::TC) {
+        const int i = (int)kvq[c].y;
+        list_i[sl] = i;
+        num[sl] = gnum[c];
+        msk[sl] = gmask[c] | ((unsigned)r << 16);
+        const uint32_t word = ((uint32_t)(i + 1) << T::IDX_BITS) | (uint32_t)sl;
+        uint32_t h = ((uint32_t)i * 2654435761u >> 12) & (T::HC - 1);
+        while (atomicCAS(&hk[h], 0u, word) != 0u) h = (h + 1) & (T::HC - 1);
+      }
     }
-  }
-  __syncthreads();
-  if (ctl[1]) {  // more commands than the tables hold: the key goes the long way
-    if (threadIdx.x == 0) b.fused[k] = 0, atomicAdd(b.unfused, 1);
-    return;
-  }
-  // every command finds its slot; the scan below only needs (slot, is_set, leader) per lane.  The puts of this
-  // wavefront's part (per column the largest id + 1) are the carry of the parts behind it.
-  uint16_t* mystage = stage + (size_t)r * T::TC + first;
-  int* mytot = tot + (r * T::W + w) * 2 * N;
+    __syncthreads();
+    const bool give_up = ctl[1] != 0;  // more commands than the tables hold: the key goes the long way
+    if (give_up && threadIdx.x == 0) b.fused[k] = 0, atomicAdd(b.unfused, 1);
+    uint16_t* mystage = stage + (size_t)r * T::TC + cur.first;
+    if (!give_up) {
+      // every command finds its slot; the scan below only needs (slot, is_set, leader) per lane.  The puts of this
+      // wavefront's part (per column the largest id + 1) are the carry of the parts behind it.
+      int* mytot = tot + (r * T::W + w) * 2 * N;
 #pragma unroll
-  for (int c = 0; c < T::CPW; ++c) {
-    if (have[c]) {
-      const uint32_t want = kvq[c].y + 1u;
-      uint32_t h = (kvq[c].y * 2654435761u >> 12) & (T::HC - 1);
-      uint32_t wd = hk[h];
-      while ((wd >> T::IDX_BITS) != want) h = (h + 1) & (T::HC - 1), wd = hk[h];
-      const uint32_t sl = wd & ((1u << T::IDX_BITS) - 1u);
-      const uint32_t flags = kvq[c].x >> EPX_SET_SHIFT;  // bit 0 is_set, bits 1.. leader
-      mystage[c * 64 + lane] = (uint16_t)(sl | (flags << T::IDX_BITS));
-      atomicMax(&mytot[(flags & 1u) * N + (flags >> 1)], num[sl] + 1);
+      for (int c = 0; c < T::CPW; ++c) {
+        if (have[c]) {
+          const uint32_t want = kvq[c].y + 1u;
+          uint32_t h = (kvq[c].y * 2654435761u >> 12) & (T::HC - 1);
+          uint32_t wd = hk[h];
+          while ((wd >> T::IDX_BITS) != want) h = (h + 1) & (T::HC - 1), wd = hk[h];
+          const uint32_t sl = wd & ((1u << T::IDX_BITS) - 1u);
+          const uint32_t flags = kvq[c].x >> EPX_SET_SHIFT;  // bit 0 is_set, bits 1.. leader
+          mystage[c * 64 + lane] = (uint16_t)(sl | (flags << T::IDX_BITS));
+          atomicMax(&mytot[(flags & 1u) * N + (flags >> 1)], num[sl] + 1);
+        }
+      }
     }
-  }
-  __syncthreads();
-  for (int w2 = 0; w2 < w; ++w2) {
-    const int* o = tot + (r * T::W + w2) * 2 * N;
+    if (more) fetch_b(nxt, kvn, haven);  // the current key's pairs are spent
+    __syncthreads();
+    if (!give_up) {
+      int cg[N], cs[N];
 #pragma unroll
-    for (int l = 0; l < N; ++l) cg[l] = imax(cg[l], o[l]), cs[l] = imax(cs[l], o[N + l]);
-  }
-  if (w == 0 && lane == 0) {  // what the commit teaches the other replicas: this tick's puts alone
-    int32_t* out = b.tick + (size_t)seg * 2 * N;
-    for (int l = 0; l < 2 * N; ++l) {
-      int v = 0;
-      for (int w2 = 0; w2 < T::W; ++w2) v = imax(v, tot[(r * T::W + w2) * 2 * N + l]);
-      out[l] = v;
+      for (int l = 0; l < N; ++l) cg[l] = cur.cg[l], cs[l] = cur.cs[l];
+      for (int w2 = 0; w2 < w; ++w2) {
+        const int* o = tot + (r * T::W + w2) * 2 * N;
+#pragma unroll
+        for (int l = 0; l < N; ++l) cg[l] = imax(cg[l], o[l]), cs[l] = imax(cs[l], o[N + l]);
+      }
+      if (w == 0 && lane == 0) {  // what the commit teaches the other replicas: this tick's puts alone
+        int32_t* out = b.tick + ((size_t)r * st.num_keys + k) * 2 * N;
+        for (int l = 0; l < 2 * N; ++l) {
+          int v = 0;
+          for (int w2 = 0; w2 < T::W; ++w2) v = imax(v, tot[(r * T::W + w2) * 2 * N + l]);
+          out[l] = v;
+        }
+      }
+      int ng[N], ns[N];
+#pragma unroll
+      for (int l = 0; l < N; ++l) ng[l] = 0, ns[l] = 0;
+      for (int base = 0; base < cur.cpw * 64 && cur.first + base < cur.len; base += 64) {
+        const bool valid = cur.first + base + lane < cur.len;
+        const unsigned code = valid ? mystage[base + lane] : 0u;
+        const int sl = (int)(code & ((1u << T::IDX_BITS) - 1u));
+        const bool t = (code >> T::IDX_BITS) & 1u;
+        const int L = (int)(code >> (T::IDX_BITS + 1));
+        const int id1 = valid ? num[sl] + 1 : 0;  // TopOne.put: max(.., id + 1), util/TopOne.scala:12-15
+        int dep[N];
+        scan_chunk<N>(valid, t, L, id1, cg, cs, ng, ns, dep);
+        if (valid) {
+#pragma unroll
+          for (int l = 0; l < N; ++l) rows[((size_t)sl * N + r) * N + l] = dep[l];
+        }
+      }
     }
-  }
-  int ng[N], ns[N];
+    if (more) fetch_c(kvn, haven, gnumn, gmaskn);
+    __syncthreads();
+    if (!give_up) {
+      const int count = ctl[0];
+      for (int sl = threadIdx.x; sl < count; sl += T::THREADS) {
+        const int i = list_i[sl];
+        const unsigned mw = msk[sl];
+        auto load_row = [&](int rr, int* out) {
 #pragma unroll
-  for (int l = 0; l < N; ++l) ng[l] = 0, ns[l] = 0;
-  for (int base = 0; base < cpw * 64 && first + base < len; base += 64) {
-    const bool valid = first + base + lane < len;
-    const unsigned code = valid ? mystage[base + lane] : 0u;
-    const int sl = (int)(code & ((1u << T::IDX_BITS) - 1u));
-    const bool t = (code >> T::IDX_BITS) & 1u;
-    const int L = (int)(code >> (T::IDX_BITS + 1));
-    const int id1 = valid ? num[sl] + 1 : 0;  // TopOne.put: max(.., id + 1), util/TopOne.scala:12-15
-    int dep[N];
-    scan_chunk<N>(valid, t, L, id1, cg, cs, ng, ns, dep);
-    if (valid) {
+          for (int l = 0; l < N; ++l) out[l] = rows[((size_t)sl * N + rr) * N + l];
+        };
+        int od[N], ol[N], oe[2];
+        const bool fast = epx_decide_core<N>(st, b, i, (int)(mw >> 16), mw & 0xffu, (mw >> 8) & 0xffu, num[sl], load_row,
+                                             od, ol, oe);
+        if (b.fast) b.fast[i] = fast ? 1 : 0;
+        if (b.own_values_end) *reinterpret_cast<int2*>(b.own_values_end + (size_t)i * 2) = make_int2(oe[0], oe[1]);
+        // the command's rows are spent: its decision takes their place, to leave below as whole n-int lines (one
+        // store instruction per column and thread here would touch 64 different lines each)
 #pragma unroll
-      for (int l = 0; l < N; ++l) rows[((size_t)sl * N + r) * N + l] = dep[l];
+        for (int l = 0; l < N; ++l) rows[((size_t)sl * N + 0) * N + l] = od[l], rows[((size_t)sl * N + 1) * N + l] = ol[l];
+      }
+      __syncthreads();
+      for (int t = threadIdx.x; t < count * N; t += T::THREADS) {
+        const int sl = t / N, l = t - sl * N;
+        const size_t o = (size_t)list_i[sl] * N + l;
+        if (b.deps) b.deps[o] = rows[((size_t)sl * N + 0) * N + l];
+        if (b.leader_deps) b.leader_deps[o] = rows[((size_t)sl * N + 1) * N + l];
+      }
+      if (threadIdx.x == 0) b.fused[k] = 1;
     }
-  }
-  __syncthreads();
-  const int count = ctl[0];
-  for (int sl = threadIdx.x; sl < count; sl += T::THREADS) {
-    const int i = list_i[sl];
-    const unsigned mw = msk[sl];
-    auto load_row = [&](int rr, int* out) {
+    __syncthreads();  // the tables are reused by the next key
+    cur = nxt;
 #pragma unroll
-      for (int l = 0; l < N; ++l) out[l] = rows[((size_t)sl * N + rr) * N + l];
-    };
-    int od[N], ol[N], oe[2];
-    const bool fast = epx_decide_core<N>(st, b, i, (int)(mw >> 16), mw & 0xffu, (mw >> 8) & 0xffu, num[sl], load_row, od,
-                                         ol, oe);
-    if (b.fast) b.fast[i] = fast ? 1 : 0;
-    if (b.own_values_end) *reinterpret_cast<int2*>(b.own_values_end + (size_t)i * 2) = make_int2(oe[0], oe[1]);
-    // the command's rows are spent: its decision takes their place, to leave below as whole n-int lines (one store
-    // instruction per column and thread here would touch 64 different lines each)
-#pragma unroll
-    for (int l = 0; l < N; ++l) rows[((size_t)sl * N + 0) * N + l] = od[l], rows[((size_t)sl * N + 1) * N + l] = ol[l];
+    for (int c = 0; c < T::CPW; ++c) kvq[c] = kvn[c], have[c] = haven[c], gnum[c] = gnumn[c], gmask[c] = gmaskn[c];
   }
-  __syncthreads();
-  for (int t = threadIdx.x; t < count * N; t += T::THREADS) {
-    const int sl = t / N, l = t - sl * N;
-    const size_t o = (size_t)list_i[sl] * N + l;
-    if (b.deps) b.deps[o] = rows[((size_t)sl * N + 0) * N + l];
-    if (b.leader_deps) b.leader_deps[o] = rows[((size_t)sl * N + 1) * N + l];
-  }
-  if (threadIdx.x == 0) b.fused[k] = 1;
 }
 
 __global__ void __launch_bounds__(256) k_epx_commit(const EpxState st, const EpxBatch b) {
@@ -1170,6 +1199,7 @@ struct fpx_epx {
   Buf kv, kv2, seg, conf, tmp, tick, h_leader, h_number, h_key, h_set, h_mask, h_seen, h_rank, h_triple, o_fast, o_deps, o_ldeps, o_own, cl, hp, fusedb;
   uint32_t cl_run = 0;
   bool lds_allowed = false, sort_lds_allowed = false;
+  int num_cus = 256;
 };
 
 namespace {
@@ -1216,7 +1246,7 @@ void launch_scan_decide(fpx_epx* e, const EpxBatch& b) {
                                 (int)KeyTile<N>::BYTES);
       e->lds_allowed = true;
     }
-    hipLaunchKernelGGL((k_epx_key<N>), dim3(e->st.num_keys), dim3(KeyTile<N>::THREADS), KeyTile<N>::BYTES, e->stream, e->st, b);
+    hipLaunchKernelGGL((k_epx_key<N>), dim3(std::min(e->st.num_keys, e->num_cus)), dim3(KeyTile<N>::THREADS), KeyTile<N>::BYTES, e->stream, e->st, b);
   }
   hipLaunchKernelGGL((k_epx_scan<N>), dim3((segs + 3) / 4), dim3(256), 0, e->stream, e->st, b);
   hipLaunchKernelGGL((k_epx_decide<N>), dim3((b.m + 255) / 256), dim3(256), 0, e->stream, e->st, b);
@@ -1303,6 +1333,11 @@ int32_t fpx_epx_create(const fpx_epx_config* cfg, fpx_epx** out) {
   if (hipSetDevice(cfg->device) != hipSuccess) return fail(FPX_ENODEVICE);
   if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(FPX_EHIP);
   e->stream = e->own_stream;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
+      e->num_cus = prop.multiProcessorCount;
+  }
   const size_t cells = (size_t)n * cfg->num_keys * n;
   if (hipMalloc((void**)&e->st.gets, cells * 4) != hipSuccess) return fail(FPX_ENOMEM);
   if (hipMalloc((void**)&e->st.sets, cells * 4) != hipSuccess) return fail(FPX_ENOMEM);
