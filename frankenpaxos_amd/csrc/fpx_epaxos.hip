@@ -166,7 +166,7 @@ constexpr int RS_ITEMS = FPX_RS_ITEMS;      // 64-element steps per wavefront
 constexpr int RS_TILE = 256 * RS_ITEMS;     // elements per workgroup tile
 constexpr int RS_MAXW = 11;                 // widest digit
 constexpr int RS_MAXB = 1 << RS_MAXW;
-constexpr size_t RS_SCATTER_LDS = (size_t)RS_TILE * 8 + (size_t)4 * RS_MAXB * 4 + (size_t)RS_MAXB * 4 + 64;
+constexpr size_t RS_SCATTER_LDS = (size_t)RS_TILE * 8 + (size_t)8 * (RS_MAXB / 2) * 4 + (size_t)RS_MAXB * 4 + 64;
 
 struct RsArgs {
   int m, tiles, shift;
@@ -263,9 +263,9 @@ __global__ void __launch_bounds__(256) k_rs_scan(const RsArgs a) {
   }
 }
 
-// exclusive prefix of one value per thread over the 256 threads of the workgroup (sh: 4 words of LDS)
-__device__ __forceinline__ uint32_t block_excl_sum_256(uint32_t v, uint32_t* sh) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+// exclusive prefix of one value per thread over the threads of the workgroup (up to 512; sh: 8 words of LDS)
+__device__ __forceinline__ uint32_t block_excl_sum(uint32_t v, uint32_t* sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   uint32_t inc = v;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -276,65 +276,94 @@ __device__ __forceinline__ uint32_t block_excl_sum_256(uint32_t v, uint32_t* sh)
   if (lane == 63) sh[w] = inc;
   __syncthreads();
   uint32_t before = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) before += j < w ? sh[j] : 0u;
+  for (int j = 0; j < nw; ++j) before += j < w ? sh[j] : 0u;
   return before + inc - v;
 }
+__device__ __forceinline__ uint32_t block_excl_sum_256(uint32_t v, uint32_t* sh) { return block_excl_sum(v, sh); }
 
-__global__ void __launch_bounds__(256) k_rs_scatter(const RsArgs a) {
+// 8 wavefronts per tile, each ranks an eighth of it (8 steps of 64): twice the wavefronts per CU of a 4-wavefront
+// version at the same LDS, and half the serial chain per wavefront.  The per-wavefront digit counters / cursors are
+// 16 bits wide (a tile has 4096 elements), two digits per LDS word, updated with 32-bit LDS atomics on the half.
+constexpr int RS_SW = 8;                      // wavefronts of a scatter workgroup
+constexpr int RS_SITEMS = RS_TILE / (64 * RS_SW);
+static_assert(RS_TILE <= 65535 && RS_TILE % (64 * RS_SW) == 0, "16-bit cursors; whole steps");
+
+__global__ void __launch_bounds__(64 * RS_SW) k_rs_scatter(const RsArgs a) {
   extern __shared__ __align__(16) unsigned char rs_smem[];
   uint2* sorted = reinterpret_cast<uint2*>(rs_smem);                       // the tile in digit order
-  uint32_t* cnt = reinterpret_cast<uint32_t*>(sorted + RS_TILE);           // [4][B] per wavefront: count, then cursor
-  int32_t* gpos = reinterpret_cast<int32_t*>(cnt + 4 * RS_MAXB);           // digit -> (global position - position in tile)
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(sorted + RS_TILE);           // [RS_SW][B / 2] packed 16-bit count, then cursor
+  int32_t* gpos = reinterpret_cast<int32_t*>(cnt + RS_SW * (RS_MAXB / 2)); // digit -> (global position - position in tile)
   uint32_t* sh = reinterpret_cast<uint32_t*>(gpos + RS_MAXB);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = blockIdx.y, tile = blockIdx.x;
-  const int B = 1 << a.width;
-  for (int j = threadIdx.x; j < 4 * B; j += 256) cnt[(j / B) * RS_MAXB + (j % B)] = 0;
+  const int B = 1 << a.width, HB = B > 1 ? B / 2 : 1;  // words per wavefront
+  constexpr int CW = RS_MAXB / 2;
+  for (int j = threadIdx.x; j < RS_SW * HB; j += 64 * RS_SW) cnt[(j / HB) * CW + (j % HB)] = 0;
   const uint2* src = a.src + (size_t)r * a.m;
   uint2* dst = a.dst + (size_t)r * a.m;
-  const int first = tile * RS_TILE + w * (RS_TILE / 4);
-  uint2 kvs[RS_ITEMS];
+  const int first = tile * RS_TILE + w * (RS_TILE / RS_SW);
+  uint2 kvs[RS_SITEMS];
 #pragma unroll
-  for (int it = 0; it < RS_ITEMS; ++it) {
+  for (int it = 0; it < RS_SITEMS; ++it) {
     const int idx = first + it * 64 + lane;
     kvs[it] = idx < a.m ? src[idx] : make_uint2(0u, 0u);
   }
   __syncthreads();
-  uint32_t* mycnt = cnt + w * RS_MAXB;
+  uint32_t* mycnt = cnt + w * CW;
 #pragma unroll
-  for (int it = 0; it < RS_ITEMS; ++it)
-    if (first + it * 64 + lane < a.m) atomicAdd(&mycnt[(kvs[it].x >> a.shift) & (B - 1)], 1u);
+  for (int it = 0; it < RS_SITEMS; ++it) {
+    if (first + it * 64 + lane < a.m) {
+      const uint32_t d = (kvs[it].x >> a.shift) & (B - 1);
+      atomicAdd(&mycnt[d >> 1], 1u << (16 * (d & 1u)));
+    }
+  }
   __syncthreads();
-  // thread j owns the digits [j * per, (j + 1) * per): where each starts in the tile, where in the whole sequence
+  // thread j owns the digit pairs [j * pp, (j + 1) * pp): where each digit starts in the tile, where in the whole
+  // sequence; the counters become every wavefront's first position for the digit
   {
-    const int per = B >= 256 ? B / 256 : 1;
-    const int d0 = threadIdx.x * per;
+    const int npairs = HB, pp = npairs >= 64 * RS_SW ? npairs / (64 * RS_SW) : 1;
+    const int p0 = threadIdx.x * pp;
     uint32_t mine = 0, all = 0;
-    for (int j = 0; j < per; ++j) {
-      const int d = d0 + j;
-      if (d < B) {
-        mine += cnt[d] + cnt[RS_MAXB + d] + cnt[2 * RS_MAXB + d] + cnt[3 * RS_MAXB + d];
-        all += a.tot[r * B + d];
+    for (int j = 0; j < pp; ++j) {
+      const int p = p0 + j;
+      if (p < npairs) {
+        for (int w2 = 0; w2 < RS_SW; ++w2) {
+          const uint32_t c = cnt[w2 * CW + p];
+          mine += (c & 0xffffu) + (c >> 16);
+        }
+        all += a.tot[r * B + 2 * p] + (2 * p + 1 < B ? a.tot[r * B + 2 * p + 1] : 0u);
       }
     }
-    uint32_t tstart = block_excl_sum_256(mine, sh);
-    uint32_t gstart = block_excl_sum_256(all, sh);
-    for (int j = 0; j < per; ++j) {
-      const int d = d0 + j;
-      if (d < B) {
-        const uint32_t c0 = cnt[d], c1 = cnt[RS_MAXB + d], c2 = cnt[2 * RS_MAXB + d], c3 = cnt[3 * RS_MAXB + d];
-        gpos[d] = (int32_t)(gstart + a.hist[((size_t)r * a.tiles + tile) * B + d]) - (int32_t)tstart;
-        cnt[d] = tstart, cnt[RS_MAXB + d] = tstart + c0, cnt[2 * RS_MAXB + d] = tstart + c0 + c1;
-        cnt[3 * RS_MAXB + d] = tstart + c0 + c1 + c2;
-        tstart += c0 + c1 + c2 + c3;
-        gstart += a.tot[r * B + d];
+    uint32_t tstart = block_excl_sum(mine, sh);
+    uint32_t gstart = block_excl_sum(all, sh);
+    for (int j = 0; j < pp; ++j) {
+      const int p = p0 + j;
+      if (p < npairs) {
+        uint32_t c[RS_SW];
+        for (int w2 = 0; w2 < RS_SW; ++w2) c[w2] = cnt[w2 * CW + p];
+        // the even digit of the pair, then the odd one
+        uint32_t lo_start = tstart, lo_tot = 0;
+        for (int w2 = 0; w2 < RS_SW; ++w2) lo_tot += c[w2] & 0xffffu;
+        uint32_t hi_start = tstart + lo_tot, hi_tot = 0;
+        for (int w2 = 0; w2 < RS_SW; ++w2) hi_tot += c[w2] >> 16;
+        const int d = 2 * p;
+        const uint32_t* hrow = a.hist + ((size_t)r * a.tiles + tile) * B;
+        gpos[d] = (int32_t)(gstart + hrow[d]) - (int32_t)lo_start;
+        const uint32_t t_lo = a.tot[r * B + d];
+        if (d + 1 < B) gpos[d + 1] = (int32_t)(gstart + t_lo + hrow[d + 1]) - (int32_t)hi_start;
+        uint32_t run_lo = lo_start, run_hi = hi_start;
+        for (int w2 = 0; w2 < RS_SW; ++w2) {
+          cnt[w2 * CW + p] = run_lo | (run_hi << 16);
+          run_lo += c[w2] & 0xffffu, run_hi += c[w2] >> 16;
+        }
+        tstart += lo_tot + hi_tot;
+        gstart += t_lo + (d + 1 < B ? a.tot[r * B + d + 1] : 0u);
       }
     }
   }
   __syncthreads();
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
-  for (int it = 0; it < RS_ITEMS; ++it) {
+  for (int it = 0; it < RS_SITEMS; ++it) {
     const bool valid = first + it * 64 + lane < a.m;
     const uint2 kv = kvs[it];
     const uint32_t dg = (kv.x >> a.shift) & (B - 1);
@@ -345,15 +374,16 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const RsArgs a) {
       peers &= on ? bb : ~bb;
     }
     const uint32_t before = __popcll(peers & lt);
-    const uint32_t at = mycnt[dg];
+    const uint32_t sh16 = 16 * (dg & 1u);
+    const uint32_t at = (mycnt[dg >> 1] >> sh16) & 0xffffu;
     __builtin_amdgcn_wave_barrier();
-    if (valid && before == 0) mycnt[dg] = at + (uint32_t)__popcll(peers);
+    if (valid && before == 0) atomicAdd(&mycnt[dg >> 1], (uint32_t)__popcll(peers) << sh16);  // the word's other half may move too
     __builtin_amdgcn_wave_barrier();
     if (valid) sorted[at + before] = kv;
   }
   __syncthreads();
   const int have = min(RS_TILE, a.m - tile * RS_TILE);
-  for (int j = threadIdx.x; j < have; j += 256) {
+  for (int j = threadIdx.x; j < have; j += 64 * RS_SW) {
     const uint2 kv = sorted[j];
     dst[gpos[(kv.x >> a.shift) & (B - 1)] + j] = kv;
   }
@@ -1295,7 +1325,7 @@ uint2* sort_by_key(fpx_epx* e, int m, uint2* a_buf, uint2* b_buf, const int32_t*
     const dim3 tg(a.tiles, n);
     hipLaunchKernelGGL(k_rs_hist, tg, dim3(256), 0, e->stream, a);
     hipLaunchKernelGGL(k_rs_scan, dim3((B + 63) / 64, n), dim3(256), 0, e->stream, a);
-    hipLaunchKernelGGL(k_rs_scatter, tg, dim3(256), RS_SCATTER_LDS, e->stream, a);
+    hipLaunchKernelGGL(k_rs_scatter, tg, dim3(64 * RS_SW), RS_SCATTER_LDS, e->stream, a);
   }
   // one pass: the digit was the whole key, its totals are the sizes of the (replica, key) segments
   *key_totals = passes == 1 ? a.tot : nullptr, *key_buckets = (int)B;
