@@ -1,0 +1,36 @@
+"""Randomised K5 stress beside the oracle (python profiles/microbench/stress_epaxos.py on a GPU box): 24 seeds x 3 ticks,
+n in {3, 5, 7}, 7 .. 2048 keys, 1 k .. 120 k commands per tick, skews 1 .. 200, hot keys, with and without the command
+log.  Prints the number of mismatches (0 on the r02 build)."""
+import os, sys, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from frankenpaxos_amd.epaxos import EPaxos
+import oracle.pyoracle as oracle
+from test_epaxos import random_tick
+bad = 0
+for seed in range(24):
+    rng = np.random.default_rng(1000 + seed)
+    n = [3, 5, 7][seed % 3]
+    num_keys = [7, 64, 300, 1024, 2047, 2048][seed % 6]
+    m = int(rng.integers(1000, 120000))
+    NI = 0 if seed % 2 else 1 << 17
+    gpu, ref = EPaxos(n, num_keys, num_instances=NI), oracle.EPaxos(n, num_keys, num_instances=NI)
+    nxt = [0] * n
+    for tick in range(3):
+        args = random_tick(rng, n, num_keys, m, nxt, float(rng.integers(1, 200)), fifo=bool(tick & 1))
+        if seed % 4 == 0:   # a hot key
+            args = list(args); args[2] = np.where(rng.random(m) < 0.3, 3, args[2]).astype(np.int32)
+        if NI and max(nxt) >= NI: break
+        tr = rng.integers(0, 1 << 20, m).astype(np.int32) if NI else None
+        a, b = gpu.preaccept(*args, triple_id=tr), ref.preaccept(*args, triple_id=tr)
+        ok = a[0] == b[0] == 0 and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:]))
+        if not ok:
+            bad += 1
+            print("MISMATCH seed", seed, "tick", tick, n, num_keys, m)
+    for r in range(n):
+        for k in rng.choice(num_keys, size=min(num_keys, 40), replace=False):
+            ga, sa = gpu.read_index(r, int(k)); gb, sb = ref.read_index(r, int(k))
+            if ga.tolist() != gb.tolist() or sa.tolist() != sb.tolist():
+                bad += 1; print("INDEX MISMATCH seed", seed)
+print("stress done, mismatches:", bad)
