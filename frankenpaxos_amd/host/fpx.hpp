@@ -559,14 +559,51 @@ struct Decision {
 };
 
 // The conflict indices of the n replicas, resident in HBM.
+// epaxos/BallotHelpers.scala:11-21: (ordering, replicaIndex), compared lexicographically; nullBallot = (-1, -1)
+struct Ballot {
+  int32_t ordering = -1, replicaIndex = -1;
+  static Ballot decode(int32_t e) { return e < 0 ? Ballot{} : Ballot{e >> 3, e & 7}; }
+  bool operator==(const Ballot& o) const { return ordering == o.ordering && replicaIndex == o.replicaIndex; }
+};
+// Replica.cmdLog entry kinds (Replica.scala:303-330)
+enum class EntryKind { None = 0, NoCommand = 1, PreAccepted = 2, Accepted = 3, Committed = 4 };
+struct CmdLogEntry {
+  EntryKind kind = EntryKind::None;
+  Ballot ballot, voteBallot;
+  int32_t tripleId = -1;               // the command, by the caller's id
+  std::vector<int32_t> dependencies;   // the triple's dependency watermarks ({-1, ...}: known by tripleId only)
+  int32_t ownValuesEnd = 0;
+  Ballot largestBallot;                // of the replica that holds the entry (Replica.scala:458)
+};
+// a Prepare / Accept / PreAccept of one instance in one ballot, and the replicas it is delivered to
+struct InstanceMessage {
+  Instance instance;
+  Ballot ballot;
+  std::vector<int> recipients;
+  int32_t tripleId = -1;                       // Accept, PreAccept
+  Command command{-1, false};                  // PreAccept: key -1 = Noop
+  std::vector<int32_t> dependencies;           // PreAccept: n watermarks (empty = none)
+  int32_t ownValuesEnd = 0;
+};
+// what the recipients answered
+struct InstanceReplies {
+  std::vector<int> ok, resent, nacks, commits;           // replica indices
+  Ballot nackBallot;                                     // the largest largestBallot a Nack carried
+  bool committed = false;                                // Accept: f + 1 AcceptOks, the proposer's included
+  std::vector<std::vector<int32_t>> replyDependencies;   // PreAccept: per replica, what its PreAcceptOk / Commit carried
+  std::vector<int32_t> replyOwnValuesEnd, replyTripleId;
+};
+
+// The conflict indices (and, with numInstances > 0, the command logs) of the n replicas, resident in HBM.
 class PreAcceptEngine {
  public:
-  PreAcceptEngine(int f, int numKeys, int device = 0) : n_(2 * f + 1) {
+  PreAcceptEngine(int f, int numKeys, int device = 0, int numInstances = 0) : n_(2 * f + 1) {
     if (f < 1) throw std::invalid_argument("f must be >= 1.");
     fpx_epx_config c{};
     c.num_replicas = n_;
     c.num_keys = numKeys;
     c.device = device;
+    c.num_instances = numInstances;
     check(fpx_epx_create(&c, &epx_), "fpx_epx_create");
   }
   ~PreAcceptEngine() {
@@ -635,6 +672,25 @@ class PreAcceptEngine {
     return out;
   }
 
+  // Replica.handlePrepare (Replica.scala:1632-1757), Replica.handlePreAccept in full (:1159-1289) and the Accept
+  // phase (transitionToAcceptPhase :732-792, handleAccept :1421-1511, handleAcceptOk :1513-1565) on the command
+  // log, one call per batch of pairwise distinct instances, messages delivered in vector order
+  std::vector<InstanceReplies> handlePrepare(const std::vector<InstanceMessage>& msgs) { return run(0, msgs); }
+  std::vector<InstanceReplies> acceptPhase(const std::vector<InstanceMessage>& msgs) { return run(1, msgs); }
+  std::vector<InstanceReplies> handlePreAccept(const std::vector<InstanceMessage>& msgs) { return run(2, msgs); }
+
+  CmdLogEntry cmdLog(int replica, Instance instance) {
+    int32_t e[5];
+    CmdLogEntry out;
+    out.dependencies.assign(n_, 0);
+    check(fpx_epx_read_cmdlog(epx_, replica, instance.replicaIndex, instance.instanceNumber, e), "cmdLog");
+    check(fpx_epx_read_cmdlog_deps(epx_, replica, instance.replicaIndex, instance.instanceNumber, out.dependencies.data(),
+                                   &out.ownValuesEnd), "cmdLog");
+    out.kind = (EntryKind)e[0], out.ballot = Ballot::decode(e[1]), out.voteBallot = Ballot::decode(e[2]);
+    out.tripleId = e[3], out.largestBallot = Ballot::decode(e[4]);
+    return out;
+  }
+
   // replica's conflict-index entry of a key: the TopOne watermarks of gets and of sets (util/TopOne.scala)
   std::pair<std::vector<int32_t>, std::vector<int32_t>> conflictIndex(int replica, int key) {
     std::vector<int32_t> g(n_), s2(n_);
@@ -643,6 +699,66 @@ class PreAcceptEngine {
   }
 
  private:
+  static std::vector<int> replicasOf(unsigned bits) {
+    std::vector<int> v;
+    for (int r = 0; r < 8; ++r)
+      if ((bits >> r) & 1u) v.push_back(r);
+    return v;
+  }
+  // kind 0 Prepare, 1 Accept, 2 PreAccept
+  std::vector<InstanceReplies> run(int kind, const std::vector<InstanceMessage>& msgs) {
+    const int m = (int)msgs.size();
+    std::vector<int32_t> leader(m), number(m), bo(m), br(m), tr(m), key(m), dend(m), din((size_t)m * n_, 0);
+    std::vector<uint8_t> tgt(m), isSet(m);
+    for (int i = 0; i < m; ++i) {
+      const InstanceMessage& q = msgs[i];
+      leader[i] = q.instance.replicaIndex, number[i] = q.instance.instanceNumber;
+      bo[i] = q.ballot.ordering, br[i] = q.ballot.replicaIndex, tr[i] = q.tripleId;
+      key[i] = q.command.key, isSet[i] = q.command.isSet ? 1 : 0, dend[i] = q.ownValuesEnd;
+      unsigned bits = 0;
+      for (int r : q.recipients) {
+        if (r < 0 || r >= n_) throw std::invalid_argument("replica index out of range");
+        bits |= 1u << r;
+      }
+      tgt[i] = (uint8_t)bits;
+      if (!q.dependencies.empty()) {
+        if ((int)q.dependencies.size() != n_) throw std::invalid_argument("one dependency watermark per replica");
+        std::copy(q.dependencies.begin(), q.dependencies.end(), din.begin() + (size_t)i * n_);
+      }
+    }
+    std::vector<uint8_t> ok(m), resend(m), nack(m), com(m), done(m);
+    std::vector<int32_t> nb(m, -1), rd((size_t)m * n_ * n_), re((size_t)m * n_), rt((size_t)m * n_, -1);
+    int32_t st;
+    if (kind == 0)
+      st = fpx_epx_prepare(epx_, m, leader.data(), number.data(), bo.data(), br.data(), tgt.data(), ok.data(), nack.data(),
+                           com.data(), nb.data(), nullptr, nullptr, rt.data());
+    else if (kind == 1)
+      st = fpx_epx_accept(epx_, m, leader.data(), number.data(), bo.data(), br.data(), tr.data(), tgt.data(), ok.data(),
+                          nack.data(), com.data(), nb.data(), done.data());
+    else
+      st = fpx_epx_handle_preaccept(epx_, m, leader.data(), number.data(), bo.data(), br.data(), key.data(), isSet.data(),
+                                    tr.data(), din.data(), dend.data(), tgt.data(), ok.data(), resend.data(), nack.data(),
+                                    com.data(), nb.data(), rd.data(), re.data(), rt.data());
+    // a proposer that would have died in logger.fatal / logger.check (Replica.scala:740-757)
+    if (st == FPX_EFATAL_PROTOCOL) throw std::logic_error("logger.fatal: the proposer's own command log refuses the Accept");
+    check(st, kind == 0 ? "Replica.handlePrepare" : kind == 1 ? "Replica.handleAccept" : "Replica.handlePreAccept");
+    std::vector<InstanceReplies> out(m);
+    for (int i = 0; i < m; ++i) {
+      out[i].ok = replicasOf(ok[i]), out[i].resent = replicasOf(resend[i]);
+      out[i].nacks = replicasOf(nack[i]), out[i].commits = replicasOf(com[i]);
+      out[i].nackBallot = Ballot::decode(nb[i]);
+      out[i].committed = done[i] != 0;
+      out[i].replyTripleId.assign(rt.begin() + (size_t)i * n_, rt.begin() + (size_t)(i + 1) * n_);
+      if (kind == 2) {
+        out[i].replyOwnValuesEnd.assign(re.begin() + (size_t)i * n_, re.begin() + (size_t)(i + 1) * n_);
+        for (int r = 0; r < n_; ++r)
+          out[i].replyDependencies.emplace_back(rd.begin() + ((size_t)i * n_ + r) * n_,
+                                                rd.begin() + ((size_t)i * n_ + r + 1) * n_);
+      }
+    }
+    return out;
+  }
+
   int n_;
   fpx_epx* epx_ = nullptr;
 };

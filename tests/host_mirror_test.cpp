@@ -335,6 +335,67 @@ static void epaxosPreAccept() {
   }
 }
 
+// handlePreAccept in full, Prepare and the Accept phase on the command log: steps a) - e) of
+// tests/test_epaxos.py::test_oracle_handle_preaccept_every_branch_by_hand (Replica.scala:1159-1289, 1421-1565, 1632-1757)
+static void epaxosCommandLog() {
+  using namespace epaxos;
+  PreAcceptEngine engine(2, 4, 0, 16);  // n = 5, 4 keys, 16 instances per leader
+  const Instance X{0, 0};
+  // replica 1 alone knows (2, 6) on k1: a PreAccept of leader 2 delivered to it
+  InstanceMessage pre26{{2, 6}, {0, 2}, {1}, 7, {1, true}, {}, 0};
+  SHOULD_BE(engine.handlePreAccept({pre26})[0].ok, (std::vector<int>{1}));
+  // tick: X = set k1 led by 0 pre-accepts at {1, 2, 3}: replica 1 answers [0,0,7,0,0], the others zeros -> slow path
+  std::vector<Decision> d = engine.handleTick({{X, {1, true}, {1, 2, 3}}});
+  SHOULD_BE(d[0].fastPath, false);
+  SHOULD_BE(d[0].dependencies, (V{0, 0, 7, 0, 0}));
+  SHOULD_BE((int)engine.cmdLog(1, X).kind, (int)EntryKind::PreAccepted);
+  SHOULD_BE(engine.cmdLog(1, X).dependencies, (V{0, 0, 7, 0, 0}));
+  SHOULD_BE((int)engine.cmdLog(4, X).kind, (int)EntryKind::None);
+  // a) the leader re-sends PreAccept(X, Ballot(0,0)) to {1, 2, 4}: 1 and 2 answer again from the stored triple, 4 processes it
+  InstanceMessage again{X, {0, 0}, {1, 2, 4}, 42, {1, true}, {}, 0};
+  InstanceReplies a = engine.handlePreAccept({again})[0];
+  SHOULD_BE(a.ok, (std::vector<int>{4}));
+  SHOULD_BE(a.resent, (std::vector<int>{1, 2}));
+  SHOULD_BE(a.replyDependencies[1], (V{0, 0, 7, 0, 0}));
+  SHOULD_BE(a.replyDependencies[4], (V{0, 0, 0, 0, 0}));
+  // b) Prepare(X, Ballot(1,2)) at 1; the old PreAccept(X, Ballot(0,0)) is now Nacked there with largestBallot (1,2)
+  SHOULD_BE(engine.handlePrepare({{X, {1, 2}, {1}}})[0].ok, (std::vector<int>{1}));
+  again.recipients = {1};
+  InstanceReplies b = engine.handlePreAccept({again})[0];
+  SHOULD_BE(b.nacks, (std::vector<int>{1}));
+  SHOULD_BE(b.nackBallot == (Ballot{1, 2}), true);
+  // c) PreAccept(X, Ballot(2,3), deps [0,0,0,2,0]) at {1, 2}: processed afresh, X itself taken out of its conflicts
+  InstanceMessage higher{X, {2, 3}, {1, 2}, 43, {1, true}, {0, 0, 0, 2, 0}, 0};
+  InstanceReplies c = engine.handlePreAccept({higher})[0];
+  SHOULD_BE(c.ok, (std::vector<int>{1, 2}));
+  SHOULD_BE(c.replyDependencies[1], (V{0, 0, 7, 2, 0}));
+  SHOULD_BE(c.replyDependencies[2], (V{0, 0, 0, 2, 0}));
+  SHOULD_BE(engine.cmdLog(1, X).ballot == (Ballot{2, 3}), true);
+  // d) Accept(X, Ballot(3,4)) by 4 at 1: two AcceptOks are no quorum; PreAccept in that very ballot is then ignored
+  InstanceReplies acc = engine.acceptPhase({{X, {3, 4}, {1}, 44}})[0];
+  SHOULD_BE(acc.ok, (std::vector<int>{1, 4}));
+  SHOULD_BE(acc.committed, false);
+  InstanceMessage same{X, {3, 4}, {1, 4}, 44, {1, true}, {}, 0};
+  InstanceReplies ig = engine.handlePreAccept({same})[0];
+  SHOULD_BE(ig.ok.empty() && ig.resent.empty() && ig.nacks.empty() && ig.commits.empty(), true);
+  // e) Accept(X, Ballot(5,2)) at {0, 1, 3} commits; any PreAccept(X) is answered with the Commit
+  SHOULD_BE(engine.acceptPhase({{X, {5, 2}, {0, 1, 3}, 46}})[0].committed, true);
+  InstanceMessage late{X, {0, 1}, {0, 1, 2, 3, 4}, 47, {1, true}, {}, 0};
+  InstanceReplies e = engine.handlePreAccept({late})[0];
+  SHOULD_BE(e.commits, (std::vector<int>{0, 1, 2, 3, 4}));
+  SHOULD_BE(e.replyTripleId, (V{46, 46, 46, 46, 46}));
+  SHOULD_BE((int)engine.cmdLog(3, X).kind, (int)EntryKind::Committed);
+  // the proposer of an Accept that holds a CommittedEntry would have died in logger.fatal (Replica.scala:740-744)
+  {
+    bool fatal = false;
+    try { (void)engine.acceptPhase({{X, {6, 0}, {1}, 48}}); } catch (const std::logic_error&) { fatal = true; }
+    SHOULD_BE(fatal, true);
+  }
+  // two messages for one instance in a batch; a PreAccept that depends on itself
+  SHOULD_THROW(engine.handlePrepare({{{1, 1}, {1, 0}, {2}}, {{1, 1}, {1, 0}, {3}}}));
+  SHOULD_THROW(engine.handlePreAccept({{{1, 7}, {0, 1}, {0}, 1, {2, false}, {0, 8, 0, 0, 0}, 0}}));
+}
+
 int main() {
   gridTest();
   simpleMajorityTest();
@@ -345,6 +406,7 @@ int main() {
   multiPaxosRecovery();
   menciusNoopRange();
   epaxosPreAccept();
+  epaxosCommandLog();
   if (failures) {
     std::printf("%d failure(s)\n", failures);
     return 1;
