@@ -1,5 +1,7 @@
-// fpx_epaxos.hip -- K5: the EPaxos pre-accept fast path on gfx950.
+// fpx_epaxos.hip -- EPaxos on gfx950: K5 the pre-accept tick (fast path test + slow-path
+// union), K6 Prepare / Accept on the command log, K7 handlePreAccept in full (ballots, Nacks, re-sent replies).
 //
+// K5:
 // Per replica the conflict scan is a segmented (by key) exclusive prefix-max over the tick's commands
 // in that replica's delivery order, on n-wide watermark vectors (util/TopOne.scala): data-parallel as
 //   1. k_epx_keys      scatter every command to its position in the replica's delivery order (rank is a
@@ -8,8 +10,9 @@
 //                      of all replicas' sequences at once, on the key bits only (stable => (key, delivery
 //                      order)); a workgroup sorts its tile of 4096 elements into LDS (equal digits ranked with
 //                      one ballot per digit bit and 64 elements) and writes it out as runs per digit
-//   3. k_epx_segments  [lo, hi) of every (replica, key) segment by binary search
-//   4. k_epx_key<N>    one workgroup per key, for every key whose commands fit its LDS tables: the scans of all
+//   3. k_epx_segments_from_totals  [lo, hi) of every (replica, key) segment from the sort's digit totals (one pass:
+//                      digit == key); k_epx_segments (binary search) when the key took several passes
+//   4. k_epx_key<N>    one persistent workgroup per CU working through the keys whose commands fit its LDS tables: the scans of all
 //                      replicas' segments of the key (steps 4a / 5a below in one kernel, the conflict rows never
 //                      leave the chip); the other keys go through
 //   4a. k_epx_scan<N>  one wavefront per (replica, key): 64 commands per step, wave-level max-scan of the
