@@ -177,7 +177,7 @@ def epaxos_setup(fa, dev, local_rank, K, Wm):
                 workload="EPaxos n = 5: one tick = 2^20 fresh single-key commands (1024 keys, Bernoulli get/set) through "
                          "the pre-accept phase of all replicas: conflict scan in every replica's delivery order, "
                          "fast-path test, slow-path union, commit into every conflict index",
-                kernel="K5 tick (k_epx_keys, radix sort, k_epx_scan, k_epx_decide, k_epx_commit)", profile=profile,
+                kernel="K5 tick (k_epx_keys, one-pass radix sort, k_epx_key<5>: scan + decisions per key on chip, k_epx_commit)", profile=profile,
                 metric="EPaxos commands decided/sec (BASELINE.json configs[3])", cpu=cpu,
                 extra={"commands_per_tick": m, "replicas": n, "keys": num_keys}, start_timing=lambda: state.update(timing=True))
 
@@ -273,6 +273,15 @@ def mencius_setup(fa, dev, local_rank, rank, world, K, Wm):
                 start_timing=lambda: state.update(timing=True), scaling="strong")
 
 
+def traffic_of(config):
+    """HBM bytes per step from the PMC passes committed under profiles/ (None if that config was not profiled)"""
+    import json
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("config%s" % config)
+    except Exception:
+        return None
+
+
 def run(args, fa, dist, dev, rank, world, local_rank, all_reduce):
     K, Wm = args.steps, args.warmup
     ballot_mode = fa.FPX_BALLOT_PER_SLOT if args.ballot == "per_slot" else fa.FPX_BALLOT_ACCEPTOR
@@ -325,7 +334,9 @@ def run(args, fa, dist, dev, rank, world, local_rank, all_reduce):
         "config": dict({"workload": w["workload"], "baseline_config": int(args.config)}, **w["extra"]),
         "roofline": {
             "bound": "hbm", "kernel": w["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+            "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic_of(args.config),
+            "traffic_source": "profiles/traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command, "
+                              "all kernels of one step summed), not measured in this run",
             "algorithmic_bytes_per_unit": w["bytes_per_unit"], "units_per_launch": w["units"],
             "avg_kernel_ms": kernel_ms / max(launches, 1), "launches_timed": launches,
             "note": "small-row workloads are bound by request rate and dependent-step latency, not HBM bytes: the "
