@@ -86,6 +86,7 @@ struct EpxBatch {
   int32_t* deps;
   int32_t* leader_deps;
   int32_t* own_values_end;  // [m][2]: explicit values of the own-leader column of deps / leader_deps (0 = none)
+  int2* meta;               // [m] or null: (number, resp_mask | seen_mask << 8) of message i, ONE gather for k_epx_key
   uint8_t* fused;           // [num_keys] or null: 1 = k_epx_key did the key's scan and decisions on chip
   int32_t* unfused;         // number of keys left to k_epx_scan / k_epx_decide (null: all of them)
 };
@@ -134,6 +135,7 @@ __global__ void __launch_bounds__(256) k_epx_keys(const EpxState st, const EpxBa
   ok = ok && !((mask >> (ok ? L : 0)) & 1u) && (mask >> n) == 0 && __popc(mask) == n - 2;
   const unsigned seen = b.seen_mask ? b.seen_mask[i] : mask;
   ok = ok && (mask & ~seen) == 0 && !((seen >> (ok ? L : 0)) & 1u) && (seen >> n) == 0;
+  if (b.meta) b.meta[i] = make_int2(b.number[i], (int)(mask | (seen << 8)));
   for (int r = 0; r < n; ++r) {
     const int p = b.rank[(size_t)r * b.m + i];
     ok = ok && p >= 0 && p < b.m;
@@ -709,10 +711,9 @@ __global__ void __launch_bounds__(KeyTile<N>::THREADS) k_epx_key(const EpxState 
     for (int c = 0; c < T::CPW; ++c) {
       gnum[c] = 0, gmask[c] = 0;
       if (have[c] && (int)(kv[c].x >> EPX_LEADER_SHIFT) == r) {
-        const int i = (int)kv[c].y;
-        const unsigned mask = b.resp_mask[i];
-        gnum[c] = b.number[i];
-        gmask[c] = mask | ((b.seen_mask ? (unsigned)b.seen_mask[i] : mask) << 8);
+        const int2 mt = b.meta[kv[c].y];  // written by k_epx_keys: three arrays in one 8-byte gather
+        gnum[c] = mt.x;
+        gmask[c] = (unsigned)mt.y;
       }
     }
   };
@@ -1229,7 +1230,7 @@ struct fpx_epx {
   EpxState st;
   hipStream_t stream = nullptr, own_stream = nullptr;
   int last_hip = 0;
-  Buf kv, kv2, seg, conf, tmp, tick, h_leader, h_number, h_key, h_set, h_mask, h_seen, h_rank, h_triple, o_fast, o_deps, o_ldeps, o_own, cl, hp, fusedb;
+  Buf kv, kv2, seg, conf, tmp, tick, h_leader, h_number, h_key, h_set, h_mask, h_seen, h_rank, h_triple, o_fast, o_deps, o_ldeps, o_own, cl, hp, fusedb, metab;
   uint32_t cl_run = 0;
   bool lds_allowed = false, sort_lds_allowed = false;
   int num_cus = 256;
@@ -1417,7 +1418,7 @@ int32_t fpx_epx_destroy(fpx_epx* e) {
     if (p) (void)hipFree(p);
   Buf* bs[] = {&e->kv, &e->kv2, &e->seg, &e->conf, &e->tmp, &e->tick, &e->h_leader, &e->h_number,
                &e->h_key, &e->h_set, &e->h_mask, &e->h_seen, &e->h_rank, &e->h_triple, &e->o_fast, &e->o_deps, &e->o_ldeps,
-               &e->o_own, &e->cl, &e->hp, &e->fusedb};
+               &e->o_own, &e->cl, &e->hp, &e->fusedb, &e->metab};
   for (Buf* b : bs)
     if (b->p) (void)hipFree(b->p);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -1475,6 +1476,8 @@ int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, co
     if ((rc = grow(e, &e->fusedb, (size_t)e->st.num_keys + 64))) return rc;
     b.unfused = (int32_t*)e->fusedb.p;
     b.fused = (uint8_t*)e->fusedb.p + 64;
+    if ((rc = grow(e, &e->metab, (size_t)m * 8))) return rc;
+    b.meta = (int2*)e->metab.p;
   }
   // (counting the first pass's histogram in k_epx_keys with global atomics was tried: 5 M atomics on 327 k counters
   // took 450 us against 22 us for the histogram kernel)
