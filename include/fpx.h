@@ -403,7 +403,7 @@ int32_t fpx_epx_sync(fpx_epx* epx);
  * applied); it records PreAcceptedEntry(Ballot(0, leader), Ballot(0, leader), triple) at the participants, and a
  * fast-path commit turns the entry into CommittedEntry at every replica.
  *
- * Both calls below deliver message i, in array order, to the replicas in target_mask[i] (bit r); the instances
+ * The three calls below deliver message i, in array order, to the replicas in target_mask[i] (bit r); the instances
  * (leader[i], number[i]) of one call must be pairwise distinct (FPX_EINVAL otherwise, nothing applied).  Replies
  * per message (host pointers, may be NULL): ok_bits / nack_bits / commit_bits (the replica answered with the Commit
  * it already holds), nack_ballot = the largest `largestBallot` carried by a Nack (Nack(instance, largestBallot),
