@@ -131,3 +131,17 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
     assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "8", "--steps", "5"] and cmd[-5].endswith("bench.py")
+
+
+def test_bench_deadline_helper():
+    """bench.run_with_deadline: a value, an exception turned into an "error" field, and a call that never returns
+    reported as such (the multi-GPU run uses it around the extra replica-axis row)"""
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.run_with_deadline(lambda: {"x": 1}, 5, None) == ({"x": 1}, False)
+    out, hung = bench.run_with_deadline(lambda: 1 // 0, 5, None)
+    assert not hung and "ZeroDivisionError" in out["error"]
+    out, hung = bench.run_with_deadline(lambda: time.sleep(3), 0.2, None)
+    assert hung and "no answer" in out["error"]
