@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256) k_epx_keys(const EpxState st, const EpxBa
   const int L = b.leader[i], k = b.key[i];
   const unsigned mask = b.resp_mask[i];
   bool ok = L >= 0 && L < n && b.number[i] >= 0 && k >= 0 && k < st.num_keys;
-  ok = ok && !((mask >> (ok ? L : 0)) & 1u) && (mask >> n) == 0 && __popc(mask) == n - 2;
+  ok = ok && !((mask >> (ok ? L : 0)) & 1u) && (mask >> n) == 0 && (int)__popc(mask) == n - 2;
   const unsigned seen = b.seen_mask ? b.seen_mask[i] : mask;
   ok = ok && (mask & ~seen) == 0 && !((seen >> (ok ? L : 0)) & 1u) && (seen >> n) == 0;
   if (b.meta) b.meta[i] = make_int2(b.number[i], (int)(mask | (seen << 8)));
@@ -1052,7 +1052,7 @@ __global__ void __launch_bounds__(256) k_cl_commit(const EpxState st, const ClBa
   if (!b.skip[i]) {
     const unsigned ok = b.ok_bits[i] | (1u << b.b_rep[i]);  // :780-789 the proposer's own AcceptOk
     b.ok_bits[i] = (uint8_t)ok;
-    if (__popc(ok) >= f + 1) {
+    if ((int)__popc(ok) >= f + 1) {
       done = 1;
       for (int r = 0; r < n; ++r) {
         const size_t c = ((size_t)r * n + b.leader[i]) * st.num_instances + b.number[i];
