@@ -171,7 +171,11 @@ constexpr int RS_ITEMS = FPX_RS_ITEMS;      // 64-element steps per wavefront
 constexpr int RS_TILE = 256 * RS_ITEMS;     // elements per workgroup tile
 constexpr int RS_MAXW = 11;                 // widest digit
 constexpr int RS_MAXB = 1 << RS_MAXW;
-constexpr size_t RS_SCATTER_LDS = (size_t)RS_TILE * 8 + (size_t)8 * (RS_MAXB / 2) * 4 + (size_t)RS_MAXB * 4 + 64;
+#ifndef FPX_RS_SW
+#define FPX_RS_SW 8
+#endif
+constexpr int RS_SW = FPX_RS_SW;               // wavefronts of a scatter workgroup
+constexpr size_t RS_SCATTER_LDS = (size_t)RS_TILE * 8 + (size_t)RS_SW * (RS_MAXB / 2) * 4 + (size_t)RS_MAXB * 4 + 64;
 
 struct RsArgs {
   int m, tiles, shift;
@@ -289,7 +293,6 @@ __device__ __forceinline__ uint32_t block_excl_sum_256(uint32_t v, uint32_t* sh)
 // 8 wavefronts per tile, each ranks an eighth of it (8 steps of 64): twice the wavefronts per CU of a 4-wavefront
 // version at the same LDS, and half the serial chain per wavefront.  The per-wavefront digit counters / cursors are
 // 16 bits wide (a tile has 4096 elements), two digits per LDS word, updated with 32-bit LDS atomics on the half.
-constexpr int RS_SW = 8;                      // wavefronts of a scatter workgroup
 constexpr int RS_SITEMS = RS_TILE / (64 * RS_SW);
 static_assert(RS_TILE <= 65535 && RS_TILE % (64 * RS_SW) == 0, "16-bit cursors; whole steps");
 
@@ -652,7 +655,8 @@ __global__ void __launch_bounds__(256) k_epx_decide(const EpxState st, const Epx
 // correct and merely lose the shortcut on their hot keys.
 template <int N> struct KeyTile {
   static constexpr int TC = N <= 3 ? 2048 : N <= 5 ? 1152 : 576;   // commands of one key held on chip
-  static constexpr int HC = N <= 3 ? 4096 : N <= 5 ? 2048 : 1024;  // hash slots: a power of two, load <= 0.57
+  static constexpr int HC = N <= 3 ? 8192 : N <= 5 ? 4096 : 2048;  // hash slots: a power of two, load <= 0.28 (at 0.56
+                                                                   // the probe chains cost 7 us per tick, n = 5)
   static constexpr int W = N <= 3 ? 4 : N <= 5 ? 3 : 2;             // wavefronts per replica segment
   static constexpr int MAXC = (TC + 63) / 64;                       // 64-command chunks of one segment
   static constexpr int CPW = (MAXC + W - 1) / W;                    // chunks per wavefront
