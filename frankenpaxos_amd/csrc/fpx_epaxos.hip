@@ -174,7 +174,7 @@ constexpr int RS_MAXB = 1 << RS_MAXW;
 #ifndef FPX_RS_SW
 #define FPX_RS_SW 8
 #endif
-constexpr int RS_SW = FPX_RS_SW;               // wavefronts of a scatter workgroup
+constexpr int RS_SW = FPX_RS_SW;               // wavefronts of a scatter workgroup: 4 / 8 / 16 measured 0.259 / 0.240 / 0.255 ms per tick
 constexpr size_t RS_SCATTER_LDS = (size_t)RS_TILE * 8 + (size_t)RS_SW * (RS_MAXB / 2) * 4 + (size_t)RS_MAXB * 4 + 64;
 
 struct RsArgs {
