@@ -11,6 +11,7 @@ Pure-Python loops: small cases only.
     multipaxos/Acceptor.scala:148-182  handlePhase1a        :184-220  handlePhase2a
     multipaxos/ProxyLeader.scala:175-215  handlePhase2a     :217-258  handlePhase2b
     quorums/SimpleMajority.scala:41-49, quorums/Grid.scala:43-50, quorums/UnanimousWrites.scala:44-51
+    multipaxos/Leader.scala:306-329 maxPhase1bSlot / safeValue, :543-566 the recovery loop over chosenWatermark..maxSlot
 """
 
 
@@ -90,3 +91,24 @@ class ProxyLeader:
             return None
         self.states[(slot, round_)] = "done"
         return ("chosen", st[1])
+
+
+NOOP = -1
+
+
+def phase1b(acceptor, chosen_watermark):
+    """Acceptor.handlePhase1a's reply (Acceptor.scala:167-181): the votes at or above the watermark"""
+    return {slot: st for slot, st in acceptor.states.items() if slot >= chosen_watermark}
+
+
+def leader_recovery(phase1bs_by_group, chosen_watermark, num_groups):
+    """Leader.scala:543-566: maxSlot over every Phase1b received; for slot in chosenWatermark..maxSlot the safe value
+    among the Phase1b's of the slot's acceptor group (:318-329: the vote with the highest voteRound, Noop if none).
+    phase1bs_by_group[g] = the Phase1b infos ({slot: (voteRound, voteValue)}) of the acceptors that answered.
+    Returns (maxSlot, [(voteRound or -1, value or NOOP)])."""
+    max_slot = max([max(info) if info else -1 for group in phase1bs_by_group for info in group] or [-1])   # :306-312
+    out = []
+    for slot in range(chosen_watermark, max_slot + 1):
+        infos = [info[slot] for info in phase1bs_by_group[slot % num_groups] if slot in info]
+        out.append(max(infos, key=lambda rv: rv[0]) if infos else (-1, NOOP))
+    return max_slot, out

@@ -105,6 +105,15 @@ def test_flat_oracle_and_map_model_agree(oracle, R, G, f, kind, rows, cols):
                 if isinstance(got, tuple):
                     assert cr[0] == rnd and cv[0] == got[1]
                     seen["chosen"] += 1
+    # a new leader's recovery (Leader.scala:306-329, 543-566) from the Phase1b's of random acceptor subsets
+    for watermark in (0, 5, S // 2, S - 3, S + 4):
+        who = [[i for i in range(R) if rng.random() < 0.6] or [0] for _ in range(G)]
+        masks = np.stack([oracle.bits_of(w) for w in who])
+        st, mx, sr, sv = ref.leader_phase1b_scan(watermark, masks, S)
+        want_max, want = model.leader_recovery([[model.phase1b(accs[g][i], watermark) for i in who[g]] for g in range(G)],
+                                               watermark, G)
+        assert st == 0 and mx == want_max
+        assert list(zip(sr.tolist(), sv.tolist())) == want
     vr, vv, _ = ref.read_state()
     pr, mv = ref.read_scalars()
     for g in range(G):
