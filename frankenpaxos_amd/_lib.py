@@ -78,6 +78,7 @@ SIGNATURES = {
     "fpx_error_detail": (C.c_int32, [VP, I32P, I32P, I32P]),
     "fpx_last_hip_error": (C.c_int32, [VP]),
     "fpx_device_bytes": (C.c_int64, [VP]),
+    "fpx_get_config": (C.c_int32, [VP, CFGP]),
     "fpx_host_alloc": (C.c_int32, [C.c_int64, C.POINTER(C.c_void_p)]),
     "fpx_host_free": (C.c_int32, [VP]),
     "fpx_profile_enable": (C.c_int32, [VP, C.c_int32]),
@@ -110,12 +111,13 @@ SIGNATURES = {
     "fpx_proxy_forget": (C.c_int32, [VP, C.c_int32, C.c_int32]),
     "fpx_epx_create": (C.c_int32, [VP, C.POINTER(VP)]),
     "fpx_epx_destroy": (C.c_int32, [VP]),
+    "fpx_epx_info": (C.c_int32, [VP, I32P, I32P, I32P]),
     "fpx_epx_set_stream": (C.c_int32, [VP, VP]),
     "fpx_epx_sync": (C.c_int32, [VP]),
     "fpx_epx_preaccept": (C.c_int32, [VP, C.c_int32] + [VP] * 12),
     "fpx_epx_preaccept_dev": (C.c_int32, [VP, C.c_int32] + [VP] * 12),
     "fpx_epx_prepare": (C.c_int32, [VP, C.c_int32] + [VP] * 12),
-    "fpx_epx_accept": (C.c_int32, [VP, C.c_int32] + [VP] * 11),
+    "fpx_epx_accept": (C.c_int32, [VP, C.c_int32] + [VP] * 13),
     "fpx_epx_read_cmdlog": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, VP]),
     "fpx_epx_read_cmdlog_deps": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, VP, VP]),
     "fpx_epx_handle_preaccept": (C.c_int32, [VP, C.c_int32] + [VP] * 18),

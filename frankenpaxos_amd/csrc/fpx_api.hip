@@ -638,6 +638,12 @@ int host_fused_pipelined(fpx_ctx* ctx, int n, const int32_t* slot, const int32_t
   uint64_t* d_target = target_mask ? (uint64_t*)ctx->d_target.p : nullptr;
   uint8_t* d_ch = (uint8_t*)ctx->d_u8.p;
   int32_t *d_cr = (int32_t*)ctx->d_i32_a.p, *d_cv = (int32_t*)ctx->d_i32_b.p, *d_nr = (int32_t*)ctx->d_i32_c.p;
+  // every early return below (HIPCHK) must leave the context as it found it: a FPX_F_TRUSTED context that kept
+  // force_validate / index_base would silently validate and report shifted indices ever after
+  struct PieceGuard {
+    fpx_ctx* c;
+    ~PieceGuard() { c->force_validate = false, c->index_base = 0; }
+  } _pg{ctx};
   ctx->force_validate = true;
   for (int k = 0; k < pieces && rc == FPX_OK; ++k) {
     const int lo = k * piece, len = std::min(piece, n - lo);
@@ -945,6 +951,12 @@ int32_t fpx_profile_read(fpx_ctx* ctx, int32_t* launches, double* total_ms) {
 
 int32_t fpx_last_hip_error(fpx_ctx* ctx) {
   DeviceGuard _dg(ctx); return ctx ? ctx->last_hip : 0; }
+int32_t fpx_get_config(fpx_ctx* ctx, fpx_config* out) {
+  if (!ctx || !out) return FPX_EINVAL;
+  *out = ctx->cfg;
+  return FPX_OK;
+}
+
 int64_t fpx_device_bytes(fpx_ctx* ctx) {
   DeviceGuard _dg(ctx); return ctx ? ctx->bytes : 0; }
 
@@ -1741,11 +1753,15 @@ int32_t fpx_read_acceptor(fpx_ctx* ctx, int32_t group, int32_t replica, int32_t*
 }
 
 // ---- multi-GPU: RCCL behind the C ABI ------------------------------------------------------------------
+static RcclApi* rccl_bind();
+// bound once per process, also when two contexts create their communicators from two threads (a function-local
+// static's initialiser runs exactly once)
 static RcclApi* rccl() {
+  static RcclApi* const bound = rccl_bind();
+  return bound;
+}
+static RcclApi* rccl_bind() {
   static RcclApi api;
-  static bool tried = false;
-  if (tried) return api.lib ? &api : nullptr;
-  tried = true;
   void* h = nullptr;
   const char* env = getenv("FPX_RCCL_LIB");
   if (env && *env) h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);

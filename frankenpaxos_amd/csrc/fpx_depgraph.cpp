@@ -477,9 +477,10 @@ int32_t fpx_depgraph_commit(fpx_depgraph* g, int32_t n, const int32_t* leader, c
   for (int64_t k = 0; k < (int64_t)n * g->L; k++)
     if (dep_watermark[k] < 0) return FPX_EINVAL;
   if (dep_values_off) {
-    if (!dep_values_leader || !dep_values_id || dep_values_off[0] < 0) return FPX_EINVAL;
+    if (dep_values_off[0] < 0) return FPX_EINVAL;
     for (int32_t i = 0; i < n; i++)
       if (dep_values_off[i + 1] < dep_values_off[i]) return FPX_EINVAL;
+    if (dep_values_off[n] > dep_values_off[0] && (!dep_values_leader || !dep_values_id)) return FPX_EINVAL;
     for (int64_t j = dep_values_off[0]; j < dep_values_off[n]; j++)
       if (dep_values_leader[j] < 0 || dep_values_leader[j] >= g->L || dep_values_id[j] < 0) return FPX_EINVAL;
   }

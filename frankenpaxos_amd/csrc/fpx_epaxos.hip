@@ -889,6 +889,8 @@ struct ClBatch {
   const int32_t* b_ord;
   const int32_t* b_rep;
   const int32_t* triple;   // Accept
+  const int32_t* key;      // Accept: the command's key, -1 = Noop
+  const uint8_t* is_set;   // Accept
   const uint8_t* target;
   uint8_t* ok_bits;
   uint8_t* nack_bits;
@@ -906,6 +908,15 @@ struct ClBatch {
 };
 constexpr int CL_TILE = 1024;
 
+// updateConflictIndex(instance, commandOrNoop) (Replica.scala:602-614) at replica r: conflictIndex.put = a max-merge of
+// the TopOne column of the instance's leader (util/TopOne.scala:14-17), so several messages of one batch may land on
+// one cell in any order; a Noop leaves the index alone
+__device__ __forceinline__ void index_put(const EpxState& st, int r, int key, int is_set, int L, int x) {
+  if (key < 0) return;
+  int32_t* a = is_set ? st.sets : st.gets;
+  atomicMax(&a[((size_t)r * st.num_keys + key) * st.n + L], x + 1);
+}
+
 // an Accept names its triple by the caller's id alone: the stored dependencies are marked unknown
 __device__ __forceinline__ void deps_by_id(const EpxState& st, size_t cell) {
   for (int l = 0; l < st.n; ++l) st.cl_deps[cell * st.n + l] = -1;
@@ -919,6 +930,7 @@ __global__ void __launch_bounds__(256) k_cl_validate(const EpxState st, const Cl
   bool ok = L >= 0 && L < n && x >= 0 && x < st.num_instances && bo >= 0 && bo < (1 << 27) && br >= 0 && br < n &&
             (b.target[i] >> n) == 0;
   if (ok && b.accept) ok = !((b.target[i] >> br) & 1u);  // thriftyOtherReplicas: never the proposer itself (:774)
+  if (ok && b.accept) ok = b.key[i] >= -1 && b.key[i] < st.num_keys;
   if (ok) ok = atomicExch(&st.cl_stamp[(size_t)L * st.num_instances + x], b.run_id) != b.run_id;
   if (!ok) epx_report(st.status, FPX_EINVAL, i);
 }
@@ -941,6 +953,7 @@ __global__ void __launch_bounds__(256) k_cl_propose(const EpxState st, const ClB
   }
   st.cl_status[c] = CL_ACCEPTED, st.cl_ballot[c] = ballot, st.cl_vote[c] = ballot, st.cl_triple[c] = b.triple[i];  // :759-762
   deps_by_id(st, c);
+  index_put(st, P, b.key[i], b.is_set[i], b.leader[i], b.number[i]);  // :763
 }
 
 // handlePrepare (:1632-1757) / handleAccept (:1421-1511) at replica r for message i: one thread per (i, r)
@@ -977,6 +990,7 @@ __global__ void __launch_bounds__(256) k_cl_handle(const EpxState st, const ClBa
         contrib = ballot;  // :1487
         st.cl_status[c] = CL_ACCEPTED, st.cl_ballot[c] = ballot, st.cl_vote[c] = ballot, st.cl_triple[c] = b.triple[i];
         deps_by_id(st, c);
+        index_put(st, r, b.key[i], b.is_set[i], b.leader[i], b.number[i]);  // :1503
       }
     }
   }
@@ -1062,6 +1076,7 @@ __global__ void __launch_bounds__(256) k_cl_commit(const EpxState st, const ClBa
         const size_t c = ((size_t)r * n + b.leader[i]) * st.num_instances + b.number[i];
         st.cl_status[c] = CL_COMMITTED, st.cl_ballot[c] = -1, st.cl_vote[c] = -1, st.cl_triple[c] = b.triple[i];
         deps_by_id(st, c);
+        index_put(st, r, b.key[i], b.is_set[i], b.leader[i], b.number[i]);  // commit :828, at every replica (Commit)
       }
     }
   }
@@ -1548,27 +1563,29 @@ int32_t fpx_epx_preaccept(fpx_epx* e, int32_t m, const int32_t* leader, const in
 
 // Prepare / Accept on the command log: stage, validate, handle, scan the largestBallot's, (Accept) tally + commit
 static int32_t cl_run(fpx_epx* e, int accept, int32_t m, const int32_t* leader, const int32_t* number,
-                      const int32_t* b_ord, const int32_t* b_rep, const int32_t* triple, const uint8_t* target,
-                      uint8_t* ok_bits, uint8_t* nack_bits, uint8_t* commit_bits, int32_t* nack_ballot,
-                      uint8_t* committed, int32_t* reply_status, int32_t* reply_vote, int32_t* reply_triple) {
+                      const int32_t* b_ord, const int32_t* b_rep, const int32_t* triple, const int32_t* key,
+                      const uint8_t* is_set, const uint8_t* target, uint8_t* ok_bits, uint8_t* nack_bits,
+                      uint8_t* commit_bits, int32_t* nack_ballot, uint8_t* committed, int32_t* reply_status,
+                      int32_t* reply_vote, int32_t* reply_triple) {
   if (!e || m < 0) return FPX_EINVAL;
   EpxDeviceGuard _dg(e->cfg.device);
   if (e->st.num_instances <= 0) return FPX_EINVAL;
   if (m == 0) return FPX_OK;
-  if (!leader || !number || !b_ord || !b_rep || !target || (accept && !triple)) return FPX_EINVAL;
+  if (!leader || !number || !b_ord || !b_rep || !target || (accept && (!triple || !key || !is_set))) return FPX_EINVAL;
   const int n = e->st.n;
   const int tiles = (m + CL_TILE - 1) / CL_TILE;
   const size_t mp = ((size_t)m + 63) & ~(size_t)63;
-  // staging: 5 int32 inputs, target, 3 reply bit arrays, skip, committed, nack_ballot, 3 reply int arrays [m][n],
-  // contrib [n][m], nackflag [n][m], tilemax [n][tiles]
-  const size_t bytes = mp * 4 * 5 + mp * 6 + mp * 4 + (size_t)m * n * 4 * 3 + (size_t)n * mp * 4 + (size_t)n * mp +
-                       (size_t)n * tiles * 4 + 1024;
+  // staging: 6 int32 inputs, is_set, target, 3 reply bit arrays, skip, committed, nack_ballot, 3 reply int arrays
+  // [m][n], contrib [n][m], nackflag [n][m], tilemax [n][tiles]
+  const size_t bytes = mp * 4 * 6 + mp * 7 + mp * 4 + (size_t)m * n * 4 * 3 + (size_t)n * mp * 4 + (size_t)n * mp +
+                       (size_t)n * tiles * 4 + 2048;
   int rc;
   if ((rc = grow(e, &e->cl, bytes))) return rc;
   char* p = (char*)e->cl.p;
   auto take = [&](size_t sz) { char* q = p; p += (sz + 63) & ~(size_t)63; return q; };
   int32_t* d_leader = (int32_t*)take(mp * 4); int32_t* d_number = (int32_t*)take(mp * 4);
   int32_t* d_bo = (int32_t*)take(mp * 4); int32_t* d_br = (int32_t*)take(mp * 4); int32_t* d_tr = (int32_t*)take(mp * 4);
+  int32_t* d_key = (int32_t*)take(mp * 4); uint8_t* d_set = (uint8_t*)take(mp);
   uint8_t* d_tgt = (uint8_t*)take(mp); uint8_t* d_ok = (uint8_t*)take(mp); uint8_t* d_nack = (uint8_t*)take(mp);
   uint8_t* d_com = (uint8_t*)take(mp); uint8_t* d_skip = (uint8_t*)take(mp); uint8_t* d_done = (uint8_t*)take(mp);
   int32_t* d_nb = (int32_t*)take(mp * 4);
@@ -1581,12 +1598,15 @@ static int32_t cl_run(fpx_epx* e, int accept, int32_t m, const int32_t* leader, 
   EHIP(e, hipMemcpyAsync(d_bo, b_ord, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
   EHIP(e, hipMemcpyAsync(d_br, b_rep, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
   if (accept) EHIP(e, hipMemcpyAsync(d_tr, triple, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+  if (accept) EHIP(e, hipMemcpyAsync(d_key, key, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+  if (accept) EHIP(e, hipMemcpyAsync(d_set, is_set, (size_t)m, hipMemcpyHostToDevice, e->stream));
   EHIP(e, hipMemcpyAsync(d_tgt, target, (size_t)m, hipMemcpyHostToDevice, e->stream));
   EHIP(e, hipMemsetAsync(d_ok, 0, mp * 5, e->stream));  // ok, nack, commit, skip, committed are contiguous
   EHIP(e, hipMemsetAsync(d_nb, 0xFF, mp * 4, e->stream));
   ClBatch b;
   memset(&b, 0, sizeof(b));
   b.m = m, b.accept = accept, b.leader = d_leader, b.number = d_number, b.b_ord = d_bo, b.b_rep = d_br, b.triple = d_tr;
+  b.key = d_key, b.is_set = d_set;
   b.target = d_tgt, b.ok_bits = d_ok, b.nack_bits = d_nack, b.commit_bits = d_com, b.nack_ballot = d_nb;
   b.committed = d_done, b.reply_status = d_rs, b.reply_vote = d_rv, b.reply_triple = d_rt;
   b.contrib = d_contrib, b.nackflag = d_flag, b.tilemax = d_tm, b.skip = d_skip;
@@ -1623,15 +1643,16 @@ int32_t fpx_epx_prepare(fpx_epx* e, int32_t m, const int32_t* leader, const int3
                         const int32_t* ballot_replica, const uint8_t* target_mask, uint8_t* ok_bits, uint8_t* nack_bits,
                         uint8_t* commit_bits, int32_t* nack_ballot, int32_t* reply_status, int32_t* reply_vote_ballot,
                         int32_t* reply_triple) {
-  return cl_run(e, 0, m, leader, number, ballot_ordering, ballot_replica, nullptr, target_mask, ok_bits, nack_bits,
-                commit_bits, nack_ballot, nullptr, reply_status, reply_vote_ballot, reply_triple);
+  return cl_run(e, 0, m, leader, number, ballot_ordering, ballot_replica, nullptr, nullptr, nullptr, target_mask, ok_bits,
+                nack_bits, commit_bits, nack_ballot, nullptr, reply_status, reply_vote_ballot, reply_triple);
 }
 
 int32_t fpx_epx_accept(fpx_epx* e, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* ballot_ordering,
-                       const int32_t* ballot_replica, const int32_t* triple_id, const uint8_t* target_mask, uint8_t* ok_bits,
-                       uint8_t* nack_bits, uint8_t* commit_bits, int32_t* nack_ballot, uint8_t* committed) {
-  return cl_run(e, 1, m, leader, number, ballot_ordering, ballot_replica, triple_id, target_mask, ok_bits, nack_bits,
-                commit_bits, nack_ballot, committed, nullptr, nullptr, nullptr);
+                       const int32_t* ballot_replica, const int32_t* triple_id, const int32_t* key, const uint8_t* is_set,
+                       const uint8_t* target_mask, uint8_t* ok_bits, uint8_t* nack_bits, uint8_t* commit_bits,
+                       int32_t* nack_ballot, uint8_t* committed) {
+  return cl_run(e, 1, m, leader, number, ballot_ordering, ballot_replica, triple_id, key, is_set, target_mask, ok_bits,
+                nack_bits, commit_bits, nack_ballot, committed, nullptr, nullptr, nullptr);
 }
 
 int32_t fpx_epx_handle_preaccept(fpx_epx* e, int32_t m, const int32_t* leader, const int32_t* number,
@@ -1771,6 +1792,14 @@ int32_t fpx_epx_read_cmdlog(fpx_epx* e, int32_t replica, int32_t leader, int32_t
   EHIP(e, hipMemcpy(&out[2], e->st.cl_vote + c, 4, hipMemcpyDeviceToHost));
   EHIP(e, hipMemcpy(&out[3], e->st.cl_triple + c, 4, hipMemcpyDeviceToHost));
   EHIP(e, hipMemcpy(&out[4], e->st.largest + replica, 4, hipMemcpyDeviceToHost));
+  return FPX_OK;
+}
+
+int32_t fpx_epx_info(fpx_epx* e, int32_t* num_replicas, int32_t* num_keys, int32_t* num_instances) {
+  if (!e) return FPX_EINVAL;
+  if (num_replicas) *num_replicas = e->st.n;
+  if (num_keys) *num_keys = e->st.num_keys;
+  if (num_instances) *num_instances = e->st.num_instances;
   return FPX_OK;
 }
 

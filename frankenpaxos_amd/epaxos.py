@@ -94,17 +94,20 @@ class EPaxos:
                                     p(nb), p(rs), p(rv), p(rt))
         return st, ok, nack, com, nb, rs, rv, rt
 
-    def accept(self, leader, number, ballot_ordering, ballot_replica, triple_id, target_mask):
-        """the Accept phase: (status, ok_bits, nack_bits, commit_bits, nack_ballot, committed)"""
+    def accept(self, leader, number, ballot_ordering, ballot_replica, triple_id, target_mask, key=None, is_set=None):
+        """the Accept phase: (status, ok_bits, nack_bits, commit_bits, nack_ballot, committed).  key / is_set: the
+        triples' commands (updateConflictIndex wherever the triple is stored); key None = every triple is a Noop"""
         a32 = lambda x: np.ascontiguousarray(x, dtype=np.int32)
         leader, number, bo, br, tr = a32(leader), a32(number), a32(ballot_ordering), a32(ballot_replica), a32(triple_id)
         tgt = np.ascontiguousarray(target_mask, dtype=np.uint8)
         m = len(leader)
+        key = np.full(m, -1, np.int32) if key is None else a32(key)
+        is_set = np.zeros(m, np.uint8) if is_set is None else np.ascontiguousarray(is_set, dtype=np.uint8)
         ok, nack, com, done = (np.zeros(m, np.uint8) for _ in range(4))
         nb = np.full(m, -1, np.int32)
         p = lambda a: a.ctypes.data
-        st = self.L.fpx_epx_accept(self._h, m, p(leader), p(number), p(bo), p(br), p(tr), p(tgt), p(ok), p(nack),
-                                   p(com), p(nb), p(done))
+        st = self.L.fpx_epx_accept(self._h, m, p(leader), p(number), p(bo), p(br), p(tr), p(key), p(is_set), p(tgt),
+                                   p(ok), p(nack), p(com), p(nb), p(done))
         return st, ok, nack, com, nb, done
 
     def handle_preaccept(self, leader, number, ballot_ordering, ballot_replica, key, is_set, triple_id, deps_in,

@@ -14,6 +14,8 @@
 //                                                            mencius/Acceptor.scala:237-291,
 //                                                            mencius/ProxyLeader.scala:255-303, 355-411
 //   frankenpaxos.epaxos.Replica pre-accept fast path         epaxos/Replica.scala:569-600, 633-729, 1159-1419
+//   frankenpaxos.depgraph.{DependencyGraph, TarjanDependencyGraph, ZigzagTarjanDependencyGraph}
+//                                                            depgraph/*.scala; epaxos/Replica.scala:859-917
 //
 // but batched: a handler takes the messages one event-loop tick delivered and returns the messages
 // the reference handlers would have sent.  require(...) failures throw std::invalid_argument
@@ -31,6 +33,7 @@
 #include <vector>
 
 #include "../../include/fpx.h"
+#include "../../include/fpx_depgraph.h"
 
 namespace frankenpaxos {
 
@@ -533,6 +536,100 @@ class NoopRangeEngine {
 
 }  // namespace mencius
 
+namespace depgraph {
+
+// depgraph/DependencyGraph.scala:126-192 with Key = (leaderIndex, id) (epaxos.Instance; util/VertexIdLike.scala),
+// SequenceNumber = Int, KeySet = an InstancePrefixSet (per leader: a watermark + explicit ids).  Host code of libfpx
+// (csrc/fpx_depgraph.cpp); include/fpx_depgraph.h says which orders the reference leaves open and what is taken.
+using Key = std::pair<int32_t, int32_t>;
+struct KeySet {
+  std::vector<int32_t> watermarks;  // one per leader; empty = all 0
+  std::vector<Key> values;
+};
+enum class Kind { Tarjan = FPX_DG_TARJAN, ZigzagTarjan = FPX_DG_ZIGZAG };
+
+class DependencyGraph {
+ public:
+  // TarjanDependencyGraph.scala:171-183 / ZigzagTarjanDependencyGraph.scala:247-262 (options.garbageCollectEveryNCommands)
+  explicit DependencyGraph(int numLeaders, Kind kind = Kind::ZigzagTarjan, int garbageCollectEveryNCommands = 1000)
+      : n_(numLeaders) {
+    fpx_depgraph_config c{(int32_t)kind, numLeaders, garbageCollectEveryNCommands};
+    if (fpx_depgraph_create(&c, &g_) != FPX_OK) throw std::invalid_argument("DependencyGraph: bad configuration");
+  }
+  ~DependencyGraph() {
+    if (g_) fpx_depgraph_destroy(g_);
+  }
+  DependencyGraph(const DependencyGraph&) = delete;
+  DependencyGraph& operator=(const DependencyGraph&) = delete;
+  int numLeaders() const { return n_; }
+
+  // :140-144
+  void commit(Key key, int32_t sequenceNumber, const KeySet& dependencies) {
+    std::vector<int32_t> wm = dependencies.watermarks.empty() ? std::vector<int32_t>(n_, 0) : dependencies.watermarks;
+    if ((int)wm.size() != n_) throw std::invalid_argument("one watermark per leader");
+    std::vector<int32_t> vl, vi;
+    for (const Key& k : dependencies.values) vl.push_back(k.first), vi.push_back(k.second);
+    const int64_t off[2] = {0, (int64_t)vl.size()};
+    check(fpx_depgraph_commit(g_, 1, &key.first, &key.second, &sequenceNumber, wm.data(), off, vl.data(), vi.data()));
+  }
+  // a tick's committed triples in the encoding the GPU kernels produce (fpx_depgraph_commit_epx)
+  void commitEpaxos(const std::vector<int32_t>& leader, const std::vector<int32_t>& id, const std::vector<int32_t>& deps,
+                    const std::vector<int32_t>& ownValuesEnd) {
+    check(fpx_depgraph_commit_epx(g_, (int32_t)leader.size(), leader.data(), id.data(), nullptr, deps.data(),
+                                  ownValuesEnd.empty() ? nullptr : ownValuesEnd.data(), 1, nullptr));
+  }
+  // :170-176
+  std::pair<std::vector<std::vector<Key>>, std::set<Key>> executeByComponent(std::optional<int> numBlockers = {}) {
+    int64_t ne = 0, nc = 0, nb = 0;
+    check(fpx_depgraph_execute(g_, numBlockers ? *numBlockers : -1, &ne, &nc, &nb));
+    std::vector<int32_t> el((size_t)ne), ei((size_t)ne), cs((size_t)nc), bl((size_t)nb), bi((size_t)nb);
+    check(fpx_depgraph_read_result(g_, el.data(), ei.data(), cs.data(), bl.data(), bi.data()));
+    std::pair<std::vector<std::vector<Key>>, std::set<Key>> out;
+    size_t at = 0;
+    for (int32_t c : cs) {
+      out.first.emplace_back();
+      for (int32_t k = 0; k < c; ++k, ++at) out.first.back().emplace_back(el[at], ei[at]);
+    }
+    for (size_t k = 0; k < bl.size(); ++k) out.second.emplace(bl[k], bi[k]);
+    return out;
+  }
+  // :146-158
+  std::pair<std::vector<Key>, std::set<Key>> execute(std::optional<int> numBlockers = {}) {
+    auto r = executeByComponent(numBlockers);
+    std::pair<std::vector<Key>, std::set<Key>> out;
+    for (auto& c : r.first) out.first.insert(out.first.end(), c.begin(), c.end());
+    out.second = std::move(r.second);
+    return out;
+  }
+  // :160-168
+  void appendExecute(std::optional<int> numBlockers, std::vector<Key>& executables, std::set<Key>& blockers) {
+    auto r = execute(numBlockers);
+    executables.insert(executables.end(), r.first.begin(), r.first.end());
+    blockers.insert(r.second.begin(), r.second.end());
+  }
+  // :178-186
+  void updateExecuted(const KeySet& keys) {
+    std::vector<int32_t> vl, vi;
+    for (const Key& k : keys.values) vl.push_back(k.first), vi.push_back(k.second);
+    if (!keys.watermarks.empty() && (int)keys.watermarks.size() != n_)
+      throw std::invalid_argument("one watermark per leader");
+    check(fpx_depgraph_update_executed(g_, keys.watermarks.empty() ? nullptr : keys.watermarks.data(),
+                                       (int32_t)vl.size(), vl.data(), vi.data()));
+  }
+  // :188-191
+  int64_t numVertices() const { return fpx_depgraph_num_vertices(g_); }
+
+ private:
+  static void check(int32_t st) {
+    if (st == FPX_EINVAL) throw std::invalid_argument("DependencyGraph: require failed");
+    if (st != FPX_OK) throw std::runtime_error("DependencyGraph: libfpx status " + std::to_string(st));
+  }
+  int n_;
+  fpx_depgraph* g_ = nullptr;
+};
+
+}  // namespace depgraph
+
 namespace epaxos {
 
 // epaxos/EPaxos.proto:35-41
@@ -581,7 +678,7 @@ struct InstanceMessage {
   Ballot ballot;
   std::vector<int> recipients;
   int32_t tripleId = -1;                       // Accept, PreAccept
-  Command command{-1, false};                  // PreAccept: key -1 = Noop
+  Command command{-1, false};                  // Accept, PreAccept: the triple's command; key -1 = Noop
   std::vector<int32_t> dependencies;           // PreAccept: n watermarks (empty = none)
   int32_t ownValuesEnd = 0;
 };
@@ -733,8 +830,8 @@ class PreAcceptEngine {
       st = fpx_epx_prepare(epx_, m, leader.data(), number.data(), bo.data(), br.data(), tgt.data(), ok.data(), nack.data(),
                            com.data(), nb.data(), nullptr, nullptr, rt.data());
     else if (kind == 1)
-      st = fpx_epx_accept(epx_, m, leader.data(), number.data(), bo.data(), br.data(), tr.data(), tgt.data(), ok.data(),
-                          nack.data(), com.data(), nb.data(), done.data());
+      st = fpx_epx_accept(epx_, m, leader.data(), number.data(), bo.data(), br.data(), tr.data(), key.data(), isSet.data(),
+                          tgt.data(), ok.data(), nack.data(), com.data(), nb.data(), done.data());
     else
       st = fpx_epx_handle_preaccept(epx_, m, leader.data(), number.data(), bo.data(), br.data(), key.data(), isSet.data(),
                                     tr.data(), din.data(), dend.data(), tgt.data(), ok.data(), resend.data(), nack.data(),
@@ -762,6 +859,25 @@ class PreAcceptEngine {
   int n_;
   fpx_epx* epx_ = nullptr;
 };
+
+// Replica.commit's tail + Replica.execute (epaxos/Replica.scala:859-917): every committed triple of a tick goes
+// into the dependency graph (sequence number 0, :575-578), then appendExecute.  `committed[i]`: the instance of
+// proposals[i] is committed -- a fast-path Decision, or a slow-path one whose Accept phase came back committed.
+inline void commitToGraph(depgraph::DependencyGraph& graph, const std::vector<Proposal>& proposals,
+                          const std::vector<Decision>& decisions, const std::vector<bool>& committed) {
+  if (proposals.size() != decisions.size() || proposals.size() != committed.size())
+    throw std::invalid_argument("one decision and one flag per proposal");
+  const int n = graph.numLeaders();
+  std::vector<int32_t> leader, id, deps, own;
+  for (size_t i = 0; i < proposals.size(); ++i) {
+    if (!committed[i]) continue;
+    if ((int)decisions[i].dependencies.size() != n) throw std::invalid_argument("one watermark per replica");
+    leader.push_back(proposals[i].instance.replicaIndex), id.push_back(proposals[i].instance.instanceNumber);
+    deps.insert(deps.end(), decisions[i].dependencies.begin(), decisions[i].dependencies.end());
+    own.push_back(decisions[i].ownValuesEnd);
+  }
+  graph.commitEpaxos(leader, id, deps, own);
+}
 
 }  // namespace epaxos
 }  // namespace frankenpaxos

@@ -87,6 +87,7 @@ object Native {
                          replies: Array[Byte], nackBallot: Array[Int], prepareOk: Array[Int]): Int
   @native def epxAccept(handle: Long, m: Int, leader: Array[Int], number: Array[Int],
                         ballotOrdering: Array[Int], ballotReplica: Array[Int], tripleId: Array[Int],
+                        key: Array[Int], isSet: Array[Byte],
                         targetMask: Array[Byte], replies: Array[Byte], nackBallot: Array[Int]): Int
   @native def epxHandlePreaccept(handle: Long, m: Int, numReplicas: Int, leader: Array[Int],
                                  number: Array[Int], ballotOrdering: Array[Int],

@@ -60,6 +60,24 @@ static void put_bytes(JNIEnv* env, jbyteArray a, jlong n, const jbyte* p) {
   if (a && p && n > 0) (*env)->SetByteArrayRegion(env, a, 0, (jsize)n, p);
 }
 
+/* The sizes libfpx copies with are the HANDLE's (its n, its number of acceptor groups), not what the caller says the
+ * handle is: a native that takes numReplicas / numGroups (to size Java arrays on the Scala side) refuses a value that
+ * differs from the context's -- FPX_EINVAL, never a short calloc'd reply buffer. */
+static int epx_n_is(jlong h, jint numReplicas) {
+  int32_t n = 0;
+  return fpx_epx_info((fpx_epx*)(intptr_t)h, &n, NULL, NULL) == FPX_OK && n == numReplicas;
+}
+static int ctx_groups_is(jlong h, jint numGroups) {
+  fpx_config c;
+  return fpx_get_config(CTX(h), &c) == FPX_OK && c.num_groups == numGroups;
+}
+
+/* fpx_leader_phase1b_scan reads one quorum mask per (leader group, acceptor group) */
+static int ctx_all_groups_is(jlong h, jint numGroups) {
+  fpx_config c;
+  return fpx_get_config(CTX(h), &c) == FPX_OK && (jlong)c.num_groups * c.num_leader_groups == numGroups;
+}
+
 static int read_config(JNIEnv* env, jintArray jcfg, fpx_config* cfg) {
   jint c[15];
   if (!has(env, jcfg, 15)) return FPX_EINVAL;
@@ -239,7 +257,7 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_leaderPhase1bScan(JNIEnv* en
                                                                       jlongArray quorumMasks, jint cap,
                                                                       jintArray maxSlot, jintArray safeRound,
                                                                       jintArray safeValue) {
-  if (cap < 0 || numGroups < 1 || !has(env, quorumMasks, 4 * (jlong)numGroups) || !opt(env, maxSlot, 1) ||
+  if (cap < 0 || numGroups < 1 || !ctx_all_groups_is(h, numGroups) || !has(env, quorumMasks, 4 * (jlong)numGroups) || !opt(env, maxSlot, 1) ||
       !opt(env, safeRound, cap) || !opt(env, safeValue, cap))
     return FPX_EINVAL;
   jlong* q = in_longs(env, quorumMasks, 4 * (jlong)numGroups);
@@ -282,7 +300,7 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_noopRangesFused(
     JNIEnv* env, jclass cls, jlong h, jint n, jint numGroups, jintArray slotStart, jintArray slotEnd, jintArray round,
     jlongArray targetMasks, jlongArray voteBits, jlongArray nackBits, jintArray nackRound, jbyteArray isNew,
     jbyteArray chosen) {
-  if (n < 0 || numGroups < 1) return FPX_EINVAL;
+  if (n < 0 || numGroups < 1 || !ctx_groups_is(h, numGroups)) return FPX_EINVAL;
   if (n == 0) return FPX_OK;
   const jlong w = 4 * (jlong)n * numGroups;
   if (!has(env, slotStart, n) || !has(env, slotEnd, n) || !has(env, round, n) || !opt(env, targetMasks, w) ||
@@ -306,7 +324,7 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_noopRangesFused(
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_acceptorPhase2aNoopRange(
     JNIEnv* env, jclass cls, jlong h, jint slotStart, jint slotEnd, jint round, jint numGroups, jlongArray targetMasks,
     jlongArray bits, jintArray nackRound) {
-  if (numGroups < 1) return FPX_EINVAL;
+  if (numGroups < 1 || !ctx_groups_is(h, numGroups)) return FPX_EINVAL;
   const jlong w = 4 * (jlong)numGroups;
   if (!opt(env, targetMasks, w) || !opt(env, bits, 2 * w) || !opt(env, nackRound, 1)) return FPX_EINVAL;
   jlong* t = in_longs(env, targetMasks, w);
@@ -333,7 +351,9 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_proxyPhase2bNoopRange(JNIEnv
                                                                           jint slotStart, jint slotEnd, jint round,
                                                                           jint numGroups, jlongArray voteBits,
                                                                           jbyteArray newlyChosen) {
-  if (numGroups < 1 || !has(env, voteBits, 4 * (jlong)numGroups) || !opt(env, newlyChosen, 1)) return FPX_EINVAL;
+  if (numGroups < 1 || !ctx_groups_is(h, numGroups) || !has(env, voteBits, 4 * (jlong)numGroups) ||
+      !opt(env, newlyChosen, 1))
+    return FPX_EINVAL;
   jlong* vb = in_longs(env, voteBits, 4 * (jlong)numGroups);
   jbyte c = 0;
   int32_t st = fpx_proxy_phase2b_noop_range(CTX(h), slotStart, slotEnd, round, (const uint64_t*)vb, (uint8_t*)&c);
@@ -355,12 +375,12 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxDestroy(JNIEnv* env, jcla
   return fpx_epx_destroy((fpx_epx*)(intptr_t)h);
 }
 
-/* numReplicas = n of the context (the shim cannot ask the handle): sizes rank (n x m) and the deps (m x n) */
+/* numReplicas = n of the context (checked against the handle): sizes rank (n x m) and the deps (m x n) */
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxPreaccept(
     JNIEnv* env, jclass cls, jlong h, jint m, jint numReplicas, jintArray leader, jintArray number, jintArray key,
     jbyteArray isSet, jbyteArray respMask, jbyteArray seenMask, jintArray rank, jbyteArray fast, jintArray deps,
     jintArray leaderDeps, jintArray ownValuesEnd) {
-  if (m < 0 || numReplicas < 3) return FPX_EINVAL;
+  if (m < 0 || numReplicas < 3 || !epx_n_is(h, numReplicas)) return FPX_EINVAL;
   if (m == 0) return FPX_OK;
   const jlong mn = (jlong)m * numReplicas;
   if (!has(env, leader, m) || !has(env, number, m) || !has(env, key, m) || !has(env, isSet, m) ||
@@ -396,7 +416,7 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxPrepare(JNIEnv* env, jcla
                                                                jintArray ballotOrdering, jintArray ballotReplica,
                                                                jbyteArray targetMask, jbyteArray replies,
                                                                jintArray nackBallot, jintArray prepareOk) {
-  if (m < 0 || numReplicas < 3) return FPX_EINVAL;
+  if (m < 0 || numReplicas < 3 || !epx_n_is(h, numReplicas)) return FPX_EINVAL;
   if (m == 0) return FPX_OK;
   const jlong mn = (jlong)m * numReplicas;
   if (!has(env, leader, m) || !has(env, number, m) || !has(env, ballotOrdering, m) || !has(env, ballotReplica, m) ||
@@ -415,27 +435,30 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxPrepare(JNIEnv* env, jcla
   return st;
 }
 
-/* replies = okBits | nackBits | commitBits | committed (4 x m bytes) */
+/* key / isSet: the triples' commands, key -1 = Noop (updateConflictIndex wherever the triple is stored,
+ * Replica.scala:763, 1503, 828); replies = okBits | nackBits | commitBits | committed (4 x m bytes) */
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxAccept(JNIEnv* env, jclass cls, jlong h, jint m, jintArray leader,
                                                               jintArray number, jintArray ballotOrdering,
                                                               jintArray ballotReplica, jintArray tripleId,
+                                                              jintArray key, jbyteArray isSet,
                                                               jbyteArray targetMask, jbyteArray replies,
                                                               jintArray nackBallot) {
   if (m < 0) return FPX_EINVAL;
   if (m == 0) return FPX_OK;
   if (!has(env, leader, m) || !has(env, number, m) || !has(env, ballotOrdering, m) || !has(env, ballotReplica, m) ||
-      !has(env, tripleId, m) || !has(env, targetMask, m) || !opt(env, replies, 4 * (jlong)m) || !opt(env, nackBallot, m))
+      !has(env, tripleId, m) || !has(env, key, m) || !has(env, isSet, m) || !has(env, targetMask, m) ||
+      !opt(env, replies, 4 * (jlong)m) || !opt(env, nackBallot, m))
     return FPX_EINVAL;
   jint *l = in_ints(env, leader, m), *nu = in_ints(env, number, m), *bo = in_ints(env, ballotOrdering, m),
-       *br = in_ints(env, ballotReplica, m), *tr = in_ints(env, tripleId, m);
-  jbyte* tg = in_bytes(env, targetMask, m);
+       *br = in_ints(env, ballotReplica, m), *tr = in_ints(env, tripleId, m), *k = in_ints(env, key, m);
+  jbyte *tg = in_bytes(env, targetMask, m), *is = in_bytes(env, isSet, m);
   jbyte* rp = out_buf(replies, 4 * (jlong)m, 1);
   jint* nb = out_buf(nackBallot, m, 4);
   uint8_t* r8 = (uint8_t*)rp;
-  int32_t st = fpx_epx_accept((fpx_epx*)(intptr_t)h, m, l, nu, bo, br, tr, (const uint8_t*)tg, r8, r8 ? r8 + m : NULL,
-                              r8 ? r8 + 2 * (size_t)m : NULL, nb, r8 ? r8 + 3 * (size_t)m : NULL);
+  int32_t st = fpx_epx_accept((fpx_epx*)(intptr_t)h, m, l, nu, bo, br, tr, k, (const uint8_t*)is, (const uint8_t*)tg, r8,
+                              r8 ? r8 + m : NULL, r8 ? r8 + 2 * (size_t)m : NULL, nb, r8 ? r8 + 3 * (size_t)m : NULL);
   put_bytes(env, replies, 4 * (jlong)m, rp); put_ints(env, nackBallot, m, nb);
-  free(l); free(nu); free(bo); free(br); free(tr); free(tg); free(rp); free(nb);
+  free(l); free(nu); free(bo); free(br); free(tr); free(k); free(is); free(tg); free(rp); free(nb);
   return st;
 }
 
@@ -446,7 +469,7 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxHandlePreaccept(
     jintArray ballotOrdering, jintArray ballotReplica, jintArray key, jbyteArray isSet, jintArray tripleId,
     jintArray depsIn, jintArray depsInValuesEnd, jbyteArray targetMask, jbyteArray replies, jintArray nackBallot,
     jintArray replyDeps, jintArray replyEndTriple) {
-  if (m < 0 || numReplicas < 3) return FPX_EINVAL;
+  if (m < 0 || numReplicas < 3 || !epx_n_is(h, numReplicas)) return FPX_EINVAL;
   if (m == 0) return FPX_OK;
   const jlong mn = (jlong)m * numReplicas;
   if (!has(env, leader, m) || !has(env, number, m) || !has(env, ballotOrdering, m) || !has(env, ballotReplica, m) ||
@@ -476,7 +499,8 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxHandlePreaccept(
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxReadCmdlog(JNIEnv* env, jclass cls, jlong h, jint numReplicas,
                                                                   jint replica, jint leader, jint number,
                                                                   jintArray entry) {
-  if (numReplicas < 3 || numReplicas > 7 || !has(env, entry, 6 + (jlong)numReplicas)) return FPX_EINVAL;
+  if (numReplicas < 3 || numReplicas > 7 || !epx_n_is(h, numReplicas) || !has(env, entry, 6 + (jlong)numReplicas))
+    return FPX_EINVAL;
   jint out[5 + 7 + 1];
   int32_t st = fpx_epx_read_cmdlog((fpx_epx*)(intptr_t)h, replica, leader, number, out);
   if (st == FPX_OK) st = fpx_epx_read_cmdlog_deps((fpx_epx*)(intptr_t)h, replica, leader, number, out + 5, out + 5 + numReplicas);
@@ -517,15 +541,18 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_wireDecodeProxyLeaderInbound
   if (n == 0) return FPX_OK;
   jlong* off = in_longs(env, offsets, (jlong)n + 1);
   int bad = 0;
-  const uint8_t* b = direct(env, buf, off ? off[n] : 0, &bad);
-  if (bad || !b || !off) {
+  const uint8_t* b = direct(env, buf, 0, &bad);
+  /* the decoder checks every offset against the buffer's CAPACITY before it parses a byte (offsets such as
+   * [0, 10^9, 5] pass an off[n]-only check) */
+  const jlong capacity = b ? (*env)->GetDirectBufferCapacity(env, buf) : -1;
+  if (bad || !b || !off || capacity < 0) {
     free(off);
     return FPX_EINVAL;
   }
   jint* f = out_buf(fields, 7 * (jlong)n, 4);
   jlong* vo = (jlong*)calloc((size_t)n, 8);
   jint bi = -1;
-  int32_t st = fpx_wire_decode_proxy_leader_inbound(b, (const int64_t*)off, n, f, f + n, f + 2 * (size_t)n,
+  int32_t st = fpx_wire_decode_proxy_leader_inbound(b, (int64_t)capacity, (const int64_t*)off, n, f, f + n, f + 2 * (size_t)n,
                                                     f + 3 * (size_t)n, (int64_t*)vo, f + 4 * (size_t)n,
                                                     f + 5 * (size_t)n, f + 6 * (size_t)n, &bi);
   put_ints(env, fields, 7 * (jlong)n, f); put_longs(env, valueOff, n, vo); put_ints(env, badIndex, 1, &bi);

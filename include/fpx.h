@@ -163,6 +163,9 @@ int32_t fpx_error_detail(fpx_ctx* ctx, int32_t* index, int32_t* slot, int32_t* r
 int32_t fpx_last_hip_error(fpx_ctx* ctx);
 /* HBM bytes held by the context */
 int64_t fpx_device_bytes(fpx_ctx* ctx);
+/* the configuration the context was created with (replicas_total filled in): a binding sizes its buffers from the
+ * handle, not from what its caller says the handle is */
+int32_t fpx_get_config(fpx_ctx* ctx, fpx_config* out);
 /* Page-locked host memory for the host-pointer entry points: batches that live in it cross PCIe by DMA at
  * link rate instead of through the runtime's pageable staging copies.  A JVM caller wraps the region in
  * a direct ByteBuffer (JNI NewDirectByteBuffer), the counterpart of the Netty direct buffers the
@@ -376,6 +379,8 @@ typedef struct {
 } fpx_epx_config;
 int32_t fpx_epx_create(const fpx_epx_config* cfg, fpx_epx** out);
 int32_t fpx_epx_destroy(fpx_epx* epx);
+/* n, num_keys, num_instances of the context (any pointer may be NULL) */
+int32_t fpx_epx_info(fpx_epx* epx, int32_t* num_replicas, int32_t* num_keys, int32_t* num_instances);
 int32_t fpx_epx_set_stream(fpx_epx* epx, void* hip_stream);
 int32_t fpx_epx_preaccept(fpx_epx* epx, int32_t m, const int32_t* leader, const int32_t* number,
                           const int32_t* key, const uint8_t* is_set, const uint8_t* resp_mask,
@@ -417,15 +422,19 @@ int32_t fpx_epx_sync(fpx_epx* epx);
  *   not contain it), handleAccept at the targets (:1421-1511), handleAcceptOk (:1513-1565): with f + 1 responses,
  *   the proposer's own included, the instance is committed -- CommittedEntry at every replica (commit :815-860 and
  *   Commit to the others).  A proposer that holds a CommittedEntry, or an entry with a larger ballot, would have
- *   died in logger.fatal / logger.check: FPX_EFATAL_PROTOCOL, that message is skipped. */
+ *   died in logger.fatal / logger.check: FPX_EFATAL_PROTOCOL, that message is skipped.
+ *   key[i] / is_set[i] = the triple's command (key -1 = Noop): wherever the reference stores the triple it also calls
+ *   updateConflictIndex(instance, commandOrNoop) (:602-614) -- at the proposer (:763), at every replica that takes
+ *   the Accept in (:1503) and, on commit, at every replica (:828) -- so a replica that first hears of an instance
+ *   through an Accept or a Commit reports it as a conflict from then on. */
 int32_t fpx_epx_prepare(fpx_epx* epx, int32_t m, const int32_t* leader, const int32_t* number,
                         const int32_t* ballot_ordering, const int32_t* ballot_replica, const uint8_t* target_mask,
                         uint8_t* ok_bits, uint8_t* nack_bits, uint8_t* commit_bits, int32_t* nack_ballot,
                         int32_t* reply_status, int32_t* reply_vote_ballot, int32_t* reply_triple);
 int32_t fpx_epx_accept(fpx_epx* epx, int32_t m, const int32_t* leader, const int32_t* number,
                        const int32_t* ballot_ordering, const int32_t* ballot_replica, const int32_t* triple_id,
-                       const uint8_t* target_mask, uint8_t* ok_bits, uint8_t* nack_bits, uint8_t* commit_bits,
-                       int32_t* nack_ballot, uint8_t* committed);
+                       const int32_t* key, const uint8_t* is_set, const uint8_t* target_mask, uint8_t* ok_bits,
+                       uint8_t* nack_bits, uint8_t* commit_bits, int32_t* nack_ballot, uint8_t* committed);
 /* K7: Replica.handlePreAccept in full (epaxos/Replica.scala:1159-1289) -- what fpx_epx_preaccept's tick-at-once form
  * leaves out: PreAccepts for instances a replica already knows (a leader's re-sent PreAccept, a recovering replica
  * pre-accepting again in a higher ballot).  Message i = PreAccept(instance (leader, number), ballot

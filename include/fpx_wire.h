@@ -43,25 +43,40 @@ enum {
   FPX_WIRE_PHASE2B = 2,
   FPX_WIRE_PHASE1A = 3,
   FPX_WIRE_CHOSEN = 4,
-  FPX_WIRE_NACK = 5
+  FPX_WIRE_NACK = 5,
+  /* mencius/Mencius.proto */
+  FPX_WIRE_PHASE2A_NOOP_RANGE = 6,
+  FPX_WIRE_PHASE2B_NOOP_RANGE = 7,
+  FPX_WIRE_CHOSEN_NOOP_RANGE = 8,
+  /* epaxos/EPaxos.proto: the members of ReplicaInbound, by their field number + 14 */
+  FPX_WIRE_EPX_PRE_ACCEPT = 16,
+  FPX_WIRE_EPX_PRE_ACCEPT_OK = 17,
+  FPX_WIRE_EPX_ACCEPT = 18,
+  FPX_WIRE_EPX_ACCEPT_OK = 19,
+  FPX_WIRE_EPX_COMMIT = 20,
+  FPX_WIRE_EPX_PREPARE = 21,
+  FPX_WIRE_EPX_PREPARE_OK = 22,
+  FPX_WIRE_EPX_NACK = 23
 };
 
-/* Decodes n ProxyLeaderInbound messages: message i is buf[offsets[i] .. offsets[i + 1]).  Per message:
+/* Decodes n ProxyLeaderInbound messages: message i is buf[offsets[i] .. offsets[i + 1]); buf_len = the bytes buf
+ * holds: the n + 1 offsets must be non-negative, non-decreasing and at most buf_len, which is checked for ALL of them
+ * before anything is parsed (FPX_EINVAL, *bad_index = the first offender).  Per message:
  * kind[i] (PHASE2A / PHASE2B / OTHER); Phase2a: slot, round, is_noop, and the location of the serialised
  * CommandBatchOrNoop inside buf (value_off, value_len); Phase2b: group_index, acceptor_index, slot, round.
  * Fields that do not apply are set to -1.  Returns FPX_OK, or FPX_EINVAL at the first malformed message (truncated
  * varint, length past the end, missing required field); *bad_index (may be NULL) tells which. */
-int32_t fpx_wire_decode_proxy_leader_inbound(const uint8_t* buf, const int64_t* offsets, int32_t n, int32_t* kind,
+int32_t fpx_wire_decode_proxy_leader_inbound(const uint8_t* buf, int64_t buf_len, const int64_t* offsets, int32_t n, int32_t* kind,
                                              int32_t* slot, int32_t* round, int32_t* is_noop, int64_t* value_off,
                                              int32_t* value_len, int32_t* group_index, int32_t* acceptor_index,
                                              int32_t* bad_index);
 /* Decodes n AcceptorInbound messages: kind PHASE1A (round, chosen_watermark) / PHASE2A (slot, round, value) /
  * OTHER (MaxSlotRequest ...). */
-int32_t fpx_wire_decode_acceptor_inbound(const uint8_t* buf, const int64_t* offsets, int32_t n, int32_t* kind,
+int32_t fpx_wire_decode_acceptor_inbound(const uint8_t* buf, int64_t buf_len, const int64_t* offsets, int32_t n, int32_t* kind,
                                          int32_t* slot, int32_t* round, int32_t* is_noop, int64_t* value_off,
                                          int32_t* value_len, int32_t* chosen_watermark, int32_t* bad_index);
 /* Decodes n ReplicaInbound messages: kind CHOSEN (slot, value) / OTHER. */
-int32_t fpx_wire_decode_replica_inbound(const uint8_t* buf, const int64_t* offsets, int32_t n, int32_t* kind,
+int32_t fpx_wire_decode_replica_inbound(const uint8_t* buf, int64_t buf_len, const int64_t* offsets, int32_t n, int32_t* kind,
                                         int32_t* slot, int32_t* is_noop, int64_t* value_off, int32_t* value_len,
                                         int32_t* bad_index);
 
@@ -99,6 +114,124 @@ int64_t fpx_wire_encode_leader_nack(uint8_t* out, int64_t cap, int32_t round);
 int64_t fpx_wire_encode_phase2b_batch(int32_t n, const int32_t* slot, const int32_t* round,
                                       const uint64_t* vote_bits, const int32_t* group_of_slot, int32_t grid_cols,
                                       uint8_t* out, int64_t cap, int64_t* out_offsets, int64_t max_msgs);
+
+/* ---- Mencius (shared/src/main/scala/frankenpaxos/mencius/Mencius.proto) ---------------------------------------
+ *
+ *   ProxyLeaderInbound { oneof request { HighWatermark high_watermark = 1; Phase2a phase2a = 2;
+ *                        Phase2aNoopRange phase2a_noop_range = 3; Phase2b phase2b = 4;
+ *                        Phase2bNoopRange phase2b_noop_range = 5; } }                         Mencius.proto:339-350
+ *   AcceptorInbound    { oneof request { Phase1a phase1a = 1; Phase2a phase2a = 2;
+ *                        Phase2aNoopRange phase2a_noop_range = 3; } }                         Mencius.proto:352-361
+ *   ReplicaInbound     { oneof request { Chosen chosen = 1; ChosenNoopRange chosen_noop_range = 2; } }   :363-371
+ *   LeaderInbound      { oneof request { ...; Nack nack = 7; ... } }                          Mencius.proto:322-337
+ *   Phase2a          { slot = 1; round = 2; command_batch_or_noop = 3; }                      Mencius.proto:151-158
+ *   Phase2aNoopRange { slot_start_inclusive = 1; slot_end_exclusive = 2; round = 3; }         Mencius.proto:160-168
+ *   Phase2b          { acceptor_index = 1; slot = 2; round = 3; }   (no group: it follows from the slot)  :169-176
+ *   Phase2bNoopRange { acceptor_group_index = 1; acceptor_index = 2; slot_start_inclusive = 3;
+ *                      slot_end_exclusive = 4; round = 5; }                                   Mencius.proto:178-187
+ *   Chosen           { slot = 1; command_batch_or_noop = 2; }                                 Mencius.proto:189-195
+ *   ChosenNoopRange  { slot_start_inclusive = 1; slot_end_exclusive = 2; }                    Mencius.proto:197-203
+ *   Phase1a { round = 1; chosen_watermark = 2; }   Nack { round = 1; }                        :104-117, 266-271
+ *
+ * Decoders: as above (buf, buf_len, offsets, n); slot = the slot, or slot_start_inclusive of a range; slot_end =
+ * slot_end_exclusive of a range (-1 otherwise); fields that do not apply are -1; any output array but kind, slot and
+ * round may be NULL. */
+int32_t fpx_wire_mencius_decode_proxy_leader_inbound(const uint8_t* buf, int64_t buf_len, const int64_t* offsets,
+                                                     int32_t n, int32_t* kind, int32_t* slot, int32_t* slot_end,
+                                                     int32_t* round, int32_t* is_noop, int64_t* value_off,
+                                                     int32_t* value_len, int32_t* group_index, int32_t* acceptor_index,
+                                                     int32_t* bad_index);
+int32_t fpx_wire_mencius_decode_acceptor_inbound(const uint8_t* buf, int64_t buf_len, const int64_t* offsets, int32_t n,
+                                                 int32_t* kind, int32_t* slot, int32_t* slot_end, int32_t* round,
+                                                 int32_t* is_noop, int64_t* value_off, int32_t* value_len,
+                                                 int32_t* chosen_watermark, int32_t* bad_index);
+/* kind CHOSEN / CHOSEN_NOOP_RANGE / OTHER; round is not part of these messages (the array is not taken) */
+int32_t fpx_wire_mencius_decode_replica_inbound(const uint8_t* buf, int64_t buf_len, const int64_t* offsets, int32_t n,
+                                                int32_t* kind, int32_t* slot, int32_t* slot_end, int32_t* is_noop,
+                                                int64_t* value_off, int32_t* value_len, int32_t* bad_index);
+/* Encoders: one wrapped message each, return convention as above. */
+int64_t fpx_wire_mencius_encode_proxy_leader_phase2a(uint8_t* out, int64_t cap, int32_t slot, int32_t round,
+                                                     const uint8_t* value, int32_t value_len, int32_t is_noop);
+int64_t fpx_wire_mencius_encode_acceptor_phase2a(uint8_t* out, int64_t cap, int32_t slot, int32_t round,
+                                                 const uint8_t* value, int32_t value_len, int32_t is_noop);
+int64_t fpx_wire_mencius_encode_proxy_leader_phase2a_noop_range(uint8_t* out, int64_t cap, int32_t slot_start,
+                                                                int32_t slot_end, int32_t round);
+int64_t fpx_wire_mencius_encode_acceptor_phase2a_noop_range(uint8_t* out, int64_t cap, int32_t slot_start,
+                                                            int32_t slot_end, int32_t round);
+int64_t fpx_wire_mencius_encode_acceptor_phase1a(uint8_t* out, int64_t cap, int32_t round, int32_t chosen_watermark);
+int64_t fpx_wire_mencius_encode_proxy_leader_phase2b(uint8_t* out, int64_t cap, int32_t acceptor_index, int32_t slot,
+                                                     int32_t round);
+int64_t fpx_wire_mencius_encode_proxy_leader_phase2b_noop_range(uint8_t* out, int64_t cap, int32_t acceptor_group_index,
+                                                                int32_t acceptor_index, int32_t slot_start,
+                                                                int32_t slot_end, int32_t round);
+int64_t fpx_wire_mencius_encode_replica_chosen(uint8_t* out, int64_t cap, int32_t slot, const uint8_t* value,
+                                               int32_t value_len, int32_t is_noop);
+int64_t fpx_wire_mencius_encode_replica_chosen_noop_range(uint8_t* out, int64_t cap, int32_t slot_start,
+                                                          int32_t slot_end);
+int64_t fpx_wire_mencius_encode_leader_nack(uint8_t* out, int64_t cap, int32_t round);
+
+/* ---- EPaxos (shared/src/main/scala/frankenpaxos/epaxos/EPaxos.proto) -------------------------------------------
+ *
+ *   ReplicaInbound { oneof request { ClientRequest client_request = 1; PreAccept pre_accept = 2;
+ *                    PreAcceptOk pre_accept_ok = 3; Accept accept = 4; AcceptOk accept_ok = 5; Commit commit = 6;
+ *                    Prepare prepare = 7; PrepareOk prepare_ok = 8; Nack nack = 9; } }          EPaxos.proto:220-235
+ *   Instance { replica_index = 1; instance_number = 2; }   Ballot { ordering = 1; replica_index = 2; }   :35-53
+ *   CommandOrNoop { oneof value { Command command = 1; Noop noop = 2; } }                       EPaxos.proto:80-89
+ *   InstancePrefixSetProto { numReplicas = 1; repeated IntPrefixSetProto int_prefix_set = 2; }  EPaxos.proto:97-104
+ *   IntPrefixSetProto { watermark = 1; repeated int32 value = 2; }               compact/IntPrefixSet.proto:12-15
+ *   PreAccept   { instance = 1; ballot = 2; command_or_noop = 3; sequence_number = 4; dependencies = 5; }   :113-123
+ *   PreAcceptOk { instance = 1; ballot = 2; replica_index = 3; sequence_number = 4; dependencies = 5; }     :125-135
+ *   Accept      { instance = 1; ballot = 2; command_or_noop = 3; sequence_number = 4; dependencies = 5; }   :137-147
+ *   AcceptOk    { instance = 2; ballot = 3; replica_index = 7; }                                            :149-156
+ *   Commit      { instance = 1; command_or_noop = 2; sequence_number = 3; dependencies = 4; }               :158-166
+ *   Prepare     { instance = 1; ballot = 2; }                                                               :178-184
+ *   PrepareOk   { ballot = 1; instance = 2; replica_index = 3; vote_ballot = 4; status = 5 (NotSeen 0 /
+ *                 PreAccepted 1 / Accepted 2); optional command_or_noop = 6, sequence_number = 7,
+ *                 dependencies = 8; }                                                                       :186-209
+ *   Nack        { instance = 1; largest_ballot = 2; }                                                       :211-218
+ *
+ * One message as plain fields.  What a kind does not carry is -1 (is_noop: -1 = no CommandOrNoop present,
+ * num_replicas: -1 = no dependencies present).  Dependencies: deps_watermark[l] for l < num_replicas and the
+ * explicit ids (values_leader[j], values_id[j]), j < num_values.  ballot_* is the message's ballot (Nack:
+ * largest_ballot). */
+typedef struct {
+  int32_t kind; /* FPX_WIRE_EPX_* */
+  int32_t instance_leader, instance_number;
+  int32_t ballot_ordering, ballot_replica;
+  int32_t replica_index;                            /* PreAcceptOk, AcceptOk, PrepareOk */
+  int32_t sequence_number;                          /* -1 with has_sequence_number = 0 */
+  int32_t has_sequence_number;
+  int32_t vote_ballot_ordering, vote_ballot_replica, status; /* PrepareOk */
+  int32_t is_noop;                                  /* 1 Noop, 0 command, -1 none */
+  const uint8_t* command;                           /* the serialised CommandOrNoop (as the decoder locates it) */
+  int32_t command_len;
+  int32_t num_replicas;                             /* -1: no dependencies */
+  const int32_t* deps_watermark;
+  int32_t num_values;
+  const int32_t* values_leader;
+  const int32_t* values_id;
+} fpx_wire_epx_msg;
+
+/* Encodes ONE ReplicaInbound (return convention as above; -(1 << 62) for a message that cannot be encoded: unknown
+ * kind, a required part missing).  Explicit ids are written in the order given (ScalaPB writes `values.toSeq` of a
+ * hash set: no canonical order exists; any order decodes to the same set). */
+int64_t fpx_wire_epaxos_encode_replica_inbound(uint8_t* out, int64_t cap, const fpx_wire_epx_msg* msg);
+
+/* Decodes n ReplicaInbound messages into SoA (every array has n entries unless said otherwise; any but kind may be
+ * NULL).  deps_watermark is n x max_replicas (row i holds deps_num_replicas[i] <= max_replicas watermarks, the rest
+ * 0; more replicas than max_replicas is FPX_EINVAL at that message).  Explicit ids of all messages back to back:
+ * values of message i are values_leader / values_id [values_off[i] .. values_off[i + 1]) (values_off has n + 1
+ * entries); if they do not fit values_cap the call returns FPX_ECAPACITY with values_off[n] = the capacity needed
+ * (everything else is filled in) -- call again.  cmd_off / cmd_len locate the serialised CommandOrNoop in buf. */
+int32_t fpx_wire_epaxos_decode_replica_inbound(const uint8_t* buf, int64_t buf_len, const int64_t* offsets, int32_t n,
+                                               int32_t max_replicas, int32_t* kind, int32_t* instance_leader,
+                                               int32_t* instance_number, int32_t* ballot_ordering,
+                                               int32_t* ballot_replica, int32_t* replica_index,
+                                               int32_t* sequence_number, int32_t* vote_ballot_ordering,
+                                               int32_t* vote_ballot_replica, int32_t* status, int32_t* is_noop,
+                                               int64_t* cmd_off, int32_t* cmd_len, int32_t* deps_num_replicas,
+                                               int32_t* deps_watermark, int64_t* values_off, int64_t values_cap,
+                                               int32_t* values_leader, int32_t* values_id, int32_t* bad_index);
 
 #ifdef __cplusplus
 }

@@ -154,15 +154,18 @@ class EPaxos:
         return replies
 
     # ---- the Accept phase of one instance (:732-792, 1421-1565, 815-860) ------------------------------------
-    def accept(self, instance, ballot, triple_id, targets):
-        """returns (fatal, replies, committed)"""
+    def accept(self, instance, ballot, triple_id, targets, key=-1, is_set=False):
+        """returns (fatal, replies, committed); key / is_set: the triple's command (-1 = Noop: updateConflictIndex
+        has no bytes to put, Replica.scala:602-614)"""
         P = ballot[1]
         prop = self.replicas[P]
+        put = (lambda rep: rep.index_put(key, is_set, instance)) if key >= 0 else (lambda rep: None)
         e = prop.cmd_log.get(instance)
         if e is not None and (e.kind == COMMITTED or e.ballot > ballot or
                               (e.kind in (PRE_ACCEPTED, ACCEPTED) and e.vote_ballot > ballot)):
             return True, {}, False                                                    # logger.fatal / checkLe :740-757
         prop.cmd_log[instance] = Entry(ACCEPTED, ballot, ballot, triple_id, None)     # :759-762
+        put(prop)                                                                     # :763
         replies = {P: ("ok",)}                                                        # its own AcceptOk :780-789
         for r in targets:
             rep = self.replicas[r]
@@ -176,10 +179,12 @@ class EPaxos:
             else:
                 rep.largest_ballot = max(rep.largest_ballot, ballot)                  # :1487
                 rep.cmd_log[instance] = Entry(ACCEPTED, ballot, ballot, triple_id, None)   # :1493-1502
+                put(rep)                                                              # :1503
                 replies[r] = ("ok",)
         oks = [r for r, v in replies.items() if v[0] == "ok"]
         committed = len(oks) >= self.f + 1                                            # slowQuorumSize, :1557-1563
         if committed:
             for rep in self.replicas:                                                 # commit + Commit to the others
                 rep.cmd_log[instance] = Entry(COMMITTED, triple_id=triple_id, deps=None)
+                put(rep)                                                              # commit :828
         return False, replies, committed

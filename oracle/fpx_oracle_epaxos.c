@@ -548,12 +548,16 @@ int fpo_epx_prepare(fpo_epx* e, int32_t m, const int32_t* leader, const int32_t*
  *   commit (:815-860) with informOthers: CommittedEntry at every replica once the tick is over.
  * committed[i] = 1 if the instance got committed by this message. */
 int fpo_epx_accept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* b_ord,
-                   const int32_t* b_rep, const int32_t* triple_id, const uint8_t* target, uint8_t* ok_bits,
-                   uint8_t* nack_bits, uint8_t* commit_bits, int32_t* nack_ballot, uint8_t* committed) {
+                   const int32_t* b_rep, const int32_t* triple_id, const int32_t* key, const uint8_t* is_set,
+                   const uint8_t* target, uint8_t* ok_bits, uint8_t* nack_bits, uint8_t* commit_bits,
+                   int32_t* nack_ballot, uint8_t* committed) {
   const int n = e->n, f = (n - 1) / 2;
   if (!instances_ok(e, m, leader, number, b_ord, b_rep, target)) return 1;
-  for (int i = 0; i < m; ++i)
+  if (m > 0 && (!key || !is_set)) return 1;
+  for (int i = 0; i < m; ++i) {
     if ((target[i] >> b_rep[i]) & 1u) return 1; /* thriftyOtherReplicas: never the proposer itself (:774) */
+    if (key[i] < -1 || key[i] >= e->num_keys) return 1;
+  }
   int status = 0;
   for (int i = 0; i < m; ++i) {
     const int ballot = enc_ballot(b_ord[i], b_rep[i]), P = b_rep[i];
@@ -572,6 +576,8 @@ int fpo_epx_accept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_t* 
     }
     e->cl_status[cp] = CL_ACCEPTED, e->cl_ballot[cp] = e->cl_vote[cp] = ballot, e->cl_triple[cp] = triple_id[i];
     deps_by_id(e, cp);
+    /* updateConflictIndex(instance, triple.commandOrNoop) :763 -- a Noop has no bytes to put (:602-614) */
+    if (key[i] >= 0) conflict_index_put(e, P, key[i], is_set[i], leader[i], number[i]);
     ok |= 1u << P;
     for (int r = 0; r < n; ++r) {
       if (!((target[i] >> r) & 1u)) continue;
@@ -593,6 +599,7 @@ int fpo_epx_accept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_t* 
       if (ballot > e->largest_ballot[r]) e->largest_ballot[r] = ballot; /* :1487 */
       e->cl_status[c] = CL_ACCEPTED, e->cl_ballot[c] = e->cl_vote[c] = ballot, e->cl_triple[c] = triple_id[i]; /* :1493-1502 */
       deps_by_id(e, c);
+      if (key[i] >= 0) conflict_index_put(e, r, key[i], is_set[i], leader[i], number[i]); /* :1503 */
       ok |= 1u << r;
     }
     if (ok_bits) ok_bits[i] = (uint8_t)ok;
@@ -605,6 +612,7 @@ int fpo_epx_accept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_t* 
         const size_t c = ((size_t)r * n + leader[i]) * e->num_instances + number[i];
         e->cl_status[c] = CL_COMMITTED, e->cl_ballot[c] = e->cl_vote[c] = -1, e->cl_triple[c] = triple_id[i];
         deps_by_id(e, c);
+        if (key[i] >= 0) conflict_index_put(e, r, key[i], is_set[i], leader[i], number[i]); /* commit :828 */
       }
     }
   }

@@ -551,7 +551,7 @@ class EPaxos:
         L.fpo_epx_preaccept2.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, U8P, U8P, U8P, I32P, I32P, U8P, I32P,
                                          I32P, I32P]
         L.fpo_epx_prepare.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, I32P, U8P, U8P, U8P, U8P, I32P, I32P, I32P, I32P]
-        L.fpo_epx_accept.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, I32P, I32P, U8P, U8P, U8P, U8P, I32P, U8P]
+        L.fpo_epx_accept.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, I32P, I32P, I32P, U8P, U8P, U8P, U8P, U8P, I32P, U8P]
         L.fpo_epx_read_cmdlog.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, I32P]
         L.fpo_epx_read_cmdlog_deps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, I32P, I32P]
         L.fpo_epx_handle_preaccept.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, I32P, I32P, U8P, I32P, I32P, I32P,
@@ -585,14 +585,18 @@ class EPaxos:
                                    _p(rt, I32P))
         return st, ok, nack, com, nb, rs, rv, rt
 
-    def accept(self, leader, number, ballot_ordering, ballot_replica, triple_id, target_mask):
+    def accept(self, leader, number, ballot_ordering, ballot_replica, triple_id, target_mask, key=None, is_set=None):
+        """key / is_set: the triples' commands; key None = every triple is a Noop"""
         leader, number, bo, br, tr = _i32(leader), _i32(number), _i32(ballot_ordering), _i32(ballot_replica), _i32(triple_id)
         tgt = np.ascontiguousarray(target_mask, dtype=np.uint8)
         m = len(leader)
+        key = np.full(m, -1, np.int32) if key is None else _i32(key)
+        is_set = np.zeros(m, np.uint8) if is_set is None else np.ascontiguousarray(is_set, dtype=np.uint8)
         ok, nack, com, done = (np.zeros(m, np.uint8) for _ in range(4))
         nb = np.full(m, -1, np.int32)
         st = lib().fpo_epx_accept(self._h, m, _p(leader, I32P), _p(number, I32P), _p(bo, I32P), _p(br, I32P), _p(tr, I32P),
-                                  _p(tgt, U8P), _p(ok, U8P), _p(nack, U8P), _p(com, U8P), _p(nb, I32P), _p(done, U8P))
+                                  _p(key, I32P), _p(is_set, U8P), _p(tgt, U8P), _p(ok, U8P), _p(nack, U8P), _p(com, U8P),
+                                  _p(nb, I32P), _p(done, U8P))
         return st, ok, nack, com, nb, done
 
     def read_cmdlog(self, replica, leader, number):

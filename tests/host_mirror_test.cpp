@@ -4,7 +4,9 @@
 //   shared/src/test/scala/roundsystem/RoundSystemTest.scala:13-62
 // plus BASELINE.json configs[0]: MultiPaxos f = 1, 1000 commands through proxy leader + acceptors, a leader
 // change (Phase1a -> Phase1b safe values -> replica log), Mencius noop ranges and two EPaxos pre-accept ticks.
-// Needs a GPU (every predicate / handler runs in libfpx).  Built and run by tests/test_host_mirror.py.
+// Needs a GPU (every predicate / handler runs in libfpx) -- except the dependency-graph tests
+// (shared/src/test/scala/depgraph/{DependencyGraphTest,ZigzagTarjanDependencyGraphTest}.scala), which are host code
+// and run alone with `host_mirror_test --host-only`.  Built and run by tests/test_host_mirror.py.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -316,9 +318,20 @@ static void epaxosPreAccept() {
       SHOULD_BE(engine.conflictIndex(r, 1).second, (V{1, 0, 1}));
       SHOULD_BE(engine.conflictIndex(r, 2).first, (V{2, 0, 0}));
     }
-    d = engine.handleTick({{{1, 1}, {1, false}, {0}}});
+    // Replica.commit -> dependencyGraph.commit -> execute (Replica.scala:859-917): A <- B <- C <- A is one component
+    // (all sequence numbers 0: executed in key order), D depends on nothing
+    depgraph::DependencyGraph graph(3);
+    epaxos::commitToGraph(graph, tick, d, std::vector<bool>(tick.size(), true));
+    auto run = graph.executeByComponent();
+    using K = depgraph::Key;
+    SHOULD_BE(run.first, (std::vector<std::vector<K>>{{{0, 0}, {1, 0}, {2, 0}}, {{0, 1}}}));
+    SHOULD_BE(run.second, (std::set<K>{{0, 2}, {1, 1}, {2, 1}}));
+    std::vector<epaxos::Proposal> tick2 = {{{1, 1}, {1, false}, {0}}};
+    d = engine.handleTick(tick2);
     SHOULD_BE(d[0].fastPath, true);
     SHOULD_BE(d[0].dependencies, (V{1, 0, 1}));
+    epaxos::commitToGraph(graph, tick2, d, {true});
+    SHOULD_BE(graph.execute().first, (std::vector<K>{{1, 1}}));
   }
   {
     epaxos::PreAcceptEngine engine(2, 2);  // n = 5: answers that differ force the slow path
@@ -396,7 +409,88 @@ static void epaxosCommandLog() {
   SHOULD_THROW(engine.handlePreAccept({{{1, 7}, {0, 1}, {0}, 1, {2, false}, {0, 8, 0, 0, 0}, 0}}));
 }
 
-int main() {
+// depgraph/DependencyGraphTest.scala and ZigzagTarjanDependencyGraphTest.scala through the C++ mirror (the complete
+// transcription runs in tests/test_depgraph.py; these are the ones with the most structure)
+static void dependencyGraphTest() {
+  using namespace depgraph;
+  using C = std::vector<std::vector<Key>>;
+  auto ints = [](std::initializer_list<int> xs) {  // IntPrefixSet(Set(...)) with plain Int keys = column 0
+    KeySet s;
+    for (int x : xs) s.values.push_back({0, x});
+    return s;
+  };
+  auto comps = [](std::initializer_list<std::initializer_list<int>> cs) {
+    C out;
+    for (auto& c : cs) {
+      out.emplace_back();
+      for (int x : c) out.back().push_back({0, x});
+    }
+    return out;
+  };
+  {  // "correctly commit a complex graph in random order" :235-256
+    DependencyGraph graph(1, Kind::Tarjan);
+    graph.commit({0, 6}, 1, ints({4, 5}));
+    SHOULD_BE(graph.executeByComponent().first, C{});
+    graph.commit({0, 4}, 0, ints({2}));
+    SHOULD_BE(graph.executeByComponent().first, C{});
+    graph.commit({0, 0}, 0, ints({}));
+    SHOULD_BE(graph.executeByComponent().first, comps({{0}}));
+    graph.commit({0, 2}, 1, ints({1}));
+    SHOULD_BE(graph.executeByComponent().first, C{});
+    graph.commit({0, 5}, 0, ints({3, 4, 6}));
+    SHOULD_BE(graph.executeByComponent().first, C{});
+    graph.commit({0, 1}, 0, ints({0, 2}));
+    SHOULD_BE(graph.executeByComponent().first, comps({{1, 2}, {4}}));
+    graph.commit({0, 3}, 0, ints({1, 2}));
+    SHOULD_BE(graph.executeByComponent().first, comps({{3}, {5, 6}}));
+    SHOULD_BE(graph.numVertices(), (int64_t)0);
+  }
+  {  // "correctly commit a three cycle with sequence numbers" :159-172, "report blockers chain" :488-496
+    DependencyGraph graph(1, Kind::Tarjan);
+    graph.commit({0, 0}, 1, ints({1}));
+    graph.commit({0, 1}, 0, ints({2}));
+    auto r = graph.executeByComponent();
+    SHOULD_BE(r.first, C{});
+    SHOULD_BE(r.second, (std::set<Key>{{0, 2}}));
+    graph.commit({0, 2}, 2, ints({0}));
+    SHOULD_BE(graph.executeByComponent().first, comps({{1, 0, 2}}));
+  }
+  {  // ZigzagTarjanDependencyGraphTest "execute a forward edge with gap correctly" :120-131
+    DependencyGraph graph(3, Kind::ZigzagTarjan, 100);
+    graph.commit({0, 0}, 0, KeySet{{}, {{2, 0}}});
+    graph.commit({2, 0}, 1, KeySet{});
+    auto r = graph.executeByComponent();
+    SHOULD_BE(r.first, (C{{{2, 0}}, {{0, 0}}}));
+    SHOULD_BE(r.second, (std::set<Key>{{0, 1}, {1, 0}, {2, 1}}));
+    graph.commit({1, 0}, 0, KeySet{});
+    graph.commit({0, 1}, 1, KeySet{});
+    r = graph.executeByComponent();
+    SHOULD_BE(r.first, (C{{{0, 1}}, {{1, 0}}}));
+    SHOULD_BE(r.second, (std::set<Key>{{0, 2}, {1, 1}, {2, 1}}));
+  }
+  {  // "execute a cycle correctly" :112-118 and appendExecute (DependencyGraph.scala:160-168)
+    DependencyGraph graph(3);
+    graph.commit({0, 0}, 0, KeySet{{}, {{1, 0}}});
+    graph.commit({1, 0}, 1, KeySet{{}, {{0, 0}}});
+    std::vector<Key> executables{{9, 9}};
+    std::set<Key> blockers;
+    graph.appendExecute({}, executables, blockers);
+    SHOULD_BE(executables, (std::vector<Key>{{9, 9}, {0, 0}, {1, 0}}));
+    SHOULD_BE(blockers, (std::set<Key>{{0, 1}, {1, 1}, {2, 0}}));
+    SHOULD_THROW(graph.commit({3, 0}, 0, KeySet{}));
+  }
+}
+
+int main(int argc, char** argv) {
+  dependencyGraphTest();
+  if (argc > 1 && std::string(argv[1]) == "--host-only") {
+    if (failures) {
+      std::printf("%d failure(s)\n", failures);
+      return 1;
+    }
+    std::printf("host mirror: host-only tests passed\n");
+    return 0;
+  }
   gridTest();
   simpleMajorityTest();
   unanimousWritesTest();

@@ -36,14 +36,23 @@ def test_library_exports_every_declared_symbol(fa):
     # the wire adapter's header (include/fpx_wire.h) is part of the same library
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "fpx_wire.h")).read(), flags=re.S)
     wire = sorted(set(re.findall(r"\b(fpx_wire_[a-z0-9_]+)\s*\(", hdr)))
-    assert len(wire) >= 11
+    assert len(wire) >= 26
     for name in wire:
+        assert hasattr(lib, name), "libfpx.so does not export %s" % name
+    # ... and so is dependency-graph execution (include/fpx_depgraph.h)
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "fpx_depgraph.h")).read(), flags=re.S)
+    dg = sorted(set(re.findall(r"\b(fpx_depgraph_[a-z0-9_]+)\s*\(", hdr)))
+    from frankenpaxos_amd import depgraph
+    assert dg == sorted(depgraph.SIGNATURES) and len(dg) == 9
+    for name in dg:
         assert hasattr(lib, name), "libfpx.so does not export %s" % name
 
 
 def test_header_compiles_as_c_and_cxx(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "fpx.h"\n#include "fpx_wire.h"\nint main(void){fpx_config c; (void)c; return FPX_OK + FPX_WIRE_OTHER;}\n')
+    src.write_text('#include "fpx.h"\n#include "fpx_wire.h"\n#include "fpx_depgraph.h"\n'
+                   'int main(void){fpx_config c; fpx_wire_epx_msg m; fpx_depgraph_config d; (void)c; (void)m; (void)d; '
+                   'return FPX_OK + FPX_WIRE_OTHER + FPX_DG_TARJAN;}\n')
     inc = os.path.join(ROOT, "include")
     assert os.system("gcc -std=c99 -Wall -Werror -I%s -c %s -o %s" % (inc, src, tmp_path / "t.o")) == 0
     assert os.system("g++ -std=c++17 -Wall -Werror -I%s -x c++ -c %s -o %s" % (inc, src, tmp_path / "t2.o")) == 0

@@ -534,6 +534,77 @@ def test_oracle_accept_phase_by_hand(oracle):
     assert oracle.EPaxos(5, 2).accept([1], [3], [0], [1], [1], [0b00101])[0] == 1   # no command log configured
 
 
+def _accept_teaches_the_conflict_index(e):
+    """updateConflictIndex wherever a triple is stored (Replica.scala:602-614).  n = 5, key 1.
+      X = (0, 0) = set k1 reaches replicas 1 and 2 as a PreAccept (they index it, :1279); replicas 3 and 4 have never
+        heard of X;
+      Accept(X, Ballot(0,0), set k1) by 0 to {3}: the proposer indexes X (:763), replica 3 takes the Accept in and
+        indexes X (:1503); two AcceptOks are no quorum.  Replica 4 still knows nothing;
+      PreAccept(Y = (4, 0), set k1) at 3 and at 4: replica 3 -- which only ever saw X in an Accept -- answers with the
+        dependency X; replica 4 with none;
+      the Accept again to {1, 3}: 3 answers again, 1 accepts -> f + 1 = 3 AcceptOks -> commit at EVERY replica (:828):
+        replica 4 learns X from the Commit;
+      PreAccept(Z = (4, 1), get k1) at 4: depends on X now.  A Noop triple (key -1) teaches nothing."""
+    zeros = np.zeros((1, 5), np.int32)
+    X = [1, 0, 0, 0, 0]
+    st, ok, resend, nack, com, nb, rd, re, rt = e.handle_preaccept([0], [0], [0], [0], [1], [1], [7], zeros, None, [0b00110])
+    assert st == 0 and ok[0] == 0b00110
+    for r, want in ((0, [0] * 5), (1, X), (2, X), (3, [0] * 5), (4, [0] * 5)):
+        assert e.read_index(r, 1)[1].tolist() == want
+    st, ok, nack, com, nb, done = e.accept([0], [0], [0], [0], [7], [0b01000], key=[1], is_set=[1])
+    assert st == 0 and ok[0] == 0b01001 and done[0] == 0
+    for r, want in ((0, X), (3, X), (4, [0] * 5)):
+        assert e.read_index(r, 1)[1].tolist() == want and e.read_index(r, 1)[0].tolist() == [0] * 5
+    st, ok, resend, nack, com, nb, rd, re, rt = e.handle_preaccept([4], [0], [0], [4], [1], [1], [8], zeros, None, [0b11000])
+    assert st == 0 and ok[0] == 0b11000
+    assert rd[0][3].tolist() == X and rd[0][4].tolist() == [0] * 5
+    st, ok, nack, com, nb, done = e.accept([0], [0], [0], [0], [7], [0b01010], key=[1], is_set=[1])
+    assert st == 0 and ok[0] == 0b01011 and done[0] == 1
+    for r in range(5):
+        assert e.read_index(r, 1)[1].tolist() == [1, 0, 0, 0, 1 if r >= 3 else 0]   # X everywhere; Y where it was pre-accepted
+    st, ok, resend, nack, com, nb, rd, re, rt = e.handle_preaccept([4], [1], [0], [4], [1], [0], [9], zeros, None, [0b10000])
+    assert st == 0 and ok[0] == 0b10000 and rd[0][4].tolist() == [1, 0, 0, 0, 1]
+    # a Noop triple: the entry is stored, the index is left alone
+    before = [e.read_index(r, k) for r in range(5) for k in range(4)]
+    st, ok, nack, com, nb, done = e.accept([2], [3], [0], [2], [10], [0b01010], key=[-1], is_set=[0])
+    assert st == 0 and done[0] == 1 and e.read_cmdlog(4, 2, 3)[0] == 4
+    after = [e.read_index(r, k) for r in range(5) for k in range(4)]
+    assert all(a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist() for a, b in zip(before, after))
+    # a key outside the store is a require failure, nothing applied
+    assert e.accept([2], [4], [0], [2], [11], [0b01010], key=[4], is_set=[0])[0] == 1
+    assert e.read_cmdlog(2, 2, 4)[0] == 0
+
+
+def test_oracle_accept_teaches_the_conflict_index_by_hand(oracle):
+    _accept_teaches_the_conflict_index(oracle.EPaxos(5, 4, num_instances=16))
+
+
+@pytest.mark.gpu
+def test_epaxos_accept_teaches_the_conflict_index(oracle):
+    """the same by-hand trace on the GPU, and random Accept batches with commands: every replica's whole index"""
+    from frankenpaxos_amd.epaxos import EPaxos
+
+    _accept_teaches_the_conflict_index(EPaxos(5, 4, num_instances=16))
+    n, NI, K = 5, 256, 6
+    gpu, ref = EPaxos(n, K, num_instances=NI), oracle.EPaxos(n, K, num_instances=NI)
+    rng = np.random.default_rng(77)
+    nxt = [0] * n
+    for step in range(8):
+        leader, number, b_ord, b_rep, tgt = _cl_batch(rng, n, NI, 300, nxt)
+        tgt = (tgt & ~(1 << b_rep)).astype(np.uint8)
+        tr = rng.integers(0, 1 << 20, len(leader)).astype(np.int32)
+        key = rng.integers(-1, K, len(leader)).astype(np.int32)
+        is_set = rng.integers(0, 2, len(leader)).astype(np.uint8)
+        _same(gpu.accept(leader, number, b_ord, b_rep, tr, tgt, key, is_set),
+              ref.accept(leader, number, b_ord, b_rep, tr, tgt, key, is_set))
+        for r in range(n):
+            for k in range(K):
+                ga, sa = gpu.read_index(r, k)
+                gb, sb = ref.read_index(r, k)
+                assert ga.tolist() == gb.tolist() and sa.tolist() == sb.tolist()
+    assert any(ref.read_index(r, k)[1].max() > 0 for r in range(n) for k in range(K))
+
+
 def _cl_batch(rng, n, NI, m, nxt):
     """m distinct instances, random ballots and target sets.  Instances come from the upper half of every leader's
     numbers and from those the pre-accept ticks have already used (nxt): the numbers the NEXT pre-accept tick will
@@ -862,3 +933,135 @@ def test_epaxos_ticks_without_the_per_key_workgroups(oracle, monkeypatch):
             assert gpu.read_cmdlog(r, L, x) == ref.read_cmdlog(r, L, x)
             a, b = gpu.read_cmdlog_deps(r, L, x), ref.read_cmdlog_deps(r, L, x)
             assert a[0].tolist() == b[0].tolist() and a[1] == b[1]
+
+
+# ------------------------------------------------ commit -> dependency graph -> execution ----
+def _slow_path_accepts(e, leader, number, key, is_set, mask, fast, triple, f):
+    """the slow-path instances of a tick go through the Accept phase (preAcceptingSlowPath ->
+    transitionToAcceptPhase, Replica.scala:796-813, 732-792): Ballot(0, leader), sent to the first f replicas of the
+    fast quorum (thriftyOtherReplicas(slowQuorumSize - 1), :774); with the proposer's own AcceptOk that is f + 1"""
+    slow = np.nonzero(fast == 0)[0]
+    tgt = np.zeros(len(slow), np.uint8)
+    for j, i in enumerate(slow):
+        picked = [r for r in range(8) if (mask[i] >> r) & 1][:f]
+        tgt[j] = sum(1 << r for r in picked)
+    out = e.accept(leader[slow], number[slow], np.zeros(len(slow), np.int32), leader[slow], triple[slow], tgt,
+                   key[slow], is_set[slow])
+    return slow, out
+
+
+def check_execution_order(n, leader, number, deps, own_end, el, ei, cs):
+    """size-independent properties of an execution order when EVERYTHING was committed: every instance exactly once;
+    a dependency's component never comes after the instance's (reverse topological order of the condensation)"""
+    m = len(leader)
+    assert len(el) == m and int(cs.sum()) == m
+    comp_of_pos = np.repeat(np.arange(len(cs)), cs)
+    per = [int(number[leader == L].max()) + 1 if (leader == L).any() else 0 for L in range(n)]
+    comp = [np.full(per[L], -1, np.int64) for L in range(n)]
+    for L in range(n):
+        sel = el == L
+        comp[L][ei[sel]] = comp_of_pos[sel]
+        assert (comp[L] >= 0).all()                       # every instance of the column executed (ids are dense)
+    seen = sum(len(np.unique(ei[el == L])) for L in range(n))
+    assert seen == m                                      # ... and none twice
+    prefmax = [np.concatenate([[-1], np.maximum.accumulate(comp[L])]) for L in range(n)]
+    mine = np.empty(m, np.int64)
+    for L in range(n):
+        sel = leader == L
+        mine[sel] = comp[L][number[sel]]
+    for L in range(n):
+        w = np.minimum(deps[:, L], per[L])
+        assert (prefmax[L][w] <= mine).all()
+    for i in np.nonzero(own_end)[0]:                      # the explicit ids of the own column
+        L = leader[i]
+        assert comp[L][number[i] + 1: own_end[i]].max(initial=-1) <= mine[i]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,num_keys,m,fifo,kind", [(3, 8, 3000, True, "zigzag"), (5, 16, 8000, True, "zigzag"),
+                                                    (5, 64, 12000, False, "zigzag"), (7, 4, 3000, False, "zigzag"),
+                                                    (5, 16, 4000, False, "tarjan")])
+def test_epaxos_commits_execute_in_the_oracles_order(oracle, n, num_keys, m, fifo, kind):
+    """two ticks end to end: GPU pre-accept -> Accept phase for the slow path (GPU) -> every committed triple into the
+    product's dependency graph -> execution order; beside it the oracle chain (C oracle EPaxos -> oracle/depgraph.py).
+    Executables, component boundaries and blockers are compared after every tick, bit for bit."""
+    from frankenpaxos_amd import depgraph as P
+    from frankenpaxos_amd.epaxos import EPaxos
+    from oracle import depgraph as O
+
+    NI = 2 * m
+    gpu, ref = EPaxos(n, num_keys, num_instances=NI), oracle.EPaxos(n, num_keys, num_instances=NI)
+    f = (n - 1) // 2
+    if kind == "zigzag":
+        pg, og = P.DependencyGraph(n, kind=P.FPX_DG_ZIGZAG), O.ZigzagTarjanDependencyGraph(O.InstancePrefixSet(n), n)
+    else:
+        pg, og = P.DependencyGraph(n, kind=P.FPX_DG_TARJAN), O.TarjanDependencyGraph(O.InstancePrefixSet(n))
+    rng = np.random.default_rng(n * 100 + num_keys)
+    nxt = [0] * n
+    executed = cycles = holes = 0
+    for tick in range(2):
+        leader, number, key, is_set, mask, rank = random_tick(rng, n, num_keys, m, nxt, 6.0, fifo=fifo)
+        triple = np.arange(tick * m, (tick + 1) * m, dtype=np.int32)
+        a = gpu.preaccept(leader, number, key, is_set, mask, rank, triple_id=triple)
+        b = ref.preaccept(leader, number, key, is_set, mask, rank, triple_id=triple)
+        _same(a, b)
+        st, fast, deps, ldeps, own = a
+        slow, acc_g = _slow_path_accepts(gpu, leader, number, key, is_set, mask, fast, triple, f)
+        _, acc_r = _slow_path_accepts(ref, leader, number, key, is_set, mask, b[1], triple, f)
+        _same(acc_g, acc_r)
+        committed = fast.copy()
+        committed[slow] = acc_g[5]
+        assert committed.all() and (n == 3 or len(slow) > 0)
+        holes += int((own[:, 0] != 0).sum())
+        # product: the GPU's outputs as they are; oracle: the oracle's outputs through the reference-shaped sets
+        pg.commit_epx(leader, number, deps, own, mask=committed)
+        for i in range(m):
+            og.commit((int(leader[i]), int(number[i])), 0,
+                      O.InstancePrefixSet.from_epx(int(leader[i]), int(number[i]), b[2][i], int(b[4][i, 0])))
+        want = O.with_deep_stack(og.execute_by_component)
+        got = pg.execute_by_component()
+        assert got[0] == [list(c) for c in want[0]] and got[1] == want[1]
+        executed += sum(len(c) for c in got[0])
+        cycles += sum(1 for c in got[0] if len(c) > 1)
+    assert executed == 2 * m and cycles > 0 and (holes > 0) == (not fifo)
+
+
+@pytest.mark.gpu
+def test_config4_commits_execute_at_full_size(oracle):
+    """BASELINE.json configs[3] carried through: a 2^20-command tick (n = 5, 1024 keys) pre-accepts on the GPU, the
+    slow path goes through the Accept phase at size (K6 at 10^5-10^6 messages, GPU == oracle on every reply), every
+    committed triple enters the dependency graph and the whole tick executes: each instance exactly once, no
+    dependency after its dependent (check_execution_order).  The zigzag variant only: TarjanDependencyGraph walks every
+    vertex's whole dependency prefix (its executed set moves after the pass, TarjanDependencyGraph.scala:266-273) --
+    quadratic on prefix sets, in the reference as here, which is why the reference deploys the zigzag one."""
+    from frankenpaxos_amd import depgraph as P
+    from frankenpaxos_amd.epaxos import EPaxos
+    from tests import workloads as W
+
+    n, num_keys, m = 5, 1024, 1 << 20
+    NI = m // n + 4096
+    gpu, ref = EPaxos(n, num_keys, num_instances=NI), oracle.EPaxos(n, num_keys, num_instances=NI)
+    rng = np.random.default_rng(44)
+    nxt = [0] * n
+    leader, number, key, is_set, mask, rank = random_tick(rng, n, num_keys, m, nxt, 64.0, fifo=False)
+    assert max(nxt) <= NI
+    key = (W.splitmix64_at(np.arange(m, dtype=np.uint64)) % np.uint64(num_keys)).astype(np.int32)
+    triple = np.arange(m, dtype=np.int32)
+    a = gpu.preaccept(leader, number, key, is_set, mask, rank, triple_id=triple)
+    b = ref.preaccept(leader, number, key, is_set, mask, rank, triple_id=triple)
+    _same(a, b)
+    st, fast, deps, ldeps, own = a
+    slow, acc_g = _slow_path_accepts(gpu, leader, number, key, is_set, mask, fast, triple, 2)
+    _, acc_r = _slow_path_accepts(ref, leader, number, key, is_set, mask, fast, triple, 2)
+    _same(acc_g, acc_r)
+    assert len(slow) > 10_000 and acc_g[5].all()
+    for r in range(n):                                    # the Accept phase left every index as the oracle's
+        for k in range(0, num_keys, 37):
+            ga, sa = gpu.read_index(r, k)
+            gb, sb = ref.read_index(r, k)
+            assert ga.tolist() == gb.tolist() and sa.tolist() == sb.tolist()
+    zz = P.DependencyGraph(n, kind=P.FPX_DG_ZIGZAG)
+    zz.commit_epx(leader, number, deps, own)
+    el, ei, cs, bl, bi = zz.execute_arrays()
+    check_execution_order(n, leader, number, deps, own[:, 0], el, ei, cs)
+    assert sorted(zip(bl.tolist(), bi.tolist())) == [(L, nxt[L]) for L in range(n)]   # blocked on the next ids only

@@ -159,8 +159,9 @@ def test_flat_oracle_and_set_model_agree(oracle, n, num_keys, seed):
             targets = [r for r in targets if r != ballot[1]]
             tmask = [sum(1 << r for r in targets)]
             tid = int(rng.integers(0, 1000))
-            st, ok, nack, com, nb, done = ref.accept([L], [x], [ballot[0]], [ballot[1]], [tid], tmask)
-            fatal, got, committed = mod.accept((L, x), ballot, tid, targets)
+            akey, aset = int(rng.integers(-1, num_keys)), bool(rng.integers(0, 2))   # the triple's command; -1 = Noop
+            st, ok, nack, com, nb, done = ref.accept([L], [x], [ballot[0]], [ballot[1]], [tid], tmask, [akey], [aset])
+            fatal, got, committed = mod.accept((L, x), ballot, tid, targets, akey, aset)
             assert (st == 9) == fatal and st in (0, 9)
             seen["fatal"] += fatal
             if not fatal:

@@ -28,6 +28,14 @@ def test_host_mirror_compiles_and_links():
     assert os.path.exists(build_driver())
 
 
+def test_host_mirror_dependency_graph_tests():
+    """the dependency-graph part of the mirror is host code: the reference's depgraph tests run without a GPU"""
+    exe = build_driver()
+    out = subprocess.run([exe, "--host-only"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "host-only tests passed" in out.stdout
+
+
 @pytest.mark.gpu
 def test_host_mirror_reference_unit_tests():
     exe = build_driver()

@@ -132,8 +132,9 @@ def test_short_arrays_are_rejected_before_native_code_touches_them(jvm):
     assert jvm.call("epxPreaccept", C.c_int32, 0, n, 5, i32(n), i32(n), i32(n), i8(n), i8(n), None, i32(5 * n - 1), None, None, None, None) == EINVAL
     assert jvm.call("epxPrepare", C.c_int32, 0, n, 5, i32(n), i32(n), i32(n), i32(n), i8(n), i8(3 * n - 1), None, None) == EINVAL
     assert jvm.call("epxPrepare", C.c_int32, 0, n, 5, i32(n), i32(n), i32(n), i32(n), i8(n), None, None, i32(15 * n - 1)) == EINVAL
-    assert jvm.call("epxAccept", C.c_int32, 0, n, i32(n), i32(n), i32(n), i32(n), i32(n - 1), i8(n), None, None) == EINVAL
-    assert jvm.call("epxAccept", C.c_int32, 0, n, i32(n), i32(n), i32(n), i32(n), i32(n), i8(n), i8(4 * n - 1), None) == EINVAL
+    assert jvm.call("epxAccept", C.c_int32, 0, n, i32(n), i32(n), i32(n), i32(n), i32(n - 1), i32(n), i8(n), i8(n), None, None) == EINVAL
+    assert jvm.call("epxAccept", C.c_int32, 0, n, i32(n), i32(n), i32(n), i32(n), i32(n), i32(n), i8(n - 1), i8(n), None, None) == EINVAL
+    assert jvm.call("epxAccept", C.c_int32, 0, n, i32(n), i32(n), i32(n), i32(n), i32(n), i32(n), i8(n), i8(n), i8(4 * n - 1), None) == EINVAL
     hp = lambda **kw: jvm.call("epxHandlePreaccept", C.c_int32, 0, n, 5, i32(n), i32(n), i32(n), i32(n), i32(n), i8(n),
                                kw.get("tr"), kw.get("din", i32(5 * n)), kw.get("dend"), i8(n), kw.get("rep"), None,
                                kw.get("rd"), kw.get("re"))
@@ -262,8 +263,11 @@ def test_epaxos_command_log_through_the_shim(jvm, oracle):
     np.testing.assert_array_equal(jvm.read(po, np.int32, 3 * n), np.concatenate([want[5][0], want[6][0], want[7][0]]))
     assert hp(0, 1, 0b00100, 70, [0, 1, 0, 4, 0]).tolist() == [0, 0, 0b00100, 0]
     rep4, nb = jvm.arr(np.zeros(4, np.int8)), jvm.arr(np.zeros(1, np.int32))
-    assert jvm.call("epxAccept", C.c_int32, h, 1, i32([1]), i32([3]), i32([2]), i32([4]), i32([71]), i8([0b00101]), rep4, nb) == 0
-    want = ref.accept([1], [3], [2], [4], [71], [0b00101])
+    # a handle is the authority on its own n: a caller that says otherwise is refused (it would size the replies short)
+    assert jvm.call("epxPrepare", C.c_int32, h, 1, 3, i32([1]), i32([3]), i32([2]), i32([4]), i8([0b00100]), rep, nb, po) == 1
+    assert jvm.call("epxAccept", C.c_int32, h, 1, i32([1]), i32([3]), i32([2]), i32([4]), i32([71]), i32([2]), i8([1]),
+                    i8([0b00101]), rep4, nb) == 0
+    want = ref.accept([1], [3], [2], [4], [71], [0b00101], [2], [1])
     assert jvm.read(rep4, np.int8, 4).view(np.uint8).tolist() == [int(want[k][0]) for k in (1, 2, 3, 5)]
     entry = jvm.arr(np.zeros(6 + n, np.int32))
     for r in range(n):
