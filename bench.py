@@ -69,9 +69,10 @@ def algorithmic_bytes_per_slot(ballot_mode):
     return 8 + 8 * r + 8              # faithful scalar model: reads 8 B/slot (+1 KiB/batch)
 
 
-def cpu_baseline(ballot_mode):
+def cpu_baseline(ballot_mode, light=False):
     """The CPU oracle (a plain-C, single-threaded port of the reference handlers; the JVM reference
-    cannot run here) timed on this box on a bounded sample of the same workload."""
+    cannot run here) timed on this box on a bounded sample of the same workload.  light: only the
+    single-thread flat port (what an N > 1 line carries: the other ranks wait for rank 0 meanwhile)."""
     from oracle import pyoracle
     from tests import workloads as W
 
@@ -85,6 +86,11 @@ def cpu_baseline(ballot_mode):
     st, ch, cr, cv, nr = ref.phase2_fused(slot, rnd, val)
     dt = time.perf_counter() - t0
     assert st == 0 and int(ch.sum()) == S
+    if light:
+        return {"value": S / dt, "unit": "slots/s", "cores": 1, "kind": "port",
+                "sample": "oracle/fpx_oracle.c fpo_phase2_fused (flat arrays), 2^19 slots x 256 acceptors, steady stream, "
+                          "1 thread, on rank 0's host cores; the N = 1 line carries the other CPU forms; nproc=%d"
+                          % os.cpu_count()}
     # the same handlers behind a strict FIFO message pump (stand-in for the in-process Transport)
     Sp = 1 << 15
     ref2 = pyoracle.System(pyoracle.make_config(num_slots=Sp, num_replicas=REPLICAS, f=F,
@@ -282,6 +288,9 @@ def main():
     ap.add_argument("--config", choices=["headline", "2", "3", "4", "5"], default="headline",
                     help="headline = BASELINE.json's metric grid (2^20 slots x 256 acceptors); 2..5 = the other "
                          "BASELINE.json configs as bench lines of the same schema (bench_configs.py)")
+    ap.add_argument("--configs-block-steps", type=int, default=5,
+                    help="N = 1 headline run: steps of each of BASELINE.json's other configs (2..5) timed after the "
+                         "headline and reported in the line's `configs` block (0 = leave the block out)")
     ap.add_argument("--replica-row-deadline", type=int, default=120,
                     help="seconds the extra replica-axis row may take before the line is printed without it")
     ap.add_argument("--replica-row-steps", type=int, default=5,
@@ -435,6 +444,7 @@ def main():
     launches, kernel_ms = ctx.profile_read()
     coll_n, coll_ms = ctx.profile_read_collective()
     assert ctx.sync() == 0
+    hbm_bytes = ctx.device_bytes
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         all_reduce(t, dist.ReduceOp.MAX)
@@ -470,6 +480,57 @@ def main():
             args.replica_row_deadline, dev)
         if rank != 0 and not hung:
             replica_row = None
+
+    # N > 1: does RCCL carry bytes between these GPUs at all?  Asked on its own (a communicator behind the C ABI on a
+    # small context + one all-gather of Chosen records), so that `rccl` in the line does not depend on the extra
+    # row having finished; deadline-guarded like the row.
+    rccl_info = None
+    if world > 1 and backend == "nccl" and not hung:
+        def rccl_probe():
+            pctx = fa.Context(fa.make_config(num_slots=4096, num_replicas=4, f=1, device=local_rank))
+            pctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            setup_comm(fa, pctx, dist, backend, dev, rank, world)
+            nloc = 1024
+            mine = [torch.full((nloc,), rank + 1, dtype=dt, device=dev) for dt in (torch.uint8, torch.int32, torch.int32)]
+            alls = [torch.zeros((world * nloc,), dtype=t.dtype, device=dev) for t in mine]
+            pctx.comm_allgather_chosen_dev(*mine, *alls)
+            assert pctx.sync() == 0
+            want = torch.arange(1, world + 1, device=dev).repeat_interleave(nloc)
+            ok = all(bool((a.to(torch.int64) == want).all()) for a in alls)
+            r, w2 = pctx.comm_info()
+            pctx.close()
+            return {"ranks": w2, "allgather_of_chosen_records_ok": ok}
+        rccl_info, hung2 = run_with_deadline(rccl_probe, 90, dev)
+        hung = hung or hung2
+
+    # N = 1: BASELINE.json's other configs, a few steps each, so that the driver's own run times them too
+    configs_block = None
+    if world == 1 and args.configs_block_steps > 0 and not replica_shard:
+        import types
+        import bench_configs
+        ctx.close()
+        torch.cuda.empty_cache()
+        configs_block = {}
+        for c in ("2", "3", "4", "5"):
+            t_c = time.perf_counter()
+            try:
+                sub = types.SimpleNamespace(steps=args.configs_block_steps, warmup=2, ballot=args.ballot, config=c,
+                                            no_cpu_baseline=True)
+                full = bench_configs.run(sub, fa, None, dev, 0, 1, local_rank, all_reduce)
+                configs_block[c] = {
+                    "metric": full["metric"], "value": full["value"], "unit": full["unit"], "steps": full["steps"],
+                    "ms_per_step": full["ms_per_step"], "workload": full["config"]["workload"],
+                    "roofline_frac": full["roofline"]["frac"], "achieved_GBs": full["roofline"]["achieved"],
+                    "avg_kernel_ms": full["roofline"]["avg_kernel_ms"],
+                    "algorithmic_bytes_per_unit": full["roofline"]["algorithmic_bytes_per_unit"],
+                    "verified": full["config"].get("verified"), "wall_s": None,
+                }
+                if "note" in full["roofline"]:
+                    configs_block[c]["note"] = full["roofline"]["note"]
+            except BaseException as e:  # noqa: BLE001 -- the headline line must survive a failing extra config
+                configs_block[c] = {"error": "%s: %s" % (type(e).__name__, e)}
+            configs_block[c]["wall_s"] = time.perf_counter() - t_c
+            torch.cuda.empty_cache()
 
     if rank == 0:
         bps = algorithmic_bytes_per_slot(ballot_mode)
@@ -509,7 +570,7 @@ def main():
                 "slots_per_step": SLOTS_PER_STEP, "replicas": REPLICAS, "quorum": F + 1,
                 "ballot_model": args.ballot, "sharding": args.shard if world > 1 else "none",
                 "run_contract_validation_in_timed_region": bool(args.validate),
-                "log_windows_in_hbm": windows, "hbm_bytes": ctx.device_bytes,
+                "log_windows_in_hbm": windows, "hbm_bytes": hbm_bytes,
                 "steps_reproposing_old_slots": sum(1 for i in range(Wm, Wm + K) if i // windows > 0),
             },
             "roofline": {
@@ -527,7 +588,13 @@ def main():
                 "frac_of_measured_read_stream": (achieved / MEASURED_STREAM_GBS["read"]) if achieved else None,
             },
         }
-        line["rccl_ranks"] = world if (have_comm or (replica_row or {}).get("rccl_ranks")) else 0
+        # how many ranks an RCCL communicator created in THIS run actually spans (0 at N = 1: none is needed)
+        line["rccl_ranks"] = world if (have_comm or (replica_row or {}).get("rccl_ranks") or
+                                       (rccl_info or {}).get("ranks") == world) else 0
+        if rccl_info is not None:
+            line["rccl"] = rccl_info
+        if configs_block is not None:
+            line["configs"] = configs_block
         if replica_shard:
             line["collective"] = {
                 "op": "ncclReduceScatter(ncclSum, ncclUint64) via fpx_phase2_replica_sharded_dev" if have_comm
@@ -537,8 +604,8 @@ def main():
             }
         if replica_row is not None:
             line["replica_axis"] = replica_row
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(ballot_mode)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(ballot_mode, light=world > 1)
         print(json.dumps(line), flush=True)
     if hung:  # a collective of the extra row never returned: no barrier, no teardown that could wait for it
         sys.stderr.write("bench.py: rank %d: the replica-axis row did not finish; exiting without it\n" % rank)

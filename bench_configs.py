@@ -114,8 +114,8 @@ def multipaxos_setup(fa, dev, local_rank, ballot_mode, cfg, K, Wm):
 # ------------------------------------------------------------------------------------------------------------------
 def epaxos_setup(fa, dev, local_rank, K, Wm):
     from frankenpaxos_amd.epaxos import EPaxos
-    from tests.test_epaxos import random_tick
     from tests import workloads as W
+    from tests.workloads import random_tick
 
     n, num_keys, m = 5, 1024, 1 << 20
     epx = EPaxos(n, num_keys, device=local_rank)
@@ -142,12 +142,24 @@ def epaxos_setup(fa, dev, local_rank, K, Wm):
             epx.preaccept_dev(leader, number, key, is_set, mask, rank, fast, deps, ldeps, own_values_end=own)
 
     def verify(lo, hi):
+        """the first timed tick against the oracle on EVERY output (the oracle replays the ticks before it: the conflict
+        indexes carry over), the others by their path counts"""
+        from oracle import pyoracle
         assert epx.sync() == 0
+        pyoracle.build()
+        ref = pyoracle.EPaxos(n, num_keys)
+        h = lambda t: t.cpu().numpy()
+        for i in range(lo + 1):
+            want = ref.preaccept(*[h(x) for x in ticks[i][:6]])
+            assert want[0] == 0
+        fast, deps, ldeps, own = (h(x) for x in ticks[lo][6:10])
+        assert (fast == want[1]).all() and (deps == want[2]).all() and (ldeps == want[3]).all() and (own == want[4]).all(), \
+            "tick %d differs from the oracle" % lo
         done = 0
         for i in range(lo, hi):
             fast = ticks[i][6]
             nf = int(fast.sum().item())
-            assert 0 < nf <= m, "tick %d: %d fast-path commits" % (i, nf)
+            assert 0 < nf < m, "tick %d: %d fast-path commits" % (i, nf)
             assert bool((ticks[i][9] == 0).all())       # FIFO channels: no own-column holes
             done += m                                   # every command is decided (fast commit or Accept phase)
         return done
@@ -331,7 +343,11 @@ def run(args, fa, dist, dev, rank, world, local_rank, all_reduce):
         "metric": w["metric"], "value": done / elapsed, "unit": w["unit"], "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": w.get("scaling", "weak"),
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": dict({"workload": w["workload"], "baseline_config": int(args.config)}, **w["extra"]),
+        "config": dict({"workload": w["workload"], "baseline_config": int(args.config),
+                        "verified": "every timed step checked after the timed region" +
+                                    (": first timed tick == the CPU oracle on every output, all ticks by path counts"
+                                     if args.config == "4" else ": every slot chosen with its proposed value")},
+                       **w["extra"]),
         "roofline": {
             "bound": "hbm", "kernel": w["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic_of(args.config),
@@ -343,6 +359,11 @@ def run(args, fa, dist, dev, rank, world, local_rank, all_reduce):
                     "fraction of the HBM peak is reported for the contract, the absolute rate is the figure of merit",
         },
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if args.config == "2":
+        line["roofline"]["bound_in_practice"] = "launch latency: a 65 536-slot x 3 step is one ~20 us kernel; the config is " \
+                                                "BASELINE.json's bring-up / bit-exactness case, not a bandwidth case"
+    if not args.no_cpu_baseline:
         line["cpu_baseline"] = w["cpu"]()
+    if hasattr(ctx, "close"):
+        ctx.close()
     return line

@@ -221,3 +221,36 @@ def assert_same_state(be_a, be_b, tally_slots=()):
         np.testing.assert_array_equal(sa[key], sb[key], err_msg=key)
     for s in tally_slots:
         assert be_a.read_tally(int(s)) == be_b.read_tally(int(s)), "tally of slot %d" % s
+
+
+# ---- EPaxos: one tick of fresh instances (used by tests/test_epaxos.py and bench_configs.py) ----------------------
+def random_tick(rng, n, num_keys, m, next_number, skew, fifo=True):
+    """One tick of fresh instances.  Every replica sees the tick in roughly the global order, perturbed by a
+    replica-specific skew.  A leader numbers its instances in the order IT processes them
+    (Replica.scala nextAvailableInstance), and with fifo=True every other replica receives one leader's
+    PreAccepts in sending order (the reference's transports are TCP channels: per-pair FIFO).  fifo=False
+    lets the channels reorder, which is what makes a replica meet (L, 5) before (L, 4) -- the case
+    dependencies.subtractOne(instance) (Replica.scala:582) exists for."""
+    leader = rng.integers(0, n, m).astype(np.int32)
+    key = rng.integers(0, num_keys, m).astype(np.int32)
+    is_set = (rng.random(m) < 0.5).astype(np.uint8)  # Bernoulli get/set, J/Workload.scala:75-103
+    mask = np.zeros(m, np.uint8)
+    others = np.array([[r for r in range(n) if r != L] for L in range(n)])   # [n][n-1]
+    drop = rng.integers(0, n - 1, m)
+    for j in range(n - 1):
+        mask |= np.where(drop != j, 1 << others[leader, j], 0).astype(np.uint8)
+    rank = np.zeros((n, m), np.int32)
+    for r in range(n):
+        noisy = np.arange(m) + rng.normal(0, skew, m)
+        rank[r, np.argsort(noisy, kind="stable")] = np.arange(m)
+    number = np.zeros(m, np.int32)
+    for L in range(n):
+        idx = np.nonzero(leader == L)[0]
+        by_own = idx[np.argsort(rank[L, idx], kind="stable")]     # the leader's own processing order
+        number[by_own] = next_number[L] + np.arange(len(idx))
+        next_number[L] += len(idx)
+        if fifo:
+            for r in range(n):
+                if r != L:   # the positions leader L's messages occupy at r, refilled in sending order
+                    rank[r, by_own] = np.sort(rank[r, idx])
+    return leader, number, key, is_set, mask, rank
