@@ -108,6 +108,7 @@ SIGNATURES = {
     "fpx_noop_ranges_fused": (C.c_int32, [VP, C.c_int32] + [VP] * 9),
     "fpx_noop_ranges_fused_dev": (C.c_int32, [VP, C.c_int32] + [VP] * 9),
     "fpx_read_range_tally": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, I32P, VP]),
+    "fpx_recycle_slots": (C.c_int32, [VP, C.c_int32, C.c_int32]),
     "fpx_proxy_forget": (C.c_int32, [VP, C.c_int32, C.c_int32]),
     "fpx_epx_create": (C.c_int32, [VP, C.POINTER(VP)]),
     "fpx_epx_destroy": (C.c_int32, [VP]),
@@ -128,6 +129,7 @@ SIGNATURES = {
     "fpx_replica_chosen_noop_range": (C.c_int32, [VP, C.c_int32, C.c_int32, I32P, I32P]),
     "fpx_replica_read_log": (C.c_int32, [VP, C.c_int32, C.c_int32, VP, VP]),
     "fpx_leader_phase1b_scan": (C.c_int32, [VP, C.c_int32, VP, C.c_int32, I32P, VP, VP]),
+    "fpx_acceptor_phase1b_info": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, I32P, VP, VP, VP]),
     "fpx_read_acceptor": (C.c_int32, [VP, C.c_int32, C.c_int32, I32P, I32P, VP, VP, VP]),
     "fpx_read_state": (C.c_int32, [VP, VP, VP, VP]),
     "fpx_read_scalars": (C.c_int32, [VP, VP, VP]),

@@ -246,6 +246,12 @@ class Context:
         if st:
             raise FpxError(st, "fpx_proxy_forget")
 
+    def recycle_slots(self, first_slot, count):
+        """the rows of a slot range become fresh: votes dropped, tallies forgotten, promises kept (async)"""
+        st = self.L.fpx_recycle_slots(self._h, first_slot, count)
+        if st:
+            raise FpxError(st, "fpx_recycle_slots")
+
     # ---- K4: Mencius noop ranges ----------------------------------------------------------------
     def acceptor_phase2a_noop_range(self, slot_start, slot_end, round_, target_masks=None):
         A = self.cfg.num_groups
@@ -370,6 +376,20 @@ class Context:
                                             _hp(sv))
         k = max(0, min(cap, mx.value - watermark + 1))
         return st, mx.value, sr[:k], sv[:k]
+
+    def acceptor_phase1b_info(self, group, replica, watermark=0):
+        """Phase1b.info of one acceptor: (slot, vote_round, vote_value) of its votes in slots >= watermark, ascending"""
+        k = C.c_int32()
+        st = self.L.fpx_acceptor_phase1b_info(self._h, group, replica, watermark, 0, C.byref(k), None, None, None)
+        if st:
+            raise FpxError(st, "fpx_acceptor_phase1b_info")
+        n = k.value
+        sl, vr, vv = (np.zeros(n, np.int32) for _ in range(3))
+        if n:
+            st = self.L.fpx_acceptor_phase1b_info(self._h, group, replica, watermark, n, C.byref(k), _hp(sl), _hp(vr), _hp(vv))
+            if st:
+                raise FpxError(st, "fpx_acceptor_phase1b_info")
+        return sl, vr, vv
 
     # ---- readback ------------------------------------------------------------------------------
     def read_acceptor(self, group, replica):

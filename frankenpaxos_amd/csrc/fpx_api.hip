@@ -1307,6 +1307,17 @@ int32_t fpx_proxy_forget(fpx_ctx* ctx, int32_t first_slot, int32_t count) {
   return FPX_OK;
 }
 
+int32_t fpx_recycle_slots(fpx_ctx* ctx, int32_t first_slot, int32_t count) {
+  DeviceGuard _dg(ctx);
+  if (!ctx || first_slot < 0 || count < 0 || (int64_t)first_slot + count > ctx->g.S) return FPX_EINVAL;
+  if (count == 0) return FPX_OK;
+  const size_t row = (size_t)ctx->g.RS * 4, at = (size_t)first_slot * row, len = (size_t)count * row;
+  HIPCHK(ctx, hipMemsetAsync((char*)ctx->st.vote_round + at, 0xFF, len, ctx->stream));  // -1: no vote
+  HIPCHK(ctx, hipMemsetAsync((char*)ctx->st.vote_value + at, 0xFF, len, ctx->stream));
+  if (ctx->st.row_voted) HIPCHK(ctx, hipMemsetAsync(ctx->st.row_voted + first_slot, 0, (size_t)count, ctx->stream));
+  return fpx_proxy_forget(ctx, first_slot, count);
+}
+
 // ---- K4: Mencius noop ranges (batched; kernels in fpx_ranges.hpp) -----------------------------------------
 static int32_t ranges_ctx_ok(fpx_ctx* ctx, int32_t n) {
   if (!ctx || n < 0) return FPX_EINVAL;
@@ -1749,6 +1760,44 @@ int32_t fpx_read_acceptor(fpx_ctx* ctx, int32_t group, int32_t replica, int32_t*
     if (vote_value) HIPCHK(ctx, hipMemcpy(vote_value, base + S, S * 4, hipMemcpyDeviceToHost));
     if (ballot) HIPCHK(ctx, hipMemcpy(ballot, base + 2 * S, S * 4, hipMemcpyDeviceToHost));
   }
+  return FPX_OK;
+}
+
+// Acceptor.handlePhase1a's Phase1b.info (multipaxos/Acceptor.scala:166-178): the acceptor's votes in slots >=
+// chosen_watermark, ascending (states.iteratorFrom).  Phase 1 is off the steady path: one gather of the acceptor's
+// column, compacted on the host.
+int32_t fpx_acceptor_phase1b_info(fpx_ctx* ctx, int32_t group, int32_t replica, int32_t chosen_watermark, int32_t cap,
+                                  int32_t* count, int32_t* slot, int32_t* vote_round, int32_t* vote_value) {
+  DeviceGuard _dg(ctx);
+  if (!ctx || !count || cap < 0 || group < 0 || group >= ctx->g.ngroups || replica < 0 || replica >= ctx->g.R ||
+      (cap > 0 && (!slot || !vote_round || !vote_value)))
+    return FPX_EINVAL;
+  *count = 0;
+  const size_t e = (size_t)group * ctx->g.R + replica;
+  const int64_t S = ctx->g.S;
+  int rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  int32_t max_voted = -1;
+  HIPCHK(ctx, hipMemcpy(&max_voted, ctx->st.max_voted + e, 4, hipMemcpyDeviceToHost));
+  const int64_t lo = chosen_watermark < 0 ? 0 : chosen_watermark;
+  if (max_voted < lo || lo >= S) return FPX_OK;  // no vote at or above the watermark
+  if ((rc = grow(ctx, &ctx->d_scratch, (size_t)S * 12 + 128))) return rc;
+  int32_t* base = (int32_t*)((char*)ctx->d_scratch.p + 128);
+  hipLaunchKernelGGL(k_gather_acceptor, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream, ctx->g, ctx->st,
+                     group, replica, base, base + S, base + 2 * S);
+  if ((rc = launch_check(ctx))) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t len = (size_t)(max_voted - lo + 1);
+  std::vector<int32_t> vr(len), vv(len);
+  HIPCHK(ctx, hipMemcpy(vr.data(), base + lo, len * 4, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(vv.data(), base + S + lo, len * 4, hipMemcpyDeviceToHost));
+  int32_t k = 0;
+  for (size_t j = 0; j < len; ++j) {
+    if (vr[j] < 0) continue;  // no vote in the slot (or another group's slot)
+    if (k < cap) slot[k] = (int32_t)(lo + (int64_t)j), vote_round[k] = vr[j], vote_value[k] = vv[j];
+    ++k;
+  }
+  *count = k;
   return FPX_OK;
 }
 

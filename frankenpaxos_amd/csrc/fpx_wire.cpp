@@ -380,6 +380,108 @@ int64_t fpx_wire_encode_leader_nack(uint8_t* out, int64_t cap, int32_t round) {
   return wrapped(out, cap, 6, i32_len(round), [&](Writer& w) { w.i32(1, round); });
 }
 
+int64_t fpx_wire_encode_leader_phase1b(uint8_t* out, int64_t cap, int32_t group_index, int32_t acceptor_index,
+                                       int32_t round, int32_t n_info, const int32_t* slot, const int32_t* vote_round,
+                                       const uint8_t* values, const int64_t* value_off, const int32_t* value_len,
+                                       const uint8_t* is_noop) {
+  if (n_info < 0 || (n_info > 0 && (!slot || !vote_round))) return 0;
+  auto value_of = [&](int32_t j, const uint8_t*& v, int32_t& len) {
+    const bool noop = is_noop && is_noop[j];
+    v = (!noop && values && value_off) ? values + value_off[j] : nullptr;
+    len = (!noop && value_len) ? value_len[j] : 0;
+    pick_value(v, len, noop ? 1 : 0);
+  };
+  auto info_len = [&](int32_t j) {
+    const uint8_t* v;
+    int32_t len;
+    value_of(j, v, len);
+    return i32_len(slot[j]) + i32_len(vote_round[j]) + 1 + varint_len((uint64_t)len) + len;
+  };
+  int64_t inner = i32_len(group_index) + i32_len(acceptor_index) + i32_len(round);
+  for (int32_t j = 0; j < n_info; ++j) {
+    const int64_t il = info_len(j);
+    inner += 1 + varint_len((uint64_t)il) + il;
+  }
+  return wrapped(out, cap, 1, inner, [&](Writer& w) {
+    w.i32(1, group_index);
+    w.i32(2, acceptor_index);
+    w.i32(3, round);
+    for (int32_t j = 0; j < n_info; ++j) {
+      const uint8_t* v;
+      int32_t len;
+      value_of(j, v, len);
+      w.tag(4, 2);
+      w.varint((uint64_t)info_len(j));
+      w.i32(1, slot[j]);
+      w.i32(2, vote_round[j]);
+      w.tag(3, 2);
+      w.varint((uint64_t)len);
+      w.bytes(v, len);
+    }
+  });
+}
+
+int32_t fpx_wire_decode_leader_inbound(const uint8_t* buf, int64_t buf_len, const int64_t* offsets, int32_t n,
+                                       int32_t* kind, int32_t* round, int32_t* group_index, int32_t* acceptor_index,
+                                       int32_t* info_first, int32_t* info_count, int32_t info_cap, int32_t* info_total,
+                                       int32_t* info_slot, int32_t* info_vote_round, int32_t* info_is_noop,
+                                       int64_t* info_value_off, int32_t* info_value_len, int32_t* bad_index) {
+  if ((n > 0 && (!kind || !round)) || info_cap < 0 || (info_cap > 0 && (!info_slot || !info_vote_round))) return FPX_EINVAL;
+  int32_t total = 0;
+  if (info_total) *info_total = 0;
+  const int32_t st = decode_loop(buf, buf_len, offsets, n, bad_index, [&](int32_t i, Reader r) {
+    kind[i] = FPX_WIRE_OTHER, round[i] = -1;
+    if (group_index) group_index[i] = -1;
+    if (acceptor_index) acceptor_index[i] = -1;
+    if (info_first) info_first[i] = total;
+    if (info_count) info_count[i] = 0;
+    while (r.more()) {  // LeaderInbound: the last member of the oneof that is present wins
+      const uint64_t tag = r.varint();
+      const uint32_t field = (uint32_t)(tag >> 3), wt = (uint32_t)(tag & 7);
+      if (field == 1 && wt == 2) {  // Phase1b
+        Reader p = r.sub();
+        if (!r.ok) return false;
+        int32_t hdr[4] = {0, 0, 0, 0};
+        unsigned seen = 0;
+        const int32_t first = total;  // a second phase1b member replaces the first one's entries
+        while (p.more()) {
+          const uint64_t t2 = p.varint();
+          const uint32_t f2 = (uint32_t)(t2 >> 3), w2 = (uint32_t)(t2 & 7);
+          if (f2 >= 1 && f2 <= 3 && w2 == 0) {
+            hdr[f2] = as_i32(p.varint()), seen |= 1u << f2;
+          } else if (f2 == 4 && w2 == 2) {
+            Fields f;
+            if (!parse_flat(p.sub(), 3, &f) || !p.ok || (f.seen & 0x6) != 0x6 || !f.has_value) return false;
+            if (total >= info_cap) return false;
+            info_slot[total] = f.i[1], info_vote_round[total] = f.i[2];
+            if (info_is_noop) info_is_noop[total] = f.value.is_noop;
+            if (info_value_off) info_value_off[total] = f.value.at - buf;
+            if (info_value_len) info_value_len[total] = f.value.len;
+            ++total;
+          } else {
+            p.skip(w2);
+          }
+        }
+        if (!p.ok || (seen & 0xe) != 0xe) return false;
+        kind[i] = FPX_WIRE_PHASE1B, round[i] = hdr[3];
+        if (group_index) group_index[i] = hdr[1];
+        if (acceptor_index) acceptor_index[i] = hdr[2];
+        if (info_first) info_first[i] = first;
+        if (info_count) info_count[i] = total - first;
+      } else if (field == 6 && wt == 2) {  // Nack
+        Fields f;
+        if (!parse_flat(r.sub(), 0, &f) || !r.ok || (f.seen & 0x2) != 0x2) return false;
+        kind[i] = FPX_WIRE_NACK, round[i] = f.i[1];
+      } else {
+        r.skip(wt);  // ClientRequest, ChosenWatermark, Recover, ...: the JVM Leader's own
+      }
+    }
+    return r.ok;
+  });
+  if (info_total) *info_total = total;
+  return st;
+}
+
 int64_t fpx_wire_encode_phase2b_batch(int32_t n, const int32_t* slot, const int32_t* round, const uint64_t* vote_bits,
                                       const int32_t* group_of_slot, int32_t grid_cols, uint8_t* out, int64_t cap,
                                       int64_t* out_offsets, int64_t max_msgs) {

@@ -1,12 +1,17 @@
 // Native.scala -- the reference-side binding a frankenpaxos maintainer would add (source only: no
 // JDK / scalac in this image).  Drop into jvm/src/main/scala/frankenpaxos/gpu/ of the reference.
 //
-// `Native` is the JNI surface of frankenpaxos_amd/jni/fpx_jni.c; `GpuPhase2` is a batched stand-in for
-// the acceptors of every group plus one proxy leader that plugs into the unchanged Actor/Transport
-// trait surface: it is an Actor whose `receive` only ENQUEUES the decoded Phase2a / Phase2b messages,
-// and a zero-delay Transport timer (the "tick") flushes the queue through ONE native call and then
-// `send`s the Phase2b / Nack / Chosen messages the Scala handlers would have sent
-// (multipaxos/Acceptor.scala:192-219, multipaxos/ProxyLeader.scala:246-253).
+// `Native` is the JNI surface of frankenpaxos_amd/jni/fpx_jni.c.  `GpuPhase2Engine` owns one libfpx context --
+// the acceptors of every group plus the proxy leader's tallies -- and maps the unbounded log onto the
+// context's window of rows.  Two thin actors put it behind the unchanged Actor/Transport trait surface:
+//   * `GpuProxyLeader` stands at a proxy leader's address: its `receive` only ENQUEUES Phase2a messages, a
+//     zero-delay Transport timer (the "tick") flushes the queue through ONE native call and then `send`s the
+//     Nack / Chosen messages the Scala handlers would have sent (multipaxos/Acceptor.scala:192-219,
+//     multipaxos/ProxyLeader.scala:246-253);
+//   * `GpuAcceptor` stands at EVERY acceptor address (all instances share the engine): the Leader's Phase1a
+//     (multipaxos/Leader.scala:231, 410-420) is answered with the Phase1b / Nack of
+//     multipaxos/Acceptor.scala:148-182, built from fpx_acceptor_phase1a + fpx_acceptor_phase1b_info, which
+//     is what the unchanged Leader.handlePhase1b (Leader.scala:504-577) needs to recover and re-propose.
 package frankenpaxos.gpu
 
 import frankenpaxos.Actor
@@ -107,6 +112,22 @@ object Native {
   @native def wireDecodeProxyLeaderInbound(buf: java.nio.ByteBuffer, offsets: Array[Long], n: Int,
                                            fields: Array[Int], valueOff: Array[Long],
                                            badIndex: Array[Int]): Int
+  // the acceptors' half of Phase 1 and the log window (fpx_acceptor_phase1b_info, fpx_read_acceptor,
+  // fpx_recycle_slots, fpx_proxy_forget)
+  @native def acceptorPhase1bInfo(handle: Long, group: Int, replica: Int, chosenWatermark: Int, cap: Int,
+                                  slot: Array[Int], voteRound: Array[Int], voteValue: Array[Int]): Int // count, < 0: -status
+  @native def acceptorRound(handle: Long, group: Int, replica: Int): Int // Acceptor.round, < -1: -status - 1
+  @native def recycleSlots(handle: Long, firstSlot: Int, count: Int): Int
+  @native def proxyForget(handle: Long, firstSlot: Int, count: Int): Int
+  // wire adapter, acceptor side: AcceptorInbound bytes -> fields = kind | slot | round | isNoop | valueLen |
+  // chosenWatermark (6 x n); LeaderInbound{Phase1b} / {Nack} bytes into a direct buffer (length, < 0: -needed)
+  @native def wireDecodeAcceptorInbound(buf: java.nio.ByteBuffer, offsets: Array[Long], n: Int,
+                                        fields: Array[Int], valueOff: Array[Long], badIndex: Array[Int]): Int
+  @native def wireEncodeLeaderPhase1b(out: java.nio.ByteBuffer, groupIndex: Int, acceptorIndex: Int, round: Int,
+                                      nInfo: Int, slot: Array[Int], voteRound: Array[Int],
+                                      values: java.nio.ByteBuffer, valueOff: Array[Long], valueLen: Array[Int],
+                                      isNoop: Array[Byte]): Long
+  @native def wireEncodeLeaderNack(out: java.nio.ByteBuffer, round: Int): Long
 
   def check(status: Int, logger: Logger): Unit = status match {
     case OK                       => ()
@@ -117,37 +138,187 @@ object Native {
   }
 }
 
-// A GPU-backed replacement for the acceptor groups + one proxy leader of a (non-flexible or
-// flexible) MultiPaxos deployment.  Leaders keep sending Phase2a to it exactly as they send to a
-// ProxyLeader (multipaxos/Leader.scala:364-398); replicas keep receiving Chosen from it.
-class GpuPhase2[Transport <: frankenpaxos.Transport[Transport]](
+// One libfpx context = the acceptors of every group + the proxy leader's tallies, for a deployment whose
+// acceptors and proxy leaders run in ONE process on the GPU box (one Transport event loop: the engine is
+// not thread-safe, like every actor, Transport.scala:37-39).
+//
+// The log window.  The context holds `numSlots` rows; slot s lives in row s % numSlots, the window is
+// [base, base + numSlots).  A Phase2a beyond the window waits (`deferred`) until the window has moved; the
+// window moves, in chunks, over slots that (a) were chosen through this engine -- Chosen was sent to every
+// replica -- and (b) lie at least `retain` slots behind the highest chosen slot: their rows are recycled
+// (votes dropped, tallies forgotten, the JVM-side value bytes released).  The reference's acceptors and proxy
+// leaders never forget anything (Acceptor.scala:98, ProxyLeader.scala:135); the deviation this buys bounded
+// memory with: a replica that lost a Chosen more than `retain` slots ago can no longer recover it from these
+// acceptors, so `retain` bounds how far a replica may lag.
+class GpuPhase2Engine[Transport <: frankenpaxos.Transport[Transport]](
+    logger: Logger,
+    config: Config[Transport],
+    numSlots: Int = 1 << 20,
+    retainSlots: Int = 1 << 18
+) {
+  config.checkValid()
+  val perGroup: Int = config.acceptorAddresses(0).size
+  val numGroups: Int = config.numAcceptorGroups
+  // rows keep their acceptor group when the log wraps (slot % numGroups == row % numGroups)
+  logger.check(config.flexible || numSlots % numGroups == 0)
+  private val chunk = math.max(1, numSlots / 16)
+  logger.check(retainSlots + 2 * chunk <= numSlots)
+
+  private val cfg: Array[Int] =
+    if (!config.flexible)
+      Array(numSlots, perGroup, numGroups, 1, config.f, /*THRESHOLD*/ 0, 0, 0,
+            config.numLeaders, /*ACCEPTOR*/ 0, 4, 0, 0, 0, 0)
+    else
+      Array(numSlots, numGroups * perGroup, 1, 1, config.f, /*GRID*/ 2,
+            numGroups, perGroup, config.numLeaders, 0, 4, 0, 0, 0, 0)
+  private val handle = Native.create(cfg)
+  if (handle < 0) Native.check((-handle).toInt, logger)
+
+  // where acceptor (groupIndex, index) of the reference's addressing lives in the context
+  def ctxGroup(groupIndex: Int): Int = if (config.flexible) 0 else groupIndex
+  def ctxReplica(groupIndex: Int, index: Int): Int = if (config.flexible) groupIndex * perGroup + index else index
+
+  // ---- value ids: the int32 the GPU carries stands for a CommandBatchOrNoop kept here; Noop is FPX_NOOP = -1.
+  // An id lives as long as the row it was proposed in: votes and tallies of the row are its only holders.
+  private val values = mutable.ArrayBuffer[CommandBatchOrNoop]()
+  private val freeIds = mutable.ArrayStack[Int]()
+  private val idsOfRow = Array.fill(numSlots)(List.empty[Int])
+  private def intern(row: Int, v: CommandBatchOrNoop): Int =
+    if (v.value.isNoop) -1
+    else {
+      val id = if (freeIds.nonEmpty) freeIds.pop() else { values += null; values.size - 1 }
+      values(id) = v
+      idsOfRow(row) = id :: idsOfRow(row)
+      id
+    }
+  def valueOf(id: Int): CommandBatchOrNoop =
+    if (id < 0) CommandBatchOrNoop().withNoop(Noop()) else values(id)
+
+  // ---- the window
+  private var base = 0                                   // first slot of the window (a multiple of chunk)
+  private val chosenInWindow = new java.util.BitSet(numSlots) // by row
+  private var chosenPrefix = 0                           // every slot in [base, chosenPrefix) is chosen
+  private var highestChosen = -1
+  private val deferred = mutable.Queue[Phase2a]()
+  private def row(slot: Int): Int = slot % numSlots
+  private def slotOfRow(r: Int): Int = base + ((r - row(base)) % numSlots + numSlots) % numSlots
+
+  private def markChosen(slot: Int): Unit = {
+    chosenInWindow.set(row(slot))
+    highestChosen = math.max(highestChosen, slot)
+    while (chosenPrefix < base + numSlots && chosenInWindow.get(row(chosenPrefix))) chosenPrefix += 1
+  }
+  // moves the window over chosen slots that are old enough; true if it moved
+  private def advanceWindow(): Boolean = {
+    var moved = false
+    while (chosenPrefix - base >= chunk && highestChosen - (base + chunk) >= retainSlots) {
+      val r0 = row(base)                                 // chunk | numSlots: the chunk does not wrap
+      Native.check(Native.recycleSlots(handle, r0, chunk), logger)
+      for (r <- r0 until r0 + chunk) {
+        idsOfRow(r).foreach(id => { values(id) = null; freeIds.push(id) })
+        idsOfRow(r) = Nil
+        chosenInWindow.clear(r)
+      }
+      base += chunk
+      moved = true
+    }
+    moved
+  }
+
+  // ---- Phase 2: one tick of Phase2a messages (ProxyLeader.handlePhase2a + every Acceptor.handlePhase2a +
+  // ProxyLeader.handlePhase2b).  Returns, in message order, Chosen to broadcast and (round, Nack) to route.
+  case class TickResult(chosen: Seq[Chosen], nacks: Seq[(Int, Nack)])
+  def phase2Tick(incoming: Seq[Phase2a]): TickResult = {
+    val chosenOut = mutable.Buffer[Chosen](); val nackOut = mutable.Buffer[(Int, Nack)]()
+    var batch: Seq[Phase2a] = deferred.dequeueAll(_ => true) ++ incoming
+    while (batch.nonEmpty) {
+      // below the window: chosen long ago and recycled -- nothing left to vote on; beyond it: wait
+      val (now, later) = batch.filter(_.slot >= base).partition(_.slot < base + numSlots)
+      val n = now.size
+      val slot = new Array[Int](n); val round = new Array[Int](n); val value = new Array[Int](n)
+      for ((p, i) <- now.zipWithIndex) {
+        slot(i) = row(p.slot); round(i) = p.round; value(i) = intern(row(p.slot), p.commandBatchOrNoop)
+      }
+      val chosen = new Array[Byte](n); val cr = new Array[Int](n); val cv = new Array[Int](n)
+      val nr = new Array[Int](n)
+      // dense delivery (targetMask = null).  A thrifty deployment passes one random f+1 / grid-column
+      // mask per message here (ProxyLeader.scala:190-196).
+      if (n > 0) Native.check(Native.phase2Fused(handle, n, slot, round, value, null, chosen, cr, cv, nr), logger)
+      for (i <- 0 until n) {
+        if (chosen(i) != 0) {
+          chosenOut += Chosen(slot = now(i).slot, commandBatchOrNoop = valueOf(cv(i))) // ProxyLeader.scala:246-253
+          markChosen(now(i).slot)
+        }
+        // Acceptor.scala:197-198: Nack(round = acceptor's round) to leaders(roundSystem.leader(phase2a.round))
+        if (nr(i) >= 0) nackOut += ((round(i), Nack(round = nr(i))))
+      }
+      // a moved window may admit what waited; otherwise it keeps waiting for the slots before it to be chosen
+      batch = if (advanceWindow()) later else { deferred ++= later; Seq.empty }
+    }
+    TickResult(chosenOut, nackOut)
+  }
+
+  // ---- Phase 1, acceptor side (Acceptor.handlePhase1a, multipaxos/Acceptor.scala:148-182)
+  def handlePhase1a(groupIndex: Int, index: Int, phase1a: Phase1a): Either[Nack, Phase1b] = {
+    val g = ctxGroup(groupIndex); val a = ctxReplica(groupIndex, index)
+    val target = new Array[Long](4); target(a >> 6) = 1L << (a & 63)
+    val bits = new Array[Long](8)
+    // rows, not slots: a watermark inside the window is a row boundary only when the window does not wrap
+    // between it and the window's end -- promise from row 0 on (more than asked for is safe, Acceptor.scala
+    // promises on its single `round` anyway) and filter the info by slot below
+    Native.check(Native.acceptorPhase1a(handle, g, phase1a.round, 0, target, bits), logger)
+    if ((bits(4 + (a >> 6)) & (1L << (a & 63))) != 0) {
+      // :155-162  phase1a.round < round: Nack(round)
+      return Left(Nack(round = Native.acceptorRound(handle, g, a)))
+    }
+    // :163-181  Phase1b(info = votes in slots >= chosenWatermark, ascending)
+    var cap = 1024
+    var slots = new Array[Int](cap); var vr = new Array[Int](cap); var vv = new Array[Int](cap)
+    var k = Native.acceptorPhase1bInfo(handle, g, a, 0, cap, slots, vr, vv)
+    if (k > cap) {
+      cap = k; slots = new Array[Int](cap); vr = new Array[Int](cap); vv = new Array[Int](cap)
+      k = Native.acceptorPhase1bInfo(handle, g, a, 0, cap, slots, vr, vv)
+    }
+    if (k < 0) Native.check(-k, logger)
+    val info = (0 until k)
+      .map(j => Phase1bSlotInfo(slot = slotOfRow(slots(j)), voteRound = vr(j), voteValue = valueOf(vv(j))))
+      .filter(_.slot >= phase1a.chosenWatermark)
+      .sortBy(_.slot)
+    Right(Phase1b(groupIndex = groupIndex, acceptorIndex = index, round = phase1a.round, info = info))
+  }
+
+  // a Phase2a sent straight to one acceptor (not how the reference's Leader sends them, but part of
+  // AcceptorInbound): Acceptor.handlePhase2a, multipaxos/Acceptor.scala:184-220
+  def handlePhase2a(groupIndex: Int, index: Int, p: Phase2a): Either[Nack, Phase2b] = {
+    logger.check(p.slot >= base && p.slot < base + numSlots)
+    val a = ctxReplica(groupIndex, index)
+    val target = new Array[Long](4); target(a >> 6) = 1L << (a & 63)
+    val votes = new Array[Long](4); val nacks = new Array[Long](4); val nr = new Array[Int](1)
+    Native.check(Native.acceptorPhase2a(handle, 1, Array(row(p.slot)), Array(p.round),
+                                        Array(intern(row(p.slot), p.commandBatchOrNoop)), target, votes, nacks, nr),
+                 logger)
+    if (nr(0) >= 0) Left(Nack(round = nr(0)))
+    else Right(Phase2b(groupIndex = groupIndex, acceptorIndex = index, slot = p.slot, round = p.round))
+  }
+
+  def close(): Unit = Native.check(Native.destroy(handle), logger)
+}
+
+// Stands where a ProxyLeader stands (ProxyLeaderMain): Leaders keep sending Phase2a to it exactly as they send
+// to a ProxyLeader (multipaxos/Leader.scala:364-398); replicas keep receiving Chosen from it.
+class GpuProxyLeader[Transport <: frankenpaxos.Transport[Transport]](
     address: Transport#Address,
     transport: Transport,
     logger: Logger,
     config: Config[Transport],
-    numSlots: Int = 1 << 20
+    engine: GpuPhase2Engine[Transport]
 ) extends Actor(address, transport, logger) {
-  config.checkValid()
   override type InboundMessage = ProxyLeaderInbound
   override val serializer = ProxyLeaderInboundSerializer
-
-  private val perGroup = config.acceptorAddresses(0).size
-  private val cfg: Array[Int] =
-    if (!config.flexible)
-      Array(numSlots, perGroup, config.numAcceptorGroups, 1, config.f, /*THRESHOLD*/ 0, 0, 0,
-            config.numLeaders, /*ACCEPTOR*/ 0, 4, 0, 0, 0, 0)
-    else
-      Array(numSlots, config.numAcceptorGroups * perGroup, 1, 1, config.f, /*GRID*/ 2,
-            config.numAcceptorGroups, perGroup, config.numLeaders, 0, 4, 0, 0, 0, 0)
-  private val handle = Native.create(cfg)
-  if (handle < 0) Native.check((-handle).toInt, logger)
 
   private val roundSystem = new RoundSystem.ClassicRoundRobin(config.numLeaders)
   private val leaders = for (a <- config.leaderAddresses) yield chan[Leader[Transport]](a, Leader.serializer)
   private val replicas = for (a <- config.replicaAddresses) yield chan[Replica[Transport]](a, Replica.serializer)
-
-  // value ids: the int32 the GPU carries stands for a CommandBatchOrNoop kept on the JVM side
-  private val values = mutable.Buffer[CommandBatchOrNoop]()
   private val pending = mutable.Buffer[Phase2a]()
 
   // one tick: a zero-delay timer, i.e. "after the messages already queued on the event loop"
@@ -159,35 +330,61 @@ class GpuPhase2[Transport <: frankenpaxos.Transport[Transport]](
         if (pending.isEmpty) tick.start()
         pending += p
       case ProxyLeaderInbound.Request.Phase2B(_) =>
-        logger.fatal("GpuPhase2 tallies on the device; it never receives Phase2b messages.")
+        logger.fatal("GpuProxyLeader tallies on the device; it never receives Phase2b messages.")
       case ProxyLeaderInbound.Request.Empty =>
         logger.fatal("Empty ProxyLeaderInbound encountered.")
     }
   }
 
   private def flushTick(): Unit = {
-    val n = pending.size
-    val slot = new Array[Int](n); val round = new Array[Int](n); val value = new Array[Int](n)
-    for ((p, i) <- pending.zipWithIndex) {
-      slot(i) = p.slot; round(i) = p.round
-      value(i) = values.size; values += p.commandBatchOrNoop
-    }
-    val chosen = new Array[Byte](n); val cr = new Array[Int](n); val cv = new Array[Int](n)
-    val nr = new Array[Int](n)
-    // dense delivery (targetMask = null).  A thrifty deployment passes one random f+1 / grid-column
-    // mask per message here (ProxyLeader.scala:190-196).
-    Native.check(Native.phase2Fused(handle, n, slot, round, value, null, chosen, cr, cv, nr), logger)
-    for (i <- 0 until n) {
-      if (chosen(i) != 0) {
-        // ProxyLeader.scala:246-253
-        val msg = ReplicaInbound().withChosen(Chosen(slot = slot(i), commandBatchOrNoop = values(cv(i))))
-        replicas.foreach(_.send(msg))
-      }
-      if (nr(i) >= 0) {
-        // Acceptor.scala:197-198: Nack(round = acceptor's round) to leaders(roundSystem.leader(phase2a.round))
-        leaders(roundSystem.leader(round(i))).send(LeaderInbound().withNack(Nack(round = nr(i))))
-      }
-    }
+    val result = engine.phase2Tick(pending.toList)
     pending.clear()
+    for (c <- result.chosen) replicas.foreach(_.send(ReplicaInbound().withChosen(c)))
+    for ((round, nack) <- result.nacks)
+      leaders(roundSystem.leader(round)).send(LeaderInbound().withNack(nack))
+  }
+}
+
+// Stands at ONE acceptor address (AcceptorMain); every acceptor address of the deployment gets one, all over the
+// same engine.  The Leader's Phase1a goes to acceptor addresses (multipaxos/Leader.scala:410-420): without an
+// actor here a new leader would never finish Phase 1.
+class GpuAcceptor[Transport <: frankenpaxos.Transport[Transport]](
+    address: Transport#Address,
+    transport: Transport,
+    logger: Logger,
+    config: Config[Transport],
+    engine: GpuPhase2Engine[Transport]
+) extends Actor(address, transport, logger) {
+  override type InboundMessage = AcceptorInbound
+  override val serializer = AcceptorInboundSerializer
+
+  logger.check(config.acceptorAddresses.flatten.contains(address))
+  private val groupIndex = config.acceptorAddresses.indexWhere(_.contains(address))
+  private val index = config.acceptorAddresses(groupIndex).indexOf(address)
+  private val roundSystem = new RoundSystem.ClassicRoundRobin(config.numLeaders)
+
+  override def receive(src: Transport#Address, inbound: AcceptorInbound): Unit = {
+    inbound.request match {
+      case AcceptorInbound.Request.Phase1A(phase1a) =>
+        val leader = chan[Leader[Transport]](src, Leader.serializer)
+        engine.handlePhase1a(groupIndex, index, phase1a) match {
+          case Left(nack)     => leader.send(LeaderInbound().withNack(nack))        // Acceptor.scala:155-162
+          case Right(phase1b) => leader.send(LeaderInbound().withPhase1B(phase1b))  // Acceptor.scala:163-181
+        }
+      case AcceptorInbound.Request.Phase2A(phase2a) =>
+        engine.handlePhase2a(groupIndex, index, phase2a) match {
+          case Left(nack) =>                                                          // Acceptor.scala:192-199
+            val leader = chan[Leader[Transport]](config.leaderAddresses(roundSystem.leader(phase2a.round)),
+                                                 Leader.serializer)
+            leader.send(LeaderInbound().withNack(nack))
+          case Right(phase2b) =>                                                      // Acceptor.scala:211-219
+            chan[ProxyLeader[Transport]](src, ProxyLeader.serializer)
+              .send(ProxyLeaderInbound().withPhase2B(phase2b))
+        }
+      case AcceptorInbound.Request.MaxSlotRequest(_) | AcceptorInbound.Request.BatchMaxSlotRequest(_) =>
+        logger.fatal("GpuAcceptor does not serve the read path (MaxSlotRequest): outside the Phase-2 path.")
+      case AcceptorInbound.Request.Empty =>
+        logger.fatal("Empty AcceptorInbound encountered.")
+    }
   }
 }

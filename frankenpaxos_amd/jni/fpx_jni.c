@@ -559,3 +559,104 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_wireDecodeProxyLeaderInbound
   free(off); free(f); free(vo);
   return st;
 }
+
+/* ---- the acceptors' half of Phase 1, and the log window -------------------------------------------------------- */
+/* Phase1b.info of one acceptor (multipaxos/Acceptor.scala:166-178): returns the number of votes at or above the
+ * watermark (>= 0; the first min(count, cap) are written), or -status */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_acceptorPhase1bInfo(JNIEnv* env, jclass cls, jlong h, jint group,
+                                                                        jint replica, jint chosenWatermark, jint cap,
+                                                                        jintArray slot, jintArray voteRound,
+                                                                        jintArray voteValue) {
+  if (cap < 0 || (cap > 0 && (!has(env, slot, cap) || !has(env, voteRound, cap) || !has(env, voteValue, cap))))
+    return -FPX_EINVAL;
+  jint *s = out_buf(slot, cap, 4), *r = out_buf(voteRound, cap, 4), *v = out_buf(voteValue, cap, 4);
+  int32_t count = 0;
+  int32_t st = (cap > 0 && (!s || !r || !v)) ? FPX_ENOMEM
+                                              : fpx_acceptor_phase1b_info(CTX(h), group, replica, chosenWatermark, cap, &count, s, r, v);
+  const jlong k = count < cap ? count : cap;
+  if (st == FPX_OK) { put_ints(env, slot, k, s); put_ints(env, voteRound, k, r); put_ints(env, voteValue, k, v); }
+  free(s); free(r); free(v);
+  return st == FPX_OK ? count : -st;
+}
+
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_recycleSlots(JNIEnv* env, jclass cls, jlong h, jint firstSlot, jint count) {
+  return fpx_recycle_slots(CTX(h), firstSlot, count);
+}
+
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_proxyForget(JNIEnv* env, jclass cls, jlong h, jint firstSlot, jint count) {
+  return fpx_proxy_forget(CTX(h), firstSlot, count);
+}
+
+/* a tick of AcceptorInbound byte arrays (Phase1a / Phase2a): fields = kind, slot, round, isNoop, valueLen,
+ * chosenWatermark (6 x n ints); valueOff n longs */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_wireDecodeAcceptorInbound(
+    JNIEnv* env, jclass cls, jobject buf, jlongArray offsets, jint n, jintArray fields, jlongArray valueOff,
+    jintArray badIndex) {
+  if (n < 0 || !has(env, offsets, (jlong)n + 1) || !has(env, fields, 6 * (jlong)n) || !opt(env, valueOff, n) ||
+      !opt(env, badIndex, 1))
+    return FPX_EINVAL;
+  if (n == 0) return FPX_OK;
+  jlong* off = in_longs(env, offsets, (jlong)n + 1);
+  int bad = 0;
+  const uint8_t* b = direct(env, buf, 0, &bad);
+  const jlong capacity = b ? (*env)->GetDirectBufferCapacity(env, buf) : -1;
+  if (bad || !b || !off || capacity < 0) {
+    free(off);
+    return FPX_EINVAL;
+  }
+  jint* f = out_buf(fields, 6 * (jlong)n, 4);
+  jlong* vo = (jlong*)calloc((size_t)n, 8);
+  jint bi = -1;
+  int32_t st = (!f || !vo) ? FPX_ENOMEM
+                           : fpx_wire_decode_acceptor_inbound(b, (int64_t)capacity, (const int64_t*)off, n, f, f + n,
+                                                              f + 2 * (size_t)n, f + 3 * (size_t)n, (int64_t*)vo,
+                                                              f + 4 * (size_t)n, f + 5 * (size_t)n, &bi);
+  put_ints(env, fields, 6 * (jlong)n, f); put_longs(env, valueOff, n, vo); put_ints(env, badIndex, 1, &bi);
+  free(off); free(f); free(vo);
+  return st;
+}
+
+/* LeaderInbound{Phase1b} into a direct buffer: the serialised CommandBatchOrNoop of entry j is
+ * values[valueOff[j] .. + valueLen[j]) (a direct buffer too), Noop where isNoop[j] != 0.  Returns the length, or the
+ * negated length needed when `out` is too small, or Long.MinValue on a bad argument */
+JNIEXPORT jlong JNICALL Java_frankenpaxos_gpu_Native_wireEncodeLeaderPhase1b(
+    JNIEnv* env, jclass cls, jobject out, jint groupIndex, jint acceptorIndex, jint round, jint nInfo, jintArray slot,
+    jintArray voteRound, jobject values, jlongArray valueOff, jintArray valueLen, jbyteArray isNoop) {
+  const jlong BAD = INT64_MIN;
+  if (nInfo < 0 || (nInfo > 0 && (!has(env, slot, nInfo) || !has(env, voteRound, nInfo) || !has(env, valueOff, nInfo) ||
+                                  !has(env, valueLen, nInfo))) || !opt(env, isNoop, nInfo))
+    return BAD;
+  int bad = 0;
+  uint8_t* o = direct(env, out, 0, &bad);
+  const uint8_t* vals = direct(env, values, 0, &bad);
+  if (bad || !o) return BAD;
+  const jlong ocap = (*env)->GetDirectBufferCapacity(env, out);
+  const jlong vcap = vals ? (*env)->GetDirectBufferCapacity(env, values) : 0;
+  jint *s = in_ints(env, slot, nInfo), *r = in_ints(env, voteRound, nInfo), *vl = in_ints(env, valueLen, nInfo);
+  jlong* vo = in_longs(env, valueOff, nInfo);
+  jbyte* nz = in_bytes(env, isNoop, nInfo);
+  jlong len = BAD;
+  int ok = nInfo == 0 || (s && r && vl && vo);
+  for (jint j = 0; ok && j < nInfo; ++j)   /* every value must lie inside the values buffer (or be a Noop) */
+    if (!(nz && nz[j]) && (vl[j] < 0 || vo[j] < 0 || vo[j] + vl[j] > vcap)) ok = 0;
+  if (ok)
+    len = fpx_wire_encode_leader_phase1b(o, ocap, groupIndex, acceptorIndex, round, nInfo, s, r, vals, (const int64_t*)vo, vl,
+                                         (const uint8_t*)nz);
+  free(s); free(r); free(vl); free(vo); free(nz);
+  return len;
+}
+
+JNIEXPORT jlong JNICALL Java_frankenpaxos_gpu_Native_wireEncodeLeaderNack(JNIEnv* env, jclass cls, jobject out, jint round) {
+  int bad = 0;
+  uint8_t* o = direct(env, out, 0, &bad);
+  if (bad || !o) return INT64_MIN;
+  return fpx_wire_encode_leader_nack(o, (*env)->GetDirectBufferCapacity(env, out), round);
+}
+
+/* Acceptor.round (multipaxos/Acceptor.scala:95) of one acceptor: >= -1, or -(status + 1) <= -2 on error.  What a
+ * Nack to a stale Phase1a carries (:155-162). */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_acceptorRound(JNIEnv* env, jclass cls, jlong h, jint group, jint replica) {
+  int32_t round = -1;
+  int32_t st = fpx_read_acceptor(CTX(h), group, replica, &round, NULL, NULL, NULL, NULL);
+  return st == FPX_OK ? round : -(st + 1);
+}

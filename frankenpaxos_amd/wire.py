@@ -7,6 +7,7 @@ import numpy as np
 from . import _lib
 
 OTHER, PHASE2A, PHASE2B, PHASE1A, CHOSEN, NACK, PHASE2A_NOOP_RANGE, PHASE2B_NOOP_RANGE, CHOSEN_NOOP_RANGE = range(9)
+PHASE1B = 9
 EPX_PRE_ACCEPT, EPX_PRE_ACCEPT_OK, EPX_ACCEPT, EPX_ACCEPT_OK, EPX_COMMIT, EPX_PREPARE, EPX_PREPARE_OK, EPX_NACK = range(16, 24)
 
 
@@ -56,6 +57,9 @@ def _L():
         L.fpx_wire_encode_proxy_leader_phase2b.argtypes = [VP, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
         L.fpx_wire_encode_replica_chosen.argtypes = [VP, C.c_int64, C.c_int32, VP, C.c_int32, C.c_int32]
         L.fpx_wire_encode_leader_nack.argtypes = [VP, C.c_int64, C.c_int32]
+        L.fpx_wire_encode_leader_phase1b.argtypes = [VP, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [VP] * 6
+        L.fpx_wire_encode_leader_phase1b.restype = C.c_int64
+        L.fpx_wire_decode_leader_inbound.argtypes = [VP, C.c_int64, VP, C.c_int32] + [VP] * 6 + [C.c_int32, I32P] + [VP] * 5 + [I32P]
         L.fpx_wire_encode_phase2b_batch.argtypes = [C.c_int32, VP, VP, VP, VP, C.c_int32, VP, C.c_int64, VP, C.c_int64]
         for name in ("fpx_wire_encode_proxy_leader_phase2a", "fpx_wire_encode_acceptor_phase2a",
                      "fpx_wire_encode_acceptor_phase1a", "fpx_wire_encode_proxy_leader_phase2b",
@@ -163,6 +167,40 @@ def encode_replica_chosen(slot, value):
 
 def encode_leader_nack(round_):
     return _enc(_L().fpx_wire_encode_leader_nack, round_)
+
+
+def encode_leader_phase1b(group_index, acceptor_index, round_, info):
+    """info: [(slot, vote_round, value)] with value = the serialised CommandBatchOrNoop or None for Noop
+    -> LeaderInbound{Phase1b} (what Acceptor.handlePhase1a sends, multipaxos/Acceptor.scala:163-181)"""
+    n = len(info)
+    slot = np.array([x[0] for x in info], np.int32)
+    vr = np.array([x[1] for x in info], np.int32)
+    blobs = [b"" if x[2] is None else bytes(x[2]) for x in info]
+    if any(x[2] is not None and len(x[2]) == 0 for x in info):
+        raise ValueError("an empty CommandBatchOrNoop (no oneof member) cannot be sent; pass None for Noop")
+    noop = np.array([1 if x[2] is None else 0 for x in info], np.uint8)
+    vbuf, voff = pack(blobs)
+    vlen = np.diff(voff).astype(np.int32)
+    return _enc(_L().fpx_wire_encode_leader_phase1b, group_index, acceptor_index, round_, n, slot.ctypes.data,
+                vr.ctypes.data, vbuf.ctypes.data, voff.ctypes.data, vlen.ctypes.data, noop.ctypes.data)
+
+
+def decode_leader_inbound(messages, info_cap=1 << 16):
+    """-> kind (PHASE1B / NACK / OTHER), round, group_index, acceptor_index, info_first, info_count per message and the
+    Phase1bSlotInfo entries (info_slot, info_vote_round, info_is_noop, info_value_off, info_value_len)"""
+    buf, off = pack(messages)
+    n = len(messages)
+    per = {k: np.zeros(n, np.int32) for k in ("kind", "round", "group_index", "acceptor_index", "info_first", "info_count")}
+    inf = {k: (np.zeros(info_cap, np.int64) if k == "info_value_off" else np.zeros(info_cap, np.int32))
+           for k in ("info_slot", "info_vote_round", "info_is_noop", "info_value_off", "info_value_len")}
+    bad, total = C.c_int32(-1), C.c_int32(0)
+    st = _L().fpx_wire_decode_leader_inbound(buf.ctypes.data, sum(len(m) for m in messages), off.ctypes.data, n,
+                                             *[per[k].ctypes.data for k in per], info_cap, C.byref(total),
+                                             *[inf[k].ctypes.data for k in inf], C.byref(bad))
+    out = dict(per)
+    out.update({k: v[:total.value] for k, v in inf.items()})
+    out["status"], out["bad_index"], out["buf"] = st, bad.value, buf
+    return out
 
 
 def encode_phase2b_batch(slot, round_, vote_bits, group_of_slot=None, grid_cols=0):

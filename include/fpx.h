@@ -267,6 +267,17 @@ int32_t fpx_proxy_phase2b_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, co
  * Asynchronous on the context's stream.  After it, a Phase2b for a forgotten (slot, round) is "unknown". */
 int32_t fpx_proxy_forget(fpx_ctx* ctx, int32_t first_slot, int32_t count);
 
+/* Recycling of log-window rows (NOT in the reference, whose Acceptor.states and ProxyLeader.states grow forever,
+ * multipaxos/Acceptor.scala:98, ProxyLeader.scala:135): the rows [first_slot, first_slot + count) of the window
+ * become fresh -- every acceptor's vote in them is dropped (voteRound = voteValue = -1, as if `states` had no
+ * entry) and their tallies are forgotten (fpx_proxy_forget).  What an acceptor PROMISED stays: its scalar round
+ * (FPX_BALLOT_ACCEPTOR) is untouched, and in FPX_BALLOT_PER_SLOT mode the cells keep their ballots, so a recycled
+ * row never accepts a round the old row would have refused.  maxVotedSlot is left as it is (an upper bound).  A
+ * host that maps an unbounded log onto the window as row = slot % num_slots calls this for the rows whose slots are
+ * chosen and no longer needed before it lets the log wrap onto them (frankenpaxos_amd/jni/Native.scala, GpuPhase2).
+ * Asynchronous on the context's stream. */
+int32_t fpx_recycle_slots(fpx_ctx* ctx, int32_t first_slot, int32_t count);
+
 /* ---- K3: fused step = fpx_proxy_open + fpx_acceptor_phase2a + fpx_proxy_phase2b ------------------
  * For each message in order: open (slot, round) (duplicates are ignored and NOT forwarded to the
  * acceptors, :177-184), deliver the Phase2a to the targeted acceptors (target_mask NULL = all: the
@@ -505,6 +516,16 @@ int32_t fpx_replica_read_log(fpx_ctx* ctx, int32_t first, int32_t count, int32_t
 int32_t fpx_leader_phase1b_scan(fpx_ctx* ctx, int32_t chosen_watermark, const uint64_t* quorum_masks,
                                 int32_t cap, int32_t* max_slot, int32_t* safe_round,
                                 int32_t* safe_value);
+
+/* Acceptor.handlePhase1a's reply (multipaxos/Acceptor.scala:163-181; mencius/Acceptor.scala:181-199): the
+ * Phase1b.info of acceptor `replica` of `group` -- one Phase1bSlotInfo(slot, voteRound, voteValue) per slot >=
+ * chosen_watermark in which the acceptor has voted, in ascending slot order (states.iteratorFrom).  *count = how
+ * many there are; the first min(*count, cap) are written (call with cap = 0 to size the arrays).  Together with
+ * fpx_acceptor_phase1a (the round movement) this is everything an acceptor-side actor needs to answer a Leader's
+ * Phase1a with the Phase1b the unchanged Leader.handlePhase1b expects (multipaxos/Leader.scala:504-577). */
+int32_t fpx_acceptor_phase1b_info(fpx_ctx* ctx, int32_t group, int32_t replica, int32_t chosen_watermark,
+                                  int32_t cap, int32_t* count, int32_t* slot, int32_t* vote_round,
+                                  int32_t* vote_value);
 
 /* ---- state readback (parity) ------------------------------------------------------------------- */
 /* acceptor `replica` of `group`: its round (FPX_BALLOT_ACCEPTOR; -1 in PER_SLOT mode),

@@ -44,6 +44,7 @@ enum {
   FPX_WIRE_PHASE1A = 3,
   FPX_WIRE_CHOSEN = 4,
   FPX_WIRE_NACK = 5,
+  FPX_WIRE_PHASE1B = 9,
   /* mencius/Mencius.proto */
   FPX_WIRE_PHASE2A_NOOP_RANGE = 6,
   FPX_WIRE_PHASE2B_NOOP_RANGE = 7,
@@ -104,6 +105,27 @@ int64_t fpx_wire_encode_proxy_leader_phase2b(uint8_t* out, int64_t cap, int32_t 
 int64_t fpx_wire_encode_replica_chosen(uint8_t* out, int64_t cap, int32_t slot, const uint8_t* value,
                                        int32_t value_len, int32_t is_noop);
 int64_t fpx_wire_encode_leader_nack(uint8_t* out, int64_t cap, int32_t round);
+
+/* The acceptor's answer to a Phase1a (multipaxos/Acceptor.scala:163-181), as the Leader parses it:
+ *   LeaderInbound { oneof request { Phase1b phase1b = 1; ...; Nack nack = 6; ... } }          MultiPaxos.proto:525-539
+ *   Phase1b { required int32 group_index = 1; required int32 acceptor_index = 2; required int32 round = 3;
+ *             repeated Phase1bSlotInfo info = 4; }                                            MultiPaxos.proto:263-271
+ *   Phase1bSlotInfo { required int32 slot = 1; required int32 vote_round = 2;
+ *                     required CommandBatchOrNoop vote_value = 3; }                           MultiPaxos.proto:254-261
+ * Entry j's CommandBatchOrNoop body is values[value_off[j] .. + value_len[j]) (the JVM-side bytes kept under the
+ * value id fpx_acceptor_phase1b_info returned), or Noop where is_noop[j] != 0 (is_noop may be NULL: none is). */
+int64_t fpx_wire_encode_leader_phase1b(uint8_t* out, int64_t cap, int32_t group_index, int32_t acceptor_index,
+                                       int32_t round, int32_t n_info, const int32_t* slot, const int32_t* vote_round,
+                                       const uint8_t* values, const int64_t* value_off, const int32_t* value_len,
+                                       const uint8_t* is_noop);
+/* Decodes n LeaderInbound messages: kind PHASE1B (round, group_index, acceptor_index, info) / NACK (round) / OTHER.
+ * The Phase1bSlotInfo entries of all messages go, in order, into the info_* arrays (capacity info_cap entries;
+ * FPX_EINVAL if there are more): message i owns entries info_first[i] .. info_first[i] + info_count[i]. */
+int32_t fpx_wire_decode_leader_inbound(const uint8_t* buf, int64_t buf_len, const int64_t* offsets, int32_t n,
+                                       int32_t* kind, int32_t* round, int32_t* group_index, int32_t* acceptor_index,
+                                       int32_t* info_first, int32_t* info_count, int32_t info_cap, int32_t* info_total,
+                                       int32_t* info_slot, int32_t* info_vote_round, int32_t* info_is_noop,
+                                       int64_t* info_value_off, int32_t* info_value_len, int32_t* bad_index);
 
 /* The replies of one K1 batch as wire bytes: for message i every acceptor in vote_bits[i] answers
  * ProxyLeaderInbound{Phase2b(group_index, acceptor_index, slot[i], round[i])} (Acceptor.scala:211-219).  The bit

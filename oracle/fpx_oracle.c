@@ -678,6 +678,17 @@ int fpo_proxy_forget(fpo_sys* s, int32_t first_slot, int32_t count) {
   return FPO_OK;
 }
 
+/* GC extension of fpx.h (fpx_recycle_slots; not in the reference): the acceptors' `states` lose their entries of
+ * the slots [first_slot, first_slot + count) (Acceptor.scala:98 -- as if `states -= slot`), the proxy leader its
+ * tallies; rounds / ballots stay */
+int fpo_recycle_slots(fpo_sys* s, int32_t first_slot, int32_t count) {
+  if (first_slot < 0 || count < 0 || (int64_t)first_slot + count > s->cfg.num_slots) return FPO_EINVAL;
+  const int R = s->cfg.num_replicas;
+  for (int sl = first_slot; sl < first_slot + count; ++sl)
+    for (int r = 0; r < R; ++r) s->vote_round[(size_t)sl * R + r] = -1, s->vote_value[(size_t)sl * R + r] = -1;
+  return fpo_proxy_forget(s, first_slot, count);
+}
+
 int fpo_proxy_handle_phase2a(fpo_sys* s, int slot, int round, int value) {
   /* ProxyLeader.scala:176-184  states.get(slotround) match { case Some(_) => ignore */
   if (tab_find(s, tkey(slot, round))) return 0;
@@ -1251,6 +1262,26 @@ int fpo_read_acceptor(fpo_sys* s, int32_t group, int32_t replica, int32_t* promi
     if (vote_value) vote_value[sl] = mine ? s->vote_value[cell] : -1;
     if (ballot) ballot[sl] = (mine && s->ballot) ? s->ballot[cell] : -1;
   }
+  return FPO_OK;
+}
+
+/* multipaxos/Acceptor.scala:166-178
+ *   info = states.iteratorFrom(phase1a.chosenWatermark).map({ case (slot, state) =>
+ *            Phase1bSlotInfo(slot = slot, voteRound = state.voteRound, voteValue = state.voteValue) }).toSeq
+ * `states` is a SortedMap keyed by slot that holds exactly the slots the acceptor has voted in. */
+int fpo_acceptor_phase1b_info(fpo_sys* s, int32_t group, int32_t replica, int32_t chosen_watermark, int32_t cap,
+                              int32_t* count, int32_t* slot, int32_t* vote_round, int32_t* vote_value) {
+  const int R = s->cfg.num_replicas, S = s->cfg.num_slots;
+  if (!count || cap < 0 || group < 0 || group >= s->ngroups || replica < 0 || replica >= R) return FPO_EINVAL;
+  int k = 0;
+  for (int sl = chosen_watermark < 0 ? 0 : chosen_watermark; sl < S; ++sl) {
+    if (fpo_group_of_slot(&s->cfg, sl) != group) continue;
+    const size_t cell = (size_t)sl * R + replica;
+    if (s->vote_round[cell] < 0) continue; /* not in `states` */
+    if (k < cap) slot[k] = sl, vote_round[k] = s->vote_round[cell], vote_value[k] = s->vote_value[cell];
+    ++k;
+  }
+  *count = k;
   return FPO_OK;
 }
 

@@ -148,6 +148,7 @@ int fpo_noop_ranges_fused(fpo_sys* sys, int32_t n, const int32_t* start, const i
                           const uint64_t* target_masks, uint64_t* vote_bits, uint64_t* nack_bits, int32_t* nack_round,
                           uint8_t* is_new, uint8_t* chosen);
 int fpo_read_range_tally(fpo_sys* sys, int32_t start, int32_t end, int32_t round, int32_t* state, uint64_t* vote_bits);
+int fpo_recycle_slots(fpo_sys* sys, int32_t first_slot, int32_t count);
 int fpo_proxy_forget(fpo_sys* sys, int32_t first_slot, int32_t count);
 
 /* f1: Replica.handleChosen per message (multipaxos/Replica.scala:572-590) on the system's replica log */
@@ -161,6 +162,9 @@ int fpo_replica_read_log(fpo_sys* sys, int32_t first, int32_t count, int32_t* va
 int fpo_leader_phase1b_scan(fpo_sys* sys, int32_t chosen_watermark, const uint64_t* quorum_masks,
                             int32_t cap, int32_t* max_slot, int32_t* safe_round, int32_t* safe_value);
 
+/* Phase1b.info of one acceptor: multipaxos/Acceptor.scala:166-178 */
+int fpo_acceptor_phase1b_info(fpo_sys* sys, int32_t group, int32_t replica, int32_t chosen_watermark, int32_t cap,
+                              int32_t* count, int32_t* slot, int32_t* vote_round, int32_t* vote_value);
 int fpo_error_detail(fpo_sys* sys, int32_t* index, int32_t* slot, int32_t* round);
 int fpo_read_acceptor(fpo_sys* sys, int32_t group, int32_t replica, int32_t* promised,
                       int32_t* max_voted_slot, int32_t* vote_round, int32_t* vote_value,

@@ -122,11 +122,13 @@ def lib():
     L.fpo_proxy_phase2b_noop_ranges.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, U64P, U8P]
     L.fpo_noop_ranges_fused.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, U64P, U64P, U64P, I32P, U8P, U8P]
     L.fpo_read_range_tally.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, I32P, U64P]
+    L.fpo_recycle_slots.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     L.fpo_proxy_forget.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     L.fpo_replica_chosen.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, U8P, I32P, I32P]
     L.fpo_replica_chosen_noop_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32, I32P, I32P]
     L.fpo_replica_read_log.argtypes = [C.c_void_p, C.c_int32, C.c_int32, I32P, U8P]
     L.fpo_leader_phase1b_scan.argtypes = [C.c_void_p, C.c_int32, U64P, C.c_int32, I32P, I32P, I32P]
+    L.fpo_acceptor_phase1b_info.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, I32P, I32P, I32P, I32P]
     L.fpo_error_detail.argtypes = [C.c_void_p, I32P, I32P, I32P]
     L.fpo_read_acceptor.argtypes = [C.c_void_p, C.c_int32, C.c_int32, I32P, I32P, I32P, I32P, I32P]
     L.fpo_read_state.argtypes = [C.c_void_p, I32P, I32P, I32P]
@@ -438,6 +440,11 @@ class System:
         if st:
             raise ValueError("FPX_EINVAL")
 
+    def recycle_slots(self, first_slot, count):
+        st = lib().fpo_recycle_slots(self._h, first_slot, count)
+        if st:
+            raise ValueError("FPX_EINVAL")
+
     def replica_chosen(self, slot, value, mask=None):
         slot, value = _i32(slot), _i32(value)
         mask = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
@@ -466,6 +473,16 @@ class System:
                                            _p(sr, I32P), _p(sv, I32P))
         k = max(0, min(cap, mx.value - watermark + 1))
         return st, mx.value, sr[:k], sv[:k]
+
+    def acceptor_phase1b_info(self, group, replica, watermark=0):
+        k = C.c_int32()
+        cap = self.S
+        sl, vr, vv = (np.zeros(cap, np.int32) for _ in range(3))
+        st = lib().fpo_acceptor_phase1b_info(self._h, group, replica, watermark, cap, C.byref(k), _p(sl, I32P),
+                                             _p(vr, I32P), _p(vv, I32P))
+        if st:
+            raise ValueError("FPX_EINVAL")
+        return sl[:k.value], vr[:k.value], vv[:k.value]
 
     def error_detail(self):
         i, s, r = C.c_int32(), C.c_int32(), C.c_int32()

@@ -2,8 +2,8 @@
 reference C++/Python implementation of the wire format -- ScalaPB's toByteArray emits the same canonical bytes)
 produces for the Phase-2 messages of the reference, from descriptors transcribed field by field from
 /root/reference/shared/src/main/scala/frankenpaxos/multipaxos/MultiPaxos.proto (Noop :183-186, CommandId
-:188-196, Command :198-204, CommandBatch :206-211, CommandBatchOrNoop :213-221, Phase1a :238-253, Phase2a
-:273-281, Phase2b :283-291, Chosen :293-299, Nack :455-460, LeaderInbound.nack = 6 :535, ProxyLeaderInbound
+:188-196, Command :198-204, CommandBatch :206-211, CommandBatchOrNoop :213-221, Phase1a :238-253, Phase1bSlotInfo :254-261, Phase1b :263-271, Phase2a
+:273-281, Phase2b :283-291, Chosen :293-299, Nack :455-460, LeaderInbound.phase1b = 1 :530, LeaderInbound.nack = 6 :535, ProxyLeaderInbound
 :541-549, AcceptorInbound :551-561, ReplicaInbound :563-575).
 
 Round 3: the same for mencius/Mencius.proto (Phase1a :104-117, Phase2a :151-158, Phase2aNoopRange :160-167, Phase2b
@@ -50,6 +50,10 @@ def build():
     msg("CommandBatchOrNoop", ("command_batch", 1, MSG, OPT, "CommandBatch", "value"),
         ("noop", 2, MSG, OPT, "Noop", "value"))
     msg("Phase1a", ("round", 1, I32, REQ, None, None), ("chosen_watermark", 2, I32, REQ, None, None))
+    msg("Phase1bSlotInfo", ("slot", 1, I32, REQ, None, None), ("vote_round", 2, I32, REQ, None, None),
+        ("vote_value", 3, MSG, REQ, "CommandBatchOrNoop", None))
+    msg("Phase1b", ("group_index", 1, I32, REQ, None, None), ("acceptor_index", 2, I32, REQ, None, None),
+        ("round", 3, I32, REQ, None, None), ("info", 4, MSG, REP, "Phase1bSlotInfo", None))
     msg("Phase2a", ("slot", 1, I32, REQ, None, None), ("round", 2, I32, REQ, None, None),
         ("command_batch_or_noop", 3, MSG, REQ, "CommandBatchOrNoop", None))
     msg("Phase2b", ("group_index", 1, I32, REQ, None, None), ("acceptor_index", 2, I32, REQ, None, None),
@@ -59,11 +63,11 @@ def build():
     msg("ProxyLeaderInbound", ("phase2a", 1, MSG, OPT, "Phase2a", "request"), ("phase2b", 2, MSG, OPT, "Phase2b", "request"))
     msg("AcceptorInbound", ("phase1a", 1, MSG, OPT, "Phase1a", "request"), ("phase2a", 2, MSG, OPT, "Phase2a", "request"))
     msg("ReplicaInbound", ("chosen", 1, MSG, OPT, "Chosen", "request"))
-    msg("LeaderInbound", ("nack", 6, MSG, OPT, "Nack", "request"))
+    msg("LeaderInbound", ("phase1b", 1, MSG, OPT, "Phase1b", "request"), ("nack", 6, MSG, OPT, "Nack", "request"))
     pool = descriptor_pool.DescriptorPool()
     pool.Add(fd)
     get = lambda n: message_factory.GetMessageClass(pool.FindMessageTypeByName("frankenpaxos.multipaxos." + n))
-    return {n: get(n) for n in ("Noop", "CommandId", "Command", "CommandBatch", "CommandBatchOrNoop", "Phase1a", "Phase2a",
+    return {n: get(n) for n in ("Noop", "CommandId", "Command", "CommandBatch", "CommandBatchOrNoop", "Phase1a", "Phase1bSlotInfo", "Phase1b", "Phase2a",
                                 "Phase2b", "Chosen", "Nack", "ProxyLeaderInbound", "AcceptorInbound", "ReplicaInbound",
                                 "LeaderInbound")}
 
@@ -326,6 +330,19 @@ def main():
         l.nack.round = x
         vectors.append({"msg": "phase1a_nack", "round": x, "chosen_watermark": a.phase1a.chosen_watermark,
                         "acceptor_inbound": a.SerializeToString().hex(), "leader_inbound_nack": l.SerializeToString().hex()})
+    # Phase1b (MultiPaxos.proto:254-271, LeaderInbound.phase1b = 1 :530): what Acceptor.handlePhase1a answers
+    for g, a_, rnd, info in [(0, 0, 0, []), (0, 2, 1, [(0, 0, "one")]), (3, 1, 300, [(5, 1, "noop"), (7, 0, "batch"), (1 << 20, 299, "one")]),
+                             (15, 255, 2147483647, [(s_, s_ % 3, ("noop", "one", "empty_batch")[s_ % 3]) for s_ in range(40)])]:
+        l = M["LeaderInbound"]()
+        l.phase1b.group_index, l.phase1b.acceptor_index, l.phase1b.round = g, a_, rnd
+        l.phase1b.SetInParent()
+        for slot, vr, vname in info:
+            e = l.phase1b.info.add()
+            e.slot, e.vote_round = slot, vr
+            e.vote_value.CopyFrom(value(M, vals[vname]))
+        vectors.append({"msg": "phase1b", "group_index": g, "acceptor_index": a_, "round": rnd,
+                        "info": [[slot, vr, vname, value(M, vals[vname]).SerializeToString().hex()] for slot, vr, vname in info],
+                        "leader_inbound": l.SerializeToString().hex()})
     vectors += mencius_vectors() + epaxos_vectors()
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "wire_vectors.json")
     json.dump({"generator": "google.protobuf " + __import__("google.protobuf").protobuf.__version__,

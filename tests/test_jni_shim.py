@@ -277,3 +277,155 @@ def test_epaxos_command_log_through_the_shim(jvm, oracle):
         deps, end = ref.read_cmdlog_deps(r, 1, 3)
         assert got[5:5 + n].tolist() == deps.tolist() and got[5 + n] == end
     assert jvm.call("epxDestroy", C.c_int32, h) == 0
+
+
+@pytest.mark.gpu
+def test_a_leader_change_on_wire_bytes_through_the_shim(jvm, oracle):
+    """The sequence the unchanged Leader drives (multipaxos/Leader.scala:231, 410-420, 504-577, 672-697), on wire
+    bytes, through the natives GpuAcceptor / GpuProxyLeader call (frankenpaxos_amd/jni/Native.scala):
+      1. leader 0: Phase1a(round 0) to every acceptor address -> Phase1b with no votes
+      2. a tick of Phase2a (round 0, slots 0..199; slots >= 100 reach acceptors 0 and 1 only) -> Chosen
+      3. leader 1 takes over: Phase1a(round 1, chosenWatermark 50) reaches acceptors 0 and 1 -> Phase1b with their votes
+      4. leader 0, unaware, sends a tick in round 0 (slots 200..209): acceptors 0 and 1 Nack with round 1, acceptor 2
+         still votes -- nothing is chosen, Nack(1) goes to leaders(roundSystem.leader(0))
+      5. leader 0 reacts (Leader.handleNack): Phase1a(nextClassicRound = 2) to all three; the Phase1b of acceptor 2
+         carries its round-0 votes of step 4, the safe values (Leader.scala:306-329) make leader 0 re-propose them
+      6. the re-proposals in round 2 are chosen
+    Every integer that comes out equals the oracle fed the same calls; every byte string equals the python codec
+    (pinned on google.protobuf, tests/test_wire.py)."""
+    from frankenpaxos_amd import wire
+
+    S, R = 4096, 3
+    cfg = np.array([S, R, 1, 1, 1, 0, 0, 0, 2, 0, 8, 0, 0, 0, 0], np.int32)   # f = 1, 2 leaders, acceptor-scalar rounds
+    h = jvm.call("create", C.c_int64, jvm.arr(cfg))
+    assert h > 0
+    ref = oracle.System(oracle.make_config(num_slots=S, num_replicas=R, f=1, tally_ways=8, num_leaders=2))
+    i32 = lambda a: jvm.arr(np.asarray(a, np.int32))
+    payload = {}                                     # value id -> the CommandBatchOrNoop bytes the JVM keeps
+
+    def direct(b):
+        d = C.c_void_p(jvm.lib.mock_new_direct(max(1, len(b))))
+        if len(b):
+            C.memmove(jvm.lib.mock_data(d), bytes(b), len(b))
+        return d
+
+    def dbytes(d, n):
+        return bytes(np.ctypeslib.as_array(C.cast(jvm.lib.mock_data(d), C.POINTER(C.c_uint8)), (n,)))
+
+    def phase1a_at(acceptor, msg):
+        """AcceptorInbound bytes at one acceptor address -> the LeaderInbound bytes it answers with"""
+        buf, off = wire.pack([msg])
+        fields, bad = jvm.arr(np.zeros(6, np.int32)), jvm.arr(np.zeros(1, np.int32))
+        assert jvm.call("wireDecodeAcceptorInbound", C.c_int32, direct(buf), jvm.arr(off), 1, fields, None, bad) == 0
+        kind, _, rnd, _, _, wm = jvm.read(fields, np.int32, 6).tolist()
+        assert kind == wire.PHASE1A
+        bits = jvm.arr(np.zeros(8, np.int64))
+        tgt = oracle.bits_of([acceptor])
+        assert jvm.call("acceptorPhase1a", C.c_int32, h, 0, rnd, wm, jvm.arr(tgt.view(np.int64)), bits) == 0
+        st, pb, nb = ref.acceptor_phase1a(0, rnd, wm, tgt)
+        got = jvm.read(bits, np.int64, 8).view(np.uint64)
+        assert st == 0 and got[:4].tolist() == pb.tolist() and got[4:].tolist() == nb.tolist()
+        out = direct(b"\0" * 65536)
+        if nb.any():                                  # Acceptor.scala:155-162
+            cur = jvm.call("acceptorRound", C.c_int32, h, 0, acceptor)
+            assert cur == ref.read_acceptor(0, acceptor)[0]
+            n = jvm.call("wireEncodeLeaderNack", C.c_int64, out, cur)
+            assert dbytes(out, n) == wire.encode_leader_nack(cur)
+            return dbytes(out, n)
+        cap = 1024                                    # Acceptor.scala:163-181
+        sl, vr, vv = (jvm.arr(np.zeros(cap, np.int32)) for _ in range(3))
+        k = jvm.call("acceptorPhase1bInfo", C.c_int32, h, 0, acceptor, wm, cap, sl, vr, vv)
+        want = ref.acceptor_phase1b_info(0, acceptor, wm)
+        assert k == len(want[0])
+        sl, vr, vv = (jvm.read(x, np.int32, k) for x in (sl, vr, vv))
+        for a, b in zip((sl, vr, vv), want):
+            np.testing.assert_array_equal(a, b)
+        blobs = [payload[int(v)] for v in vv]
+        vbuf, voff = wire.pack(blobs)
+        n = jvm.call("wireEncodeLeaderPhase1b", C.c_int64, out, 0, acceptor, rnd, k, i32(sl), i32(vr), direct(vbuf),
+                     jvm.arr(voff[:-1] if k else np.zeros(1, np.int64)), i32(np.diff(voff) if k else [0]), None)
+        assert n > 0
+        assert dbytes(out, n) == wire.encode_leader_phase1b(0, acceptor, rnd, [(int(s), int(r), p) for s, r, p in zip(sl, vr, blobs)])
+        return dbytes(out, n)
+
+    def tick(msgs, target_bits):
+        """ProxyLeaderInbound{Phase2a} bytes -> (chosen ReplicaInbound bytes, Nack LeaderInbound bytes with their leader)"""
+        buf, off = wire.pack(msgs)
+        n = len(msgs)
+        fields, voff, bad = jvm.arr(np.zeros(7 * n, np.int32)), jvm.arr(np.zeros(n, np.int64)), jvm.arr(np.zeros(1, np.int32))
+        assert jvm.call("wireDecodeProxyLeaderInbound", C.c_int32, direct(buf), jvm.arr(off), n, fields, voff, bad) == 0
+        f = jvm.read(fields, np.int32, 7 * n).reshape(7, n)
+        vo = jvm.read(voff, np.int64, n)
+        assert (f[0] == wire.PHASE2A).all()
+        slot, rnd = f[1].copy(), f[2].copy()
+        val = np.zeros(n, np.int32)
+        for i in range(n):                            # intern: value id = next free index (GpuPhase2Engine.intern)
+            val[i] = len(payload)
+            payload[int(val[i])] = bytes(buf[vo[i]:vo[i] + f[4][i]])
+        tgt = np.tile(target_bits, (n, 1))
+        ch, cr, cv, nr = (jvm.arr(np.zeros(n, t)) for t in (np.int8, np.int32, np.int32, np.int32))
+        assert jvm.call("phase2Fused", C.c_int32, h, n, i32(slot), i32(rnd), i32(val), jvm.arr(tgt.view(np.int64)), ch, cr, cv, nr) == 0
+        st, ch_r, cr_r, cv_r, nr_r = ref.phase2_fused(slot, rnd, val, tgt)
+        ch, cv, nr = jvm.read(ch, np.int8, n), jvm.read(cv, np.int32, n), jvm.read(nr, np.int32, n)
+        assert st == 0
+        np.testing.assert_array_equal(ch, ch_r.astype(np.int8))
+        np.testing.assert_array_equal(cv, cv_r)
+        np.testing.assert_array_equal(nr, nr_r)
+        chosen = [wire.encode_replica_chosen(int(slot[i]), payload[int(cv[i])]) for i in range(n) if ch[i]]
+        nacks = [(jvm.call("roundLeader", C.c_int32, 2, int(rnd[i])), wire.encode_leader_nack(int(nr[i]))) for i in range(n) if nr[i] >= 0]
+        return chosen, nacks
+
+    cmd = lambda s, tag: bytes.fromhex("0a") + bytes([len(b"%s %d" % (tag, s)) + 0]) + b"%s %d" % (tag, s)  # opaque CommandBatch bytes
+    everyone, zero_one = oracle.bits_of([0, 1, 2]), oracle.bits_of([0, 1])
+    # 1
+    for a in range(R):
+        reply = phase1a_at(a, wire.encode_acceptor_phase1a(0, 0))
+        assert reply.hex() == "0a06" + "0800" + "10%02x" % a + "1800"          # Phase1b(group 0, acceptor a, round 0, no info)
+    # 2
+    chosen, nacks = tick([wire.encode_proxy_leader_phase2a(s, 0, cmd(s, b"set")) for s in range(100)], everyone)
+    assert len(chosen) == 100 and not nacks
+    chosen, nacks = tick([wire.encode_proxy_leader_phase2a(s, 0, cmd(s, b"set")) for s in range(100, 200)], zero_one)
+    assert len(chosen) == 100 and not nacks
+    d = wire.decode_replica_inbound(chosen)
+    assert d["slot"].tolist() == list(range(100, 200))
+    assert bytes(d["buf"][d["value_off"][7]:d["value_off"][7] + d["value_len"][7]]) == cmd(107, b"set")
+    # 3
+    for a in (0, 1):
+        d = wire.decode_leader_inbound([phase1a_at(a, wire.encode_acceptor_phase1a(1, 50))])
+        assert d["kind"].tolist() == [wire.PHASE1B] and d["round"].tolist() == [1] and d["acceptor_index"].tolist() == [a]
+        assert d["info_slot"].tolist() == list(range(50, 200)) and set(d["info_vote_round"].tolist()) == {0}
+        assert bytes(d["buf"][d["info_value_off"][0]:d["info_value_off"][0] + d["info_value_len"][0]]) == cmd(50, b"set")
+    # 4
+    chosen, nacks = tick([wire.encode_proxy_leader_phase2a(s, 0, cmd(s, b"stale")) for s in range(200, 210)], everyone)
+    assert not chosen and nacks == [(0, bytes.fromhex("32020801"))] * 10      # Nack(round 1) to leader 0
+    # 5
+    nxt = jvm.call("roundLeader", C.c_int32, 2, 2)
+    assert nxt == 0                                                            # round 2 is leader 0's (ClassicRoundRobin)
+    infos = [wire.decode_leader_inbound([phase1a_at(a, wire.encode_acceptor_phase1a(2, 50))]) for a in range(R)]
+    assert infos[0]["info_slot"].tolist() == list(range(50, 200)) and infos[2]["info_slot"].tolist() == list(range(50, 100)) + list(range(200, 210))
+    mx, sr, sv = (jvm.arr(np.zeros(k, np.int32)) for k in (1, 256, 256))
+    assert jvm.call("leaderPhase1bScan", C.c_int32, h, 50, 1, jvm.arr(everyone.view(np.int64)), 256, mx, sr, sv) == 0
+    st, mx_r, sr_r, sv_r = ref.leader_phase1b_scan(50, everyone, 256)
+    assert st == 0 and int(jvm.read(mx, np.int32, 1)[0]) == mx_r == 209
+    k = mx_r - 50 + 1
+    safe_round, safe_value = jvm.read(sr, np.int32, k), jvm.read(sv, np.int32, k)
+    np.testing.assert_array_equal(safe_round, sr_r)
+    np.testing.assert_array_equal(safe_value, sv_r)
+    assert (safe_round == 0).all() and payload[int(safe_value[-1])] == cmd(209, b"stale")
+    # 6  the safe values go out again in round 2 (Leader.scala:549-566)
+    chosen, nacks = tick([wire.encode_proxy_leader_phase2a(50 + j, 2, payload[int(safe_value[j])]) for j in range(k)], everyone)
+    assert len(chosen) == k and not nacks
+    d = wire.decode_replica_inbound(chosen)
+    assert d["slot"].tolist() == list(range(50, 210))
+    assert bytes(d["buf"][d["value_off"][-1]:d["value_off"][-1] + d["value_len"][-1]]) == cmd(209, b"stale")
+    # the log window: the first 2048 rows are recycled on both sides, the states stay equal, the rows vote afresh
+    assert jvm.call("recycleSlots", C.c_int32, h, 0, 2048) == 0
+    ref.recycle_slots(0, 2048)
+    cap = 8
+    sl, vr, vv = (jvm.arr(np.zeros(cap, np.int32)) for _ in range(3))
+    assert jvm.call("acceptorPhase1bInfo", C.c_int32, h, 0, 0, 0, cap, sl, vr, vv) == 0 == len(ref.acceptor_phase1b_info(0, 0, 0)[0])
+    chosen, nacks = tick([wire.encode_proxy_leader_phase2a(s, 2, cmd(s, b"lap2")) for s in range(0, 64)], everyone)
+    assert len(chosen) == 64 and not nacks
+    # a short array is refused before native code touches it
+    assert jvm.call("acceptorPhase1bInfo", C.c_int32, h, 0, 0, 0, 16, sl, vr, vv) == -1
+    assert jvm.call("destroy", C.c_int32, h) == 0

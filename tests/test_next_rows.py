@@ -165,3 +165,82 @@ def test_proxy_forget_gc(fa, oracle):
     assert gpu.read_tally(100) == ref.read_tally(100)
     with pytest.raises(fa.FpxError):
         gpu.proxy_forget(0, S + 1)
+
+
+# ---- the acceptor's half of Phase 1: Phase1b.info, and recycling rows of the window ------------------------------
+def test_oracle_phase1b_info_trace(oracle):
+    """multipaxos/Acceptor.scala:163-181, by hand: states.iteratorFrom(chosenWatermark), ascending slots, only the
+    slots the acceptor voted in, overwritten votes report the LAST vote (states(slot) = State(round, value), :205-208)"""
+    s = oracle.System(oracle.make_config(num_slots=16, num_replicas=3, f=1))
+    s.acceptor_handle_phase2a(0, 1, 4, 2, 300)
+    s.acceptor_handle_phase2a(0, 1, 1, 2, 200)
+    s.acceptor_handle_phase2a(0, 1, 9, 3, 900)
+    s.acceptor_handle_phase2a(0, 1, 4, 3, 301)      # equal-or-higher round: the vote in slot 4 is overwritten
+    s.acceptor_handle_phase2a(0, 0, 2, 0, 50)       # another acceptor
+    sl, vr, vv = s.acceptor_phase1b_info(0, 1, 0)
+    assert (sl.tolist(), vr.tolist(), vv.tolist()) == ([1, 4, 9], [2, 3, 3], [200, 301, 900])
+    sl, vr, vv = s.acceptor_phase1b_info(0, 1, 2)
+    assert (sl.tolist(), vr.tolist(), vv.tolist()) == ([4, 9], [3, 3], [301, 900])
+    assert len(s.acceptor_phase1b_info(0, 1, 10)[0]) == 0 and len(s.acceptor_phase1b_info(0, 2, 0)[0]) == 0
+    assert s.acceptor_phase1b_info(0, 0, 0)[0].tolist() == [2]
+    # recycled rows: the votes are gone, the round is not (a stale Phase2a still is refused)
+    s.recycle_slots(0, 8)
+    assert s.acceptor_phase1b_info(0, 1, 0)[0].tolist() == [9]
+    assert s.read_acceptor(0, 1)[0] == 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,kw", [(3, dict(f=1)), (5, dict(quorum_kind=1, ballot_mode=1)), (256, dict(f=127)),
+                                  (4, dict(num_groups=4, quorum_kind=2, grid_rows=2, grid_cols=2)),
+                                  (3, dict(f=1, num_groups=2, num_leader_groups=4))])
+def test_phase1b_info_and_recycle_match_oracle(fa, oracle, R, kw):
+    S = 2048
+    gpu, ref = both(fa, oracle, num_slots=S, num_replicas=R, tally_ways=8, **kw)
+    ng = kw.get("num_groups", 1) * kw.get("num_leader_groups", 1)
+    script = W.adversarial_script(S // 2, R, R // 2 + 1, 77 + R, epochs=16, fused=True, ngroups=kw.get("num_groups", 1)) \
+        if "num_leader_groups" not in kw else None
+    if script is not None:
+        W.assert_same_outputs(W.run_script(gpu, script), W.run_script(ref, script))
+    else:  # Mencius geometry: a plain stream in two rounds with thrifty targets
+        rng0 = np.random.default_rng(5)
+        for rnd in (0, 1):
+            slot = rng0.permutation(S)[: S // 2].astype(np.int32)
+            tgt = W.bits_from_bool(W.random_subsets(rng0, len(slot), R, 1, R))
+            a = gpu.phase2_fused(slot, np.full(len(slot), rnd, np.int32), W.steady_values(slot), tgt)
+            b = ref.phase2_fused(slot, np.full(len(slot), rnd, np.int32), W.steady_values(slot), tgt)
+            assert a[0] == b[0] == 0
+    rng = np.random.default_rng(R)
+
+    def compare():
+        for g in range(ng):
+            for r in sorted(set([0, R - 1] + rng.integers(0, R, 3).tolist())):
+                for wm in (0, 17, S // 4, S // 2 - 1, S - 1):
+                    a, b = gpu.acceptor_phase1b_info(g, r, wm), ref.acceptor_phase1b_info(g, r, wm)
+                    for x, y in zip(a, b):
+                        np.testing.assert_array_equal(x, y)
+    compare()
+    assert sum(len(ref.acceptor_phase1b_info(g, 0, 0)[0]) for g in range(ng)) > 0
+    # cap smaller than the count: the count is the total, the first cap entries are written
+    import ctypes as C
+    k = C.c_int32()
+    sl, vr, vv = (np.full(4, -7, np.int32) for _ in range(3))
+    want = ref.acceptor_phase1b_info(0, 0, 0)
+    assert gpu.L.fpx_acceptor_phase1b_info(gpu._h, 0, 0, 0, 4, C.byref(k), sl.ctypes.data, vr.ctypes.data, vv.ctypes.data) == 0
+    assert k.value == len(want[0]) and sl.tolist()[: min(4, k.value)] == want[0][:4].tolist()
+    assert gpu.L.fpx_acceptor_phase1b_info(gpu._h, ng, 0, 0, 0, C.byref(k), None, None, None) == fa.FPX_EINVAL
+    # recycle the middle of the window on both, then the same stream continues on it in a higher round
+    gpu.recycle_slots(S // 8, S // 4)
+    ref.recycle_slots(S // 8, S // 4)
+    compare()
+    W.assert_same_state(gpu, ref)
+    slot = np.arange(S // 8, S // 8 + S // 4, dtype=np.int32)
+    hi = np.full(len(slot), 1000, np.int32)   # above every round of the stream
+    a, b = gpu.phase2_fused(slot, hi, W.steady_values(slot)), ref.phase2_fused(slot, hi, W.steady_values(slot))
+    assert a[0] == b[0] == 0
+    for x, y in zip(a[1:], b[1:]):
+        np.testing.assert_array_equal(x, y)
+    assert a[1].all()            # every recycled row chooses again: the tallies were forgotten with the votes
+    compare()
+    W.assert_same_state(gpu, ref)
+    with pytest.raises(fa.FpxError):
+        gpu.recycle_slots(S - 1, 2)
