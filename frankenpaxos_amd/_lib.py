@@ -117,6 +117,8 @@ SIGNATURES = {
     "fpx_epx_sync": (C.c_int32, [VP]),
     "fpx_epx_preaccept": (C.c_int32, [VP, C.c_int32] + [VP] * 12),
     "fpx_epx_preaccept_dev": (C.c_int32, [VP, C.c_int32] + [VP] * 12),
+    "fpx_epx_preaccept_packed_dev": (C.c_int32, [VP, C.c_int32] + [VP] * 9),
+    "fpx_epx_packed_stride": (C.c_int32, [C.c_int32]),
     "fpx_epx_prepare": (C.c_int32, [VP, C.c_int32] + [VP] * 12),
     "fpx_epx_accept": (C.c_int32, [VP, C.c_int32] + [VP] * 13),
     "fpx_epx_read_cmdlog": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, VP]),

@@ -643,6 +643,8 @@ __global__ void __launch_bounds__(256) k_epx_decide(const EpxState st, const Epx
   }
 }
 
+#include "fpx_epaxos_kp.hpp"
+
 // ---- scan + decide of ONE key on chip ------------------------------------------------------------------------
 // k_epx_scan hands every (command, replica) conflict row to k_epx_decide through HBM at [command][replica]: n * m
 // rows written in (key, delivery order), i.e. at random -- 5 M random row writes are ~70 us on this GPU whatever
@@ -875,6 +877,19 @@ __global__ void __launch_bounds__(256) k_epx_commit(const EpxState st, const Epx
   int32_t* s2 = &st.sets[(size_t)r * per + e];
   if (tg > *g) *g = tg;
   if (ts > *s2) *s2 = ts;
+}
+
+// the four output arrays -> one packed line per command (fpx_epx_preaccept_packed_dev through the first form)
+__global__ void __launch_bounds__(256) k_epx_pack(const EpxState st, int m, const uint8_t* fast, const int32_t* deps,
+                                                  const int32_t* ldeps, const int32_t* own, int32_t* packed, int stride) {
+  if (st.status[0] != 0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const int n = st.n;
+  int32_t* o = packed + (size_t)i * stride;
+  for (int l = 0; l < n; ++l) o[l] = deps[(size_t)i * n + l], o[n + l] = ldeps[(size_t)i * n + l];
+  o[2 * n] = own[(size_t)i * 2], o[2 * n + 1] = own[(size_t)i * 2 + 1], o[2 * n + 2] = fast[i] ? 1 : 0;
+  for (int l = 2 * n + 3; l < stride; ++l) o[l] = 0;
 }
 
 // ---- the per-instance Paxos of EPaxos on the command log: Prepare (phase 1) and Accept (phase 2) ---------------
@@ -1250,6 +1265,12 @@ struct fpx_epx {
   hipStream_t stream = nullptr, own_stream = nullptr;
   int last_hip = 0;
   Buf kv, kv2, seg, conf, tmp, tick, h_leader, h_number, h_key, h_set, h_mask, h_seen, h_rank, h_triple, o_fast, o_deps, o_ldeps, o_own, cl, hp, fusedb, metab;
+  Buf p_fast, p_deps, p_ldeps, p_own;      // the four output arrays when a packed tick goes the first form's way
+  Buf kp_hist, kp_recs, kp_misc;          // K5 second form (fpx_epaxos_kp.hpp)
+  uint32_t* kp_flag = nullptr;            // page-locked: [0] sequence number of the tick whose count [1] is valid
+  uint32_t* kp_flag_dev = nullptr;
+  uint32_t kp_seq = 0;
+  bool kp_lds_allowed = false, kp_off = false;
   uint32_t cl_run = 0;
   bool lds_allowed = false, sort_lds_allowed = false;
   int num_cus = 256;
@@ -1355,6 +1376,54 @@ uint2* sort_by_key(fpx_epx* e, int m, uint2* a_buf, uint2* b_buf, const int32_t*
   return buf[cur];  // where the last pass left the sequence
 }
 
+// K5, second form: returns FPX_OK with *done = true when the tick went through it, *done = false when the first
+// form has to take the tick (a key with more commands than the on-chip tables hold; nothing was applied)
+template <int N>
+int launch_kp(fpx_epx* e, const EpxBatch& b, int32_t* d_packed, bool* done) {
+  using T = KpTile<N>;
+  *done = false;
+  KpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.m = b.m, a.tiles = (b.m + KP_TILE - 1) / KP_TILE, a.B = e->st.num_keys;
+  int rc;
+  if ((rc = grow(e, &e->kp_hist, (size_t)a.tiles * a.B * 4))) return rc;
+  if ((rc = grow(e, &e->kp_recs, (size_t)b.m * T::NI * 4))) return rc;
+  if ((rc = grow(e, &e->kp_misc, (size_t)a.B * 12 + 256))) return rc;
+  a.hist = (uint32_t*)e->kp_hist.p, a.recs = (int32_t*)e->kp_recs.p;
+  a.fp = (unsigned long long*)e->kp_misc.p;              // 16 words of 8 bytes
+  a.ctl = (uint32_t*)((char*)e->kp_misc.p + 128);        // 2 words
+  a.tot = (uint32_t*)((char*)e->kp_misc.p + 256);
+  a.seg = (int32_t*)(a.tot + a.B);
+  a.host_flag = e->kp_flag_dev, a.seq = ++e->kp_seq, a.tc = T::TC;
+  a.packed = d_packed, a.stride = fpx_epx_packed_stride(N);
+  if (!e->kp_lds_allowed) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_epx_key2<N>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)T::BYTES);
+    e->kp_lds_allowed = true;
+  }
+  hipLaunchKernelGGL(k_kp_hist, dim3(a.tiles), dim3(256), 0, e->stream, e->st, b, a);
+  hipLaunchKernelGGL(k_kp_scan, dim3((a.B + KP_SCAN_WAVES - 1) / KP_SCAN_WAVES), dim3(64 * KP_SCAN_WAVES), 0, e->stream, a);
+  hipLaunchKernelGGL((k_kp_scatter<N>), dim3(8 * ((a.tiles + 7) / 8)), dim3(256), 0, e->stream, e->st, b, a);
+  // k_epx_key2 is enqueued at once -- it returns at its first instruction when a key does not fit -- and the host then
+  // learns, while the GPU works on, whether the first form has to take the tick after all (launching the kernel
+  // only after the answer left the GPU idle for ~30 us per tick when ticks were enqueued back to back)
+  const int grid = std::min(e->st.num_keys, e->num_cus);
+  hipLaunchKernelGGL((k_epx_key2<N>), dim3(grid), dim3(T::THREADS), T::BYTES, e->stream, e->st, b, a);
+  volatile uint32_t* flag = e->kp_flag;
+  bool seen = false;
+  for (long spin = 0; spin < 200000000L; ++spin) {
+    if (flag[0] == a.seq) { seen = true; break; }
+    if ((spin & 0xffff) == 0xffff && hipStreamQuery(e->stream) != hipErrorNotReady) break;  // finished, or failed
+  }
+  if (!seen) {
+    EHIP(e, hipStreamSynchronize(e->stream));
+    if (flag[0] != a.seq) return FPX_EHIP;
+  }
+  if (flag[1] != 0) return FPX_OK;  // a hot key: the first form takes the whole tick
+  *done = true;
+  return FPX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1422,6 +1491,15 @@ int32_t fpx_epx_create(const fpx_epx_config* cfg, fpx_epx** out) {
     if (hipMemsetAsync(e->st.cl_triple, 0xFF, ce * 4, e->stream) != hipSuccess) return fail(FPX_EHIP);
     if (hipMemsetAsync(e->st.cl_stamp, 0, (size_t)n * cfg->num_instances * 4, e->stream) != hipSuccess) return fail(FPX_EHIP);
   }
+  // the word k_kp_scan tells the host through (how many keys of the tick are too big for the on-chip tables)
+  if (hipHostMalloc((void**)&e->kp_flag, 64, hipHostMallocDefault) == hipSuccess) {
+    memset(e->kp_flag, 0, 64);
+    if (hipHostGetDevicePointer((void**)&e->kp_flag_dev, e->kp_flag, 0) != hipSuccess) e->kp_flag_dev = nullptr;
+  } else {
+    e->kp_flag = nullptr;
+    (void)hipGetLastError();
+  }
+  e->kp_off = getenv("FPX_EPX_V1") != nullptr;
   if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(FPX_EHIP);
   *out = e;
   return FPX_OK;
@@ -1440,6 +1518,9 @@ int32_t fpx_epx_destroy(fpx_epx* e) {
                &e->o_own, &e->cl, &e->hp, &e->fusedb, &e->metab};
   for (Buf* b : bs)
     if (b->p) (void)hipFree(b->p);
+  for (Buf* b : {&e->kp_hist, &e->kp_recs, &e->kp_misc, &e->p_fast, &e->p_deps, &e->p_ldeps, &e->p_own})
+    if (b->p) (void)hipFree(b->p);
+  if (e->kp_flag) (void)hipHostFree(e->kp_flag);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
   return FPX_OK;
@@ -1466,15 +1547,49 @@ int32_t fpx_epx_sync(fpx_epx* e) {
   return h[0];
 }
 
-int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, const int32_t* d_number,
-                              const int32_t* d_key, const uint8_t* d_is_set, const uint8_t* d_resp_mask,
-                              const uint8_t* d_seen_mask, const int32_t* d_rank, const int32_t* d_triple_id,
-                              uint8_t* d_fast, int32_t* d_deps, int32_t* d_leader_deps, int32_t* d_own_values_end) {
+static int32_t preaccept_dev_impl(fpx_epx* e, int32_t m, const int32_t* d_leader, const int32_t* d_number,
+                                  const int32_t* d_key, const uint8_t* d_is_set, const uint8_t* d_resp_mask,
+                                  const uint8_t* d_seen_mask, const int32_t* d_rank, const int32_t* d_triple_id,
+                                  uint8_t* d_fast, int32_t* d_deps, int32_t* d_leader_deps, int32_t* d_own_values_end,
+                                  int32_t* d_packed) {
   if (!e || m < 0) return FPX_EINVAL;
   EpxDeviceGuard _dg(e->cfg.device);
   if (m == 0) return FPX_OK;
   const int n = e->st.n;
   int rc;
+  // the second form (fpx_epaxos_kp.hpp): one partition pass by key, everything else on chip -- when the keys are
+  // one LDS counter each, ranks and slots share a 32-bit sort word, and no command log is kept
+  if (!e->kp_off && e->kp_flag_dev && e->st.num_keys <= KP_MAXB && m < (1 << 21) && e->st.num_instances == 0 &&
+      !d_triple_id) {
+    EpxBatch kb;
+    memset(&kb, 0, sizeof(kb));
+    kb.m = m, kb.leader = d_leader, kb.number = d_number, kb.key = d_key, kb.is_set = d_is_set, kb.resp_mask = d_resp_mask;
+    kb.seen_mask = d_seen_mask, kb.rank = d_rank;
+    kb.fast = d_fast, kb.deps = d_deps, kb.leader_deps = d_leader_deps, kb.own_values_end = d_own_values_end;
+    bool done = false;
+    switch (n) {
+      case 3: rc = launch_kp<3>(e, kb, d_packed, &done); break;
+      case 5: rc = launch_kp<5>(e, kb, d_packed, &done); break;
+      default: rc = launch_kp<7>(e, kb, d_packed, &done); break;
+    }
+    if (rc) return rc;
+    if (done) {
+      hipError_t le = hipGetLastError();
+      if (le != hipSuccess) {
+        e->last_hip = (int)le;
+        return FPX_EHIP;
+      }
+      return FPX_OK;
+    }
+  }
+  if (d_packed) {  // the first form writes the four arrays: into the context's own, packed at the end
+    if ((rc = grow(e, &e->p_fast, (size_t)m))) return rc;
+    if ((rc = grow(e, &e->p_deps, (size_t)m * n * 4))) return rc;
+    if ((rc = grow(e, &e->p_ldeps, (size_t)m * n * 4))) return rc;
+    if ((rc = grow(e, &e->p_own, (size_t)m * 8))) return rc;
+    d_fast = (uint8_t*)e->p_fast.p, d_deps = (int32_t*)e->p_deps.p, d_leader_deps = (int32_t*)e->p_ldeps.p;
+    d_own_values_end = (int32_t*)e->p_own.p;
+  }
   if ((rc = grow(e, &e->kv, (size_t)n * m * 8))) return rc;
   if ((rc = grow(e, &e->kv2, (size_t)n * m * 8))) return rc;
   if ((rc = grow(e, &e->tick, (size_t)n * e->st.num_keys * 2 * n * 4))) return rc;
@@ -1514,12 +1629,34 @@ int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, co
   }
   const long long tot = (long long)e->st.num_keys * n * n;
   hipLaunchKernelGGL(k_epx_commit, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, e->stream, e->st, b);
+  if (d_packed)
+    hipLaunchKernelGGL(k_epx_pack, dim3((m + 255) / 256), dim3(256), 0, e->stream, e->st, m, d_fast, d_deps, d_leader_deps,
+                       d_own_values_end, d_packed, fpx_epx_packed_stride(n));
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) {
     e->last_hip = (int)le;
     return FPX_EHIP;
   }
   return FPX_OK;
+}
+
+int32_t fpx_epx_packed_stride(int32_t num_replicas) { return (2 * num_replicas + 3 + 3) / 4 * 4; }
+
+int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, const int32_t* d_number,
+                              const int32_t* d_key, const uint8_t* d_is_set, const uint8_t* d_resp_mask,
+                              const uint8_t* d_seen_mask, const int32_t* d_rank, const int32_t* d_triple_id,
+                              uint8_t* d_fast, int32_t* d_deps, int32_t* d_leader_deps, int32_t* d_own_values_end) {
+  return preaccept_dev_impl(e, m, d_leader, d_number, d_key, d_is_set, d_resp_mask, d_seen_mask, d_rank, d_triple_id, d_fast,
+                            d_deps, d_leader_deps, d_own_values_end, nullptr);
+}
+
+int32_t fpx_epx_preaccept_packed_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, const int32_t* d_number,
+                                     const int32_t* d_key, const uint8_t* d_is_set, const uint8_t* d_resp_mask,
+                                     const uint8_t* d_seen_mask, const int32_t* d_rank, const int32_t* d_triple_id,
+                                     int32_t* d_packed) {
+  if (!d_packed && m > 0) return FPX_EINVAL;
+  return preaccept_dev_impl(e, m, d_leader, d_number, d_key, d_is_set, d_resp_mask, d_seen_mask, d_rank, d_triple_id, nullptr,
+                            nullptr, nullptr, nullptr, d_packed);
 }
 
 int32_t fpx_epx_preaccept(fpx_epx* e, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* key,

@@ -157,6 +157,22 @@ class EPaxos:
         if st:
             raise FpxError(st, "fpx_epx_preaccept_dev")
 
+    def packed_stride(self):
+        return int(self.L.fpx_epx_packed_stride(self.n))
+
+    def preaccept_packed_dev(self, leader, number, key, is_set, resp_mask, rank, packed, seen_mask=None, triple_id=None):
+        """one line of packed_stride() ints per command: deps | leader_deps | own_values_end[2] | fast (see unpack)"""
+        d = lambda t: None if t is None else t.data_ptr()
+        st = self.L.fpx_epx_preaccept_packed_dev(self._h, leader.numel(), d(leader), d(number), d(key), d(is_set),
+                                                 d(resp_mask), d(seen_mask), d(rank), d(triple_id), d(packed))
+        if st:
+            raise FpxError(st, "fpx_epx_preaccept_packed_dev")
+
+    def unpack(self, packed):
+        """packed [m, stride] (numpy or torch) -> fast [m], deps [m, n], leader_deps [m, n], own_values_end [m, 2]"""
+        n = self.n
+        return packed[:, 2 * n + 2], packed[:, :n], packed[:, n:2 * n], packed[:, 2 * n:2 * n + 2]
+
     def read_index(self, replica, key):
         g = np.zeros(self.n, np.int32)
         s = np.zeros(self.n, np.int32)

@@ -356,7 +356,9 @@ int32_t fpx_read_range_tally(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end,
  * (thrifty fast quorum, Replica.scala:705-706).  rank is n x m: rank[r * m + i] = the position of
  * message i in replica r's processing order (a permutation of 0..m-1 per replica; only replicas that
  * take part in message i -- its leader and resp_mask[i] -- matter; a rank row that is not a permutation
- * is FPX_EINVAL and nothing is applied).  Every participating replica
+ * is FPX_EINVAL and nothing is applied; values outside 0..m-1 are always caught, and a row whose values are in
+ * range but repeat is told from a permutation by comparing two independent 64-bit additive fingerprints of its
+ * multiset of values with those of 0..m-1 -- no scatter / gather of the row is needed for it).  Every participating replica
  * computes the command's conflicts against ITS conflict index in ITS order (getTopOneConflicts), the
  * leader's become the PreAccept's dependencies, the others answer PreAcceptOk with the union; the
  * leader takes the fast path iff the n-2 answers are identical (popularItems(..., n-2)), otherwise
@@ -403,6 +405,16 @@ int32_t fpx_epx_preaccept_dev(fpx_epx* epx, int32_t m, const int32_t* d_leader, 
                               const uint8_t* d_seen_mask, const int32_t* d_rank, const int32_t* d_triple_id,
                               uint8_t* d_fast, int32_t* d_deps, int32_t* d_leader_deps,
                               int32_t* d_own_values_end);
+/* The same with ONE packed line per command instead of the four output arrays (what the kernel that decides a key
+ * writes most cheaply: a command's outputs are contiguous and sector-aligned, where the four arrays take four
+ * partial sectors at every message index).  d_packed: m x fpx_epx_packed_stride(n) ints; line i =
+ *   [0, n) deps   [n, 2n) leader_deps   [2n] own_values_end (deps)   [2n + 1] own_values_end (leader_deps)
+ *   [2n + 2] fast (0 / 1)   the rest 0            (stride = 12 / 16 / 20 ints for n = 3 / 5 / 7) */
+int32_t fpx_epx_packed_stride(int32_t num_replicas);
+int32_t fpx_epx_preaccept_packed_dev(fpx_epx* epx, int32_t m, const int32_t* d_leader, const int32_t* d_number,
+                                     const int32_t* d_key, const uint8_t* d_is_set, const uint8_t* d_resp_mask,
+                                     const uint8_t* d_seen_mask, const int32_t* d_rank, const int32_t* d_triple_id,
+                                     int32_t* d_packed);
 int32_t fpx_epx_sync(fpx_epx* epx);
 
 /* ---- EPaxos beyond fresh instances: the per-instance Paxos on the command log (num_instances > 0) --------------

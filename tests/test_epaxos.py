@@ -1036,3 +1036,152 @@ def test_config4_commits_execute_at_full_size(oracle):
     el, ei, cs, bl, bi = zz.execute_arrays()
     check_execution_order(n, leader, number, deps, own[:, 0], el, ei, cs)
     assert sorted(zip(bl.tolist(), bi.tolist())) == [(L, nxt[L]) for L in range(n)]   # blocked on the next ids only
+
+
+# ---- K5, second form (fpx_epaxos_kp.hpp): packed lines, hot keys, both forms on the same ticks -------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,num_keys,m,fifo", [(5, 64, 20000, True), (3, 8, 6000, False), (7, 32, 9000, False),
+                                                (5, 2048, 30000, True), (5, 1, 900, False)])
+def test_epaxos_packed_lines_equal_the_four_arrays_and_the_oracle(oracle, n, num_keys, m, fifo):
+    """fpx_epx_preaccept_packed_dev: line i = deps | leader_deps | own_values_end | fast, bit for bit what the four
+    arrays of fpx_epx_preaccept hold and what the oracle computes, tick after tick (the index carries over)"""
+    import torch
+    from frankenpaxos_amd.epaxos import EPaxos
+
+    gpu, ref = EPaxos(n, num_keys), oracle.EPaxos(n, num_keys)
+    rng = np.random.default_rng(n * 1000 + num_keys)
+    nxt = [0] * n
+    dev = torch.device("cuda:0")
+    stride = gpu.packed_stride()
+    assert stride == {3: 12, 5: 16, 7: 20}[n]
+    for tick in range(3):
+        leader, number, key, is_set, mask, rank = random_tick(rng, n, num_keys, m, nxt, 9.0, fifo=fifo)
+        want = ref.preaccept(leader, number, key, is_set, mask, rank)
+        assert want[0] == 0
+        t = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (leader, number, key, is_set, mask, rank)]
+        packed = torch.full((m, stride), -7, dtype=torch.int32, device=dev)
+        gpu.preaccept_packed_dev(*t, packed)
+        assert gpu.sync() == 0
+        fast, deps, ldeps, own = (x.cpu().numpy() for x in gpu.unpack(packed))
+        np.testing.assert_array_equal(fast, want[1].astype(np.int32))
+        np.testing.assert_array_equal(deps, want[2])
+        np.testing.assert_array_equal(ldeps, want[3])
+        np.testing.assert_array_equal(own, want[4])
+        assert not packed[:, 2 * n + 3:].any()                           # the padding is written (zeros)
+    for r in range(n):
+        for k in range(min(num_keys, 40)):
+            ga, sa = gpu.read_index(r, k)
+            gb, sb = ref.read_index(r, k)
+            assert ga.tolist() == gb.tolist() and sa.tolist() == sb.tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [3, 5, 7])
+def test_epaxos_a_hot_key_goes_the_first_forms_way(oracle, n):
+    """one key holds more commands than the on-chip tables of k_epx_key2 take (and one exactly as many as fit): the
+    tick is handed to the first form whole, packed or not, with the same results; the next tick is small again"""
+    import torch
+    from frankenpaxos_amd.epaxos import EPaxos
+
+    num_keys = 16
+    tc = {3: 1536, 5: 1152, 7: 832}[n]
+    gpu, ref = EPaxos(n, num_keys), oracle.EPaxos(n, num_keys)
+    rng = np.random.default_rng(n)
+    nxt = [0] * n
+    dev = torch.device("cuda:0")
+    for tick, hot in enumerate([tc, tc + 1, 3 * tc + 17, 10]):
+        m = hot + 3000
+        leader, number, key, is_set, mask, rank = random_tick(rng, n, num_keys, m, nxt, 9.0, fifo=tick % 2 == 0)
+        key[:] = 1 + rng.integers(0, num_keys - 1, m)       # ~200 commands on each of the other keys
+        key[rng.permutation(m)[:hot]] = 0                   # `hot` commands on key 0
+        want = ref.preaccept(leader, number, key, is_set, mask, rank)
+        assert want[0] == 0
+        if tick % 2:
+            got = gpu.preaccept(leader, number, key, is_set, mask, rank)
+            assert got[0] == 0
+            for x, y in zip(got[1:], want[1:]):
+                np.testing.assert_array_equal(x, y)
+        else:
+            t = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (leader, number, key, is_set, mask, rank)]
+            packed = torch.zeros((m, gpu.packed_stride()), dtype=torch.int32, device=dev)
+            gpu.preaccept_packed_dev(*t, packed)
+            assert gpu.sync() == 0
+            fast, deps, ldeps, own = (x.cpu().numpy() for x in gpu.unpack(packed))
+            np.testing.assert_array_equal(fast, want[1].astype(np.int32))
+            np.testing.assert_array_equal(deps, want[2])
+            np.testing.assert_array_equal(ldeps, want[3])
+            np.testing.assert_array_equal(own, want[4])
+    for r in range(n):
+        for k in range(num_keys):
+            ga, sa = gpu.read_index(r, k)
+            gb, sb = ref.read_index(r, k)
+            assert ga.tolist() == gb.tolist() and sa.tolist() == sb.tolist()
+
+
+@pytest.mark.gpu
+def test_epaxos_both_forms_agree_and_bad_ranks_are_refused(oracle, monkeypatch):
+    """FPX_EPX_V1 forces the first form: the two agree on the same ticks; a rank row with a repeated value, with a value
+    out of range, or two rows swapped into each other's multisets -- FPX_EINVAL from both, nothing applied"""
+    from frankenpaxos_amd.epaxos import EPaxos
+    import frankenpaxos_amd as fa
+
+    n, num_keys, m = 5, 128, 40000
+    v2 = EPaxos(n, num_keys)
+    monkeypatch.setenv("FPX_EPX_V1", "1")
+    v1 = EPaxos(n, num_keys)
+    monkeypatch.delenv("FPX_EPX_V1")
+    ref = oracle.EPaxos(n, num_keys)
+    rng = np.random.default_rng(11)
+    nxt = [0] * n
+    for tick in range(3):
+        args = random_tick(rng, n, num_keys, m, nxt, 12.0, fifo=False)
+        a, b, c = v2.preaccept(*args), v1.preaccept(*args), ref.preaccept(*args)
+        assert a[0] == b[0] == c[0] == 0
+        for x, y, z in zip(a[1:], b[1:], c[1:]):
+            np.testing.assert_array_equal(x, y)
+            np.testing.assert_array_equal(x, z)
+        leader, number, key, is_set, mask, rank = random_tick(rng, n, num_keys, m, list(nxt), 12.0)
+        for kind in range(3):
+            bad = rank.copy()
+            if kind == 0:
+                bad[3, 17] = bad[3, 18]                      # a repeated position (another one is empty)
+            elif kind == 1:
+                bad[1, 5] = m                                # out of range
+            else:
+                lo, hi = (7, 8) if bad[0, 7] < bad[0, 8] else (8, 7)
+                bad[0, lo] += 1                              # the same sum of values ...
+                bad[0, hi] -= 1                              # ... but two positions now taken twice
+                if (np.sort(bad[0]) == np.arange(m)).all():
+                    continue
+            assert v2.preaccept(leader, number, key, is_set, mask, bad)[0] == fa.FPX_EINVAL
+            assert v1.preaccept(leader, number, key, is_set, mask, bad)[0] == fa.FPX_EINVAL
+            assert ref.preaccept(leader, number, key, is_set, mask, bad)[0] == 1
+    for r in range(n):
+        for k in range(num_keys):
+            assert [x.tolist() for x in v2.read_index(r, k)] == [x.tolist() for x in ref.read_index(r, k)]
+            assert [x.tolist() for x in v1.read_index(r, k)] == [x.tolist() for x in ref.read_index(r, k)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [3, 5, 7])
+def test_epaxos_clumped_ranks_take_the_radix_sort(oracle, n):
+    """k_epx_key2 orders a key's commands by rank with a bucket sort that assumes the ranks spread out; two clumps at
+    the ends of the delivery order put dozens of commands into one bucket and the key through the LSD radix sort"""
+    from frankenpaxos_amd.epaxos import EPaxos
+
+    num_keys, m = 8, 20000
+    gpu, ref = EPaxos(n, num_keys), oracle.EPaxos(n, num_keys)
+    rng = np.random.default_rng(70 + n)
+    nxt = [0] * n
+    for tick in range(3):
+        leader, number, key, is_set, mask, rank = random_tick(rng, n, num_keys, m, nxt, 2.0, fifo=tick != 1)
+        key[:] = 1 + rng.integers(0, num_keys - 1, m)
+        key[:150] = 0                                       # delivered first everywhere (skew 2) ...
+        key[m - 150:] = 0                                   # ... and last: 150 commands in each end bucket of key 0
+        a, b = gpu.preaccept(leader, number, key, is_set, mask, rank), ref.preaccept(leader, number, key, is_set, mask, rank)
+        assert a[0] == b[0] == 0
+        for x, y in zip(a[1:], b[1:]):
+            np.testing.assert_array_equal(x, y)
+    for r in range(n):
+        for k in range(num_keys):
+            assert [x.tolist() for x in gpu.read_index(r, k)] == [x.tolist() for x in ref.read_index(r, k)]
