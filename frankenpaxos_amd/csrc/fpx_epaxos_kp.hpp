@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(64 * KP_SCAN_WAVES) k_kp_scan(const KpArgs a) 
   }
 }
 
-// validation of one message exactly as k_epx_keys (fpo_epx_preaccept2's checks), record out, fingerprints
+// validation of one message exactly as k_epx_keys, record out, fingerprints
 template <int N>
 __global__ void __launch_bounds__(256) k_kp_scatter(const EpxState st, const EpxBatch b, const KpArgs a) {
   using T = KpTile<N>;
