@@ -127,19 +127,19 @@ def epaxos_setup(fa, dev, local_rank, K, Wm):
         leader, number, key, is_set, mask, rank = random_tick(rng, n, num_keys, m, nxt, 64.0)
         key = (W.splitmix64_at(np.arange(t * m, (t + 1) * m, dtype=np.uint64)) % np.uint64(num_keys)).astype(np.int32)
         d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        # one packed line per command (fpx_epx_preaccept_packed_dev): deps | leader_deps | own_values_end | fast
         ticks.append((d(leader), d(number), d(key), d(is_set), d(mask), d(rank),
-                      torch.zeros(m, dtype=torch.uint8, device=dev), torch.zeros((m, n), dtype=torch.int32, device=dev),
-                      torch.zeros((m, n), dtype=torch.int32, device=dev), torch.zeros((m, 2), dtype=torch.int32, device=dev)))
+                      torch.full((m, epx.packed_stride()), -7, dtype=torch.int32, device=dev)))
     timer = Timer(K)
     state = {"timing": False}
 
     def step(i):
-        leader, number, key, is_set, mask, rank, fast, deps, ldeps, own = ticks[i]
+        leader, number, key, is_set, mask, rank, packed = ticks[i]
         if state["timing"]:
             with timer:
-                epx.preaccept_dev(leader, number, key, is_set, mask, rank, fast, deps, ldeps, own_values_end=own)
+                epx.preaccept_packed_dev(leader, number, key, is_set, mask, rank, packed)
         else:
-            epx.preaccept_dev(leader, number, key, is_set, mask, rank, fast, deps, ldeps, own_values_end=own)
+            epx.preaccept_packed_dev(leader, number, key, is_set, mask, rank, packed)
 
     def verify(lo, hi):
         """the first timed tick against the oracle on EVERY output (the oracle replays the ticks before it: the conflict
@@ -152,15 +152,15 @@ def epaxos_setup(fa, dev, local_rank, K, Wm):
         for i in range(lo + 1):
             want = ref.preaccept(*[h(x) for x in ticks[i][:6]])
             assert want[0] == 0
-        fast, deps, ldeps, own = (h(x) for x in ticks[lo][6:10])
+        fast, deps, ldeps, own = (h(x) for x in epx.unpack(ticks[lo][6]))
         assert (fast == want[1]).all() and (deps == want[2]).all() and (ldeps == want[3]).all() and (own == want[4]).all(), \
             "tick %d differs from the oracle" % lo
         done = 0
         for i in range(lo, hi):
-            fast = ticks[i][6]
+            fast, _, _, own = epx.unpack(ticks[i][6])
             nf = int(fast.sum().item())
-            assert 0 < nf < m, "tick %d: %d fast-path commits" % (i, nf)
-            assert bool((ticks[i][9] == 0).all())       # FIFO channels: no own-column holes
+            assert 0 < nf < m and int(fast.max().item()) == 1, "tick %d: %d fast-path commits" % (i, nf)
+            assert bool((own == 0).all())               # FIFO channels: no own-column holes
             done += m                                   # every command is decided (fast commit or Accept phase)
         return done
 
@@ -181,17 +181,21 @@ def epaxos_setup(fa, dev, local_rank, K, Wm):
         return {"value": mm / dt, "unit": "commands/s", "cores": 1, "kind": "port",
                 "sample": "oracle/fpx_oracle_epaxos.c fpo_epx_preaccept, one tick of 2^18 commands, 1 thread"}
 
-    # per command: inputs (leader, number, key 12 B, is_set + mask 2 B, rank 5 x 4 B) read; the n-1 = 4 PreAcceptOk
-    # dependency rows (n x 4 B each) written by the scans and read by the decision; fast + deps + leader_deps +
-    # own_values_end written
-    bpc = 34 + 4 * 20 * 2 + (1 + 20 + 20 + 8)
+    # per command, what has to cross HBM: inputs (leader, number, key 12 B, is_set + mask 2 B, rank 5 x 4 B) read once, one
+    # 64-byte output line written once (the conflict rows never leave the chip) = 98 B.  The 32-byte record the
+    # partition pass writes and the key kernel reads back is the design's own traffic, not part of the model.
+    bpc = 34 + 64
     return dict(ctx=epx, step=step, verify=verify, units=m, unit="commands/s", bytes_per_unit=bpc,
                 workload="EPaxos n = 5: one tick = 2^20 fresh single-key commands (1024 keys, Bernoulli get/set) through "
                          "the pre-accept phase of all replicas: conflict scan in every replica's delivery order, "
                          "fast-path test, slow-path union, commit into every conflict index",
-                kernel="K5 tick (k_epx_keys, one-pass radix sort, k_epx_key<5>: scan + decisions per key on chip, k_epx_commit)", profile=profile,
+                kernel="K5 tick, second form (k_kp_hist, k_kp_scan, k_kp_scatter<5>: one record per command into its key's segment; "
+                       "k_epx_key2<5>: per key on chip -- order by rank per replica, scans, decisions, index update)", profile=profile,
                 metric="EPaxos commands decided/sec (BASELINE.json configs[3])", cpu=cpu,
-                extra={"commands_per_tick": m, "replicas": n, "keys": num_keys}, start_timing=lambda: state.update(timing=True))
+                extra={"commands_per_tick": m, "replicas": n, "keys": num_keys,
+                       "byte_model": "34 B inputs + 64 B packed output line per command; round 2's model (243 B) also counted "
+                                     "the 4 conflict rows of 20 B each way, which no longer cross HBM"},
+                start_timing=lambda: state.update(timing=True))
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -1399,9 +1399,11 @@ int launch_kp(fpx_epx* e, const EpxBatch& b, int32_t* d_packed, bool* done) {
   if (!e->kp_lds_allowed) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_epx_key2<N>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)T::BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_kp_hist), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              KP_HG * KP_MAXB * 4);
     e->kp_lds_allowed = true;
   }
-  hipLaunchKernelGGL(k_kp_hist, dim3(a.tiles), dim3(256), 0, e->stream, e->st, b, a);
+  hipLaunchKernelGGL(k_kp_hist, dim3((a.tiles + KP_HG - 1) / KP_HG), dim3(128 * KP_HG), (size_t)KP_HG * a.B * 4, e->stream, e->st, b, a);
   hipLaunchKernelGGL(k_kp_scan, dim3((a.B + KP_SCAN_WAVES - 1) / KP_SCAN_WAVES), dim3(64 * KP_SCAN_WAVES), 0, e->stream, a);
   hipLaunchKernelGGL((k_kp_scatter<N>), dim3(8 * ((a.tiles + 7) / 8)), dim3(256), 0, e->stream, e->st, b, a);
   // k_epx_key2 is enqueued at once -- it returns at its first instruction when a key does not fit -- and the host then

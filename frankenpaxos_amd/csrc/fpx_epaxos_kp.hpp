@@ -49,7 +49,8 @@ template <int N> struct KpTile {
   static constexpr size_t SORT_BYTES = (size_t)2 * N * TC * 4 + (size_t)N * NBK * 4;
   static constexpr size_t ROWS_BYTES = (size_t)TC * (N - 1) * N * 4;
   static constexpr size_t R_BYTES = SORT_BYTES > ROWS_BYTES ? SORT_BYTES : ROWS_BYTES;
-  static constexpr size_t BYTES = (size_t)TC * NI * 4 + R_BYTES + (size_t)2 * N * W * KP_RADIX * 4 + (size_t)N * W * 2 * N * 4 + 256;
+  static constexpr size_t BYTES = (size_t)TC * NI * 4 + R_BYTES + (size_t)2 * N * W * KP_RADIX * 4 + (size_t)N * W * 2 * N * 4 + 256 +
+                                  (size_t)N * 2 * N * 4;
   static_assert(BYTES <= 160 * 1024, "LDS of one CU");
 };
 
@@ -91,31 +92,46 @@ __device__ __forceinline__ uint32_t kp_wave_excl_sum(uint32_t v) {
   return inc - v;
 }
 
-__global__ void __launch_bounds__(256) k_kp_hist(const EpxState st, const EpxBatch b, const KpArgs a) {
-  __shared__ uint32_t h[KP_MAXB];
+// KP_HG tiles per workgroup (128 threads each): the counts of a key for the workgroup's tiles are neighbours in
+// hist[key][tile] and leave as one 32-byte sector (one tile per workgroup wrote 2 MB of counts as 17 MB of partial sectors)
+constexpr int KP_HG = 8;
+__global__ void __launch_bounds__(128 * KP_HG) k_kp_hist(const EpxState st, const EpxBatch b, const KpArgs a) {
+  extern __shared__ uint32_t kp_h[];  // [KP_HG][B]
   if (blockIdx.x == 0) {
     if (threadIdx.x < 2) a.ctl[threadIdx.x] = 0;
     if (threadIdx.x < 2 * (st.n + 1)) a.fp[threadIdx.x] = 0ull;
   }
-  for (int j = threadIdx.x; j < a.B; j += 256) h[j] = 0;
+  for (int j = threadIdx.x; j < KP_HG * a.B; j += 128 * KP_HG) kp_h[j] = 0;
   __syncthreads();
-  const int first = blockIdx.x * KP_TILE;
-  int k[KP_TILE / 256];
+  const int sub = threadIdx.x >> 7, t = threadIdx.x & 127;
+  const int tile = blockIdx.x * KP_HG + sub;
+  uint32_t* h = kp_h + sub * a.B;
+  const int first = tile * KP_TILE;
+  int k[KP_TILE / 128];
 #pragma unroll
-  for (int j = 0; j < KP_TILE / 256; ++j) {
-    const int i = first + j * 256 + threadIdx.x;
-    k[j] = i < a.m ? b.key[i] : -1;
+  for (int j = 0; j < KP_TILE / 128; ++j) {
+    const int i = first + j * 128 + t;
+    k[j] = (tile < a.tiles && i < a.m) ? b.key[i] : -1;
   }
 #pragma unroll
-  for (int j = 0; j < KP_TILE / 256; ++j) {
-    const int i = first + j * 256 + threadIdx.x;
-    if (i < a.m) {
+  for (int j = 0; j < KP_TILE / 128; ++j) {
+    const int i = first + j * 128 + t;
+    if (tile < a.tiles && i < a.m) {
       if (k[j] < 0 || k[j] >= a.B) epx_report(st.status, FPX_EINVAL, i);
       else atomicAdd(&h[k[j]], 1u);
     }
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < a.B; j += 256) a.hist[(size_t)j * a.tiles + blockIdx.x] = h[j];  // [key][tile]
+  const int t0 = blockIdx.x * KP_HG, nt = min(KP_HG, a.tiles - t0);
+  for (int j = threadIdx.x; j < a.B; j += 128 * KP_HG) {
+    uint32_t* out = a.hist + (size_t)j * a.tiles + t0;  // [key][tile]
+    if (nt == KP_HG && (a.tiles & 3) == 0) {
+      reinterpret_cast<uint4*>(out)[0] = make_uint4(kp_h[j], kp_h[a.B + j], kp_h[2 * a.B + j], kp_h[3 * a.B + j]);
+      reinterpret_cast<uint4*>(out)[1] = make_uint4(kp_h[4 * a.B + j], kp_h[5 * a.B + j], kp_h[6 * a.B + j], kp_h[7 * a.B + j]);
+    } else {
+      for (int q = 0; q < nt; ++q) out[q] = kp_h[q * a.B + j];
+    }
+  }
 }
 
 // exclusive scan of every key's per-tile counts: one wavefront per key, the key's counts are contiguous ([key][tile];
@@ -269,6 +285,7 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
   int* rmin = cntr + N;                                                         // [N] smallest / largest rank among them
   int* rmax = rmin + N;
   int* degenerate = rmax + N;                                                   // a rank bucket is too full: radix sort
+  int* base = degenerate + 1;                                                   // [N][2N] the replicas' TopOne vectors of the key
   if (st.status[0] != 0) return;
   if (a.ctl[1] != 0) return;  // a key does not fit the tables: the host sends the whole tick the first form's way
   // a rank row is a permutation of 0..m-1 iff (values are in range, checked by k_kp_scatter, and) its multiset of
@@ -294,14 +311,10 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
 
   struct Next {
     int lo, len;
-    int cg[N], cs[N];
     int4 q[T::RQ];
   };
   auto fetch = [&](int k, Next& s) {
     s.lo = a.seg[(size_t)k * 2], s.len = a.seg[(size_t)k * 2 + 1];
-    const size_t ib = ((size_t)r * st.num_keys + k) * N;
-#pragma unroll
-    for (int l = 0; l < N; ++l) s.cg[l] = st.gets[ib + l], s.cs[l] = st.sets[ib + l];
     const int4* src = reinterpret_cast<const int4*>(a.recs + (size_t)s.lo * T::NI);
     const int total = s.len * (T::NI / 4);
 #pragma unroll
@@ -316,7 +329,8 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
   if (k >= st.num_keys) return;
   fetch(k, cur);
   for (; k < st.num_keys; k += gridDim.x) {
-    const int c = cur.len;  // <= TC: the host only launches this kernel when every key fits
+    const int c = cur.len;  // <= TC: the kernel does not run otherwise
+    int carry_in = 0;
     // ---- the records, the counters
     {
       const int total = c * (T::NI / 4);
@@ -333,6 +347,12 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
       for (int j = threadIdx.x; j < N * T::NBK; j += T::THREADS) bk[j] = 0;
       if (threadIdx.x < N) rmin[threadIdx.x] = 0x7fffffff, rmax[threadIdx.x] = 0;
       if (threadIdx.x == 0) *degenerate = 0;
+      // the replicas' TopOne vectors of the key (KeyValueStore.scala:229-230), the carries of the scans: requested
+      // here, parked in LDS before the scans need them (held in registers across the key they spilled)
+      if (w == 0 && lane < 2 * N) {
+        const size_t ib = ((size_t)r * st.num_keys + k) * N;
+        carry_in = lane < N ? st.gets[ib + lane] : st.sets[ib + lane - N];
+      }
     }
     const int kn = k + gridDim.x;
     const bool more = kn < st.num_keys;
@@ -480,6 +500,7 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
         atomicMax(&mytot[((fl >> 3) & 1) * N + (fl & 7)], RF(1, sl) + 1);
       }
     }
+    if (w == 0 && lane < 2 * N) base[r * 2 * N + lane] = carry_in;
     __syncthreads();
     // ---- the segmented scans (the sort buffers are spent: their place takes the conflict rows).  Row n-2 of a command
     // is its leader's own conflicts D (the PreAccept's dependencies), rows 0 .. n-3 those of the replicas whose
@@ -487,7 +508,7 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
     {
       int cg[N], cs[N], ng[N], ns[N];
 #pragma unroll
-      for (int l = 0; l < N; ++l) cg[l] = cur.cg[l], cs[l] = cur.cs[l], ng[l] = 0, ns[l] = 0;
+      for (int l = 0; l < N; ++l) cg[l] = base[r * 2 * N + l], cs[l] = base[r * 2 * N + N + l], ng[l] = 0, ns[l] = 0;
       for (int w2 = 0; w2 < w; ++w2) {
         const int* o = tot + (r * T::W + w2) * 2 * N;
 #pragma unroll
@@ -577,10 +598,7 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
       for (int j = 0; j < N * T::W; ++j) v = imax(v, tot[j * 2 * N + lane]);
       const size_t ib = ((size_t)r * st.num_keys + k) * N;
       int32_t* p = lane < N ? &st.gets[ib + lane] : &st.sets[ib + lane - N];
-      int old = 0;
-#pragma unroll
-      for (int l = 0; l < N; ++l) old = (lane == l) ? cur.cg[l] : (lane == N + l) ? cur.cs[l] : old;
-      if (v > old) *p = v;
+      if (v > base[r * 2 * N + lane]) *p = v;
     }
     __syncthreads();  // the tables are reused by the next key
     cur = nxt;
