@@ -162,6 +162,8 @@ void make_geom(const fpx_config& c, Geom* g) {
   g->S = c.num_slots;
   g->R = c.num_replicas;
   g->RS = (c.num_replicas + 3) & ~3;
+  // small groups (R <= 4): the vote round and vote value rows of a slot share one 32-byte sector
+  { const char* il = getenv("FPX_INTERLEAVE"); g->VS = (g->RS == 4 && il && atoi(il) != 0) ? 8 : g->RS; }
   g->num_groups = c.num_groups;
   g->num_leader_groups = c.num_leader_groups;
   g->ngroups = c.num_groups * c.num_leader_groups;
@@ -387,8 +389,12 @@ int init_state(fpx_ctx* ctx) {
   const size_t ncell = (size_t)g.S * g.RS, nsc = (size_t)g.ngroups * g.R;
   HIPCHK(ctx, hipMemsetAsync(st.promised, 0xFF, nsc * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.max_voted, 0xFF, nsc * 4, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(st.vote_round, 0xFF, ncell * 4, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(st.vote_value, 0xFF, ncell * 4, ctx->stream));
+  if (g.VS != g.RS) {
+    HIPCHK(ctx, hipMemsetAsync(st.vote_round, 0xFF, ncell * 8, ctx->stream));  // both rows of every slot, interleaved
+  } else {
+    HIPCHK(ctx, hipMemsetAsync(st.vote_round, 0xFF, ncell * 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(st.vote_value, 0xFF, ncell * 4, ctx->stream));
+  }
   if (st.ballot) HIPCHK(ctx, hipMemsetAsync(st.ballot, 0xFF, ncell * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.pl_key, 0, (size_t)g.S * g.wp * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.pl_value, 0xFF, (size_t)g.S * g.wp * 4, ctx->stream));
@@ -835,7 +841,8 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
     ctx->bytes += (int64_t)(stride * narr);
     ctx->slab = slab;
     st.vote_round = (int32_t*)slab;
-    st.vote_value = (int32_t*)(slab + stride);
+    st.vote_value = g.VS != g.RS ? st.vote_round + g.RS : (int32_t*)(slab + stride);  // interleaved: the slab's first two
+                                                                                      // arrays are one [S][2][RS] array
     st.ballot = g.per_slot ? (int32_t*)(slab + 2 * stride) : nullptr;
   }
   if ((rc = dalloc(ctx, &st.pl_key, (size_t)g.S * g.wp))) return fail(rc);
@@ -1311,9 +1318,9 @@ int32_t fpx_recycle_slots(fpx_ctx* ctx, int32_t first_slot, int32_t count) {
   DeviceGuard _dg(ctx);
   if (!ctx || first_slot < 0 || count < 0 || (int64_t)first_slot + count > ctx->g.S) return FPX_EINVAL;
   if (count == 0) return FPX_OK;
-  const size_t row = (size_t)ctx->g.RS * 4, at = (size_t)first_slot * row, len = (size_t)count * row;
+  const size_t row = (size_t)ctx->g.VS * 4, at = (size_t)first_slot * row, len = (size_t)count * row;
   HIPCHK(ctx, hipMemsetAsync((char*)ctx->st.vote_round + at, 0xFF, len, ctx->stream));  // -1: no vote
-  HIPCHK(ctx, hipMemsetAsync((char*)ctx->st.vote_value + at, 0xFF, len, ctx->stream));
+  if (ctx->g.VS == ctx->g.RS) HIPCHK(ctx, hipMemsetAsync((char*)ctx->st.vote_value + at, 0xFF, len, ctx->stream));
   if (ctx->st.row_voted) HIPCHK(ctx, hipMemsetAsync(ctx->st.row_voted + first_slot, 0, (size_t)count, ctx->stream));
   return fpx_proxy_forget(ctx, first_slot, count);
 }
@@ -1355,9 +1362,15 @@ static int enqueue_ranges(fpx_ctx* ctx, RangeBatch& b, int mode) {
   if (acceptors) {
     const long long threads = (long long)b.n * g.num_groups * g.R;
     hipLaunchKernelGGL(k_ranges_acceptors, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, g, ctx->st, b);
-    const int gy = std::min(b.n, 4096);
-    const int gx = std::max(1, std::min(ctx->num_cus * 16 / gy, 64));
-    hipLaunchKernelGGL(k_ranges_fill, dim3(gx, gy), dim3(256), 0, ctx->stream, g, ctx->st, b);
+    if (b.n <= RF_MAXN && g.num_leader_groups <= RF_MAXL && !getenv("FPX_RANGES_FILL_V1")) {
+      // sweep the log rows the ranges touch in memory order (fpx_ranges.hpp)
+      hipLaunchKernelGGL(k_ranges_fill_rows, dim3(ctx->num_cus * 8), dim3(256), (size_t)RF_JB * g.num_leader_groups * 4,
+                         ctx->stream, g, ctx->st, b);
+    } else {
+      const int gy = std::min(b.n, 4096);
+      const int gx = std::max(1, std::min(ctx->num_cus * 16 / gy, 64));
+      hipLaunchKernelGGL(k_ranges_fill, dim3(gx, gy), dim3(256), 0, ctx->stream, g, ctx->st, b);
+    }
   }
   if (mode == RANGES_TALLY) hipLaunchKernelGGL(k_ranges_open, dim3(gn), dim3(256), 0, ctx->stream, g, ctx->st, rt, b, 1);
   if (mode == RANGES_FUSED || mode == RANGES_TALLY)
@@ -1713,9 +1726,9 @@ int32_t fpx_read_state(fpx_ctx* ctx, int32_t* vote_round, int32_t* vote_value, i
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   // device rows are RS cells long, the caller's are R
   if (vote_round)
-    HIPCHK(ctx, hipMemcpy2D(vote_round, R * 4, ctx->st.vote_round, RS * 4, R * 4, S, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy2D(vote_round, R * 4, ctx->st.vote_round, (size_t)ctx->g.VS * 4, R * 4, S, hipMemcpyDeviceToHost));
   if (vote_value)
-    HIPCHK(ctx, hipMemcpy2D(vote_value, R * 4, ctx->st.vote_value, RS * 4, R * 4, S, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy2D(vote_value, R * 4, ctx->st.vote_value, (size_t)ctx->g.VS * 4, R * 4, S, hipMemcpyDeviceToHost));
   if (ballot) {
     if (ctx->st.ballot)
       HIPCHK(ctx, hipMemcpy2D(ballot, R * 4, ctx->st.ballot, RS * 4, R * 4, S, hipMemcpyDeviceToHost));
@@ -1989,9 +2002,9 @@ int32_t fpx_state_digest(fpx_ctx* ctx, uint64_t out[8]) {
   const int big = ctx->num_cus * 16;
   const size_t n4 = (size_t)g.S * (size_t)(g.RS / 4);
   const int gc = (int)std::max<size_t>(1, std::min<size_t>((n4 + 255) / 256, (size_t)big));
-  hipLaunchKernelGGL(k_digest_cells, dim3(gc), dim3(256), 0, ctx->stream, g, ctx->st.vote_round, d + 0);
-  hipLaunchKernelGGL(k_digest_cells, dim3(gc), dim3(256), 0, ctx->stream, g, ctx->st.vote_value, d + 1);
-  if (ctx->st.ballot) hipLaunchKernelGGL(k_digest_cells, dim3(gc), dim3(256), 0, ctx->stream, g, ctx->st.ballot, d + 2);
+  hipLaunchKernelGGL(k_digest_cells, dim3(gc), dim3(256), 0, ctx->stream, g, ctx->st.vote_round, g.VS, d + 0);
+  hipLaunchKernelGGL(k_digest_cells, dim3(gc), dim3(256), 0, ctx->stream, g, ctx->st.vote_value, g.VS, d + 1);
+  if (ctx->st.ballot) hipLaunchKernelGGL(k_digest_cells, dim3(gc), dim3(256), 0, ctx->stream, g, ctx->st.ballot, g.RS, d + 2);
   const int nsc = g.ngroups * g.R;
   const int gs = std::max(1, std::min((nsc + 255) / 256, big));
   hipLaunchKernelGGL(k_digest_1d, dim3(gs), dim3(256), 0, ctx->stream, ctx->st.promised, nsc, d + 3);

@@ -67,6 +67,9 @@ enum { ST_CODE = 0, ST_INDEX = 1, ST_SLOT = 2, ST_ROUND = 3, ST_ABORT = 4 };
 
 struct Geom {
   int32_t S, R;
+  int32_t VS;                                      // row stride of vote_round / vote_value: RS, or 2 RS when the two rows of
+                                                   // a slot are interleaved (R <= 4: [round x 4 | value x 4] is ONE 32-byte sector;
+                                                   // as two arrays every small-group vote wrote two half sectors)
   int32_t RS;                                      // row stride of the cell arrays: R rounded up to a multiple of 4,
                                                    // so that every lane moves one aligned int4 whatever R is
   int32_t num_groups, num_leader_groups, ngroups;  // ngroups = num_leader_groups * num_groups
@@ -82,8 +85,8 @@ struct Geom {
 struct State {
   int32_t* promised;    // [ngroups][R]   Acceptor.round
   int32_t* max_voted;   // [ngroups][R]   Acceptor.maxVotedSlot
-  int32_t* vote_round;  // [S][R]
-  int32_t* vote_value;  // [S][R]
+  int32_t* vote_round;  // [S][VS]  (cell (s, r) at s * VS + r)
+  int32_t* vote_value;  // [S][VS]  (= vote_round + RS when the rows are interleaved)
   int32_t* ballot;      // [S][R] or null
   uint32_t* pl_key;     // [S][wp]        0 = empty, else (round + 1) | KEY_DONE
   int32_t* pl_value;    // [S][wp]
@@ -576,7 +579,7 @@ __global__ void __launch_bounds__(256)
         // first votes of the slot: cells whose acceptor does not vote hold -1 / -1.  ONE store path for the whole
         // row (fully voted cells included): two half-masked store instructions per array cost the issue
         // slots of two full ones
-        const size_t row = (size_t)s * (size_t)g.RS + (size_t)r0;
+        const size_t row = (size_t)s * (size_t)g.RS + (size_t)r0, vrow = (size_t)s * (size_t)g.VS + (size_t)r0;
         int4v rr, vv, nb = thr;
         bool ballot_moves = false;
 #pragma unroll
@@ -585,17 +588,17 @@ __global__ void __launch_bounds__(256)
           rr[k] = a ? rnd : -1, vv[k] = a ? val : -1;
           if (a) ballot_moves = ballot_moves || thr[k] != rnd, nb[k] = rnd;
         }
-        row_store(rr, reinterpret_cast<int4v*>(st.vote_round + row));
-        row_store(vv, reinterpret_cast<int4v*>(st.vote_value + row));
+        row_store(rr, reinterpret_cast<int4v*>(st.vote_round + vrow));
+        row_store(vv, reinterpret_cast<int4v*>(st.vote_value + vrow));
         if (PERSLOT && ballot_moves) row_store(nb, reinterpret_cast<int4v*>(st.ballot + row));
       } else if (acc) {
-        const size_t row = (size_t)s * (size_t)g.RS + (size_t)r0;
+        const size_t row = (size_t)s * (size_t)g.RS + (size_t)r0, vrow = (size_t)s * (size_t)g.VS + (size_t)r0;
         // whole-lane fast path: every acceptor this lane owns voted (padding cells may be overwritten)
         if (VEC && full_cell) {
           const int4v rr = {rnd, rnd, rnd, rnd};
           const int4v vv = {val, val, val, val};
-          row_store(rr, reinterpret_cast<int4v*>(st.vote_round + row));
-          row_store(vv, reinterpret_cast<int4v*>(st.vote_value + row));
+          row_store(rr, reinterpret_cast<int4v*>(st.vote_round + vrow));
+          row_store(vv, reinterpret_cast<int4v*>(st.vote_value + vrow));
           if (PERSLOT) {
             if (((own & 1u) && thr[0] != rnd) || ((own & 2u) && thr[1] != rnd) || ((own & 4u) && thr[2] != rnd) ||
                 ((own & 8u) && thr[3] != rnd))
@@ -607,8 +610,8 @@ __global__ void __launch_bounds__(256)
           // sectors that cost a DRAM read-modify-write each at eviction (+15 % on random f+1 of 255,
           // profiles/r01_thrifty.txt).  Its own instantiation: the load in the step costs registers (one
           // wave less per SIMD) and a wait that contiguous or dense targets do not want.
-          int4v* pr = reinterpret_cast<int4v*>(st.vote_round + row);
-          int4v* pv = reinterpret_cast<int4v*>(st.vote_value + row);
+          int4v* pr = reinterpret_cast<int4v*>(st.vote_round + vrow);
+          int4v* pv = reinterpret_cast<int4v*>(st.vote_value + vrow);
           int4v orr = *pr, ovv = *pv;
           int4v nb = {thr[0], thr[1], thr[2], thr[3]};
           bool ballot_moves = false;
@@ -627,8 +630,8 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             if (acc >> k & 1u) {
-              st.vote_round[row + k] = rnd;
-              st.vote_value[row + k] = val;
+              st.vote_round[vrow + k] = rnd;
+              st.vote_value[vrow + k] = val;
               if (PERSLOT && thr[k] != rnd) st.ballot[row + k] = rnd;
             }
           }
@@ -1077,9 +1080,9 @@ __global__ void __launch_bounds__(256) k_gather_acceptor(const Geom g, const Sta
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= g.S) return;
   const bool mine = group_of_slot(g, s) == group;
-  const size_t c = (size_t)s * g.RS + replica;
-  vr[s] = mine ? st.vote_round[c] : -1;
-  vv[s] = mine ? st.vote_value[c] : -1;
+  const size_t c = (size_t)s * g.RS + replica, vc = (size_t)s * g.VS + replica;
+  vr[s] = mine ? st.vote_round[vc] : -1;
+  vv[s] = mine ? st.vote_value[vc] : -1;
   bl[s] = (mine && st.ballot) ? st.ballot[c] : -1;
 }
 
@@ -1240,7 +1243,7 @@ __global__ void __launch_bounds__(256)
     int best_round = -1, best_val = -1, best_idx = 1 << 30;
     if (live && r0 < g.R) {
       const int grp = group_of_slot(g, s);
-      const size_t row = (size_t)s * g.RS + r0;
+      const size_t row = (size_t)s * g.VS + r0;
       int vr[4] = {-1, -1, -1, -1}, vv[4] = {-1, -1, -1, -1};
       if (vec) {
         const int4v a = *reinterpret_cast<const int4v*>(st.vote_round + row);
@@ -1324,14 +1327,14 @@ __device__ __forceinline__ void block_add_u64(uint64_t v, uint64_t* out) {
 }
 
 // a cell array [S][RS]: element (s, r), r < R, contributes digest_term(s * R + r, a[s][r])
-__global__ void __launch_bounds__(256) k_digest_cells(const Geom g, const int32_t* a, uint64_t* out) {
-  const size_t q = (size_t)(g.RS >> 2);  // int4's per row
+__global__ void __launch_bounds__(256) k_digest_cells(const Geom g, const int32_t* a, int stride, uint64_t* out) {
+  const size_t q = (size_t)(g.RS >> 2);  // int4's per row; row s starts at a + s * stride
   const size_t n4 = (size_t)g.S * q;
   uint64_t acc = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const size_t s = i / q;
     const int r0 = (int)(i - s * q) * 4;
-    const int4v v = *reinterpret_cast<const int4v*>(a + i * 4);
+    const int4v v = *reinterpret_cast<const int4v*>(a + s * (size_t)stride + (size_t)r0);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (r0 + k < g.R) acc += digest_term(s * (size_t)g.R + (size_t)(r0 + k), v[k]);

@@ -211,12 +211,122 @@ __global__ void __launch_bounds__(256) k_ranges_fill(const Geom g, const State s
       const int r = (int)(c % g.R);
       const int ag = (s / L) % A, bit = g.base + r;
       if ((votes[(size_t)ag * 4 + (bit >> 6)] >> (bit & 63)) & 1ull) {
-        const size_t cell = (size_t)s * g.RS + r;
+        const size_t cell = (size_t)s * g.VS + r;
         st.vote_round[cell] = round;  // :271-276 State(voteRound = round, voteValue = Noop)
         st.vote_value[cell] = -1;
         if (st.row_voted[s] == 0) st.row_voted[s] = 1;
       }
     }
+  }
+}
+
+// The same, walking the LOG instead of the ranges.  One range writes a 16-byte row (R = 3) every L x 16 B = 4 KB: a
+// different DRAM page per store, 3 four-byte stores per row (k_ranges_fill above: 0.8 TB/s of written bytes on
+// BASELINE.json configs[4]).  Here a workgroup takes a span of RF_JB consecutive rows of L slots, marks in LDS which
+// range (if any) covers each slot, and sweeps the span in memory order: the rows of neighbouring leader groups that
+// skip are neighbours in memory, every row of fully voting acceptors leaves as one aligned 16-byte store per array.
+// Measured on configs[4] (every other leader group skips: a 16-byte row every 32 bytes): 67 us, the same as the
+// range-major kernel -- and the same again with the two vote arrays interleaved into one 32-byte sector per slot
+// (FPX_INTERLEAVE=1), which halves the bytes written (138 -> 71 MB).  So neither DRAM page locality nor bytes bound
+// it; what is left is one request per 16 useful bytes (profiles/r03_cfg5.md).
+// Two ranges of the launch that cover the same slot (a leader group that sends overlapping ranges in one tick) send
+// the span through a per-slot loop over all ranges instead.  Chosen by the host for launches of at most RF_MAXN ranges.
+constexpr int RF_JB = 8, RF_MAXN = 1024, RF_MAXL = 2048;
+__global__ void __launch_bounds__(256) k_ranges_fill_rows(const Geom g, const State st, const RangeBatch b) {
+  extern __shared__ uint32_t rf_own[];  // [RF_JB][L] index + 1 of the range that covers the slot, 0 = none
+  __shared__ int span_lo, span_hi, overlap;
+  if (st.status[ST_ABORT] != 0) return;
+  const int A = g.num_groups, L = g.num_leader_groups, Q = g.RS >> 2;
+  if (threadIdx.x == 0) span_lo = 0x7fffffff, span_hi = -1;
+  __syncthreads();
+  {
+    int lo = 0x7fffffff, hi = -1;
+    for (int i = threadIdx.x; i < b.n; i += 256) {
+      if (b.fused && b.entry[i] < 0) continue;
+      const int s0 = b.start[i], e0 = b.end[i];
+      if (e0 <= s0) continue;
+      lo = min(lo, s0 / L), hi = max(hi, (e0 - 1 - s0 % L) / L);  // rows of its first and last slot
+    }
+    if (hi >= 0) atomicMin(&span_lo, lo), atomicMax(&span_hi, hi);
+  }
+  __syncthreads();
+  const int r_lo = span_lo, r_hi = span_hi;
+  if (r_hi < r_lo) return;
+  const int nspans = (r_hi - r_lo) / RF_JB + 1;
+  for (int q = blockIdx.x; q < nspans; q += gridDim.x) {
+    const int j0 = r_lo + q * RF_JB;
+    for (int t = threadIdx.x; t < RF_JB * L; t += 256) rf_own[t] = 0;
+    if (threadIdx.x == 0) overlap = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < b.n; i += 256) {
+      if (b.fused && b.entry[i] < 0) continue;
+      const int s0 = b.start[i], e0 = b.end[i];
+      if (e0 <= s0) continue;
+      const int lg = s0 % L, ja = max(s0 / L, j0), jb = min((e0 - 1 - lg) / L, j0 + RF_JB - 1);
+      for (int j = ja; j <= jb; ++j) {
+        const uint32_t old = atomicCAS(&rf_own[(j - j0) * L + lg], 0u, (uint32_t)i + 1u);
+        if (old != 0 && old != (uint32_t)i + 1u) overlap = 1;
+      }
+    }
+    __syncthreads();
+    const bool slow = overlap != 0;
+    // one row of L x Q quads at a time (no division by run-time values per cell when Q == 1)
+    for (int jrel = 0; jrel < RF_JB; ++jrel)
+    for (int u = threadIdx.x; u < L * Q; u += 256) {
+      const int lg = Q == 1 ? u : u / Q, quad = Q == 1 ? 0 : u - lg * Q;
+      const uint32_t o = rf_own[jrel * L + lg];
+      if (o == 0) continue;
+      const int row = j0 + jrel, s = row * L + lg, ag = row % A, r0 = quad * 4;
+      unsigned voted = 0, valid = 0;
+      int round = 0;
+      if (!slow) {
+        const int i = (int)o - 1;
+        const uint64_t* votes = b.vote_bits + ((size_t)i * A + ag) * 4;
+#ifdef RF_X_NOLOAD
+        round = i & 1, voted = valid = 7;
+        if (round == 5)
+#endif
+        round = b.round[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int bit = g.base + r0 + c;
+          if (r0 + c < g.R) valid |= 1u << c, voted |= (unsigned)((votes[bit >> 6] >> (bit & 63)) & 1ull) << c;
+        }
+      } else {  // every range that covers the slot (one round per leader group and launch: the votes are a union)
+        for (int i = 0; i < b.n; ++i) {
+          if (b.fused && b.entry[i] < 0) continue;
+          const int s0 = b.start[i], e0 = b.end[i];
+          if (s < s0 || s >= e0 || s0 % L != lg) continue;
+          const uint64_t* votes = b.vote_bits + ((size_t)i * A + ag) * 4;
+          round = b.round[i];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int bit = g.base + r0 + c;
+            if (r0 + c < g.R) valid |= 1u << c, voted |= (unsigned)((votes[bit >> 6] >> (bit & 63)) & 1ull) << c;
+          }
+        }
+      }
+      if (voted == 0) continue;
+      const size_t cell = (size_t)s * g.VS + r0;
+#ifdef RF_X_NOSTORE
+      if (round == -12345) st.row_voted[s] = 1;
+      continue;
+#endif
+      if (voted == valid) {  // :271-276 State(voteRound = round, voteValue = Noop); padding cells stay -1
+        int4 vr = make_int4(round, round, round, round);
+        if (!(valid & 2u)) vr.y = -1;
+        if (!(valid & 4u)) vr.z = -1;
+        if (!(valid & 8u)) vr.w = -1;
+        *reinterpret_cast<int4*>(st.vote_round + cell) = vr;
+        *reinterpret_cast<int4*>(st.vote_value + cell) = make_int4(-1, -1, -1, -1);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if ((voted >> c) & 1u) st.vote_round[cell + c] = round, st.vote_value[cell + c] = -1;
+      }
+      st.row_voted[s] = 1;
+    }
+    __syncthreads();
   }
 }
 

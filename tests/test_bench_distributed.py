@@ -62,7 +62,9 @@ def test_group_sharded_bench_two_ranks():
     # every rank commits its own 2^20 slots per step: whole-job value counts both
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 * 3 - 2 * 3 * (1 << 20)) < 1e-3 * 2 * 3 * (1 << 20)
     assert d["roofline"]["launches_timed"] == 3 and d["roofline"]["frac"] > 0
-    assert "cpu_baseline" not in d
+    # the CPU baseline rides on every line, at N > 1 the single-thread flat port only (rank 0 times it)
+    assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    assert d["rccl_ranks"] == 0 and "rccl" not in d           # gloo hook: no RCCL communicator was created
 
 
 def test_replica_sharded_bench_two_ranks():
