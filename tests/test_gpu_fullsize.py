@@ -176,3 +176,81 @@ def test_config5_mencius_256_leader_groups_4m_slots(fa, oracle):
         assert a[:2] == b[:2]
         for x, y in zip(a[2:], b[2:]):
             np.testing.assert_array_equal(x, y)
+
+
+def test_epaxos_full_size_scenario_with_the_command_log(oracle):
+    """BASELINE.json configs[3] end to end AT SIZE with the command log kept (K6 / K7 were only
+    held at <= 5 000 messages): a tick of 2^20 commands (K5) -> every slow-path command through the Accept phase
+    (fpx_epx_accept, K6: ~800 000 instances, quorum f + 1) -> 2^18 PreAccepts once more at random replicas in old and
+    new ballots (fpx_epx_handle_preaccept, K7: re-sent replies, Nacks, Commits sent back, fresh processing) -> a second
+    tick on top.  Every output array of every step, the conflict indexes and a sample of the command log equal the
+    oracle's."""
+    from frankenpaxos_amd.epaxos import EPaxos
+    from tests.workloads import random_tick
+
+    n, num_keys, m, NI = 5, 1024, 1 << 20, 1 << 19
+    gpu, ref = EPaxos(n, num_keys, num_instances=NI), oracle.EPaxos(n, num_keys, num_instances=NI)
+    rng = np.random.default_rng(2020)
+    nxt = [0] * n
+
+    def same(a, b, what):
+        assert a[0] == b[0] == 0, (what, a[0], b[0])
+        for j, (x, y) in enumerate(zip(a[1:], b[1:])):
+            np.testing.assert_array_equal(np.asarray(x), np.asarray(y), err_msg="%s output %d" % (what, j))
+
+    # 1. the tick
+    leader, number, key, is_set, mask, rank = random_tick(rng, n, num_keys, m, nxt, 3000.0, fifo=False)   # reordering
+    tr = np.arange(m, dtype=np.int32)                                    # channels: most answers differ -> slow path
+    a, b = (e.preaccept(leader, number, key, is_set, mask, rank, triple_id=tr) for e in (gpu, ref))
+    same(a, b, "tick 1")
+    fast = a[1].astype(bool)
+    assert 0 < fast.sum() < m
+    # 2. 2^18 PreAccepts of the tick's instances once more, at random replicas: half in their original ballot (re-sent
+    #    replies where the replica voted in it, fresh processing where it never saw the instance, Commit sent back for
+    #    the fast-path commits), half in a higher ballot of another replica (processed afresh; Nacked by replicas that
+    #    have meanwhile seen a still higher one)
+    pick = rng.choice(m, size=1 << 18, replace=False)
+    hl, hx = leader[pick], number[pick]
+    tgt = rng.integers(1, 1 << n, len(pick)).astype(np.uint8)
+    din = rng.integers(0, max(nxt), (len(pick), n)).astype(np.int32)
+    din[np.arange(len(pick)), hl] = np.minimum(din[np.arange(len(pick)), hl], hx)     # own column: a plain watermark
+    dend = np.zeros(len(pick), np.int32)
+    higher = rng.random(len(pick)) < 0.5
+    counts = np.zeros(4, np.int64)
+    for round_ in range(2):   # second round: the same PreAccepts in the ORIGINAL ballots -- below what round one left
+        b_ord = np.where(higher & (round_ == 0), rng.integers(1, 3, len(pick)), 0).astype(np.int32)
+        b_rep = np.where(higher & (round_ == 0), rng.integers(0, n, len(pick)), hl).astype(np.int32)
+        a, b = (e.handle_preaccept(hl, hx, b_ord, b_rep, key[pick], is_set[pick], (tr[pick] + (2 + round_) * m).astype(np.int32),
+                                   din, dend, tgt) for e in (gpu, ref))
+        same(a, b, "handle_preaccept %d" % round_)
+        counts += [int(np.unpackbits(np.asarray(x)).sum()) for x in a[1:5]]           # ok, resend, nack, commit
+    assert all(c > 1000 for c in counts), counts
+    # 3. Accept phase of the slow-path commands: every leader proposes in Ballot(3, leader) -- above everything step 2
+    #    used -- to f = 2 of the 4 other replicas
+    slow = np.nonzero(~fast)[0]
+    sl, sx = leader[slow], number[slow]
+    others = np.array([[r for r in range(n) if r != L] for L in range(n)])
+    two = np.argsort(rng.random((len(slow), n - 1)), axis=1)[:, :2]
+    tgt = np.zeros(len(slow), np.uint8)
+    for j in range(2):
+        tgt |= (1 << others[sl, two[:, j]]).astype(np.uint8)
+    a, b = (e.accept(sl, sx, np.full(len(slow), 3, np.int32), sl, (tr[slow] + m).astype(np.int32), tgt, key[slow], is_set[slow])
+            for e in (gpu, ref))
+    same(a, b, "accept")
+    assert int(np.asarray(a[5]).sum()) == len(slow)                                   # all commit: proposer + 2 = f + 1
+    # 4. a second tick on top of all that
+    leader2, number2, key2, is_set2, mask2, rank2 = random_tick(rng, n, num_keys, 1 << 18, nxt, 64.0, fifo=False)
+    a, b = (e.preaccept(leader2, number2, key2, is_set2, mask2, rank2, triple_id=np.arange(1 << 18, dtype=np.int32) + 4 * m)
+            for e in (gpu, ref))
+    same(a, b, "tick 2")
+    # state: every conflict index, and the command log where the steps above left the most different entries
+    for r in range(n):
+        for k in range(0, num_keys, 7):
+            for x, y in zip(gpu.read_index(r, k), ref.read_index(r, k)):
+                np.testing.assert_array_equal(x, y)
+    for r in range(n):
+        for j in rng.choice(m, size=120, replace=False):
+            L, x = int(leader[j]), int(number[j])
+            assert gpu.read_cmdlog(r, L, x) == ref.read_cmdlog(r, L, x)
+            c, d = gpu.read_cmdlog_deps(r, L, x), ref.read_cmdlog_deps(r, L, x)
+            assert c[0].tolist() == d[0].tolist() and c[1] == d[1]
