@@ -46,7 +46,7 @@ struct RcclApi {
   const char* (*GetErrorString)(int) = nullptr;
 };
 static_assert(sizeof(RcclUniqueId) == FPX_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
-enum { RCCL_SUM = 0, RCCL_UINT8 = 1, RCCL_INT32 = 2, RCCL_UINT64 = 5 };
+enum { RCCL_SUM = 0, RCCL_MAX = 2, RCCL_UINT8 = 1, RCCL_INT32 = 2, RCCL_UINT64 = 5 };  // ncclRedOp_t / ncclDataType_t values
 
 struct fpx_ctx {
   fpx_config cfg;
@@ -1949,6 +1949,12 @@ int32_t fpx_phase2_replica_sharded_dev(fpx_ctx* ctx, int32_t n, const int32_t* d
       ctx->cev_used += 2;
     }
     mine = (const uint64_t*)ctx->d_mine.p;
+    // a Nack from ANY rank's acceptors reaches the caller (Leader.handleNack reacts to the largest round, Leader.scala:
+    // 672-697): max over the ranks, 4 B per slot more on the wire
+    if (d_nack_round && world > 1) {
+      if (!r->AllReduce) return FPX_ERCCL;
+      RCCLCHK(ctx, r->AllReduce(d_nack_round, d_nack_round, (size_t)n, RCCL_INT32, RCCL_MAX, ctx->comm, ctx->stream));
+    }
   }
   // ProxyLeader.handlePhase2a bookkeeping + handlePhase2b for my slice of the slots; K1's validation pass
   // covered the whole batch (slots distinct), so the slice needs none

@@ -55,6 +55,15 @@ def allreduce_vote_bitmaps(bitmaps, group=None):
     return bitmaps
 
 
+def allreduce_nack_rounds(nack_round, group=None):
+    """in-place all-reduce(max) of the per-message Nack rounds: a Nack from any rank's acceptors reaches the
+    leader (fpx_phase2_replica_sharded_dev does the same with ncclAllReduce(ncclMax) behind the C ABI)"""
+    import torch.distributed as dist
+
+    dist.all_reduce(nack_round, op=dist.ReduceOp.MAX, group=group)
+    return nack_round
+
+
 def slot_slice(n, world, rank):
     """[lo, hi) of the messages whose tally `rank` runs after a reduce-scatter of the bitmaps"""
     if n % world:

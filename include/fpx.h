@@ -589,7 +589,8 @@ int32_t fpx_last_rccl_error(fpx_ctx* ctx);
  * words over the WHOLE group (bit j = acceptor j of replicas_total) or NULL.  Outputs cover this rank's
  * slice of the batch, messages [rank * n / world, (rank + 1) * n / world): d_chosen / d_chosen_round /
  * d_chosen_value have n / world entries (as fpx_proxy_phase2b_dev); d_nack_round (n entries or NULL) is the
- * largest round Nacked by THIS rank's acceptors.  Without a communicator (world 1) it is K1 + open + K2. */
+ * largest round Nacked by ANY rank's acceptors (ncclAllReduce(ncclMax) of the ranks' own, in place: the same n
+ * values on every rank).  Without a communicator (world 1) it is K1 + open + K2. */
 int32_t fpx_phase2_replica_sharded_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,
                                        const int32_t* d_value_id, const uint64_t* d_target_mask,
                                        uint8_t* d_chosen, int32_t* d_chosen_round, int32_t* d_chosen_value,

@@ -108,3 +108,28 @@ def test_headline_line_survives_an_extra_row_that_never_finishes():
     d = _run(["--replica-row-steps", "2", "--replica-row-deadline", "0"])
     assert d["n_gpus"] == 2 and d["value"] > 0
     assert "no answer" in d["replica_axis"]["error"]
+
+
+def test_config5_bench_line_on_two_ranks():
+    """BASELINE.json configs[4] sharded by leader group over 2 ranks (gloo hook, both on cuda:0):
+    128 leader groups and half of the band per rank, strong scaling, whole-job value"""
+    d = _run(["--config", "5", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["baseline_config"] == 5
+    assert d["config"]["leader_groups_per_gpu"] == 128 and d["config"]["slots_per_step_per_gpu"] == 1 << 21
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - (1 << 22)) < 1e-3 * (1 << 22)
+
+
+def test_bench_spawns_eight_ranks():
+    """the driver's SCALE run asks for --gpus 8: the self-spawn path with 8 ranks (all on cuda:0 here, gloo)"""
+    env = dict(os.environ, FPX_BENCH_SHARE_GPU="1", FPX_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                          "--replica-row-steps", "0"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 8 * (1 << 20)) < 1e-3 * 8 * (1 << 20)
+    assert d["cpu_baseline"]["cores"] == 1

@@ -136,14 +136,16 @@ def _replica_axis_reduce_scatter(rank):
     rng = np.random.default_rng(42)
     slot, rnd, val = W.steady_stream(S)
     tgt = W.bits_from_bool(W.random_subsets(rng, S, R, 135, 165))
-    shard.acceptor_phase1a(0, 3, 0, W.bits_from_bool((np.arange(R) % 7 == 0)[None, :])[0])
+    shard.acceptor_phase1a(0, 3, 0, W.bits_from_bool((np.arange(R) >= 200)[None, :])[0])   # all on rank 1's shard
     st, vb, nb, nr = shard.acceptor_phase2a(slot, rnd + 2, val, tgt)       # K1: all slots, my acceptors
     mine = sharding.reduce_scatter_vote_bitmaps(torch.from_numpy(vb.view(np.int64).copy()))
     lo, hi = sharding.slot_slice(S, WORLD, rank)
     full = mine.numpy().view(np.uint64)
     shard.proxy_open(slot[lo:hi], rnd[lo:hi] + 2, val[lo:hi])              # K2: my slice of the slots only
     st, ch, cr, cv = shard.proxy_phase2b(slot[lo:hi], rnd[lo:hi] + 2, full)
-    return lo, hi, full.copy(), ch, cv
+    own = nr.copy()
+    nack = sharding.allreduce_nack_rounds(torch.from_numpy(nr.copy())).numpy()  # the Nacks of every rank's acceptors
+    return lo, hi, full.copy(), ch, cv, nack.copy(), own
 
 
 def test_replica_axis_sharding_reduce_scatter_slices_the_tally():
@@ -154,14 +156,17 @@ def test_replica_axis_sharding_reduce_scatter_slices_the_tally():
     rng = np.random.default_rng(42)
     slot, rnd, val = W.steady_stream(S)
     tgt = W.bits_from_bool(W.random_subsets(rng, S, R, 135, 165))
-    whole.acceptor_phase1a(0, 3, 0, W.bits_from_bool((np.arange(R) % 7 == 0)[None, :])[0])
+    whole.acceptor_phase1a(0, 3, 0, W.bits_from_bool((np.arange(R) >= 200)[None, :])[0])   # all on rank 1's shard
     whole.proxy_open(slot, rnd + 2, val)
     st, vb, nb, nr = whole.acceptor_phase2a(slot, rnd + 2, val, tgt)
     st, ch, cr, cv = whole.proxy_phase2b(slot, rnd + 2, vb)
     covered = 0
-    for lo, hi, full, ch_r, cv_r in outs:
+    for lo, hi, full, ch_r, cv_r, nack, own in outs:
         np.testing.assert_array_equal(full, vb[lo:hi])
         np.testing.assert_array_equal(ch_r, ch[lo:hi])
         np.testing.assert_array_equal(cv_r, cv[lo:hi])
+        np.testing.assert_array_equal(nack, nr)             # == the whole group's largest Nacked round per message
         covered += hi - lo
     assert covered == S
+    # ... which no single rank saw on its own: each shard's acceptors Nack only some of the messages
+    assert (nr >= 0).any() and any((own != nr).any() for *_, own in outs)
