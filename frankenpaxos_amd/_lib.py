@@ -98,6 +98,8 @@ SIGNATURES = {
     "fpx_proxy_phase2b": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP, VP, VP]),
     "fpx_proxy_phase2b_dev": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP, VP, VP]),
     "fpx_phase2_fused": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP, VP, VP, VP, VP]),
+    "fpx_phase2_fused_submit": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP, VP, VP, VP, VP, I32P]),
+    "fpx_phase2_fused_wait": (C.c_int32, [VP, C.c_int32]),
     "fpx_phase2_fused_dev": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP, VP, VP, VP, VP]),
     "fpx_acceptor_phase2a_noop_range": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, VP, VP, VP, I32P]),
     "fpx_proxy_open_noop_range": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, U8P]),

@@ -48,6 +48,17 @@ struct RcclApi {
 static_assert(sizeof(RcclUniqueId) == FPX_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
 enum { RCCL_SUM = 0, RCCL_MAX = 2, RCCL_UINT8 = 1, RCCL_INT32 = 2, RCCL_UINT64 = 5 };  // ncclRedOp_t / ncclDataType_t values
 
+// One call in flight: staging buffers of its own, the three events of its pipeline, a page-locked copy of the status
+// words taken right after its fused step.
+constexpr int HOST_DEPTH = 3;
+struct HostSlot {
+  DevBuf in[4], out[4];
+  hipEvent_t up = nullptr, k3 = nullptr, done = nullptr;
+  int32_t* status = nullptr;  // page-locked, 8 words
+  bool busy = false;
+  int n = 0;
+};
+
 struct fpx_ctx {
   fpx_config cfg;
   Geom g;
@@ -80,6 +91,8 @@ struct fpx_ctx {
   size_t ev_used = 0;
   // host-pointer K3 on big batches: upload / K3 / download of consecutive pieces overlap on three streams
   hipStream_t up_stream = nullptr, down_stream = nullptr;
+  HostSlot* hslots = nullptr;  // calls in flight on page-locked arrays (host_submit / host_wait)
+  int hnext = 0;
   std::vector<hipEvent_t> pipe_ev;  // [2 * pieces]: uploaded, computed
   int32_t index_base = 0;           // message index of the piece being launched (error reports are batch-relative)
   bool lazy_active = false;  // PER_SLOT: lazy Phase1a promises may be outstanding (k_phase2 runs its lazy-aware form)
@@ -448,6 +461,19 @@ void free_state(fpx_ctx* ctx) {
   ctx->cev.clear();
   for (hipEvent_t e : ctx->pipe_ev) (void)hipEventDestroy(e);
   ctx->pipe_ev.clear();
+  if (ctx->hslots) {
+    for (int k = 0; k < HOST_DEPTH; ++k) {
+      HostSlot& h = ctx->hslots[k];
+      for (DevBuf& b : h.in)
+        if (b.p) (void)hipFree(b.p);
+      for (DevBuf& b : h.out)
+        if (b.p) (void)hipFree(b.p);
+      if (h.up) (void)hipEventDestroy(h.up), (void)hipEventDestroy(h.k3), (void)hipEventDestroy(h.done);
+      if (h.status) (void)hipHostFree(h.status);
+    }
+    delete[] ctx->hslots;
+    ctx->hslots = nullptr;
+  }
   if (ctx->up_stream) (void)hipStreamDestroy(ctx->up_stream);
   if (ctx->down_stream) (void)hipStreamDestroy(ctx->down_stream);
   if (ctx->d_part.p) (void)hipFree(ctx->d_part.p);
@@ -690,6 +716,163 @@ int host_fused_pipelined(fpx_ctx* ctx, int n, const int32_t* slot, const int32_t
   // the piece that holds the first offender and everything after it applied nothing: replay from its first message
   const int from = (ctx->err_index / piece) * piece;
   return host_fused_replay(ctx, n, slot, round, target_mask != nullptr, from, chosen, chosen_round, chosen_value, nack_round);
+}
+
+// ---- page-locked host batches: staging by kernels instead of by the copy engines ------------------------------
+// hipMemcpyAsync of a page-locked buffer is one SDMA engine per direction: ~25 GB/s on this host interface, and
+// three 4 MB copies each way are 0.5 ms of a 1.09 ms call (profiles/r02_host_path.txt).  Memory from fpx_host_alloc is
+// mapped into the GPU's address space, so a kernel can move it itself: k_stage copies up to four arrays per launch
+// with 16-byte accesses from a few thousand threads (enough requests in flight to fill the link), on its own stream,
+// while the fused step of the previous piece streams HBM.  Used when EVERY array of the call is mapped host memory.
+struct StageJob {
+  const void* src[4];
+  void* dst[4];
+  unsigned long long bytes[4];
+};
+__global__ void __launch_bounds__(256) k_stage(const StageJob j) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const size_t bytes = j.bytes[a];
+    if (!bytes) continue;
+    const bool wide = (((uintptr_t)j.src[a] | (uintptr_t)j.dst[a]) & 15u) == 0;
+    if (wide) {
+      const int4* s = reinterpret_cast<const int4*>(j.src[a]);
+      int4* d = reinterpret_cast<int4*>(j.dst[a]);
+      const size_t n16 = bytes >> 4;
+      for (size_t i = tid; i < n16; i += nth) d[i] = s[i];
+      const unsigned char* sb = reinterpret_cast<const unsigned char*>(j.src[a]);
+      unsigned char* db = reinterpret_cast<unsigned char*>(j.dst[a]);
+      for (size_t i = (n16 << 4) + tid; i < bytes; i += nth) db[i] = sb[i];
+    } else {
+      const unsigned char* sb = reinterpret_cast<const unsigned char*>(j.src[a]);
+      unsigned char* db = reinterpret_cast<unsigned char*>(j.dst[a]);
+      for (size_t i = tid; i < bytes; i += nth) db[i] = sb[i];
+    }
+  }
+}
+
+// the device address of mapped (page-locked) host memory, nullptr for anything else
+void* mapped_host(const void* p) {
+  if (!p) return nullptr;
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();  // pageable memory: "invalid value", not an error of ours
+    return nullptr;
+  }
+  return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
+}
+
+// submit: stage-in (up stream) -> validation + fused step (the context's stream) -> stage-out (down stream); the
+// stage-in of call i + 1 and the stage-out of call i - 1 run beside the fused step of call i.  Every array must be
+// mapped host memory (FPX_EINVAL otherwise).
+int host_submit(fpx_ctx* ctx, int n, const int32_t* slot, const int32_t* round, const int32_t* value_id,
+                const uint64_t* target_mask, uint8_t* chosen, int32_t* chosen_round, int32_t* chosen_value,
+                int32_t* nack_round, int* ticket) {
+  const void* in[4] = {slot, round, value_id, target_mask};
+  void* out[4] = {chosen, chosen_round, chosen_value, nack_round};
+  const void* din[4];
+  void* dout[4];
+  for (int a = 0; a < 4; ++a) {
+    din[a] = mapped_host(in[a]), dout[a] = mapped_host(out[a]);
+    if ((in[a] && !din[a]) || (out[a] && !dout[a])) return FPX_EINVAL;
+  }
+  if (!ctx->hslots) {
+    ctx->hslots = new (std::nothrow) HostSlot[HOST_DEPTH];
+    if (!ctx->hslots) return FPX_ENOMEM;
+  }
+  int t = -1;
+  for (int k = 0; k < HOST_DEPTH && t < 0; ++k)
+    if (!ctx->hslots[(ctx->hnext + k) % HOST_DEPTH].busy) t = (ctx->hnext + k) % HOST_DEPTH;
+  if (t < 0) return FPX_ECAPACITY;  // HOST_DEPTH calls in flight: wait for the oldest first
+  HostSlot& h = ctx->hslots[t];
+  if (!h.up) {
+    HIPCHK(ctx, hipEventCreateWithFlags(&h.up, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&h.k3, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&h.done, hipEventDisableTiming));
+    HIPCHK(ctx, hipHostMalloc((void**)&h.status, 64, hipHostMallocDefault));
+  }
+  if (!ctx->up_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+  if (!ctx->down_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
+  const size_t in_elem[4] = {4, 4, 4, 32}, out_elem[4] = {1, 4, 4, 4};
+  int rc;
+  for (int a = 0; a < 4; ++a) {
+    if (in[a] && (rc = grow(ctx, &h.in[a], (size_t)n * in_elem[a]))) return rc;
+    if ((rc = grow(ctx, &h.out[a], (size_t)n * out_elem[a]))) return rc;
+  }
+  StageJob ji, jo;
+  memset(&ji, 0, sizeof(ji)), memset(&jo, 0, sizeof(jo));
+  for (int a = 0; a < 4; ++a) {
+    if (din[a]) ji.src[a] = din[a], ji.dst[a] = h.in[a].p, ji.bytes[a] = (size_t)n * in_elem[a];
+    if (dout[a]) jo.src[a] = h.out[a].p, jo.dst[a] = dout[a], jo.bytes[a] = (size_t)n * out_elem[a];
+  }
+  hipLaunchKernelGGL(k_stage, dim3(64), dim3(256), 0, ctx->up_stream, ji);
+  HIPCHK(ctx, hipEventRecord(h.up, ctx->up_stream));
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, h.up, 0));
+  {
+    struct Guard {
+      fpx_ctx* c;
+      ~Guard() { c->force_validate = false; }
+    } _g{ctx};
+    ctx->force_validate = true;  // also under FPX_F_TRUSTED: that flag is a promise about _dev batches only
+    rc = fpx_phase2_fused_dev(ctx, n, (int32_t*)h.in[0].p, (int32_t*)h.in[1].p, (int32_t*)h.in[2].p,
+                              target_mask ? (uint64_t*)h.in[3].p : nullptr, (uint8_t*)h.out[0].p, (int32_t*)h.out[1].p,
+                              (int32_t*)h.out[2].p, (int32_t*)h.out[3].p);
+  }
+  if (rc) {
+    (void)hipStreamSynchronize(ctx->stream);
+    return rc;
+  }
+  HIPCHK(ctx, hipMemcpyAsync(h.status, ctx->st.status, 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(h.k3, ctx->stream));
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->down_stream, h.k3, 0));
+  hipLaunchKernelGGL(k_stage, dim3(64), dim3(256), 0, ctx->down_stream, jo);
+  HIPCHK(ctx, hipEventRecord(h.done, ctx->down_stream));
+  if ((rc = launch_check(ctx))) return rc;
+  h.busy = true, h.n = n;
+  ctx->hnext = (t + 1) % HOST_DEPTH;
+  *ticket = t;
+  return FPX_OK;
+}
+
+// the status of call `ticket` as the device left it right after that call's fused step (a run-contract violation or a
+// range error aborts the call -- and the calls queued behind it -- before anything is applied)
+int host_wait(fpx_ctx* ctx, int ticket) {
+  if (!ctx->hslots || ticket < 0 || ticket >= HOST_DEPTH || !ctx->hslots[ticket].busy) return FPX_EINVAL;
+  HostSlot& h = ctx->hslots[ticket];
+  const hipError_t e = hipEventSynchronize(h.done);
+  h.busy = false;
+  if (e != hipSuccess) {
+    ctx->last_hip = (int)e;
+    return FPX_EHIP;
+  }
+  const int st = h.status[0];
+  if (st != 0) {
+    // drain and clear the sticky status (the calls behind this one have aborted too and report it from their own copy)
+    const int now = fetch_status(ctx);
+    if (now == 0) ctx->err_index = h.status[ST_INDEX], ctx->err_slot = h.status[ST_SLOT], ctx->err_round = h.status[ST_ROUND];
+  }
+  return st;
+}
+
+// the synchronous call on page-locked arrays = submit + wait; *used = false: not every array is mapped host memory (or
+// the knob is off, or calls are in flight) -- the caller takes the copy-engine path
+int host_fused_staged(fpx_ctx* ctx, int n, const int32_t* slot, const int32_t* round, const int32_t* value_id,
+                      const uint64_t* target_mask, uint8_t* chosen, int32_t* chosen_round, int32_t* chosen_value,
+                      int32_t* nack_round, bool* used) {
+  *used = false;
+  if (getenv("FPX_HOST_NO_STAGE")) return FPX_OK;
+  int ticket = -1;
+  int rc = host_submit(ctx, n, slot, round, value_id, target_mask, chosen, chosen_round, chosen_value, nack_round, &ticket);
+  if (rc == FPX_EINVAL || rc == FPX_ECAPACITY) return FPX_OK;  // not page-locked / ring busy: the other path
+  *used = true;
+  if (rc) return rc;
+  rc = host_wait(ctx, ticket);
+  if (rc == FPX_EINVAL) return check_inputs(ctx, n, slot, round);  // the FIRST offender, for fpx_error_detail
+  if (rc != FPX_EORDER) return rc;
+  // not one device run: cut into runs on the host and replayed (from the copy-engine path's staging buffers)
+  *used = false;
+  return FPX_OK;
 }
 
 }  // namespace
@@ -1133,6 +1316,11 @@ int32_t fpx_phase2_fused(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int
   if ((rc = grow(ctx, &ctx->d_i32_a, (size_t)n * 4))) return rc;
   if ((rc = grow(ctx, &ctx->d_i32_b, (size_t)n * 4))) return rc;
   if ((rc = grow(ctx, &ctx->d_i32_c, (size_t)n * 4))) return rc;
+  if (n >= 4096) {  // page-locked arrays: staged by kernels, pipelined with the fused step
+    bool used = false;
+    rc = host_fused_staged(ctx, n, slot, round, value_id, target_mask, chosen, chosen_round, chosen_value, nack_round, &used);
+    if (used) return rc;
+  }
   if (n >= 2 * host_piece(ctx, n))
     return host_fused_pipelined(ctx, n, slot, round, value_id, target_mask, chosen, chosen_round, chosen_value, nack_round);
   if ((rc = h2d(ctx, &ctx->d_slot, slot, n))) return rc;
@@ -1166,6 +1354,25 @@ int32_t fpx_phase2_fused(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int
   }
   return host_fused_replay(ctx, n, slot, round, target_mask != nullptr, replay_from, chosen, chosen_round, chosen_value,
                            nack_round);
+}
+
+int32_t fpx_phase2_fused_submit(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round, const int32_t* value_id,
+                                const uint64_t* target_mask, uint8_t* chosen, int32_t* chosen_round, int32_t* chosen_value,
+                                int32_t* nack_round, int32_t* ticket) {
+  DeviceGuard _dg(ctx);
+  int rc = check_args(ctx, n, slot, round);
+  if (rc) return rc;
+  if (n == 0 || !value_id || !ticket) return FPX_EINVAL;
+  int t = -1;
+  rc = host_submit(ctx, n, slot, round, value_id, target_mask, chosen, chosen_round, chosen_value, nack_round, &t);
+  *ticket = t;
+  return rc;
+}
+
+int32_t fpx_phase2_fused_wait(fpx_ctx* ctx, int32_t ticket) {
+  DeviceGuard _dg(ctx);
+  if (!ctx) return FPX_EINVAL;
+  return host_wait(ctx, ticket);
 }
 
 int32_t fpx_proxy_open(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round, const int32_t* value_id,

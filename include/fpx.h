@@ -286,6 +286,21 @@ int32_t fpx_recycle_slots(fpx_ctx* ctx, int32_t first_slot, int32_t count);
 int32_t fpx_phase2_fused(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round,
                          const int32_t* value_id, const uint64_t* target_mask, uint8_t* chosen,
                          int32_t* chosen_round, int32_t* chosen_value, int32_t* nack_round);
+/* The same, asynchronous, for batches in PAGE-LOCKED host memory (fpx_host_alloc or any memory mapped into the GPU's
+ * address space -- FPX_EINVAL otherwise): submit returns at once with a ticket, wait(ticket) blocks until that call's
+ * outputs are in the caller's arrays and returns its status.  Up to 3 calls may be in flight (FPX_ECAPACITY: wait for
+ * the oldest first); they execute in submission order.  The three stages of a call -- inputs over PCIe (a staging
+ * kernel, not a copy engine), validation + fused step, outputs over PCIe -- run on three streams, so with calls
+ * submitted back to back the PCIe transfers of one call hide behind the fused step of its neighbours: 0.6 ms per
+ * 2^20 x 256 call sustained instead of 1.1 ms (profiles/r03_host_path.txt).  A call must be ONE device run (the run
+ * contract above): a violation is FPX_EORDER from wait with nothing applied -- pass that batch to fpx_phase2_fused,
+ * which cuts it into runs.  After an error the calls queued behind the failed one have applied nothing either and
+ * report the same status.  fpx_phase2_fused itself uses submit + wait when it is handed page-locked arrays. */
+int32_t fpx_phase2_fused_submit(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round,
+                                const int32_t* value_id, const uint64_t* target_mask, uint8_t* chosen,
+                                int32_t* chosen_round, int32_t* chosen_value, int32_t* nack_round,
+                                int32_t* ticket);
+int32_t fpx_phase2_fused_wait(fpx_ctx* ctx, int32_t ticket);
 int32_t fpx_phase2_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,
                              const int32_t* d_value_id, const uint64_t* d_target_mask,
                              uint8_t* d_chosen, int32_t* d_chosen_round, int32_t* d_chosen_value,

@@ -695,3 +695,118 @@ def test_pipelined_host_batches(fa, oracle, ballot_mode, monkeypatch):
     check(gpu, ref, [("fused", dup, r2, val, None), ("fused", slot[::-1].copy(), rnd + 3, val, tgt)],
           tally_slots=range(0, S, 997))
     monkeypatch.delenv("FPX_HOST_PIECE")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,shape", [(5000, "steady"), (300000, "steady"), (1 << 20, "steady"), (300000, "repeats"),
+                                      (700001, "rounds")])
+def test_page_locked_batches_are_staged_by_kernels(fa, oracle, n, shape):
+    """fpx_phase2_fused with EVERY array in page-locked memory (fpx_host_alloc): the batch is staged by k_stage on its own
+    streams in pieces, pipelined with the fused step, the outputs are written back to host memory by kernels too.  Same
+    results as the oracle for batches that are one device run (steady), that repeat slots (split into runs by the
+    replay), and that change rounds in the middle; a slot out of range is FPX_EINVAL with its index, nothing applied."""
+    import ctypes as C
+
+    S, R = 1 << 21, 5
+    kw = dict(num_slots=S, num_replicas=R, f=2, tally_ways=8)
+    gpu, ref = fa.Context(fa.make_config(**kw)), oracle.System(oracle.make_config(**kw))
+    rng = np.random.default_rng(n)
+    pins = {k: fa.PinnedArray((n,), dt) for k, dt in (("slot", np.int32), ("rnd", np.int32), ("val", np.int32), ("ch", np.uint8),
+                                                      ("cr", np.int32), ("cv", np.int32), ("nr", np.int32))}
+    tm = fa.PinnedArray((n, 4), np.uint64)
+    slot, rnd, val = pins["slot"].array, pins["rnd"].array, pins["val"].array
+    slot[:] = rng.permutation(S)[:n] if shape != "steady" else np.arange(n)
+    rnd[:] = 0
+    if shape == "repeats":
+        slot[n // 2:] = slot[:n - n // 2]                 # every slot of the first half once more: Done -> ignored
+    if shape == "rounds":
+        rnd[n // 3:] = 2                                  # a leader change in the middle of the batch
+        slot[:] = np.sort(slot)
+    val[:] = W.steady_values(slot)
+    tm.array[:] = 0
+    tm.array[:, 0] = rng.integers(1, 32, n).astype(np.uint64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L = fa.lib()
+    for k in ("ch", "cr", "cv", "nr"):
+        pins[k].array[:] = 77
+    st = L.fpx_phase2_fused(gpu._h, n, p(slot), p(rnd), p(val), p(tm.array), p(pins["ch"].array), p(pins["cr"].array),
+                            p(pins["cv"].array), p(pins["nr"].array))
+    b = ref.phase2_fused(slot.copy(), rnd.copy(), val.copy(), tm.array.copy())
+    assert st == b[0] == 0
+    for got, want in zip((pins["ch"].array, pins["cr"].array, pins["cv"].array, pins["nr"].array), b[1:]):
+        np.testing.assert_array_equal(got, want)
+    assert 0 < int(pins["ch"].array.sum()) < n
+    np.testing.assert_array_equal(gpu.state_digest(), ref.state_digest())
+    # a slot outside the window: refused whole, the first offender reported
+    bad = n * 2 // 3
+    slot[:] = (np.arange(n) + 7) % S
+    slot[bad] = S
+    before = gpu.state_digest()
+    st = L.fpx_phase2_fused(gpu._h, n, p(slot), p(rnd), p(val), None, p(pins["ch"].array), None, p(pins["cv"].array), None)
+    assert st == fa.FPX_EINVAL and gpu.error_detail()[0] == bad
+    np.testing.assert_array_equal(gpu.state_digest(), before)
+    for x in list(pins.values()) + [tm]:
+        x.free()
+
+
+@pytest.mark.gpu
+def test_page_locked_calls_in_flight(fa, oracle):
+    """fpx_phase2_fused_submit / _wait: three calls in flight, waited for in order, equal the oracle fed the same batches
+    in the same order; a fourth submit is FPX_ECAPACITY; pageable arrays are FPX_EINVAL; a batch that is not one device
+    run comes back FPX_EORDER with nothing applied (and the calls queued behind it with it), after which the
+    synchronous call takes the same batch"""
+    import ctypes as C
+
+    S, R, n = 1 << 18, 5, 40000
+    kw = dict(num_slots=S, num_replicas=R, f=2, tally_ways=8)
+    gpu, ref = fa.Context(fa.make_config(**kw)), oracle.System(oracle.make_config(**kw))
+    L = fa.lib()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rng = np.random.default_rng(8)
+
+    def batch(k, shape="run"):
+        a = {name: fa.PinnedArray((n,), dt) for name, dt in (("slot", np.int32), ("rnd", np.int32), ("val", np.int32),
+                                                             ("ch", np.uint8), ("cr", np.int32), ("cv", np.int32), ("nr", np.int32))}
+        a["slot"].array[:] = np.arange(k * n, (k + 1) * n)
+        if shape == "twice":
+            a["slot"].array[n // 2:] = a["slot"].array[:n - n // 2]
+        a["rnd"].array[:] = k % 2
+        a["val"].array[:] = W.steady_values(a["slot"].array) + k
+        return a
+
+    def submit(a):
+        t = C.c_int32(-1)
+        st = L.fpx_phase2_fused_submit(gpu._h, n, p(a["slot"].array), p(a["rnd"].array), p(a["val"].array), None,
+                                       p(a["ch"].array), p(a["cr"].array), p(a["cv"].array), p(a["nr"].array), C.byref(t))
+        return st, t.value
+
+    def same(a):
+        b = ref.phase2_fused(a["slot"].array.copy(), a["rnd"].array.copy(), a["val"].array.copy())
+        assert b[0] == 0
+        for k, want in zip(("ch", "cr", "cv", "nr"), b[1:]):
+            np.testing.assert_array_equal(a[k].array, want)
+
+    bs = [batch(k) for k in range(5)]
+    tickets = [submit(b) for b in bs[:3]]
+    assert [st for st, _ in tickets] == [0, 0, 0] and sorted(t for _, t in tickets) == [0, 1, 2]
+    assert submit(bs[3])[0] == fa.FPX_ECAPACITY
+    for (st, t), b in zip(tickets, bs[:3]):
+        assert L.fpx_phase2_fused_wait(gpu._h, t) == 0
+        same(b)
+    assert L.fpx_phase2_fused_wait(gpu._h, tickets[0][1]) == fa.FPX_EINVAL           # not in flight any more
+    pageable = np.zeros(n, np.int32)
+    t = C.c_int32()
+    assert L.fpx_phase2_fused_submit(gpu._h, n, p(pageable), p(pageable), p(pageable), None, None, None, None, None,
+                                     C.byref(t)) == fa.FPX_EINVAL
+    # a batch that repeats its slots is not one device run
+    bad, after = batch(3, "twice"), bs[4]
+    (s1, t1), (s2, t2) = submit(bad), submit(after)
+    assert s1 == s2 == 0
+    assert L.fpx_phase2_fused_wait(gpu._h, t1) == fa.FPX_EORDER
+    assert L.fpx_phase2_fused_wait(gpu._h, t2) in (fa.FPX_EORDER, 0)
+    np.testing.assert_array_equal(gpu.state_digest(), ref.state_digest())            # nothing of either was applied ...
+    st = L.fpx_phase2_fused(gpu._h, n, p(bad["slot"].array), p(bad["rnd"].array), p(bad["val"].array), None, p(bad["ch"].array),
+                            p(bad["cr"].array), p(bad["cv"].array), p(bad["nr"].array))
+    assert st == 0
+    same(bad)                                                                        # ... the synchronous call splits it
+    np.testing.assert_array_equal(gpu.state_digest(), ref.state_digest())
