@@ -53,6 +53,15 @@ object Native {
                                 chosenRound: java.nio.ByteBuffer, chosenValue: java.nio.ByteBuffer,
                                 nackRound: java.nio.ByteBuffer): Int
 
+  // up to 3 ticks in flight on page-locked batches: submit returns a ticket (< 0: -status), wait its status; the
+  // PCIe transfers of one tick hide behind the fused step of its neighbours (fpx_phase2_fused_submit / _wait)
+  @native def phase2FusedSubmitDirect(handle: Long, n: Int, slot: java.nio.ByteBuffer,
+                                      round: java.nio.ByteBuffer, value: java.nio.ByteBuffer,
+                                      targetMask: java.nio.ByteBuffer, chosen: java.nio.ByteBuffer,
+                                      chosenRound: java.nio.ByteBuffer, chosenValue: java.nio.ByteBuffer,
+                                      nackRound: java.nio.ByteBuffer): Int
+  @native def phase2FusedWait(handle: Long, ticket: Int): Int
+
   // the rows around the fused step
   @native def roundLeader(numLeaders: Int, round: Int): Int // < 0: -status (numLeaders < 1)
   @native def acceptorPhase1a(handle: Long, group: Int, round: Int, chosenWatermark: Int,

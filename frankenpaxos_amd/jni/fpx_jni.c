@@ -660,3 +660,28 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_acceptorRound(JNIEnv* env, j
   int32_t st = fpx_read_acceptor(CTX(h), group, replica, &round, NULL, NULL, NULL, NULL);
   return st == FPX_OK ? round : -(st + 1);
 }
+
+/* ---- calls in flight on page-locked batches (fpx_phase2_fused_submit / _wait): every buffer a direct ByteBuffer over
+ * hostAlloc memory.  submit returns the ticket (>= 0) or -status */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_phase2FusedSubmitDirect(
+    JNIEnv* env, jclass cls, jlong h, jint n, jobject slot, jobject round, jobject value, jobject targetMask,
+    jobject chosen, jobject chosenRound, jobject chosenValue, jobject nackRound) {
+  if (n <= 0) return -FPX_EINVAL;
+  int bad = 0;
+  const jlong n4 = 4 * (jlong)n, n32 = 32 * (jlong)n;
+  const int32_t* s = direct(env, slot, n4, &bad);
+  const int32_t* r = direct(env, round, n4, &bad);
+  const int32_t* v = direct(env, value, n4, &bad);
+  const uint64_t* t = direct(env, targetMask, n32, &bad);
+  uint8_t* ch = direct(env, chosen, n, &bad);
+  int32_t *cr = direct(env, chosenRound, n4, &bad), *cv = direct(env, chosenValue, n4, &bad);
+  int32_t* nr = direct(env, nackRound, n4, &bad);
+  if (bad || !s || !r || !v) return -FPX_EINVAL;
+  int32_t ticket = -1;
+  const int32_t st = fpx_phase2_fused_submit(CTX(h), n, s, r, v, t, ch, cr, cv, nr, &ticket);
+  return st == FPX_OK ? ticket : -st;
+}
+
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_phase2FusedWait(JNIEnv* env, jclass cls, jlong h, jint ticket) {
+  return fpx_phase2_fused_wait(CTX(h), ticket);
+}
