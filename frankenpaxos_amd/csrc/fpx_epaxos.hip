@@ -1397,7 +1397,9 @@ int launch_kp(fpx_epx* e, const EpxBatch& b, int32_t* d_packed, bool* done) {
   a.host_flag = e->kp_flag_dev, a.seq = ++e->kp_seq, a.tc = T::TC;
   a.packed = d_packed, a.stride = fpx_epx_packed_stride(N);
   if (!e->kp_lds_allowed) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_epx_key2<N>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_epx_key2<N, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)T::BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_epx_key2<N, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)T::BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_kp_hist), hipFuncAttributeMaxDynamicSharedMemorySize,
                               KP_HG * KP_MAXB * 4);
@@ -1410,7 +1412,10 @@ int launch_kp(fpx_epx* e, const EpxBatch& b, int32_t* d_packed, bool* done) {
   // learns, while the GPU works on, whether the first form has to take the tick after all (launching the kernel
   // only after the answer left the GPU idle for ~30 us per tick when ticks were enqueued back to back)
   const int grid = std::min(e->st.num_keys, e->num_cus);
-  hipLaunchKernelGGL((k_epx_key2<N>), dim3(grid), dim3(T::THREADS), T::BYTES, e->stream, e->st, b, a);
+  if (e->st.num_instances > 0)
+    hipLaunchKernelGGL((k_epx_key2<N, true>), dim3(grid), dim3(T::THREADS), T::BYTES, e->stream, e->st, b, a);
+  else
+    hipLaunchKernelGGL((k_epx_key2<N, false>), dim3(grid), dim3(T::THREADS), T::BYTES, e->stream, e->st, b, a);
   volatile uint32_t* flag = e->kp_flag;
   bool seen = false;
   for (long spin = 0; spin < 200000000L; ++spin) {
@@ -1560,13 +1565,13 @@ static int32_t preaccept_dev_impl(fpx_epx* e, int32_t m, const int32_t* d_leader
   const int n = e->st.n;
   int rc;
   // the second form (fpx_epaxos_kp.hpp): one partition pass by key, everything else on chip -- when the keys are
-  // one LDS counter each, ranks and slots share a 32-bit sort word, and no command log is kept
-  if (!e->kp_off && e->kp_flag_dev && e->st.num_keys <= KP_MAXB && m < (1 << 21) && e->st.num_instances == 0 &&
-      !d_triple_id) {
+  // one LDS counter each and ranks and slots share a 32-bit sort word
+  if (!e->kp_off && e->kp_flag_dev && e->st.num_keys <= KP_MAXB && m < (1 << 21) &&
+      ((e->st.num_instances == 0 && !d_triple_id) || n >= 5)) {  // (n = 3 with a command log: the first form)
     EpxBatch kb;
     memset(&kb, 0, sizeof(kb));
     kb.m = m, kb.leader = d_leader, kb.number = d_number, kb.key = d_key, kb.is_set = d_is_set, kb.resp_mask = d_resp_mask;
-    kb.seen_mask = d_seen_mask, kb.rank = d_rank;
+    kb.seen_mask = d_seen_mask, kb.rank = d_rank, kb.triple = d_triple_id;
     kb.fast = d_fast, kb.deps = d_deps, kb.leader_deps = d_leader_deps, kb.own_values_end = d_own_values_end;
     bool done = false;
     switch (n) {

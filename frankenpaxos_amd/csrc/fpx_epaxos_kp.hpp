@@ -23,6 +23,8 @@
 //                  is updated in place (what k_epx_commit did for all keys).
 //
 // HBM traffic per command (n = 5): 35 B of inputs + 32 B record out + 32 B record in + the outputs.
+// With a command log (num_instances > 0, n >= 5): k_epx_key2<N, true> scans a second time after the decisions and
+// writes the entries of every replica that saw the PreAccept (or of every replica, for a fast-path commit).
 #pragma once
 
 constexpr int KP_TILE = 2048;   // messages per partition tile
@@ -237,6 +239,14 @@ __global__ void __launch_bounds__(256) k_kp_scatter(const EpxState st, const Epx
         f[2 + 2 * r] += kp_mix((unsigned long long)(unsigned)rkq[u][r] + 0x9E3779B97F4A7C15ull);
         f[3 + 2 * r] += kp_mix((unsigned long long)(unsigned)rkq[u][r] ^ 0xD1B54A32D192ED03ull);
       }
+      if (ok && st.num_instances > 0) {
+        // this tick-at-once form covers handlePreAccept's `cmdLog.get(instance) == None` branch only: an instance a
+        // participating replica already knows is rejected (nothing of the tick is applied)
+        ok = x < st.num_instances;
+        const unsigned part = seen | (1u << L);
+        for (int r = 0; ok && r < N; ++r)
+          if (((part >> r) & 1u) && st.cl_status[((size_t)r * N + L) * st.num_instances + x] != CL_NONE) ok = false;
+      }
       if (!ok) {
         epx_report(st.status, FPX_EINVAL, i);
         continue;
@@ -267,7 +277,8 @@ __global__ void __launch_bounds__(256) k_kp_scatter(const EpxState st, const Epx
     atomicAdd(&a.fp[threadIdx.x], fsum[0][threadIdx.x] + fsum[1][threadIdx.x] + fsum[2][threadIdx.x] + fsum[3][threadIdx.x]);
 }
 
-template <int N>
+// LOG: the command log is kept (its own instantiation: the extra pass costs registers the plain tick must not pay for)
+template <int N, bool LOG>
 __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState st, const EpxBatch b, const KpArgs a) {
   using T = KpTile<N>;
   extern __shared__ __align__(16) unsigned char kp_smem[];
@@ -541,10 +552,12 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
     // ---- handlePreAcceptOk (Replica.scala:1291-1419): every counted answer is local conflicts U the PreAccept's
     // dependencies (handlePreAccept :1257-1262); fast path iff the n-2 answers are identical (popularItems); the union
     // the slow path proposes (preAcceptingSlowPath :796-813) is their column-wise max, which is the agreed row as well
+    constexpr bool COOP = (N - 1) * N >= 2 * N + 6;  // a command's conflict rows can hold its packed line
+    constexpr bool CLOG = LOG && (N - 1) * N >= 2 * N + 8;  // ... and what the command-log pass needs behind it (n >= 5)
     for (int sl = threadIdx.x; sl < c; sl += T::THREADS) {
       const int i = RF(0, sl), x = RF(1, sl), L = RF(2, sl) & 7;
       bool fast = true;
-      int od[N], ol[N], oe0 = 0, oe1 = 0;
+      int od[N], ol[N], oe0 = 0, oe1 = 0, raw_hi = 0, raw_d = 0;
       const int* row = rows + (size_t)sl * (N - 1) * N;
 #pragma unroll
       for (int l = 0; l < N; ++l) {
@@ -557,29 +570,48 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
           hi = imax(hi, v);
         }
         od[l] = hi, ol[l] = dl;
-        if (l == L) own_column(hi, x, &od[l], &oe0), own_column(dl, x, &ol[l], &oe1);
+        if (l == L) raw_hi = hi, raw_d = dl, own_column(hi, x, &od[l], &oe0), own_column(dl, x, &ol[l], &oe1);
       }
 #ifdef KP_X_NOOUT
       if (fast && x == -12345) b.fast[i] = 1;
       continue;
 #endif
       if (a.packed) {
-        int o[2 * N + 3 + 3];
+        // the packed line takes the place of the command's conflict rows (read above) and leaves below, four lanes
+        // per 64-byte line: a store instruction then covers 16 whole lines instead of 16 bytes of 64 different ones
+        int line[2 * N + 6];
+        int* o = COOP ? rows + (size_t)sl * (N - 1) * N : line;  // (n = 3: the rows are too short, the thread stores its line)
 #pragma unroll
         for (int l = 0; l < N; ++l) o[l] = od[l], o[N + l] = ol[l];
         o[2 * N] = oe0, o[2 * N + 1] = oe1, o[2 * N + 2] = fast ? 1 : 0;
 #pragma unroll
         for (int l = 2 * N + 3; l < 2 * N + 6; ++l) o[l] = 0;
-        int4* out = reinterpret_cast<int4*>(a.packed + (size_t)i * a.stride);
-        constexpr int Q = (2 * N + 3 + 3) / 4;  // 3, 4, 5 int4 for n = 3, 5, 7
+        if constexpr (!COOP) {
+          int4* out = reinterpret_cast<int4*>(a.packed + (size_t)i * a.stride);
 #pragma unroll
-        for (int q = 0; q < Q; ++q) out[q] = make_int4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+          for (int q = 0; q < (2 * N + 6) / 4; ++q) out[q] = make_int4(line[4 * q], line[4 * q + 1], line[4 * q + 2], line[4 * q + 3]);
+        }
       } else {
         if (b.fast) b.fast[i] = fast ? 1 : 0;
         if (b.own_values_end) *reinterpret_cast<int2*>(b.own_values_end + (size_t)i * 2) = make_int2(oe0, oe1);
         // the rows leave below as whole n-int lines: the command's conflict rows are spent, rows 0 and 1 take them
 #pragma unroll
         for (int l = 0; l < N; ++l) rows[(sl * (N - 1)) * N + l] = od[l], rows[(sl * (N - 1) + 1) * N + l] = ol[l];
+      }
+      if constexpr (CLOG) {
+        if (st.num_instances > 0) {  // what the command-log pass below needs of the decision, behind the packed line
+          int* o = rows + (size_t)sl * (N - 1) * N;
+          o[2 * N] = oe0, o[2 * N + 1] = oe1, o[2 * N + 2] = fast ? 1 : 0, o[2 * N + 6] = raw_hi, o[2 * N + 7] = raw_d;
+        }
+      }
+    }
+    if (COOP && a.packed) {
+      __syncthreads();
+      constexpr int Q = (2 * N + 3 + 3) / 4;  // int4's of a line: 3, 4, 5 for n = 3, 5, 7
+      for (int t = threadIdx.x; t < c * Q; t += T::THREADS) {
+        const int sl = t / Q, q = t - sl * Q;
+        const int* o = rows + (size_t)sl * (N - 1) * N + 4 * q;
+        reinterpret_cast<int4*>(a.packed + (size_t)RF(0, sl) * a.stride)[q] = make_int4(o[0], o[1], o[2], o[3]);
       }
     }
     if (!a.packed) {
@@ -589,6 +621,65 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
         const size_t o = (size_t)RF(0, sl) * N + l;
         if (b.deps) b.deps[o] = rows[(sl * (N - 1)) * N + l];
         if (b.leader_deps) b.leader_deps[o] = rows[(sl * (N - 1) + 1) * N + l];
+      }
+    }
+    // ---- the command log (num_instances > 0; Replica.scala:688-696, 815-823, 1259-1271): a fast-path commit is a
+    // CommittedEntry with the agreed dependencies at EVERY replica; otherwise every replica that processed the PreAccept
+    // holds PreAcceptedEntry(Ballot(0, leader), Ballot(0, leader), triple) with what IT answered (its conflicts U the
+    // PreAccept's; the leader: what it proposed).  The answers of the replicas that are not counted were never kept: the
+    // scans run once more (registers only), now knowing every command's decision.
+    if constexpr (CLOG) {
+      if (st.num_instances > 0) {
+        int cg[N], cs[N], ng[N], ns[N];
+#pragma unroll
+        for (int l = 0; l < N; ++l) cg[l] = base[r * 2 * N + l], cs[l] = base[r * 2 * N + N + l], ng[l] = 0, ns[l] = 0;
+        for (int w2 = 0; w2 < w; ++w2) {
+          const int* o = tot + (r * T::W + w2) * 2 * N;
+#pragma unroll
+          for (int l = 0; l < N; ++l) cg[l] = imax(cg[l], o[l]), cs[l] = imax(cs[l], o[N + l]);
+        }
+#pragma unroll
+        for (int cc = 0; cc < T::CPW; ++cc) {
+          const bool valid = code[cc] != 0xffffffffu;
+          const int sl = valid ? (int)(code[cc] & KP_SLOT_MASK) : 0;
+          const int fl = valid ? RF(2, sl) : 0;
+          const int x = valid ? RF(1, sl) : 0;
+          const int L = fl & 7;
+          int dep[N];
+          if (p0 + cc * 64 < p1) scan_chunk<N>(valid, (fl >> 3) & 1, L, x + 1, cg, cs, ng, ns, dep);
+          if (!valid) continue;
+          const unsigned seen = (((unsigned)fl >> 16) & 0xffu) | (1u << L);
+          const int* o = rows + (size_t)sl * (N - 1) * N;
+          const bool fast = o[2 * N + 2] != 0;
+          const int tr = b.triple ? b.triple[RF(0, sl)] : -1;
+          int t[N], end = 0;
+          if (fast) {
+#pragma unroll
+            for (int l = 0; l < N; ++l) t[l] = o[l];
+            end = o[2 * N];
+          } else if (r == L) {
+#pragma unroll
+            for (int l = 0; l < N; ++l) t[l] = o[N + l];
+            end = o[2 * N + 1];
+          } else {
+#pragma unroll
+            for (int l = 0; l < N; ++l) {
+              const int v = imax(dep[l], l == L ? o[2 * N + 7] : o[N + l]);
+              t[l] = v;
+              if (l == L) own_column(v, x, &t[l], &end);
+            }
+          }
+          for (int rr = 0; rr < N; ++rr) {
+            // my own entry; the leader's lane also writes those of the replicas that never saw a fast-path commit's PreAccept
+            if (!(rr == r || (fast && r == L && !((seen >> rr) & 1u)))) continue;
+            const size_t e = ((size_t)rr * N + L) * st.num_instances + x;
+#pragma unroll
+            for (int l = 0; l < N; ++l) st.cl_deps[e * N + l] = t[l];
+            st.cl_dend[e] = end;
+            st.cl_status[e] = fast ? CL_COMMITTED : CL_PRE_ACCEPTED;
+            st.cl_ballot[e] = fast ? -1 : L, st.cl_vote[e] = fast ? -1 : L, st.cl_triple[e] = tr;  // Ballot(0, L) = 0 * 8 + L
+          }
+        }
       }
     }
     // ---- commit -> updateConflictIndex at every replica (Replica.scala:815-828): the key's watermarks learn every

@@ -231,7 +231,10 @@ __global__ void __launch_bounds__(256) k_ranges_fill(const Geom g, const State s
 // it; what is left is one request per 16 useful bytes (profiles/r03_cfg5.md).
 // Two ranges of the launch that cover the same slot (a leader group that sends overlapping ranges in one tick) send
 // the span through a per-slot loop over all ranges instead.  Chosen by the host for launches of at most RF_MAXN ranges.
-constexpr int RF_JB = 8, RF_MAXN = 1024, RF_MAXL = 2048;
+#ifndef FPX_RF_JB
+#define FPX_RF_JB 8
+#endif
+constexpr int RF_JB = FPX_RF_JB, RF_MAXN = 1024, RF_MAXL = 2048;
 __global__ void __launch_bounds__(256) k_ranges_fill_rows(const Geom g, const State st, const RangeBatch b) {
   extern __shared__ uint32_t rf_own[];  // [RF_JB][L] index + 1 of the range that covers the slot, 0 = none
   __shared__ int span_lo, span_hi, overlap;
