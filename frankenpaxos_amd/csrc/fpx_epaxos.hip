@@ -1098,6 +1098,78 @@ __global__ void __launch_bounds__(256) k_cl_commit(const EpxState st, const ClBa
   if (b.committed) b.committed[i] = done;
 }
 
+// ---- K8: Replica.handlePrepareOk (Replica.scala:1759-1884), the recovering replica's decision -- one thread per instance
+struct RcBatch {
+  int m, as_intended;
+  const int32_t* leader;
+  const int32_t* number;
+  const int32_t* b_ord;
+  const int32_t* b_rep;
+  const uint8_t* resp_mask;
+  const int32_t* rs;  // [m][n] PrepareOk.status as the entry kind
+  const int32_t* rv;  // [m][n] PrepareOk.voteBallot, encoded
+  const int32_t* rt;  // [m][n] triple id
+  int32_t* action;
+  int32_t* source;
+  int32_t* triple;
+};
+
+__global__ void __launch_bounds__(256) k_cl_recover(const EpxState st, const RcBatch b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.m) return;
+  const int n = st.n, f = (n - 1) / 2;
+  const int L = b.leader[i], x = b.number[i], me = b.b_rep[i];
+  const unsigned mask = b.resp_mask[i];
+  bool ok = L >= 0 && L < n && x >= 0 && x < st.num_instances && me >= 0 && me < n && b.b_ord[i] >= 0 && (mask >> n) == 0;
+  const int32_t* rs = b.rs + (size_t)i * n;
+  const int32_t* rv = b.rv + (size_t)i * n;
+  const int32_t* rt = b.rt + (size_t)i * n;
+  for (int r = 0; ok && r < n; ++r)
+    if (((mask >> r) & 1u) && rs[r] < 0) ok = false;  // no PrepareOk from r
+  if (!ok) {
+    epx_report(st.status, FPX_EINVAL, i);
+    return;
+  }
+  if (st.status[0] != 0) return;
+  int act = 0, src = -1, tr = -1;
+  if ((int)__popc(mask) >= f + 1) {  // :1799 responses.size < slowQuorumSize -> wait
+    int maxvb = -2;                  // :1805-1807 only the responses of the highest voteBallot count
+    for (int r = 0; r < n; ++r)
+      if (((mask >> r) & 1u) && rv[r] > maxvb) maxvb = rv[r];
+    if (b.as_intended) {             // :1810-1824 -- never true as the reference evaluates it (status is no Option)
+      for (int r = 0; r < n && act == 0; ++r)
+        if (((mask >> r) & 1u) && rv[r] == maxvb && rs[r] == CL_ACCEPTED) act = 1, src = r, tr = rt[r];
+    }
+    if (act == 0) {
+      // :1830-1851 f matching PreAccepted triples of the default ballot, not from the recovering replica.  The
+      // reference tests the ballot of the Prepare that was answered (p.ballot), which is the recovery ballot
+      const int dflt = L;  // Ballot(0, leader) encoded: 0 * 8 + L
+      const bool in_default = b.as_intended ? maxvb == dflt : (b.b_ord[i] * 8 + me) == dflt;
+      for (int r = 0; r < n && act == 0 && in_default; ++r) {
+        if (!((mask >> r) & 1u) || rv[r] != maxvb || rs[r] != CL_PRE_ACCEPTED || r == me) continue;
+        const size_t cr = ((size_t)r * n + L) * st.num_instances + x;
+        int same = 0;
+        for (int q = 0; q < n; ++q) {
+          if (!((mask >> q) & 1u) || rv[q] != maxvb || rs[q] != CL_PRE_ACCEPTED || q == me) continue;
+          const size_t cq = ((size_t)q * n + L) * st.num_instances + x;
+          bool eq = rt[q] == rt[r] && st.cl_dend[cq] == st.cl_dend[cr];
+          for (int l = 0; l < n && eq; ++l) eq = st.cl_deps[cq * n + l] == st.cl_deps[cr * n + l];
+          same += eq ? 1 : 0;
+        }
+        if (same >= f) act = 1, src = r, tr = rt[r];  // Util.popularItems(.., config.f)
+      }
+    }
+    if (act == 0) {  // :1856-1868 start over, avoiding the fast path: with a pre-accepted command, else with a Noop
+      act = 3;
+      for (int r = 0; r < n && act == 3; ++r)
+        if (((mask >> r) & 1u) && rv[r] == maxvb && rs[r] == CL_PRE_ACCEPTED) act = 2, src = r, tr = rt[r];
+    }
+  }
+  if (b.action) b.action[i] = act;
+  if (b.source) b.source[i] = src;
+  if (b.triple) b.triple[i] = tr;
+}
+
 // ---- handlePreAccept in full (Replica.scala:1159-1289): ballots, Nacks, re-sent replies ------------------------
 // Like Prepare / Accept above: messages delivered in array order to the replicas of target[i], instances pairwise
 // distinct per batch -- so what a replica does with a message (process / Nack / answer again / ignore / answer with
@@ -1789,6 +1861,50 @@ int32_t fpx_epx_prepare(fpx_epx* e, int32_t m, const int32_t* leader, const int3
                         int32_t* reply_triple) {
   return cl_run(e, 0, m, leader, number, ballot_ordering, ballot_replica, nullptr, nullptr, nullptr, target_mask, ok_bits,
                 nack_bits, commit_bits, nack_ballot, nullptr, reply_status, reply_vote_ballot, reply_triple);
+}
+
+int32_t fpx_epx_handle_prepare_oks(fpx_epx* e, int32_t m, const int32_t* leader, const int32_t* number,
+                                   const int32_t* ballot_ordering, const int32_t* ballot_replica, const uint8_t* resp_mask,
+                                   const int32_t* reply_status, const int32_t* reply_vote_ballot, const int32_t* reply_triple,
+                                   int32_t as_intended, int32_t* action, int32_t* source, int32_t* triple) {
+  if (!e || m < 0) return FPX_EINVAL;
+  EpxDeviceGuard _dg(e->cfg.device);
+  if (e->st.num_instances <= 0) return FPX_EINVAL;
+  if (m == 0) return FPX_OK;
+  if (!leader || !number || !ballot_ordering || !ballot_replica || !resp_mask || !reply_status || !reply_vote_ballot || !reply_triple)
+    return FPX_EINVAL;
+  const int n = e->st.n;
+  const size_t mp = ((size_t)m + 63) & ~(size_t)63;
+  int rc;
+  if ((rc = grow(e, &e->cl, mp * 4 * 7 + mp + (size_t)m * n * 4 * 3 + 2048))) return rc;
+  char* p = (char*)e->cl.p;
+  auto take = [&](size_t sz) { char* q = p; p += (sz + 63) & ~(size_t)63; return q; };
+  int32_t *d_leader = (int32_t*)take(mp * 4), *d_number = (int32_t*)take(mp * 4), *d_bo = (int32_t*)take(mp * 4);
+  int32_t *d_br = (int32_t*)take(mp * 4), *d_act = (int32_t*)take(mp * 4), *d_src = (int32_t*)take(mp * 4), *d_tr = (int32_t*)take(mp * 4);
+  uint8_t* d_mask = (uint8_t*)take(mp);
+  int32_t *d_rs = (int32_t*)take((size_t)m * n * 4), *d_rv = (int32_t*)take((size_t)m * n * 4), *d_rt = (int32_t*)take((size_t)m * n * 4);
+  EHIP(e, hipMemcpyAsync(d_leader, leader, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+  EHIP(e, hipMemcpyAsync(d_number, number, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+  EHIP(e, hipMemcpyAsync(d_bo, ballot_ordering, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+  EHIP(e, hipMemcpyAsync(d_br, ballot_replica, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+  EHIP(e, hipMemcpyAsync(d_mask, resp_mask, (size_t)m, hipMemcpyHostToDevice, e->stream));
+  EHIP(e, hipMemcpyAsync(d_rs, reply_status, (size_t)m * n * 4, hipMemcpyHostToDevice, e->stream));
+  EHIP(e, hipMemcpyAsync(d_rv, reply_vote_ballot, (size_t)m * n * 4, hipMemcpyHostToDevice, e->stream));
+  EHIP(e, hipMemcpyAsync(d_rt, reply_triple, (size_t)m * n * 4, hipMemcpyHostToDevice, e->stream));
+  RcBatch b;
+  memset(&b, 0, sizeof(b));
+  b.m = m, b.as_intended = as_intended ? 1 : 0, b.leader = d_leader, b.number = d_number, b.b_ord = d_bo, b.b_rep = d_br;
+  b.resp_mask = d_mask, b.rs = d_rs, b.rv = d_rv, b.rt = d_rt, b.action = d_act, b.source = d_src, b.triple = d_tr;
+  hipLaunchKernelGGL(k_cl_recover, dim3((m + 255) / 256), dim3(256), 0, e->stream, e->st, b);
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) {
+    e->last_hip = (int)le;
+    return FPX_EHIP;
+  }
+  if (action) EHIP(e, hipMemcpyAsync(action, d_act, (size_t)m * 4, hipMemcpyDeviceToHost, e->stream));
+  if (source) EHIP(e, hipMemcpyAsync(source, d_src, (size_t)m * 4, hipMemcpyDeviceToHost, e->stream));
+  if (triple) EHIP(e, hipMemcpyAsync(triple, d_tr, (size_t)m * 4, hipMemcpyDeviceToHost, e->stream));
+  return fpx_epx_sync(e);
 }
 
 int32_t fpx_epx_accept(fpx_epx* e, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* ballot_ordering,

@@ -94,6 +94,21 @@ class EPaxos:
                                     p(nb), p(rs), p(rv), p(rt))
         return st, ok, nack, com, nb, rs, rv, rt
 
+    def handle_prepare_oks(self, leader, number, ballot_ordering, ballot_replica, resp_mask, reply_status, reply_vote,
+                           reply_triple, as_intended=False):
+        """Replica.handlePrepareOk, the recovering replica's decision: (status, action, source, triple) -- action 0 wait,
+        1 Accept phase with `source`'s triple, 2 pre-accept again with its command, 3 pre-accept a Noop"""
+        a32 = lambda x: np.ascontiguousarray(x, dtype=np.int32)
+        leader, number, bo, br = a32(leader), a32(number), a32(ballot_ordering), a32(ballot_replica)
+        mask = np.ascontiguousarray(resp_mask, dtype=np.uint8)
+        rs, rv, rt = a32(reply_status), a32(reply_vote), a32(reply_triple)
+        m = len(leader)
+        act, src, tr = (np.full(m, -9, np.int32) for _ in range(3))
+        p = lambda a: a.ctypes.data
+        st = self.L.fpx_epx_handle_prepare_oks(self._h, m, p(leader), p(number), p(bo), p(br), p(mask), p(rs), p(rv), p(rt),
+                                               int(as_intended), p(act), p(src), p(tr))
+        return st, act, src, tr
+
     def accept(self, leader, number, ballot_ordering, ballot_replica, triple_id, target_mask, key=None, is_set=None):
         """the Accept phase: (status, ok_bits, nack_bits, commit_bits, nack_ballot, committed).  key / is_set: the
         triples' commands (updateConflictIndex wherever the triple is stored); key None = every triple is a Noop"""

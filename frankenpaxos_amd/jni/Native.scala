@@ -99,6 +99,11 @@ object Native {
   @native def epxPrepare(handle: Long, m: Int, numReplicas: Int, leader: Array[Int], number: Array[Int],
                          ballotOrdering: Array[Int], ballotReplica: Array[Int], targetMask: Array[Byte],
                          replies: Array[Byte], nackBallot: Array[Int], prepareOk: Array[Int]): Int
+  // Replica.handlePrepareOk: decision = action | source | triple (3 x m); action 0 wait, 1 Accept phase with the
+  // triple, 2 pre-accept its command again, 3 pre-accept a Noop; asIntended = 0 evaluates :1810 / :1831 as written
+  @native def epxHandlePrepareOks(handle: Long, m: Int, numReplicas: Int, leader: Array[Int], number: Array[Int],
+                                  ballotOrdering: Array[Int], ballotReplica: Array[Int], respMask: Array[Byte],
+                                  prepareOk: Array[Int], asIntended: Int, decision: Array[Int]): Int
   @native def epxAccept(handle: Long, m: Int, leader: Array[Int], number: Array[Int],
                         ballotOrdering: Array[Int], ballotReplica: Array[Int], tripleId: Array[Int],
                         key: Array[Int], isSet: Array[Byte],

@@ -685,3 +685,30 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_phase2FusedSubmitDirect(
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_phase2FusedWait(JNIEnv* env, jclass cls, jlong h, jint ticket) {
   return fpx_phase2_fused_wait(CTX(h), ticket);
 }
+
+/* K8 Replica.handlePrepareOk (epaxos/Replica.scala:1759-1884): prepareOk = epxPrepare's output (status | voteBallot |
+ * triple, 3 x m x numReplicas), respMask = its okBits; decision = action | source | triple (3 x m ints) */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxHandlePrepareOks(JNIEnv* env, jclass cls, jlong h, jint m,
+                                                                        jint numReplicas, jintArray leader,
+                                                                        jintArray number, jintArray ballotOrdering,
+                                                                        jintArray ballotReplica, jbyteArray respMask,
+                                                                        jintArray prepareOk, jint asIntended,
+                                                                        jintArray decision) {
+  if (m < 0 || numReplicas < 3 || !epx_n_is(h, numReplicas)) return FPX_EINVAL;
+  if (m == 0) return FPX_OK;
+  const jlong mn = (jlong)m * numReplicas;
+  if (!has(env, leader, m) || !has(env, number, m) || !has(env, ballotOrdering, m) || !has(env, ballotReplica, m) ||
+      !has(env, respMask, m) || !has(env, prepareOk, 3 * mn) || !has(env, decision, 3 * (jlong)m))
+    return FPX_EINVAL;
+  jint *l = in_ints(env, leader, m), *nu = in_ints(env, number, m), *bo = in_ints(env, ballotOrdering, m),
+       *br = in_ints(env, ballotReplica, m), *po = in_ints(env, prepareOk, 3 * mn);
+  jbyte* mk = in_bytes(env, respMask, m);
+  jint* d = out_buf(decision, 3 * (jlong)m, 4);
+  int32_t st = (!l || !nu || !bo || !br || !po || !mk || !d)
+                   ? FPX_ENOMEM
+                   : fpx_epx_handle_prepare_oks((fpx_epx*)(intptr_t)h, m, l, nu, bo, br, (const uint8_t*)mk, po, po + mn,
+                                                po + 2 * mn, asIntended, d, d + m, d + 2 * (size_t)m);
+  put_ints(env, decision, 3 * (jlong)m, d);
+  free(l); free(nu); free(bo); free(br); free(po); free(mk); free(d);
+  return st;
+}

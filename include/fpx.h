@@ -469,6 +469,27 @@ int32_t fpx_epx_prepare(fpx_epx* epx, int32_t m, const int32_t* leader, const in
                         const int32_t* ballot_ordering, const int32_t* ballot_replica, const uint8_t* target_mask,
                         uint8_t* ok_bits, uint8_t* nack_bits, uint8_t* commit_bits, int32_t* nack_ballot,
                         int32_t* reply_status, int32_t* reply_vote_ballot, int32_t* reply_triple);
+/* K8: Replica.handlePrepareOk (epaxos/Replica.scala:1759-1884) -- the decision of the replica that recovers instance i
+ * in ballot (ballot_ordering[i], ballot_replica[i]) once it holds the PrepareOks of the replicas in resp_mask[i]
+ * (fpx_epx_prepare's ok_bits) with the contents reply_* (fpx_epx_prepare's outputs, m x n):
+ *   action 0 = fewer than f + 1 responses, wait (:1799-1801)
+ *   action 1 = transitionToAcceptPhase(instance, ballot, the triple replica `source` reported)     -> fpx_epx_accept
+ *   action 2 = transitionToPreAcceptPhase(instance, ballot, the command of `source`'s triple, avoidFastPath = true)
+ *   action 3 = transitionToPreAcceptPhase(instance, ballot, Noop, avoidFastPath = true)  -> fpx_epx_handle_preaccept
+ * triple[i] = that triple's id (-1 for action 0 / 3); source = the lowest replica index among the eligible responses
+ * (the reference takes whichever its hash map yields first; they carry the same command).
+ * as_intended = 0 reproduces the reference AS IT EVALUATES: its test for an Accepted response compares the required
+ * enum field `status` with an Option (:1810, always false) and its default-ballot filter looks at the ballot of the
+ * Prepare that was answered instead of the vote's (:1831, never the default ballot during a recovery), so only
+ * actions 0, 2 and 3 can come out.  as_intended = 1 evaluates the two tests the way the surrounding comments describe
+ * them (an Accepted response at the highest voteBallot wins; f identical PreAccepted triples voted in
+ * Ballot(0, leader), the recovering replica's own excluded, win: Util.popularItems(.., f) with the triples compared as
+ * the command log stores them).  Reads the command log, changes nothing. */
+int32_t fpx_epx_handle_prepare_oks(fpx_epx* epx, int32_t m, const int32_t* leader, const int32_t* number,
+                                   const int32_t* ballot_ordering, const int32_t* ballot_replica,
+                                   const uint8_t* resp_mask, const int32_t* reply_status,
+                                   const int32_t* reply_vote_ballot, const int32_t* reply_triple, int32_t as_intended,
+                                   int32_t* action, int32_t* source, int32_t* triple);
 int32_t fpx_epx_accept(fpx_epx* epx, int32_t m, const int32_t* leader, const int32_t* number,
                        const int32_t* ballot_ordering, const int32_t* ballot_replica, const int32_t* triple_id,
                        const int32_t* key, const uint8_t* is_set, const uint8_t* target_mask, uint8_t* ok_bits,

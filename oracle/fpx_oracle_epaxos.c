@@ -538,6 +538,86 @@ int fpo_epx_prepare(fpo_epx* e, int32_t m, const int32_t* leader, const int32_t*
   return 0;
 }
 
+/* Replica.handlePrepareOk  epaxos/Replica.scala:1759-1884 -- the recovering replica's decision once slowQuorumSize
+ * PrepareOks are in.  Instance i is recovered by replica b_rep[i] in ballot (b_ord[i], b_rep[i]); resp_mask[i] = the
+ * replicas whose PrepareOk it holds (fpo_epx_prepare's ok_bits), reply_* = their contents (fpo_epx_prepare's outputs).
+ *   action 0  fewer than f + 1 responses: wait (:1799-1801)
+ *   action 1  transitionToAcceptPhase(instance, ballot, triple of `source`)   (:1810-1824, :1846-1851)
+ *   action 2  transitionToPreAcceptPhase(instance, ballot, the command of `source`'s triple, avoidFastPath) (:1856-1862)
+ *   action 3  transitionToPreAcceptPhase(instance, ballot, Noop, avoidFastPath)  (:1863-1868)
+ * as_intended = 0: AS THE REFERENCE EVALUATES IT.  Two of its tests can never hold:
+ *   (a) :1810  prepareOks.find(_.status == Some(CommandStatus.Accepted)) -- `status` is a REQUIRED proto field
+ *       (EPaxos.proto:203), so a CommandStatus is compared with an Option and the comparison is always false: an
+ *       accepted value is never picked up here;
+ *   (b) :1831  .filter(p => p.ballot == Ballot(0, p.instance.replicaIndex)) -- p.ballot is the ballot of the Prepare
+ *       being answered (handlePrepare copies prepare.ballot), i.e. the recovery ballot, whose ordering is >= 1
+ *       (transitionToPreparePhase: largestBallot.ordering + 1): the filter keeps nothing, popularItems finds nothing.
+ *   What is left: among the responses with the highest voteBallot, ANY PreAccepted one restarts the pre-accept phase
+ *   with its command, otherwise a Noop is proposed -- also when those responses were Accepted.
+ * as_intended = 1: as the comments of :1806-1809, :1826-1829 say: an Accepted response at the highest voteBallot wins;
+ *   else f identical PreAccepted triples voted in the instance's default ballot Ballot(0, leader), not from the
+ *   recovering replica, win (popularItems(.., f), the triples compared as the command log holds them: id,
+ *   dependencies, explicit values); else as above.
+ * `responses` is a hash map: which of several eligible responses `find` returns is unspecified; they all carry the
+ * same command (one voteBallot = one proposer), `source` is the lowest replica index. */
+int fpo_epx_handle_prepare_oks(fpo_epx* e, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* b_ord,
+                               const int32_t* b_rep, const uint8_t* resp_mask, const int32_t* reply_status,
+                               const int32_t* reply_vote, const int32_t* reply_triple, int32_t as_intended,
+                               int32_t* action, int32_t* source, int32_t* triple) {
+  const int n = e->n, f = (n - 1) / 2;
+  if (e->num_instances <= 0 || m < 0) return 1;
+  for (int i = 0; i < m; ++i) {
+    if (leader[i] < 0 || leader[i] >= n || number[i] < 0 || number[i] >= e->num_instances || b_rep[i] < 0 ||
+        b_rep[i] >= n || b_ord[i] < 0 || (resp_mask[i] >> n))
+      return 1;
+    for (int r = 0; r < n; ++r)
+      if (((resp_mask[i] >> r) & 1u) && reply_status[(size_t)i * n + r] < 0) return 1; /* no PrepareOk from r */
+  }
+  for (int i = 0; i < m; ++i) {
+    const int32_t* rs = reply_status + (size_t)i * n;
+    const int32_t* rv = reply_vote + (size_t)i * n;
+    const int32_t* rt = reply_triple + (size_t)i * n;
+    const unsigned mask = resp_mask[i];
+    int act = 0, src = -1, tr = -1;
+    if (popcount8((uint8_t)mask) >= f + 1) { /* :1799 responses.size < slowQuorumSize -> wait */
+      int maxvb = -2;                          /* :1805-1807 only the responses of the highest voteBallot count */
+      for (int r = 0; r < n; ++r)
+        if (((mask >> r) & 1u) && rv[r] > maxvb) maxvb = rv[r];
+      if (as_intended) {
+        for (int r = 0; r < n && act == 0; ++r) /* :1810-1824 some response was accepted: go with it */
+          if (((mask >> r) & 1u) && rv[r] == maxvb && rs[r] == CL_ACCEPTED) act = 1, src = r, tr = rt[r];
+      }
+      if (act == 0) {
+        /* :1830-1851 f matching PreAccepted responses in the default ballot, the recovering replica's own excluded */
+        const int in_default = as_intended ? maxvb == enc_ballot(0, leader[i]) /* the vote was cast in it */
+                                           : enc_ballot(b_ord[i], b_rep[i]) == enc_ballot(0, leader[i]); /* p.ballot */
+        for (int r = 0; r < n && act == 0 && in_default; ++r) {
+          if (!((mask >> r) & 1u) || rv[r] != maxvb || rs[r] != CL_PRE_ACCEPTED || r == b_rep[i]) continue;
+          int same = 0;
+          const size_t cr = ((size_t)r * n + leader[i]) * e->num_instances + number[i];
+          for (int q = 0; q < n; ++q) {
+            if (!((mask >> q) & 1u) || rv[q] != maxvb || rs[q] != CL_PRE_ACCEPTED || q == b_rep[i]) continue;
+            const size_t cq = ((size_t)q * n + leader[i]) * e->num_instances + number[i];
+            int eq = rt[q] == rt[r] && e->cl_dend[cq] == e->cl_dend[cr];
+            for (int l = 0; l < n && eq; ++l) eq = e->cl_deps[cq * n + l] == e->cl_deps[cr * n + l];
+            same += eq;
+          }
+          if (same >= f) act = 1, src = r, tr = rt[r]; /* Util.popularItems(.., config.f) */
+        }
+      }
+      if (act == 0) { /* :1856-1868 start over: with a command if any response pre-accepted one, else with a Noop */
+        act = 3;
+        for (int r = 0; r < n && act == 3; ++r)
+          if (((mask >> r) & 1u) && rv[r] == maxvb && rs[r] == CL_PRE_ACCEPTED) act = 2, src = r, tr = rt[r];
+      }
+    }
+    if (action) action[i] = act;
+    if (source) source[i] = src;
+    if (triple) triple[i] = tr;
+  }
+  return 0;
+}
+
 /* The Accept phase of message i, proposed by replica b_rep[i] in ballot (b_ord[i], b_rep[i]):
  *   transitionToAcceptPhase at the proposer (:732-792): its own entry becomes AcceptedEntry(ballot, ballot, triple)
  *     -- a CommittedEntry there is logger.fatal (:740-744), an entry with a larger ballot a failed logger.checkLe

@@ -570,6 +570,7 @@ class EPaxos:
         L.fpo_epx_prepare.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, I32P, U8P, U8P, U8P, U8P, I32P, I32P, I32P, I32P]
         L.fpo_epx_accept.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, I32P, I32P, I32P, U8P, U8P, U8P, U8P, U8P, I32P, U8P]
         L.fpo_epx_read_cmdlog.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, I32P]
+        L.fpo_epx_handle_prepare_oks.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, I32P, U8P, I32P, I32P, I32P, C.c_int32, I32P, I32P, I32P]
         L.fpo_epx_read_cmdlog_deps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, I32P, I32P]
         L.fpo_epx_handle_preaccept.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, I32P, I32P, U8P, I32P, I32P, I32P,
                                                U8P, U8P, U8P, U8P, U8P, I32P, I32P, I32P, I32P]
@@ -601,6 +602,19 @@ class EPaxos:
                                    _p(ok, U8P), _p(nack, U8P), _p(com, U8P), _p(nb, I32P), _p(rs, I32P), _p(rv, I32P),
                                    _p(rt, I32P))
         return st, ok, nack, com, nb, rs, rv, rt
+
+    def handle_prepare_oks(self, leader, number, ballot_ordering, ballot_replica, resp_mask, reply_status, reply_vote,
+                           reply_triple, as_intended=False):
+        """Replica.handlePrepareOk: (status, action, source, triple)"""
+        leader, number, bo, br = _i32(leader), _i32(number), _i32(ballot_ordering), _i32(ballot_replica)
+        mask = np.ascontiguousarray(resp_mask, dtype=np.uint8)
+        rs, rv, rt = _i32(reply_status), _i32(reply_vote), _i32(reply_triple)
+        m = len(leader)
+        act, src, tr = (np.full(m, -9, np.int32) for _ in range(3))
+        st = lib().fpo_epx_handle_prepare_oks(self._h, m, _p(leader, I32P), _p(number, I32P), _p(bo, I32P), _p(br, I32P),
+                                              _p(mask, U8P), _p(rs, I32P), _p(rv, I32P), _p(rt, I32P), int(as_intended),
+                                              _p(act, I32P), _p(src, I32P), _p(tr, I32P))
+        return st, act, src, tr
 
     def accept(self, leader, number, ballot_ordering, ballot_replica, triple_id, target_mask, key=None, is_set=None):
         """key / is_set: the triples' commands; key None = every triple is a Noop"""

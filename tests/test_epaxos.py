@@ -1185,3 +1185,116 @@ def test_epaxos_clumped_ranks_take_the_radix_sort(oracle, n):
     for r in range(n):
         for k in range(num_keys):
             assert [x.tolist() for x in gpu.read_index(r, k)] == [x.tolist() for x in ref.read_index(r, k)]
+
+
+# ---- K8: Replica.handlePrepareOk, the recovering replica's decision (Replica.scala:1759-1884) ---------------------
+def test_oracle_handle_prepare_oks_by_hand(oracle):
+    """n = 5 (f = 2, slow quorum 3), instance X = (0, 0), recovered by replica 4.
+      * PreAccept(X, Ballot(0, 0), triple 7) processed at replicas 1, 2, 3 (identical answers: empty indexes)
+      * replica 4 prepares X in Ballot(1, 4) at {1, 2, 3}: three PrepareOk(PreAccepted, voteBallot (0, 0), triple 7)
+          two of them in hand            -> wait
+          as the reference evaluates it  -> pre-accept triple 7's command again (its popularItems filter looks at the
+                                            Prepare's ballot (1, 4), never the default ballot: nothing is "popular")
+          as its comments intend         -> f = 2 identical default-ballot pre-accepts not from replica 4: Accept phase
+      * replica 3 runs the Accept phase of X in Ballot(2, 3) with triple 9 at replica 2 only (2 of the 3 it needs)
+      * replica 4 prepares again in Ballot(3, 4): replica 1 PreAccepted in (0, 0); replicas 2, 3 Accepted in (2, 3)
+          as the reference evaluates it  -> Noop!  (status == Some(Accepted) compares an enum with an Option: never true;
+                                            no PreAccepted response at the highest voteBallot is left)
+          as its comments intend         -> Accept phase with triple 9
+      * only NotSeen responses -> Noop either way"""
+    e = oracle.EPaxos(5, 4, num_instances=16)
+    z = np.zeros((1, 5), np.int32)
+    out = e.handle_preaccept([0], [0], [0], [0], [1], [1], [7], z, None, [0b01110])
+    assert out[0] == 0 and out[1][0] == 0b01110
+    st, ok, nack, com, nb, rs, rv, rt = e.prepare([0], [0], [1], [4], [0b01110])
+    assert st == 0 and ok[0] == 0b01110 and rs[0].tolist() == [-1, 2, 2, 2, -1] and rv[0].tolist() == [-1, 0, 0, 0, -1]
+    dec = lambda mask, bo, intended: tuple(int(x[0]) for x in e.handle_prepare_oks([0], [0], [bo], [4], [mask], rs, rv, rt, intended)[1:])
+    assert dec(0b00110, 1, False) == (0, -1, -1) and dec(0b00110, 1, True) == (0, -1, -1)
+    assert dec(0b01110, 1, False) == (2, 1, 7)
+    assert dec(0b01110, 1, True) == (1, 1, 7)
+    # a response the recovering replica did not get is not a response: status -1 inside the mask is a malformed call
+    assert e.handle_prepare_oks([0], [0], [1], [4], [0b11110], rs, rv, rt)[0] == 1
+    a = e.accept([0], [0], [2], [3], [9], [0b00100], [1], [1])
+    assert a[0] == 0 and a[1][0] == 0b01100 and a[5][0] == 0            # AcceptOk from 2 and from 3 itself: 2 of the 3 needed
+    st, ok, nack, com, nb, rs, rv, rt = e.prepare([0], [0], [3], [4], [0b01110])
+    assert ok[0] == 0b01110 and rs[0].tolist() == [-1, 2, 3, 3, -1] and rv[0].tolist() == [-1, 0, 19, 19, -1] and rt[0].tolist() == [-1, 7, 9, 9, -1]
+    assert dec(0b01110, 3, False) == (3, -1, -1)
+    assert dec(0b01110, 3, True) == (1, 2, 9)
+    fresh = oracle.EPaxos(5, 4, num_instances=16)
+    st, ok, nack, com, nb, rs, rv, rt = fresh.prepare([0], [0], [1], [4], [0b00111])
+    assert rs[0].tolist() == [0, 0, 0, -1, -1]
+    for intended in (False, True):
+        assert tuple(int(x[0]) for x in fresh.handle_prepare_oks([0], [0], [1], [4], [0b00111], rs, rv, rt, intended)[1:]) == (3, -1, -1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [3, 5, 7])
+def test_epaxos_handle_prepare_oks_matches_oracle(oracle, n):
+    """random PrepareOk sets (statuses, vote ballots and triples drawn from small ranges so that ties and agreements
+    happen) over a command log filled by ticks and re-sent PreAccepts: both evaluations, GPU == oracle; then a recovery
+    end to end -- tick, Prepare by another replica, its decision, the pre-accept phase again in the recovery ballot
+    (avoiding the fast path), the Accept phase, the commit -- step by step against the oracle"""
+    from frankenpaxos_amd.epaxos import EPaxos
+    import frankenpaxos_amd as fa
+
+    NI, K = 256, 8
+    gpu, ref = EPaxos(n, K, num_instances=NI), oracle.EPaxos(n, K, num_instances=NI)
+    rng = np.random.default_rng(n)
+    nxt = [0] * n
+    leader, number, key, is_set, mask, rank = random_tick(rng, n, K, 300, nxt, 40.0, fifo=False)
+    tr = np.arange(300, dtype=np.int32)
+    a, b = gpu.preaccept(leader, number, key, is_set, mask, rank, triple_id=tr), ref.preaccept(leader, number, key, is_set, mask, rank, triple_id=tr)
+    _same(a, b)
+    slow = np.nonzero(a[1] == 0)[0]
+    assert len(slow) > 20 or n == 3     # (n = 3: one counted answer is always "identical" -- every commit is a fast one)
+    # 1. random reply sets on the tick's instances
+    m = 300
+    f = (n - 1) // 2
+    seen = {0: 0, 1: 0, 2: 0, 3: 0}
+    for intended in (False, True):
+        rs = rng.choice([0, 2, 2, 3], size=(m, n)).astype(np.int32)
+        rv = np.where(rs == 0, -1, rng.choice([0, 1, 2, 9], size=(m, n)) + rng.integers(0, 2, (m, n)) * leader[:, None]).astype(np.int32)
+        rt = np.where(rs == 0, -1, rng.integers(0, 3, (m, n)) + tr[:, None]).astype(np.int32)
+        msk = rng.integers(0, 1 << n, m).astype(np.uint8)
+        b_ord, b_rep = rng.integers(0, 3, m).astype(np.int32), rng.integers(0, n, m).astype(np.int32)
+        x, y = (e.handle_prepare_oks(leader, number, b_ord, b_rep, msk, rs, rv, rt, intended) for e in (gpu, ref))
+        _same(x, y)
+        for k in seen:
+            seen[k] += int((x[1] == k).sum())
+    assert all(v > 0 for v in seen.values()), seen
+    bad = rs.copy()
+    bad[5, 0] = -1
+    msk[5] |= 1
+    assert gpu.handle_prepare_oks(leader, number, b_ord, b_rep, msk, bad, rv, rt)[0] == fa.FPX_EINVAL
+    assert ref.handle_prepare_oks(leader, number, b_ord, b_rep, msk, bad, rv, rt)[0] == 1
+    if n == 3:
+        return
+    # 2. recovery of the slow-path instances by replica P = (leader + 1) % n in Ballot(1, P)
+    sl, sx = leader[slow], number[slow]
+    P = ((sl + 1) % n).astype(np.int32)
+    one = np.ones(len(slow), np.int32)
+    everyone_else = (((1 << n) - 1) & ~(1 << P.astype(np.int64))).astype(np.uint8)
+    x, y = (e.prepare(sl, sx, one, P, everyone_else) for e in (gpu, ref))
+    _same(x, y)
+    st, ok, nack, com, nb, rs, rv, rt = x
+    assert (ok == everyone_else).all()
+    x, y = (e.handle_prepare_oks(sl, sx, one, P, ok, rs, rv, rt) for e in (gpu, ref))
+    _same(x, y)
+    st, act, src, trp = x
+    assert (act == 2).all() and (trp == tr[slow]).all()     # every slow-path instance is PreAccepted somewhere: its command again
+    deps0 = np.zeros((len(slow), n), np.int32)
+    x, y = (e.handle_preaccept(sl, sx, one, P, key[slow], is_set[slow], trp, deps0, None, everyone_else) for e in (gpu, ref))
+    _same(x, y)
+    assert (x[1] == everyone_else).all()                    # processed afresh everywhere (a higher ballot)
+    two = np.zeros(len(slow), np.uint8)
+    for j in range(f):
+        two |= (1 << ((P + 1 + j) % n)).astype(np.uint8)
+    x, y = (e.accept(sl, sx, one, P, trp, two, key[slow], is_set[slow]) for e in (gpu, ref))
+    _same(x, y)
+    assert x[5].all()                                       # f + 1 with the proposer: committed
+    for r in range(n):
+        for j in range(0, len(slow), 5):
+            assert gpu.read_cmdlog(r, int(sl[j]), int(sx[j])) == ref.read_cmdlog(r, int(sl[j]), int(sx[j]))
+        for k in range(K):
+            for u, v in zip(gpu.read_index(r, k), ref.read_index(r, k)):
+                np.testing.assert_array_equal(u, v)
