@@ -689,6 +689,14 @@ struct InstanceReplies {
   bool committed = false;                                // Accept: f + 1 AcceptOks, the proposer's included
   std::vector<std::vector<int32_t>> replyDependencies;   // PreAccept: per replica, what its PreAcceptOk / Commit carried
   std::vector<int32_t> replyOwnValuesEnd, replyTripleId;
+  std::vector<int32_t> replyStatus, replyVoteBallot;     // Prepare: per replica the PrepareOk's status (EntryKind, -1 = no
+                                                         // PrepareOk) and voteBallot (encoded ordering * 8 + replicaIndex)
+};
+// Replica.handlePrepareOk's outcome for one instance (Replica.scala:1759-1884)
+struct RecoveryDecision {
+  enum Action { Wait = 0, AcceptPhase = 1, PreAcceptCommand = 2, PreAcceptNoop = 3 } action = Wait;
+  int source = -1;          // the replica whose PrepareOk carries the triple / command (-1: none)
+  int32_t tripleId = -1;
 };
 
 // The conflict indices (and, with numInstances > 0, the command logs) of the n replicas, resident in HBM.
@@ -775,6 +783,34 @@ class PreAcceptEngine {
   std::vector<InstanceReplies> handlePrepare(const std::vector<InstanceMessage>& msgs) { return run(0, msgs); }
   std::vector<InstanceReplies> acceptPhase(const std::vector<InstanceMessage>& msgs) { return run(1, msgs); }
   std::vector<InstanceReplies> handlePreAccept(const std::vector<InstanceMessage>& msgs) { return run(2, msgs); }
+  // Replica.handlePrepareOk (Replica.scala:1759-1884): what the replica that sent prepares[i] does once it holds the
+  // PrepareOks replies[i].ok (as handlePrepare returned them).  asIntended = false evaluates the reference's two tests
+  // as written (:1810 compares a required enum with an Option, :1831 reads the Prepare's ballot: neither can hold)
+  std::vector<RecoveryDecision> handlePrepareOks(const std::vector<InstanceMessage>& prepares,
+                                                 const std::vector<InstanceReplies>& replies, bool asIntended = false) {
+    const int m = (int)prepares.size();
+    if (replies.size() != prepares.size()) throw std::invalid_argument("one set of replies per Prepare");
+    std::vector<int32_t> leader(m), number(m), bo(m), br(m), rs((size_t)m * n_, -1), rv((size_t)m * n_, -1), rt((size_t)m * n_, -1);
+    std::vector<uint8_t> mask(m);
+    for (int i = 0; i < m; ++i) {
+      leader[i] = prepares[i].instance.replicaIndex, number[i] = prepares[i].instance.instanceNumber;
+      bo[i] = prepares[i].ballot.ordering, br[i] = prepares[i].ballot.replicaIndex;
+      if ((int)replies[i].replyStatus.size() != n_) throw std::invalid_argument("replies of handlePrepare expected");
+      unsigned bits = 0;
+      for (int r : replies[i].ok) bits |= 1u << r;
+      mask[i] = (uint8_t)bits;
+      for (int r = 0; r < n_; ++r)
+        rs[(size_t)i * n_ + r] = replies[i].replyStatus[r], rv[(size_t)i * n_ + r] = replies[i].replyVoteBallot[r],
+                      rt[(size_t)i * n_ + r] = replies[i].replyTripleId[r];
+    }
+    std::vector<int32_t> act(m), src(m), tr(m);
+    check(fpx_epx_handle_prepare_oks(epx_, m, leader.data(), number.data(), bo.data(), br.data(), mask.data(), rs.data(),
+                                     rv.data(), rt.data(), asIntended ? 1 : 0, act.data(), src.data(), tr.data()),
+          "Replica.handlePrepareOk");
+    std::vector<RecoveryDecision> out(m);
+    for (int i = 0; i < m; ++i) out[i].action = (RecoveryDecision::Action)act[i], out[i].source = src[i], out[i].tripleId = tr[i];
+    return out;
+  }
 
   CmdLogEntry cmdLog(int replica, Instance instance) {
     int32_t e[5];
@@ -825,10 +861,11 @@ class PreAcceptEngine {
     }
     std::vector<uint8_t> ok(m), resend(m), nack(m), com(m), done(m);
     std::vector<int32_t> nb(m, -1), rd((size_t)m * n_ * n_), re((size_t)m * n_), rt((size_t)m * n_, -1);
+    std::vector<int32_t> rs((size_t)m * n_, -1), rv((size_t)m * n_, -1);
     int32_t st;
     if (kind == 0)
       st = fpx_epx_prepare(epx_, m, leader.data(), number.data(), bo.data(), br.data(), tgt.data(), ok.data(), nack.data(),
-                           com.data(), nb.data(), nullptr, nullptr, rt.data());
+                           com.data(), nb.data(), rs.data(), rv.data(), rt.data());
     else if (kind == 1)
       st = fpx_epx_accept(epx_, m, leader.data(), number.data(), bo.data(), br.data(), tr.data(), key.data(), isSet.data(),
                           tgt.data(), ok.data(), nack.data(), com.data(), nb.data(), done.data());
@@ -846,6 +883,10 @@ class PreAcceptEngine {
       out[i].nackBallot = Ballot::decode(nb[i]);
       out[i].committed = done[i] != 0;
       out[i].replyTripleId.assign(rt.begin() + (size_t)i * n_, rt.begin() + (size_t)(i + 1) * n_);
+      if (kind == 0) {
+        out[i].replyStatus.assign(rs.begin() + (size_t)i * n_, rs.begin() + (size_t)(i + 1) * n_);
+        out[i].replyVoteBallot.assign(rv.begin() + (size_t)i * n_, rv.begin() + (size_t)(i + 1) * n_);
+      }
       if (kind == 2) {
         out[i].replyOwnValuesEnd.assign(re.begin() + (size_t)i * n_, re.begin() + (size_t)(i + 1) * n_);
         for (int r = 0; r < n_; ++r)

@@ -404,6 +404,26 @@ static void epaxosCommandLog() {
     try { (void)engine.acceptPhase({{X, {6, 0}, {1}, 48}}); } catch (const std::logic_error&) { fatal = true; }
     SHOULD_BE(fatal, true);
   }
+  // f) recovery of another instance Y = (2, 3), pre-accepted in Ballot(0, 2) at {0, 1, 3}: replica 4 prepares it in
+  //    Ballot(1, 4), holds three PrepareOk(PreAccepted) and -- as the reference evaluates handlePrepareOk -- pre-accepts
+  //    the command again; as its comments intend, f = 2 identical default-ballot pre-accepts go to the Accept phase
+  {
+    const Instance Y{2, 3};
+    InstanceMessage first{Y, {0, 2}, {0, 1, 3}, 60, {0, true}, {}, 0};
+    SHOULD_BE(engine.handlePreAccept({first})[0].ok, (std::vector<int>{0, 1, 3}));
+    std::vector<InstanceMessage> prep = {{Y, {1, 4}, {0, 1, 3}}};
+    std::vector<InstanceReplies> oks = engine.handlePrepare(prep);
+    SHOULD_BE(oks[0].ok, (std::vector<int>{0, 1, 3}));
+    SHOULD_BE(oks[0].replyStatus, (V{2, 2, -1, 2, -1}));
+    RecoveryDecision asWritten = engine.handlePrepareOks(prep, oks)[0];
+    SHOULD_BE((int)asWritten.action, (int)RecoveryDecision::PreAcceptCommand);
+    SHOULD_BE(asWritten.tripleId, 60);
+    RecoveryDecision asIntended = engine.handlePrepareOks(prep, oks, true)[0];
+    SHOULD_BE((int)asIntended.action, (int)RecoveryDecision::AcceptPhase);
+    SHOULD_BE(asIntended.source, 0);
+    oks[0].ok = {0, 1};  // only two of them in hand: no slow quorum yet
+    SHOULD_BE((int)engine.handlePrepareOks(prep, oks)[0].action, (int)RecoveryDecision::Wait);
+  }
   // two messages for one instance in a batch; a PreAccept that depends on itself
   SHOULD_THROW(engine.handlePrepare({{{1, 1}, {1, 0}, {2}}, {{1, 1}, {1, 0}, {3}}}));
   SHOULD_THROW(engine.handlePreAccept({{{1, 7}, {0, 1}, {0}, 1, {2, false}, {0, 8, 0, 0, 0}, 0}}));
