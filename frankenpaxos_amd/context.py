@@ -421,7 +421,8 @@ class Context:
         return pr, mv
 
     def state_digest(self):
-        """8 uint64 digests of the whole state (fpx_state_digest): two states are equal iff their digests are"""
+        """8 uint64 digests of the whole state (fpx_state_digest): equal states have equal digests; the converse holds up
+        to a collision of a 64-bit additive hash of (position, value) terms -- improbable, not impossible"""
         out = np.zeros(8, np.uint64)
         st = self.L.fpx_state_digest(self._h, _hp(out))
         if st:
