@@ -45,7 +45,12 @@ for f, label, alg in (("bench", "per_slot", 3088), ("bench_acceptor", "acceptor"
     rd_b, wr_b = fe * fetch_scale * 1024, wr * write_scale * 1024
     traffic[label] = rd_b + wr_b
     rows.append((label, fe, wr, rd_b, wr_b, rd_b + wr_b, alg * (1 << 20)))
-json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+try:  # keep the entries other scripts maintain (config4: profiles/microbench/k5_pmc.sh)
+    kept = json.load(open(os.path.join(out, "traffic.json")))
+except Exception:
+    kept = {}
+kept.update(traffic)
+json.dump(kept, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 stats = list(csv.DictReader(open(os.path.join(out, tag + "_kernel_stats.csv"))))
 k2 = [r for r in stats if "k_phase2" in r["Name"]][0]
 bench = json.load(open(os.path.join(base, "trace_bench.json")))
