@@ -414,7 +414,14 @@ int32_t fpx_epx_preaccept(fpx_epx* epx, int32_t m, const int32_t* leader, const 
                           const int32_t* key, const uint8_t* is_set, const uint8_t* resp_mask,
                           const uint8_t* seen_mask, const int32_t* rank, const int32_t* triple_id,
                           uint8_t* fast, int32_t* deps, int32_t* leader_deps, int32_t* own_values_end);
-/* device-resident inputs / outputs, asynchronous; fpx_epx_sync returns the sticky status */
+/* device-resident inputs / outputs; the work is enqueued on the context's stream and fpx_epx_sync returns the sticky
+ * status.  One host wait is inside: for ticks of at most 2048 keys the library partitions the tick by key and runs
+ * one kernel per key group on chip, which needs every key's commands to fit the on-chip tables (1152 per key at
+ * n = 5); whether they do is known once the tick's key histogram is -- a few microseconds of device work after the
+ * stream reaches this call -- and is read from a page-locked word while the next kernels (already enqueued) run.  The
+ * call therefore returns when the stream has reached the tick's first two small kernels, not before; a tick with a
+ * hotter key is then enqueued again in the general form (radix sort of all (key, message) pairs).  Not capturable
+ * into a HIP graph.  FPX_EPX_V1 in the environment at fpx_epx_create selects the general form always. */
 int32_t fpx_epx_preaccept_dev(fpx_epx* epx, int32_t m, const int32_t* d_leader, const int32_t* d_number,
                               const int32_t* d_key, const uint8_t* d_is_set, const uint8_t* d_resp_mask,
                               const uint8_t* d_seen_mask, const int32_t* d_rank, const int32_t* d_triple_id,
