@@ -879,17 +879,23 @@ __global__ void __launch_bounds__(256) k_epx_commit(const EpxState st, const Epx
   if (ts > *s2) *s2 = ts;
 }
 
-// the four output arrays -> one packed line per command (fpx_epx_preaccept_packed_dev through the first form)
+// the four output arrays -> one packed line per command (fpx_epx_preaccept_packed_dev through the first form): 256
+// commands per workgroup, every array read and the lines written with consecutive lanes on consecutive words
 __global__ void __launch_bounds__(256) k_epx_pack(const EpxState st, int m, const uint8_t* fast, const int32_t* deps,
                                                   const int32_t* ldeps, const int32_t* own, int32_t* packed, int stride) {
+  __shared__ int32_t line[256 * 20];
   if (st.status[0] != 0) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
-  const int n = st.n;
-  int32_t* o = packed + (size_t)i * stride;
-  for (int l = 0; l < n; ++l) o[l] = deps[(size_t)i * n + l], o[n + l] = ldeps[(size_t)i * n + l];
-  o[2 * n] = own[(size_t)i * 2], o[2 * n + 1] = own[(size_t)i * 2 + 1], o[2 * n + 2] = fast[i] ? 1 : 0;
-  for (int l = 2 * n + 3; l < stride; ++l) o[l] = 0;
+  const int n = st.n, i0 = blockIdx.x * 256, cnt = min(256, m - i0);
+  for (int t = threadIdx.x; t < cnt * stride; t += 256) line[t] = 0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < cnt * n; t += 256) {
+    const int c = t / n, l = t - c * n;
+    line[c * stride + l] = deps[(size_t)i0 * n + t], line[c * stride + n + l] = ldeps[(size_t)i0 * n + t];
+  }
+  for (int t = threadIdx.x; t < cnt * 2; t += 256) line[(t >> 1) * stride + 2 * n + (t & 1)] = own[(size_t)i0 * 2 + t];
+  if ((int)threadIdx.x < cnt) line[threadIdx.x * stride + 2 * n + 2] = fast[i0 + threadIdx.x] ? 1 : 0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < cnt * stride; t += 256) packed[(size_t)i0 * stride + t] = line[t];
 }
 
 // ---- the per-instance Paxos of EPaxos on the command log: Prepare (phase 1) and Accept (phase 2) ---------------
@@ -1638,7 +1644,9 @@ static int32_t preaccept_dev_impl(fpx_epx* e, int32_t m, const int32_t* d_leader
   int rc;
   // the second form (fpx_epaxos_kp.hpp): one partition pass by key, everything else on chip -- when the keys are
   // one LDS counter each and ranks and slots share a 32-bit sort word
+  const int kp_tc = n == 3 ? KpTile<3>::TC : n == 5 ? KpTile<5>::TC : KpTile<7>::TC;
   if (!e->kp_off && e->kp_flag_dev && e->st.num_keys <= KP_MAXB && m < (1 << 21) &&
+      (long long)m <= (long long)e->st.num_keys * kp_tc &&  // (else some key must overflow the on-chip tables)
       ((e->st.num_instances == 0 && !d_triple_id) || n >= 5)) {  // (n = 3 with a command log: the first form)
     EpxBatch kb;
     memset(&kb, 0, sizeof(kb));

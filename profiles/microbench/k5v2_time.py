@@ -1,5 +1,5 @@
 """times the K5 tick (BASELINE.json configs[3] workload) on the library FPX_LIB names: packed lines and the four arrays"""
-import sys, time
+import os, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, ".")
@@ -7,7 +7,7 @@ from frankenpaxos_amd.epaxos import EPaxos
 from tests import workloads as W
 from tests.workloads import random_tick
 
-n, num_keys, m = 5, 1024, 1 << 20
+n, num_keys, m = int(os.environ.get("K5_N", "5")), 1024, 1 << 20
 dev = torch.device("cuda:0")
 epx = EPaxos(n, num_keys)
 epx.set_stream(torch.cuda.current_stream().cuda_stream)
