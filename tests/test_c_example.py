@@ -28,3 +28,28 @@ def test_plain_c_caller_builds_links_and_fails_loudly_without_a_device():
     else:
         assert run.returncode == 77, run.stdout + run.stderr
         assert "no usable gfx950 device" in run.stdout
+
+
+def test_plain_c_epaxos_caller():
+    """examples/epaxos_demo.c: tick -> Accept phase of the slow path -> dependency graph -> execution, through
+    include/fpx.h and include/fpx_depgraph.h alone"""
+    import torch
+
+    import frankenpaxos_amd
+
+    if not os.path.exists(frankenpaxos_amd._lib.SO_PATH):
+        frankenpaxos_amd.build()
+    csrc = os.path.join(ROOT, "frankenpaxos_amd", "csrc")
+    out_dir = os.path.join(ROOT, "tests", "build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "epaxos_demo")
+    subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "examples", "epaxos_demo.c"),
+                           "-I" + os.path.join(ROOT, "include"), "-L" + csrc, "-lfpx", "-Wl,-rpath," + csrc,
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    if torch.cuda.is_available():
+        assert run.returncode == 0, run.stdout + run.stderr
+        assert "400 of 400 commands executed" in run.stdout and " 5 blockers" in run.stdout
+    else:
+        assert run.returncode == 77, run.stdout + run.stderr
+        assert "no usable gfx950 device" in run.stdout
