@@ -1,6 +1,6 @@
 """Randomised K5 stress beside the oracle (python profiles/microbench/stress_epaxos.py on a GPU box): 24 seeds x 3 ticks,
 n in {3, 5, 7}, 7 .. 2048 keys, 1 k .. 120 k commands per tick, skews 1 .. 200, hot keys, with and without the command
-log.  Prints the number of mismatches (0 on the r02 build)."""
+log.  Prints the number of mismatches (0 on the r02 and r03 builds)."""
 import os, sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -33,4 +33,12 @@ for seed in range(24):
             ga, sa = gpu.read_index(r, int(k)); gb, sb = ref.read_index(r, int(k))
             if ga.tolist() != gb.tolist() or sa.tolist() != sb.tolist():
                 bad += 1; print("INDEX MISMATCH seed", seed)
+        if NI:   # the command log, sampled
+            for inst in rng.choice(n * min(NI, max(nxt) + 1), size=60, replace=False):
+                L, x = int(inst) % n, int(inst) // n
+                if gpu.read_cmdlog(r, L, x) != ref.read_cmdlog(r, L, x):
+                    bad += 1; print("CMDLOG MISMATCH seed", seed, r, L, x)
+                c, d = gpu.read_cmdlog_deps(r, L, x), ref.read_cmdlog_deps(r, L, x)
+                if c[0].tolist() != d[0].tolist() or c[1] != d[1]:
+                    bad += 1; print("CMDLOG DEPS MISMATCH seed", seed, r, L, x)
 print("stress done, mismatches:", bad)
