@@ -49,7 +49,10 @@ template <int N> struct KpTile {
   // LDS: records | region R | radix counters + cursors | part totals | misc.  R holds the two sort buffers and the rank
   // buckets while a key is sorted, then the conflict rows [TC][N - 1][N]: the n-2 counted answers and the leader's own
   static constexpr size_t SORT_BYTES = (size_t)2 * N * TC * 4 + (size_t)N * NBK * 4;
-  static constexpr size_t ROWS_BYTES = (size_t)TC * (N - 1) * N * 4;
+  static constexpr int RSTR = (N - 1) * N + 1;  // ints between two commands' conflict rows: odd, so that random commands
+                                                // spread over all LDS banks ((N - 1) N = 20 reaches 16 of 64: 40 % of the
+                                                // kernel's LDS cycles were bank conflicts)
+  static constexpr size_t ROWS_BYTES = (size_t)TC * RSTR * 4;
   static constexpr size_t R_BYTES = SORT_BYTES > ROWS_BYTES ? SORT_BYTES : ROWS_BYTES;
   static constexpr size_t BYTES = (size_t)TC * NI * 4 + R_BYTES + (size_t)2 * N * W * KP_RADIX * 4 + (size_t)N * W * 2 * N * 4 + 256 +
                                   (size_t)N * 2 * N * 4;
@@ -543,7 +546,7 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
         if (valid && (L == r || ((resp >> r) & 1u))) {
           const int ri = L == r ? N - 2 : (int)__popc(resp & ((1u << r) - 1u));
 #pragma unroll
-          for (int l = 0; l < N; ++l) rows[(sl * (N - 1) + ri) * N + l] = dep[l];
+          for (int l = 0; l < N; ++l) rows[sl * T::RSTR + ri * N + l] = dep[l];
         }
       }
     }
@@ -558,7 +561,7 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
       const int i = RF(0, sl), x = RF(1, sl), L = RF(2, sl) & 7;
       bool fast = true;
       int od[N], ol[N], oe0 = 0, oe1 = 0, raw_hi = 0, raw_d = 0;
-      const int* row = rows + (size_t)sl * (N - 1) * N;
+      const int* row = rows + (size_t)sl * T::RSTR;
 #pragma unroll
       for (int l = 0; l < N; ++l) {
         const int dl = row[(N - 2) * N + l];
@@ -580,7 +583,7 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
         // the packed line takes the place of the command's conflict rows (read above) and leaves below, four lanes
         // per 64-byte line: a store instruction then covers 16 whole lines instead of 16 bytes of 64 different ones
         int line[2 * N + 6];
-        int* o = COOP ? rows + (size_t)sl * (N - 1) * N : line;  // (n = 3: the rows are too short, the thread stores its line)
+        int* o = COOP ? rows + (size_t)sl * T::RSTR : line;  // (n = 3: the rows are too short, the thread stores its line)
 #pragma unroll
         for (int l = 0; l < N; ++l) o[l] = od[l], o[N + l] = ol[l];
         o[2 * N] = oe0, o[2 * N + 1] = oe1, o[2 * N + 2] = fast ? 1 : 0;
@@ -596,11 +599,11 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
         if (b.own_values_end) *reinterpret_cast<int2*>(b.own_values_end + (size_t)i * 2) = make_int2(oe0, oe1);
         // the rows leave below as whole n-int lines: the command's conflict rows are spent, rows 0 and 1 take them
 #pragma unroll
-        for (int l = 0; l < N; ++l) rows[(sl * (N - 1)) * N + l] = od[l], rows[(sl * (N - 1) + 1) * N + l] = ol[l];
+        for (int l = 0; l < N; ++l) rows[sl * T::RSTR + l] = od[l], rows[sl * T::RSTR + N + l] = ol[l];
       }
       if constexpr (CLOG) {
         if (st.num_instances > 0) {  // what the command-log pass below needs of the decision, behind the packed line
-          int* o = rows + (size_t)sl * (N - 1) * N;
+          int* o = rows + (size_t)sl * T::RSTR;
           o[2 * N] = oe0, o[2 * N + 1] = oe1, o[2 * N + 2] = fast ? 1 : 0, o[2 * N + 6] = raw_hi, o[2 * N + 7] = raw_d;
         }
       }
@@ -610,7 +613,7 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
       constexpr int Q = (2 * N + 3 + 3) / 4;  // int4's of a line: 3, 4, 5 for n = 3, 5, 7
       for (int t = threadIdx.x; t < c * Q; t += T::THREADS) {
         const int sl = t / Q, q = t - sl * Q;
-        const int* o = rows + (size_t)sl * (N - 1) * N + 4 * q;
+        const int* o = rows + (size_t)sl * T::RSTR + 4 * q;
         reinterpret_cast<int4*>(a.packed + (size_t)RF(0, sl) * a.stride)[q] = make_int4(o[0], o[1], o[2], o[3]);
       }
     }
@@ -619,8 +622,8 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
       for (int t = threadIdx.x; t < c * N; t += T::THREADS) {
         const int sl = t / N, l = t - sl * N;
         const size_t o = (size_t)RF(0, sl) * N + l;
-        if (b.deps) b.deps[o] = rows[(sl * (N - 1)) * N + l];
-        if (b.leader_deps) b.leader_deps[o] = rows[(sl * (N - 1) + 1) * N + l];
+        if (b.deps) b.deps[o] = rows[sl * T::RSTR + l];
+        if (b.leader_deps) b.leader_deps[o] = rows[sl * T::RSTR + N + l];
       }
     }
     // ---- the command log (num_instances > 0; Replica.scala:688-696, 815-823, 1259-1271): a fast-path commit is a
@@ -649,7 +652,7 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
           if (p0 + cc * 64 < p1) scan_chunk<N>(valid, (fl >> 3) & 1, L, x + 1, cg, cs, ng, ns, dep);
           if (!valid) continue;
           const unsigned seen = (((unsigned)fl >> 16) & 0xffu) | (1u << L);
-          const int* o = rows + (size_t)sl * (N - 1) * N;
+          const int* o = rows + (size_t)sl * T::RSTR;
           const bool fast = o[2 * N + 2] != 0;
           const int tr = b.triple ? b.triple[RF(0, sl)] : -1;
           int t[N], end = 0;
