@@ -220,7 +220,10 @@ def mencius_setup(fa, dev, local_rank, rank, world, K, Wm):
         active = (lgs + w) % 2 == 0                       # the leader groups with commands alternate
         base = w * band
         r = torch.arange(rows, device=dev, dtype=torch.int64)
-        slot = (base + r[:, None] * L + lgs[active][None, :]).reshape(-1).to(torch.int32)
+        if os.environ.get("FPX_CFG5_ORDER") == "slot":      # one batch in slot order over all proposing leader groups
+            slot = (base + r[:, None] * L + lgs[active][None, :]).reshape(-1).to(torch.int32)
+        else:                                               # the proposing leader groups' batches back to back, each in slot order
+            slot = (base + r[None, :] * L + lgs[active][:, None]).reshape(-1).to(torch.int32)
         idle = lgs[~active]
         start = (base + idle).to(torch.int32)
         end = (base + (rows - 1) * L + idle + 1).to(torch.int32)

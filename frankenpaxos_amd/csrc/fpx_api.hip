@@ -170,6 +170,11 @@ int check_config(const fpx_config* c) {
   return FPX_OK;
 }
 
+// the row of slot s in the cell arrays and tally tables (device: phys_slot)
+static inline size_t host_phys_slot(const Geom& g, int s) {
+  return g.lg_rows ? (size_t)(s % g.num_leader_groups) * g.lg_rows + (size_t)(s / g.num_leader_groups) : (size_t)s;
+}
+
 void make_geom(const fpx_config& c, Geom* g) {
   memset(g, 0, sizeof(*g));
   g->S = c.num_slots;
@@ -180,6 +185,9 @@ void make_geom(const fpx_config& c, Geom* g) {
   g->num_groups = c.num_groups;
   g->num_leader_groups = c.num_leader_groups;
   g->ngroups = c.num_groups * c.num_leader_groups;
+  // Mencius: rows leader-group-major when the window is a whole number of rounds over the leader groups
+  g->lg_rows = (c.num_leader_groups > 1 && c.num_slots % c.num_leader_groups == 0 && !getenv("FPX_SLOT_MAJOR"))
+                   ? c.num_slots / c.num_leader_groups : 0;
   g->qkind = c.quorum_kind;
   g->total = c.replicas_total ? c.replicas_total : c.num_replicas;
   g->base = c.replica_base;
@@ -1505,8 +1513,12 @@ int32_t fpx_proxy_forget(fpx_ctx* ctx, int32_t first_slot, int32_t count) {
   if (!ctx || first_slot < 0 || count < 0 || (int64_t)first_slot + count > ctx->g.S) return FPX_EINVAL;
   if (count == 0) return FPX_OK;
   // an empty key word is all a tally entry needs to be free again (values / bitmaps are rewritten on open)
-  HIPCHK(ctx, hipMemsetAsync(ctx->st.pl_key + (size_t)first_slot * ctx->g.wp, 0, (size_t)count * ctx->g.wp * 4,
-                             ctx->stream));
+  if (ctx->g.lg_rows) {  // the slots of the range are not neighbours in memory: one thread per slot
+    hipLaunchKernelGGL(k_clear_slots, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, ctx->g, ctx->st, first_slot, count, 0);
+  } else {
+    HIPCHK(ctx, hipMemsetAsync(ctx->st.pl_key + (size_t)first_slot * ctx->g.wp, 0, (size_t)count * ctx->g.wp * 4,
+                               ctx->stream));
+  }
   if (ctx->rt[0].key) {
     // the noop-range tallies that lie inside the window go too: the survivors move to the other table buffer
     const RangeTable& from = ctx->rt[ctx->rt_cur];
@@ -1525,10 +1537,15 @@ int32_t fpx_recycle_slots(fpx_ctx* ctx, int32_t first_slot, int32_t count) {
   DeviceGuard _dg(ctx);
   if (!ctx || first_slot < 0 || count < 0 || (int64_t)first_slot + count > ctx->g.S) return FPX_EINVAL;
   if (count == 0) return FPX_OK;
-  const size_t row = (size_t)ctx->g.VS * 4, at = (size_t)first_slot * row, len = (size_t)count * row;
-  HIPCHK(ctx, hipMemsetAsync((char*)ctx->st.vote_round + at, 0xFF, len, ctx->stream));  // -1: no vote
-  if (ctx->g.VS == ctx->g.RS) HIPCHK(ctx, hipMemsetAsync((char*)ctx->st.vote_value + at, 0xFF, len, ctx->stream));
-  if (ctx->st.row_voted) HIPCHK(ctx, hipMemsetAsync(ctx->st.row_voted + first_slot, 0, (size_t)count, ctx->stream));
+  if (ctx->g.lg_rows) {
+    hipLaunchKernelGGL(k_clear_slots, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, ctx->g, ctx->st, first_slot, count, 1);
+  } else {
+    const size_t row = (size_t)ctx->g.VS * 4, at = (size_t)first_slot * row, len = (size_t)count * row;
+    HIPCHK(ctx, hipMemsetAsync((char*)ctx->st.vote_round + at, 0xFF, len, ctx->stream));  // -1: no vote
+    if (ctx->g.VS == ctx->g.RS) HIPCHK(ctx, hipMemsetAsync((char*)ctx->st.vote_value + at, 0xFF, len, ctx->stream));
+    if (ctx->st.row_voted) HIPCHK(ctx, hipMemsetAsync(ctx->st.row_voted + first_slot, 0, (size_t)count, ctx->stream));
+  }
+
   return fpx_proxy_forget(ctx, first_slot, count);
 }
 
@@ -1569,7 +1586,11 @@ static int enqueue_ranges(fpx_ctx* ctx, RangeBatch& b, int mode) {
   if (acceptors) {
     const long long threads = (long long)b.n * g.num_groups * g.R;
     hipLaunchKernelGGL(k_ranges_acceptors, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, g, ctx->st, b);
-    if (b.n <= RF_MAXN && g.num_leader_groups <= RF_MAXL && !getenv("FPX_RANGES_FILL_V1")) {
+    if (g.lg_rows) {  // leader-group-major rows: a range is one run of rows
+      const int gy = std::min(b.n, 4096);
+      const int gx = std::max(1, std::min(ctx->num_cus * 16 / gy, 64));
+      hipLaunchKernelGGL(k_ranges_fill_lg, dim3(gx, gy), dim3(256), 0, ctx->stream, g, ctx->st, b);
+    } else if (b.n <= RF_MAXN && g.num_leader_groups <= RF_MAXL && !getenv("FPX_RANGES_FILL_V1")) {
       // sweep the log rows the ranges touch in memory order (fpx_ranges.hpp)
       hipLaunchKernelGGL(k_ranges_fill_rows, dim3(ctx->num_cus * 8), dim3(256), (size_t)RF_JB * g.num_leader_groups * 4,
                          ctx->stream, g, ctx->st, b);
@@ -1932,15 +1953,22 @@ int32_t fpx_read_state(fpx_ctx* ctx, int32_t* vote_round, int32_t* vote_value, i
   }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   // device rows are RS cells long, the caller's are R
-  if (vote_round)
-    HIPCHK(ctx, hipMemcpy2D(vote_round, R * 4, ctx->st.vote_round, (size_t)ctx->g.VS * 4, R * 4, S, hipMemcpyDeviceToHost));
-  if (vote_value)
-    HIPCHK(ctx, hipMemcpy2D(vote_value, R * 4, ctx->st.vote_value, (size_t)ctx->g.VS * 4, R * 4, S, hipMemcpyDeviceToHost));
+  // leader-group-major rows: leader group lg's rows are contiguous on the device and every L-th row of the caller's array
+  const size_t L = ctx->g.lg_rows ? (size_t)ctx->g.num_leader_groups : 1, rows = S / L;
+  auto fetch = [&](int32_t* dst, const int32_t* src, size_t src_stride) -> int {
+    for (size_t lg = 0; lg < L; ++lg)
+      HIPCHK(ctx, hipMemcpy2D(dst + lg * R, L * R * 4, src + lg * rows * src_stride, src_stride * 4, R * 4, rows, hipMemcpyDeviceToHost));
+    return FPX_OK;
+  };
+  int rc2;
+  if (vote_round && (rc2 = fetch(vote_round, ctx->st.vote_round, (size_t)ctx->g.VS))) return rc2;
+  if (vote_value && (rc2 = fetch(vote_value, ctx->st.vote_value, (size_t)ctx->g.VS))) return rc2;
   if (ballot) {
-    if (ctx->st.ballot)
-      HIPCHK(ctx, hipMemcpy2D(ballot, R * 4, ctx->st.ballot, RS * 4, R * 4, S, hipMemcpyDeviceToHost));
-    else
+    if (ctx->st.ballot) {
+      if ((rc2 = fetch(ballot, ctx->st.ballot, RS))) return rc2;
+    } else {
       std::fill(ballot, ballot + S * R, -1);
+    }
   }
   return FPX_OK;
 }
@@ -2245,9 +2273,10 @@ int32_t fpx_read_tally(fpx_ctx* ctx, int32_t slot, int32_t* num_entries, int32_t
   int32_t vals[8];
   uint64_t bits[32];
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  HIPCHK(ctx, hipMemcpy(keys, ctx->st.pl_key + (size_t)slot * wp, (size_t)wp * 4, hipMemcpyDeviceToHost));
-  HIPCHK(ctx, hipMemcpy(vals, ctx->st.pl_value + (size_t)slot * wp, (size_t)wp * 4, hipMemcpyDeviceToHost));
-  HIPCHK(ctx, hipMemcpy(bits, ctx->st.pl_bits + (size_t)slot * wp * 4, (size_t)wp * 32, hipMemcpyDeviceToHost));
+  const size_t prow = host_phys_slot(ctx->g, slot);
+  HIPCHK(ctx, hipMemcpy(keys, ctx->st.pl_key + prow * wp, (size_t)wp * 4, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(vals, ctx->st.pl_value + prow * wp, (size_t)wp * 4, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(bits, ctx->st.pl_bits + prow * wp * 4, (size_t)wp * 32, hipMemcpyDeviceToHost));
   int cnt = 0;
   for (int w = 0; w < ctx->g.ways; ++w) {
     if (keys[w] == 0 || (keys[w] & KEY_RANGE)) continue;  // range tallies are not per-slot tallies

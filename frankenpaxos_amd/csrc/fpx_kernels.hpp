@@ -67,6 +67,10 @@ enum { ST_CODE = 0, ST_INDEX = 1, ST_SLOT = 2, ST_ROUND = 3, ST_ABORT = 4 };
 
 struct Geom {
   int32_t S, R;
+  int32_t lg_rows;                                 // > 0: rows are stored leader-group-major -- slot s lives in row
+                                                   // (s % L) * lg_rows + s / L (lg_rows = S / L): the slots of one leader group are
+                                                   // neighbours in memory, so what one group's leader proposes or skips covers whole
+                                                   // lines whatever the other groups do (0: row = slot)
   int32_t VS;                                      // row stride of vote_round / vote_value: RS, or 2 RS when the two rows of
                                                    // a slot are interleaved (R <= 4: [round x 4 | value x 4] is ONE 32-byte sector;
                                                    // as two arrays every small-group vote wrote two half sectors)
@@ -143,6 +147,15 @@ __device__ __forceinline__ int group_of_slot(const Geom& g, int slot) {
   const int lg = slot % g.num_leader_groups;
   const int ag = (slot / g.num_leader_groups) % g.num_groups;
   return lg * g.num_groups + ag;
+}
+
+// where slot s lives in the cell arrays and the tally tables (vote_round, vote_value, ballot, pl_key, pl_value, pl_bits),
+// row_voted), and which slot a row holds; stamp and the replica log are indexed by the slot itself
+__device__ __forceinline__ int phys_slot(const Geom& g, int s) {
+  return g.lg_rows ? (s % g.num_leader_groups) * g.lg_rows + s / g.num_leader_groups : s;
+}
+__device__ __forceinline__ int slot_of_row(const Geom& g, int p) {
+  return g.lg_rows ? (p % g.lg_rows) * g.num_leader_groups + p / g.lg_rows : p;
 }
 
 __device__ __forceinline__ void report(const State& st, int code, int index, int slot, int round) {
@@ -293,6 +306,23 @@ __device__ __forceinline__ int group_max(int v) {
   return v;
 }
 
+// max over the 64 lanes of values >= 0 on the DPP network (4 row_shr steps inside each row of 16, row_bcast:15 / :31
+// across the rows; lanes without a source read 0): the total arrives in lane 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_or0(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ int wave_max_to_lane63(int v) {
+  int o;
+  o = dpp_or0<0x111, 0xF>(v), v = o > v ? o : v;  // row_shr:1
+  o = dpp_or0<0x112, 0xF>(v), v = o > v ? o : v;  // row_shr:2
+  o = dpp_or0<0x114, 0xF>(v), v = o > v ? o : v;  // row_shr:4
+  o = dpp_or0<0x118, 0xF>(v), v = o > v ? o : v;  // row_shr:8
+  o = dpp_or0<0x142, 0xA>(v), v = o > v ? o : v;  // row_bcast:15 -> rows 1, 3
+  o = dpp_or0<0x143, 0xC>(v), v = o > v ? o : v;  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 // wave-level ordering of LDS traffic between lanes of one wavefront (DS ops of a wave execute in
 // order; this keeps the compiler from moving them)
 __device__ __forceinline__ void wave_lds_sync() {
@@ -305,6 +335,19 @@ __device__ __forceinline__ void wave_lds_sync() {
 // kernels on this stack, a kernel launch ~5 us: profiles/r02_adversarial.txt)
 __global__ void __launch_bounds__(256) k_fill32(int32_t* p, int32_t v, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// fpx_proxy_forget / fpx_recycle_slots when rows are leader-group-major (the slots of a range are L rows apart): one
+// thread per slot -- its tally keys emptied, with votes != 0 its cells back to "no vote"
+__global__ void __launch_bounds__(256) k_clear_slots(const Geom g, const State st, int first, int count, int votes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const size_t ps = (size_t)phys_slot(g, first + i);
+  for (int w = 0; w < g.wp; ++w) st.pl_key[ps * g.wp + w] = 0;
+  if (votes) {
+    for (int r = 0; r < g.RS; ++r) st.vote_round[ps * g.VS + r] = -1, st.vote_value[ps * g.VS + r] = -1;
+    if (st.row_voted) st.row_voted[ps] = 0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -449,14 +492,14 @@ __global__ void __launch_bounds__(256)
     // vote -- thrifty delivery to a random f+1 of the group (ProxyLeader.scala:190-191), or some acceptors
     // Nacking -- can be stored as whole 16-byte cells blended with -1: full-line traffic, nothing read
     bool myfresh = false;
-    if constexpr (TGT) myfresh = mv && st.row_voted[myslot] == 0;
+    if constexpr (TGT) myfresh = mv && st.row_voted[phys_slot(g, myslot)] == 0;
     // ProxyLeader.handlePhase2a for 64 messages at once (ProxyLeader.scala:176-184): lane i reads the
     // tally-key row of its slot (one gathered 16-byte access per lane), detects a known (slot, round)
     // and picks the free way.  The key word is written back after the walk, one lane per message.
     int myway = -1;
     bool mydeliver = mv;
     if (FUSED && mv) {
-      const uint32_t* kr = st.pl_key + (size_t)myslot * g.wp;
+      const uint32_t* kr = st.pl_key + (size_t)phys_slot(g, myslot) * g.wp;
       const uint4v k0 = *reinterpret_cast<const uint4v*>(kr);
       uint4v k1 = uint4v{0, 0, 0, 0};
       if (g.wp == 8) k1 = *reinterpret_cast<const uint4v*>(kr + 4);
@@ -489,7 +532,7 @@ __global__ void __launch_bounds__(256)
       grp_out = 0;
       int4v thr = init_thr;
       if (s >= 0) {
-        const size_t row = (size_t)s * (size_t)g.RS + (size_t)r0;
+        const size_t row = (size_t)phys_slot(g, s) * (size_t)g.RS + (size_t)r0;
         if (!one_group) grp_out = group_of_slot(g, s);
         if (PERSLOT) {
           if (VEC) {
@@ -579,7 +622,7 @@ __global__ void __launch_bounds__(256)
         // first votes of the slot: cells whose acceptor does not vote hold -1 / -1.  ONE store path for the whole
         // row (fully voted cells included): two half-masked store instructions per array cost the issue
         // slots of two full ones
-        const size_t row = (size_t)s * (size_t)g.RS + (size_t)r0, vrow = (size_t)s * (size_t)g.VS + (size_t)r0;
+        const size_t ps = (size_t)phys_slot(g, s), row = ps * (size_t)g.RS + (size_t)r0, vrow = ps * (size_t)g.VS + (size_t)r0;
         int4v rr, vv, nb = thr;
         bool ballot_moves = false;
 #pragma unroll
@@ -592,7 +635,7 @@ __global__ void __launch_bounds__(256)
         row_store(vv, reinterpret_cast<int4v*>(st.vote_value + vrow));
         if (PERSLOT && ballot_moves) row_store(nb, reinterpret_cast<int4v*>(st.ballot + row));
       } else if (acc) {
-        const size_t row = (size_t)s * (size_t)g.RS + (size_t)r0, vrow = (size_t)s * (size_t)g.VS + (size_t)r0;
+        const size_t ps = (size_t)phys_slot(g, s), row = ps * (size_t)g.RS + (size_t)r0, vrow = ps * (size_t)g.VS + (size_t)r0;
         // whole-lane fast path: every acceptor this lane owns voted (padding cells may be overwritten)
         if (VEC && full_cell) {
           const int4v rr = {rnd, rnd, rnd, rnd};
@@ -640,10 +683,40 @@ __global__ void __launch_bounds__(256)
       // maxVotedSlot (Acceptor.scala:209) and the acceptor's new round.  When the WHOLE group voted
       // (the steady state) the maxima are the same for every acceptor: two wave-uniform scalars.
       const bool whole_group = (G == 64) && one_group && __all(acc == own);
+      // G = 1 with several acceptor groups: a step whose 64 slots belong to ONE group (a leader group's batch; with
+      // leader-group-major rows the batches of a launch are best sent that way) would send 64 lanes to the same LDS
+      // words, 2 R serialized atomics each.  Fold such a step in registers; lane 63 alone touches the table.
+      bool folded = false;
+      if constexpr (G == 1) {
+        if (!one_group) {
+          const uint64_t have = __ballot(acc != 0);
+          if (have) {
+            const int g0 = __shfl(grp_cur, (int)__ffsll((unsigned long long)have) - 1);
+            if (__all(acc == 0 || grp_cur == g0)) {
+              folded = true;
+              table_used = true;
+              const int e = g0 * g.R;
+              if (__all(acc == 0 || acc == own)) {  // every acceptor of the group voted wherever one did
+                const int ms = wave_max_to_lane63(acc ? s + 1 : 0), mr = wave_max_to_lane63(acc ? rnd + 1 : 0);
+                if (lane == 63) {
+                  for (int k = 0; k < g.R; ++k) atomicMax(&tab_mv[e + k], ms - 1), atomicMax(&tab_pr[e + k], mr - 1);
+                }
+              } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  const bool a = (acc >> k) & 1u;
+                  const int ms = wave_max_to_lane63(a ? s + 1 : 0), mr = wave_max_to_lane63(a ? rnd + 1 : 0);
+                  if (lane == 63 && ms > 0) atomicMax(&tab_mv[e + k], ms - 1), atomicMax(&tab_pr[e + k], mr - 1);
+                }
+              }
+            }
+          }
+        }
+      }
       if (whole_group) {
         w_slot = s > w_slot ? s : w_slot;
         w_round = rnd > w_round ? rnd : w_round;
-      } else if (acc) {
+      } else if (acc && !folded) {
         if (one_group) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -693,7 +766,7 @@ __global__ void __launch_bounds__(256)
           for (int w = 0; w < 4; ++w) x[w] = vb[w] & g.member[w];
           ch = is_write_quorum(g, x);
           if (!ch && gi == 0) {  // stays Pending: keep the votes (the key word is written below)
-            const size_t e = (size_t)s * g.wp + way;
+            const size_t e = (size_t)phys_slot(g, s) * g.wp + way;
 #pragma unroll
             for (int w = 0; w < 4; ++w) st.pl_bits[e * 4 + w] = x[w];
           }
@@ -713,7 +786,7 @@ __global__ void __launch_bounds__(256)
     // ---- outputs of the 64 messages leave as coalesced lines ------------------------------------
     wave_lds_sync();
     // the slot's row is no longer known to be all -1 (marked even if every acceptor Nacked: that only costs the shortcut)
-    if (TGT ? (myfresh && mydeliver) : (mv && mydeliver)) st.row_voted[myslot] = 1;
+    if (TGT ? (myfresh && mydeliver) : (mv && mydeliver)) st.row_voted[phys_slot(g, myslot)] = 1;
     if (mv) {
       if constexpr (!FUSED) {
         if (b.vote_bits) {
@@ -730,7 +803,7 @@ __global__ void __launch_bounds__(256)
         const bool ch = wo->chosen[lane] != 0;
         if (mydeliver) {
           // states(slotround) = Done (ProxyLeader.scala:256) or Pending(phase2a, votes) (:213)
-          const size_t e = (size_t)myslot * g.wp + myway;
+          const size_t e = (size_t)phys_slot(g, myslot) * g.wp + myway;
           st.pl_key[e] = ((uint32_t)myround + 1u) | (ch ? KEY_DONE : 0u);
           if (!ch) st.pl_value[e] = myvalue;
         }
@@ -841,7 +914,8 @@ __global__ void __launch_bounds__(256) k_open(const Geom g, const State st, cons
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b.n) return;
   const int s = b.slot[i], rnd = b.round[i];
-  uint32_t* kr = st.pl_key + (size_t)s * g.wp;
+  const size_t ps = (size_t)phys_slot(g, s);
+  uint32_t* kr = st.pl_key + ps * g.wp;
   const uint32_t want = (uint32_t)rnd + 1u;
   int way = -1;
   bool dup = false;
@@ -855,7 +929,7 @@ __global__ void __launch_bounds__(256) k_open(const Geom g, const State st, cons
     if (way < 0) {
       report(st, 5, i, s, rnd);
     } else {
-      const size_t e = (size_t)s * g.wp + way;
+      const size_t e = ps * g.wp + way;
       st.pl_key[e] = want;
       st.pl_value[e] = b.value[i];
 #pragma unroll
@@ -882,7 +956,8 @@ __global__ void __launch_bounds__(256) k_tally(const Geom g, const State st, con
   uint8_t ch = 0;
   int cr = -1, cv = -1;
   if ((in[0] | in[1] | in[2] | in[3]) != 0) {
-    const uint32_t* kr = st.pl_key + (size_t)s * g.wp;
+    const size_t ps = (size_t)phys_slot(g, s);
+    const uint32_t* kr = st.pl_key + ps * g.wp;
     const uint32_t want = (uint32_t)rnd + 1u;
     int way = -1;
     uint32_t key = 0;
@@ -894,7 +969,7 @@ __global__ void __launch_bounds__(256) k_tally(const Geom g, const State st, con
       report(st, 2 /*FPX_EFATAL_UNKNOWN_SLOTROUND*/, i, s, rnd);  // :220-225
     } else if (!(key & (KEY_DONE | KEY_RANGE))) {  // Done -> ignored, :227-232; a pending noop range
                                                    // under the same key -> ignored, mencius :327-333
-      const size_t e = (size_t)s * g.wp + way;
+      const size_t e = ps * g.wp + way;
       uint64_t x[4];
 #pragma unroll
       for (int w = 0; w < 4; ++w) x[w] = st.pl_bits[e * 4 + w] | in[w];  // :237
@@ -991,7 +1066,7 @@ __global__ void __launch_bounds__(256) k_p1a_sweep(const Geom g, const State st,
   const int wm = watermark < 0 ? 0 : watermark;
   const size_t ncell = (size_t)g.S * g.RS;
   for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += (size_t)gridDim.x * blockDim.x) {
-    const int s = (int)(c / g.RS), r = (int)(c % g.RS);
+    const int s = slot_of_row(g, (int)(c / g.RS)), r = (int)(c % g.RS);
     if (r >= g.R) continue;
     const int m = mode[r];
     if (m == 0 || group_of_slot(g, s) != group) continue;
@@ -1037,7 +1112,7 @@ __global__ void __launch_bounds__(256) k_p1a_sweep(const Geom g, const State st,
 __global__ void __launch_bounds__(256) k_lazy_flush(const Geom g, const State st) {
   const size_t ncell = (size_t)g.S * g.RS;
   for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += (size_t)gridDim.x * blockDim.x) {
-    const int s = (int)(c / g.RS), r = (int)(c % g.RS);
+    const int s = slot_of_row(g, (int)(c / g.RS)), r = (int)(c % g.RS);
     if (r >= g.R) continue;
     const size_t e = (size_t)group_of_slot(g, s) * g.R + r;
     const int lr = st.lz_round[e];
@@ -1080,7 +1155,7 @@ __global__ void __launch_bounds__(256) k_gather_acceptor(const Geom g, const Sta
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= g.S) return;
   const bool mine = group_of_slot(g, s) == group;
-  const size_t c = (size_t)s * g.RS + replica, vc = (size_t)s * g.VS + replica;
+  const size_t ps = (size_t)phys_slot(g, s), c = ps * g.RS + replica, vc = ps * g.VS + replica;
   vr[s] = mine ? st.vote_round[vc] : -1;
   vv[s] = mine ? st.vote_value[vc] : -1;
   bl[s] = (mine && st.ballot) ? st.ballot[c] : -1;
@@ -1243,7 +1318,7 @@ __global__ void __launch_bounds__(256)
     int best_round = -1, best_val = -1, best_idx = 1 << 30;
     if (live && r0 < g.R) {
       const int grp = group_of_slot(g, s);
-      const size_t row = (size_t)s * g.VS + r0;
+      const size_t row = (size_t)phys_slot(g, s) * g.VS + r0;
       int vr[4] = {-1, -1, -1, -1}, vv[4] = {-1, -1, -1, -1};
       if (vec) {
         const int4v a = *reinterpret_cast<const int4v*>(st.vote_round + row);
@@ -1332,9 +1407,9 @@ __global__ void __launch_bounds__(256) k_digest_cells(const Geom g, const int32_
   const size_t n4 = (size_t)g.S * q;
   uint64_t acc = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t s = i / q;
-    const int r0 = (int)(i - s * q) * 4;
-    const int4v v = *reinterpret_cast<const int4v*>(a + s * (size_t)stride + (size_t)r0);
+    const size_t prow = i / q, s = (size_t)slot_of_row(g, (int)prow);
+    const int r0 = (int)(i - prow * q) * 4;
+    const int4v v = *reinterpret_cast<const int4v*>(a + prow * (size_t)stride + (size_t)r0);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (r0 + k < g.R) acc += digest_term(s * (size_t)g.R + (size_t)(r0 + k), v[k]);
@@ -1353,7 +1428,7 @@ __global__ void __launch_bounds__(256) k_digest_tally(const Geom g, const State 
   uint64_t acc = 0;
   for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < g.S; s += gridDim.x * blockDim.x) {
     for (int w = 0; w < g.ways; ++w) {
-      const size_t e = (size_t)s * g.wp + w;
+      const size_t e = (size_t)phys_slot(g, s) * g.wp + w;
       const uint32_t k = st.pl_key[e];
       if (k == 0 || (k & KEY_RANGE)) continue;
       const uint32_t round = (k & KEY_ROUND_MASK) - 1u;

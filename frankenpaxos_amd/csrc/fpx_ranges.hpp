@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256) k_ranges_open(const Geom g, const State s
   if (e == s + 1) {
     // the key (slot, slot + 1, round) is also the key of the single-slot tally: if that one exists -- Pending or
     // Done -- the range message is swallowed (:259-266 on open, :370-385 on Phase2bNoopRange)
-    const uint32_t* kr = st.pl_key + (size_t)s * g.wp;
+    const uint32_t* kr = st.pl_key + (size_t)phys_slot(g, s) * g.wp;
     for (int w = 0; w < g.ways; ++w)
       if ((kr[w] & KEY_ROUND_MASK) == want && !(kr[w] & KEY_RANGE)) {
         b.entry[i] = -2;  // swallowed
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256) k_ranges_resolve(const Geom g, const Stat
     fresh = (uint32_t)(k1 >> 32) == b.run_id && rt.owner[e] == i;
   }
   if (fresh && b.end[i] == b.start[i] + 1) {
-    uint32_t* kr = st.pl_key + (size_t)b.start[i] * g.wp;
+    uint32_t* kr = st.pl_key + (size_t)phys_slot(g, b.start[i]) * g.wp;
     int way = -1;
     for (int w = g.ways - 1; w >= 0; --w)
       if (kr[w] == 0) way = w;
@@ -211,10 +211,10 @@ __global__ void __launch_bounds__(256) k_ranges_fill(const Geom g, const State s
       const int r = (int)(c % g.R);
       const int ag = (s / L) % A, bit = g.base + r;
       if ((votes[(size_t)ag * 4 + (bit >> 6)] >> (bit & 63)) & 1ull) {
-        const size_t cell = (size_t)s * g.VS + r;
+        const size_t cell = (size_t)phys_slot(g, s) * g.VS + r;
         st.vote_round[cell] = round;  // :271-276 State(voteRound = round, voteValue = Noop)
         st.vote_value[cell] = -1;
-        if (st.row_voted[s] == 0) st.row_voted[s] = 1;
+        if (st.row_voted[phys_slot(g, s)] == 0) st.row_voted[phys_slot(g, s)] = 1;
       }
     }
   }
@@ -274,8 +274,8 @@ __global__ void __launch_bounds__(256) k_ranges_fill_rows(const Geom g, const St
     __syncthreads();
     const bool slow = overlap != 0;
     // one row of L x Q quads at a time (no division by run-time values per cell when Q == 1)
-    for (int jrel = 0; jrel < RF_JB; ++jrel)
-    for (int u = threadIdx.x; u < L * Q; u += 256) {
+    for (int t = threadIdx.x; t < RF_JB * L * Q; t += 256) {
+      const int jrel = t / (L * Q), u = t - jrel * (L * Q);
       const int lg = Q == 1 ? u : u / Q, quad = Q == 1 ? 0 : u - lg * Q;
       const uint32_t o = rf_own[jrel * L + lg];
       if (o == 0) continue;
@@ -310,9 +310,9 @@ __global__ void __launch_bounds__(256) k_ranges_fill_rows(const Geom g, const St
         }
       }
       if (voted == 0) continue;
-      const size_t cell = (size_t)s * g.VS + r0;
+      const size_t cell = (size_t)phys_slot(g, s) * g.VS + r0;
 #ifdef RF_X_NOSTORE
-      if (round == -12345) st.row_voted[s] = 1;
+      if (round == -12345) st.row_voted[phys_slot(g, s)] = 1;
       continue;
 #endif
       if (voted == valid) {  // :271-276 State(voteRound = round, voteValue = Noop); padding cells stay -1
@@ -327,9 +327,117 @@ __global__ void __launch_bounds__(256) k_ranges_fill_rows(const Geom g, const St
         for (int c = 0; c < 4; ++c)
           if ((voted >> c) & 1u) st.vote_round[cell + c] = round, st.vote_value[cell + c] = -1;
       }
-      st.row_voted[s] = 1;
+      st.row_voted[phys_slot(g, s)] = 1;
     }
     __syncthreads();
+  }
+}
+
+// The same with leader-group-major rows (Geom::lg_rows): the slots of a range are rows ja..jb of ONE leader group and
+// neighbours in memory, so the range is two runs of 16-byte stores (voteRound = round, voteValue = Noop) and a run of
+// row_voted bytes -- every 128-byte line leaves the wavefront whole.  blockIdx.y strides over the ranges, x over the
+// range's rows.  A range that shares rows with another range of its leader group in the same launch, acceptor groups
+// that differ in who voted (A > 1), or interleaved vote arrays go row by row through the union of the covering ranges.
+__global__ void __launch_bounds__(256) k_ranges_fill_lg(const Geom g, const State st, const RangeBatch b) {
+  __shared__ int overlap;
+  if (st.status[ST_ABORT] != 0) return;
+  const int A = g.num_groups, L = g.num_leader_groups, Q = g.RS >> 2;
+  const int tid = threadIdx.x;
+  for (int i = blockIdx.y; i < b.n; i += gridDim.y) {
+    if (b.fused && b.entry[i] < 0) continue;
+    const int s0 = b.start[i], e0 = b.end[i];
+    if (e0 <= s0) continue;
+    const int lg = s0 % L, ja = s0 / L, jb = (e0 - 1 - lg) / L;
+    __syncthreads();
+    if (tid == 0) overlap = 0;
+    __syncthreads();
+    for (int k = tid; k < b.n; k += 256) {
+      if (k == i || (b.fused && b.entry[k] < 0)) continue;
+      const int s1 = b.start[k], e1 = b.end[k];
+      if (e1 <= s1 || s1 % L != lg) continue;
+      if (s1 / L <= jb && (e1 - 1 - lg) / L >= ja) overlap = 1;
+    }
+    __syncthreads();
+    const size_t p0 = (size_t)lg * g.lg_rows;
+    const long long nthreads = (long long)gridDim.x * 256, me = (long long)blockIdx.x * 256 + tid;
+    if (overlap == 0 && A == 1 && g.VS == g.RS) {
+      const int round = b.round[i];
+      const uint64_t* votes = b.vote_bits + (size_t)i * 4;
+      uint64_t vb[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) vb[w] = votes[w];
+      // the int4 units of rows ja..jb: unit e is quad e % Q of row e / Q
+      const long long e_lo = (long long)(p0 + ja) * Q, e_hi = (long long)(p0 + jb + 1) * Q;
+      bool any = false;
+      for (int q4 = 0; q4 < Q; ++q4) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int bit = g.base + q4 * 4 + c;
+          if (q4 * 4 + c < g.R) any |= (vb[bit >> 6] >> (bit & 63)) & 1ull;
+        }
+      }
+      if (!any) continue;
+      for (long long e = e_lo + me; e < e_hi; e += nthreads) {
+        const int quad = Q == 1 ? 0 : (int)(e % Q), r0 = quad * 4;
+        unsigned voted = 0, valid = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int bit = g.base + r0 + c;
+          if (r0 + c < g.R) valid |= 1u << c, voted |= (unsigned)((vb[bit >> 6] >> (bit & 63)) & 1ull) << c;
+        }
+        if (voted == 0) continue;
+        const size_t cell = (size_t)e * 4;
+        if (voted == valid) {  // :271-276 State(voteRound = round, voteValue = Noop); padding cells stay -1
+          int4 vr = make_int4(round, round, round, round);
+          if (!(valid & 2u)) vr.y = -1;
+          if (!(valid & 4u)) vr.z = -1;
+          if (!(valid & 8u)) vr.w = -1;
+          *reinterpret_cast<int4*>(st.vote_round + cell) = vr;
+          *reinterpret_cast<int4*>(st.vote_value + cell) = make_int4(-1, -1, -1, -1);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if ((voted >> c) & 1u) st.vote_round[cell + c] = round, st.vote_value[cell + c] = -1;
+        }
+      }
+      // row_voted[pa..pb] = 1, four rows to a store where the range covers the aligned four
+      const long long pa = (long long)(p0 + ja), pb = (long long)(p0 + jb);
+      for (long long q4 = (pa >> 2) + me; q4 <= (pb >> 2); q4 += nthreads) {
+        const long long r4 = q4 << 2;
+        if (r4 >= pa && r4 + 3 <= pb) {
+          *reinterpret_cast<uint32_t*>(st.row_voted + r4) = 0x01010101u;
+        } else {
+          for (int c = 0; c < 4; ++c)
+            if (r4 + c >= pa && r4 + c <= pb) st.row_voted[r4 + c] = 1;
+        }
+      }
+      continue;
+    }
+    // row by row: every range of the launch that covers the slot (one round per leader group and launch)
+    for (long long t = me; t < (long long)(jb - ja + 1) * Q; t += nthreads) {
+      const int row = ja + (int)(t / Q), quad = (int)(t % Q), r0 = quad * 4, s = row * L + lg, ag = row % A;
+      unsigned voted = 0;
+      int round = 0;
+      for (int k = 0; k < b.n; ++k) {
+        if (k != i && overlap == 0) continue;
+        if (b.fused && b.entry[k] < 0) continue;
+        const int s1 = b.start[k], e1 = b.end[k];
+        if (s < s1 || s >= e1 || s1 % L != lg) continue;
+        const uint64_t* votes = b.vote_bits + ((size_t)k * A + ag) * 4;
+        round = b.round[k];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int bit = g.base + r0 + c;
+          if (r0 + c < g.R) voted |= (unsigned)((votes[bit >> 6] >> (bit & 63)) & 1ull) << c;
+        }
+      }
+      if (voted == 0) continue;
+      const size_t ps = p0 + row, cell = ps * g.VS + r0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if ((voted >> c) & 1u) st.vote_round[cell + c] = round, st.vote_value[cell + c] = -1;
+      st.row_voted[ps] = 1;
+    }
   }
 }
 
