@@ -33,6 +33,7 @@ FPX_BALLOT_PER_SLOT = 1
 
 FPX_F_TRUSTED = 1
 FPX_F_SCATTERED_TARGETS = 2
+FPX_F_SLOT_MAJOR_ROWS = 4
 
 FPX_NOOP = -1
 

@@ -186,7 +186,8 @@ void make_geom(const fpx_config& c, Geom* g) {
   g->num_leader_groups = c.num_leader_groups;
   g->ngroups = c.num_groups * c.num_leader_groups;
   // Mencius: rows leader-group-major when the window is a whole number of rounds over the leader groups
-  g->lg_rows = (c.num_leader_groups > 1 && c.num_slots % c.num_leader_groups == 0 && !getenv("FPX_SLOT_MAJOR"))
+  g->lg_rows = (c.num_leader_groups > 1 && c.num_slots % c.num_leader_groups == 0 &&
+                !(c.flags & FPX_F_SLOT_MAJOR_ROWS) && !getenv("FPX_SLOT_MAJOR"))
                    ? c.num_slots / c.num_leader_groups : 0;
   g->qkind = c.quorum_kind;
   g->total = c.replicas_total ? c.replicas_total : c.num_replicas;
@@ -1573,19 +1574,24 @@ static int enqueue_ranges(fpx_ctx* ctx, RangeBatch& b, int mode) {
     if (acceptors) fill32(ctx, ctx->st.run_round, -1, (size_t)g.ngroups);
     hipLaunchKernelGGL(k_ranges_validate, dim3(gn), dim3(256), 0, ctx->stream, g, ctx->st, b, acceptors ? 1 : 0);
   }
-  if (acceptors) {
+  const RangeTable& rt = ctx->rt[ctx->rt_cur];
+  // a few ranges: one workgroup walks clear -> open -> resolve -> acceptors -> tally (fpx_ranges.hpp: k_ranges_chain)
+  const bool chain = mode == RANGES_FUSED && b.n <= RANGES_CHAIN_MAX && (long long)b.n * g.num_groups * g.R <= 16 * RANGES_CHAIN_MAX &&
+                     !getenv("FPX_RANGES_NO_CHAIN");
+  if (chain) hipLaunchKernelGGL(k_ranges_chain, dim3(1), dim3(1024), 0, ctx->stream, g, ctx->st, rt, b);
+  if (acceptors && !chain) {
     fill32(ctx, b.vote_bits, 0, words * 2);
     if (b.nack_bits) fill32(ctx, b.nack_bits, 0, words * 2);
     if (b.nack_round) fill32(ctx, b.nack_round, -1, (size_t)b.n);
   }
-  const RangeTable& rt = ctx->rt[ctx->rt_cur];
-  if (mode == RANGES_FUSED || mode == RANGES_OPEN) {
+  if (!chain && (mode == RANGES_FUSED || mode == RANGES_OPEN)) {
     hipLaunchKernelGGL(k_ranges_open, dim3(gn), dim3(256), 0, ctx->stream, g, ctx->st, rt, b, 0);
     hipLaunchKernelGGL(k_ranges_resolve, dim3(gn), dim3(256), 0, ctx->stream, g, ctx->st, rt, b);
   }
   if (acceptors) {
     const long long threads = (long long)b.n * g.num_groups * g.R;
-    hipLaunchKernelGGL(k_ranges_acceptors, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, g, ctx->st, b);
+    if (!chain)
+      hipLaunchKernelGGL(k_ranges_acceptors, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, g, ctx->st, b);
     if (g.lg_rows) {  // leader-group-major rows: a range is one run of rows
       const int gy = std::min(b.n, 4096);
       const int gx = std::max(1, std::min(ctx->num_cus * 16 / gy, 64));
@@ -1601,7 +1607,7 @@ static int enqueue_ranges(fpx_ctx* ctx, RangeBatch& b, int mode) {
     }
   }
   if (mode == RANGES_TALLY) hipLaunchKernelGGL(k_ranges_open, dim3(gn), dim3(256), 0, ctx->stream, g, ctx->st, rt, b, 1);
-  if (mode == RANGES_FUSED || mode == RANGES_TALLY)
+  if (!chain && (mode == RANGES_FUSED || mode == RANGES_TALLY))
     hipLaunchKernelGGL(k_ranges_tally, dim3(gn), dim3(256), 0, ctx->stream, g, ctx->st, rt, b);
   return launch_check(ctx);
 }

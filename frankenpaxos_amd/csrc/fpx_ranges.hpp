@@ -83,10 +83,7 @@ __global__ void __launch_bounds__(256) k_ranges_validate(const Geom g, const Sta
 }
 
 // mencius/ProxyLeader.scala:255-303.  lookup = 1: find only (the Phase2bNoopRange entry point).
-__global__ void __launch_bounds__(256) k_ranges_open(const Geom g, const State st, const RangeTable rt, const RangeBatch b, int lookup) {
-  if (st.status[ST_ABORT] != 0) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= b.n) return;
+__device__ __forceinline__ void ranges_open_one(const Geom& g, const State& st, const RangeTable& rt, const RangeBatch& b, int lookup, int i) {
   const int s = b.start[i], e = b.end[i], rnd = b.round[i];
   b.entry[i] = -1;
   const uint32_t want = (uint32_t)rnd + 1u;
@@ -138,12 +135,15 @@ __global__ void __launch_bounds__(256) k_ranges_open(const Geom g, const State s
   if (!lookup) report(st, 5, i, s, rnd);
 }
 
-// after k_ranges_open: is_new[i] <=> this launch inserted the entry and i is its lowest index; the owner of a
-// new length-1 range also claims the per-slot shadow way
-__global__ void __launch_bounds__(256) k_ranges_resolve(const Geom g, const State st, const RangeTable rt, const RangeBatch b) {
+__global__ void __launch_bounds__(256) k_ranges_open(const Geom g, const State st, const RangeTable rt, const RangeBatch b, int lookup) {
   if (st.status[ST_ABORT] != 0) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= b.n) return;
+  if (i < b.n) ranges_open_one(g, st, rt, b, lookup, i);
+}
+
+// after k_ranges_open: is_new[i] <=> this launch inserted the entry and i is its lowest index; the owner of a
+// new length-1 range also claims the per-slot shadow way
+__device__ __forceinline__ void ranges_resolve_one(const Geom& g, const State& st, const RangeTable& rt, const RangeBatch& b, int i) {
   const int e = b.entry[i];
   bool fresh = false;
   if (e >= 0) {
@@ -162,13 +162,16 @@ __global__ void __launch_bounds__(256) k_ranges_resolve(const Geom g, const Stat
   if (!fresh && b.fused) b.entry[i] = e >= 0 ? -3 - e : e;  // not mine to drive: acceptors / fill / tally skip it
 }
 
-// mencius/Acceptor.scala:237-260, 279-290: one thread per (range, acceptor group, acceptor)
-__global__ void __launch_bounds__(256) k_ranges_acceptors(const Geom g, const State st, const RangeBatch b) {
+__global__ void __launch_bounds__(256) k_ranges_resolve(const Geom g, const State st, const RangeTable rt, const RangeBatch b) {
   if (st.status[ST_ABORT] != 0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < b.n) ranges_resolve_one(g, st, rt, b, i);
+}
+
+// mencius/Acceptor.scala:237-260, 279-290: one thread per (range, acceptor group, acceptor)
+__device__ __forceinline__ void ranges_acceptor_one(const Geom& g, const State& st, const RangeBatch& b, long long idx) {
   const int A = g.num_groups, L = g.num_leader_groups;
   const long long per = (long long)A * g.R;
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= per * b.n) return;
   const int i = (int)(idx / per), rem = (int)(idx % per);
   if (b.fused && b.entry[i] < 0) return;
   const int ag = rem / g.R, r = rem % g.R, bit = g.base + r;
@@ -194,6 +197,12 @@ __global__ void __launch_bounds__(256) k_ranges_acceptors(const Geom g, const St
       break;
     }
   }
+}
+
+__global__ void __launch_bounds__(256) k_ranges_acceptors(const Geom g, const State st, const RangeBatch b) {
+  if (st.status[ST_ABORT] != 0) return;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < (long long)g.num_groups * g.R * b.n) ranges_acceptor_one(g, st, b, idx);
 }
 
 // mencius/Acceptor.scala:262-277: blockIdx.y strides over the ranges, x over the cells of one range
@@ -442,10 +451,7 @@ __global__ void __launch_bounds__(256) k_ranges_fill_lg(const Geom g, const Stat
 }
 
 // mencius/ProxyLeader.scala:355-411: one thread per range
-__global__ void __launch_bounds__(256) k_ranges_tally(const Geom g, const State st, const RangeTable rt, const RangeBatch b) {
-  if (st.status[ST_ABORT] != 0) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= b.n) return;
+__device__ __forceinline__ void ranges_tally_one(const Geom& g, const State& st, const RangeTable& rt, const RangeBatch& b, int i) {
   uint8_t ch = 0;
   const int e = b.entry[i];
   const int A = g.num_groups;
@@ -477,6 +483,43 @@ __global__ void __launch_bounds__(256) k_ranges_tally(const Geom g, const State 
     }
   }
   if (b.chosen) b.chosen[i] = ch;
+}
+
+__global__ void __launch_bounds__(256) k_ranges_tally(const Geom g, const State st, const RangeTable rt, const RangeBatch b) {
+  if (st.status[ST_ABORT] != 0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < b.n) ranges_tally_one(g, st, rt, b, i);
+}
+
+// A fused launch of a few ranges (what a tick of a Mencius deployment carries: one per lagging leader group) is a
+// chain of five dependent steps over a few hundred items -- as five launches, ~5 us each plus the gaps between them,
+// several times what the steps compute.  ONE workgroup of 1024 threads walks the chain instead: the bitmaps cleared,
+// then open / resolve / acceptors / tally with a barrier in between (the steps talk through global memory -- hash table
+// entries, entry[], vote bitmaps -- partly with device-scope atomics that bypass the L1: the acquire fence after each
+// barrier drops the CU's L1 lines so that plain loads see them).  k_ranges_fill* follows as its own launch.
+constexpr int RANGES_CHAIN_MAX = 4096;
+__device__ __forceinline__ void ranges_chain_sync() {
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__global__ void __launch_bounds__(1024) k_ranges_chain(const Geom g, const State st, const RangeTable rt, const RangeBatch b) {
+  if (st.status[ST_ABORT] != 0) return;
+  const int tid = threadIdx.x;
+  const long long ints = (long long)b.n * g.num_groups * 8;
+  for (long long t = tid; t < ints; t += 1024) {
+    reinterpret_cast<int32_t*>(b.vote_bits)[t] = 0;
+    if (b.nack_bits) reinterpret_cast<int32_t*>(b.nack_bits)[t] = 0;
+  }
+  if (b.nack_round)
+    for (int i = tid; i < b.n; i += 1024) b.nack_round[i] = -1;
+  for (int i = tid; i < b.n; i += 1024) ranges_open_one(g, st, rt, b, 0, i);
+  ranges_chain_sync();
+  for (int i = tid; i < b.n; i += 1024) ranges_resolve_one(g, st, rt, b, i);
+  ranges_chain_sync();
+  const long long cells = (long long)g.num_groups * g.R * b.n;
+  for (long long idx = tid; idx < cells; idx += 1024) ranges_acceptor_one(g, st, b, idx);
+  ranges_chain_sync();
+  for (int i = tid; i < b.n; i += 1024) ranges_tally_one(g, st, rt, b, i);
 }
 
 // fpx_proxy_forget: live entries that do not lie inside [first, first + count) move to the other buffer

@@ -111,6 +111,14 @@ typedef enum {
  * of 2f+1 (ProxyLeader.scala:190-191).  K1 / K3 launches that carry target masks then write partially
  * voted 16-byte cells by read-modify-write instead of 4-byte stores.  Results are identical either way. */
 #define FPX_F_SCATTERED_TARGETS 2u
+/* Mencius contexts (num_leader_groups L > 1, num_slots a multiple of L) keep the per-slot rows of the cell arrays and
+ * tally tables LEADER-GROUP-MAJOR in HBM -- slot s lives in row (s % L) * (S / L) + s / L -- so that what one leader
+ * group does (a noop range = every L-th slot; its batch of Phase2as in slot order) touches neighbouring rows and
+ * every 128-byte line leaves the GPU whole.  Callers best send a launch as the leader groups' batches back to back.
+ * Callers that can only send ONE batch in slot order across all leader groups (neighbouring messages = neighbouring
+ * leader groups) set this flag: rows stay in slot order.  Results are identical either way; only speed differs
+ * (profiles/r03_cfg5.md). */
+#define FPX_F_SLOT_MAJOR_ROWS 4u
 
 typedef struct {
   int32_t num_slots;         /* S: log window held in HBM; slots are 0 .. S-1                          */

@@ -131,7 +131,7 @@ def mencius_stream(S, L, R, epochs, seed):
         yield ("ranges", i32(starts), i32(ends), i32(rnds), tm)
 
 
-def test_config5_mencius_256_leader_groups_4m_slots(fa, oracle):
+def test_config5_mencius_256_leader_groups_4m_slots(fa, oracle, row_layout):
     S, L, R = 1 << 22, 256, 3
     kw = dict(num_slots=S, num_replicas=R, num_groups=1, num_leader_groups=L, f=1, tally_ways=4)
     gpu, ref = fa.Context(fa.make_config(**kw)), oracle.System(oracle.make_config(**kw))

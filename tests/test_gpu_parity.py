@@ -114,7 +114,7 @@ def test_config3_grid_2x2_16_groups(fa, oracle, ballot_mode):
           tally_slots=range(0, S, 331))
 
 
-def test_config5_mencius_slot_map(fa, oracle):
+def test_config5_mencius_slot_map(fa, oracle, row_layout):
     """mencius: leader group = slot % L, acceptor group = (slot / L) % A (mencius/ProxyLeader.scala:231-234)"""
     S = 8192
     kw = dict(num_slots=S, num_replicas=3, num_groups=2, num_leader_groups=8, f=1, tally_ways=8)

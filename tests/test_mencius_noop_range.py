@@ -5,6 +5,8 @@ import pytest
 
 from tests import workloads as W
 
+pytestmark = pytest.mark.usefixtures("row_layout")
+
 L, A, R = 3, 2, 3  # leader groups, acceptor groups per leader group, acceptors per group (f = 1)
 KW = dict(num_slots=256, num_replicas=R, num_groups=A, num_leader_groups=L, f=1, tally_ways=8)
 
@@ -345,3 +347,35 @@ def test_range_tallies_are_reclaimed(fa, oracle):
         if st:
             break
     assert st == fa.FPX_ECAPACITY
+
+
+@pytest.mark.gpu
+def test_slot_major_flag_gives_the_same_state(fa, oracle):
+    """FPX_F_SLOT_MAJOR_ROWS (include/fpx.h) changes where a slot's row lives, nothing else: commands, noop ranges,
+    garbage collection and recycling on two contexts that differ only in the flag, and on the oracle"""
+    import os
+    if os.environ.get("FPX_SLOT_MAJOR"):
+        pytest.skip("the environment switch overrides the flag")
+    S, L = 1 << 14, 8
+    kw = dict(num_slots=S, num_replicas=3, num_groups=2, num_leader_groups=L, f=1, tally_ways=8)
+    a, b = fa.Context(fa.make_config(**kw)), fa.Context(fa.make_config(flags=fa.FPX_F_SLOT_MAJOR_ROWS, **kw))
+    ref = oracle.System(oracle.make_config(**kw))
+    rng = np.random.default_rng(77)
+    for step in range(6):
+        slots = np.unique(rng.integers(0, S, 3000)).astype(np.int32)
+        rr = np.full(len(slots), step // 3, np.int32)
+        tm = W.bits_from_bool(W.random_subsets(rng, len(slots), 3, 1, 3))
+        outs = [W.run_script(x, [("fused", slots, rr, slots * 7 + step, tm)]) for x in (a, b, ref)]
+        W.assert_same_outputs(outs[0], outs[2])
+        W.assert_same_outputs(outs[1], outs[2])
+        start, end, rnd = _random_range_batch(rng, S, L, 60, [step // 3] * L)
+        ra, rb, rc = (x.noop_ranges_fused(start, end, rnd) for x in (a, b, ref))
+        _same_ranges(ra, rc)
+        _same_ranges(rb, rc)
+        if step == 3:
+            for x in (a, b, ref):
+                x.proxy_forget(100, S // 3)
+                x.recycle_slots(S // 2 + 3, 1000)
+    for x in (a, b):
+        W.assert_same_state(x, ref, tally_slots=range(0, S, 37))
+        np.testing.assert_array_equal(x.state_digest(), ref.state_digest())

@@ -193,7 +193,7 @@ def test_oracle_phase1b_info_trace(oracle):
 @pytest.mark.parametrize("R,kw", [(3, dict(f=1)), (5, dict(quorum_kind=1, ballot_mode=1)), (256, dict(f=127)),
                                   (4, dict(num_groups=4, quorum_kind=2, grid_rows=2, grid_cols=2)),
                                   (3, dict(f=1, num_groups=2, num_leader_groups=4))])
-def test_phase1b_info_and_recycle_match_oracle(fa, oracle, R, kw):
+def test_phase1b_info_and_recycle_match_oracle(fa, oracle, row_layout, R, kw):
     S = 2048
     gpu, ref = both(fa, oracle, num_slots=S, num_replicas=R, tally_ways=8, **kw)
     ng = kw.get("num_groups", 1) * kw.get("num_leader_groups", 1)
