@@ -481,9 +481,35 @@ __global__ void __launch_bounds__(256)
   // would not otherwise fill the chip: a wave walks its chunk one row at a time)
   const int CH = (G == 64) ? b.chunk : 64;
   const int nchunks = (b.n + CH - 1) / CH;
-  for (int chunk = blockIdx.x * 4 + wib; chunk < nchunks; chunk += gridDim.x * 4) {
-    // ---- stage the chunk: lane i owns message i -------------------------------------------------
-    const int m = chunk * CH + lane;
+  // Leader-group-major rows (Geom::lg_rows) want the 64 messages of a wavefront to be 64 consecutive slots of ONE
+  // leader group.  A batch that comes as the leader groups' batches back to back is that already.  A batch in slot
+  // order across P proposing leader groups (message i + P is the next slot of message i's group) is walked COLUMN BY
+  // COLUMN instead: in tiles of 64 P messages, a wavefront takes every P-th message of its tile.  P is read off the
+  // batch (the first message after message 0 with message 0's leader group); any P gives a permutation of the
+  // messages, so a batch without that regularity only loses the speed, and outputs stay indexed by message.  The
+  // workgroups of one XCD take neighbouring columns (they share the tile's input and output lines in that L2).
+  // Measured on BASELINE.json configs[4] (profiles/r03_cfg5.md): 241 -> 92 us for the slot-ordered batch, against 50 us
+  // for the same messages grouped by leader group -- inputs and outputs are one L2 request per message and array here
+  // (a workgroup taking 32 neighbouring columns itself, for the L1's sake: 105 us, fewer workgroups in flight).
+  int period = 1, bx = blockIdx.x;
+  if (g.lg_rows && CH == 64 && b.n >= 128) {
+    const int L = g.num_leader_groups, lg0 = b.slot[0] % L, lim = b.n < 2 * L ? b.n : 2 * L;
+    for (int k0 = 1; k0 < lim; k0 += 64) {
+      const int k = k0 + lane;
+      const uint64_t hit = __ballot(k < lim && b.slot[k] % L == lg0);
+      if (hit) {
+        period = k0 + (int)__ffsll((unsigned long long)hit) - 1;
+        break;
+      }
+    }
+    if (period > 1 && (gridDim.x & 7) == 0) bx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  }
+  const int tile = 64 * period, tiled = period > 1 ? (b.n / tile) * tile : 0;
+  for (int chunk = bx * 4 + wib; chunk < nchunks; chunk += gridDim.x * 4) {
+    // ---- stage the chunk: lane i owns message i (or every period-th message of the chunk's tile) --
+    const int v0 = chunk * CH;
+    const bool strided = v0 < tiled;
+    const int m = strided ? (v0 / tile) * tile + lane * period + (v0 % tile) / 64 : v0 + lane;
     const bool mv = lane < CH && m < b.n;
     const int myslot = mv ? b.slot[m] : -1;
     const int myround = mv ? b.round[m] : 0;
@@ -518,9 +544,14 @@ __global__ void __launch_bounds__(256)
     }
 
     if constexpr (TGT) {
-      const size_t w0 = (size_t)chunk * CH * 4, wend = (size_t)b.n * 4;
-      for (int w = lane; w < CH * 4; w += 64)
-        if (w0 + w < wend) wt[w] = b.target[w0 + w];
+      if (strided) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) wt[lane * 4 + w] = b.target[(size_t)m * 4 + w];
+      } else {
+        const size_t w0 = (size_t)chunk * CH * 4, wend = (size_t)b.n * 4;
+        for (int w = lane; w < CH * 4; w += 64)
+          if (w0 + w < wend) wt[w] = b.target[w0 + w];
+      }
       wave_lds_sync();
     }
 

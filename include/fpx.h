@@ -114,10 +114,10 @@ typedef enum {
 /* Mencius contexts (num_leader_groups L > 1, num_slots a multiple of L) keep the per-slot rows of the cell arrays and
  * tally tables LEADER-GROUP-MAJOR in HBM -- slot s lives in row (s % L) * (S / L) + s / L -- so that what one leader
  * group does (a noop range = every L-th slot; its batch of Phase2as in slot order) touches neighbouring rows and
- * every 128-byte line leaves the GPU whole.  Callers best send a launch as the leader groups' batches back to back.
- * Callers that can only send ONE batch in slot order across all leader groups (neighbouring messages = neighbouring
- * leader groups) set this flag: rows stay in slot order.  Results are identical either way; only speed differs
- * (profiles/r03_cfg5.md). */
+ * every 128-byte line leaves the GPU whole.  A launch is fastest as the leader groups' batches back to back; one batch
+ * in slot order across the leader groups is walked column by column by the kernel and is still faster than on
+ * slot-ordered rows (profiles/r03_cfg5.md).  This flag keeps rows in slot order (round 2's layout).  Results are
+ * identical either way; only speed differs. */
 #define FPX_F_SLOT_MAJOR_ROWS 4u
 
 typedef struct {
