@@ -859,9 +859,25 @@ __global__ void __launch_bounds__(256)
   }
   bool any_table = false;
   if (one_group) {
+    // the 64 / G lanes with the same gi hold maxima of the same acceptors: fold them across the wavefront first, one
+    // lane per acceptor quad touches the LDS table (at G = 1 all 256 lanes of the workgroup would otherwise queue on
+    // the same 2 R words: 12 us of a 19 us kernel on a 65 536 x 3 step, profiles/r03_small_n.txt)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (own >> k & 1u) {
+      if constexpr (G == 1) {
+        acc_mv[k] = wave_max_to_lane63(acc_mv[k] + 1) - 1, acc_pr[k] = wave_max_to_lane63(acc_pr[k] + 1) - 1;
+      } else if constexpr (G < 64) {
+#pragma unroll
+        for (int m = G; m < 64; m <<= 1) {
+          const int a = __shfl_xor(acc_mv[k], m), c = __shfl_xor(acc_pr[k], m);
+          acc_mv[k] = a > acc_mv[k] ? a : acc_mv[k], acc_pr[k] = c > acc_pr[k] ? c : acc_pr[k];
+        }
+      }
+    }
+    const bool folder = G == 1 ? lane == 63 : q == 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (folder && (own >> k & 1u)) {
         if (acc_mv[k] >= 0) atomicMax(&tab_mv[r0 + k], acc_mv[k]), any_table = true;
         if (acc_pr[k] >= 0) atomicMax(&tab_pr[r0 + k], acc_pr[k]), any_table = true;
       }
