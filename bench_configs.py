@@ -362,13 +362,15 @@ def run(args, fa, dist, dev, rank, world, local_rank, all_reduce):
                               "all kernels of one step summed), not measured in this run",
             "algorithmic_bytes_per_unit": w["bytes_per_unit"], "units_per_launch": w["units"],
             "avg_kernel_ms": kernel_ms / max(launches, 1), "launches_timed": launches,
-            "note": "small-row workloads are bound by request rate and dependent-step latency, not HBM bytes: the "
-                    "fraction of the HBM peak is reported for the contract, the absolute rate is the figure of merit",
+            "note": "small-row workloads (16-byte rows) run at 3.6 - 4.0 TB/s of actual traffic at best and are bound by "
+                    "dependent-step latency below ~10^6 slots per launch: the fraction of the HBM peak is reported for "
+                    "the contract, the absolute rate is the figure of merit",
         },
     }
     if args.config == "2":
-        line["roofline"]["bound_in_practice"] = "launch latency: a 65 536-slot x 3 step is one ~20 us kernel; the config is " \
-                                                "BASELINE.json's bring-up / bit-exactness case, not a bandwidth case"
+        line["roofline"]["bound_in_practice"] = "launch latency: a 65 536-slot x 3 step is one ~6 us vote kernel and a ~4 us " \
+                                                "k_finalize, two launches from Python per step (profiles/r03_small_n.txt); " \
+                                                "the config is BASELINE.json's bring-up / bit-exactness case, not a bandwidth case"
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = w["cpu"]()
     if hasattr(ctx, "close"):
