@@ -342,10 +342,14 @@ int enqueue_phase2(fpx_ctx* ctx, Batch& b, bool fused) {
   b.index_base = ctx->index_base;
   int rc = enqueue_validate(ctx, b, true);
   if (rc) return rc;
-  const int grid = grid_for(ctx, b.n);
+  int grid = grid_for(ctx, b.n);
   b.chunk = chunk_for(ctx, b.n);
   b.index_base = ctx->index_base;
-  b.parity = (int32_t)(ctx->phase2_launches++ & 1u);  // every K1 / K3 launch is followed by its k_finalize
+  // at most two chunks per wavefront of one workgroup: that workgroup finalises itself (k_phase2, `solo`); the parity
+  // of the partial-maxima buffers is not consumed
+  b.solo = ((b.n + b.chunk - 1) / b.chunk <= 8 && !getenv("FPX_NO_SOLO")) ? 1 : 0;
+  if (b.solo) grid = 1;
+  b.parity = b.solo ? 0 : (int32_t)(ctx->phase2_launches++ & 1u);  // every other K1 / K3 launch is followed by its k_finalize
   if (++ctx->launch_seq == 0) ctx->launch_seq = 1;
   b.launch_seq = ctx->launch_seq;
   const bool prof = ctx->profiling && ctx->ev_used + 2 <= ctx->ev.size();
@@ -357,6 +361,7 @@ int enqueue_phase2(fpx_ctx* ctx, Batch& b, bool fused) {
     HIPCHK(ctx, hipEventRecord(ctx->ev[ctx->ev_used + 1], ctx->stream));
     ctx->ev_used += 2;
   }
+  if (b.solo) return FPX_OK;
   const int ntab = ctx->g.ngroups * ctx->g.R;
   const int slices = std::max(FINALIZE_SLICES, std::min(256, grid / 32));  // ~8 partial rows per wavefront
   hipLaunchKernelGGL(k_finalize, dim3((ntab + 63) / 64, slices), dim3(256), 0, ctx->stream, ctx->g, ctx->st,

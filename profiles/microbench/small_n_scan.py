@@ -9,7 +9,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dir
 import frankenpaxos_amd as fa  # noqa: E402
 
 dev = torch.device("cuda:0")
-sizes = [1 << k for k in (10, 12, 14, 16, 18, 20)]
+sizes = [int(x) for x in os.environ["SIZES"].split(",")] if os.environ.get("SIZES") else [1 << k for k in (10, 12, 14, 16, 18, 20)]
 reps = 9
 mode = int(os.environ.get("BALLOT", "1"))
 S = sum(sizes) * reps
