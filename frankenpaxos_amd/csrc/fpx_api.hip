@@ -186,7 +186,7 @@ void make_geom(const fpx_config& c, Geom* g) {
   g->num_leader_groups = c.num_leader_groups;
   g->ngroups = c.num_groups * c.num_leader_groups;
   // Mencius: rows leader-group-major when the window is a whole number of rounds over the leader groups
-  g->lg_rows = (c.num_leader_groups > 1 && c.num_slots % c.num_leader_groups == 0 &&
+  g->lg_rows = (c.num_leader_groups > 1 && c.num_slots % c.num_leader_groups == 0 && c.num_replicas <= 32 &&
                 !(c.flags & FPX_F_SLOT_MAJOR_ROWS) && !getenv("FPX_SLOT_MAJOR"))
                    ? c.num_slots / c.num_leader_groups : 0;
   g->qkind = c.quorum_kind;
@@ -257,8 +257,18 @@ void allow_lds(K kernel, size_t lds) {
 }
 
 template <int G, int MODE, int PS>
-void launch_phase2_3(fpx_ctx* ctx, const Batch& b, bool fused, int grid) {
-  const size_t lds = lds_bytes(ctx, fused, MODE != 0);
+void launch_phase2_3(fpx_ctx* ctx, const Batch& b0, bool fused, int grid) {
+  size_t lds = lds_bytes(ctx, fused, MODE != 0);
+  Batch b = b0;
+  // leader-group-major rows: 3 KiB of LDS per wavefront for the column quads of a slot-ordered batch (k_phase2), when
+  // every array they move as 16 bytes is aligned for it
+  auto al = [](const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+  if (ctx->g.lg_rows && al(b.slot, 16) && al(b.round, 16) && al(b.value, 16) && al(b.chosen, 4) && al(b.chosen_round, 16) &&
+      al(b.chosen_value, 16) && al(b.nack_round, 16) && !getenv("FPX_NO_QUADS")) {
+    lds = (lds + 15) & ~(size_t)15;
+    b.sc_lds = (int32_t)lds;
+    lds += 4 * 3 * 4 * 64 * sizeof(int32_t);
+  }
   if (fused) allow_lds(k_phase2<G, MODE, PS, true>, lds);
   else allow_lds(k_phase2<G, MODE, PS, false>, lds);
   if (fused)

@@ -136,6 +136,7 @@ struct Batch {
   int32_t chunk;           // K1 / K3 at G = 64: messages per wavefront (4 .. FPX_CHUNK)
   int32_t index_base;      // added to the message index an error reports (host batches launched in pieces)
   int32_t solo;            // K1 / K3: the launch is ONE workgroup, which applies its maxima itself (no k_finalize follows)
+  int32_t sc_lds;          // K1 / K3 on leader-group-major rows: byte offset of 4 x 3 KiB of LDS for the column quads (0 = none)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -154,6 +155,13 @@ __device__ __forceinline__ int group_of_slot(const Geom& g, int slot) {
 // row_voted), and which slot a row holds; stamp and the replica log are indexed by the slot itself
 __device__ __forceinline__ int phys_slot(const Geom& g, int s) {
   return g.lg_rows ? (s % g.num_leader_groups) * g.lg_rows + s / g.num_leader_groups : s;
+}
+// k_phase2: leader-group-major rows exist only for groups of at most 32 acceptors (make_geom), so the instantiations
+// for bigger groups -- the headline's among them -- carry no trace of them
+template <int G>
+__device__ __forceinline__ int phys_slot_g(const Geom& g, int s) {
+  if constexpr (G > 8) return s;
+  else return phys_slot(g, s);
 }
 __device__ __forceinline__ int slot_of_row(const Geom& g, int p) {
   return g.lg_rows ? (p % g.lg_rows) * g.num_leader_groups + p / g.lg_rows : p;
@@ -481,7 +489,6 @@ __global__ void __launch_bounds__(256)
   // messages per wavefront chunk: 64, or at G = 64 the launch's choice (32 for big batches, fewer when the batch
   // would not otherwise fill the chip: a wave walks its chunk one row at a time)
   const int CH = (G == 64) ? b.chunk : 64;
-  const int nchunks = (b.n + CH - 1) / CH;
   // Leader-group-major rows (Geom::lg_rows) want the 64 messages of a wavefront to be 64 consecutive slots of ONE
   // leader group.  A batch that comes as the leader groups' batches back to back is that already.  A batch in slot
   // order across P proposing leader groups (message i + P is the next slot of message i's group) is walked COLUMN BY
@@ -493,7 +500,10 @@ __global__ void __launch_bounds__(256)
   // for the same messages grouped by leader group -- inputs and outputs are one L2 request per message and array here
   // (a workgroup taking 32 neighbouring columns itself, for the L1's sake: 105 us, fewer workgroups in flight).
   int period = 1, bx = blockIdx.x;
-  if (g.lg_rows && CH == 64 && b.n >= 128) {
+  // (small groups only: at R > 32 a slot's row is 128 bytes or more by itself, and the G = 64 kernel of the headline
+  // must not pay registers for this)
+  constexpr bool COLS = G <= 8;
+  if (COLS && g.lg_rows && CH == 64 && b.n >= 128) {
     const int L = g.num_leader_groups, lg0 = b.slot[0] % L, lim = b.n < 2 * L ? b.n : 2 * L;
     for (int k0 = 1; k0 < lim; k0 += 64) {
       const int k = k0 + lane;
@@ -505,28 +515,46 @@ __global__ void __launch_bounds__(256)
     }
     if (period > 1 && (gridDim.x & 7) == 0) bx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   }
+  // a period that is a multiple of 4: a wavefront takes FOUR neighbouring columns in one go -- lane j reads the 16
+  // bytes (row j, columns c0 .. c0 + 3) of each input array (a quarter of the L2 requests of four strided dword loads)
+  // into its own four words of LDS, walks the columns one after the other, parks each column's result there and stores
+  // the four results of its row as 16 bytes per output array
+  const int kc = (COLS && period > 1 && (period & 3) == 0 && b.sc_lds) ? 4 : 1;
   const int tile = 64 * period, tiled = period > 1 ? (b.n / tile) * tile : 0;
-  for (int chunk = bx * 4 + wib; chunk < nchunks; chunk += gridDim.x * 4) {
-    // ---- stage the chunk: lane i owns message i (or every period-th message of the chunk's tile) --
-    const int v0 = chunk * CH;
-    const bool strided = v0 < tiled;
-    const int m = strided ? (v0 / tile) * tile + lane * period + (v0 % tile) / 64 : v0 + lane;
-    const bool mv = lane < CH && m < b.n;
-    const int myslot = mv ? b.slot[m] : -1;
-    const int myround = mv ? b.round[m] : 0;
-    const int myvalue = mv ? b.value[m] : 0;
+  const int u1 = tiled / (64 * kc), per_tile = period / kc;  // units of kc columns x 64 rows; units per tile
+  const int units = u1 + (b.n - tiled + CH - 1) / CH;        // + the plain chunks behind the tiles
+  int32_t* sc = reinterpret_cast<int32_t*>(smem + b.sc_lds) + wib * (3 * 4 * 64);  // [3][4][64] per wavefront
+  for (int unit = bx * 4 + wib; unit < units; unit += gridDim.x * 4) {
+    const bool strided = COLS && unit < u1;
+    const bool quad = COLS && strided && kc == 4;
+    const int v0 = tiled + (unit - u1) * CH;  // plain chunk: its first message
+    const int mbase = strided ? (unit / per_tile) * tile + lane * period + (unit % per_tile) * kc : v0 + lane;
+    if (quad) {
+      const int4 a = *reinterpret_cast<const int4*>(b.slot + mbase), c = *reinterpret_cast<const int4*>(b.round + mbase),
+                 d = *reinterpret_cast<const int4*>(b.value + mbase);
+      sc[0 * 256 + 0 * 64 + lane] = a.x, sc[0 * 256 + 1 * 64 + lane] = a.y, sc[0 * 256 + 2 * 64 + lane] = a.z, sc[0 * 256 + 3 * 64 + lane] = a.w;
+      sc[1 * 256 + 0 * 64 + lane] = c.x, sc[1 * 256 + 1 * 64 + lane] = c.y, sc[1 * 256 + 2 * 64 + lane] = c.z, sc[1 * 256 + 3 * 64 + lane] = c.w;
+      sc[2 * 256 + 0 * 64 + lane] = d.x, sc[2 * 256 + 1 * 64 + lane] = d.y, sc[2 * 256 + 2 * 64 + lane] = d.z, sc[2 * 256 + 3 * 64 + lane] = d.w;
+    }
+    for (int cc = 0; cc < (quad ? 4 : 1); ++cc) {
+    // ---- stage the chunk: lane i owns message i (or every period-th message of the unit's tile) ----
+    const int m = mbase + cc;
+    const bool mv = strided || (lane < CH && m < b.n);
+    const int myslot = quad ? sc[0 * 256 + cc * 64 + lane] : (mv ? b.slot[m] : -1);
+    const int myround = quad ? sc[1 * 256 + cc * 64 + lane] : (mv ? b.round[m] : 0);
+    const int myvalue = quad ? sc[2 * 256 + cc * 64 + lane] : (mv ? b.value[m] : 0);
     // a slot nobody has voted in yet (the common case: a first proposal) holds -1 in every cell, so a partial
     // vote -- thrifty delivery to a random f+1 of the group (ProxyLeader.scala:190-191), or some acceptors
     // Nacking -- can be stored as whole 16-byte cells blended with -1: full-line traffic, nothing read
     bool myfresh = false;
-    if constexpr (TGT) myfresh = mv && st.row_voted[phys_slot(g, myslot)] == 0;
+    if constexpr (TGT) myfresh = mv && st.row_voted[phys_slot_g<G>(g, myslot)] == 0;
     // ProxyLeader.handlePhase2a for 64 messages at once (ProxyLeader.scala:176-184): lane i reads the
     // tally-key row of its slot (one gathered 16-byte access per lane), detects a known (slot, round)
     // and picks the free way.  The key word is written back after the walk, one lane per message.
     int myway = -1;
     bool mydeliver = mv;
     if (FUSED && mv) {
-      const uint32_t* kr = st.pl_key + (size_t)phys_slot(g, myslot) * g.wp;
+      const uint32_t* kr = st.pl_key + (size_t)phys_slot_g<G>(g, myslot) * g.wp;
       const uint4v k0 = *reinterpret_cast<const uint4v*>(kr);
       uint4v k1 = uint4v{0, 0, 0, 0};
       if (g.wp == 8) k1 = *reinterpret_cast<const uint4v*>(kr + 4);
@@ -549,7 +577,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
         for (int w = 0; w < 4; ++w) wt[lane * 4 + w] = b.target[(size_t)m * 4 + w];
       } else {
-        const size_t w0 = (size_t)chunk * CH * 4, wend = (size_t)b.n * 4;
+        const size_t w0 = (size_t)v0 * 4, wend = (size_t)b.n * 4;
         for (int w = lane; w < CH * 4; w += 64)
           if (w0 + w < wend) wt[w] = b.target[w0 + w];
       }
@@ -564,7 +592,7 @@ __global__ void __launch_bounds__(256)
       grp_out = 0;
       int4v thr = init_thr;
       if (s >= 0) {
-        const size_t row = (size_t)phys_slot(g, s) * (size_t)g.RS + (size_t)r0;
+        const size_t row = (size_t)phys_slot_g<G>(g, s) * (size_t)g.RS + (size_t)r0;
         if (!one_group) grp_out = group_of_slot(g, s);
         if (PERSLOT) {
           if (VEC) {
@@ -654,7 +682,7 @@ __global__ void __launch_bounds__(256)
         // first votes of the slot: cells whose acceptor does not vote hold -1 / -1.  ONE store path for the whole
         // row (fully voted cells included): two half-masked store instructions per array cost the issue
         // slots of two full ones
-        const size_t ps = (size_t)phys_slot(g, s), row = ps * (size_t)g.RS + (size_t)r0, vrow = ps * (size_t)g.VS + (size_t)r0;
+        const size_t ps = (size_t)phys_slot_g<G>(g, s), row = ps * (size_t)g.RS + (size_t)r0, vrow = ps * (size_t)g.VS + (size_t)r0;
         int4v rr, vv, nb = thr;
         bool ballot_moves = false;
 #pragma unroll
@@ -667,7 +695,7 @@ __global__ void __launch_bounds__(256)
         row_store(vv, reinterpret_cast<int4v*>(st.vote_value + vrow));
         if (PERSLOT && ballot_moves) row_store(nb, reinterpret_cast<int4v*>(st.ballot + row));
       } else if (acc) {
-        const size_t ps = (size_t)phys_slot(g, s), row = ps * (size_t)g.RS + (size_t)r0, vrow = ps * (size_t)g.VS + (size_t)r0;
+        const size_t ps = (size_t)phys_slot_g<G>(g, s), row = ps * (size_t)g.RS + (size_t)r0, vrow = ps * (size_t)g.VS + (size_t)r0;
         // whole-lane fast path: every acceptor this lane owns voted (padding cells may be overwritten)
         if (VEC && full_cell) {
           const int4v rr = {rnd, rnd, rnd, rnd};
@@ -798,7 +826,7 @@ __global__ void __launch_bounds__(256)
           for (int w = 0; w < 4; ++w) x[w] = vb[w] & g.member[w];
           ch = is_write_quorum(g, x);
           if (!ch && gi == 0) {  // stays Pending: keep the votes (the key word is written below)
-            const size_t e = (size_t)phys_slot(g, s) * g.wp + way;
+            const size_t e = (size_t)phys_slot_g<G>(g, s) * g.wp + way;
 #pragma unroll
             for (int w = 0; w < 4; ++w) st.pl_bits[e * 4 + w] = x[w];
           }
@@ -818,7 +846,7 @@ __global__ void __launch_bounds__(256)
     // ---- outputs of the 64 messages leave as coalesced lines ------------------------------------
     wave_lds_sync();
     // the slot's row is no longer known to be all -1 (marked even if every acceptor Nacked: that only costs the shortcut)
-    if (TGT ? (myfresh && mydeliver) : (mv && mydeliver)) st.row_voted[phys_slot(g, myslot)] = 1;
+    if (TGT ? (myfresh && mydeliver) : (mv && mydeliver)) st.row_voted[phys_slot_g<G>(g, myslot)] = 1;
     if (mv) {
       if constexpr (!FUSED) {
         if (b.vote_bits) {
@@ -835,17 +863,43 @@ __global__ void __launch_bounds__(256)
         const bool ch = wo->chosen[lane] != 0;
         if (mydeliver) {
           // states(slotround) = Done (ProxyLeader.scala:256) or Pending(phase2a, votes) (:213)
-          const size_t e = (size_t)phys_slot(g, myslot) * g.wp + myway;
+          const size_t e = (size_t)phys_slot_g<G>(g, myslot) * g.wp + myway;
           st.pl_key[e] = ((uint32_t)myround + 1u) | (ch ? KEY_DONE : 0u);
           if (!ch) st.pl_value[e] = myvalue;
         }
-        if (b.chosen) b.chosen[m] = ch ? 1 : 0;
-        if (b.chosen_round) b.chosen_round[m] = ch ? myround : -1;
-        if (b.chosen_value) b.chosen_value[m] = ch ? myvalue : -1;
+        if (quad) {  // parked: chosen flag and nack_round; the round and the value are still there
+          sc[0 * 256 + cc * 64 + lane] = ((wo->nack_round[lane] + 1) << 1) | (ch ? 1 : 0);
+        } else {
+          if (b.chosen) b.chosen[m] = ch ? 1 : 0;
+          if (b.chosen_round) b.chosen_round[m] = ch ? myround : -1;
+          if (b.chosen_value) b.chosen_value[m] = ch ? myvalue : -1;
+        }
       }
-      if (b.nack_round) b.nack_round[m] = wo->nack_round[lane];
+      if (b.nack_round && !(FUSED && quad)) b.nack_round[m] = wo->nack_round[lane];
     }
     wave_lds_sync();
+    }  // columns of the unit
+    if (FUSED && quad) {  // the four results of my row, 16 bytes per output array
+      int4 cr, cv, nr;
+      uint32_t chb = 0;
+      int* crp = &cr.x;
+      int* cvp = &cv.x;
+      int* nrp = &nr.x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int w = sc[0 * 256 + k * 64 + lane];
+        const bool ch = w & 1;
+        chb |= (ch ? 1u : 0u) << (8 * k);
+        crp[k] = ch ? sc[1 * 256 + k * 64 + lane] : -1;
+        cvp[k] = ch ? sc[2 * 256 + k * 64 + lane] : -1;
+        nrp[k] = (w >> 1) - 1;
+      }
+      if (b.chosen) *reinterpret_cast<uint32_t*>(b.chosen + mbase) = chb;
+      if (b.chosen_round) *reinterpret_cast<int4*>(b.chosen_round + mbase) = cr;
+      if (b.chosen_value) *reinterpret_cast<int4*>(b.chosen_value + mbase) = cv;
+      if (b.nack_round) *reinterpret_cast<int4*>(b.nack_round + mbase) = nr;
+      wave_lds_sync();
+    }
   }
 
   // ---- fold maxima --------------------------------------------------------------------------------

@@ -379,3 +379,36 @@ def test_slot_major_flag_gives_the_same_state(fa, oracle):
     for x in (a, b):
         W.assert_same_state(x, ref, tally_slots=range(0, S, 37))
         np.testing.assert_array_equal(x.state_digest(), ref.state_digest())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,A,R", [(8, 1, 3), (12, 2, 4), (6, 1, 3), (256, 1, 3), (16, 1, 8)])
+def test_slot_ordered_batches_are_walked_by_column(fa, oracle, L, A, R):
+    """a batch in slot order across the leader groups (message i + P is the next slot of message i's leader group): on
+    leader-group-major rows k_phase2 walks it column by column -- four columns at a time when P is a multiple of 4 --
+    with a tail of plain chunks; dense and with target masks, fused and unfused, some leader groups silent (P < L),
+    leader groups in different rounds; every output and the whole state against the oracle"""
+    S = L * max(1024, -(-65536 // L))
+    kw = dict(num_slots=S, num_replicas=R, num_groups=A, num_leader_groups=L, f=(R - 1) // 2, tally_ways=8)
+    gpu, ref = fa.Context(fa.make_config(**kw)), oracle.System(oracle.make_config(**kw))
+    rng = np.random.default_rng(L * 7 + R)
+    rounds = rng.integers(0, 3, L)
+    lo = 0
+    for step in range(6):
+        n = int(rng.integers(3000, 9000))
+        slots = np.arange(lo, min(S, lo + n), dtype=np.int32)
+        lo += n // 2                                  # the next batch re-proposes half of this one (known (slot, round))
+        if step % 3 == 2:                             # every other leader group is silent: the period halves
+            slots = slots[(slots % L) % 2 == 0]
+        if step == 4:
+            rounds = rounds + 1
+        rr = rounds[slots % L].astype(np.int32)
+        val = (slots * 11 + step).astype(np.int32)
+        tm = None if step % 2 == 0 else W.bits_from_bool(W.random_subsets(rng, len(slots), R, 1, R))
+        if step == 3:
+            script = [("k1k2", slots, rr, val, tm, rng.random(len(slots)) < 0.1)]
+        else:
+            script = [("fused", slots, rr, val, tm)]
+        W.assert_same_outputs(W.run_script(gpu, script), W.run_script(ref, script))
+    W.assert_same_state(gpu, ref, tally_slots=range(0, S, max(1, S // 200)))
+    np.testing.assert_array_equal(gpu.state_digest(), ref.state_digest())
