@@ -111,7 +111,7 @@ typedef enum {
  * of 2f+1 (ProxyLeader.scala:190-191).  K1 / K3 launches that carry target masks then write partially
  * voted 16-byte cells by read-modify-write instead of 4-byte stores.  Results are identical either way. */
 #define FPX_F_SCATTERED_TARGETS 2u
-/* Mencius contexts (num_leader_groups L > 1, num_slots a multiple of L) keep the per-slot rows of the cell arrays and
+/* Mencius contexts (num_leader_groups L > 1, num_slots a multiple of L, num_replicas <= 32) keep the per-slot rows of the cell arrays and
  * tally tables LEADER-GROUP-MAJOR in HBM -- slot s lives in row (s % L) * (S / L) + s / L -- so that what one leader
  * group does (a noop range = every L-th slot; its batch of Phase2as in slot order) touches neighbouring rows and
  * every 128-byte line leaves the GPU whole.  A launch is fastest as the leader groups' batches back to back; one batch
