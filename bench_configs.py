@@ -283,8 +283,10 @@ def mencius_setup(fa, dev, local_rank, rank, world, K, Wm):
     bps = 24 + 0.5 * (12 + 5 + 20)
     return dict(ctx=ctx, step=step, verify=verify, units=band, unit="slots/s", bytes_per_unit=bps,
                 workload="Mencius: %d leader groups x 3 acceptors on this GPU (256 in the job), one step = a band of "
-                         "%d slots: half of the leader groups propose commands in their slots (fused K3), the others "
-                         "skip theirs with one noop range each (fused K4)" % (L, band),
+                         "%d slots: half of the leader groups propose commands in their slots (fused K3; %s), the "
+                         "others skip theirs with one noop range each (fused K4)"
+                         % (L, band, "one batch in slot order across the leader groups" if os.environ.get("FPX_CFG5_ORDER") == "slot"
+                            else "the proposing leader groups' batches back to back, each in slot order"),
                 kernel="k_phase2 (fused K3) + K4 chain (k_ranges_open .. k_ranges_tally)", profile=profile,
                 metric="committed log slots/sec (BASELINE.json configs[4])", cpu=cpu,
                 extra={"slots_per_step_per_gpu": band, "leader_groups_per_gpu": L, "replicas": R,
