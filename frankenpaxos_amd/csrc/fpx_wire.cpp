@@ -5,7 +5,6 @@
 #include "../../include/fpx_wire.h"
 
 #include <cstring>
-#include <unordered_map>
 #include <vector>
 
 #include "../../include/fpx.h"
@@ -20,6 +19,7 @@ struct Reader {
 
   bool more() const { return ok && p < end; }
   uint64_t varint() {
+    if (p < end && !(*p & 0x80)) return *p++;  // tags and small values: one byte
     uint64_t v = 0;
     for (int shift = 0; shift < 70; shift += 7) {
       if (p >= end) break;
@@ -312,27 +312,53 @@ int32_t fpx_wire_phase2b_rows(int32_t n, const int32_t* kind, const int32_t* gro
   if (n < 0 || !num_rows || (n > 0 && (!kind || !group_index || !acceptor_index || !slot || !round || !row_slot ||
                                        !row_round || !row_bits)))
     return FPX_EINVAL;
-  std::unordered_map<uint64_t, int32_t> index;  // (slot, round) -> row
-  index.reserve((size_t)n * 2);
-  int32_t rows = 0;
+  // (slot, round) -> row: open addressing over a power-of-two table at most half full, linear probing; the votes of
+  // one slot usually arrive next to each other, so the previous message's row is tried first
+  size_t cap = 16;
+  while (cap < (size_t)n * 2) cap <<= 1;
+  // row index per table entry (the key is read back from row_slot / row_round).  The table lives across calls (one per
+  // calling thread) and only the entries a call used are reset: a tick's worth of fresh pages per call would cost more
+  // than the fold itself
+  static thread_local std::vector<int32_t> table;
+  static thread_local std::vector<uint32_t> used;
+  if (table.size() < cap) table.assign(cap, -1);
+  used.clear();
+  const size_t mask = cap - 1;
+  int32_t rows = 0, prev = -1;
   for (int32_t i = 0; i < n; ++i) {
     if (kind[i] != FPX_WIRE_PHASE2B) continue;
     const int64_t bit = grid_cols > 0 ? (int64_t)group_index[i] * grid_cols + acceptor_index[i] : acceptor_index[i];
-    if (bit < 0 || bit >= FPX_MAX_REPLICAS || acceptor_index[i] < 0 || (grid_cols > 0 && acceptor_index[i] >= grid_cols))
+    if (bit < 0 || bit >= FPX_MAX_REPLICAS || acceptor_index[i] < 0 || (grid_cols > 0 && acceptor_index[i] >= grid_cols)) {
+      for (uint32_t at : used) table[at] = -1;
       return FPX_EINVAL;
-    const uint64_t key = ((uint64_t)(uint32_t)slot[i] << 32) | (uint32_t)round[i];
-    auto it = index.find(key);
-    int32_t row;
-    if (it == index.end()) {
-      row = rows++;
-      index.emplace(key, row);
-      row_slot[row] = slot[i], row_round[row] = round[i];
-      memset(row_bits + (size_t)row * 4, 0, 32);
-    } else {
-      row = it->second;
     }
+    int32_t row = -1;
+    if (prev >= 0 && row_slot[prev] == slot[i] && row_round[prev] == round[i]) {
+      row = prev;
+    } else {
+      uint64_t h = ((uint64_t)(uint32_t)slot[i] << 32) | (uint32_t)round[i];
+      h ^= h >> 33, h *= 0xff51afd7ed558ccdull, h ^= h >> 33;  // the slot sits in the high half: fold it down first
+      size_t at = (size_t)h & mask;
+      for (;; at = (at + 1) & mask) {
+        const int32_t r = table[at];
+        if (r < 0) break;
+        if (row_slot[r] == slot[i] && row_round[r] == round[i]) {
+          row = r;
+          break;
+        }
+      }
+      if (row < 0) {
+        row = rows++;
+        table[at] = row;
+        used.push_back((uint32_t)at);
+        row_slot[row] = slot[i], row_round[row] = round[i];
+        memset(row_bits + (size_t)row * 4, 0, 32);
+      }
+    }
+    prev = row;
     row_bits[(size_t)row * 4 + (bit >> 6)] |= 1ull << (bit & 63);
   }
+  for (uint32_t at : used) table[at] = -1;
   *num_rows = rows;
   return FPX_OK;
 }
