@@ -254,3 +254,55 @@ def test_epaxos_full_size_scenario_with_the_command_log(oracle):
             assert gpu.read_cmdlog(r, L, x) == ref.read_cmdlog(r, L, x)
             c, d = gpu.read_cmdlog_deps(r, L, x), ref.read_cmdlog_deps(r, L, x)
             assert c[0].tolist() == d[0].tolist() and c[1] == d[1]
+
+
+# ---------------------------------------------------------------------------------------------------
+# size-independent properties at the headline size, no oracle involved: what Paxos itself promises about a batch
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ballot_mode", [0, 1])
+def test_headline_size_properties(fa, ballot_mode):
+    """2^20 slots x 256 acceptors, the GPU alone.  (1) a steady batch chooses every slot with its own value; (2) the
+    same batch again changes nothing -- no output, no state (idempotence: a known (slot, round) is ignored,
+    ProxyLeader.scala:176-184); (3) the batch in a shuffled order, and (4) in two halves with a stale half in between,
+    leave the SAME state (a digest of the whole state: votes, ballots, scalars, tallies) and the same per-slot results;
+    (5) a higher round proposing the chosen values again chooses them again, a stale round is Nacked by everybody and
+    chooses nothing, and no slot ever reports two different chosen values (safety)."""
+    S, R = 1 << 20, 256
+    kw = dict(num_slots=S, num_replicas=R, f=127, ballot_mode=ballot_mode, tally_ways=8)
+    slot, rnd, val = W.steady_stream(S)
+    rnd = rnd + 2                                            # round 2: leaves room for a stale round below it
+    a = fa.Context(fa.make_config(**kw))
+    assert a.acceptor_phase1a(0, 2)[0] == 0                  # the leader of round 2 ran Phase 1
+    st, ch, cr, cv, nr = a.phase2_fused(slot, rnd, val)
+    assert st == 0 and ch.all() and (cr == 2).all() and (cv == val).all() and (nr == -1).all()      # (1)
+    d1 = a.state_digest()
+    st, ch2, cr2, cv2, nr2 = a.phase2_fused(slot, rnd, val)
+    assert st == 0 and not ch2.any() and (cr2 == -1).all() and (cv2 == -1).all()                    # (2)
+    np.testing.assert_array_equal(a.state_digest(), d1)
+
+    b = fa.Context(fa.make_config(**kw))
+    assert b.acceptor_phase1a(0, 2)[0] == 0
+    perm = np.random.default_rng(9).permutation(S)
+    st, chp, crp, cvp, nrp = b.phase2_fused(slot[perm], rnd[perm], val[perm])
+    assert st == 0 and chp.all() and (cvp == val[perm]).all()                                       # (3)
+    np.testing.assert_array_equal(b.state_digest(), d1)
+    b.close()
+
+    c = fa.Context(fa.make_config(**kw))
+    assert c.acceptor_phase1a(0, 2)[0] == 0
+    h = S // 2
+    st, c1, _, v1, _ = c.phase2_fused(slot[:h], rnd[:h], val[:h])
+    stale = c.phase2_fused(slot[h:h + 4096], rnd[h:h + 4096] - 1, val[h:h + 4096] + 1)              # round 1 < 2
+    assert stale[0] == 0 and not stale[1].any() and (stale[4] == 2).all()     # Nacked with the acceptors' round
+    st, c2, _, v2, _ = c.phase2_fused(slot[h:], rnd[h:], val[h:])
+    assert c1.all() and c2.all() and (np.concatenate([v1, v2]) == val).all()                        # (4)
+    # the stale proposals left their tally entries behind (Pending forever), so the digests differ in the tallies
+    # only: compare the acceptors' side
+    np.testing.assert_array_equal(c.state_digest()[:5], d1[:5])
+    c.close()
+
+    st, ch5, cr5, cv5, _ = a.phase2_fused(slot, rnd + 2, val)                                       # (5) round 4
+    assert st == 0 and ch5.all() and (cr5 == 4).all() and (cv5 == val).all()
+    st, ch6, _, _, nr6 = a.phase2_fused(slot[:8192], rnd[:8192] + 1, val[:8192] + 7)                # round 3 < 4
+    assert st == 0 and not ch6.any() and (nr6 == 4).all()
+    a.close()
