@@ -46,10 +46,33 @@ struct ExecSet {
     return w >= 0 && w < (int64_t)bits.size() && ((bits[(size_t)w] >> (x & 63)) & 1u);
   }
   bool contains(int32_t x) const { return x < wm || bit(x); }
+  // the first id in [from, to) that is not an explicit member (from >= wm), or `to`: a word at a time -- a column whose
+  // watermark waits for one instance while thousands beyond it have executed is scanned by every dependent
+  int32_t first_unset(int32_t from, int32_t to) const {
+    int64_t x = from;
+    while (x < to) {
+      const int64_t w = (x >> 6) - base_word;
+      if (w < 0 || w >= (int64_t)bits.size()) return (int32_t)x;
+      const uint64_t zeros = ~bits[(size_t)w] >> (x & 63);  // bit k: id x + k is not a member
+      if (zeros) {
+        const int64_t y = x + __builtin_ctzll(zeros);
+        return (int32_t)(y < to ? y : to);
+      }
+      x = (x | 63) + 1;
+    }
+    return to;
+  }
   void compact() {  // :386-391
-    while (bit(wm)) {
-      bits[(size_t)((wm >> 6) - base_word)] &= ~(1ull << (wm & 63));
-      wm++;
+    for (;;) {
+      const int64_t w = (wm >> 6) - base_word;
+      if (w < 0 || w >= (int64_t)bits.size()) break;
+      const uint64_t run = bits[(size_t)w] >> (wm & 63);  // members from wm on, within this word
+      if (!(run & 1)) break;
+      const int k = ~run ? __builtin_ctzll(~run) : 64 - (wm & 63);  // how many in a row
+      const int take = k < 64 - (wm & 63) ? k : 64 - (wm & 63);
+      const uint64_t mask = (take >= 64 ? ~0ull : ((1ull << take) - 1)) << (wm & 63);
+      bits[(size_t)w] &= ~mask;
+      wm += take;
     }
     // drop whole words below the watermark
     int64_t dead = (wm >> 6) - base_word;
@@ -159,8 +182,7 @@ struct fpx_depgraph {
       if (f.stage == 0) {  // WatermarkIterator.getNext :124-145
         int32_t to = wm[f.col];
         if (f.x < to && to > E.wm) {
-          int32_t start = std::max(f.x, E.wm);
-          while (start < to && E.bit(start)) start++;
+          int32_t start = E.first_unset(std::max(f.x, E.wm), to);
           if (start < to) {
             f.x = start + 1;
             *l = f.col;
@@ -176,7 +198,8 @@ struct fpx_depgraph {
         while (f.ri < rs->size() && (*rs)[f.ri].leader == f.col) {
           const Range& r = (*rs)[f.ri];
           int32_t x = std::max(f.x, r.lo);
-          while (x < r.hi && E.contains(x)) x++;
+          if (x < E.wm) x = E.wm;
+          if (x < r.hi) x = E.first_unset(x, r.hi);
           if (x < r.hi) {
             f.x = x + 1;
             *l = f.col;
