@@ -69,6 +69,8 @@ for seed in range(seeds):
                 # the range table holds 2048 live entries here (fpx_create sizes it by the leader groups): big launches
                 # stay below that and the window is garbage-collected right after them
                 k = int(rng.integers(1, 300)) if kind != 6 else int(rng.integers(600, 1900))
+                if k >= 600:
+                    gpu.proxy_forget(0, S), ref.proxy_forget(0, S)
                 lgs = rng.integers(0, L, k)
                 a = rng.integers(0, rows, k)
                 b = np.minimum(rows, a + rng.integers(1, 400, k))
