@@ -95,7 +95,9 @@ class GpuMenciusProxyLeader[Transport <: frankenpaxos.Transport[Transport]](
   private def flushTick(): Unit = {
     // ---- commands: the leader groups' batches back to back, each sorted by slot.  A slot that appears twice in the
     // burst (a re-proposal in a higher round) must not share a device run with its first message: the library
-    // splits such a batch into runs itself (host entry points), in message order
+    // splits such a batch into runs itself (host entry points), in message order.  Regrouping the burst is a
+    // reordering of messages that were in flight together -- something the asynchronous network may do anyway; one
+    // leader's own messages (increasing slots of its group) keep their order, and sortBy is stable for equal slots
     val now = pending.flatMap(_.sortBy(_.slot)).toArray
     pending.foreach(_.clear())
     val n = now.length
