@@ -53,3 +53,28 @@ def test_plain_c_epaxos_caller():
     else:
         assert run.returncode == 77, run.stdout + run.stderr
         assert "no usable gfx950 device" in run.stdout
+
+
+def test_plain_c_mencius_caller():
+    """examples/mencius_demo.c: leader groups with commands (their batches back to back), leader groups that skip with
+    noop ranges, the replica log executing the band, a leader change in one group -- through include/fpx.h alone"""
+    import torch
+
+    import frankenpaxos_amd
+
+    if not os.path.exists(frankenpaxos_amd._lib.SO_PATH):
+        frankenpaxos_amd.build()
+    csrc = os.path.join(ROOT, "frankenpaxos_amd", "csrc")
+    out_dir = os.path.join(ROOT, "tests", "build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "mencius_demo")
+    subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "examples", "mencius_demo.c"),
+                           "-I" + os.path.join(ROOT, "include"), "-L" + csrc, "-lfpx", "-Wl,-rpath," + csrc,
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    if torch.cuda.is_available():
+        assert run.returncode == 0, run.stdout + run.stderr
+        assert "2048 of 2048 chosen" in run.stdout and "executed watermark 4096 of 4096, 4096 slots in the log" in run.stdout
+    else:
+        assert run.returncode == 77, run.stdout + run.stderr
+        assert "no usable gfx950 device" in run.stdout
