@@ -78,3 +78,14 @@ def test_plain_c_mencius_caller():
     else:
         assert run.returncode == 77, run.stdout + run.stderr
         assert "no usable gfx950 device" in run.stdout
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_plain_c_callers_on_the_gpu():
+    """the three examples again under `-m gpu`: on the MI355X box they run to the end and check their own results"""
+    test_plain_c_caller_builds_links_and_fails_loudly_without_a_device()
+    test_plain_c_epaxos_caller()
+    test_plain_c_mencius_caller()
