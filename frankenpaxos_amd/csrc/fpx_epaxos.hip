@@ -114,8 +114,13 @@ __device__ __forceinline__ int wave_incl_max(int v) {
   v = imax(v, dpp0<0x112, 0xF>(v));  // row_shr:2
   v = imax(v, dpp0<0x114, 0xF>(v));  // row_shr:4
   v = imax(v, dpp0<0x118, 0xF>(v));  // row_shr:8
-  v = imax(v, dpp0<0x142, 0xA>(v));  // row_bcast:15 -> rows 1, 3
-  v = imax(v, dpp0<0x143, 0xC>(v));  // row_bcast:31 -> rows 2, 3
+  // row_bcast:15 -> rows 1, 3, then row_bcast:31 -> rows 2, 3.  Written out: from update_dpp + max the compiler makes a
+  // v_mov, a v_mov_dpp and the v_max per step (it does not fold a move under a partial row mask), 6 instructions where 2
+  // do -- and this scan is a third of the K5 key kernel's vector instructions.  The s_nops are the two wait states
+  // between a VALU write and a DPP read of the same register, which the hazard recogniser does not see through asm.
+  asm("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+      : "+v"(v));
   return v;
 }
 __device__ __forceinline__ int wave_shr1(int v) { return dpp0<0x138, 0xF>(v); }  // lane 0 gets 0
@@ -1463,15 +1468,24 @@ int launch_kp(fpx_epx* e, const EpxBatch& b, int32_t* d_packed, bool* done) {
   KpArgs a;
   memset(&a, 0, sizeof(a));
   a.m = b.m, a.tiles = (b.m + KP_TILE - 1) / KP_TILE, a.B = e->st.num_keys;
+  a.groups = (a.tiles + KP_HG - 1) / KP_HG;
   int rc;
-  if ((rc = grow(e, &e->kp_hist, (size_t)a.tiles * a.B * 4))) return rc;
-  if ((rc = grow(e, &e->kp_recs, (size_t)b.m * T::NI * 4))) return rc;
-  if ((rc = grow(e, &e->kp_misc, (size_t)a.B * 12 + 256))) return rc;
-  a.hist = (uint32_t*)e->kp_hist.p, a.recs = (int32_t*)e->kp_recs.p;
+  if ((rc = grow(e, &e->kp_hist, (size_t)a.tiles * a.B * 2))) return rc;
+  if ((rc = grow(e, &e->kp_recs, (size_t)a.B * T::TC * T::NI * 4))) return rc;
+  {
+    // fingerprints, control word, one word per group of tiles (m < 2^21: at most 128 groups), then the claim counters
+    // (one 64-byte sector per key): they must read zero before the first tick, later the key kernel leaves them at zero
+    const size_t need = 1024 + (size_t)a.B * KP_TOT_STRIDE * 4;
+    if (need > e->kp_misc.cap) {
+      if ((rc = grow(e, &e->kp_misc, need))) return rc;
+      EHIP(e, hipMemsetAsync(e->kp_misc.p, 0, e->kp_misc.cap, e->stream));
+    }
+  }
+  a.hist = (uint16_t*)e->kp_hist.p, a.recs = (uint32_t*)e->kp_recs.p;
   a.fp = (unsigned long long*)e->kp_misc.p;              // 16 words of 8 bytes
-  a.ctl = (uint32_t*)((char*)e->kp_misc.p + 128);        // 2 words
-  a.tot = (uint32_t*)((char*)e->kp_misc.p + 256);
-  a.seg = (int32_t*)(a.tot + a.B);
+  a.ctl = (uint32_t*)((char*)e->kp_misc.p + 128);        // 1 word
+  a.big = (uint32_t*)((char*)e->kp_misc.p + 512);        // [groups <= 128]
+  a.tot = (uint32_t*)((char*)e->kp_misc.p + 1024);
   a.host_flag = e->kp_flag_dev, a.seq = ++e->kp_seq, a.tc = T::TC;
   a.packed = d_packed, a.stride = fpx_epx_packed_stride(N);
   if (!e->kp_lds_allowed) {
@@ -1483,9 +1497,8 @@ int launch_kp(fpx_epx* e, const EpxBatch& b, int32_t* d_packed, bool* done) {
                               KP_HG * KP_MAXB * 4);
     e->kp_lds_allowed = true;
   }
-  hipLaunchKernelGGL(k_kp_hist, dim3((a.tiles + KP_HG - 1) / KP_HG), dim3(128 * KP_HG), (size_t)KP_HG * a.B * 4, e->stream, e->st, b, a);
-  hipLaunchKernelGGL(k_kp_scan, dim3((a.B + KP_SCAN_WAVES - 1) / KP_SCAN_WAVES), dim3(64 * KP_SCAN_WAVES), 0, e->stream, a);
-  hipLaunchKernelGGL((k_kp_scatter<N>), dim3(8 * ((a.tiles + 7) / 8)), dim3(256), 0, e->stream, e->st, b, a);
+  hipLaunchKernelGGL(k_kp_hist, dim3(a.groups), dim3(128 * KP_HG), (size_t)KP_HG * a.B * 4, e->stream, e->st, b, a);
+  hipLaunchKernelGGL((k_kp_scatter<N>), dim3(8 * ((a.tiles + 7) / 8)), dim3(KP_ST), 0, e->stream, e->st, b, a);
   // k_epx_key2 is enqueued at once -- it returns at its first instruction when a key does not fit -- and the host then
   // learns, while the GPU works on, whether the first form has to take the tick after all (launching the kernel
   // only after the answer left the GPU idle for ~30 us per tick when ticks were enqueued back to back)

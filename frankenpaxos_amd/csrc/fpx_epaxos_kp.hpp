@@ -1,28 +1,27 @@
 // fpx_epaxos_kp.hpp -- K5, second form: the tick is partitioned by KEY once, each key is ordered per replica ON CHIP.
-// Included by fpx_epaxos.hip inside its anonymous namespace (uses EpxState, EpxBatch, scan_chunk, own_column, ...).
+// Included by fpx_epaxos.hip inside its anonymous namespace (uses EpxState, EpxBatch, own_column, wave_incl_max, ...).
 //
 // The first form (k_epx_keys -> radix sort of n x m (key, message) pairs -> k_epx_key) moves every command n times
 // through HBM as an 8-byte pair, twice each way, and gathers its fields again by message index afterwards: 651 MB
 // per 2^20-command tick for 84 B of compulsory traffic per command (profiles/r02_k5_pmc.md).  Here a command
 // crosses HBM once more than it has to, as ONE record that holds everything the per-key work needs:
 //
-//   k_kp_hist      per tile of 2048 messages: how many of each key           (reads key[]: 4 B per command)
-//   k_kp_scan      tile offsets within every key, key segments [start, count), and how many keys hold more
-//                  commands than the on-chip tables take (written to a page-locked word the host waits for while
-//                  the next kernel runs: such a tick goes the first form's way, nothing of it is applied here)
-//   k_kp_scatter   validates the tick, writes record(i) = {i, number, leader | is_set | resp | seen, rank[0..n)} to
-//                  its place in its key's segment (a tile-local LDS counter + the tile's offset: no order is needed
-//                  inside a key), and accumulates the fingerprints that tell a permutation from a non-permutation
-//   k_epx_key2<N>  one persistent workgroup per CU, key after key: the key's records -> LDS; per replica the
-//                  participating commands as (rank << 11 | slot) words, sorted by an LSD radix sort in LDS (7-bit
-//                  digits, wavefront-private counters, ballots rank equal digits); the segmented scans of
-//                  scan_chunk on the sorted order (conflict rows stay in registers); the leader's rows D go to
-//                  LDS, every responder folds max(conflicts, D) into a per-command max and min (fast path <=> max
-//                  == min in every column, and the union the slow path proposes IS the max); decisions leave as
-//                  one packed line per command (or the four arrays of the first form); the key's conflict index
-//                  is updated in place (what k_epx_commit did for all keys).
+//   k_kp_hist      8 tiles of 2048 messages per workgroup: how many of each key; every key of the group CLAIMS its run of
+//                  records in the key's segment with one returning atomic (no order is needed inside a key, so no
+//                  scan over tiles: round 3's k_kp_scan and its table of per-tile counts in key order are gone); a
+//                  claim that runs past the segment (more commands of one key than the on-chip tables take) is
+//                  reported: such a tick goes the first form's way, nothing of it is applied here
+//   k_kp_scatter   validates the tick, writes record(i) = {i | header, number, rank[0..n) packed} to its place (the
+//                  tile's claimed run + a tile-local LDS counter), accumulates the fingerprints that tell a permutation
+//                  from a non-permutation, and tells the host through a page-locked word whether a claim overflowed
+//   k_epx_key2<N>  one persistent workgroup per CU, key after key, the next key's records in flight: a thread unpacks a
+//                  record into the per-replica sort words (rank << 11 | slot; ~0 where the replica takes no part) IN
+//                  PLACE of a compaction pass; the words are ordered by a bucket sort in LDS (LSD radix sort for
+//                  clumped ranks); the segmented scans run on the sorted order; conflict rows meet in LDS
+//                  [command][n-1][n]; one thread per command decides; decisions leave as one packed line per command
+//                  (or the four arrays of the first form); the key's conflict index is updated in place.
 //
-// HBM traffic per command (n = 5): 35 B of inputs + 32 B record out + 32 B record in + the outputs.
+// HBM traffic per command (n = 5): 35 B of inputs + 24 B record out + 24 B record in + the outputs.
 // With a command log (num_instances > 0, n >= 5): k_epx_key2<N, true> scans a second time after the decisions and
 // writes the entries of every replica that saw the PreAccept (or of every replica, for a fast-path commit).
 #pragma once
@@ -32,46 +31,104 @@ constexpr int KP_MAXB = 2048;   // keys (one LDS counter each in the partition p
 constexpr int KP_SLOT_BITS = 11;
 constexpr uint32_t KP_SLOT_MASK = (1u << KP_SLOT_BITS) - 1u;
 constexpr int KP_RADIX_BITS = 7, KP_RADIX = 1 << KP_RADIX_BITS;
-#ifndef KP_SCATTER_MB
-#define KP_SCATTER_MB 4
-#endif
-constexpr int KP_MAX_OCC = 24;   // fullest rank bucket the bucket sort accepts before the key is radix-sorted instead
+constexpr int KP_MAX_OCC = 24;           // fullest rank bucket the bucket sort accepts before the key is radix-sorted instead
+constexpr int KP_TOT_STRIDE = 16;        // words between two keys' claim counters: a 64-byte sector each (the claims of
+                                         // 1024 keys are returning atomics on 1024 different sectors, not on 32 lines)
+constexpr int KP_IDX_BITS = 21;          // message indices and ranks: m < 2^21
+constexpr uint32_t KP_IDX_MASK = (1u << KP_IDX_BITS) - 1u;
+constexpr uint32_t KP_INVALID = 0xffffffffu;  // sort word of a command the replica takes no part in (sorts last)
+constexpr int KP_ST = 512;               // threads of a scatter workgroup: every thread's KP_TILE / KP_ST messages in flight at once
 
 template <int N> struct KpTile {
-  static constexpr int NI = N <= 5 ? 8 : 12;                       // ints per record: i, number, flags, rank[N], padding
+  // words per record.  n <= 5: {i | header << 21, number, ranks packed 21 bits each} -- 16 B (n = 3), 24 B (n = 5);
+  // n = 7: {i, number, flags, ranks packed} -- 32 B.  Round 3's record was {i, number, flags, rank[n], padding}: 32 / 48 B
+  static constexpr int NI = N <= 3 ? 4 : N <= 5 ? 6 : 8;
   static constexpr int TC = N <= 3 ? 1536 : N <= 5 ? 1152 : 640;   // commands of one key held on chip (<= 2^11)
   static constexpr int W = N <= 3 ? 4 : N <= 5 ? 3 : 2;            // wavefronts per replica
   static constexpr int THREADS = 64 * N * W;
   static constexpr int MAXC = (TC + 63) / 64;
   static constexpr int CPW = (MAXC + W - 1) / W;                   // 64-command chunks per wavefront
   static constexpr int NBK = N <= 5 ? 1024 : 512;                  // rank buckets of the bucket sort
-  static constexpr int RQ = (TC * (NI / 4) + THREADS - 1) / THREADS;  // int4 loads per thread for one key's records
-  // LDS: records | region R | radix counters + cursors | part totals | misc.  R holds the two sort buffers and the rank
-  // buckets while a key is sorted, then the conflict rows [TC][N - 1][N]: the n-2 counted answers and the leader's own
+  static constexpr int RQ = (TC + THREADS - 1) / THREADS;          // records per thread
+  // LDS: i, number, flags [3][TC] | region R | radix counters + cursors | part totals | misc.  R holds the two sort
+  // buffers and the rank buckets while a key is sorted, then the conflict rows [TC][N - 1][N]: the n-2 counted answers
+  // and the leader's own
+  static constexpr size_t META_BYTES = (size_t)3 * TC * 4;
   static constexpr size_t SORT_BYTES = (size_t)2 * N * TC * 4 + (size_t)N * NBK * 4;
   static constexpr int RSTR = (N - 1) * N + 1;  // ints between two commands' conflict rows: odd, so that random commands
                                                 // spread over all LDS banks ((N - 1) N = 20 reaches 16 of 64: 40 % of the
                                                 // kernel's LDS cycles were bank conflicts)
   static constexpr size_t ROWS_BYTES = (size_t)TC * RSTR * 4;
   static constexpr size_t R_BYTES = SORT_BYTES > ROWS_BYTES ? SORT_BYTES : ROWS_BYTES;
-  static constexpr size_t BYTES = (size_t)TC * NI * 4 + R_BYTES + (size_t)2 * N * W * KP_RADIX * 4 + (size_t)N * W * 2 * N * 4 + 256 +
+  static constexpr size_t BYTES = META_BYTES + R_BYTES + (size_t)2 * N * W * KP_RADIX * 4 + (size_t)N * W * 2 * N * 4 + 256 +
                                   (size_t)N * 2 * N * 4;
   static_assert(BYTES <= 160 * 1024, "LDS of one CU");
+  static_assert(TC <= (1 << KP_SLOT_BITS), "slots share the sort word with the rank");
 };
 
-// record flags: leader | is_set << 3 | resp_mask << 8 | seen_mask << 16
+// flags of a command as the key kernel keeps them: leader | is_set << 3 | resp_mask << 8 | seen_mask << 16
 __device__ __forceinline__ int kp_flags(int L, int is_set, unsigned resp, unsigned seen) {
   return L | (is_set ? 8 : 0) | (int)(resp << 8) | (int)(seen << 16);
 }
 
+// The record.  resp_mask is n - 2 of the n - 1 replicas that are not the leader: the header names the ONE that is left
+// out (its index among the non-leaders), which with leader, is_set and seen_mask fits beside a 21-bit message index for
+// n <= 5.  Ranks are < m < 2^21: two ranks' words carry a third rank's halves in their upper 11 bits.
+template <int N>
+__device__ __forceinline__ void kp_pack(uint32_t* w, int i, int x, int L, int is_set, unsigned resp, unsigned seen, const int* rk) {
+  const unsigned full = (1u << N) - 1u;
+  const int q = __ffs((int)(full & ~resp & ~(1u << L))) - 1;  // the non-leader whose answer is not waited for
+  const unsigned e = (unsigned)(q - (q > L ? 1 : 0));
+  const unsigned hdr = (unsigned)L | (is_set ? 8u : 0u) | (seen << 4) | (e << (4 + N));
+  auto pair_lo = [](int a, int c) { return (uint32_t)a | (((uint32_t)c & 0x7ffu) << KP_IDX_BITS); };
+  auto pair_hi = [](int a, int c) { return (uint32_t)a | (((uint32_t)c >> 11) << KP_IDX_BITS); };
+  if constexpr (N <= 3) {
+    w[0] = (uint32_t)i | (hdr << KP_IDX_BITS), w[1] = (uint32_t)x;
+    w[2] = pair_lo(rk[0], rk[2]), w[3] = pair_hi(rk[1], rk[2]);
+  } else if constexpr (N <= 5) {
+    w[0] = (uint32_t)i | (hdr << KP_IDX_BITS), w[1] = (uint32_t)x;
+    w[2] = pair_lo(rk[0], rk[4]), w[3] = pair_hi(rk[1], rk[4]), w[4] = (uint32_t)rk[2], w[5] = (uint32_t)rk[3];
+  } else {
+    w[0] = (uint32_t)i, w[1] = (uint32_t)x, w[2] = (uint32_t)kp_flags(L, is_set, resp, seen);
+    w[3] = pair_lo(rk[0], rk[4]), w[4] = pair_hi(rk[1], rk[4]);
+    w[5] = pair_lo(rk[2], rk[5]), w[6] = pair_hi(rk[3], rk[5]), w[7] = (uint32_t)rk[6];
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void kp_unpack(const uint32_t* w, int* i, int* x, int* flags, int* rk) {
+  auto third = [](uint32_t a, uint32_t c) { return (int)((a >> KP_IDX_BITS) | ((c >> KP_IDX_BITS) << 11)); };
+  if constexpr (N <= 5) {
+    *i = (int)(w[0] & KP_IDX_MASK), *x = (int)w[1];
+    const unsigned hdr = w[0] >> KP_IDX_BITS, full = (1u << N) - 1u;
+    const int L = (int)(hdr & 7u);
+    const unsigned seen = (hdr >> 4) & full, e = hdr >> (4 + N);
+    const unsigned q = e + (e >= (unsigned)L ? 1u : 0u);
+    *flags = kp_flags(L, (int)((hdr >> 3) & 1u), full & ~(1u << L) & ~(1u << q), seen);
+    rk[0] = (int)(w[2] & KP_IDX_MASK), rk[1] = (int)(w[3] & KP_IDX_MASK);
+    if constexpr (N <= 3) {
+      rk[2] = third(w[2], w[3]);
+    } else {
+      rk[2] = (int)w[4], rk[3] = (int)w[5], rk[4] = third(w[2], w[3]);
+    }
+  } else {
+    *i = (int)w[0], *x = (int)w[1], *flags = (int)w[2];
+    rk[0] = (int)(w[3] & KP_IDX_MASK), rk[1] = (int)(w[4] & KP_IDX_MASK), rk[4] = third(w[3], w[4]);
+    rk[2] = (int)(w[5] & KP_IDX_MASK), rk[3] = (int)(w[6] & KP_IDX_MASK), rk[5] = third(w[5], w[6]);
+    rk[6] = (int)w[7];
+  }
+}
+
 struct KpArgs {
   int m, tiles, B;                  // B = num_keys
-  uint32_t* hist;                   // [B][tiles] per-tile key counts -> exclusive offsets of the tile within the key
-  uint32_t* tot;                    // [B]
-  int32_t* seg;                     // [B][2] start, count of the key's records
-  uint32_t* ctl;                    // [0] scan blocks done, [1] keys that do not fit the on-chip tables
+  int groups;                       // workgroups of k_kp_hist (KP_HG tiles each)
+  uint16_t* hist;                   // [tiles][B] where the tile's records of the key start within the key's segment
+  uint32_t* tot;                    // [B * KP_TOT_STRIDE] records claimed in the key's segment; zero between ticks (the key
+                                    // kernel clears what it read)
+  uint32_t* big;                    // [groups] 1 = a claim of this group of tiles ran past its key's segment
+  uint32_t* ctl;                    // [1] groups with such a claim (written by k_kp_scatter, read by the key kernel)
   unsigned long long* fp;           // [2 (N + 1)] additive fingerprints: of the indices 0..m-1, then of every rank row
-  int32_t* recs;                    // [m][NI]
+  uint32_t* recs;                   // [B][tc][NI]: a key's segment has room for what the on-chip tables take
   volatile uint32_t* host_flag;     // page-locked: [1] = ctl[1], then [0] = seq
   uint32_t seq;
   int tc;                           // KpTile<N>::TC
@@ -79,10 +136,16 @@ struct KpArgs {
   int stride;
 };
 
-__device__ __forceinline__ unsigned long long kp_mix(unsigned long long z) {  // splitmix64 finaliser
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
+// two independent 32-bit mixes of one value (murmur3's finaliser on differently salted inputs): the additive
+// fingerprints are sums of these in 64-bit accumulators.  (Round 3 summed two splitmix64 finalisers: four 64-bit
+// multiplies per value, a third of the scatter kernel's issue slots.)
+__device__ __forceinline__ uint32_t kp_mix32(uint32_t h) {
+  h ^= h >> 16, h *= 0x85EBCA6Bu;
+  h ^= h >> 13, h *= 0xC2B2AE35u;
+  return h ^ (h >> 16);
+}
+__device__ __forceinline__ void kp_fp_add(unsigned long long* f, uint32_t v) {
+  f[0] += kp_mix32(v + 0x9E3779B9u), f[1] += kp_mix32(v ^ 0x7F4A7C15u) ^ 0x5BD1E995u;
 }
 
 // wave64 exclusive sum of one value per lane
@@ -97,15 +160,14 @@ __device__ __forceinline__ uint32_t kp_wave_excl_sum(uint32_t v) {
   return inc - v;
 }
 
-// KP_HG tiles per workgroup (128 threads each): the counts of a key for the workgroup's tiles are neighbours in
-// hist[key][tile] and leave as one 32-byte sector (one tile per workgroup wrote 2 MB of counts as 17 MB of partial sectors)
+// KP_HG tiles per workgroup (128 threads each).  After the count, thread j owns key j: the key's commands in the
+// workgroup's tiles are ONE claim in the key's segment (so the records of 8 neighbouring tiles are neighbours there, and
+// the workgroups of one XCD take neighbouring tiles in k_kp_scatter: their 24-byte stores meet in one L2 and leave it as
+// whole lines), split among the tiles in tile order.
 constexpr int KP_HG = 8;
 __global__ void __launch_bounds__(128 * KP_HG) k_kp_hist(const EpxState st, const EpxBatch b, const KpArgs a) {
   extern __shared__ uint32_t kp_h[];  // [KP_HG][B]
-  if (blockIdx.x == 0) {
-    if (threadIdx.x < 2) a.ctl[threadIdx.x] = 0;
-    if (threadIdx.x < 2 * (st.n + 1)) a.fp[threadIdx.x] = 0ull;
-  }
+  if (blockIdx.x == 0 && threadIdx.x < 2 * (st.n + 1)) a.fp[threadIdx.x] = 0ull;
   for (int j = threadIdx.x; j < KP_HG * a.B; j += 128 * KP_HG) kp_h[j] = 0;
   __syncthreads();
   const int sub = threadIdx.x >> 7, t = threadIdx.x & 127;
@@ -128,142 +190,109 @@ __global__ void __launch_bounds__(128 * KP_HG) k_kp_hist(const EpxState st, cons
   }
   __syncthreads();
   const int t0 = blockIdx.x * KP_HG, nt = min(KP_HG, a.tiles - t0);
+  int over = 0;
   for (int j = threadIdx.x; j < a.B; j += 128 * KP_HG) {
-    uint32_t* out = a.hist + (size_t)j * a.tiles + t0;  // [key][tile]
-    if (nt == KP_HG && (a.tiles & 3) == 0) {
-      reinterpret_cast<uint4*>(out)[0] = make_uint4(kp_h[j], kp_h[a.B + j], kp_h[2 * a.B + j], kp_h[3 * a.B + j]);
-      reinterpret_cast<uint4*>(out)[1] = make_uint4(kp_h[4 * a.B + j], kp_h[5 * a.B + j], kp_h[6 * a.B + j], kp_h[7 * a.B + j]);
-    } else {
-      for (int q = 0; q < nt; ++q) out[q] = kp_h[q * a.B + j];
-    }
+    uint32_t c[KP_HG], total = 0;
+#pragma unroll
+    for (int q = 0; q < KP_HG; ++q) c[q] = kp_h[q * a.B + j], total += c[q];
+    uint32_t run = total ? atomicAdd(&a.tot[(size_t)j * KP_TOT_STRIDE], total) : 0u;
+    if (run + total > (uint32_t)a.tc) over = 1;
+#pragma unroll
+    for (int q = 0; q < KP_HG; ++q)
+      if (q < nt) a.hist[(size_t)(t0 + q) * a.B + j] = (uint16_t)min(run, 0xffffu), run += c[q];
   }
-}
-
-// exclusive scan of every key's per-tile counts: one wavefront per key, the key's counts are contiguous ([key][tile];
-// with [tile][key] a key's column is one word every 4 KB -- 16 workgroups x 128 dependent round trips were 53 us, and
-// finer splits of the columns only moved the time around: 23 - 46 us).  No "last workgroup" epilogue here: its
-// __threadfence() per workgroup (an L2 write-back on this multi-die GPU) cost 30 us; k_kp_scatter turns the totals into
-// key segments itself
-constexpr int KP_SCAN_WAVES = 4;
-__global__ void __launch_bounds__(64 * KP_SCAN_WAVES) k_kp_scan(const KpArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int d = blockIdx.x * KP_SCAN_WAVES + (threadIdx.x >> 6);
-  if (d < a.B) {
-    uint32_t* row = a.hist + (size_t)d * a.tiles;
-    const int per = (a.tiles + 63) / 64, t0 = min(a.tiles, lane * per), t1 = min(a.tiles, t0 + per);
-    uint32_t sum = 0;
-    for (int t = t0; t < t1; ++t) sum += row[t];
-    uint32_t run = kp_wave_excl_sum(sum);
-    if (lane == 63) a.tot[d] = run + sum;
-    for (int t = t0; t < t1; ++t) {
-      const uint32_t v = row[t];
-      row[t] = run, run += v;
-    }
-  }
+  over = __syncthreads_or(over);
+  if (threadIdx.x == 0) a.big[blockIdx.x] = over ? 1u : 0u;
 }
 
 // validation of one message exactly as k_epx_keys, record out, fingerprints
 template <int N>
-__global__ void __launch_bounds__(256) k_kp_scatter(const EpxState st, const EpxBatch b, const KpArgs a) {
+__global__ void __launch_bounds__(KP_ST) k_kp_scatter(const EpxState st, const EpxBatch b, const KpArgs a) {
   using T = KpTile<N>;
   __shared__ uint32_t cnt[KP_MAXB];
-  __shared__ uint32_t goff[KP_MAXB];
-  __shared__ uint32_t sh[4];
-  __shared__ unsigned long long fsum[4][2 * (N + 1)];
+  __shared__ uint32_t goff[KP_MAXB];  // the tile's first record of the key, in records from the start of a.recs
+  __shared__ unsigned long long fsum[KP_ST / 64][2 * (N + 1)];
   // workgroups go round-robin over the 8 XCDs: the ones of one XCD take consecutive tiles, whose records are neighbours
-  // in every key's segment -- their 32-byte stores meet in the same L2 and leave it as whole lines
+  // in every key's segment -- their stores meet in the same L2 and leave it as whole lines
   const int tps = (a.tiles + 7) / 8, tile = ((int)blockIdx.x % 8) * tps + (int)blockIdx.x / 8;
-  if ((int)blockIdx.x / 8 >= tps || tile >= a.tiles) return;
-  // where every key's records start: the exclusive prefix of the key totals, recomputed by every workgroup (4 KB from
-  // L2); workgroup 0 also publishes the segments and tells the host how many keys are too big for the on-chip tables
-  {
-    const int per_t = (a.B + 255) / 256, k0 = threadIdx.x * per_t;
-    uint32_t mine = 0, big = 0;
-    for (int j = 0; j < per_t; ++j)
-      if (k0 + j < a.B) {
-        const uint32_t c = a.tot[k0 + j];
-        mine += c, big += c > (uint32_t)a.tc ? 1u : 0u;
-      }
-    uint32_t start = block_excl_sum(mine, sh);
-    for (int j = 0; j < per_t; ++j)
-      if (k0 + j < a.B) {
-        const uint32_t c = a.tot[k0 + j];
-        cnt[k0 + j] = 0, goff[k0 + j] = start + a.hist[(size_t)(k0 + j) * a.tiles + tile];
-        if (blockIdx.x == 0) a.seg[(size_t)(k0 + j) * 2] = (int32_t)start, a.seg[(size_t)(k0 + j) * 2 + 1] = (int32_t)c;
-        start += c;
-      }
-    if (blockIdx.x == 0) {
-      __syncthreads();
-      const uint32_t nbig_before = block_excl_sum(big, sh);
-      if (threadIdx.x == 255) {
-        const uint32_t nbig = nbig_before + big;
-        a.ctl[1] = nbig;
-        if (a.host_flag) {
-          a.host_flag[1] = nbig;
-          __threadfence_system();
-          a.host_flag[0] = a.seq;
-        }
+  if (blockIdx.x == 0) {
+    // did a claim run past a key's segment?  the key kernel reads ctl[0], the host the page-locked word
+    uint32_t nbig = 0;
+    for (int j = threadIdx.x; j < a.groups; j += KP_ST) nbig += a.big[j];
+    nbig = (uint32_t)__syncthreads_count(nbig != 0);
+    if (threadIdx.x == 0) {
+      a.ctl[0] = nbig;
+      if (a.host_flag) {
+        a.host_flag[1] = nbig;
+        __threadfence_system();
+        a.host_flag[0] = a.seq;
       }
     }
   }
+  if ((int)blockIdx.x / 8 >= tps || tile >= a.tiles) return;
+  for (int k = threadIdx.x; k < a.B; k += KP_ST) cnt[k] = 0, goff[k] = (uint32_t)k * (uint32_t)a.tc + a.hist[(size_t)tile * a.B + k];
   __syncthreads();
   unsigned long long f[2 * (N + 1)];
 #pragma unroll
   for (int q = 0; q < 2 * (N + 1); ++q) f[q] = 0ull;
   const int first = tile * KP_TILE;
-  constexpr int MB = KP_SCATTER_MB;  // messages of one thread whose loads are in flight together
-  for (int j0 = 0; j0 < KP_TILE / 256; j0 += MB) {
-    int Lq[MB], kq[MB], xq[MB], rkq[MB][N];
-    unsigned mq[MB], sq[MB], tq[MB];
+  constexpr int MB = KP_TILE / KP_ST;  // messages of one thread: all their loads are in flight together
+  int Lq[MB], kq[MB], xq[MB], rkq[MB][N];
+  unsigned mq[MB], sq[MB], tq[MB];
 #pragma unroll
-    for (int u = 0; u < MB; ++u) {
-      const int i = first + (j0 + u) * 256 + threadIdx.x;
-      const bool in = i < a.m;
-      Lq[u] = in ? b.leader[i] : 0, kq[u] = in ? b.key[i] : 0, xq[u] = in ? b.number[i] : 0;
-      mq[u] = in ? b.resp_mask[i] : 0u, tq[u] = in ? b.is_set[i] : 0u;
-      sq[u] = in ? (b.seen_mask ? b.seen_mask[i] : mq[u]) : 0u;
+  for (int u = 0; u < MB; ++u) {
+    const int i = first + u * KP_ST + threadIdx.x;
+    const bool in = i < a.m;
+    Lq[u] = in ? b.leader[i] : 0, kq[u] = in ? b.key[i] : 0, xq[u] = in ? b.number[i] : 0;
+    mq[u] = in ? b.resp_mask[i] : 0u, tq[u] = in ? b.is_set[i] : 0u;
+    sq[u] = in ? (b.seen_mask ? b.seen_mask[i] : mq[u]) : 0u;
 #pragma unroll
-      for (int r = 0; r < N; ++r) rkq[u][r] = in ? b.rank[(size_t)r * a.m + i] : 0;
+    for (int r = 0; r < N; ++r) rkq[u][r] = in ? b.rank[(size_t)r * a.m + i] : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < MB; ++u) {
+    const int i = first + u * KP_ST + threadIdx.x;
+    if (i >= a.m) continue;
+    const int L = Lq[u], k = kq[u], x = xq[u];
+    const unsigned mask = mq[u], seen = sq[u];
+    const int is_set = tq[u] ? 1 : 0;
+    bool ok = L >= 0 && L < N && x >= 0 && k >= 0 && k < a.B;
+    ok = ok && !((mask >> (ok ? L : 0)) & 1u) && (mask >> N) == 0 && (int)__popc(mask) == N - 2;
+    ok = ok && (mask & ~seen) == 0 && !((seen >> (ok ? L : 0)) & 1u) && (seen >> N) == 0;
+    kp_fp_add(f, (uint32_t)i);
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      ok = ok && rkq[u][r] >= 0 && rkq[u][r] < a.m;
+      kp_fp_add(f + 2 + 2 * r, (uint32_t)rkq[u][r]);
     }
-#pragma unroll
-    for (int u = 0; u < MB; ++u) {
-      const int i = first + (j0 + u) * 256 + threadIdx.x;
-      if (i >= a.m) continue;
-      const int L = Lq[u], k = kq[u], x = xq[u];
-      const unsigned mask = mq[u], seen = sq[u];
-      const int is_set = tq[u] ? 1 : 0;
-      bool ok = L >= 0 && L < N && x >= 0 && k >= 0 && k < a.B;
-      ok = ok && !((mask >> (ok ? L : 0)) & 1u) && (mask >> N) == 0 && (int)__popc(mask) == N - 2;
-      ok = ok && (mask & ~seen) == 0 && !((seen >> (ok ? L : 0)) & 1u) && (seen >> N) == 0;
-      f[0] += kp_mix((unsigned long long)i + 0x9E3779B97F4A7C15ull), f[1] += kp_mix((unsigned long long)i ^ 0xD1B54A32D192ED03ull);
-#pragma unroll
-      for (int r = 0; r < N; ++r) {
-        ok = ok && rkq[u][r] >= 0 && rkq[u][r] < a.m;
-        f[2 + 2 * r] += kp_mix((unsigned long long)(unsigned)rkq[u][r] + 0x9E3779B97F4A7C15ull);
-        f[3 + 2 * r] += kp_mix((unsigned long long)(unsigned)rkq[u][r] ^ 0xD1B54A32D192ED03ull);
+    if (ok && st.num_instances > 0) {
+      // this tick-at-once form covers handlePreAccept's `cmdLog.get(instance) == None` branch only: an instance a
+      // participating replica already knows is rejected (nothing of the tick is applied)
+      ok = x < st.num_instances;
+      const unsigned part = seen | (1u << L);
+      for (int r = 0; ok && r < N; ++r)
+        if (((part >> r) & 1u) && st.cl_status[((size_t)r * N + L) * st.num_instances + x] != CL_NONE) ok = false;
+    }
+    if (!ok) {
+      epx_report(st.status, FPX_EINVAL, i);
+      continue;
+    }
+    const uint32_t pos = goff[k] + atomicAdd(&cnt[k], 1u);
+    if (pos >= (uint32_t)(k + 1) * (uint32_t)a.tc) continue;  // past the key's segment: the tick goes the first form's way
+    uint32_t w[T::NI];
+    kp_pack<N>(w, i, x, L, is_set, mask, seen, rkq[u]);
+    uint32_t* rec = a.recs + (size_t)pos * T::NI;
+    if constexpr (T::NI == 6) {  // 24 bytes at an 8-byte boundary: 16 + 8 or 8 + 16
+      if (pos & 1u) {
+        *reinterpret_cast<uint2*>(rec) = make_uint2(w[0], w[1]);
+        *reinterpret_cast<uint4*>(rec + 2) = make_uint4(w[2], w[3], w[4], w[5]);
+      } else {
+        *reinterpret_cast<uint4*>(rec) = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint2*>(rec + 4) = make_uint2(w[4], w[5]);
       }
-      if (ok && st.num_instances > 0) {
-        // this tick-at-once form covers handlePreAccept's `cmdLog.get(instance) == None` branch only: an instance a
-        // participating replica already knows is rejected (nothing of the tick is applied)
-        ok = x < st.num_instances;
-        const unsigned part = seen | (1u << L);
-        for (int r = 0; ok && r < N; ++r)
-          if (((part >> r) & 1u) && st.cl_status[((size_t)r * N + L) * st.num_instances + x] != CL_NONE) ok = false;
-      }
-      if (!ok) {
-        epx_report(st.status, FPX_EINVAL, i);
-        continue;
-      }
-      const uint32_t pos = goff[k] + atomicAdd(&cnt[k], 1u);
-      int4* rec = reinterpret_cast<int4*>(a.recs + (size_t)pos * T::NI);
-      int w[T::NI];
+    } else {
 #pragma unroll
-      for (int q = 0; q < T::NI; ++q) w[q] = 0;
-      w[0] = i, w[1] = x, w[2] = kp_flags(L, is_set, mask, seen);
-#pragma unroll
-      for (int r = 0; r < N; ++r) w[3 + r] = rkq[u][r];
-#pragma unroll
-      for (int q = 0; q < T::NI / 4; ++q) rec[q] = make_int4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+      for (int q = 0; q < T::NI / 4; ++q) reinterpret_cast<uint4*>(rec)[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
     }
   }
   // the fingerprints: wavefront sums, then one 64-bit atomic per workgroup and word
@@ -276,8 +305,11 @@ __global__ void __launch_bounds__(256) k_kp_scatter(const EpxState st, const Epx
     if (lane == 0) fsum[wv][q] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 2 * (N + 1))
-    atomicAdd(&a.fp[threadIdx.x], fsum[0][threadIdx.x] + fsum[1][threadIdx.x] + fsum[2][threadIdx.x] + fsum[3][threadIdx.x]);
+  if (threadIdx.x < 2 * (N + 1)) {
+    unsigned long long v = 0;
+    for (int q = 0; q < KP_ST / 64; ++q) v += fsum[q][threadIdx.x];
+    atomicAdd(&a.fp[threadIdx.x], v);
+  }
 }
 
 // LOG: the command log is kept (its own instantiation: the extra pass costs registers the plain tick must not pay for)
@@ -285,23 +317,30 @@ template <int N, bool LOG>
 __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState st, const EpxBatch b, const KpArgs a) {
   using T = KpTile<N>;
   extern __shared__ __align__(16) unsigned char kp_smem[];
-  int* recs = reinterpret_cast<int*>(kp_smem);                                 // [NI][TC] field-major: i, number, flags, rank[N]
+  int* recs = reinterpret_cast<int*>(kp_smem);                                 // [3][TC] field-major: i, number, flags
 #define RF(f, sl) recs[(f) * T::TC + (sl)]
-  unsigned char* region = reinterpret_cast<unsigned char*>(recs + (size_t)T::TC * T::NI);
+  unsigned char* region = kp_smem + T::META_BYTES;
   uint32_t* sortA = reinterpret_cast<uint32_t*>(region);                        // [N][TC]
   uint32_t* sortB = sortA + (size_t)N * T::TC;                                  // [N][TC]
   uint32_t* bk = sortB + (size_t)N * T::TC;                                     // [N][NBK] rank buckets
   int* rows = reinterpret_cast<int*>(region);                                   // [TC][N - 1][N] (after the sort)
   uint32_t* rcnt = reinterpret_cast<uint32_t*>(region + T::R_BYTES);            // [N][W][128]
   uint32_t* rcur = rcnt + N * T::W * KP_RADIX;                                  // [N][W][128]
-  int* tot = reinterpret_cast<int*>(rcur + N * T::W * KP_RADIX);                // [N][W][2N]
+  int* tot = reinterpret_cast<int*>(rcur + N * T::W * KP_RADIX);                // [N][W][2N] puts of a wavefront's part: gets, sets
   int* cntr = tot + N * T::W * 2 * N;                                           // [N] participants of replica r
   int* rmin = cntr + N;                                                         // [N] smallest / largest rank among them
   int* rmax = rmin + N;
   int* degenerate = rmax + N;                                                   // a rank bucket is too full: radix sort
   int* base = degenerate + 1;                                                   // [N][2N] the replicas' TopOne vectors of the key
-  if (st.status[0] != 0) return;
-  if (a.ctl[1] != 0) return;  // a key does not fit the tables: the host sends the whole tick the first form's way
+  // a tick that is not applied (an error, a key beyond the tables, ranks that are no permutation) still has to leave
+  // the claim counters at zero for the next one
+  auto give_up = [&]() {
+    for (int k = blockIdx.x * T::THREADS + threadIdx.x; k < a.B; k += gridDim.x * T::THREADS) a.tot[(size_t)k * KP_TOT_STRIDE] = 0;
+  };
+  if (st.status[0] != 0 || a.ctl[0] != 0) {  // ctl[0]: a key does not fit the tables, the host sends the whole tick the first form's way
+    give_up();
+    return;
+  }
   // a rank row is a permutation of 0..m-1 iff (values are in range, checked by k_kp_scatter, and) its multiset of
   // values is that of the indices: compared through two additive 64-bit fingerprints of independently mixed values
   {
@@ -309,6 +348,7 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
     for (int r = 0; r < N; ++r) bad = bad || a.fp[2 + 2 * r] != a.fp[0] || a.fp[3 + 2 * r] != a.fp[1];
     if (bad) {
       if (threadIdx.x == 0 && blockIdx.x == 0) epx_report(st.status, FPX_EINVAL, -1);
+      give_up();
       return;
     }
   }
@@ -316,25 +356,34 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
   const int r = wave / T::W, w = wave - r * T::W;
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   int rank_bits = 1;
-  while ((1 << rank_bits) < a.m) ++rank_bits;
-#ifdef KP_X_NOSORT
-  const int passes = 0;
-#else
+  while ((1 << rank_bits) <= a.m) ++rank_bits;  // 2^rank_bits > m: no rank is all ones in the bits the radix passes look at
   const int passes = (rank_bits + KP_RADIX_BITS - 1) / KP_RADIX_BITS;
-#endif
 
   struct Next {
-    int lo, len;
-    int4 q[T::RQ];
+    int len;
+    uint32_t q[T::RQ][T::NI];
   };
   auto fetch = [&](int k, Next& s) {
-    s.lo = a.seg[(size_t)k * 2], s.len = a.seg[(size_t)k * 2 + 1];
-    const int4* src = reinterpret_cast<const int4*>(a.recs + (size_t)s.lo * T::NI);
-    const int total = s.len * (T::NI / 4);
+    s.len = min((int)a.tot[(size_t)k * KP_TOT_STRIDE], T::TC);
+    const uint32_t* src = a.recs + (size_t)k * T::TC * T::NI;
 #pragma unroll
     for (int j = 0; j < T::RQ; ++j) {
-      const int p = j * T::THREADS + threadIdx.x;
-      s.q[j] = p < total ? src[p] : make_int4(0, 0, 0, 0);
+      const int sl = j * T::THREADS + threadIdx.x;
+      if (sl < s.len) {
+        if constexpr (T::NI == 6) {
+#pragma unroll
+          for (int h = 0; h < 3; ++h) {
+            const uint2 v = reinterpret_cast<const uint2*>(src + (size_t)sl * 6)[h];
+            s.q[j][2 * h] = v.x, s.q[j][2 * h + 1] = v.y;
+          }
+        } else {
+#pragma unroll
+          for (int h = 0; h < T::NI / 4; ++h) {
+            const uint4 v = reinterpret_cast<const uint4*>(src + (size_t)sl * T::NI)[h];
+            s.q[j][4 * h] = v.x, s.q[j][4 * h + 1] = v.y, s.q[j][4 * h + 2] = v.z, s.q[j][4 * h + 3] = v.w;
+          }
+        }
+      }
     }
   };
 
@@ -343,21 +392,35 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
   if (k >= st.num_keys) return;
   fetch(k, cur);
   for (; k < st.num_keys; k += gridDim.x) {
-    const int c = cur.len;  // <= TC: the kernel does not run otherwise
+    const int c = cur.len;  // <= TC
+    const int cpad = (c + 63) & ~63;
     int carry_in = 0;
-    // ---- the records, the counters
+    // ---- the records: i, number, flags field-major; per replica the command's sort word rank << 11 | slot at the
+    // command's slot, ~0 where the replica takes no part (they sort last and are not counted)
     {
-      const int total = c * (T::NI / 4);
+      int lo[N], hi[N];
+#pragma unroll
+      for (int q = 0; q < N; ++q) lo[q] = 0x7fffffff, hi[q] = 0;
 #pragma unroll
       for (int j = 0; j < T::RQ; ++j) {
-        const int p = j * T::THREADS + threadIdx.x;
-        if (p < total) {  // int4 p = fields 4 h .. 4 h + 3 of record sl; field-major in LDS (a record-major table is read
-                          // with a stride of NI words: 8 lanes per bank)
-          const int sl = p / (T::NI / 4), h = p - sl * (T::NI / 4);
-          RF(4 * h, sl) = cur.q[j].x, RF(4 * h + 1, sl) = cur.q[j].y, RF(4 * h + 2, sl) = cur.q[j].z, RF(4 * h + 3, sl) = cur.q[j].w;
+        const int sl = j * T::THREADS + threadIdx.x;
+        if (sl < c) {
+          int i, x, fl, rk[N];
+          kp_unpack<N>(cur.q[j], &i, &x, &fl, rk);
+          RF(0, sl) = i, RF(1, sl) = x, RF(2, sl) = fl;
+          const unsigned part = (((unsigned)fl >> 16) & 0xffu) | (1u << (fl & 7));
+#pragma unroll
+          for (int q = 0; q < N; ++q) {
+            const bool in = (part >> q) & 1u;
+            sortA[(size_t)q * T::TC + sl] = in ? (((uint32_t)rk[q] << KP_SLOT_BITS) | (uint32_t)sl) : KP_INVALID;
+            lo[q] = in ? min(lo[q], rk[q]) : lo[q], hi[q] = in ? imax(hi[q], rk[q]) : hi[q];
+          }
+        } else if (sl < cpad) {
+#pragma unroll
+          for (int q = 0; q < N; ++q) sortA[(size_t)q * T::TC + sl] = KP_INVALID;
         }
       }
-      for (int j = threadIdx.x; j < N * T::W * 2 * N + N; j += T::THREADS) tot[j] = 0;  // tot and cntr
+      for (int j = threadIdx.x; j < N * T::W * 2 * N; j += T::THREADS) tot[j] = 0;
       for (int j = threadIdx.x; j < N * T::NBK; j += T::THREADS) bk[j] = 0;
       if (threadIdx.x < N) rmin[threadIdx.x] = 0x7fffffff, rmax[threadIdx.x] = 0;
       if (threadIdx.x == 0) *degenerate = 0;
@@ -367,66 +430,48 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
         const size_t ib = ((size_t)r * st.num_keys + k) * N;
         carry_in = lane < N ? st.gets[ib + lane] : st.sets[ib + lane - N];
       }
+      __syncthreads();  // rmin / rmax are reset (the barrier at the end of the previous key is not enough: they were read after it)
+      // the spread of every replica's ranks: wavefront reductions on the DPP network, then one LDS atomic per wavefront
+#pragma unroll
+      for (int q = 0; q < N; ++q) {
+        const int mx = __builtin_amdgcn_readlane(wave_incl_max(hi[q]), 63);
+        const int mn = 0x7fffffff - __builtin_amdgcn_readlane(wave_incl_max(0x7fffffff - lo[q]), 63);
+        if (lane == 0 && mn <= mx) atomicMin(&rmin[q], mn), atomicMax(&rmax[q], mx);
+      }
     }
     const int kn = k + gridDim.x;
     const bool more = kn < st.num_keys;
     __syncthreads();
-    // ---- per replica: (rank << 11 | slot) of the commands it takes part in, compacted with one counter bump per
-    // wavefront and 64 slots
-    for (int base = w * 64; base < c; base += T::W * 64) {
-      const int j = base + lane;
-      bool part = false;
-      uint32_t code = 0;
-      if (j < c) {
-        const int fl = RF(2, j);
-        const int L = fl & 7;
-        part = r == L || ((fl >> (16 + r)) & 1);
-        code = ((uint32_t)RF(3 + r, j) << KP_SLOT_BITS) | (uint32_t)j;
-      }
-      const unsigned long long bal = __ballot(part);
-      if (bal) {
-        int at = 0;
-        if (lane == 0) at = atomicAdd(&cntr[r], (int)__popcll(bal));
-        at = __builtin_amdgcn_readfirstlane(at);
-        if (part) sortA[(size_t)r * T::TC + at + (int)__popcll(bal & lt)] = code;
-        int lo = part ? (int)(code >> KP_SLOT_BITS) : 0x7fffffff, hi = part ? (int)(code >> KP_SLOT_BITS) : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) lo = min(lo, __shfl_xor(lo, o)), hi = imax(hi, __shfl_xor(hi, o));
-        if (lane == 0) atomicMin(&rmin[r], lo), atomicMax(&rmax[r], hi);
-      }
-    }
-    __syncthreads();
-    const int cr = cntr[r];
-    const int per = ((cr + T::W * 64 - 1) / (T::W * 64)) * 64;  // elements of one wavefront's part
-    const int p0 = w * per, p1 = min(cr, p0 + per);
-    // ---- the replica's words in rank order.  Bucket sort: the ranks of one key spread over [rmin, rmax]; NBK buckets
-    // of equal width hold about one word each, a word's place is its bucket's start + the words of the bucket below
-    // it (found by looking at them: buckets are tiny) -- 4 LDS round trips per word where an LSD radix sort of the
-    // 21 rank bits takes 3 passes of ~90 instructions per 64 words.  Ranks that clump (a bucket with more than
-    // KP_MAX_OCC words) send the key through the radix sort below instead: any order of ranks is sorted correctly.
+    // ---- the replica's words in rank order.  A wavefront owns a run of slots.  Bucket sort: the ranks of one key
+    // spread over [rmin, rmax]; NBK buckets of equal width hold about one word each, a word's place is its bucket's
+    // start + the words of the bucket below it (found by looking at them: buckets are tiny) -- 4 LDS round trips per
+    // word where an LSD radix sort of the 21 rank bits takes 3 passes of ~90 instructions per 64 words.  Ranks that
+    // clump (a bucket with more than KP_MAX_OCC words) send the key through the radix sort below instead: any order of
+    // ranks is sorted correctly.
+    const int per = ((cpad / 64 + T::W - 1) / T::W) * 64;  // slots of one wavefront's run
+    const int p0 = min(cpad, w * per), p1 = min(cpad, p0 + per);
     uint32_t* src = sortA + (size_t)r * T::TC;
     uint32_t* dst = sortB + (size_t)r * T::TC;
     uint32_t* mycnt = rcnt + (r * T::W + w) * KP_RADIX;
     uint32_t* mycur = rcur + (r * T::W + w) * KP_RADIX;
     int sort_passes = passes;
-#if !defined(KP_X_RADIX_ONLY) && !defined(KP_X_NOSORT)
     {
       uint32_t* bkr = bk + r * T::NBK;
       const int lo = rmin[r];
-      const unsigned span1 = cr > 0 ? (unsigned)(rmax[r] - lo) : 0u;  // span - 1
+      const unsigned span1 = rmax[r] >= lo ? (unsigned)(rmax[r] - lo) : 0u;  // span - 1
       constexpr int LOG_NBK = T::NBK == 1024 ? 10 : 9;
       const int sh = max(0, (32 - __clz((int)span1 | 1)) - LOG_NBK);   // (span - 1) >> sh < NBK
       uint32_t ec[T::CPW], eq[T::CPW], ea[T::CPW];
 #pragma unroll
       for (int cc = 0; cc < T::CPW; ++cc) {
         const int p = p0 + cc * 64 + lane;
-        ec[cc] = 0xffffffffu, eq[cc] = 0, ea[cc] = 0;
-        if (p < p1) {
-          ec[cc] = src[p];
+        ec[cc] = p < p1 ? src[p] : KP_INVALID, eq[cc] = 0, ea[cc] = 0;
+        if (ec[cc] != KP_INVALID) {
           eq[cc] = (uint32_t)((int)(ec[cc] >> KP_SLOT_BITS) - lo) >> sh;
           ea[cc] = atomicAdd(&bkr[eq[cc]], 1u);
         }
       }
+      if (w == 0 && lane < 2 * N) base[r * 2 * N + lane] = carry_in;
       __syncthreads();
       if (w == 0) {  // bucket counts -> bucket starts, by one wavefront per replica: NBK / 64 consecutive buckets per lane
         constexpr int PL = T::NBK / 64;
@@ -434,30 +479,38 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
 #pragma unroll
         for (int j = 0; j < PL; ++j) v[j] = bkr[lane * PL + j], sum += v[j], big = max(big, v[j]);
         uint32_t run = kp_wave_excl_sum(sum);
+        if (lane == 63) cntr[r] = (int)(run + sum);
 #pragma unroll
         for (int j = 0; j < PL; ++j) bkr[lane * PL + j] = run, run += v[j];
         if (big > (uint32_t)KP_MAX_OCC) *degenerate = 1;
       }
       __syncthreads();
       if (*degenerate == 0) {
+        const uint32_t crr = (uint32_t)cntr[r];
+        const int perq = max(64, (((int)crr + T::W * 64 - 1) / (T::W * 64)) * 64);  // words of one wavefront's run in the scans
 #pragma unroll
         for (int cc = 0; cc < T::CPW; ++cc)
-          if (ec[cc] != 0xffffffffu) dst[bkr[eq[cc]] + ea[cc]] = ec[cc];
+          if (ec[cc] != KP_INVALID) dst[bkr[eq[cc]] + ea[cc]] = ec[cc];
         __syncthreads();
 #pragma unroll
         for (int cc = 0; cc < T::CPW; ++cc)
-          if (ec[cc] != 0xffffffffu) {
-            const uint32_t s0 = bkr[eq[cc]], s1 = eq[cc] + 1 < (uint32_t)T::NBK ? bkr[eq[cc] + 1] : (uint32_t)cr;
+          if (ec[cc] != KP_INVALID) {
+            const uint32_t s0 = bkr[eq[cc]], s1 = eq[cc] + 1 < (uint32_t)T::NBK ? bkr[eq[cc] + 1] : crr;
             uint32_t below = 0;
             for (uint32_t j = s0; j < s1; ++j) below += dst[j] < ec[cc] ? 1u : 0u;
             src[s0 + below] = ec[cc];
+            // the word's place is known: its put (per column the largest id + 1) is part of the carry of the runs
+            // behind the one it lands in
+            const int sl = (int)(ec[cc] & KP_SLOT_MASK);
+            const int fl = RF(2, sl);
+            atomicMax(&tot[(r * T::W + (int)((s0 + below) / (uint32_t)perq)) * 2 * N + ((fl >> 3) & 1) * N + (fl & 7)], RF(1, sl) + 1);
           }
         __syncthreads();
         sort_passes = 0;  // sorted, in sortA
       }
     }
-#endif
-    // ---- LSD radix sort of the replica's words on the rank bits, in LDS
+    // ---- LSD radix sort of the replica's words on the rank bits, in LDS (the words the replica has no part in are
+    // all ones: they stay behind the others)
     for (int pass = 0; pass < sort_passes; ++pass) {
       const int shift = KP_SLOT_BITS + pass * KP_RADIX_BITS;
       mycnt[lane] = 0, mycnt[lane + 64] = 0;
@@ -500,25 +553,31 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
       uint32_t* t = src;
       src = dst, dst = t;
     }
-    // ---- the sorted words of this wavefront's part -> registers (the buffers are reused below); the puts of the
-    // part (per column the largest id + 1) are the carry of the parts behind it
+    // ---- the scans.  The replica's cr sorted words are split into runs of whole chunks, one per wavefront; the puts of
+    // the runs before a wavefront's own are its carry (learnt where the sort placed the words; after the radix sort, here)
+    const int cr = cntr[r];
+    const int perq = max(64, ((cr + T::W * 64 - 1) / (T::W * 64)) * 64);
+    const int q0 = w * perq, q1 = min(cr, q0 + perq);
     uint32_t code[T::CPW];
-    int* mytot = tot + (r * T::W + w) * 2 * N;
 #pragma unroll
     for (int cc = 0; cc < T::CPW; ++cc) {
-      const int p = p0 + cc * 64 + lane;
-      code[cc] = p < p1 ? src[p] : 0xffffffffu;
-      if (p < p1) {
-        const int sl = (int)(code[cc] & KP_SLOT_MASK);
-        const int fl = RF(2, sl);
-        atomicMax(&mytot[((fl >> 3) & 1) * N + (fl & 7)], RF(1, sl) + 1);
-      }
+      const int p = q0 + cc * 64 + lane;
+      code[cc] = p < q1 ? src[p] : KP_INVALID;
     }
-    if (w == 0 && lane < 2 * N) base[r * 2 * N + lane] = carry_in;
-    __syncthreads();
-    // ---- the segmented scans (the sort buffers are spent: their place takes the conflict rows).  Row n-2 of a command
-    // is its leader's own conflicts D (the PreAccept's dependencies), rows 0 .. n-3 those of the replicas whose
-    // answers the leader counts, in replica order
+    if (sort_passes > 0) {
+      int* mytot = tot + (r * T::W + w) * 2 * N;
+#pragma unroll
+      for (int cc = 0; cc < T::CPW; ++cc)
+        if (code[cc] != KP_INVALID) {
+          const int sl = (int)(code[cc] & KP_SLOT_MASK);
+          const int fl = RF(2, sl);
+          atomicMax(&mytot[((fl >> 3) & 1) * N + (fl & 7)], RF(1, sl) + 1);
+        }
+      __syncthreads();
+    }
+    // (the sort buffers are spent once every wavefront holds its words: their place takes the conflict rows.)  Row n-2
+    // of a command is its leader's own conflicts D (the PreAccept's dependencies), rows 0 .. n-3 those of the replicas
+    // whose answers the leader counts, in replica order
     {
       int cg[N], cs[N], ng[N], ns[N];
 #pragma unroll
@@ -528,20 +587,20 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
 #pragma unroll
         for (int l = 0; l < N; ++l) cg[l] = imax(cg[l], o[l]), cs[l] = imax(cs[l], o[N + l]);
       }
+      bool first = true;
 #pragma unroll
       for (int cc = 0; cc < T::CPW; ++cc) {
-        const bool valid = code[cc] != 0xffffffffu;
+        const bool valid = code[cc] != KP_INVALID;
         const int sl = valid ? (int)(code[cc] & KP_SLOT_MASK) : 0;
         const int fl = valid ? RF(2, sl) : 0;
         const int id1 = valid ? RF(1, sl) + 1 : 0;  // TopOne.put: max(.., id + 1), util/TopOne.scala:12-15
         const int L = fl & 7;
         int dep[N];
-#ifndef KP_X_NOSCAN
-        if (p0 + cc * 64 < p1)
-#else
-        if (p0 + cc * 64 < -1)
-#endif
-          scan_chunk<N>(valid, (fl >> 3) & 1, L, id1, cg, cs, ng, ns, dep);
+        if (q0 + cc * 64 < q1) scan_chunk<N>(valid, (fl >> 3) & 1, L, id1, cg, cs, ng, ns, dep);
+        if (first) {  // the rows go where the sorted words were: every wavefront of the workgroup must hold its own first
+          __syncthreads();
+          first = false;
+        }
         const unsigned resp = ((unsigned)fl >> 8) & 0xffu;
         if (valid && (L == r || ((resp >> r) & 1u))) {
           const int ri = L == r ? N - 2 : (int)__popc(resp & ((1u << r) - 1u));
@@ -575,10 +634,6 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
         od[l] = hi, ol[l] = dl;
         if (l == L) raw_hi = hi, raw_d = dl, own_column(hi, x, &od[l], &oe0), own_column(dl, x, &ol[l], &oe1);
       }
-#ifdef KP_X_NOOUT
-      if (fast && x == -12345) b.fast[i] = 1;
-      continue;
-#endif
       if (a.packed) {
         // the packed line takes the place of the command's conflict rows (read above) and leaves below, four lanes
         // per 64-byte line: a store instruction then covers 16 whole lines instead of 16 bytes of 64 different ones
@@ -643,13 +698,13 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
         }
 #pragma unroll
         for (int cc = 0; cc < T::CPW; ++cc) {
-          const bool valid = code[cc] != 0xffffffffu;
+          const bool valid = code[cc] != KP_INVALID;
           const int sl = valid ? (int)(code[cc] & KP_SLOT_MASK) : 0;
           const int fl = valid ? RF(2, sl) : 0;
           const int x = valid ? RF(1, sl) : 0;
           const int L = fl & 7;
-          int dep[N];
-          if (p0 + cc * 64 < p1) scan_chunk<N>(valid, (fl >> 3) & 1, L, x + 1, cg, cs, ng, ns, dep);
+          int dep2[N];
+          if (q0 + cc * 64 < q1) scan_chunk<N>(valid, (fl >> 3) & 1, L, x + 1, cg, cs, ng, ns, dep2);
           if (!valid) continue;
           const unsigned seen = (((unsigned)fl >> 16) & 0xffu) | (1u << L);
           const int* o = rows + (size_t)sl * T::RSTR;
@@ -667,7 +722,7 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
           } else {
 #pragma unroll
             for (int l = 0; l < N; ++l) {
-              const int v = imax(dep[l], l == L ? o[2 * N + 7] : o[N + l]);
+              const int v = imax(dep2[l], l == L ? o[2 * N + 7] : o[N + l]);
               t[l] = v;
               if (l == L) own_column(v, x, &t[l], &end);
             }
@@ -694,6 +749,7 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
       int32_t* p = lane < N ? &st.gets[ib + lane] : &st.sets[ib + lane - N];
       if (v > base[r * 2 * N + lane]) *p = v;
     }
+    if (threadIdx.x == 0) a.tot[(size_t)k * KP_TOT_STRIDE] = 0;  // the next tick claims from zero
     __syncthreads();  // the tables are reused by the next key
     cur = nxt;
   }
