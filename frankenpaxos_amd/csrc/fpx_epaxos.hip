@@ -1469,24 +1469,28 @@ int launch_kp(fpx_epx* e, const EpxBatch& b, int32_t* d_packed, bool* done) {
   memset(&a, 0, sizeof(a));
   a.m = b.m, a.tiles = (b.m + KP_TILE - 1) / KP_TILE, a.B = e->st.num_keys;
   a.groups = (a.tiles + KP_HG - 1) / KP_HG;
+  a.seq = ++e->kp_seq;
   int rc;
   if ((rc = grow(e, &e->kp_hist, (size_t)a.tiles * a.B * 2))) return rc;
   if ((rc = grow(e, &e->kp_recs, (size_t)a.B * T::TC * T::NI * 4))) return rc;
   {
-    // fingerprints, control word, one word per group of tiles (m < 2^21: at most 128 groups), then the claim counters
-    // (one 64-byte sector per key): they must read zero before the first tick, later the key kernel leaves them at zero
+    // fingerprints, control and verdict words, one word per group of tiles (m < 2^21: at most 128 groups), then the claim
+    // counters (one 64-byte sector per key): they must read zero before the first tick, later the key kernel leaves
+    // them at zero
     const size_t need = 1024 + (size_t)a.B * KP_TOT_STRIDE * 4;
     if (need > e->kp_misc.cap) {
       if ((rc = grow(e, &e->kp_misc, need))) return rc;
       EHIP(e, hipMemsetAsync(e->kp_misc.p, 0, e->kp_misc.cap, e->stream));
     }
   }
+  char* misc = (char*)e->kp_misc.p;
   a.hist = (uint16_t*)e->kp_hist.p, a.recs = (uint32_t*)e->kp_recs.p;
-  a.fp = (unsigned long long*)e->kp_misc.p;              // 16 words of 8 bytes
-  a.ctl = (uint32_t*)((char*)e->kp_misc.p + 128);        // 1 word
-  a.big = (uint32_t*)((char*)e->kp_misc.p + 512);        // [groups <= 128]
-  a.tot = (uint32_t*)((char*)e->kp_misc.p + 1024);
-  a.host_flag = e->kp_flag_dev, a.seq = ++e->kp_seq, a.tc = T::TC;
+  a.fp = (unsigned long long*)misc;              // 16 words of 8 bytes
+  a.ctl = (uint32_t*)(misc + 128);               // 1 word
+  a.bad = (uint32_t*)(misc + 192);               // 2 words
+  a.big = (uint32_t*)(misc + 512);               // [groups <= 128]
+  a.tot = (uint32_t*)(misc + 1024);
+  a.host_flag = e->kp_flag_dev, a.tc = T::TC;
   a.packed = d_packed, a.stride = fpx_epx_packed_stride(N);
   if (!e->kp_lds_allowed) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_epx_key2<N, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1497,8 +1501,12 @@ int launch_kp(fpx_epx* e, const EpxBatch& b, int32_t* d_packed, bool* done) {
                               KP_HG * KP_MAXB * 4);
     e->kp_lds_allowed = true;
   }
-  hipLaunchKernelGGL(k_kp_hist, dim3(a.groups), dim3(128 * KP_HG), (size_t)KP_HG * a.B * 4, e->stream, e->st, b, a);
-  hipLaunchKernelGGL((k_kp_scatter<N>), dim3(8 * ((a.tiles + 7) / 8)), dim3(KP_ST), 0, e->stream, e->st, b, a);
+  // (Round 4 tried the partition of tick t + 1 on a stream of its own beside the key kernel of tick t: the key kernel's
+  // 15 wavefronts of 128 registers fill the register files of three of a CU's four SIMDs, no partition workgroup finds
+  // room beside it, and the two event hops between the streams cost 15 us per tick -- 0.125 ms against 0.119 in order.)
+  hipStream_t ps = e->stream;
+  hipLaunchKernelGGL(k_kp_hist, dim3(a.groups), dim3(128 * KP_HG), (size_t)KP_HG * a.B * 4, ps, e->st, b, a);
+  hipLaunchKernelGGL((k_kp_scatter<N>), dim3(8 * ((a.tiles + 7) / 8)), dim3(KP_ST), 0, ps, e->st, b, a);
   // k_epx_key2 is enqueued at once -- it returns at its first instruction when a key does not fit -- and the host then
   // learns, while the GPU works on, whether the first form has to take the tick after all (launching the kernel
   // only after the answer left the GPU idle for ~30 us per tick when ticks were enqueued back to back)
@@ -1511,10 +1519,10 @@ int launch_kp(fpx_epx* e, const EpxBatch& b, int32_t* d_packed, bool* done) {
   bool seen = false;
   for (long spin = 0; spin < 200000000L; ++spin) {
     if (flag[0] == a.seq) { seen = true; break; }
-    if ((spin & 0xffff) == 0xffff && hipStreamQuery(e->stream) != hipErrorNotReady) break;  // finished, or failed
+    if ((spin & 0xffff) == 0xffff && hipStreamQuery(ps) != hipErrorNotReady) break;  // finished, or failed
   }
   if (!seen) {
-    EHIP(e, hipStreamSynchronize(e->stream));
+    EHIP(e, hipStreamSynchronize(ps));
     if (flag[0] != a.seq) return FPX_EHIP;
   }
   if (flag[1] != 0) return FPX_OK;  // a hot key: the first form takes the whole tick
@@ -1589,7 +1597,7 @@ int32_t fpx_epx_create(const fpx_epx_config* cfg, fpx_epx** out) {
     if (hipMemsetAsync(e->st.cl_triple, 0xFF, ce * 4, e->stream) != hipSuccess) return fail(FPX_EHIP);
     if (hipMemsetAsync(e->st.cl_stamp, 0, (size_t)n * cfg->num_instances * 4, e->stream) != hipSuccess) return fail(FPX_EHIP);
   }
-  // the word k_kp_scan tells the host through (how many keys of the tick are too big for the on-chip tables)
+  // the word k_kp_scatter tells the host through (did a key of the tick outgrow the on-chip tables?)
   if (hipHostMalloc((void**)&e->kp_flag, 64, hipHostMallocDefault) == hipSuccess) {
     memset(e->kp_flag, 0, 64);
     if (hipHostGetDevicePointer((void**)&e->kp_flag_dev, e->kp_flag, 0) != hipSuccess) e->kp_flag_dev = nullptr;

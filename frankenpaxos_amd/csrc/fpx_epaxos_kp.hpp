@@ -50,9 +50,9 @@ template <int N> struct KpTile {
   static constexpr int CPW = (MAXC + W - 1) / W;                   // 64-command chunks per wavefront
   static constexpr int NBK = N <= 5 ? 1024 : 512;                  // rank buckets of the bucket sort
   static constexpr int RQ = (TC + THREADS - 1) / THREADS;          // records per thread
-  // LDS: i, number, flags [3][TC] | region R | radix counters + cursors | part totals | misc.  R holds the two sort
-  // buffers and the rank buckets while a key is sorted, then the conflict rows [TC][N - 1][N]: the n-2 counted answers
-  // and the leader's own
+  // LDS: i, number, flags [3][TC] | region R | part totals | misc.  R holds the two sort buffers and the rank buckets
+  // (the radix sort's counters and cursors, when a key's ranks clump) while a key is sorted, then the conflict rows
+  // [TC][N - 1][N]: the n-2 counted answers and the leader's own
   static constexpr size_t META_BYTES = (size_t)3 * TC * 4;
   static constexpr size_t SORT_BYTES = (size_t)2 * N * TC * 4 + (size_t)N * NBK * 4;
   static constexpr int RSTR = (N - 1) * N + 1;  // ints between two commands' conflict rows: odd, so that random commands
@@ -60,9 +60,9 @@ template <int N> struct KpTile {
                                                 // kernel's LDS cycles were bank conflicts)
   static constexpr size_t ROWS_BYTES = (size_t)TC * RSTR * 4;
   static constexpr size_t R_BYTES = SORT_BYTES > ROWS_BYTES ? SORT_BYTES : ROWS_BYTES;
-  static constexpr size_t BYTES = META_BYTES + R_BYTES + (size_t)2 * N * W * KP_RADIX * 4 + (size_t)N * W * 2 * N * 4 + 256 +
-                                  (size_t)N * 2 * N * 4;
+  static constexpr size_t BYTES = META_BYTES + R_BYTES + (size_t)N * W * 2 * N * 4 + 256 + (size_t)N * 2 * N * 4;
   static_assert(BYTES <= 160 * 1024, "LDS of one CU");
+  static_assert((size_t)2 * N * W * KP_RADIX * 4 <= (size_t)N * NBK * 4, "the radix sort's counters take the bucket table's place");
   static_assert(TC <= (1 << KP_SLOT_BITS), "slots share the sort word with the rank");
 };
 
@@ -127,6 +127,9 @@ struct KpArgs {
                                     // kernel clears what it read)
   uint32_t* big;                    // [groups] 1 = a claim of this group of tiles ran past its key's segment
   uint32_t* ctl;                    // [1] groups with such a claim (written by k_kp_scatter, read by the key kernel)
+  uint32_t* bad;                    // [2] {seq of the last tick a partition kernel rejected, index of the message}: the
+                                    // partition of tick t + 1 may run beside the key kernel of tick t, so its verdict
+                                    // must not land in the context's status words before tick t + 1's own turn
   unsigned long long* fp;           // [2 (N + 1)] additive fingerprints: of the indices 0..m-1, then of every rank row
   uint32_t* recs;                   // [B][tc][NI]: a key's segment has room for what the on-chip tables take
   volatile uint32_t* host_flag;     // page-locked: [1] = ctl[1], then [0] = seq
@@ -135,6 +138,11 @@ struct KpArgs {
   int32_t* packed;                  // [m][stride] or null
   int stride;
 };
+
+// the partition kernels' verdict on the tick: first reporter wins (seq grows from tick to tick)
+__device__ __forceinline__ void kp_reject(const KpArgs& a, int index) {
+  if (atomicMax(&a.bad[0], a.seq) < a.seq) a.bad[1] = (uint32_t)index;
+}
 
 // two independent 32-bit mixes of one value (murmur3's finaliser on differently salted inputs): the additive
 // fingerprints are sums of these in 64-bit accumulators.  (Round 3 summed two splitmix64 finalisers: four 64-bit
@@ -184,7 +192,7 @@ __global__ void __launch_bounds__(128 * KP_HG) k_kp_hist(const EpxState st, cons
   for (int j = 0; j < KP_TILE / 128; ++j) {
     const int i = first + j * 128 + t;
     if (tile < a.tiles && i < a.m) {
-      if (k[j] < 0 || k[j] >= a.B) epx_report(st.status, FPX_EINVAL, i);
+      if (k[j] < 0 || k[j] >= a.B) kp_reject(a, i);
       else atomicAdd(&h[k[j]], 1u);
     }
   }
@@ -274,7 +282,7 @@ __global__ void __launch_bounds__(KP_ST) k_kp_scatter(const EpxState st, const E
         if (((part >> r) & 1u) && st.cl_status[((size_t)r * N + L) * st.num_instances + x] != CL_NONE) ok = false;
     }
     if (!ok) {
-      epx_report(st.status, FPX_EINVAL, i);
+      kp_reject(a, i);
       continue;
     }
     const uint32_t pos = goff[k] + atomicAdd(&cnt[k], 1u);
@@ -324,9 +332,9 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
   uint32_t* sortB = sortA + (size_t)N * T::TC;                                  // [N][TC]
   uint32_t* bk = sortB + (size_t)N * T::TC;                                     // [N][NBK] rank buckets
   int* rows = reinterpret_cast<int*>(region);                                   // [TC][N - 1][N] (after the sort)
-  uint32_t* rcnt = reinterpret_cast<uint32_t*>(region + T::R_BYTES);            // [N][W][128]
+  uint32_t* rcnt = bk;                                                          // [N][W][128] (radix sort: the buckets are spent)
   uint32_t* rcur = rcnt + N * T::W * KP_RADIX;                                  // [N][W][128]
-  int* tot = reinterpret_cast<int*>(rcur + N * T::W * KP_RADIX);                // [N][W][2N] puts of a wavefront's part: gets, sets
+  int* tot = reinterpret_cast<int*>(region + T::R_BYTES);                       // [N][W][2N] puts of a wavefront's part: gets, sets
   int* cntr = tot + N * T::W * 2 * N;                                           // [N] participants of replica r
   int* rmin = cntr + N;                                                         // [N] smallest / largest rank among them
   int* rmax = rmin + N;
@@ -337,7 +345,8 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
   auto give_up = [&]() {
     for (int k = blockIdx.x * T::THREADS + threadIdx.x; k < a.B; k += gridDim.x * T::THREADS) a.tot[(size_t)k * KP_TOT_STRIDE] = 0;
   };
-  if (st.status[0] != 0 || a.ctl[0] != 0) {  // ctl[0]: a key does not fit the tables, the host sends the whole tick the first form's way
+  if (st.status[0] != 0 || a.bad[0] == a.seq || a.ctl[0] != 0) {  // ctl[0]: a key does not fit the tables, the host sends the whole tick the first form's way
+    if (st.status[0] == 0 && a.bad[0] == a.seq && threadIdx.x == 0 && blockIdx.x == 0) epx_report(st.status, FPX_EINVAL, (int)a.bad[1]);
     give_up();
     return;
   }
@@ -391,6 +400,8 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
   int k = blockIdx.x;
   if (k >= st.num_keys) return;
   fetch(k, cur);
+  if (threadIdx.x < N) rmin[threadIdx.x] = 0x7fffffff, rmax[threadIdx.x] = 0;
+  __syncthreads();
   for (; k < st.num_keys; k += gridDim.x) {
     const int c = cur.len;  // <= TC
     const int cpad = (c + 63) & ~63;
@@ -422,7 +433,6 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
       }
       for (int j = threadIdx.x; j < N * T::W * 2 * N; j += T::THREADS) tot[j] = 0;
       for (int j = threadIdx.x; j < N * T::NBK; j += T::THREADS) bk[j] = 0;
-      if (threadIdx.x < N) rmin[threadIdx.x] = 0x7fffffff, rmax[threadIdx.x] = 0;
       if (threadIdx.x == 0) *degenerate = 0;
       // the replicas' TopOne vectors of the key (KeyValueStore.scala:229-230), the carries of the scans: requested
       // here, parked in LDS before the scans need them (held in registers across the key they spilled)
@@ -430,13 +440,18 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
         const size_t ib = ((size_t)r * st.num_keys + k) * N;
         carry_in = lane < N ? st.gets[ib + lane] : st.sets[ib + lane - N];
       }
-      __syncthreads();  // rmin / rmax are reset (the barrier at the end of the previous key is not enough: they were read after it)
-      // the spread of every replica's ranks: wavefront reductions on the DPP network, then one LDS atomic per wavefront
+      // the spread of every replica's ranks (rmin / rmax were reset while the previous key was sorted): a reduction over
+      // each row of 16 lanes on the DPP network, then LDS atomics from the rows' last lanes
 #pragma unroll
       for (int q = 0; q < N; ++q) {
-        const int mx = __builtin_amdgcn_readlane(wave_incl_max(hi[q]), 63);
-        const int mn = 0x7fffffff - __builtin_amdgcn_readlane(wave_incl_max(0x7fffffff - lo[q]), 63);
-        if (lane == 0 && mn <= mx) atomicMin(&rmin[q], mn), atomicMax(&rmax[q], mx);
+        if ((int)(threadIdx.x & ~63u) >= c) break;  // (a wavefront without records)
+        int mx = hi[q], mn = 0x7fffffff - lo[q];
+        mx = imax(mx, dpp0<0x111, 0xF>(mx)), mn = imax(mn, dpp0<0x111, 0xF>(mn));
+        mx = imax(mx, dpp0<0x112, 0xF>(mx)), mn = imax(mn, dpp0<0x112, 0xF>(mn));
+        mx = imax(mx, dpp0<0x114, 0xF>(mx)), mn = imax(mn, dpp0<0x114, 0xF>(mn));
+        mx = imax(mx, dpp0<0x118, 0xF>(mx)), mn = imax(mn, dpp0<0x118, 0xF>(mn));
+        mn = 0x7fffffff - mn;
+        if ((lane & 15) == 15 && mn <= mx) atomicMin(&rmin[q], mn), atomicMax(&rmax[q], mx);
       }
     }
     const int kn = k + gridDim.x;
@@ -473,6 +488,7 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
       }
       if (w == 0 && lane < 2 * N) base[r * 2 * N + lane] = carry_in;
       __syncthreads();
+      if (threadIdx.x < N) rmin[threadIdx.x] = 0x7fffffff, rmax[threadIdx.x] = 0;  // (read above by everybody: free for the next key)
       if (w == 0) {  // bucket counts -> bucket starts, by one wavefront per replica: NBK / 64 consecutive buckets per lane
         constexpr int PL = T::NBK / 64;
         uint32_t v[PL], sum = 0, big = 0;
@@ -496,8 +512,18 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
         for (int cc = 0; cc < T::CPW; ++cc)
           if (ec[cc] != KP_INVALID) {
             const uint32_t s0 = bkr[eq[cc]], s1 = eq[cc] + 1 < (uint32_t)T::NBK ? bkr[eq[cc] + 1] : crr;
+            // the first six words of the bucket in flight at once (a bucket holds about one; what lies behind a short
+            // bucket is somebody else's word or the bucket table: read, not counted), a loop only for fuller buckets --
+            // the plain loop was compiled into three nested divergent loops with an LDS round trip each
+            const uint32_t nb = s1 - s0;
             uint32_t below = 0;
-            for (uint32_t j = s0; j < s1; ++j) below += dst[j] < ec[cc] ? 1u : 0u;
+#pragma unroll
+            for (uint32_t j = 0; j < 6; ++j) {
+              const uint32_t v = dst[s0 + j];
+              below += ((j < nb) & (v < ec[cc])) ? 1u : 0u;
+            }
+#pragma nounroll
+            for (uint32_t j = s0 + 6; j < s1; ++j) below += dst[j] < ec[cc] ? 1u : 0u;
             src[s0 + below] = ec[cc];
             // the word's place is known: its put (per column the largest id + 1) is part of the carry of the runs
             // behind the one it lands in

@@ -19,11 +19,12 @@ for t in range(T):
     leader, number, key, is_set, mask, rank = random_tick(rng, n, num_keys, m, nxt, 64.0)
     key = (W.splitmix64_at(np.arange(t * m, (t + 1) * m, dtype=np.uint64)) % np.uint64(num_keys)).astype(np.int32)
     ticks.append([torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (leader, number, key, is_set, mask, rank)])
+torch.cuda.synchronize()
 packed = torch.zeros((m, epx.packed_stride()), dtype=torch.int32, device=dev)
 fast = torch.zeros(m, dtype=torch.uint8, device=dev)
 deps, ldeps = (torch.zeros((m, n), dtype=torch.int32, device=dev) for _ in range(2))
 own = torch.zeros((m, 2), dtype=torch.int32, device=dev)
-for mode in ("packed", "arrays"):
+for mode in os.environ.get("K5_MODES", "packed,arrays").split(","):
     ms = []
     for t in range(T):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -36,4 +37,16 @@ for mode in ("packed", "arrays"):
         torch.cuda.synchronize()
         ms.append(e0.elapsed_time(e1))
     print("%s %s: ms per tick %s  (mean of the last 5: %.4f)" % (sys.argv[1] if len(sys.argv) > 1 else "", mode, " ".join("%.3f" % x for x in ms), float(np.mean(ms[3:]))), flush=True)
-assert epx.sync() == 0
+for mode in os.environ.get("K5_MODES", "packed,arrays").split(","):
+    if mode != "packed":
+        continue
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    R = 5
+    for rep in range(R):
+        for t in range(T):
+            epx.preaccept_packed_dev(*ticks[t], packed)
+    torch.cuda.synchronize()
+    print("%s packed, %d ticks back to back: %.4f ms per tick (wall)" % (sys.argv[1] if len(sys.argv) > 1 else "", R * T, (time.perf_counter() - t0) * 1e3 / (R * T)), flush=True)
+rc = epx.sync()
+assert rc == 0 or "FPX_LIB" in os.environ, rc

@@ -1332,3 +1332,76 @@ def test_config4_size_properties_without_the_oracle(monkeypatch):
             ia, ib, ic = a.read_index(r, k), b.read_index(r, k), c.read_index(r, k)
             assert ia[0].tolist() == ib[0].tolist() == ic[0].tolist()
             assert ia[1].tolist() == ib[1].tolist() == ic[1].tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,num_keys,m", [(5, 64, 20000), (3, 16, 9000), (5, 1024, 60000)])
+def test_epaxos_ticks_queued_back_to_back(oracle, n, num_keys, m):
+    """Six ticks enqueued back to back without a host wait in between (the claim counters, the verdict word and the
+    segments of the partition are reused from tick to tick) == the oracle, tick by tick; then a queue with a malformed
+    tick in the middle: the ticks before it are applied, the tick and everything behind it are not (the status is
+    sticky until fpx_epx_sync)."""
+    import torch
+    import frankenpaxos_amd as fa
+    from frankenpaxos_amd.epaxos import EPaxos
+
+    gpu, ref = EPaxos(n, num_keys), oracle.EPaxos(n, num_keys)
+    rng = np.random.default_rng(n * 77 + num_keys)
+    nxt = [0] * n
+    dev = torch.device("cuda:0")
+    up = lambda args: [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in args]
+    host, devs, outs = [], [], []
+    for tick in range(6):
+        host.append(random_tick(rng, n, num_keys, m - 37 * tick, nxt, 9.0, fifo=tick % 2 == 0))
+        devs.append(up(host[-1]))
+        outs.append(torch.full((m - 37 * tick, gpu.packed_stride()), -7, dtype=torch.int32, device=dev))
+    torch.cuda.synchronize()
+    for t, o in zip(devs, outs):
+        gpu.preaccept_packed_dev(*t, o)
+    assert gpu.sync() == 0
+    for h, o in zip(host, outs):
+        want = ref.preaccept(*h)
+        assert want[0] == 0
+        fast, deps, ldeps, own = (x.cpu().numpy() for x in gpu.unpack(o))
+        np.testing.assert_array_equal(fast, want[1].astype(np.int32))
+        np.testing.assert_array_equal(deps, want[2])
+        np.testing.assert_array_equal(ldeps, want[3])
+        np.testing.assert_array_equal(own, want[4])
+    # a malformed tick (a leader that does not exist) third in a queue of five
+    host, devs, outs = [], [], []
+    keep = None
+    for tick in range(5):
+        args = list(random_tick(rng, n, num_keys, m // 2, nxt, 9.0))
+        if tick == 1:
+            keep = list(nxt)                        # the instance numbers after the last tick that will be applied
+        if tick == 2:
+            args[0] = args[0].copy()
+            args[0][m // 5] = n
+        host.append(args)
+        devs.append(up(args))
+        outs.append(torch.full((m // 2, gpu.packed_stride()), -7, dtype=torch.int32, device=dev))
+    torch.cuda.synchronize()
+    for t, o in zip(devs, outs):
+        gpu.preaccept_packed_dev(*t, o)
+    assert gpu.sync() == fa.FPX_EINVAL
+    for tick in range(5):
+        if tick < 2:
+            want = ref.preaccept(*host[tick])
+            assert want[0] == 0
+            fast, deps, _, _ = (x.cpu().numpy() for x in gpu.unpack(outs[tick]))
+            np.testing.assert_array_equal(fast, want[1].astype(np.int32))
+            np.testing.assert_array_equal(deps, want[2])
+        else:
+            assert bool((outs[tick] == -7).all()), "tick %d behind a rejected one was applied" % tick
+    assert ref.preaccept(*host[2])[0] != 0
+    # the context works on after the sync, from the state two applied ticks left
+    args = random_tick(rng, n, num_keys, 3000, keep, 9.0)
+    a, b = gpu.preaccept(*args), ref.preaccept(*args)
+    assert a[0] == b[0] == 0
+    for x, y in zip(a[1:], b[1:]):
+        np.testing.assert_array_equal(x, y)
+    for r in range(n):
+        for k in range(min(num_keys, 40)):
+            ga, sa = gpu.read_index(r, k)
+            gb, sb = ref.read_index(r, k)
+            assert ga.tolist() == gb.tolist() and sa.tolist() == sb.tolist()
