@@ -69,6 +69,11 @@ def algorithmic_bytes_per_slot(ballot_mode):
     return 8 + 8 * r + 8              # faithful scalar model: reads 8 B/slot (+1 KiB/batch)
 
 
+def read_bytes_per_slot(ballot_mode):
+    """the reads of SURVEY.md 8(d)'s byte model alone: ballot row + proposal (round, value)"""
+    return (4 * REPLICAS + 8) if ballot_mode == 1 else 8
+
+
 def cpu_baseline(ballot_mode, light=False):
     """The CPU oracle (a plain-C, single-threaded port of the reference handlers; the JVM reference
     cannot run here) timed on this box on a bounded sample of the same workload.  light: only the
@@ -285,7 +290,7 @@ def main():
     ap.add_argument("--validate", action="store_true",
                     help="keep the run-contract validation kernel in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", choices=["headline", "2", "3", "4", "5"], default="headline",
+    ap.add_argument("--config", choices=["headline", "2", "3", "4", "5", "thrifty"], default="headline",
                     help="headline = BASELINE.json's metric grid (2^20 slots x 256 acceptors); 2..5 = the other "
                          "BASELINE.json configs as bench lines of the same schema (bench_configs.py)")
     ap.add_argument("--configs-block-steps", type=int, default=5,
@@ -511,7 +516,7 @@ def main():
         ctx.close()
         torch.cuda.empty_cache()
         configs_block = {}
-        for c in ("2", "3", "4", "5"):
+        for c in ("2", "3", "4", "5", "thrifty"):
             t_c = time.perf_counter()
             try:
                 sub = types.SimpleNamespace(steps=args.configs_block_steps, warmup=2, ballot=args.ballot, config=c,
@@ -577,9 +582,17 @@ def main():
                 "bound": "hbm", "kernel": kernel,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                # SURVEY.md 8(d) asks for both accountings: `achieved` counts every algorithmic byte (reads + writes,
+                # 3088 B per slot in the PER_SLOT model); achieved_read only the reads (ballot row + proposal, 1032 B
+                # per slot; 8 B in the ACCEPTOR model) -- two thirds of the bytes are writes, so the read-only figure is
+                # bounded at a third of what the kernel moves
+                "achieved_total": achieved,
+                "achieved_read": (read_bytes_per_slot(ballot_mode) * slots_per_launch / avg_kernel_s / 1e9) if launches else None,
+                "frac_read": (read_bytes_per_slot(ballot_mode) * slots_per_launch / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if launches else None,
                 "traffic": traffic,
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command in an earlier profiled run "
-                                  "(profiles/traffic.json, profiles/r02_pmc_summary.md) -- not measured in this run",
+                                  "(profiles/traffic.json; collection and calibration: profiles/r03_pmc_summary.md) -- not "
+                                  "measured in this run",
                 "algorithmic_bytes_per_slot": bps, "slots_per_launch": slots_per_launch,
                 "avg_kernel_ms": kernel_ms / max(launches, 1), "launches_timed": launches,
                 # what bare streaming kernels reach on this chip (profiles/microbench/hbm_mix.hip, best of the

@@ -5,6 +5,8 @@ roofline with that workload's algorithmic bytes, cpu_baseline from the oracle). 
   2  MultiPaxos f=1, 64k slots x 3 acceptors               fused K3, one step = 65 536 fresh slots
   3  Compartmentalized MultiPaxos, 16 groups of 2x2 grids   fused K3, one step = 2^20 fresh slots (slot % 16 -> group)
   4  EPaxos, 5 replicas                                     K5, one step = one tick of 2^20 fresh commands, 1024 keys
+  thrifty  MultiPaxos, R = 255, f = 127                     fused K3, every Phase2a to a rotating window of f + 1 acceptors (the
+                                                            reference's default delivery, ProxyLeader.scala:190-191)
   5  Mencius, 256 leader groups x 3 acceptors, 4M slots     one step = a band of 2^22 slots: the leader groups that have
                                                             commands propose them (fused K3), the others skip their
                                                             slots with one noop range each (fused K4); N > 1: leader
@@ -106,6 +108,79 @@ def multipaxos_setup(fa, dev, local_rank, ballot_mode, cfg, K, Wm):
                 workload=shapes["name"], kernel="k_phase2 (fused K3)", profile=lambda: ctx.profile_read(),
                 metric="committed log slots/sec (BASELINE.json configs[%d])" % (int(cfg) - 1), cpu=cpu,
                 extra={"slots_per_step": n, "replicas": R, "acceptor_groups": G,
+                       "ballot_model": "per_slot" if ballot_mode == 1 else "acceptor"})
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# thrifty: the reference's DEFAULT delivery -- every Phase2a goes to f + 1 of the group's 2f + 1 acceptors
+# (multipaxos/ProxyLeader.scala:190-191).  R = 255 = 2f + 1 (the reference's legal group size), f = 127; the f + 1 are a
+# window of neighbouring acceptors that rotates from slot to slot in steps of 16 (what jni/Native.scala's
+# GpuProxyLeader sends; any f + 1 will do) -- k_phase2's packed walk, two rows per wavefront step.
+# ------------------------------------------------------------------------------------------------------------------
+def thrifty_setup(fa, dev, local_rank, ballot_mode, K, Wm):
+    n, R, F = 1 << 20, 255, 127
+    windows = K + Wm
+    ctx = fa.Context(fa.make_config(num_slots=windows * n, num_replicas=R, f=F, ballot_mode=ballot_mode, tally_ways=4,
+                                    device=local_rank, flags=fa.FPX_F_TRUSTED))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    assert ctx.acceptor_phase1a(0, 0)[0] == 0
+    ctx.flush_promises()
+    s = torch.arange(n, device=dev)[:, None]
+    j = torch.arange(256, device=dev)[None, :]
+    start = 16 * (s % ((R - (F + 1)) // 16 + 1))
+    bits = ((j >= start) & (j < start + F + 1)).view(-1, 4, 64).to(torch.int64)
+    sh = torch.arange(64, device=dev, dtype=torch.int64)
+    tgt = ((bits[..., :63] << sh[:63]).sum(-1) | (bits[..., 63] << 63)).contiguous()
+    steps = []
+    for w in range(windows):
+        slot = torch.arange(w * n, (w + 1) * n, dtype=torch.int32, device=dev)
+        steps.append((slot, torch.zeros_like(slot), _splitmix_values(slot), torch.zeros(n, dtype=torch.uint8, device=dev),
+                      torch.full((n,), -7, dtype=torch.int32, device=dev), torch.full((n,), -7, dtype=torch.int32, device=dev)))
+
+    def step(i):
+        slot, rnd, val, ch, cr, cv = steps[i]
+        ctx.phase2_fused_dev(slot, rnd, val, tgt, ch, cr, cv)
+
+    def verify(lo, hi):
+        done = 0
+        for i in range(lo, hi):
+            slot, rnd, val, ch, cr, cv = steps[i]
+            assert bool(ch.all()) and bool((cv == val).all()) and bool((cr == 0).all()), "step %d" % i
+            done += int(ch.sum().item())
+        # the votes are where the targets were, nowhere else (one acceptor inside and one outside every window)
+        vr, vv = ctx.read_acceptor(0, 127)[2], ctx.read_acceptor(0, 0)[2]
+        assert bool((np.asarray(vr)[lo * n:hi * n] == 0).all())              # acceptor 127 is in every window
+        first = np.asarray(vv)[lo * n:hi * n].reshape(-1, 8)                 # acceptor 0: only in the windows that start at 0
+        assert bool((first[:, 0] == 0).all()) and bool((first[:, 1:] == -1).all())
+        return done
+
+    # per slot: 128 voters x (voteRound 4 + voteValue 4) written, 32 B target mask + 12 B proposal read, 9 B chosen
+    # record written (VERDICT r03's 1077 B model); PER_SLOT adds the 128 ballots read (4 B each)
+    bps = 128 * 8 + 32 + 12 + 9 + (128 * 4 if ballot_mode == 1 else 0)
+
+    def cpu():
+        from oracle import pyoracle
+        from tests import workloads as W
+        pyoracle.build()
+        S = 1 << 16
+        ref = pyoracle.System(pyoracle.make_config(num_slots=S, num_replicas=R, f=F, ballot_mode=ballot_mode))
+        ref.acceptor_phase1a(0, 0)
+        slot, rnd, val = W.steady_stream(S)
+        t = W.bits_from_bool(W.run_subsets(np.random.default_rng(1), S, R, F + 1, F + 1))
+        t0 = time.perf_counter()
+        out = ref.phase2_fused(slot, rnd, val, t)
+        dt = time.perf_counter() - t0
+        assert out[0] == 0
+        return {"value": S / dt, "unit": "slots/s", "cores": 1, "kind": "port",
+                "sample": "oracle/fpx_oracle.c fpo_phase2_fused with f + 1 target windows, %d slots, 1 thread" % S}
+
+    return dict(ctx=ctx, step=step, verify=verify, units=n, unit="slots/s", bytes_per_unit=bps,
+                workload="MultiPaxos thrifty delivery (the reference's default): fused Phase-2 step, 2^20 fresh slots per step, "
+                         "each Phase2a to f + 1 = 128 neighbouring acceptors of 255 (a window rotating in steps of 16)",
+                kernel="k_phase2<64, 3, *, fused> (packed walk: two rows per wavefront step) behind it the row-at-a-time walk "
+                       "for chunks that are no runs (none here)", profile=lambda: ctx.profile_read(),
+                metric="committed log slots/sec, thrifty delivery (ProxyLeader.scala:190-191)", cpu=cpu,
+                extra={"slots_per_step": n, "replicas": R, "f": F, "targets_per_slot": F + 1,
                        "ballot_model": "per_slot" if ballot_mode == 1 else "acceptor"})
 
 
@@ -310,6 +385,8 @@ def run(args, fa, dist, dev, rank, world, local_rank, all_reduce):
         w = multipaxos_setup(fa, dev, local_rank, ballot_mode, args.config, K, Wm)
     elif args.config == "4":
         w = epaxos_setup(fa, dev, local_rank, K, Wm)
+    elif args.config == "thrifty":
+        w = thrifty_setup(fa, dev, local_rank, ballot_mode, K, Wm)
     else:
         w = mencius_setup(fa, dev, local_rank, rank, world, K, Wm)
     ctx = w["ctx"]
@@ -352,7 +429,7 @@ def run(args, fa, dist, dev, rank, world, local_rank, all_reduce):
         "metric": w["metric"], "value": done / elapsed, "unit": w["unit"], "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": w.get("scaling", "weak"),
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": dict({"workload": w["workload"], "baseline_config": int(args.config),
+        "config": dict({"workload": w["workload"], "baseline_config": int(args.config) if args.config.isdigit() else args.config,
                         "verified": "every timed step checked after the timed region" +
                                     (": first timed tick == the CPU oracle on every output, all ticks by path counts"
                                      if args.config == "4" else ": every slot chosen with its proposed value")},

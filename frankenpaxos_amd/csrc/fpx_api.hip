@@ -96,6 +96,8 @@ struct fpx_ctx {
   std::vector<hipEvent_t> pipe_ev;  // [2 * pieces]: uploaded, computed
   int32_t index_base = 0;           // message index of the piece being launched (error reports are batch-relative)
   bool lazy_active = false;  // PER_SLOT: lazy Phase1a promises may be outstanding (k_phase2 runs its lazy-aware form)
+  bool packed_pass = false;  // the launch being enqueued is the packed walk over runs of acceptors (k_phase2 MODE 3)
+  DevBuf d_run_done;         // one byte per chunk: taken by the packed walk
   // K4: the proxy leader's noop-range tallies (two buffers: fpx_proxy_forget rehashes into the other one)
   RangeTable rt[2];
   int rt_cur = 0;
@@ -229,7 +231,8 @@ int dalloc(fpx_ctx* ctx, T** p, size_t count) {
 
 size_t lds_bytes(const fpx_ctx* ctx, bool fused, bool targets) {
   const size_t tab = (((size_t)ctx->g.ngroups * ctx->g.R * 8) + 16 + 15) & ~(size_t)15;  // tables + 4 workgroup words
-  return tab + 4 * (fused ? sizeof(WaveOut<true>) : sizeof(WaveOut<false>)) + (targets ? 4 * 256 * sizeof(uint64_t) : 0);
+  // (targets: per wavefront the chunk's 64 masks + 16 words for the packed walk's Nack path)
+  return tab + 4 * (fused ? sizeof(WaveOut<true>) : sizeof(WaveOut<false>)) + (targets ? 4 * (256 + 16) * sizeof(uint64_t) : 0);
 }
 
 // messages per wavefront at G = 64: FPX_CHUNK for batches that fill the chip anyway, fewer (down to 4) for small
@@ -269,6 +272,11 @@ void launch_phase2_3(fpx_ctx* ctx, const Batch& b0, bool fused, int grid) {
     b.sc_lds = (int32_t)lds;
     lds += 4 * 3 * 4 * 64 * sizeof(int32_t);
   }
+  if (PS == 0 && ctx->g.ngroups != 1) {  // the acceptors' rounds of every group, staged per workgroup
+    lds = (lds + 15) & ~(size_t)15;
+    b.th_lds = (int32_t)lds;
+    lds += (size_t)ctx->g.ngroups * ctx->g.R * sizeof(int32_t);
+  }
   if (fused) allow_lds(k_phase2<G, MODE, PS, true>, lds);
   else allow_lds(k_phase2<G, MODE, PS, false>, lds);
   if (fused)
@@ -290,6 +298,13 @@ void launch_phase2_2(fpx_ctx* ctx, const Batch& b, bool fused, int grid) {
   // rows are padded to a multiple of 4 cells (Geom::RS), so int4 accesses serve every R.
   // mode 0: dense delivery (no target masks); 1: target masks; 2: target masks + FPX_F_SCATTERED_TARGETS
   const int mode = !b.target ? 0 : ((ctx->cfg.flags & FPX_F_SCATTERED_TARGETS) ? 2 : 1);
+  if constexpr (G == 64) {
+    if (ctx->packed_pass) {  // the packed walk (enqueue_phase2 runs it ahead of the row-at-a-time walk)
+      if (!ctx->g.per_slot) launch_phase2_3<64, 3, 0>(ctx, b, fused, grid);
+      else launch_phase2_3<64, 3, 1>(ctx, b, fused, grid);
+      return;
+    }
+  }
   if (mode == 0) launch_phase2_2b<G, 0>(ctx, b, fused, grid);
   else if (mode == 1) launch_phase2_2b<G, 1>(ctx, b, fused, grid);
   else launch_phase2_2b<G, 2>(ctx, b, fused, grid);
@@ -359,24 +374,43 @@ int enqueue_phase2(fpx_ctx* ctx, Batch& b, bool fused) {
   // of the partial-maxima buffers is not consumed
   b.solo = ((b.n + b.chunk - 1) / b.chunk <= 8 && !getenv("FPX_NO_SOLO")) ? 1 : 0;
   if (b.solo) grid = 1;
-  b.parity = b.solo ? 0 : (int32_t)(ctx->phase2_launches++ & 1u);  // every other K1 / K3 launch is followed by its k_finalize
-  if (++ctx->launch_seq == 0) ctx->launch_seq = 1;
-  b.launch_seq = ctx->launch_seq;
+  // Target masks on 256-cell rows of one group: thrifty delivery to RUNS of neighbouring acceptors (what GpuProxyLeader
+  // sends by default; any f + 1 will do: ProxyLeader.scala:190-191) takes two rows per wavefront step.  Two launches: the
+  // packed walk takes the chunks all of whose messages go to such runs of rows nobody voted in yet and marks them, the
+  // row-at-a-time walk behind it takes the rest (nothing is decided on the host, nothing is walked twice).
+  const Geom& g = ctx->g;
+  const bool two = b.target && ctx->lanes_per_slot == 64 && g.RS == 256 && g.ngroups == 1 && g.base == 0 && g.total == g.R &&
+                   g.qkind != 2 && !(g.per_slot && ctx->lazy_active) && !(ctx->cfg.flags & FPX_F_SCATTERED_TARGETS) &&
+                   !getenv("FPX_NO_PACKED_RUNS");  // (FPX_F_SCATTERED_TARGETS: the caller says its targets are no runs)
+  if (two) {
+    rc = grow(ctx, &ctx->d_run_done, (size_t)(b.n + b.chunk - 1) / b.chunk + 64);
+    if (rc) return rc;
+    b.run_done = (uint8_t*)ctx->d_run_done.p;
+  }
   const bool prof = ctx->profiling && ctx->ev_used + 2 <= ctx->ev.size();
   if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[ctx->ev_used], ctx->stream));
-  launch_phase2(ctx, b, fused, grid);
-  rc = launch_check(ctx);
-  if (rc) return rc;
-  if (prof) {
-    HIPCHK(ctx, hipEventRecord(ctx->ev[ctx->ev_used + 1], ctx->stream));
-    ctx->ev_used += 2;
+  for (int pass = two ? 0 : 1; pass < 2; ++pass) {
+    b.parity = b.solo ? 0 : (int32_t)(ctx->phase2_launches++ & 1u);  // every other K1 / K3 launch is followed by its k_finalize
+    if (++ctx->launch_seq == 0) ctx->launch_seq = 1;
+    b.launch_seq = ctx->launch_seq;
+    ctx->packed_pass = pass == 0;
+    launch_phase2(ctx, b, fused, grid);
+    ctx->packed_pass = false;
+    rc = launch_check(ctx);
+    if (rc) return rc;
+    if (pass == 1 && prof) {
+      HIPCHK(ctx, hipEventRecord(ctx->ev[ctx->ev_used + 1], ctx->stream));
+      ctx->ev_used += 2;
+    }
+    if (b.solo) continue;
+    const int ntab = ctx->g.ngroups * ctx->g.R;
+    const int slices = std::max(FINALIZE_SLICES, std::min(256, grid / 32));  // ~8 partial rows per wavefront
+    hipLaunchKernelGGL(k_finalize, dim3((ntab + 63) / 64, slices), dim3(256), 0, ctx->stream, ctx->g, ctx->st,
+                       (int)b.parity, grid, b.launch_seq);
+    rc = launch_check(ctx);
+    if (rc) return rc;
   }
-  if (b.solo) return FPX_OK;
-  const int ntab = ctx->g.ngroups * ctx->g.R;
-  const int slices = std::max(FINALIZE_SLICES, std::min(256, grid / 32));  // ~8 partial rows per wavefront
-  hipLaunchKernelGGL(k_finalize, dim3((ntab + 63) / 64, slices), dim3(256), 0, ctx->stream, ctx->g, ctx->st,
-                     (int)b.parity, grid, b.launch_seq);
-  return launch_check(ctx);
+  return FPX_OK;
 }
 
 int enqueue_open(fpx_ctx* ctx, Batch& b) {
@@ -472,7 +506,7 @@ void free_state(fpx_ctx* ctx) {
                 st.log_value, st.log_present, st.log_scalars, st.part_stamp, st.part_all,
                 st.row_voted, st.lz_round, st.lz_from, st.max_ballot, st.p1,
                 ctx->rt[0].key, ctx->rt[0].bits, ctx->rt[0].owner, ctx->rt[0].count,
-                ctx->rt[1].key, ctx->rt[1].bits, ctx->rt[1].owner, ctx->rt[1].count, ctx->d_rng.p};
+                ctx->rt[1].key, ctx->rt[1].bits, ctx->rt[1].owner, ctx->rt[1].count, ctx->d_rng.p, ctx->d_run_done.p};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   DevBuf* bs[] = {&ctx->d_slot,   &ctx->d_round, &ctx->d_value, &ctx->d_target, &ctx->d_bits_a, &ctx->d_bits_b,

@@ -137,6 +137,10 @@ struct Batch {
   int32_t index_base;      // added to the message index an error reports (host batches launched in pieces)
   int32_t solo;            // K1 / K3: the launch is ONE workgroup, which applies its maxima itself (no k_finalize follows)
   int32_t sc_lds;          // K1 / K3 on leader-group-major rows: byte offset of 4 x 3 KiB of LDS for the column quads (0 = none)
+  int32_t th_lds;          // K1 / K3, FPX_BALLOT_ACCEPTOR with several acceptor groups: byte offset of the staged rounds [ngroups * R]
+  uint8_t* run_done;       // K1 / K3 with target masks at G = 64 run as two launches: the packed walk (MODE 3) takes the chunks
+                           // whose messages all go to runs of acceptors and says so here, one byte per chunk; the
+                           // row-at-a-time walk behind it takes the others
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -274,6 +278,33 @@ __device__ __forceinline__ void shl256(uint64_t x[4], int sh) {
     x[1] = (x[1] << bs) | (x[0] >> (64 - bs));
     x[0] = x[0] << bs;
   }
+}
+
+// Is the 256-bit set m (bits >= R clear) a cyclic RUN of positions [start, start + len) mod 256 with start a multiple of 16
+// (a 64-byte sector of a row) and len <= 128 -- up to the positions R .. 255, which no acceptor owns (a run that passes
+// over them holds them too)?  What a thrifty proxy leader that sends every Phase2a to f + 1 NEIGHBOURING acceptors
+// produces (any f + 1 of the group will do: multipaxos/ProxyLeader.scala:190-191).  cell0 = first 16-byte cell of the
+// run, ncell = cells of the sectors it touches (a multiple of 4, at most 32).
+__device__ __forceinline__ bool classify_run(const uint64_t m[4], int R, int* cell0, int* ncell) {
+  uint64_t w[4] = {m[0], m[1], m[2], m[3]};
+  if (R < 256 && ((w[3] >> (R - 193)) & 1ull) && (w[0] & 1ull)) w[3] |= ~0ull << (R - 192);  // 192 < R: the run wraps over the gap
+  uint64_t first[4];
+  first[0] = w[0] & ~((w[0] << 1) | (w[3] >> 63));
+  first[1] = w[1] & ~((w[1] << 1) | (w[0] >> 63));
+  first[2] = w[2] & ~((w[2] << 1) | (w[1] >> 63));
+  first[3] = w[3] & ~((w[3] << 1) | (w[2] >> 63));
+  int start = -1;
+#pragma unroll
+  for (int j = 3; j >= 0; --j)
+    if (first[j]) start = 64 * j + (int)__ffsll((unsigned long long)first[j]) - 1;
+  const int len = popc256(w);
+  if (start < 0 || (start & 15) || len > 128) return false;
+  const int over = start + len - 256;
+  bool same = true;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) same = same && w[j] == (range_mask(start, len, j) | (over > 0 ? range_mask(0, over, j) : 0ull));
+  *cell0 = start >> 2, *ncell = ((len + 15) >> 4) << 2;
+  return same;
 }
 
 // Assemble the per-slot bitmap from per-lane nibbles.  A slot is handled by G consecutive lanes
@@ -435,7 +466,7 @@ __global__ void __launch_bounds__(256)
   // masks + FPX_F_SCATTERED_TARGETS.  The target-mask code (LDS staging, fresh-row blend) costs 6-12 VGPRs = one
   // wave per SIMD, which the dense stream would pay for nothing.
   constexpr bool TGT = MODE != 0;
-  constexpr bool RMW = MODE == 2;
+  constexpr bool RMW = MODE == 2;  // (3: target masks that are all runs of neighbouring acceptors, see PACK below)
   constexpr bool VEC = true;  // 16-byte row accesses
   constexpr int Q = 64 / G;           // slots per step
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -456,9 +487,16 @@ __global__ void __launch_bounds__(256)
   // load, so that the walk has no global load of its own in the ACCEPTOR model (a dependent load per row made
   // thrifty delivery latency-bound: 0.88 ms per 2^20 rows against 0.42 ms dense, profiles/r02_thrifty.txt)
   uint64_t* wt = reinterpret_cast<uint64_t*>(smem + (((size_t)ntab * 8 + 16 + 15) & ~(size_t)15) + 4 * sizeof(WaveOut<FUSED>)) +
-                 (size_t)wib * 256;
+                 (size_t)wib * (256 + 16);
 
   for (int i = threadIdx.x; i < 2 * ntab + 4; i += blockDim.x) tab_pr[i] = (i < 2 * ntab || i >= 2 * ntab + 2) ? -1 : 0;
+  // FPX_BALLOT_ACCEPTOR with several acceptor groups: every step needs the rounds of ITS group's acceptors.  They are
+  // staged in LDS once per workgroup: as global loads inside the walk they put an s_waitcnt vmcnt(0) into every step,
+  // and on gfx9 vmcnt counts STORES too -- each step then waited until the rows of the step before had reached memory
+  // (a full store round trip per row and wavefront)
+  int32_t* tab_th = reinterpret_cast<int32_t*>(smem + b.th_lds);
+  if (!PERSLOT && g.ngroups != 1)
+    for (int i = threadIdx.x; i < ntab; i += blockDim.x) tab_th[i] = st.promised[i];
   __syncthreads();
   int w_slot = -1, w_round = -1;  // maxima over the steps in which the whole group voted (wave-uniform)
   bool table_used = false;
@@ -478,6 +516,15 @@ __global__ void __launch_bounds__(256)
     for (int k = 0; k < 4; ++k)
       if (own >> k & 1) init_thr[k] = st.promised[r0 + k];
   }
+
+  // the packed walk (below): lane (half, l32) owns the cells l32 and 32 + l32 of every row it meets
+  // MODE 3 (G = 64 only): the packed walk alone, for the chunks all of whose messages go to runs; the others are left
+  // to a MODE 1 / 2 launch behind this one (Batch::run_done) -- with both walks in one kernel the register count went
+  // from 85 to 141
+  constexpr bool PACK = G == 64 && MODE == 3;
+  static_assert(MODE != 3 || (G == 64 && PS != 2), "the packed walk: 256-cell rows, no lazy promises");
+  int pk_pr[8] = {-1, -1, -1, -1, -1, -1, -1, -1}, pk_mv[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+  bool pk_used = false;
 
   int lzr[4] = {-1, -1, -1, -1}, lzf[4] = {0, 0, 0, 0};
   if (LAZY && one_group) {
@@ -526,6 +573,9 @@ __global__ void __launch_bounds__(256)
   const int units = u1 + (b.n - tiled + CH - 1) / CH;        // + the plain chunks behind the tiles
   int32_t* sc = reinterpret_cast<int32_t*>(smem + b.sc_lds) + wib * (3 * 4 * 64);  // [3][4][64] per wavefront
   for (int unit = bx * 4 + wib; unit < units; unit += gridDim.x * 4) {
+    if constexpr (G == 64 && (MODE == 1 || MODE == 2)) {
+      if (b.run_done && b.run_done[unit]) continue;  // the packed walk of the launch before this one took the chunk
+    }
     const bool strided = COLS && unit < u1;
     const bool quad = COLS && strided && kc == 4;
     const int v0 = tiled + (unit - u1) * CH;  // plain chunk: its first message
@@ -549,6 +599,20 @@ __global__ void __launch_bounds__(256)
     // Nacking -- can be stored as whole 16-byte cells blended with -1: full-line traffic, nothing read
     bool myfresh = false;
     if constexpr (TGT) myfresh = mv && st.row_voted[phys_slot_g<G>(g, myslot)] == 0;
+    // MODE 3: is this chunk the packed walk's?  Decided from the messages' masks before anything else of the chunk is
+    // loaded (a chunk that is not costs this launch its masks and row_voted bytes, nothing more)
+    int mycell0 = 0, myncell = 0;
+    if constexpr (PACK) {
+      bool okm = true;
+      if (mv) {
+        const uint64_t* tp = b.target + (size_t)m * 4;
+        const uint64_t tm[4] = {tp[0] & g.member[0], tp[1] & g.member[1], tp[2] & g.member[2], tp[3] & g.member[3]};
+        okm = myfresh && classify_run(tm, g.R, &mycell0, &myncell);
+      }
+      const bool packed = __all(okm);
+      if (lane == 0) b.run_done[unit] = packed ? 1 : 0;
+      if (!packed) continue;  // nothing of this chunk has been touched: the launch behind this one walks it row by row
+    }
     // ProxyLeader.handlePhase2a for 64 messages at once (ProxyLeader.scala:176-184): lane i reads the
     // tally-key row of its slot (one gathered 16-byte access per lane), detects a known (slot, round)
     // and picks the free way.  The key word is written back after the walk, one lane per message.
@@ -608,7 +672,7 @@ __global__ void __launch_bounds__(256)
               if (own >> k & 1) thr[k] = st.ballot[row + k];
           }
         } else if (!one_group) {
-          const int32_t* pr = st.promised + (size_t)grp_out * g.R + r0;
+          const int32_t* pr = tab_th + grp_out * g.R + r0;
 #pragma unroll
           for (int k = 0; k < 4; ++k)
             if (own >> k & 1) thr[k] = pr[k];
@@ -635,6 +699,121 @@ __global__ void __launch_bounds__(256)
       return thr;
     };
 
+    // ---- thrifty delivery to RUNS of acceptors: two rows per step -------------------------------------------------
+    // The walk below costs ~180 vector instructions per row whatever the row moves: 0.31 ms per 2^20 rows, the time of
+    // a dense step, for half the bytes (profiles/r04_thrifty.md).  When every message of the chunk goes to a sector-aligned run of
+    // at most 128 acceptors of a fresh row (classify_run), a wavefront takes TWO rows per step, 32 lanes each.  A run
+    // is a window of 32 consecutive cells (mod 64), which holds exactly one of the cells l32 and 32 + l32 for every
+    // l32: lane (half, l32) takes that one, so it only ever meets two fixed cells -- its acceptors' rounds and maxima
+    // stay in registers.  With no Nack in the step the votes of a row ARE its target set: the bitmap is not assembled.
+    if constexpr (PACK) {
+      pk_used = true;
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // the chunk's own loads (see below)
+      const int half = lane >> 5, l32 = lane & 31;
+      uint32_t own_hi = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) own_hi |= (128 + 4 * l32 + k < g.R) ? (1u << k) : 0u;
+      int4v th_lo = {-1, -1, -1, -1}, th_hi = {-1, -1, -1, -1};
+      if (!PERSLOT) {
+        th_lo = *reinterpret_cast<const int4v*>(st.promised + 4 * l32);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (own_hi >> k & 1) th_hi[k] = st.promised[128 + 4 * l32 + k];
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+      }
+      uint64_t* scr = wt + 256 + half * 8;  // [2][4]: votes, Nacks of my row when somebody Nacks
+      for (int t = 0; t < CH / 2; ++t) {
+        const int src = 2 * t + half;
+        const int s = __shfl(myslot, src);
+        const int rnd = __shfl(myround, src);
+        const int val = __shfl(myvalue, src);
+        const bool deliver = __shfl((int)mydeliver, src) != 0 && s >= 0;
+        const int c0 = __shfl(mycell0, src), nc = __shfl(myncell, src);
+        const int j = (l32 - c0) & 31;   // my place in the run's window
+        const int c = (c0 + j) & 63;     // my cell of this row
+        const bool hi = c >= 32, active = j < nc && deliver;
+        const int bp = 4 * c;
+        const uint32_t own_c = hi ? own_hi : 0xFu;
+        const uint64_t tw = active ? wt[src * 4 + (bp >> 6)] : 0ull;
+        const uint32_t tn = own_c & (uint32_t)((tw >> (bp & 63)) & 0xFull);
+        const size_t row = (size_t)s * (size_t)g.RS + (size_t)bp, vrow = (size_t)s * (size_t)g.VS + (size_t)bp;
+        int4v thr = hi ? th_hi : th_lo;
+        if (PERSLOT && active) thr = *reinterpret_cast<const int4v*>(st.ballot + row);
+        uint32_t acc = 0, nck = 0;
+        int nr = -1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool tk = (tn >> k) & 1u;
+          const bool ok = tk && (rnd >= thr[k]);  // Acceptor.scala:192
+          acc |= ok ? (1u << k) : 0u;
+          if (tk && !ok) nck |= 1u << k, nr = thr[k] > nr ? thr[k] : nr;
+        }
+        if (active) {  // a fresh row: every cell of the sectors the run touches is written whole, -1 where nobody votes
+          int4v rr, vv, nb = thr;
+          bool ballot_moves = false;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bool a = (acc >> k) & 1u;
+            rr[k] = a ? rnd : -1, vv[k] = a ? val : -1;
+            if (a) ballot_moves = ballot_moves || thr[k] != rnd, nb[k] = rnd;
+          }
+          row_store(rr, reinterpret_cast<int4v*>(st.vote_round + vrow));
+          row_store(vv, reinterpret_cast<int4v*>(st.vote_value + vrow));
+          if (PERSLOT && ballot_moves) row_store(nb, reinterpret_cast<int4v*>(st.ballot + row));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool a = (acc >> k) & 1u;
+          const bool al = a && !hi, ah = a && hi;
+          pk_mv[k] = (al && s > pk_mv[k]) ? s : pk_mv[k], pk_pr[k] = (al && rnd > pk_pr[k]) ? rnd : pk_pr[k];
+          pk_mv[4 + k] = (ah && s > pk_mv[4 + k]) ? s : pk_mv[4 + k], pk_pr[4 + k] = (ah && rnd > pk_pr[4 + k]) ? rnd : pk_pr[4 + k];
+        }
+        uint64_t vb[4], nbits[4] = {0, 0, 0, 0};
+        int nrm = -1;
+        if (!__any(nck != 0u)) {  // everybody asked voted: the votes are the targets
+#pragma unroll
+          for (int w = 0; w < 4; ++w) vb[w] = deliver ? (wt[src * 4 + w] & g.member[w]) : 0ull;
+        } else {
+          if (l32 < 8) scr[l32] = 0ull;
+          wave_lds_sync();
+          if (acc) atomicOr(reinterpret_cast<unsigned long long*>(&scr[bp >> 6]), (unsigned long long)acc << (bp & 63));
+          if (nck) atomicOr(reinterpret_cast<unsigned long long*>(&scr[4 + (bp >> 6)]), (unsigned long long)nck << (bp & 63));
+          wave_lds_sync();
+#pragma unroll
+          for (int w = 0; w < 4; ++w) vb[w] = scr[w], nbits[w] = scr[4 + w];
+          nrm = group_max<32>(nr);
+          wave_lds_sync();
+        }
+        if constexpr (!FUSED) {
+          if (l32 == 0) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) wo->votes[src][w] = vb[w], wo->nacks[src][w] = b.nack_bits ? nbits[w] : 0ull;
+            wo->nack_round[src] = nrm;
+          }
+        } else {
+          bool ch = false;  // ProxyLeader.scala:235-256
+          const int way = __shfl(myway, src);
+          if (deliver) {
+            uint64_t x[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) x[w] = vb[w] & g.member[w];
+            ch = is_write_quorum(g, x);
+            if (!ch && l32 == 0) {
+              const size_t e = (size_t)s * g.wp + way;
+#pragma unroll
+              for (int w = 0; w < 4; ++w) st.pl_bits[e * 4 + w] = x[w];
+            }
+          }
+          if (l32 == 0) wo->chosen[src] = ch ? 1 : 0, wo->nack_round[src] = nrm;
+        }
+      }
+    }
+    if constexpr (!PACK) {
+    // Everything the chunk loaded (messages, tally keys, row_voted, masks, and at kernel start the acceptors' rounds) is
+    // waited for HERE: left to the compiler, the s_waitcnt vmcnt(0) of a first use inside the walk sits in the loop
+    // body, where -- vmcnt counts stores on gfx9 -- it makes every step wait for the rows the step before it wrote.
+    // In the FPX_BALLOT_ACCEPTOR model the walk then has no vector-memory wait at all: rows stream out back to back.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt and lgkmcnt untouched
     int s_cur, grp_cur;
     int4v thr_cur = load_thr(0, s_cur, grp_cur);
     for (int t = 0; t < G * CH / 64; ++t) {
@@ -843,6 +1022,7 @@ __global__ void __launch_bounds__(256)
       if (t + 1 < G) thr_cur = load_thr(t + 1, s_cur, grp_cur);
 #endif
     }
+    }  // (the walk, one row per step)
 
     // ---- outputs of the 64 messages leave as coalesced lines ------------------------------------
     wave_lds_sync();
@@ -912,6 +1092,18 @@ __global__ void __launch_bounds__(256)
   if (lane == 0 && w_slot >= 0) {  // wave -> workgroup (LDS)
     atomicMax(&blk_flag[2], w_round);
     atomicMax(&blk_flag[3], w_slot);
+  }
+  if constexpr (PACK) {
+    if (__any(pk_used)) {  // cell gi's maxima sit in the lanes gi & 31 of both halves, in their low or high set
+      const int la = lane & 31, lb = 32 + (lane & 31);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int m0 = __shfl(pk_mv[k], la), m1 = __shfl(pk_mv[k], lb), m2 = __shfl(pk_mv[4 + k], la), m3 = __shfl(pk_mv[4 + k], lb);
+        const int p0 = __shfl(pk_pr[k], la), p1 = __shfl(pk_pr[k], lb), p2 = __shfl(pk_pr[4 + k], la), p3 = __shfl(pk_pr[4 + k], lb);
+        const int mm = lane < 32 ? (m0 > m1 ? m0 : m1) : (m2 > m3 ? m2 : m3), pp = lane < 32 ? (p0 > p1 ? p0 : p1) : (p2 > p3 ? p2 : p3);
+        acc_mv[k] = mm > acc_mv[k] ? mm : acc_mv[k], acc_pr[k] = pp > acc_pr[k] ? pp : acc_pr[k];
+      }
+    }
   }
   bool any_table = false;
   if (one_group) {

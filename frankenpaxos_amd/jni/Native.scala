@@ -168,7 +168,11 @@ class GpuPhase2Engine[Transport <: frankenpaxos.Transport[Transport]](
     logger: Logger,
     config: Config[Transport],
     numSlots: Int = 1 << 20,
-    retainSlots: Int = 1 << 18
+    retainSlots: Int = 1 << 18,
+    // thrifty delivery (the reference's default, ProxyLeader.scala:190-191: every Phase2a goes to f + 1 of its group's
+    // 2f + 1 acceptors).  The reference shuffles; any f + 1 will do, and this engine sends to a window of f + 1
+    // NEIGHBOURING acceptors that rotates from message to message -- see thriftyMask
+    thrifty: Boolean = true
 ) {
   config.checkValid()
   val perGroup: Int = config.acceptorAddresses(0).size
@@ -239,6 +243,21 @@ class GpuPhase2Engine[Transport <: frankenpaxos.Transport[Transport]](
     moved
   }
 
+  // ---- which acceptors a Phase2a goes to.  A window of f + 1 neighbouring acceptors: on groups of 253 .. 256 acceptors it
+  // moves in steps of 16 (a 64-byte sector of the group's row in HBM) and does not wrap over the end of the row -- the
+  // runs libfpx walks two rows per wavefront step (include/fpx.h, FPX_F_SCATTERED_TARGETS); on the small groups of an
+  // everyday deployment it moves by one acceptor and wraps, so every acceptor sees (f + 1) / (2f + 1) of the messages
+  private var rotor = 0
+  private def thriftyMask(masks: Array[Long], at: Int): Unit = {
+    val q = config.f + 1
+    val start = if (perGroup >= 253) 16 * (rotor % ((perGroup - q) / 16 + 1)) else rotor % perGroup
+    rotor += 1
+    for (j <- 0 until q) {
+      val a = (start + j) % perGroup
+      masks(4 * at + (a >> 6)) |= 1L << (a & 63)
+    }
+  }
+
   // ---- Phase 2: one tick of Phase2a messages (ProxyLeader.handlePhase2a + every Acceptor.handlePhase2a +
   // ProxyLeader.handlePhase2b).  Returns, in message order, Chosen to broadcast and (round, Nack) to route.
   case class TickResult(chosen: Seq[Chosen], nacks: Seq[(Int, Nack)])
@@ -255,9 +274,15 @@ class GpuPhase2Engine[Transport <: frankenpaxos.Transport[Transport]](
       }
       val chosen = new Array[Byte](n); val cr = new Array[Int](n); val cv = new Array[Int](n)
       val nr = new Array[Int](n)
-      // dense delivery (targetMask = null).  A thrifty deployment passes one random f+1 / grid-column
-      // mask per message here (ProxyLeader.scala:190-196).
-      if (n > 0) Native.check(Native.phase2Fused(handle, n, slot, round, value, null, chosen, cr, cv, nr), logger)
+      // thrifty: one mask of f + 1 acceptors per message (ProxyLeader.scala:190-191); a flexible deployment's grid
+      // column (:193-196) is not generated here: dense delivery (targetMask = null), as without `thrifty`
+      val masks: Array[Long] =
+        if (thrifty && !config.flexible && perGroup > config.f + 1) {
+          val m = new Array[Long](4 * n)
+          for (i <- 0 until n) thriftyMask(m, i)
+          m
+        } else null
+      if (n > 0) Native.check(Native.phase2Fused(handle, n, slot, round, value, masks, chosen, cr, cv, nr), logger)
       for (i <- 0 until n) {
         if (chosen(i) != 0) {
           chosenOut += Chosen(slot = now(i).slot, commandBatchOrNoop = valueOf(cv(i))) // ProxyLeader.scala:246-253

@@ -111,6 +111,14 @@ typedef enum {
  * of 2f+1 (ProxyLeader.scala:190-191).  K1 / K3 launches that carry target masks then write partially
  * voted 16-byte cells by read-modify-write instead of 4-byte stores.  Results are identical either way. */
 #define FPX_F_SCATTERED_TARGETS 2u
+/* Without that hint, on 256-cell rows of one acceptor group (R = 253 .. 256, threshold / majority / unanimous quorums),
+ * launches that carry target masks run as TWO kernels: chunks of 32 messages that all go to a RUN of neighbouring
+ * acceptors -- positions [start, start + len) of the row, cyclically, start a multiple of 16, len <= 128: what a proxy
+ * leader sends that rotates a window of f + 1 acceptors over the group instead of shuffling (any f + 1 will do,
+ * ProxyLeader.scala:190-191; jni/Native.scala's GpuProxyLeader does) -- of rows nobody voted in yet are walked two
+ * rows per wavefront step (a row costs the same instructions whatever it moves, so half a row at a time ran at the
+ * dense rate: 3.0e9 slots/s; now 4.4e9), every other chunk by the row-at-a-time walk behind it.  The hint skips the
+ * first kernel.  Results are identical either way (FPX_NO_PACKED_RUNS in the environment switches the first kernel off). */
 /* Mencius contexts (num_leader_groups L > 1, num_slots a multiple of L, num_replicas <= 32) keep the per-slot rows of the cell arrays and
  * tally tables LEADER-GROUP-MAJOR in HBM -- slot s lives in row (s % L) * (S / L) + s / L -- so that what one leader
  * group does (a noop range = every L-th slot; its batch of Phase2as in slot order) touches neighbouring rows and

@@ -46,7 +46,18 @@ def rotating_masks(n):
     return pack(bits)
 
 
-for name, maker in (("random f+1 subsets", random_masks), ("rotating f+1 run", rotating_masks), ("dense", None)):
+def aligned_masks(n):
+    """rotating sector-aligned windows of f + 1 acceptors (start a multiple of 16, no wrap over the end of the row):
+    what GpuProxyLeader sends by default -- k_phase2's packed walk"""
+    s = torch.arange(n, device=dev)[:, None]
+    j = torch.arange(256, device=dev)[None, :]
+    start = 16 * (s % ((R - (F + 1)) // 16 + 1))
+    bits = (j >= start) & (j < start + F + 1)
+    return pack(bits)
+
+
+for name, maker in (("random f+1 subsets", random_masks), ("rotating f+1 run", rotating_masks), ("aligned f+1 run", aligned_masks),
+                    ("dense", None)):
     if only != "all" and not name.startswith(only):
         continue
     ctx = fa.Context(fa.make_config(num_slots=windows * S, num_replicas=R, f=F, ballot_mode=ballot,

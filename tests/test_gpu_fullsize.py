@@ -61,6 +61,20 @@ def test_headline_adversarial_1m_slots_256_replicas(fa, oracle, seed, ballot_mod
     assert chosen >= S and nacks > 0          # every slot got chosen at least once; stale rounds were Nacked
 
 
+@pytest.mark.parametrize("ballot_mode,R", [(0, 256), (1, 256), (0, 255), (1, 255)])
+def test_headline_size_thrifty_runs(fa, oracle, ballot_mode, R):
+    """the adversarial stream at 2^20 slots with every Phase2a sent to a RUN of neighbouring acceptors (rotating
+    sector-aligned windows of 120 .. 128: the packed walk of k_phase2, two rows per wavefront step) -- first proposals
+    take the packed walk, the epochs that re-propose voted slots fall back to the row-at-a-time walk on the device's
+    own verdict (k_runs_check), pre-promised acceptors Nack inside packed steps"""
+    S = 1 << 20
+    script = W.adversarial_script(S, R, 128, 5 + ballot_mode, epochs=64, fused=True, subsets=W.run_subsets)
+    out, chosen = run_both(fa, oracle, script, range(0, S, 65537), num_slots=S, num_replicas=R, f=127,
+                           ballot_mode=ballot_mode, tally_ways=8)
+    nacks = sum(int((o[5] >= 0).sum()) for o in out if o[0] == "fused")
+    assert chosen > S // 32 and nacks > 0        # (windows of 120 .. 128 positions: about one in nine holds a quorum of 128)
+
+
 # ---------------------------------------------------------------------------------------------------
 # BASELINE.json configs[2]: compartmentalized MultiPaxos, 2x2 grid quorums, 1M slots x 16 acceptor groups
 # ---------------------------------------------------------------------------------------------------

@@ -524,6 +524,43 @@ def test_scattered_targets_hint_changes_nothing(fa, oracle, R, ballot_mode):
     check(gpu, ref, W.adversarial_script(S, R, q, 29 + R, epochs=16, fused=False), tally_slots=range(0, S, 61))
 
 
+@pytest.mark.parametrize("R,quorum_kind", [(256, 0), (255, 0), (253, 1), (256, 3)])
+@pytest.mark.parametrize("ballot_mode", [0, 1])
+@pytest.mark.parametrize("fused", [True, False])
+def test_thrifty_runs_take_the_packed_walk(fa, oracle, R, quorum_kind, ballot_mode, fused, monkeypatch):
+    """Phase2as sent to RUNS of neighbouring acceptors (W.run_subsets: rotating sector-aligned windows, 100 .. 128 wide,
+    some short of the quorum) on 256-cell rows: k_runs_check + the packed walk of k_phase2 (two rows per wavefront step,
+    the vote set taken from the target set unless somebody Nacks).  The adversarial stream brings pre-promised
+    acceptors (Nacks inside packed steps), re-proposals of voted slots (those launches fall back to the row-at-a-time
+    walk on the device's own verdict), duplicated votes; every output and the whole state == the oracle, for the
+    threshold, majority and unanimous predicates, with and without the padding positions 253 .. 255; and the same
+    stream with the packed walk switched off (FPX_NO_PACKED_RUNS) gives the same again."""
+    S = 2048
+    f = 127 if quorum_kind == 0 else 0
+    q = {0: 128, 1: R // 2 + 1, 3: R}[quorum_kind]
+    kw = dict(num_slots=S, num_replicas=R, quorum_kind=quorum_kind, f=f, ballot_mode=ballot_mode, tally_ways=8)
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("FPX_NO_PACKED_RUNS", "1")
+        gpu, ref = both(fa, oracle, **kw)
+        script = W.adversarial_script(S - 700, R, min(q, 108), 41 + R + quorum_kind, epochs=16, fused=fused, subsets=W.run_subsets)
+        check(gpu, ref, script, tally_slots=range(0, S, 61))
+        # odd chunk tails, a single message, and a batch one of whose masks is no run
+        rng = np.random.default_rng(R)
+        base = S - 700
+        for n in (1, 2, 31, 33, 257):
+            slot = np.arange(base, base + n, dtype=np.int32)
+            base += n
+            tgt = W.bits_from_bool(W.run_subsets(rng, n, R, 120, 128))
+            if n == 33:
+                tgt[7] = W.bits_from_bool(W.random_subsets(rng, 1, R, 100, 100))[0]
+            ops = [("fused", slot, np.full(n, 900, np.int32), W.steady_values(slot), tgt)] if fused else \
+                  [("k1k2", slot, np.full(n, 900, np.int32), W.steady_values(slot), tgt, np.zeros(n, bool))]
+            W.assert_same_outputs(W.run_script(gpu, ops), W.run_script(ref, ops))
+        W.assert_same_state(gpu, ref, tally_slots=range(S - 700, S, 7))
+        gpu.close()
+
+
 def test_capacity_error_applies_everything_else(fa, oracle):
     """a fused launch that hits FPX_ECAPACITY on some messages must still apply the others in
     full -- votes AND the acceptors' round / maxVotedSlot (a vote in round r with promised < r would let a

@@ -94,6 +94,17 @@ def fast_subsets(nprng, n, total, lo, hi):
     return j < sizes[:, None]
 
 
+def run_subsets(nprng, n, total, lo, hi):
+    """n RUNS of neighbouring acceptors: positions [start, start + len) of the 256 a row has room for, cyclically, start a
+    multiple of 16 (a 64-byte sector of the row), len uniform in [lo, min(hi, 128)]; positions >= total have no
+    acceptor.  What a thrifty proxy leader sends when it rotates a window of f + 1 acceptors over the group instead of
+    shuffling (any f + 1 will do: multipaxos/ProxyLeader.scala:190-191) -- the delivery k_phase2's packed walk takes."""
+    start = 16 * nprng.integers(0, 16, size=n)
+    length = nprng.integers(lo, min(hi, 128) + 1, size=n)
+    j = np.arange(256)[None, :]
+    return ((((j - start[:, None]) % 256) < length[:, None]) & (j < total))[:, :total]
+
+
 def next_classic_round(n, leader, rnd):
     if rnd < 0:
         return leader
