@@ -475,6 +475,16 @@ __global__ void __launch_bounds__(256)
 
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
+  if constexpr (G == 64 && (MODE == 1 || MODE == 2)) {
+    // behind a packed walk: a workgroup all of whose chunks that walk took leaves before it sets anything up (8192
+    // workgroups that only found out in their unit loop were 24 us of a 260 us step)
+    if (b.run_done) {
+      const int nunits = (b.n + b.chunk - 1) / b.chunk;
+      bool mine = false;
+      for (int unit = blockIdx.x * 4 + wib; unit < nunits; unit += gridDim.x * 4) mine = mine || b.run_done[unit] == 0;
+      if (!__syncthreads_or(mine)) return;
+    }
+  }
   const int gi = lane & (G - 1);
   const int q = lane / G;
   const int ntab = g.ngroups * g.R;
