@@ -142,6 +142,28 @@ object Native {
                                       values: java.nio.ByteBuffer, valueOff: Array[Long], valueLen: Array[Int],
                                       isNoop: Array[Byte]): Long
   @native def wireEncodeLeaderNack(out: java.nio.ByteBuffer, round: Int): Long
+  // Mencius on the wire (mencius/Mencius.proto): ProxyLeaderInbound -> fields = kind | slot | slotEnd | round | isNoop |
+  // valueLen | groupIndex | acceptorIndex (8 x n); AcceptorInbound -> kind | slot | slotEnd | round | isNoop | valueLen |
+  // chosenWatermark (7 x n); LeaderInbound{Nack} is field 7 there.  Phase1b has MultiPaxos' layout: wireEncodeLeaderPhase1b
+  @native def wireMenciusDecodeProxyLeaderInbound(buf: java.nio.ByteBuffer, offsets: Array[Long], n: Int,
+                                                  fields: Array[Int], valueOff: Array[Long],
+                                                  badIndex: Array[Int]): Int
+  @native def wireMenciusDecodeAcceptorInbound(buf: java.nio.ByteBuffer, offsets: Array[Long], n: Int,
+                                               fields: Array[Int], valueOff: Array[Long], badIndex: Array[Int]): Int
+  @native def wireMenciusEncodeLeaderNack(out: java.nio.ByteBuffer, round: Int): Long
+  // EPaxos on the wire (epaxos/EPaxos.proto ReplicaInbound): fields = kind | instanceLeader | instanceNumber |
+  // ballotOrdering | ballotReplica | replicaIndex | sequenceNumber | voteBallotOrdering | voteBallotReplica | status |
+  // isNoop | cmdLen | depsNumReplicas (13 x n); explicit ids of message i: values[valuesOff(i) .. valuesOff(i + 1))
+  // (leaders) and the same range behind valuesCap (ids)
+  @native def wireEpaxosDecodeReplicaInbound(buf: java.nio.ByteBuffer, offsets: Array[Long], n: Int, maxReplicas: Int,
+                                             fields: Array[Int], cmdOff: Array[Long], depsWatermark: Array[Int],
+                                             valuesOff: Array[Long], valuesCap: Int, values: Array[Int],
+                                             badIndex: Array[Int]): Int
+  // head = kind | instanceLeader | instanceNumber | ballotOrdering | ballotReplica | replicaIndex | sequenceNumber |
+  // voteBallotOrdering | voteBallotReplica | status | isNoop (11 ints)
+  @native def wireEpaxosEncodeReplicaInbound(out: java.nio.ByteBuffer, head: Array[Int], command: java.nio.ByteBuffer,
+                                             commandOff: Long, commandLen: Int, numReplicas: Int,
+                                             depsWatermark: Array[Int], numValues: Int, values: Array[Int]): Long
 
   def check(status: Int, logger: Logger): Unit = status match {
     case OK                       => ()

@@ -455,8 +455,10 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxAccept(JNIEnv* env, jclas
   jbyte* rp = out_buf(replies, 4 * (jlong)m, 1);
   jint* nb = out_buf(nackBallot, m, 4);
   uint8_t* r8 = (uint8_t*)rp;
-  int32_t st = fpx_epx_accept((fpx_epx*)(intptr_t)h, m, l, nu, bo, br, tr, k, (const uint8_t*)is, (const uint8_t*)tg, r8,
-                              r8 ? r8 + m : NULL, r8 ? r8 + 2 * (size_t)m : NULL, nb, r8 ? r8 + 3 * (size_t)m : NULL);
+  int32_t st = (!l || !nu || !bo || !br || !tr || !k || !tg || !is || (replies && !rp) || (nackBallot && !nb))
+                   ? FPX_ENOMEM
+                   : fpx_epx_accept((fpx_epx*)(intptr_t)h, m, l, nu, bo, br, tr, k, (const uint8_t*)is, (const uint8_t*)tg, r8,
+                                    r8 ? r8 + m : NULL, r8 ? r8 + 2 * (size_t)m : NULL, nb, r8 ? r8 + 3 * (size_t)m : NULL);
   put_bytes(env, replies, 4 * (jlong)m, rp); put_ints(env, nackBallot, m, nb);
   free(l); free(nu); free(bo); free(br); free(tr); free(k); free(is); free(tg); free(rp); free(nb);
   return st;
@@ -484,9 +486,12 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxHandlePreaccept(
   jbyte* rp = out_buf(replies, 4 * (jlong)m, 1);
   jint *nb = out_buf(nackBallot, m, 4), *rd = out_buf(replyDeps, mn * numReplicas, 4), *re = out_buf(replyEndTriple, 2 * mn, 4);
   uint8_t* r8 = (uint8_t*)rp;
-  int32_t st = fpx_epx_handle_preaccept((fpx_epx*)(intptr_t)h, m, l, nu, bo, br, k, (const uint8_t*)is, tr, di, de,
-                                        (const uint8_t*)tg, r8, r8 ? r8 + m : NULL, r8 ? r8 + 2 * (size_t)m : NULL,
-                                        r8 ? r8 + 3 * (size_t)m : NULL, nb, rd, re, re ? re + mn : NULL);
+  int32_t st = (!l || !nu || !bo || !br || !k || !di || !is || !tg || (tripleId && !tr) || (depsInValuesEnd && !de) ||
+                (replies && !rp) || (nackBallot && !nb) || (replyDeps && !rd) || (replyEndTriple && !re))
+                   ? FPX_ENOMEM
+                   : fpx_epx_handle_preaccept((fpx_epx*)(intptr_t)h, m, l, nu, bo, br, k, (const uint8_t*)is, tr, di, de,
+                                              (const uint8_t*)tg, r8, r8 ? r8 + m : NULL, r8 ? r8 + 2 * (size_t)m : NULL,
+                                              r8 ? r8 + 3 * (size_t)m : NULL, nb, rd, re, re ? re + mn : NULL);
   put_bytes(env, replies, 4 * (jlong)m, rp); put_ints(env, nackBallot, m, nb);
   put_ints(env, replyDeps, mn * numReplicas, rd); put_ints(env, replyEndTriple, 2 * mn, re);
   free(l); free(nu); free(bo); free(br); free(k); free(tr); free(di); free(de); free(is); free(tg); free(rp); free(nb);
@@ -711,4 +716,157 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxHandlePrepareOks(JNIEnv* 
   put_ints(env, decision, 3 * (jlong)m, d);
   free(l); free(nu); free(bo); free(br); free(po); free(mk); free(d);
   return st;
+}
+
+/* ---- Mencius on the wire (fpx_wire.h, mencius/Mencius.proto) ----------------------------------------------------
+ * a tick of mencius ProxyLeaderInbound byte arrays: fields = kind, slot (slotStartInclusive of a range), slotEnd
+ * (slotEndExclusive, -1 for a single slot), round, isNoop, valueLen, groupIndex, acceptorIndex (8 x n ints) */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_wireMenciusDecodeProxyLeaderInbound(
+    JNIEnv* env, jclass cls, jobject buf, jlongArray offsets, jint n, jintArray fields, jlongArray valueOff,
+    jintArray badIndex) {
+  if (n < 0 || !has(env, offsets, (jlong)n + 1) || !has(env, fields, 8 * (jlong)n) || !opt(env, valueOff, n) ||
+      !opt(env, badIndex, 1))
+    return FPX_EINVAL;
+  if (n == 0) return FPX_OK;
+  jlong* off = in_longs(env, offsets, (jlong)n + 1);
+  int bad = 0;
+  const uint8_t* b = direct(env, buf, 0, &bad);
+  const jlong capacity = b ? (*env)->GetDirectBufferCapacity(env, buf) : -1;
+  if (bad || !b || !off || capacity < 0) {
+    free(off);
+    return FPX_EINVAL;
+  }
+  jint* f = out_buf(fields, 8 * (jlong)n, 4);
+  jlong* vo = (jlong*)calloc((size_t)n, 8);
+  jint bi = -1;
+  const size_t N = (size_t)n;
+  int32_t st = (!f || !vo) ? FPX_ENOMEM
+                           : fpx_wire_mencius_decode_proxy_leader_inbound(b, (int64_t)capacity, (const int64_t*)off, n, f, f + N,
+                                                                          f + 2 * N, f + 3 * N, f + 4 * N, (int64_t*)vo,
+                                                                          f + 5 * N, f + 6 * N, f + 7 * N, &bi);
+  put_ints(env, fields, 8 * (jlong)n, f); put_longs(env, valueOff, n, vo); put_ints(env, badIndex, 1, &bi);
+  free(off); free(f); free(vo);
+  return st;
+}
+
+/* a tick of mencius AcceptorInbound byte arrays (Phase1a / Phase2a / Phase2aNoopRange): fields = kind, slot, slotEnd,
+ * round, isNoop, valueLen, chosenWatermark (7 x n ints) */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_wireMenciusDecodeAcceptorInbound(
+    JNIEnv* env, jclass cls, jobject buf, jlongArray offsets, jint n, jintArray fields, jlongArray valueOff,
+    jintArray badIndex) {
+  if (n < 0 || !has(env, offsets, (jlong)n + 1) || !has(env, fields, 7 * (jlong)n) || !opt(env, valueOff, n) ||
+      !opt(env, badIndex, 1))
+    return FPX_EINVAL;
+  if (n == 0) return FPX_OK;
+  jlong* off = in_longs(env, offsets, (jlong)n + 1);
+  int bad = 0;
+  const uint8_t* b = direct(env, buf, 0, &bad);
+  const jlong capacity = b ? (*env)->GetDirectBufferCapacity(env, buf) : -1;
+  if (bad || !b || !off || capacity < 0) {
+    free(off);
+    return FPX_EINVAL;
+  }
+  jint* f = out_buf(fields, 7 * (jlong)n, 4);
+  jlong* vo = (jlong*)calloc((size_t)n, 8);
+  jint bi = -1;
+  const size_t N = (size_t)n;
+  int32_t st = (!f || !vo) ? FPX_ENOMEM
+                           : fpx_wire_mencius_decode_acceptor_inbound(b, (int64_t)capacity, (const int64_t*)off, n, f, f + N,
+                                                                      f + 2 * N, f + 3 * N, f + 4 * N, (int64_t*)vo, f + 5 * N,
+                                                                      f + 6 * N, &bi);
+  put_ints(env, fields, 7 * (jlong)n, f); put_longs(env, valueOff, n, vo); put_ints(env, badIndex, 1, &bi);
+  free(off); free(f); free(vo);
+  return st;
+}
+
+/* mencius LeaderInbound{Nack} (field 7, not MultiPaxos' 6) */
+JNIEXPORT jlong JNICALL Java_frankenpaxos_gpu_Native_wireMenciusEncodeLeaderNack(JNIEnv* env, jclass cls, jobject out,
+                                                                                 jint round) {
+  int bad = 0;
+  uint8_t* o = direct(env, out, 0, &bad);
+  if (bad || !o) return INT64_MIN;
+  return fpx_wire_mencius_encode_leader_nack(o, (*env)->GetDirectBufferCapacity(env, out), round);
+}
+
+/* ---- EPaxos on the wire (epaxos/EPaxos.proto: ReplicaInbound) ---------------------------------------------------
+ * a tick of ReplicaInbound byte arrays: fields = kind, instanceLeader, instanceNumber, ballotOrdering, ballotReplica,
+ * replicaIndex, sequenceNumber, voteBallotOrdering, voteBallotReplica, status, isNoop, cmdLen, depsNumReplicas
+ * (13 x n ints); cmdOff n longs; depsWatermark n x maxReplicas ints; the explicit ids of message i are
+ * values[valuesOff[i] .. valuesOff[i + 1]) (leader) and values[valuesCap + the same] (id): valuesOff n + 1 longs,
+ * values 2 x valuesCap ints.  FPX_ECAPACITY: valuesOff[n] = the capacity needed, call again. */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_wireEpaxosDecodeReplicaInbound(
+    JNIEnv* env, jclass cls, jobject buf, jlongArray offsets, jint n, jint maxReplicas, jintArray fields,
+    jlongArray cmdOff, jintArray depsWatermark, jlongArray valuesOff, jint valuesCap, jintArray values,
+    jintArray badIndex) {
+  if (n < 0 || maxReplicas < 1 || maxReplicas > 8 || valuesCap < 0 || !has(env, offsets, (jlong)n + 1) ||
+      !has(env, fields, 13 * (jlong)n) || !opt(env, cmdOff, n) || !opt(env, depsWatermark, (jlong)n * maxReplicas) ||
+      !has(env, valuesOff, (jlong)n + 1) || (valuesCap > 0 && !has(env, values, 2 * (jlong)valuesCap)) ||
+      !opt(env, badIndex, 1))
+    return FPX_EINVAL;
+  if (n == 0) return FPX_OK;
+  jlong* off = in_longs(env, offsets, (jlong)n + 1);
+  int bad = 0;
+  const uint8_t* b = direct(env, buf, 0, &bad);
+  const jlong capacity = b ? (*env)->GetDirectBufferCapacity(env, buf) : -1;
+  if (bad || !b || !off || capacity < 0) {
+    free(off);
+    return FPX_EINVAL;
+  }
+  const size_t N = (size_t)n;
+  jint* f = out_buf(fields, 13 * (jlong)n, 4);
+  jlong* co = (jlong*)calloc(N, 8);
+  jint* dw = (jint*)calloc(N * (size_t)maxReplicas, 4);
+  jlong* vo = (jlong*)calloc(N + 1, 8);
+  jint* vals = (jint*)calloc(2 * (size_t)valuesCap + 1, 4);
+  jint bi = -1;
+  int32_t st = (!f || !co || !dw || !vo || !vals)
+                   ? FPX_ENOMEM
+                   : fpx_wire_epaxos_decode_replica_inbound(b, (int64_t)capacity, (const int64_t*)off, n, maxReplicas, f, f + N,
+                                                            f + 2 * N, f + 3 * N, f + 4 * N, f + 5 * N, f + 6 * N, f + 7 * N,
+                                                            f + 8 * N, f + 9 * N, f + 10 * N, (int64_t*)co, f + 11 * N,
+                                                            f + 12 * N, dw, (int64_t*)vo, (int64_t)valuesCap, vals,
+                                                            vals + valuesCap, &bi);
+  put_ints(env, fields, 13 * (jlong)n, f); put_longs(env, cmdOff, n, co);
+  put_ints(env, depsWatermark, (jlong)n * maxReplicas, dw); put_longs(env, valuesOff, (jlong)n + 1, vo);
+  put_ints(env, values, 2 * (jlong)valuesCap, vals); put_ints(env, badIndex, 1, &bi);
+  free(off); free(f); free(co); free(dw); free(vo); free(vals);
+  return st;
+}
+
+/* ONE ReplicaInbound into a direct buffer.  head = kind, instanceLeader, instanceNumber, ballotOrdering, ballotReplica,
+ * replicaIndex, sequenceNumber (-1: absent), voteBallotOrdering, voteBallotReplica, status, isNoop (-1: no
+ * CommandOrNoop) (11 ints); command = the serialised CommandOrNoop (direct, commandLen bytes at commandOff);
+ * numReplicas < 0: no dependencies, else depsWatermark[numReplicas] and the explicit ids values = leader[numValues] |
+ * id[numValues].  Returns the length, the negated length needed, or Long.MinValue on a bad argument. */
+JNIEXPORT jlong JNICALL Java_frankenpaxos_gpu_Native_wireEpaxosEncodeReplicaInbound(
+    JNIEnv* env, jclass cls, jobject out, jintArray head, jobject command, jlong commandOff, jint commandLen,
+    jint numReplicas, jintArray depsWatermark, jint numValues, jintArray values) {
+  const jlong BAD = INT64_MIN;
+  if (!has(env, head, 11) || numValues < 0 || commandLen < 0 || commandOff < 0 ||
+      (numReplicas > 0 && !has(env, depsWatermark, numReplicas)) || (numValues > 0 && !has(env, values, 2 * (jlong)numValues)))
+    return BAD;
+  int bad = 0;
+  uint8_t* o = direct(env, out, 0, &bad);
+  const uint8_t* cmd = direct(env, command, 0, &bad);
+  if (bad || !o) return BAD;
+  if (commandLen > 0 && (!cmd || commandOff + commandLen > (*env)->GetDirectBufferCapacity(env, command))) return BAD;
+  jint h[11];
+  (*env)->GetIntArrayRegion(env, head, 0, 11, h);
+  jint* dw = in_ints(env, depsWatermark, numReplicas);
+  jint* vals = in_ints(env, values, 2 * (jlong)numValues);
+  if ((numReplicas > 0 && !dw) || (numValues > 0 && !vals)) {
+    free(dw); free(vals);
+    return BAD;
+  }
+  fpx_wire_epx_msg m;
+  memset(&m, 0, sizeof(m));
+  m.kind = h[0], m.instance_leader = h[1], m.instance_number = h[2], m.ballot_ordering = h[3], m.ballot_replica = h[4];
+  m.replica_index = h[5], m.sequence_number = h[6], m.has_sequence_number = h[6] >= 0;
+  m.vote_ballot_ordering = h[7], m.vote_ballot_replica = h[8], m.status = h[9], m.is_noop = h[10];
+  m.command = cmd ? cmd + commandOff : NULL, m.command_len = commandLen;
+  m.num_replicas = numReplicas, m.deps_watermark = dw, m.num_values = numValues;
+  m.values_leader = vals, m.values_id = vals ? vals + numValues : NULL;
+  const jlong len = fpx_wire_epaxos_encode_replica_inbound(o, (*env)->GetDirectBufferCapacity(env, out), &m);
+  free(dw); free(vals);
+  return len;
 }

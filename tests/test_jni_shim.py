@@ -429,3 +429,318 @@ def test_a_leader_change_on_wire_bytes_through_the_shim(jvm, oracle):
     # a short array is refused before native code touches it
     assert jvm.call("acceptorPhase1bInfo", C.c_int32, h, 0, 0, 0, 16, sl, vr, vv) == -1
     assert jvm.call("destroy", C.c_int32, h) == 0
+
+
+def _direct(jvm, b):
+    d = C.c_void_p(jvm.lib.mock_new_direct(max(1, len(b))))
+    if len(b):
+        C.memmove(jvm.lib.mock_data(d), bytes(b), len(b))
+    return d
+
+
+def _dbytes(jvm, d, n):
+    return bytes(np.ctypeslib.as_array(C.cast(jvm.lib.mock_data(d), C.POINTER(C.c_uint8)), (n,)))
+
+
+@pytest.mark.gpu
+def test_a_mencius_leader_change_on_wire_bytes_through_the_shim(jvm, oracle):
+    """What the unchanged mencius Leaders drive (mencius/Leader.scala:342-345, 455, 486-491, 288-297), on wire bytes,
+    through the natives GpuMenciusAcceptor / GpuMenciusProxyLeader call (frankenpaxos_amd/jni/MenciusNative.scala).
+    2 leader groups x 2 acceptor groups x 3 acceptors (f = 1), 2 leaders per group:
+      1. the leaders of both groups run Phase 1 in round 0: Phase1a to every acceptor address of their group
+      2. a burst: group 0 proposes commands in its slots, group 1 skips its slots with a noop range, then proposes
+      3. in group 1 leader 1 takes over: Phase1a(round 1, chosenWatermark 9) reaches two acceptors of each of its
+         acceptor groups -> Phase1b with the group's votes from the watermark on (noops of the range included)
+      4. the old leader of group 1, unaware, sends a command and a noop range in round 0: the acceptors that promised
+         Nack with round 1 (LeaderInbound field 7), nothing is chosen; group 0 is not disturbed
+      5. the new leader's re-proposals and a noop range in round 1 are chosen
+    Every integer equals the oracle fed the same calls; every byte string equals the python codec (pinned on
+    google.protobuf, tests/test_wire.py)."""
+    from frankenpaxos_amd import wire
+
+    S, R, A, L = 1024, 3, 2, 2
+    cfg = np.array([S, R, A, L, 1, 0, 0, 0, 2, 0, 8, 0, 0, 0, 0], np.int32)
+    h = jvm.call("create", C.c_int64, jvm.arr(cfg))
+    assert h > 0
+    ref = oracle.System(oracle.make_config(num_slots=S, num_replicas=R, num_groups=A, num_leader_groups=L, f=1,
+                                           tally_ways=8, num_leaders=2))
+    i32 = lambda a: jvm.arr(np.asarray(a, np.int32))
+    payload = {}
+    group_of = lambda slot: (slot % L) * A + (slot // L) % A       # mencius/ProxyLeader.scala:169-176, 231-234
+
+    def phase1a_at(group, acceptor, msg):
+        """mencius AcceptorInbound{Phase1a} bytes at one acceptor address -> the LeaderInbound bytes it answers with"""
+        buf, off = wire.pack([msg])
+        fields, bad = jvm.arr(np.zeros(7, np.int32)), jvm.arr(np.zeros(1, np.int32))
+        assert jvm.call("wireMenciusDecodeAcceptorInbound", C.c_int32, _direct(jvm, buf), jvm.arr(off), 1, fields, None, bad) == 0
+        kind, _, _, rnd, _, _, wm = jvm.read(fields, np.int32, 7).tolist()
+        assert kind == wire.PHASE1A
+        bits = jvm.arr(np.zeros(8, np.int64))
+        tgt = oracle.bits_of([acceptor])
+        assert jvm.call("acceptorPhase1a", C.c_int32, h, group, rnd, wm, jvm.arr(tgt.view(np.int64)), bits) == 0
+        st, pb, nb = ref.acceptor_phase1a(group, rnd, wm, tgt)
+        got = jvm.read(bits, np.int64, 8).view(np.uint64)
+        assert st == 0 and got[:4].tolist() == pb.tolist() and got[4:].tolist() == nb.tolist()
+        out = _direct(jvm, b"\0" * 65536)
+        if nb.any():                                  # mencius/Acceptor.scala:173-180
+            cur = jvm.call("acceptorRound", C.c_int32, h, group, acceptor)
+            assert cur == ref.read_acceptor(group, acceptor)[0]
+            n = jvm.call("wireMenciusEncodeLeaderNack", C.c_int64, out, cur)
+            assert _dbytes(jvm, out, n) == wire.mencius_encode("leader_nack", cur)
+            return _dbytes(jvm, out, n)
+        cap = 1024                                    # mencius/Acceptor.scala:184-199
+        sl, vr, vv = (jvm.arr(np.zeros(cap, np.int32)) for _ in range(3))
+        k = jvm.call("acceptorPhase1bInfo", C.c_int32, h, group, acceptor, wm, cap, sl, vr, vv)
+        want = ref.acceptor_phase1b_info(group, acceptor, wm)
+        assert k == len(want[0])
+        sl, vr, vv = (jvm.read(x, np.int32, k) for x in (sl, vr, vv))
+        for a, b in zip((sl, vr, vv), want):
+            np.testing.assert_array_equal(a, b)
+        blobs = [payload[int(v)] if v >= 0 else b"" for v in vv]
+        vbuf, voff = wire.pack(blobs)
+        noop = jvm.arr((vv < 0).astype(np.int8)) if k else None
+        n = jvm.call("wireEncodeLeaderPhase1b", C.c_int64, out, group % A, acceptor, rnd, k, i32(sl), i32(vr), _direct(jvm, vbuf),
+                     jvm.arr(voff[:-1] if k else np.zeros(1, np.int64)), i32(np.diff(voff) if k else [0]), noop)
+        assert n > 0
+        info = [(int(s), int(r), (None if v < 0 else payload[int(v)])) for s, r, v in zip(sl, vr, vv)]
+        assert _dbytes(jvm, out, n) == wire.encode_leader_phase1b(group % A, acceptor, rnd, info)   # (the same layout as MultiPaxos')
+        return _dbytes(jvm, out, n)
+
+    def burst(msgs, targets=None):
+        """mencius ProxyLeaderInbound bytes (Phase2a and Phase2aNoopRange, in arrival order) -> what the proxy leader sends:
+        ReplicaInbound bytes (Chosen / ChosenNoopRange) and (leader group, leader, LeaderInbound{Nack} bytes)"""
+        buf, off = wire.pack(msgs)
+        n = len(msgs)
+        fields, voff, bad = jvm.arr(np.zeros(8 * n, np.int32)), jvm.arr(np.zeros(n, np.int64)), jvm.arr(np.zeros(1, np.int32))
+        assert jvm.call("wireMenciusDecodeProxyLeaderInbound", C.c_int32, _direct(jvm, buf), jvm.arr(off), n, fields, voff, bad) == 0
+        f = jvm.read(fields, np.int32, 8 * n).reshape(8, n)
+        vo = jvm.read(voff, np.int64, n)
+        want = wire.mencius_decode_proxy_leader_inbound(msgs)
+        for j, name in enumerate(("kind", "slot", "slot_end", "round", "is_noop", "value_len", "group_index", "acceptor_index")):
+            np.testing.assert_array_equal(f[j], want[name], err_msg=name)
+        sent, nacked = [], []
+        # maximal runs of one kind, in arrival order (GpuMenciusProxyLeader.flushTick)
+        i = 0
+        while i < n:
+            j = i
+            while j < n and f[0][j] == f[0][i]:
+                j += 1
+            idx = np.arange(i, j)
+            if f[0][i] == wire.PHASE2A:
+                slot, rnd = f[1][idx].copy(), f[3][idx].copy()
+                val = np.zeros(len(idx), np.int32)
+                for k, m in enumerate(idx):
+                    if f[4][m]:
+                        val[k] = -1
+                    else:
+                        val[k] = len(payload)
+                        payload[int(val[k])] = bytes(buf[vo[m]:vo[m] + f[5][m]])
+                tgt = None if targets is None else np.tile(targets, (len(idx), 1))
+                ch, cr, cv, nr = (jvm.arr(np.zeros(len(idx), t)) for t in (np.int8, np.int32, np.int32, np.int32))
+                assert jvm.call("phase2Fused", C.c_int32, h, len(idx), i32(slot), i32(rnd), i32(val),
+                                None if tgt is None else jvm.arr(tgt.view(np.int64)), ch, cr, cv, nr) == 0
+                st, ch_r, cr_r, cv_r, nr_r = ref.phase2_fused(slot, rnd, val, tgt)
+                ch, cv, nr = jvm.read(ch, np.int8, len(idx)), jvm.read(cv, np.int32, len(idx)), jvm.read(nr, np.int32, len(idx))
+                assert st == 0
+                np.testing.assert_array_equal(ch, ch_r.astype(np.int8))
+                np.testing.assert_array_equal(cv, cv_r)
+                np.testing.assert_array_equal(nr, nr_r)
+                for k in range(len(idx)):
+                    if ch[k]:
+                        sent.append(wire.mencius_encode("replica_chosen", int(slot[k]), None if cv[k] < 0 else payload[int(cv[k])]))
+                    if nr[k] >= 0:
+                        nacked.append((int(slot[k]) % L, jvm.call("roundLeader", C.c_int32, 2, int(rnd[k])), wire.mencius_encode("leader_nack", int(nr[k]))))
+            else:
+                assert f[0][i] == wire.PHASE2A_NOOP_RANGE
+                m = len(idx)
+                start, end, rnd = f[1][idx].copy(), f[2][idx].copy(), f[3][idx].copy()
+                tm = None if targets is None else np.tile(targets, (m, A, 1))
+                votes, nacks = jvm.arr(np.zeros(m * A * 4, np.int64)), jvm.arr(np.zeros(m * A * 4, np.int64))
+                nr, isnew, chosen = jvm.arr(np.zeros(m, np.int32)), jvm.arr(np.zeros(m, np.int8)), jvm.arr(np.zeros(m, np.int8))
+                assert jvm.call("noopRangesFused", C.c_int32, h, m, A, i32(start), i32(end), i32(rnd),
+                                None if tm is None else jvm.arr(tm.reshape(-1).view(np.int64)), votes, nacks, nr, isnew, chosen) == 0
+                st, vb_r, nb_r, nr_r, new_r, ch_r = ref.noop_ranges_fused(start, end, rnd, tm)
+                assert st == 0
+                np.testing.assert_array_equal(jvm.read(votes, np.int64, m * A * 4).view(np.uint64).reshape(m, A, 4), vb_r)
+                np.testing.assert_array_equal(jvm.read(nr, np.int32, m), nr_r)
+                ch = jvm.read(chosen, np.int8, m)
+                np.testing.assert_array_equal(ch, ch_r.astype(np.int8))
+                for k in range(m):
+                    if ch[k]:
+                        sent.append(wire.mencius_encode("replica_chosen_noop_range", int(start[k]), int(end[k])))
+                    if nr_r[k] >= 0:
+                        nacked.append((int(start[k]) % L, jvm.call("roundLeader", C.c_int32, 2, int(rnd[k])), wire.mencius_encode("leader_nack", int(nr_r[k]))))
+            i = j
+        return sent, nacked
+
+    cmd = lambda s, tag: bytes.fromhex("0a") + bytes([len(b"%s %d" % (tag, s))]) + b"%s %d" % (tag, s)
+    p2a = lambda s, r, tag: wire.mencius_encode("proxy_leader_phase2a", s, r, cmd(s, tag))
+    rng = lambda a, b, r: wire.mencius_encode("proxy_leader_phase2a_noop_range", a, b, r)
+    # 1: Phase 1 in round 0, everywhere
+    for lg in range(L):
+        for ag in range(A):
+            for a in range(R):
+                reply = phase1a_at(lg * A + ag, a, wire.mencius_encode("acceptor_phase1a", 0, 0))
+                assert reply.hex() == "0a06" + "08%02x" % ag + "10%02x" % a + "1800"
+    # 2: group 0 proposes in slots 0, 2, .. 38; group 1 skips slots 1 .. 19 (a range), then proposes 21 .. 39
+    msgs = ([p2a(s, 0, b"set") for s in range(0, 40, 2)][:10] + [rng(1, 21, 0)] + [p2a(s, 0, b"set") for s in range(20, 40, 2)] +
+            [p2a(s, 0, b"set") for s in range(21, 41, 2)])
+    sent, nacked = burst(msgs)
+    assert len(sent) == 10 + 1 + 10 + 10 and not nacked
+    d = wire.mencius_decode_replica_inbound(sent)
+    assert d["kind"].tolist().count(wire.CHOSEN_NOOP_RANGE) == 1 and d["slot"][10] == 1 and d["slot_end"][10] == 21
+    # 3: leader 1 of group 1 starts Phase 1 in round 1 with two acceptors of each of the group's acceptor groups
+    for ag in range(A):
+        for a in (0, 1):
+            d = wire.decode_leader_inbound([phase1a_at(1 * A + ag, a, wire.mencius_encode("acceptor_phase1a", 1, 9))])
+            assert d["kind"].tolist() == [wire.PHASE1B] and d["round"].tolist() == [1] and d["group_index"].tolist() == [ag]
+            slots = d["info_slot"].tolist()
+            assert slots == [s for s in range(9, 41, 2) if group_of(s) == A + ag] and set(d["info_vote_round"].tolist()) == {0}
+    # 4: the old leader of group 1 (round 0) and group 0 (undisturbed), dense delivery
+    sent, nacked = burst([p2a(41, 0, b"stale"), rng(43, 61, 0), p2a(40, 0, b"set"), p2a(42, 0, b"set")])
+    assert [wire.mencius_decode_replica_inbound([x])["slot"][0] for x in sent] == [40, 42]
+    assert nacked == [(1, 0, bytes.fromhex("3a020801"))] * 2                     # LeaderInbound.nack = field 7, Nack(round 1)
+    # 5: the new leader finishes Phase 1 with everybody, re-proposes what the acceptors reported beyond the watermark, and
+    #    skips on in its round
+    for ag in range(A):
+        phase1a_at(1 * A + ag, 2, wire.mencius_encode("acceptor_phase1a", 1, 9))
+    sent, nacked = burst([p2a(41, 1, b"stale"), rng(43, 61, 1), p2a(61, 1, b"set")])   # (slot 41: the value acceptor 2 voted for)
+    assert len(sent) == 3 and not nacked
+    d = wire.mencius_decode_replica_inbound(sent)
+    assert d["slot"].tolist() == [41, 43, 61] and d["slot_end"].tolist() == [-1, 61, -1]
+    np.testing.assert_array_equal(np.asarray(ref.state_digest()), np.asarray(_digest(jvm, h)))
+    assert jvm.call("destroy", C.c_int32, h) == 0
+
+
+def _digest(jvm, h):
+    import frankenpaxos_amd as fa
+    out = (C.c_uint64 * 8)()
+    assert fa.lib().fpx_state_digest(C.c_void_p(h), out) == 0
+    return list(out)
+
+
+@pytest.mark.gpu
+def test_an_epaxos_slow_path_commit_on_wire_bytes_through_the_shim(jvm, oracle):
+    """Two conflicting commands led by different replicas meet at one replica in the other order: the PreAcceptOks of
+    instance A differ, its leader takes the slow path (epaxos/Replica.scala:1291-1419, 796-813) -- Accept, AcceptOk, Commit.
+    Every message between the replica addresses crosses as ReplicaInbound BYTES: encoded by wireEpaxosEncodeReplicaInbound,
+    decoded by wireEpaxosDecodeReplicaInbound, handled by the natives GpuEPaxosReplica batches a tick onto
+    (epxHandlePreaccept = Replica.handlePreAccept :1159-1289, epxAccept = transitionToAcceptPhase + handleAccept +
+    handleAcceptOk :732-792, 1421-1565).  n = 5 (f = 2), all five replicas hosted by one libfpx context.  Every integer
+    equals the oracle fed the same calls, every byte string the python codec (pinned on google.protobuf)."""
+    from frankenpaxos_amd import wire
+
+    n, keys, NI = 5, 4, 16
+    h = jvm.call("epxCreateWithLog", C.c_int64, n, keys, 0, NI)
+    assert h > 0
+    ref = oracle.EPaxos(n, keys, num_instances=NI)
+    i32 = lambda a: jvm.arr(np.asarray(a, np.int32))
+    i8 = lambda a: jvm.arr(np.asarray(a, np.int8))
+    command = {7: bytes.fromhex("0a0b") + b"set k1 = 07", 9: bytes.fromhex("0a0b") + b"set k1 = 09"}   # triple id -> CommandOrNoop
+
+    def enc(kind, instance, ballot=(-1, -1), replica_index=-1, seq=-1, triple=None, deps=None, values=()):
+        """through the native; == the python codec"""
+        head = i32([kind, instance[0], instance[1], ballot[0], ballot[1], replica_index, seq, -1, -1, -1,
+                    -1 if triple is None else 0])
+        cmd = command[triple] if triple is not None else b""
+        out = _direct(jvm, b"\0" * 512)
+        vals = i32([v[0] for v in values] + [v[1] for v in values]) if values else None
+        ln = jvm.call("wireEpaxosEncodeReplicaInbound", C.c_int64, out, head, _direct(jvm, cmd), 0, len(cmd),
+                      -1 if deps is None else n, None if deps is None else i32(deps), len(values), vals)
+        assert ln > 0
+        got = _dbytes(jvm, out, ln)
+        assert got == wire.epaxos_encode(kind, instance, ballot, replica_index, None if seq < 0 else seq,
+                                         command=False if triple is None else cmd, deps=deps, values=values)
+        return got
+
+    def dec(msgs):
+        """through the native; == the python codec"""
+        buf, off = wire.pack(msgs)
+        k = len(msgs)
+        fields, co, dw = jvm.arr(np.zeros(13 * k, np.int32)), jvm.arr(np.zeros(k, np.int64)), jvm.arr(np.zeros(k * n, np.int32))
+        vo, vals, bad = jvm.arr(np.zeros(k + 1, np.int64)), jvm.arr(np.zeros(2 * 16, np.int32)), jvm.arr(np.zeros(1, np.int32))
+        assert jvm.call("wireEpaxosDecodeReplicaInbound", C.c_int32, _direct(jvm, buf), jvm.arr(off), k, n, fields, co, dw, vo, 16, vals, bad) == 0
+        f = jvm.read(fields, np.int32, 13 * k).reshape(13, k)
+        want = wire.epaxos_decode_replica_inbound(msgs, max_replicas=n)
+        for j, name in enumerate(("kind", "instance_leader", "instance_number", "ballot_ordering", "ballot_replica", "replica_index",
+                                  "sequence_number", "vote_ballot_ordering", "vote_ballot_replica", "status", "is_noop", "cmd_len",
+                                  "deps_num_replicas")):
+            np.testing.assert_array_equal(f[j], want[name], err_msg=name)
+        deps = jvm.read(dw, np.int32, k * n).reshape(k, n)
+        np.testing.assert_array_equal(deps, want["deps_watermark"])
+        return f, deps, jvm.read(co, np.int64, k), buf
+
+    def preaccept_at(msg, targets, key, triple):
+        """a PreAccept's bytes delivered to the replicas `targets` -> {replica: PreAcceptOk bytes}"""
+        f, deps, co, buf = dec([msg])
+        assert f[0][0] == wire.EPX_PRE_ACCEPT and bytes(buf[co[0]:co[0] + f[11][0]]) == command[triple]
+        L, x, bo, br = (int(f[j][0]) for j in (1, 2, 3, 4))
+        mask = sum(1 << r for r in targets)
+        rep, nb = jvm.arr(np.zeros(4, np.int8)), jvm.arr(np.zeros(1, np.int32))
+        rd, ret = jvm.arr(np.zeros(n * n, np.int32)), jvm.arr(np.zeros(2 * n, np.int32))
+        assert jvm.call("epxHandlePreaccept", C.c_int32, h, 1, n, i32([L]), i32([x]), i32([bo]), i32([br]), i32([key]), i8([1]),
+                        i32([triple]), i32(deps[0]), i32([0]), i8([mask]), rep, nb, rd, ret) == 0
+        want = ref.handle_preaccept([L], [x], [bo], [br], [key], [1], [triple], deps[:1], [0], [mask])
+        assert want[0] == 0
+        got = jvm.read(rep, np.int8, 4).view(np.uint8).tolist()
+        assert got == [int(want[k][0]) for k in (1, 2, 3, 4)] and got[0] == mask        # every target processed it
+        reply_deps = jvm.read(rd, np.int32, n * n).reshape(n, n)
+        np.testing.assert_array_equal(reply_deps, want[6][0])
+        ends = jvm.read(ret, np.int32, 2 * n)[:n]
+        np.testing.assert_array_equal(ends, want[7][0])
+        assert not ends.any()
+        return {r: enc(wire.EPX_PRE_ACCEPT_OK, (L, x), (bo, br), replica_index=r, seq=0, deps=reply_deps[r].tolist()) for r in targets}
+
+    A, B = (0, 0), (4, 0)
+    none = [0] * n
+    # the two leaders pre-accept their own instances (transitionToPreAcceptPhase: conflicts in THEIR index, none yet)
+    own_a = preaccept_at(enc(wire.EPX_PRE_ACCEPT, A, (0, 0), seq=0, triple=7, deps=none), [0], 1, 7)
+    own_b = preaccept_at(enc(wire.EPX_PRE_ACCEPT, B, (0, 4), seq=0, triple=9, deps=none), [4], 1, 9)
+    d_a = dec([own_a[0]])[1][0].tolist()
+    d_b = dec([own_b[4]])[1][0].tolist()
+    assert d_a == none and d_b == none
+    # B's PreAccept reaches replica 1 first ...
+    ok_b = preaccept_at(enc(wire.EPX_PRE_ACCEPT, B, (0, 4), seq=0, triple=9, deps=d_b), [1], 1, 9)
+    assert dec([ok_b[1]])[1][0].tolist() == none
+    # ... then A's reaches replicas 1, 2, 3: replica 1 already holds B, which conflicts (two sets of one key)
+    ok_a = preaccept_at(enc(wire.EPX_PRE_ACCEPT, A, (0, 0), seq=0, triple=7, deps=d_a), [1, 2, 3], 1, 7)
+    f, answers, _, _ = dec([ok_a[r] for r in (1, 2, 3)])
+    assert f[0].tolist() == [wire.EPX_PRE_ACCEPT_OK] * 3 and f[5].tolist() == [1, 2, 3]
+    assert answers[0].tolist() == [0, 0, 0, 0, 1] and answers[1].tolist() == none and answers[2].tolist() == none
+    # Replica.handlePreAcceptOk (:1376-1419): n - 2 = 3 answers, not all equal -> preAcceptingSlowPath: the union, Accept
+    union = np.maximum.reduce([answers[0], answers[1], answers[2], np.asarray(d_a)]).tolist()
+    assert union == [0, 0, 0, 0, 1]
+    accept = enc(wire.EPX_ACCEPT, A, (0, 0), seq=0, triple=7, deps=union)
+    f, deps, co, buf = dec([accept])
+    assert f[0][0] == wire.EPX_ACCEPT and deps[0].tolist() == union
+    rep4, nb = jvm.arr(np.zeros(4, np.int8)), jvm.arr(np.zeros(1, np.int32))
+    # to f = 2 other replicas: with the proposer's own vote that is the slow quorum f + 1
+    assert jvm.call("epxAccept", C.c_int32, h, 1, i32([0]), i32([0]), i32([0]), i32([0]), i32([7]), i32([1]), i8([1]),
+                    i8([0b00110]), rep4, nb) == 0
+    want = ref.accept([0], [0], [0], [0], [7], [0b00110], [1], [1])
+    got = jvm.read(rep4, np.int8, 4).view(np.uint8).tolist()
+    assert want[0] == 0 and got == [int(want[k][0]) for k in (1, 2, 3, 5)]
+    assert got[0] == 0b00111 and got[3] == 1                  # the proposer's own vote + two AcceptOks = f + 1: committed
+    oks = [enc(wire.EPX_ACCEPT_OK, A, (0, 0), replica_index=r) for r in (1, 2)]
+    f, _, _, _ = dec(oks)
+    assert f[0].tolist() == [wire.EPX_ACCEPT_OK] * 2 and f[5].tolist() == [1, 2]
+    commit = enc(wire.EPX_COMMIT, A, seq=0, triple=7, deps=union)
+    f, deps, _, _ = dec([commit])
+    assert f[0][0] == wire.EPX_COMMIT and deps[0].tolist() == union
+    # the command logs and the conflict indices of all five replicas == the oracle's
+    entry = jvm.arr(np.zeros(6 + n, np.int32))
+    for inst in (A, B):
+        for r in range(n):
+            assert jvm.call("epxReadCmdlog", C.c_int32, h, n, r, inst[0], inst[1], entry) == 0
+            got = jvm.read(entry, np.int32, 6 + n)
+            assert tuple(got[:5]) == ref.read_cmdlog(r, *inst)
+            dd, end = ref.read_cmdlog_deps(r, *inst)
+            assert got[5:5 + n].tolist() == dd.tolist() and got[5 + n] == end
+    assert ref.read_cmdlog(3, *A)[0] == 4 and ref.read_cmdlog(0, *A)[0] == 4         # CommittedEntry everywhere
+    import frankenpaxos_amd as fa
+    for r in range(n):
+        gg, ss = (C.c_int32 * n)(), (C.c_int32 * n)()
+        assert fa.lib().fpx_epx_read_index(C.c_void_p(h), r, 1, gg, ss) == 0
+        g2, s2 = ref.read_index(r, 1)
+        assert list(gg) == g2.tolist() and list(ss) == s2.tolist()
+    assert jvm.call("epxDestroy", C.c_int32, h) == 0
