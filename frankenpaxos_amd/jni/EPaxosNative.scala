@@ -1,0 +1,217 @@
+// EPaxosNative.scala -- the EPaxos part of the reference-side binding (source only, like Native.scala: no JDK / scalac in
+// this image).  Drop into jvm/src/main/scala/frankenpaxos/gpu/ next to Native.scala.
+//
+//   GpuEPaxosEngine    ONE libfpx EPaxos context = the conflict indices and command logs of ALL n replicas, for a
+//                      deployment whose replicas run in one process on the GPU box (one Transport event loop).
+//   GpuEPaxosReplica   stands at ONE replica address (epaxos/ReplicaMain.scala); every replica address gets one, all over
+//                      the same engine.  `receive` (epaxos/Replica.scala:1081-1119) only enqueues; one zero-delay
+//                      Transport timer per burst flushes the queue, one native call per kind of message:
+//                        ClientRequest  -> a pre-accept tick (Native.epxPreaccept: transitionToPreAcceptPhase at the
+//                                          leaders, handlePreAccept at the others, handlePreAcceptOk -- K5), then
+//                                          Native.epxAccept for the commands that took the slow path (K6), then Commit
+//                        PreAccept      -> Native.epxHandlePreaccept (K7: a re-sent PreAccept, a recovering replica's)
+//                        Accept         -> Native.epxAccept           Prepare -> Native.epxPrepare
+//                      and `send`s what the Scala handlers would have sent.  Between hosted replicas nothing crosses the
+//                      transport: the PreAccept / PreAcceptOk / Accept / AcceptOk of a tick are the kernels' own traffic.
+//
+// The same natives driven on wire bytes -- two conflicting commands met in different orders, differing PreAcceptOks, the
+// slow path, Accept, AcceptOk, Commit -- against the oracle: tests/test_jni_shim.py::test_an_epaxos_slow_path_commit_...
+//
+// Scope (DESIGN.md section 8): single-key get / set commands of the key-value store (statemachine/KeyValueStore.scala),
+// top-one dependencies, sequence number 0; the leader-side recovery timers (Replica.scala:1021-1078) stay with a
+// reference Replica if one is wanted -- Prepare / PrepareOk are answered here, not originated.
+package frankenpaxos.gpu
+
+import frankenpaxos.Actor
+import frankenpaxos.Logger
+import frankenpaxos.epaxos._
+import frankenpaxos.statemachine.{GetRequest, KeyValueStoreInput, SetRequest}
+import scala.collection.mutable
+
+class GpuEPaxosEngine[Transport <: frankenpaxos.Transport[Transport]](
+    logger: Logger,
+    config: Config[Transport],
+    numKeys: Int = 1 << 10,
+    numInstances: Int = 1 << 20          // instances (leader, number < numInstances) the command logs hold
+) {
+  val n: Int = config.n
+  val handle: Long = Native.epxCreateWithLog(n, numKeys, 0, numInstances)
+  if (handle < 0) Native.check((-handle).toInt, logger)
+
+  // a command's triple id is its index here (the GPU carries the int32; Accept and Commit name a triple by it)
+  val triples = mutable.ArrayBuffer[CommandOrNoop]()
+  val depsOf = mutable.Map[(Int, Int), Array[Int]]()        // instance -> the dependency watermarks it committed with
+  val nextNumber: Array[Int] = Array.fill(n)(0)             // Replica.nextAvailableInstance, per hosted leader
+  private val keyIds = mutable.Map[String, Int]()
+  def keyOf(k: String): Int = keyIds.getOrElseUpdate(k, { logger.check(keyIds.size < numKeys); keyIds.size })
+
+  // (key id, is set) of a key-value-store command; anything else is outside the device's conflict model
+  def classify(c: Command): (Int, Boolean) =
+    KeyValueStoreInput.parseFrom(c.command.toByteArray).request match {
+      case KeyValueStoreInput.Request.GetRequest(GetRequest(Seq(k)))             => (keyOf(k), false)
+      case KeyValueStoreInput.Request.SetRequest(SetRequest(Seq(kv)))            => (keyOf(kv.key), true)
+      case _ => logger.fatal("GpuEPaxosEngine: single-key get / set commands only (DESIGN.md section 8).")
+    }
+
+  def close(): Unit = Native.check(Native.epxDestroy(handle), logger)
+}
+
+class GpuEPaxosReplica[Transport <: frankenpaxos.Transport[Transport]](
+    address: Transport#Address,
+    transport: Transport,
+    logger: Logger,
+    config: Config[Transport],
+    engine: GpuEPaxosEngine[Transport]
+) extends Actor(address, transport, logger) {
+  override type InboundMessage = ReplicaInbound
+  override val serializer = ReplicaInboundSerializer
+
+  private val n = config.n
+  private val index = config.replicaAddresses.indexOf(address)
+  logger.check(index >= 0)
+  private val replicas = for (a <- config.replicaAddresses) yield chan[Replica[Transport]](a, Replica.serializer)
+
+  private val requests = mutable.Buffer[(Transport#Address, ClientRequest)]()
+  private val preAccepts = mutable.Buffer[(Transport#Address, PreAccept)]()
+  private val accepts = mutable.Buffer[(Transport#Address, Accept)]()
+  private val prepares = mutable.Buffer[(Transport#Address, Prepare)]()
+  private var queued = 0
+  private val tick = timer("gpuEPaxosTick", java.time.Duration.ZERO, () => flushTick())
+  private def enqueue[T](q: mutable.Buffer[T], x: T): Unit = { if (queued == 0) tick.start(); q += x; queued += 1 }
+
+  override def receive(src: Transport#Address, inbound: ReplicaInbound): Unit = {
+    import ReplicaInbound.Request
+    inbound.request match {
+      case Request.ClientRequest(r) => enqueue(requests, (src, r))
+      case Request.PreAccept(r)     => enqueue(preAccepts, (src, r))
+      case Request.Accept(r)        => enqueue(accepts, (src, r))
+      case Request.Prepare(r)       => enqueue(prepares, (src, r))
+      case Request.Commit(_)        => ()   // a hosted replica's log already holds what the tick committed
+      case Request.PreAcceptOk(_) | Request.AcceptOk(_) | Request.PrepareOk(_) | Request.Nack(_) =>
+        // replies to a leader role: between hosted replicas they never leave the device; from a replica outside, they
+        // belong to a reference Replica that originated the round (see the scope note above)
+        logger.debug("GpuEPaxosReplica: a reply addressed to a leader role this actor does not play.")
+      case Request.Empty => logger.fatal("Empty ReplicaInbound encountered.")
+    }
+  }
+
+  private def bit(r: Int): Byte = (1 << r).toByte
+  private def watermarks(deps: InstancePrefixSetProto): Array[Int] = deps.intPrefixSet.map(_.watermark).toArray
+  private def prefixSet(w: Array[Int], own: Int, valuesEnd: Int, number: Int): InstancePrefixSetProto =
+    InstancePrefixSetProto(numReplicas = n, intPrefixSet = w.indices.map(l =>
+      // the own-leader column carries the explicit ids number + 1 .. valuesEnd - 1 (dependencies.subtractOne, :582)
+      frankenpaxos.compact.IntPrefixSetProto(watermark = w(l), value = if (l == own && valuesEnd > 0) (number + 1 until valuesEnd) else Seq())))
+
+  private def flushTick(): Unit = {
+    // ---- the burst's client requests, led by THIS replica: one pre-accept tick (epaxos/Replica.scala:1121-1157,
+    // 633-729, 1159-1419).  The tick's delivery order at every replica is the arrival order here; the PreAccept goes to
+    // all other replicas (ThriftySystem.NotThrifty, :83), the first n - 2 answers are counted (:1376)
+    val m = requests.size
+    if (m > 0) {
+      val leader = Array.fill(m)(index); val number = new Array[Int](m)
+      val key = new Array[Int](m); val isSet = new Array[Byte](m)
+      val resp = new Array[Byte](m); val seen = new Array[Byte](m)
+      val rank = Array.tabulate(n * m)(i => i % m)
+      val others = (0 until n).filter(_ != index)
+      val counted = others.take(n - 2).map(1 << _).sum.toByte; val all = others.map(1 << _).sum.toByte
+      val first = engine.triples.size
+      for (((_, r), i) <- requests.zipWithIndex) {
+        number(i) = engine.nextNumber(index); engine.nextNumber(index) += 1
+        val (k, set) = engine.classify(r.command); key(i) = k; isSet(i) = if (set) 1 else 0
+        resp(i) = counted; seen(i) = all
+        engine.triples += CommandOrNoop().withCommand(r.command)
+      }
+      val fast = new Array[Byte](m); val deps = new Array[Int](m * n); val ldeps = new Array[Int](m * n); val ends = new Array[Int](2 * m)
+      Native.check(Native.epxPreaccept(engine.handle, m, n, leader, number, key, isSet, resp, seen, rank, fast, deps, ldeps, ends), logger)
+      // the slow path: Accept with the union of the answers (preAcceptingSlowPath :796-813), f other replicas + the proposer
+      val slow = (0 until m).filter(fast(_) == 0).toArray
+      if (slow.nonEmpty) {
+        val k = slow.length
+        val tgt = Array.fill(k)(others.take(config.f).map(1 << _).sum.toByte)
+        val replies = new Array[Byte](4 * k); val nb = new Array[Int](k)
+        Native.check(Native.epxAccept(engine.handle, k, slow.map(leader), slow.map(number), Array.fill(k)(0), Array.fill(k)(index),
+                                      slow.map(first + _), slow.map(key), slow.map(isSet), tgt, replies, nb), logger)
+        for ((i, j) <- slow.zipWithIndex) logger.check(replies(3 * k + j) != 0)   // f + 1 votes: committed (no competing ballot exists)
+      }
+      // commit (:815-860): every replica outside this process learns it; the hosted ones already hold the CommittedEntry
+      for (i <- 0 until m) {
+        val w = deps.slice(i * n, (i + 1) * n)
+        engine.depsOf((index, number(i))) = w
+        val commit = Commit(instance = Instance(index, number(i)), commandOrNoop = engine.triples(first + i), sequenceNumber = 0,
+                            dependencies = prefixSet(w, index, ends(2 * i), number(i)))
+        for ((a, r) <- config.replicaAddresses.zipWithIndex if !hosted(a)) replicas(r).send(ReplicaInbound().withCommit(commit))
+      }
+      requests.clear()
+    }
+    // ---- PreAccepts from replicas outside (a leader's re-sent PreAccept, a recovering replica's): Replica.handlePreAccept
+    // in full (:1159-1289) at THIS replica; Nack / PreAcceptOk / Commit back to the sender
+    if (preAccepts.nonEmpty) {
+      val k = preAccepts.size
+      val ps = preAccepts.map(_._2)
+      val keyset = ps.map(p => if (p.commandOrNoop.value.isNoop) (-1, false) else engine.classify(p.commandOrNoop.getCommand))
+      val first = engine.triples.size; ps.foreach(p => engine.triples += p.commandOrNoop)
+      val depsIn = ps.flatMap(p => watermarks(p.dependencies)).toArray
+      val endsIn = ps.map(p => { val v = p.dependencies.intPrefixSet(p.instance.replicaIndex).value; if (v.isEmpty) 0 else v.max + 1 }).toArray
+      val replies = new Array[Byte](4 * k); val nb = new Array[Int](k); val rd = new Array[Int](k * n * n); val ret = new Array[Int](2 * k * n)
+      Native.check(Native.epxHandlePreaccept(engine.handle, k, n, ps.map(_.instance.replicaIndex).toArray, ps.map(_.instance.instanceNumber).toArray,
+                                             ps.map(_.ballot.ordering).toArray, ps.map(_.ballot.replicaIndex).toArray, keyset.map(_._1).toArray,
+                                             keyset.map(x => (if (x._2) 1 else 0).toByte).toArray, Array.tabulate(k)(first + _), depsIn, endsIn,
+                                             Array.fill(k)(bit(index)), replies, nb, rd, ret), logger)
+      for (((src, p), i) <- preAccepts.zipWithIndex) {
+        val back = chan[Replica[Transport]](src, Replica.serializer)
+        val mine = (replies(i) & bit(index)) != 0 || (replies(k + i) & bit(index)) != 0        // processed, or answered again
+        if ((replies(2 * k + i) & bit(index)) != 0)                                             // :1176-1186 Nack(instance, largestBallot)
+          back.send(ReplicaInbound().withNack(Nack(p.instance, Ballot(nb(i) >> 3, nb(i) & 7))))
+        else if (mine) {
+          val w = rd.slice((i * n + index) * n, (i * n + index + 1) * n)
+          back.send(ReplicaInbound().withPreAcceptOk(PreAcceptOk(p.instance, p.ballot, index, 0,
+            prefixSet(w, p.instance.replicaIndex, ret(i * n + index), p.instance.instanceNumber))))
+        } else if ((replies(3 * k + i) & bit(index)) != 0)                                      // :1228-1238 the Commit back
+          engine.depsOf.get((p.instance.replicaIndex, p.instance.instanceNumber)).foreach(w =>
+            back.send(ReplicaInbound().withCommit(Commit(p.instance, engine.triples(ret(k * n + i * n + index)), 0,
+                                                         prefixSet(w, p.instance.replicaIndex, 0, p.instance.instanceNumber)))))
+      }
+      preAccepts.clear()
+    }
+    // ---- Accepts (:1421-1511) and Prepares (:1632-1757) from replicas outside, at THIS replica
+    if (accepts.nonEmpty) {
+      val k = accepts.size; val as = accepts.map(_._2)
+      val keyset = as.map(a => if (a.commandOrNoop.value.isNoop) (-1, false) else engine.classify(a.commandOrNoop.getCommand))
+      val first = engine.triples.size; as.foreach(a => engine.triples += a.commandOrNoop)
+      val replies = new Array[Byte](4 * k); val nb = new Array[Int](k)
+      Native.check(Native.epxAccept(engine.handle, k, as.map(_.instance.replicaIndex).toArray, as.map(_.instance.instanceNumber).toArray,
+                                    as.map(_.ballot.ordering).toArray, as.map(_.ballot.replicaIndex).toArray, Array.tabulate(k)(first + _),
+                                    keyset.map(_._1).toArray, keyset.map(x => (if (x._2) 1 else 0).toByte).toArray,
+                                    Array.fill(k)(bit(index)), replies, nb), logger)
+      for (((src, a), i) <- accepts.zipWithIndex) {
+        val back = chan[Replica[Transport]](src, Replica.serializer)
+        if ((replies(i) & bit(index)) != 0) back.send(ReplicaInbound().withAcceptOk(AcceptOk(a.instance, a.ballot, index)))
+        else if ((replies(k + i) & bit(index)) != 0) back.send(ReplicaInbound().withNack(Nack(a.instance, Ballot(nb(i) >> 3, nb(i) & 7))))
+      }
+      accepts.clear()
+    }
+    if (prepares.nonEmpty) {
+      val k = prepares.size; val ps = prepares.map(_._2)
+      val replies = new Array[Byte](3 * k); val nb = new Array[Int](k); val ok = new Array[Int](3 * k * n)
+      Native.check(Native.epxPrepare(engine.handle, k, n, ps.map(_.instance.replicaIndex).toArray, ps.map(_.instance.instanceNumber).toArray,
+                                     ps.map(_.ballot.ordering).toArray, ps.map(_.ballot.replicaIndex).toArray, Array.fill(k)(bit(index)),
+                                     replies, nb, ok), logger)
+      for (((src, p), i) <- prepares.zipWithIndex) {
+        val back = chan[Replica[Transport]](src, Replica.serializer)
+        if ((replies(k + i) & bit(index)) != 0) back.send(ReplicaInbound().withNack(Nack(p.instance, Ballot(nb(i) >> 3, nb(i) & 7))))
+        else if ((replies(i) & bit(index)) != 0) {
+          val status = ok(i * n + index); val vote = ok(k * n + i * n + index); val triple = ok(2 * k * n + i * n + index)
+          back.send(ReplicaInbound().withPrepareOk(PrepareOk(
+            ballot = p.ballot, instance = p.instance, replicaIndex = index, voteBallot = Ballot(vote >> 3, vote & 7),
+            status = status match { case 0 => CommandStatus.NotSeen; case 2 => CommandStatus.PreAccepted; case _ => CommandStatus.Accepted },
+            commandOrNoop = if (triple >= 0) Some(engine.triples(triple)) else None)))
+        }
+      }
+      prepares.clear()
+    }
+    queued = 0
+  }
+
+  // replicas of this process: the addresses a GpuEPaxosReplica was created for (set by the main that creates them)
+  var hosted: Transport#Address => Boolean = _ => true
+}
