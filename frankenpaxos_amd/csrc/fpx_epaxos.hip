@@ -649,6 +649,7 @@ __global__ void __launch_bounds__(256) k_epx_decide(const EpxState st, const Epx
 }
 
 #include "fpx_epaxos_kp.hpp"
+#include "fpx_depgraph_dev.hpp"
 
 // ---- scan + decide of ONE key on chip ------------------------------------------------------------------------
 // k_epx_scan hands every (command, replica) conflict row to k_epx_decide through HBM at [command][replica]: n * m
@@ -1350,6 +1351,8 @@ struct fpx_epx {
   Buf kv, kv2, seg, conf, tmp, tick, h_leader, h_number, h_key, h_set, h_mask, h_seen, h_rank, h_triple, o_fast, o_deps, o_ldeps, o_own, cl, hp, fusedb, metab;
   Buf p_fast, p_deps, p_ldeps, p_own;      // the four output arrays when a packed tick goes the first form's way
   Buf kp_hist, kp_recs, kp_misc;          // K5 second form (fpx_epaxos_kp.hpp)
+  Buf dg_msg, dg_direct, dg_clo, dg_pre, dg_tmax, dg_pairs, dg_pairs2, dg_ctl, dg_key;  // device dependency-graph execution
+  int32_t dg_seq = 0;
   uint32_t* kp_flag = nullptr;            // page-locked: [0] sequence number of the tick whose count [1] is valid
   uint32_t* kp_flag_dev = nullptr;
   uint32_t kp_seq = 0;
@@ -1423,12 +1426,11 @@ void launch_segments(fpx_epx* e, const EpxBatch& b, const uint32_t* key_totals, 
     hipLaunchKernelGGL(k_epx_segments, dim3((e->st.n * e->st.num_keys + 255) / 256), dim3(256), 0, e->stream, e->st, b);
 }
 
-// stable LSD radix sort of the n sequences of m pairs on the key bits; returns the buffer that holds the result
-uint2* sort_by_key(fpx_epx* e, int m, uint2* a_buf, uint2* b_buf, const int32_t* check_rank, int* rc_out,
-                   const uint32_t** key_totals, int* key_buckets) {
-  const int n = e->st.n;
-  unsigned bits = 1;
-  while ((1u << bits) <= (unsigned)e->st.num_keys) ++bits;
+// stable LSD radix sort of nseq sequences of m pairs on the low `bits` bits of the key word; returns the buffer that
+// holds the result
+uint2* radix_sort_pairs(fpx_epx* e, int nseq, int m, unsigned bits, uint2* a_buf, uint2* b_buf, const int32_t* check_rank, int* rc_out,
+                        const uint32_t** key_totals, int* key_buckets) {
+  const int n = nseq;
   const unsigned passes = (bits + RS_MAXW - 1) / RS_MAXW, width = (bits + passes - 1) / passes;
   const unsigned B = 1u << width;
   RsArgs a;
@@ -1454,9 +1456,18 @@ uint2* sort_by_key(fpx_epx* e, int m, uint2* a_buf, uint2* b_buf, const int32_t*
     hipLaunchKernelGGL(k_rs_scan, dim3((B + 63) / 64, n), dim3(256), 0, e->stream, a);
     hipLaunchKernelGGL(k_rs_scatter, tg, dim3(64 * RS_SW), RS_SCATTER_LDS, e->stream, a);
   }
-  // one pass: the digit was the whole key, its totals are the sizes of the (replica, key) segments
-  *key_totals = passes == 1 ? a.tot : nullptr, *key_buckets = (int)B;
+  // one pass: the digit was the whole key, its totals are the sizes of the key segments
+  if (key_totals) *key_totals = passes == 1 ? a.tot : nullptr;
+  if (key_buckets) *key_buckets = (int)B;
   return buf[cur];  // where the last pass left the sequence
+}
+
+// the n replicas' sequences of a tick on the key bits
+uint2* sort_by_key(fpx_epx* e, int m, uint2* a_buf, uint2* b_buf, const int32_t* check_rank, int* rc_out,
+                   const uint32_t** key_totals, int* key_buckets) {
+  unsigned bits = 1;
+  while ((1u << bits) <= (unsigned)e->st.num_keys) ++bits;
+  return radix_sort_pairs(e, e->st.n, m, bits, a_buf, b_buf, check_rank, rc_out, key_totals, key_buckets);
 }
 
 // K5, second form: returns FPX_OK with *done = true when the tick went through it, *done = false when the first
@@ -1527,6 +1538,108 @@ int launch_kp(fpx_epx* e, const EpxBatch& b, int32_t* d_packed, bool* done) {
   }
   if (flag[1] != 0) return FPX_OK;  // a hot key: the first form takes the whole tick
   *done = true;
+  return FPX_OK;
+}
+
+// device dependency-graph execution of one tick's commits (fpx_depgraph_dev.hpp)
+template <int N>
+int dg_execute(fpx_epx* e, int m, const int32_t* d_leader, const int32_t* d_number, const int32_t* d_packed, const uint8_t* d_mask,
+               const int32_t* first, const int32_t* count, int32_t* d_order, int32_t* d_comp, int64_t* nexec, int64_t* ncomp,
+               int32_t* needs_host) {
+  constexpr int NP = DgRow<N>::NP;
+  DgArgs a;
+  memset(&a, 0, sizeof(a));
+  a.m = m, a.n = N, a.stride = fpx_epx_packed_stride(N);
+  long long total = 0;
+  for (int l = 0; l < N; ++l) {
+    if (first[l] < 0 || count[l] < 0) return FPX_EINVAL;
+    a.first[l] = first[l], a.count[l] = count[l], a.base[l] = (int32_t)total;
+    a.tiles[l] = (count[l] + DG_TILE - 1) / DG_TILE, a.tile_base[l] = a.ntiles;
+    a.ntiles += a.tiles[l], total += count[l];
+  }
+  for (int l = N; l < 8; ++l) a.base[l] = (int32_t)total, a.tile_base[l] = a.ntiles;
+  if (total != m) return FPX_EINVAL;  // the columns are dense: every instance first[l] .. first[l] + count[l] - 1, once
+  int rc;
+  const int out_tiles = (m + DG_TILE - 1) / DG_TILE;
+  if ((rc = grow(e, &e->dg_msg, (size_t)m * 4))) return rc;
+  if ((rc = grow(e, &e->dg_direct, (size_t)m * NP * 4))) return rc;
+  if ((rc = grow(e, &e->dg_clo, (size_t)m * NP * 4))) return rc;
+  if ((rc = grow(e, &e->dg_pre, (size_t)m * NP * 4))) return rc;
+  if ((rc = grow(e, &e->dg_tmax, (size_t)std::max(a.ntiles * NP, out_tiles) * 4 + 64))) return rc;
+  if ((rc = grow(e, &e->dg_pairs, (size_t)m * 8))) return rc;
+  if ((rc = grow(e, &e->dg_pairs2, (size_t)m * 8))) return rc;
+  if ((rc = grow(e, &e->dg_key, (size_t)m * 4))) return rc;
+  if ((rc = grow(e, &e->dg_ctl, 64))) return rc;
+  if (!e->kp_flag_dev) return FPX_EHIP;
+  a.leader = d_leader, a.number = d_number, a.packed = d_packed, a.mask = d_mask;
+  a.msg_of = (int32_t*)e->dg_msg.p, a.direct = (int32_t*)e->dg_direct.p, a.clo = (int32_t*)e->dg_clo.p, a.pre = (int32_t*)e->dg_pre.p;
+  a.tmax = (int32_t*)e->dg_tmax.p, a.pairs = (uint2*)e->dg_pairs.p, a.pairs2 = (uint2*)e->dg_pairs2.p, a.ctl = (int32_t*)e->dg_ctl.p;
+  a.key32 = (uint32_t*)e->dg_key.p;
+  a.host = reinterpret_cast<volatile int32_t*>(e->kp_flag_dev + 8);  // the second half of the page-locked line
+  a.order = d_order, a.comp = d_comp;
+  volatile int32_t* host = reinterpret_cast<volatile int32_t*>(e->kp_flag + 8);
+  const int call = (++e->dg_seq) & 0xffff;
+  auto wait_for = [&](int round) -> int {
+    const int32_t want = call * 64 + round;
+    for (long spin = 0; spin < 400000000L; ++spin) {
+      if (host[7] == want) return FPX_OK;
+      if ((spin & 0xfffff) == 0xfffff) {  // now and then: did the stream die?  (hipErrorNotReady is what a live one answers;
+        const hipError_t q = hipStreamQuery(e->stream);  // it must not stay behind as the thread's last error)
+        (void)hipGetLastError();
+        if (q != hipErrorNotReady) break;
+      }
+    }
+    EHIP(e, hipStreamSynchronize(e->stream));
+    return host[7] == want ? FPX_OK : FPX_EHIP;
+  };
+  EHIP(e, hipMemsetAsync(a.msg_of, 0xFF, (size_t)m * 4, e->stream));
+  EHIP(e, hipMemsetAsync(a.ctl, 0, 32, e->stream));
+  const int grid = (m + 255) / 256;
+  hipLaunchKernelGGL((k_dg_scatter<N>), dim3(grid), dim3(256), 0, e->stream, a);
+  int round = 0;
+  for (;;) {
+    ++round;
+    a.seq = call * 64 + round;
+    hipLaunchKernelGGL((k_dg_tilemax<N>), dim3(a.ntiles), dim3(256), 0, e->stream, a);
+    hipLaunchKernelGGL((k_dg_prefix<N>), dim3(a.ntiles), dim3(256), 0, e->stream, a);
+    hipLaunchKernelGGL((k_dg_relax<N>), dim3(grid), dim3(256), 0, e->stream, a);
+    hipLaunchKernelGGL(k_dg_publish, dim3(1), dim3(64), 0, e->stream, a, round);
+    if ((rc = wait_for(round))) return rc;
+    if (host[1] != 0) return FPX_EINVAL;        // an instance outside its column, twice, or missing
+    if (host[0] != a.seq) break;                // nothing moved: pre[] belongs to the final closures
+    if (round >= 48) return FPX_EHIP;           // (a round doubles the hops covered: 2^48 hops do not exist)
+  }
+  hipLaunchKernelGGL((k_dg_keys<N>), dim3(grid), dim3(256), 0, e->stream, a);
+  // least significant first: the closures' hashes, then (stable) the closure sums and kinds
+  uint2* sorted = radix_sort_pairs(e, 1, m, DG_HASH_BITS, a.pairs, a.pairs2, nullptr, &rc, nullptr, nullptr);
+  if (rc) return rc;
+  if (sorted != a.pairs) std::swap(a.pairs, a.pairs2);
+  hipLaunchKernelGGL(k_dg_rekey, dim3(grid), dim3(256), 0, e->stream, a);
+  sorted = radix_sort_pairs(e, 1, m, 24, a.pairs, a.pairs2, nullptr, &rc, nullptr, nullptr);
+  if (rc) return rc;
+  if (sorted != a.pairs) std::swap(a.pairs, a.pairs2);
+  ++round;
+  a.seq = call * 64 + round;
+  hipLaunchKernelGGL(k_dg_publish, dim3(1), dim3(64), 0, e->stream, a, round);   // the number of executables sizes what follows
+  if ((rc = wait_for(round))) return rc;
+  const int executables = host[3];
+  if (executables > 0) {
+    const int et = (executables + DG_TILE - 1) / DG_TILE;
+    hipLaunchKernelGGL((k_dg_count_starts<N>), dim3(et), dim3(256), 0, e->stream, a, executables);
+    hipLaunchKernelGGL((k_dg_emit<N>), dim3(et), dim3(256), 0, e->stream, a, executables);
+  }
+  ++round;
+  a.seq = call * 64 + round;
+  hipLaunchKernelGGL(k_dg_publish, dim3(1), dim3(64), 0, e->stream, a, round);
+  if ((rc = wait_for(round))) return rc;
+  if (nexec) *nexec = executables;
+  if (ncomp) *ncomp = executables > 0 ? host[4] : 0;
+  if (needs_host) *needs_host = host[2];
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) {
+    e->last_hip = (int)le;
+    return FPX_EHIP;
+  }
   return FPX_OK;
 }
 
@@ -1624,7 +1737,8 @@ int32_t fpx_epx_destroy(fpx_epx* e) {
                &e->o_own, &e->cl, &e->hp, &e->fusedb, &e->metab};
   for (Buf* b : bs)
     if (b->p) (void)hipFree(b->p);
-  for (Buf* b : {&e->kp_hist, &e->kp_recs, &e->kp_misc, &e->p_fast, &e->p_deps, &e->p_ldeps, &e->p_own})
+  for (Buf* b : {&e->kp_hist, &e->kp_recs, &e->kp_misc, &e->p_fast, &e->p_deps, &e->p_ldeps, &e->p_own, &e->dg_msg, &e->dg_direct,
+                 &e->dg_clo, &e->dg_pre, &e->dg_tmax, &e->dg_pairs, &e->dg_pairs2, &e->dg_ctl, &e->dg_key})
     if (b->p) (void)hipFree(b->p);
   if (e->kp_flag) (void)hipHostFree(e->kp_flag);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -1749,6 +1863,23 @@ static int32_t preaccept_dev_impl(fpx_epx* e, int32_t m, const int32_t* d_leader
 }
 
 int32_t fpx_epx_packed_stride(int32_t num_replicas) { return (2 * num_replicas + 3 + 3) / 4 * 4; }
+
+int32_t fpx_epx_execute_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, const int32_t* d_number, const int32_t* d_packed,
+                            const uint8_t* d_committed, const int32_t* first, const int32_t* count, int32_t* d_order,
+                            int32_t* d_component, int64_t* num_executed, int64_t* num_components, int32_t* needs_host_path) {
+  if (!e || m < 0 || !first || !count || (m > 0 && (!d_leader || !d_number || !d_packed || !d_order || !d_component))) return FPX_EINVAL;
+  EpxDeviceGuard _dg(e->cfg.device);
+  if (num_executed) *num_executed = 0;
+  if (num_components) *num_components = 0;
+  if (needs_host_path) *needs_host_path = 0;
+  if (m == 0) return FPX_OK;
+  if (m >= (1 << 21)) return FPX_EINVAL;
+  switch (e->st.n) {
+    case 3: return dg_execute<3>(e, m, d_leader, d_number, d_packed, d_committed, first, count, d_order, d_component, num_executed, num_components, needs_host_path);
+    case 5: return dg_execute<5>(e, m, d_leader, d_number, d_packed, d_committed, first, count, d_order, d_component, num_executed, num_components, needs_host_path);
+    default: return dg_execute<7>(e, m, d_leader, d_number, d_packed, d_committed, first, count, d_order, d_component, num_executed, num_components, needs_host_path);
+  }
+}
 
 int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, const int32_t* d_number,
                               const int32_t* d_key, const uint8_t* d_is_set, const uint8_t* d_resp_mask,

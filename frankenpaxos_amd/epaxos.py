@@ -183,6 +183,19 @@ class EPaxos:
         if st:
             raise FpxError(st, "fpx_epx_preaccept_packed_dev")
 
+    def execute_dev(self, leader, number, packed, first, count, order, component, committed=None):
+        """fpx_epx_execute_dev: the tick's commits through the device dependency graph.  Returns (num_executed,
+        num_components, needs_host_path); order / component are filled on the device"""
+        d = lambda t: None if t is None else t.data_ptr()
+        f = np.ascontiguousarray(first, np.int32)
+        c = np.ascontiguousarray(count, np.int32)
+        ne, nc, nh = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        st = self.L.fpx_epx_execute_dev(self._h, leader.numel(), d(leader), d(number), d(packed), d(committed), f.ctypes.data,
+                                        c.ctypes.data, d(order), d(component), C.addressof(ne), C.addressof(nc), C.addressof(nh))
+        if st:
+            raise FpxError(st, "fpx_epx_execute_dev")
+        return ne.value, nc.value, nh.value
+
     def unpack(self, packed):
         """packed [m, stride] (numpy or torch) -> fast [m], deps [m, n], leader_deps [m, n], own_values_end [m, 2]"""
         n = self.n

@@ -454,6 +454,25 @@ int32_t fpx_epx_preaccept_packed_dev(fpx_epx* epx, int32_t m, const int32_t* d_l
                                      const uint8_t* d_seen_mask, const int32_t* d_rank, const int32_t* d_triple_id,
                                      int32_t* d_packed);
 int32_t fpx_epx_sync(fpx_epx* epx);
+/* Dependency-graph execution of one tick's commits ON THE DEVICE (the general, host-side graph is
+ * include/fpx_depgraph.h): what Replica.execute does with the committed triples (epaxos/Replica.scala:859-917,
+ * depgraph/TarjanDependencyGraph.scala:225-276) -- strongly connected components of the committed instances, components
+ * in reverse topological order, inside a component by (leader, id) (sequence numbers are 0 with top-k dependencies).
+ * Message i = instance (leader[i], number[i]) with the dependencies of line i of d_packed (fpx_epx_preaccept_packed_dev's
+ * output: deps watermarks + the explicit ids of the own column); d_committed (may be NULL = all) 0 = not committed yet:
+ * it and whatever reaches it wait.  The columns must be DENSE: leader l's instances first[l] .. first[l] + count[l] - 1
+ * each exactly once (sum of count = m), everything below first[l] executed earlier (FPX_EINVAL otherwise).
+ * Outputs: d_order[p] = the message executed p-th, d_component[p] = its component's number (consecutive from 0; equal
+ * numbers = one strongly connected component), for p < *num_executed; *num_components.  Where the reference leaves the
+ * order open (components that do not depend on each other) this path takes its own; the SET of components and the
+ * validity of the order equal fpx_depgraph's.  *needs_host_path != 0: a component too large to regroup on the device (a
+ * hot key under reordering channels) -- the outputs are not valid, run the tick through fpx_depgraph_commit_epx.
+ * Device pointers, the context's stream; a few host waits on page-locked words inside (the closure rounds), so the call
+ * returns when the order is on the device: not capturable into a HIP graph. */
+int32_t fpx_epx_execute_dev(fpx_epx* epx, int32_t m, const int32_t* d_leader, const int32_t* d_number,
+                            const int32_t* d_packed, const uint8_t* d_committed, const int32_t* first,
+                            const int32_t* count, int32_t* d_order, int32_t* d_component, int64_t* num_executed,
+                            int64_t* num_components, int32_t* needs_host_path);
 
 /* ---- EPaxos beyond fresh instances: the per-instance Paxos on the command log (num_instances > 0) --------------
  * Ballots are (ordering, replicaIndex), compared lexicographically (epaxos/BallotHelpers.scala:11-21); where one
