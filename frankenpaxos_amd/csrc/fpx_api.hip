@@ -1646,6 +1646,9 @@ static int enqueue_ranges(fpx_ctx* ctx, RangeBatch& b, int mode) {
       const int gx = std::max(1, std::min(ctx->num_cus * 16 / gy, 64));
       hipLaunchKernelGGL(k_ranges_fill_lg, dim3(gx, gy), dim3(256), 0, ctx->stream, g, ctx->st, b);
     } else if (b.n <= RF_MAXN && g.num_leader_groups <= RF_MAXL && !getenv("FPX_RANGES_FILL_V1")) {
+      // (RF_JB rows of L ownership words + the kernel's own 12 static bytes: beyond the default 64 KiB of dynamic LDS
+      // the kernel needs the opt-in -- ADVICE r03: L close to 2048 failed every launch with FPX_EHIP)
+      allow_lds(k_ranges_fill_rows, (size_t)RF_JB * g.num_leader_groups * 4 + 64);
       // sweep the log rows the ranges touch in memory order (fpx_ranges.hpp)
       hipLaunchKernelGGL(k_ranges_fill_rows, dim3(ctx->num_cus * 8), dim3(256), (size_t)RF_JB * g.num_leader_groups * 4,
                          ctx->stream, g, ctx->st, b);

@@ -483,10 +483,17 @@ int32_t fpx_depgraph_destroy(fpx_depgraph* g) {
   return FPX_OK;
 }
 
+// The vertex columns and the executed sets are dense from their watermark on (one slot / one bit per id): an id far ahead
+// of its column's executed watermark would buy hundreds of megabytes for ONE key (the reference's hash-based
+// sets cost O(members)).  Such a key is refused -- FPX_ECAPACITY, nothing applied: a replica that far ahead of what it
+// has executed has other problems (Replica.scala:859-917 commits what it is about to execute).
+constexpr int64_t DG_MAX_AHEAD = (int64_t)1 << 26;
 static int32_t check_keys(const fpx_depgraph* g, int32_t n, const int32_t* leader, const int32_t* id) {
   if (n < 0 || (n > 0 && (!leader || !id))) return FPX_EINVAL;
   for (int32_t i = 0; i < n; i++)
     if (leader[i] < 0 || leader[i] >= g->L || id[i] < 0) return FPX_EINVAL;
+  for (int32_t i = 0; i < n; i++)
+    if ((int64_t)id[i] - g->executed[(size_t)leader[i]].wm > DG_MAX_AHEAD) return FPX_ECAPACITY;
   return FPX_OK;
 }
 

@@ -1164,6 +1164,8 @@ __global__ void __launch_bounds__(256) k_cl_recover(const EpxState st, const RcB
         for (int q = 0; q < n; ++q) {
           if (!((mask >> q) & 1u) || rv[q] != maxvb || rs[q] != CL_PRE_ACCEPTED || q == me) continue;
           const size_t cq = ((size_t)q * n + L) * st.num_instances + x;
+          // (the triples' dependencies are read from the command log, not from the replies: the caller keeps these
+          // instances untouched between fpx_epx_prepare and this call -- include/fpx.h)
           bool eq = rt[q] == rt[r] && st.cl_dend[cq] == st.cl_dend[cr];
           for (int l = 0; l < n && eq; ++l) eq = st.cl_deps[cq * n + l] == st.cl_deps[cr * n + l];
           same += eq ? 1 : 0;

@@ -558,6 +558,7 @@ struct MenciusOut {
     Fields f;
     const unsigned need = value_field == 3 ? 0x6u : 0x2u;
     if (!parse_flat(r.sub(), value_field, &f) || !r.ok || (f.seen & need) != need || !f.has_value) return false;
+    clear(i);  // a oneof: the last member wins, and nothing of an earlier member stays behind
     kind[i] = k, slot[i] = f.i[1];
     if (round && value_field == 3) round[i] = f.i[2];
     if (is_noop) is_noop[i] = f.value.is_noop;
@@ -570,6 +571,7 @@ struct MenciusOut {
     Fields f;
     const unsigned need = has_round ? 0xeu : 0x6u;
     if (!parse_flat(r.sub(), 0, &f) || !r.ok || (f.seen & need) != need) return false;
+    clear(i);
     kind[i] = k, slot[i] = f.i[1];
     if (slot_end) slot_end[i] = f.i[2];
     if (round && has_round) round[i] = f.i[3];
@@ -853,6 +855,7 @@ bool parse_epx_member(Reader r, int32_t kind, EpxOne* o) {
     const int field = (int)(tag >> 3);
     const uint32_t wt = (uint32_t)(tag & 7);
     bool known = true;
+    if (field == 0) return false;  // no such field (a layout entry of 0 means "this kind has none": never a match)
     if (field == L.instance && wt == 2) {
       if (!parse_pair(r.sub(), &o->il, &o->in)) return false;
     } else if (field == L.ballot && wt == 2) {

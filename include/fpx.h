@@ -526,7 +526,11 @@ int32_t fpx_epx_prepare(fpx_epx* epx, int32_t m, const int32_t* leader, const in
  * actions 0, 2 and 3 can come out.  as_intended = 1 evaluates the two tests the way the surrounding comments describe
  * them (an Accepted response at the highest voteBallot wins; f identical PreAccepted triples voted in
  * Ballot(0, leader), the recovering replica's own excluded, win: Util.popularItems(.., f) with the triples compared as
- * the command log stores them).  Reads the command log, changes nothing. */
+ * the command log stores them).  Reads the command log, changes nothing.  The PrepareOks' triples are compared through
+ * the command-log entries they were answered from (reply_triple names a triple, the entry holds its dependencies): the
+ * caller must not let another call touch these instances between fpx_epx_prepare and this one -- a decision taken on
+ * entries that moved meanwhile is taken on other data than the PrepareOks carried (the reference's replies carry the
+ * triples themselves, Replica.scala:1717-1731). */
 int32_t fpx_epx_handle_prepare_oks(fpx_epx* epx, int32_t m, const int32_t* leader, const int32_t* number,
                                    const int32_t* ballot_ordering, const int32_t* ballot_replica,
                                    const uint8_t* resp_mask, const int32_t* reply_status,

@@ -63,7 +63,10 @@ int32_t fpx_depgraph_destroy(fpx_depgraph* g);
  * (NULL = all 0: what EPaxos uses with top-k dependencies, Replica.scala:575-578), dependencies =
  *   { (l, x) : x < dep_watermark[i * num_leaders + l] }  U  the explicit ids
  *   (dep_values_leader[j], dep_values_id[j]) for j in dep_values_off[i] .. dep_values_off[i + 1]  (all three NULL = none).
- * FPX_EINVAL (nothing committed): a leader outside [0, num_leaders), a negative id or watermark. */
+ * FPX_EINVAL (nothing committed): a leader outside [0, num_leaders), a negative id or watermark.
+ * FPX_ECAPACITY (nothing committed; commit, commit_epx and update_executed alike): a key more than 2^26 ids ahead of its
+ * column's executed watermark -- the columns are dense from the watermark on, one far-away key would cost memory for
+ * everything in between. */
 int32_t fpx_depgraph_commit(fpx_depgraph* g, int32_t n, const int32_t* leader, const int32_t* id, const int32_t* seq,
                             const int32_t* dep_watermark, const int64_t* dep_values_off,
                             const int32_t* dep_values_leader, const int32_t* dep_values_id);

@@ -700,3 +700,25 @@ def test_bad_arguments_are_einval(P):
     with pytest.raises(fa.FpxError):
         P.DependencyGraph(0)
     assert g.execute_by_component() == ([], {(0, 0), (1, 0), (2, 0)})  # nothing was committed
+
+
+def test_a_key_far_ahead_of_the_executed_watermark_is_refused():
+    """the vertex columns and the executed sets are dense from the watermark on; one key near 2^31 would
+    allocate gigabytes.  FPX_ECAPACITY, nothing applied; after the watermark has moved the same key is welcome"""
+    import frankenpaxos_amd as fa
+    from frankenpaxos_amd import depgraph as P
+
+    for kind in (P.FPX_DG_TARJAN, P.FPX_DG_ZIGZAG):
+        g = P.DependencyGraph(2, kind=kind)
+        far = (1 << 26) + 5
+        with pytest.raises(fa.FpxError) as e:
+            g.commit_epx([1], [far], [[0, 0]])
+        assert e.value.status == fa.FPX_ECAPACITY
+        with pytest.raises(fa.FpxError):
+            g.update_executed(None, [(0, 2_000_000_000)])
+        assert g.num_vertices == 0
+        g.commit_epx([0, 1], [0, 1 << 20], [[0, 0], [0, 0]])        # a megabyte away is fine
+        assert g.num_vertices == 2
+        g.update_executed([0, far - 10])
+        g.commit_epx([1], [far], [[0, 0]])
+        assert g.num_vertices >= 2

@@ -412,3 +412,23 @@ def test_slot_ordered_batches_are_walked_by_column(fa, oracle, L, A, R):
         W.assert_same_outputs(W.run_script(gpu, script), W.run_script(ref, script))
     W.assert_same_state(gpu, ref, tally_slots=range(0, S, max(1, S // 200)))
     np.testing.assert_array_equal(gpu.state_digest(), ref.state_digest())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [2048, 1500])
+def test_row_sweep_fill_with_two_thousand_leader_groups(fa, oracle, L):
+    """on slot-ordered rows (FPX_F_SLOT_MAJOR_ROWS) the noop-range fill that sweeps 8 log rows with an LDS
+    ownership map (k_ranges_fill_rows) needs 8 x L x 4 B of dynamic LDS + its static words: beyond the default 64 KiB at
+    L close to 2048 -- without the opt-in every fused range call failed with FPX_EHIP instead of working"""
+    import os
+    if os.environ.get("FPX_SLOT_MAJOR"):
+        pytest.skip("the environment switch overrides the flag")
+    S = L * 16
+    kw = dict(num_slots=S, num_replicas=3, num_groups=1, num_leader_groups=L, f=1, tally_ways=4)
+    gpu, ref = fa.Context(fa.make_config(flags=fa.FPX_F_SLOT_MAJOR_ROWS, **kw)), oracle.System(oracle.make_config(**kw))
+    rng = np.random.default_rng(L)
+    for step in range(3):
+        start, end, rnd = _random_range_batch(rng, S, L, 300, [step] * L)
+        _same_ranges(gpu.noop_ranges_fused(start, end, rnd), ref.noop_ranges_fused(start, end, rnd))
+    W.assert_same_state(gpu, ref, tally_slots=range(0, S, 511))
+    np.testing.assert_array_equal(gpu.state_digest(), ref.state_digest())
