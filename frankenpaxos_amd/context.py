@@ -198,6 +198,24 @@ class Context:
         if st:
             raise FpxError(st, "fpx_phase2_fused_dev")
 
+    # ---- the wire adapter on the device (include/fpx_wire.h) -------------------------------------------
+    def wire_decode_dev(self, which, buf, offsets, value_id_base=0, buf_len=None):
+        """which = "proxy_leader_inbound" | "acceptor_inbound"; buf: uint8 CUDA tensor holding the tick's messages back
+        to back, offsets: int64 CUDA tensor [n + 1].  Returns a dict of CUDA tensors (the SoA batch), enqueued on the
+        context's stream; errors surface at sync() like every _dev call."""
+        import torch
+        n = offsets.numel() - 1
+        names = ["kind", "slot", "round", "is_noop", "value_off", "value_len"] + \
+            (["group_index", "acceptor_index"] if which == "proxy_leader_inbound" else ["chosen_watermark"]) + ["value_id"]
+        out = {k: torch.empty(max(n, 1), dtype=torch.int64 if k == "value_off" else torch.int32, device=buf.device)[:n]
+               for k in names}
+        fn = getattr(self.L, "fpx_wire_decode_%s_dev" % which)
+        st = fn(self._h, _dp(buf), buf.numel() if buf_len is None else buf_len, _dp(offsets), n,
+                *[out[k].data_ptr() for k in names[:-1]], value_id_base, out["value_id"].data_ptr())
+        if st:
+            raise FpxError(st, "fpx_wire_decode_%s_dev" % which)
+        return out
+
     # ---- multi-GPU: RCCL communicator behind the C ABI (fpx_comm_*) ----------------------------------
     def comm_create(self, unique_id, rank, world):
         """collective over the `world` contexts (one per GPU): unique_id = comm_unique_id() of one rank"""

@@ -17,6 +17,8 @@
 
 #include "fpx_kernels.hpp"
 #include "fpx_ranges.hpp"
+#include "fpx_wire_dev.hpp"
+#include "../../include/fpx_wire.h"
 
 using namespace fpx;
 
@@ -938,6 +940,21 @@ int host_fused_staged(fpx_ctx* ctx, int n, const int32_t* slot, const int32_t* r
 // ================================================================================================
 // C ABI
 // ================================================================================================
+// ---- the wire adapter on the device (include/fpx_wire.h) ---------------------------------------------------
+template <int WHICH>
+static int32_t wire_decode_dev(fpx_ctx* ctx, const uint8_t* d_buf, int64_t buf_len, const int64_t* d_offsets, int32_t n,
+                               const WireOut& o) {
+  DeviceGuard _dg(ctx);
+  if (!ctx || n < 0 || n >= (1 << 30) || buf_len < 0) return FPX_EINVAL;
+  if (n == 0) return FPX_OK;
+  if (!d_buf || !d_offsets || !o.kind || !o.slot || !o.round) return FPX_EINVAL;
+  hipLaunchKernelGGL(k_wire_decode<WHICH>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->st, d_buf, buf_len,
+                     d_offsets, n, o);
+  hipLaunchKernelGGL(k_wire_tail, dim3(1), dim3(1), 0, ctx->stream, ctx->st);
+  HIPCHK(ctx, hipGetLastError());
+  return FPX_OK;
+}
+
 extern "C" {
 
 int32_t fpx_version(void) { return FPX_VERSION; }
@@ -1286,6 +1303,26 @@ int32_t fpx_acceptor_phase2a_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot,
   b.n = n, b.slot = d_slot, b.round = d_round, b.value = d_value_id, b.target = d_target_mask;
   b.vote_bits = d_vote_bits, b.nack_bits = d_nack_bits, b.nack_round = d_nack_round;
   return enqueue_phase2(ctx, b, false);
+}
+
+int32_t fpx_wire_decode_proxy_leader_inbound_dev(fpx_ctx* ctx, const uint8_t* d_buf, int64_t buf_len,
+                                                 const int64_t* d_offsets, int32_t n, int32_t* d_kind, int32_t* d_slot,
+                                                 int32_t* d_round, int32_t* d_is_noop, int64_t* d_value_off,
+                                                 int32_t* d_value_len, int32_t* d_group_index, int32_t* d_acceptor_index,
+                                                 int32_t value_id_base, int32_t* d_value_id) {
+  WireOut o{d_kind, d_slot, d_round, d_is_noop, d_value_len, d_group_index, d_acceptor_index, d_value_id, d_value_off,
+            value_id_base};
+  return wire_decode_dev<0>(ctx, d_buf, buf_len, d_offsets, n, o);
+}
+
+int32_t fpx_wire_decode_acceptor_inbound_dev(fpx_ctx* ctx, const uint8_t* d_buf, int64_t buf_len,
+                                             const int64_t* d_offsets, int32_t n, int32_t* d_kind, int32_t* d_slot,
+                                             int32_t* d_round, int32_t* d_is_noop, int64_t* d_value_off,
+                                             int32_t* d_value_len, int32_t* d_chosen_watermark, int32_t value_id_base,
+                                             int32_t* d_value_id) {
+  WireOut o{d_kind, d_slot, d_round, d_is_noop, d_value_len, d_chosen_watermark, nullptr, d_value_id, d_value_off,
+            value_id_base};
+  return wire_decode_dev<1>(ctx, d_buf, buf_len, d_offsets, n, o);
 }
 
 int32_t fpx_phase2_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,

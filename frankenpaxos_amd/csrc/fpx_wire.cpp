@@ -8,106 +8,11 @@
 #include <vector>
 
 #include "../../include/fpx.h"
+#include "fpx_wire_parse.hpp"
 
 namespace {
 
-// ---- reading ---------------------------------------------------------------------------------------------
-struct Reader {
-  const uint8_t* p;
-  const uint8_t* end;
-  bool ok = true;
-
-  bool more() const { return ok && p < end; }
-  uint64_t varint() {
-    if (p < end && !(*p & 0x80)) return *p++;  // tags and small values: one byte
-    uint64_t v = 0;
-    for (int shift = 0; shift < 70; shift += 7) {
-      if (p >= end) break;
-      const uint8_t b = *p++;
-      if (shift < 64) v |= (uint64_t)(b & 0x7f) << shift;
-      if (!(b & 0x80)) return v;
-    }
-    ok = false;  // truncated, or longer than 10 bytes
-    return 0;
-  }
-  // a length-delimited field: the sub-range, consumed
-  Reader sub() {
-    const uint64_t len = varint();
-    Reader r{p, p, ok};
-    if (!ok || len > (uint64_t)(end - p)) {
-      ok = false;
-      r.ok = false;
-      return r;
-    }
-    r.end = p + len;
-    p += len;
-    return r;
-  }
-  void skip(uint32_t wire_type) {
-    switch (wire_type) {
-      case 0: (void)varint(); break;
-      case 1: if (end - p < 8) ok = false; else p += 8; break;
-      case 2: (void)sub(); break;
-      case 5: if (end - p < 4) ok = false; else p += 4; break;
-      default: ok = false;  // groups are not used by these messages
-    }
-  }
-};
-
-// int32 fields travel as (sign-extended) varints
-inline int32_t as_i32(uint64_t v) { return (int32_t)(uint32_t)v; }
-
-struct Value {  // a CommandBatchOrNoop field
-  const uint8_t* at = nullptr;
-  int32_t len = -1;
-  int32_t is_noop = -1;
-};
-
-// CommandBatchOrNoop { oneof value { CommandBatch command_batch = 1; Noop noop = 2; } }   MultiPaxos.proto:213-221
-bool parse_value(Reader r, Value* out) {
-  out->at = r.p;
-  out->len = (int32_t)(r.end - r.p);
-  int which = 0;
-  while (r.more()) {
-    const uint64_t tag = r.varint();
-    const uint32_t field = (uint32_t)(tag >> 3), wt = (uint32_t)(tag & 7);
-    if ((field == 1 || field == 2) && wt == 2) {
-      (void)r.sub();
-      which = (int)field;  // the last one set wins, as in every protobuf runtime
-    } else {
-      r.skip(wt);
-    }
-  }
-  if (!r.ok || which == 0) return false;  // logger.fatal("Empty CommandBatchOrNoop") territory: reject
-  out->is_noop = which == 2;
-  return true;
-}
-
-struct Fields {
-  int32_t i[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // int32 fields 1..7
-  unsigned seen = 0;               // bit f set: field f was present
-  Value value;
-  bool has_value = false;
-};
-
-// a flat message of int32 fields and at most one CommandBatchOrNoop field (number value_field, 0 = none)
-bool parse_flat(Reader r, int value_field, Fields* f) {
-  while (r.more()) {
-    const uint64_t tag = r.varint();
-    const uint32_t field = (uint32_t)(tag >> 3), wt = (uint32_t)(tag & 7);
-    if (value_field && (int)field == value_field && wt == 2) {
-      Reader s = r.sub();
-      if (!r.ok || !parse_value(s, &f->value)) return false;
-      f->has_value = true;
-    } else if (field >= 1 && field <= 7 && wt == 0) {
-      f->i[field] = as_i32(r.varint());
-      f->seen |= 1u << field;
-    } else {
-      r.skip(wt);
-    }
-  }
-  return r.ok;
-}
+using namespace fpxw;
 
 // ---- writing ---------------------------------------------------------------------------------------------
 struct Writer {
@@ -185,8 +90,7 @@ int32_t decode_loop(const uint8_t* buf, int64_t buf_len, const int64_t* offsets,
   // every offset is checked against the buffer BEFORE a single byte is parsed: offsets like [0, 10^9, 5] must not
   // send message 0's parser a gigabyte past the end before the non-monotone pair is noticed
   for (int32_t i = 0; i <= n && n > 0; ++i) {
-    const bool ok = offsets[i] >= 0 && offsets[i] <= buf_len && (i == 0 || offsets[i] >= offsets[i - 1]);
-    if (!ok) {
+    if (!offset_ok(offsets, i, buf_len)) {
       if (bad_index) *bad_index = i < n ? i : n - 1;
       return FPX_EINVAL;
     }
@@ -215,33 +119,15 @@ int32_t fpx_wire_decode_proxy_leader_inbound(const uint8_t* buf, int64_t buf_len
                                              int32_t* bad_index) {
   if (n > 0 && (!kind || !slot || !round)) return FPX_EINVAL;
   return decode_loop(buf, buf_len, offsets, n, bad_index, [&](int32_t i, Reader r) {
-    kind[i] = FPX_WIRE_OTHER, slot[i] = -1, round[i] = -1;
-    if (is_noop) is_noop[i] = -1;
-    if (value_off) value_off[i] = -1;
-    if (value_len) value_len[i] = -1;
-    if (group_index) group_index[i] = -1;
-    if (acceptor_index) acceptor_index[i] = -1;
-    while (r.more()) {  // ProxyLeaderInbound: the last member of the oneof that is present wins
-      const uint64_t tag = r.varint();
-      const uint32_t field = (uint32_t)(tag >> 3), wt = (uint32_t)(tag & 7);
-      if (field == 1 && wt == 2) {  // Phase2a
-        Fields f;
-        if (!parse_flat(r.sub(), 3, &f) || !r.ok || (f.seen & 0x6) != 0x6 || !f.has_value) return false;
-        kind[i] = FPX_WIRE_PHASE2A, slot[i] = f.i[1], round[i] = f.i[2];
-        if (is_noop) is_noop[i] = f.value.is_noop;
-        if (value_off) value_off[i] = f.value.at - buf;
-        if (value_len) value_len[i] = f.value.len;
-      } else if (field == 2 && wt == 2) {  // Phase2b
-        Fields f;
-        if (!parse_flat(r.sub(), 0, &f) || !r.ok || (f.seen & 0x1e) != 0x1e) return false;
-        kind[i] = FPX_WIRE_PHASE2B, slot[i] = f.i[3], round[i] = f.i[4];
-        if (group_index) group_index[i] = f.i[1];
-        if (acceptor_index) acceptor_index[i] = f.i[2];
-      } else {
-        r.skip(wt);
-      }
-    }
-    return r.ok;
+    Msg o;  // the parser itself is fpx_wire_parse.hpp's, shared with the device decoder
+    const bool ok = parse_proxy_leader_inbound(buf, r, &o);
+    kind[i] = o.kind, slot[i] = o.slot, round[i] = o.round;
+    if (is_noop) is_noop[i] = o.is_noop;
+    if (value_off) value_off[i] = o.value_off;
+    if (value_len) value_len[i] = o.value_len;
+    if (group_index) group_index[i] = o.a;
+    if (acceptor_index) acceptor_index[i] = o.b;
+    return ok;
   });
 }
 
@@ -250,31 +136,14 @@ int32_t fpx_wire_decode_acceptor_inbound(const uint8_t* buf, int64_t buf_len, co
                                          int32_t* value_len, int32_t* chosen_watermark, int32_t* bad_index) {
   if (n > 0 && (!kind || !slot || !round)) return FPX_EINVAL;
   return decode_loop(buf, buf_len, offsets, n, bad_index, [&](int32_t i, Reader r) {
-    kind[i] = FPX_WIRE_OTHER, slot[i] = -1, round[i] = -1;
-    if (is_noop) is_noop[i] = -1;
-    if (value_off) value_off[i] = -1;
-    if (value_len) value_len[i] = -1;
-    if (chosen_watermark) chosen_watermark[i] = -1;
-    while (r.more()) {
-      const uint64_t tag = r.varint();
-      const uint32_t field = (uint32_t)(tag >> 3), wt = (uint32_t)(tag & 7);
-      if (field == 1 && wt == 2) {  // Phase1a
-        Fields f;
-        if (!parse_flat(r.sub(), 0, &f) || !r.ok || (f.seen & 0x6) != 0x6) return false;
-        kind[i] = FPX_WIRE_PHASE1A, round[i] = f.i[1], slot[i] = -1;
-        if (chosen_watermark) chosen_watermark[i] = f.i[2];
-      } else if (field == 2 && wt == 2) {  // Phase2a
-        Fields f;
-        if (!parse_flat(r.sub(), 3, &f) || !r.ok || (f.seen & 0x6) != 0x6 || !f.has_value) return false;
-        kind[i] = FPX_WIRE_PHASE2A, slot[i] = f.i[1], round[i] = f.i[2];
-        if (is_noop) is_noop[i] = f.value.is_noop;
-        if (value_off) value_off[i] = f.value.at - buf;
-        if (value_len) value_len[i] = f.value.len;
-      } else {
-        r.skip(wt);  // MaxSlotRequest, BatchMaxSlotRequest: not this path's
-      }
-    }
-    return r.ok;
+    Msg o;
+    const bool ok = parse_acceptor_inbound(buf, r, &o);
+    kind[i] = o.kind, slot[i] = o.slot, round[i] = o.round;
+    if (is_noop) is_noop[i] = o.is_noop;
+    if (value_off) value_off[i] = o.value_off;
+    if (value_len) value_len[i] = o.value_len;
+    if (chosen_watermark) chosen_watermark[i] = o.a;
+    return ok;
   });
 }
 

@@ -81,6 +81,31 @@ int32_t fpx_wire_decode_replica_inbound(const uint8_t* buf, int64_t buf_len, con
                                         int32_t* slot, int32_t* is_noop, int64_t* value_off, int32_t* value_len,
                                         int32_t* bad_index);
 
+/* The two decoders above ON THE DEVICE: the tick's bytes and its n + 1 offsets are device pointers (or page-locked host
+ * memory the GPU can read), the outputs are device arrays of n elements, and the work is enqueued on the context's
+ * stream like every _dev entry point of include/fpx.h -- a tick goes  copy -> decode -> fpx_phase2_fused_dev /
+ * fpx_acceptor_phase2a_dev  without the host parsing a byte.  One thread per message runs the SAME parser the host
+ * decoders run (csrc/fpx_wire_parse.hpp is compiled for both sides), so the fields are identical: kind, slot, round,
+ * is_noop, value_off, value_len and group_index / acceptor_index (resp. chosen_watermark), -1 where a field does not
+ * apply; d_kind, d_slot and d_round are required, the others may be NULL.  d_value_id (may be NULL): value_id_base + i
+ * for a Phase2a, -1 otherwise -- the id under which the caller files message i's command bytes (value_off, value_len)
+ * and which the Phase-2 kernels carry through to Chosen.
+ * Errors follow the _dev convention: the call returns FPX_OK once enqueued; a bad offset or a malformed message makes
+ * the context's status FPX_EINVAL (fpx_sync; fpx_error_detail's index = the first bad offset, else the first
+ * malformed message, as *bad_index above) and every later _dev call up to that fpx_sync applies nothing, so a
+ * half-decoded tick never reaches the acceptors.  The outputs of a failed decode are unspecified.  n < 2^30. */
+struct fpx_ctx;
+int32_t fpx_wire_decode_proxy_leader_inbound_dev(struct fpx_ctx* ctx, const uint8_t* d_buf, int64_t buf_len,
+                                                 const int64_t* d_offsets, int32_t n, int32_t* d_kind, int32_t* d_slot,
+                                                 int32_t* d_round, int32_t* d_is_noop, int64_t* d_value_off,
+                                                 int32_t* d_value_len, int32_t* d_group_index,
+                                                 int32_t* d_acceptor_index, int32_t value_id_base, int32_t* d_value_id);
+int32_t fpx_wire_decode_acceptor_inbound_dev(struct fpx_ctx* ctx, const uint8_t* d_buf, int64_t buf_len,
+                                             const int64_t* d_offsets, int32_t n, int32_t* d_kind, int32_t* d_slot,
+                                             int32_t* d_round, int32_t* d_is_noop, int64_t* d_value_off,
+                                             int32_t* d_value_len, int32_t* d_chosen_watermark, int32_t value_id_base,
+                                             int32_t* d_value_id);
+
 /* Folds decoded Phase2b messages into the rows fpx_proxy_phase2b takes: one row per distinct (slot, round), in
  * order of first appearance, with the acceptors that answered as a 256-bit set.  Bit of a message =
  * acceptor_index when grid_cols == 0 (non-flexible: the acceptor group follows from the slot,
