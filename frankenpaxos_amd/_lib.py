@@ -102,8 +102,6 @@ SIGNATURES = {
     "fpx_phase2_fused_submit": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP, VP, VP, VP, VP, I32P]),
     "fpx_phase2_fused_wait": (C.c_int32, [VP, C.c_int32]),
     "fpx_phase2_fused_dev": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP, VP, VP, VP, VP]),
-    "fpx_wire_decode_proxy_leader_inbound_dev": (C.c_int32, [VP, VP, C.c_int64, VP, C.c_int32] + [VP] * 8 + [C.c_int32, VP]),
-    "fpx_wire_decode_acceptor_inbound_dev": (C.c_int32, [VP, VP, C.c_int64, VP, C.c_int32] + [VP] * 7 + [C.c_int32, VP]),
     "fpx_acceptor_phase2a_noop_range": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, VP, VP, VP, I32P]),
     "fpx_proxy_open_noop_range": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, U8P]),
     "fpx_proxy_phase2b_noop_range": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, VP, U8P]),

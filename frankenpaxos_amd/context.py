@@ -209,7 +209,8 @@ class Context:
             (["group_index", "acceptor_index"] if which == "proxy_leader_inbound" else ["chosen_watermark"]) + ["value_id"]
         out = {k: torch.empty(max(n, 1), dtype=torch.int64 if k == "value_off" else torch.int32, device=buf.device)[:n]
                for k in names}
-        fn = getattr(self.L, "fpx_wire_decode_%s_dev" % which)
+        from . import wire
+        fn = getattr(wire._L(), "fpx_wire_decode_%s_dev" % which)
         st = fn(self._h, _dp(buf), buf.numel() if buf_len is None else buf_len, _dp(offsets), n,
                 *[out[k].data_ptr() for k in names[:-1]], value_id_base, out["value_id"].data_ptr())
         if st:

@@ -188,7 +188,8 @@ __device__ __forceinline__ void ranges_acceptor_one(const Geom& g, const State& 
   }
   if (pr != round) st.promised[acc] = round;  // :260 (every message of this leader group carries this round)
   atomicOr((unsigned long long*)&b.vote_bits[row + (bit >> 6)], 1ull << (bit & 63));
-  // the largest slot of the range owned by my acceptor group (maxVotedSlot)
+  // the largest slot of the range owned by my acceptor group: maxVotedSlot, a multipaxos scalar (Acceptor.scala:104) the
+  // library keeps in every mode for one readback format -- mencius/Acceptor.scala has none and no message carries it
   const int rows = (end - start + L - 1) / L;
   for (int j = rows - 1; j >= 0 && j >= rows - A; --j) {
     const int s = start + j * L;
@@ -240,10 +241,7 @@ __global__ void __launch_bounds__(256) k_ranges_fill(const Geom g, const State s
 // it; what is left is one request per 16 useful bytes (profiles/r03_cfg5.md).
 // Two ranges of the launch that cover the same slot (a leader group that sends overlapping ranges in one tick) send
 // the span through a per-slot loop over all ranges instead.  Chosen by the host for launches of at most RF_MAXN ranges.
-#ifndef FPX_RF_JB
-#define FPX_RF_JB 8
-#endif
-constexpr int RF_JB = FPX_RF_JB, RF_MAXN = 1024, RF_MAXL = 2048;
+constexpr int RF_JB = 8, RF_MAXN = 1024, RF_MAXL = 2048;
 __global__ void __launch_bounds__(256) k_ranges_fill_rows(const Geom g, const State st, const RangeBatch b) {
   extern __shared__ uint32_t rf_own[];  // [RF_JB][L] index + 1 of the range that covers the slot, 0 = none
   __shared__ int span_lo, span_hi, overlap;
@@ -294,10 +292,6 @@ __global__ void __launch_bounds__(256) k_ranges_fill_rows(const Geom g, const St
       if (!slow) {
         const int i = (int)o - 1;
         const uint64_t* votes = b.vote_bits + ((size_t)i * A + ag) * 4;
-#ifdef RF_X_NOLOAD
-        round = i & 1, voted = valid = 7;
-        if (round == 5)
-#endif
         round = b.round[i];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -320,10 +314,6 @@ __global__ void __launch_bounds__(256) k_ranges_fill_rows(const Geom g, const St
       }
       if (voted == 0) continue;
       const size_t cell = (size_t)phys_slot(g, s) * g.VS + r0;
-#ifdef RF_X_NOSTORE
-      if (round == -12345) st.row_voted[phys_slot(g, s)] = 1;
-      continue;
-#endif
       if (voted == valid) {  // :271-276 State(voteRound = round, voteValue = Noop); padding cells stay -1
         int4 vr = make_int4(round, round, round, round);
         if (!(valid & 2u)) vr.y = -1;

@@ -33,6 +33,9 @@ def _L():
         for name in ("fpx_wire_decode_proxy_leader_inbound",):
             getattr(L, name).argtypes = [VP, C.c_int64, VP, C.c_int32] + [VP] * 8 + [I32P]
         L.fpx_wire_decode_acceptor_inbound.argtypes = [VP, C.c_int64, VP, C.c_int32] + [VP] * 7 + [I32P]
+        # the device decoders (Context.wire_decode_dev): ctx, d_buf, buf_len, d_offsets, n, outputs..., value_id_base, d_value_id
+        L.fpx_wire_decode_proxy_leader_inbound_dev.argtypes = [VP, VP, C.c_int64, VP, C.c_int32] + [VP] * 8 + [C.c_int32, VP]
+        L.fpx_wire_decode_acceptor_inbound_dev.argtypes = [VP, VP, C.c_int64, VP, C.c_int32] + [VP] * 7 + [C.c_int32, VP]
         L.fpx_wire_decode_replica_inbound.argtypes = [VP, C.c_int64, VP, C.c_int32] + [VP] * 5 + [I32P]
         L.fpx_wire_mencius_decode_proxy_leader_inbound.argtypes = [VP, C.c_int64, VP, C.c_int32] + [VP] * 9 + [I32P]
         L.fpx_wire_mencius_decode_acceptor_inbound.argtypes = [VP, C.c_int64, VP, C.c_int32] + [VP] * 8 + [I32P]

@@ -742,6 +742,9 @@ int fpo_acceptor_handle_phase2a_noop_range(fpo_sys* s, int group, int replica, i
     size_t cell = (size_t)slot * R + replica;
     s->vote_round[cell] = round;
     s->vote_value[cell] = -1; /* Noop */
+    /* NOT in mencius/Acceptor.scala, which has no maxVotedSlot at all: the library keeps the multipaxos acceptor's
+     * scalar (multipaxos/Acceptor.scala:104, :216) in every mode so that one readback / digest serves all contexts.
+     * No Mencius message carries it; it is compared GPU vs. oracle as library state only. */
     int* mvs = &s->max_voted_slot[(size_t)group * R + replica];
     if (slot > *mvs) *mvs = slot;
   }

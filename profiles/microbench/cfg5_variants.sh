@@ -5,7 +5,7 @@ V="base"
 if [ "${1:-build}" = build ]; then
   mkdir -p profiles/microbench/build
   for v in $V; do
-    D=""; [ $v = JB32 ] && D="-DFPX_RF_JB=32"; [ $v = JB2 ] && D="-DFPX_RF_JB=2"
+    D=""
     (cd frankenpaxos_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC $D -c -o /tmp/api_$v.o fpx_api.hip &&
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../profiles/microbench/build/libfpx5_$v.so /tmp/api_$v.o fpx_epaxos.o fpx_wire.o fpx_depgraph.o -ldl) &
   done
