@@ -1662,9 +1662,13 @@ static int enqueue_ranges(fpx_ctx* ctx, RangeBatch& b, int mode) {
   }
   const RangeTable& rt = ctx->rt[ctx->rt_cur];
   // a few ranges: one workgroup walks clear -> open -> resolve -> acceptors -> tally (fpx_ranges.hpp: k_ranges_chain)
-  const bool chain = mode == RANGES_FUSED && b.n <= RANGES_CHAIN_MAX && (long long)b.n * g.num_groups * g.R <= 16 * RANGES_CHAIN_MAX &&
-                     !getenv("FPX_RANGES_NO_CHAIN");
-  if (chain) hipLaunchKernelGGL(k_ranges_chain, dim3(1), dim3(1024), 0, ctx->stream, g, ctx->st, rt, b);
+  const long long chain_words = ranges_chain_words(b.n, g.num_groups);
+  const bool chain = mode == RANGES_FUSED && b.n <= RANGES_CHAIN_MAX && chain_words <= RANGES_CHAIN_LDS_WORDS &&
+                     (long long)b.n * g.num_groups * g.R <= 8 * 1024 && !getenv("FPX_RANGES_NO_CHAIN");
+  if (chain) {
+    allow_lds(k_ranges_chain, (size_t)chain_words * 4 + 64);
+    hipLaunchKernelGGL(k_ranges_chain, dim3(1), dim3(1024), (size_t)chain_words * 4, ctx->stream, g, ctx->st, rt, b);
+  }
   if (acceptors && !chain) {
     fill32(ctx, b.vote_bits, 0, words * 2);
     if (b.nack_bits) fill32(ctx, b.nack_bits, 0, words * 2);

@@ -83,9 +83,13 @@ __global__ void __launch_bounds__(256) k_ranges_validate(const Geom g, const Sta
 }
 
 // mencius/ProxyLeader.scala:255-303.  lookup = 1: find only (the Phase2bNoopRange entry point).
-__device__ __forceinline__ void ranges_open_one(const Geom& g, const State& st, const RangeTable& rt, const RangeBatch& b, int lookup, int i) {
-  const int s = b.start[i], e = b.end[i], rnd = b.round[i];
-  b.entry[i] = -1;
+// Returns the table entry (-1 unknown / refused, -2 swallowed).  *inserted: this call created the entry; *shared: the
+// entry was created by ANOTHER message of this launch (the same key twice in one batch).  count_hint: a value of
+// rt.count read at launch start, or -1 -- with n messages in the launch the table cannot reach its limit while
+// count_hint + n stays below it, and the live read of the counter (a dependent round trip to L2) is skipped.
+__device__ __forceinline__ int ranges_open_core(const Geom& g, const State& st, const RangeTable& rt, const RangeBatch& b, int lookup, int i,
+                                                int s, int e, int rnd, int count_hint, bool* inserted, bool* shared) {
+  *inserted = false, *shared = false;
   const uint32_t want = (uint32_t)rnd + 1u;
   if (e == s + 1) {
     // the key (slot, slot + 1, round) is also the key of the single-slot tally: if that one exists -- Pending or
@@ -93,8 +97,7 @@ __device__ __forceinline__ void ranges_open_one(const Geom& g, const State& st, 
     const uint32_t* kr = st.pl_key + (size_t)phys_slot(g, s) * g.wp;
     for (int w = 0; w < g.ways; ++w)
       if ((kr[w] & KEY_ROUND_MASK) == want && !(kr[w] & KEY_RANGE)) {
-        b.entry[i] = -2;  // swallowed
-        return;
+        return -2;  // swallowed
       }
   }
   const uint64_t k0 = range_k0(s, e);
@@ -103,10 +106,11 @@ __device__ __forceinline__ void ranges_open_one(const Geom& g, const State& st, 
   for (int probes = 0; probes < rt.cap; ++probes, p = (p + 1) & mask) {
     uint64_t cur = __hip_atomic_load(&rt.key[(size_t)p * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cur == 0) {
-      if (lookup) return;  // unknown key
-      if (__hip_atomic_load(rt.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= rt.cap / 2) {
+      if (lookup) return -1;  // unknown key
+      if ((count_hint < 0 || count_hint + b.n >= rt.cap / 2) &&
+          __hip_atomic_load(rt.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= rt.cap / 2) {
         report(st, 5 /*FPX_ECAPACITY*/, i, s, rnd);
-        return;
+        return -1;
       }
       const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&rt.key[(size_t)p * 2]), 0ull, (unsigned long long)k0);
       if (prev == 0) {  // mine: :295-301 PendingPhase2aNoopRange(phase2a, no votes) -- bits and owner were initialised
@@ -114,8 +118,8 @@ __device__ __forceinline__ void ranges_open_one(const Geom& g, const State& st, 
         rt.key[(size_t)p * 2 + 1] = ((uint64_t)b.run_id << 32) | ((uint64_t)(uint32_t)rnd << 2) | RT_PENDING;
         atomicAdd(rt.count, 1);
         atomicMin(&rt.owner[p], i);
-        b.entry[i] = (int)p;
-        return;
+        *inserted = true;
+        return (int)p;
       }
       cur = prev;  // somebody else claimed the slot between the load and the CAS: look at what is there now
     }
@@ -126,13 +130,19 @@ __device__ __forceinline__ void ranges_open_one(const Geom& g, const State& st, 
       const bool this_launch = k1 == 0 || (uint32_t)(k1 >> 32) == b.run_id;
       if (this_launch || (uint32_t)((k1 >> 2) & 0x3fffffffu) == (uint32_t)rnd) {
         if (this_launch && !lookup) atomicMin(&rt.owner[p], i);
-        b.entry[i] = (int)p;
-        return;
+        *shared = this_launch;
+        return (int)p;
       }
       // the same range in another round: a different key, keep probing
     }
   }
   if (!lookup) report(st, 5, i, s, rnd);
+  return -1;
+}
+
+__device__ __forceinline__ void ranges_open_one(const Geom& g, const State& st, const RangeTable& rt, const RangeBatch& b, int lookup, int i) {
+  bool inserted, shared;
+  b.entry[i] = ranges_open_core(g, st, rt, b, lookup, i, b.start[i], b.end[i], b.round[i], -1, &inserted, &shared);
 }
 
 __global__ void __launch_bounds__(256) k_ranges_open(const Geom g, const State st, const RangeTable rt, const RangeBatch b, int lookup) {
@@ -482,34 +492,132 @@ __global__ void __launch_bounds__(256) k_ranges_tally(const Geom g, const State 
 }
 
 // A fused launch of a few ranges (what a tick of a Mencius deployment carries: one per lagging leader group) is a
-// chain of five dependent steps over a few hundred items -- as five launches, ~5 us each plus the gaps between them,
-// several times what the steps compute.  ONE workgroup of 1024 threads walks the chain instead: the bitmaps cleared,
-// then open / resolve / acceptors / tally with a barrier in between (the steps talk through global memory -- hash table
-// entries, entry[], vote bitmaps -- partly with device-scope atomics that bypass the L1: the acquire fence after each
-// barrier drops the CU's L1 lines so that plain loads see them).  k_ranges_fill* follows as its own launch.
-constexpr int RANGES_CHAIN_MAX = 4096;
-__device__ __forceinline__ void ranges_chain_sync() {
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
+// chain of dependent steps over a few hundred items -- as five launches, ~5 us each plus the gaps between them, several
+// times what the steps compute.  ONE workgroup walks the chain instead, and everything the steps say to each other
+// stays in LDS: the ranges' fields, their table entries, the vote and Nack bitmaps.  Global memory sees what must
+// persist -- the table insert (one load + one CAS per range), promised / maxVotedSlot, the tally's votes -- and the
+// outputs, written once at the end; k_ranges_fill* follows as its own launch and reads entry[] and vote_bits from
+// there.  What the round-3 chain paid for and this one does not: a device-scope fence + L1 invalidate after every
+// barrier (the steps talked through global memory), the resolve step's reads of k1 / owner (an insert is the owner's
+// unless the same key came twice in the launch, which the open step notices and flags in LDS), the tally's reads of
+// an entry it has just created (no votes, Pending: known), and the live read of the table's fill counter.
+// 16 -> 6 us for the 256 ranges of BASELINE.json configs[4] (profiles/r04_cfg5.md).
+constexpr int RANGES_CHAIN_MAX = 2048, RANGES_CHAIN_LDS_WORDS = 36000;  // 144 KB of the CU's 160
+__host__ __device__ inline long long ranges_chain_words(int n, int A) { return 5ll * n + 16ll * n * A; }
 __global__ void __launch_bounds__(1024) k_ranges_chain(const Geom g, const State st, const RangeTable rt, const RangeBatch b) {
+  extern __shared__ uint32_t ch_lds[];
+  __shared__ int shared_keys;
   if (st.status[ST_ABORT] != 0) return;
-  const int tid = threadIdx.x;
-  const long long ints = (long long)b.n * g.num_groups * 8;
-  for (long long t = tid; t < ints; t += 1024) {
-    reinterpret_cast<int32_t*>(b.vote_bits)[t] = 0;
-    if (b.nack_bits) reinterpret_cast<int32_t*>(b.nack_bits)[t] = 0;
+  const int tid = threadIdx.x, n = b.n, A = g.num_groups, R = g.R, L = g.num_leader_groups;
+  int32_t* c_start = reinterpret_cast<int32_t*>(ch_lds);
+  int32_t* c_end = c_start + n;
+  int32_t* c_round = c_end + n;
+  int32_t* c_entry = c_round + n;
+  int32_t* c_nr = c_entry + n;
+  uint32_t* c_votes = reinterpret_cast<uint32_t*>(c_nr + n);  // [n][A][8]
+  uint32_t* c_nacks = c_votes + (size_t)n * A * 8;
+  const int count0 = __hip_atomic_load(rt.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = tid; i < n; i += 1024) c_start[i] = b.start[i], c_end[i] = b.end[i], c_round[i] = b.round[i], c_nr[i] = -1;
+  for (int t = tid; t < n * A * 16; t += 1024) c_votes[t] = 0;
+  if (tid == 0) shared_keys = 0;
+  __syncthreads();
+  // the acceptor this thread plays in the vote step: its round is requested now, the open step runs while it travels
+  // (two ranges of one leader group carry the same round -- the run contract -- so whichever of them writes promised
+  // first, a value read before that write leads to the same vote)
+  const int per = A * R, cells = n * per;
+  int pr0 = 0;
+  if (tid < cells) pr0 = st.promised[(size_t)((c_start[tid / per] % L) * A + (tid % per) / R) * R + (tid % per) % R];
+  // open (mencius/ProxyLeader.scala:255-303)
+  bool mine[2] = {false, false};
+  for (int i = tid, k = 0; i < n; i += 1024, ++k) {
+    bool inserted, shared;
+    c_entry[i] = ranges_open_core(g, st, rt, b, 0, i, c_start[i], c_end[i], c_round[i], count0, &inserted, &shared);
+    mine[k] = inserted;
+    if (shared) shared_keys = 1;
   }
-  if (b.nack_round)
-    for (int i = tid; i < b.n; i += 1024) b.nack_round[i] = -1;
-  for (int i = tid; i < b.n; i += 1024) ranges_open_one(g, st, rt, b, 0, i);
-  ranges_chain_sync();
-  for (int i = tid; i < b.n; i += 1024) ranges_resolve_one(g, st, rt, b, i);
-  ranges_chain_sync();
-  const long long cells = (long long)g.num_groups * g.R * b.n;
-  for (long long idx = tid; idx < cells; idx += 1024) ranges_acceptor_one(g, st, b, idx);
-  ranges_chain_sync();
-  for (int i = tid; i < b.n; i += 1024) ranges_tally_one(g, st, rt, b, i);
+  __syncthreads();
+  // resolve: is_new <=> this launch created the entry and i is the lowest index that carries its key
+  const bool twice = shared_keys != 0;
+  for (int i = tid, k = 0; i < n; i += 1024, ++k) {
+    const int e = c_entry[i];
+    bool fresh = mine[k];
+    if (twice && e >= 0) {
+      const uint64_t k1 = __hip_atomic_load(&rt.key[(size_t)e * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      fresh = (uint32_t)(k1 >> 32) == b.run_id && __hip_atomic_load(&rt.owner[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == i;
+    }
+    if (fresh && c_end[i] == c_start[i] + 1) {  // the owner of a new length-1 range also claims the per-slot shadow way
+      uint32_t* kr = st.pl_key + (size_t)phys_slot(g, c_start[i]) * g.wp;
+      int way = -1;
+      for (int w = g.ways - 1; w >= 0; --w)
+        if (kr[w] == 0) way = w;
+      if (way < 0) report(st, 5, i, c_start[i], c_round[i]);
+      else kr[way] = ((uint32_t)c_round[i] + 1u) | KEY_RANGE;
+    }
+    if (b.is_new) b.is_new[i] = fresh ? 1 : 0;
+    const int out = fresh ? e : (e >= 0 ? -3 - e : e);  // not mine to drive: acceptors / fill / tally skip it
+    c_entry[i] = out, b.entry[i] = out;
+  }
+  __syncthreads();
+  // acceptors (mencius/Acceptor.scala:237-260, 279-290): one thread per (range, acceptor group, acceptor)
+  for (int idx = tid; idx < cells; idx += 1024) {
+    const int i = idx / per, rem = idx % per;
+    if (c_entry[i] < 0) continue;
+    const int ag = rem / R, r = rem % R, bit = g.base + r;
+    const size_t row = ((size_t)i * A + ag) * 4;
+    if (b.target && !((b.target[row + (bit >> 6)] >> (bit & 63)) & 1ull)) continue;
+    const int start = c_start[i], end = c_end[i], round = c_round[i];
+    const size_t acc = (size_t)((start % L) * A + ag) * R + r;
+    const int pr = idx == tid ? pr0 : st.promised[acc];
+    const int word = (int)row * 2 + (bit >> 5);
+    if (round < pr) {  // :245-256 Nack(round = my round)
+      atomicOr(&c_nacks[word], 1u << (bit & 31));
+      atomicMax(&c_nr[i], pr);
+      continue;
+    }
+    if (pr != round) st.promised[acc] = round;  // :260
+    atomicOr(&c_votes[word], 1u << (bit & 31));
+    const int rows = (end - start + L - 1) / L;  // maxVotedSlot: see ranges_acceptor_one
+    for (int j = rows - 1; j >= 0 && j >= rows - A; --j) {
+      const int s = start + j * L;
+      if ((s / L) % A == ag) {
+        atomicMax(&st.max_voted[acc], s);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  // tally (mencius/ProxyLeader.scala:355-411) of the entries this launch created: no earlier votes, Pending
+  for (int i = tid; i < n; i += 1024) {
+    const int e = c_entry[i];
+    uint8_t ch = 0;
+    if (e >= 0) {
+      uint64_t* bits = rt.bits + (size_t)e * A * 4;
+      bool all = true;
+      for (int ag = 0; ag < A; ++ag) {
+        int c = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const uint32_t* v = &c_votes[((size_t)i * A + ag) * 8 + w * 2];
+          const uint64_t x = (((uint64_t)v[1] << 32) | v[0]) & g.member[w];  // :389-390
+          bits[ag * 4 + w] = x;
+          c += __popcll(x);
+        }
+        all = all && c >= b.quorum;  // :391
+      }
+      if (all) {  // :410 ; ChosenNoopRange(start, end) :395-407
+        rt.key[(size_t)e * 2 + 1] = ((uint64_t)b.run_id << 32) | ((uint64_t)(uint32_t)c_round[i] << 2) | RT_DONE;
+        ch = 1;
+      }
+    }
+    if (b.chosen) b.chosen[i] = ch;
+    if (b.nack_round) b.nack_round[i] = c_nr[i];
+  }
+  uint32_t* vo = reinterpret_cast<uint32_t*>(b.vote_bits);
+  uint32_t* no = reinterpret_cast<uint32_t*>(b.nack_bits);
+  for (int t = tid; t < n * A * 8; t += 1024) {
+    vo[t] = c_votes[t];
+    if (no) no[t] = c_nacks[t];
+  }
 }
 
 // fpx_proxy_forget: live entries that do not lie inside [first, first + count) move to the other buffer
