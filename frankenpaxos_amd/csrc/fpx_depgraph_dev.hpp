@@ -262,8 +262,12 @@ __global__ void __launch_bounds__(256) k_dg_rekey(const DgArgs a) {  // after th
 template <int N>
 __global__ void __launch_bounds__(256) k_dg_keys(const DgArgs a) {
   constexpr int NP = DgRow<N>::NP;
+  __shared__ int block_eligible;
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= a.m) return;
+  if (threadIdx.x == 0) block_eligible = 0;
+  __syncthreads();
+  bool eligible = false;
+  if (v < a.m) {
   int c[NP], d[NP];
   {
     const int4* cp = reinterpret_cast<const int4*>(a.clo + (size_t)v * NP);
@@ -278,7 +282,7 @@ __global__ void __launch_bounds__(256) k_dg_keys(const DgArgs a) {
   int L = 0;
   while (L + 1 < N && v >= a.base[L + 1]) ++L;
   const int x = a.first[L] + (v - a.base[L]);
-  bool eligible = true;
+  eligible = true;
   uint32_t sum = 0;
 #pragma unroll
   for (int l = 0; l < N; ++l) {
@@ -301,10 +305,13 @@ __global__ void __launch_bounds__(256) k_dg_keys(const DgArgs a) {
   // vertices on cycles with one closure sum can belong to several components: the closure's hash orders them first, so
   // that the members of a component (equal closures) end up neighbours
   a.pairs[v] = make_uint2((eligible && kind == 0u) ? dg_hash<N>(c) : 0u, (uint32_t)v);
-  if (eligible) {
-    const unsigned long long bal = __ballot(true);
-    if ((threadIdx.x & 63) == (int)__ffsll((unsigned long long)bal) - 1) atomicAdd(&a.ctl[3], (int)__popcll(bal));
   }
+  // the number of executables: wave -> workgroup (LDS) -> ONE atomic per workgroup on the counter (an atomic per
+  // wavefront was 16 384 of them queueing on one address: most of this kernel's 217 us, profiles/r04_depgraph_dev.md)
+  const unsigned long long bal = __ballot(eligible);
+  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&block_eligible, (int)__popcll(bal));
+  __syncthreads();
+  if (threadIdx.x == 0 && block_eligible) atomicAdd(&a.ctl[3], block_eligible);
 }
 
 template <int N>
