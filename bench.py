@@ -591,7 +591,7 @@ def main():
                 "frac_read": (read_bytes_per_slot(ballot_mode) * slots_per_launch / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if launches else None,
                 "traffic": traffic,
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command in an earlier profiled run "
-                                  "(profiles/traffic.json; collection and calibration: profiles/r03_pmc_summary.md) -- not "
+                                  "(profiles/traffic.json; collection and calibration: profiles/r04_pmc_summary.md) -- not "
                                   "measured in this run",
                 "algorithmic_bytes_per_slot": bps, "slots_per_launch": slots_per_launch,
                 "avg_kernel_ms": kernel_ms / max(launches, 1), "launches_timed": launches,
