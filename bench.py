@@ -293,7 +293,7 @@ def main():
     ap.add_argument("--config", choices=["headline", "2", "3", "4", "5", "thrifty"], default="headline",
                     help="headline = BASELINE.json's metric grid (2^20 slots x 256 acceptors); 2..5 = the other "
                          "BASELINE.json configs as bench lines of the same schema (bench_configs.py)")
-    ap.add_argument("--configs-block-steps", type=int, default=5,
+    ap.add_argument("--configs-block-steps", type=int, default=20,
                     help="N = 1 headline run: steps of each of BASELINE.json's other configs (2..5) timed after the "
                          "headline and reported in the line's `configs` block (0 = leave the block out)")
     ap.add_argument("--replica-row-deadline", type=int, default=120,
@@ -519,8 +519,9 @@ def main():
         for c in ("2", "3", "4", "5", "thrifty"):
             t_c = time.perf_counter()
             try:
-                sub = types.SimpleNamespace(steps=args.configs_block_steps, warmup=2, ballot=args.ballot, config=c,
-                                            no_cpu_baseline=True)
+                # config 4's ticks are drawn on the host (~0.5 s each): half as many of them
+                sub = types.SimpleNamespace(steps=max(1, args.configs_block_steps // 2) if c == "4" else args.configs_block_steps,
+                                            warmup=2, ballot=args.ballot, config=c, no_cpu_baseline=True)
                 full = bench_configs.run(sub, fa, None, dev, 0, 1, local_rank, all_reduce)
                 configs_block[c] = {
                     "metric": full["metric"], "value": full["value"], "unit": full["unit"], "steps": full["steps"],
@@ -595,6 +596,8 @@ def main():
                                   "measured in this run",
                 "algorithmic_bytes_per_slot": bps, "slots_per_launch": slots_per_launch,
                 "avg_kernel_ms": kernel_ms / max(launches, 1), "launches_timed": launches,
+                "kernel_time_source": "HIP events on the vote kernel's own dispatch packet (hipExtLaunchKernelGGL start / stop "
+                                      "events on the context's stream; fpx_profile_*), every timed launch",
                 # what bare streaming kernels reach on this chip (profiles/microbench/hbm_mix.hip, best of the
                 # grid / unroll sweep in profiles/r01_hbm_mix.txt): the practical ceiling beside the spec peak
                 "measured_stream_GBs": MEASURED_STREAM_GBS,

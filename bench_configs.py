@@ -28,23 +28,24 @@ def _splitmix_values(slot):
     return steady_values_torch(slot)
 
 
-class Timer:
-    """HIP events on the stream the library launches on (the torch current stream, handed to the context)"""
+class RegionTimer:
+    """ONE pair of HIP events around the timed steps, on the stream the library launches on (the torch current stream,
+    handed to the context): device time per step = elapsed / steps, the gaps between a step's kernels included.  (A pair
+    of events per step put two marker packets between the steps: 8 % of a config-4 tick, 15 % of a config-5 band,
+    profiles/r04_events.md.)"""
 
-    def __init__(self, n):
-        self.ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
-        self.k = 0
+    def __init__(self):
+        self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    def __enter__(self):
-        self.ev[self.k][0].record()
+    def start(self):
+        self.a.record()
 
-    def __exit__(self, *a):
-        self.ev[self.k][1].record()
-        self.k += 1
+    def stop(self):
+        self.b.record()
 
-    def avg_ms(self):
+    def total_ms(self):
         torch.cuda.synchronize()
-        return sum(a.elapsed_time(b) for a, b in self.ev[:self.k]) / max(self.k, 1)
+        return self.a.elapsed_time(self.b)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -205,16 +206,9 @@ def epaxos_setup(fa, dev, local_rank, K, Wm):
         # one packed line per command (fpx_epx_preaccept_packed_dev): deps | leader_deps | own_values_end | fast
         ticks.append((d(leader), d(number), d(key), d(is_set), d(mask), d(rank),
                       torch.full((m, epx.packed_stride()), -7, dtype=torch.int32, device=dev)))
-    timer = Timer(K)
-    state = {"timing": False}
-
     def step(i):
         leader, number, key, is_set, mask, rank, packed = ticks[i]
-        if state["timing"]:
-            with timer:
-                epx.preaccept_packed_dev(leader, number, key, is_set, mask, rank, packed)
-        else:
-            epx.preaccept_packed_dev(leader, number, key, is_set, mask, rank, packed)
+        epx.preaccept_packed_dev(leader, number, key, is_set, mask, rank, packed)
 
     def verify(lo, hi):
         """the first timed tick against the oracle on EVERY output (the oracle replays the ticks before it: the conflict
@@ -239,10 +233,6 @@ def epaxos_setup(fa, dev, local_rank, K, Wm):
             done += m                                   # every command is decided (fast commit or Accept phase)
         return done
 
-    def profile():
-        state["timing"] = False
-        return timer.k, timer.avg_ms() * timer.k
-
     def cpu():
         from oracle import pyoracle
         pyoracle.build()
@@ -264,13 +254,12 @@ def epaxos_setup(fa, dev, local_rank, K, Wm):
                 workload="EPaxos n = 5: one tick = 2^20 fresh single-key commands (1024 keys, Bernoulli get/set) through "
                          "the pre-accept phase of all replicas: conflict scan in every replica's delivery order, "
                          "fast-path test, slow-path union, commit into every conflict index",
-                kernel="K5 tick, second form (k_kp_hist, k_kp_scan, k_kp_scatter<5>: one record per command into its key's segment; "
-                       "k_epx_key2<5>: per key on chip -- order by rank per replica, scans, decisions, index update)", profile=profile,
+                kernel="K5 tick, second form (k_kp_hist, k_kp_scatter<5>: one record per command into its key's segment; "
+                       "k_epx_key2<5>: per key on chip -- order by rank per replica, scans, decisions, index update)", region_timed=True,
                 metric="EPaxos commands decided/sec (BASELINE.json configs[3])", cpu=cpu,
                 extra={"commands_per_tick": m, "replicas": n, "keys": num_keys,
                        "byte_model": "34 B inputs + 64 B packed output line per command; round 2's model (243 B) also counted "
-                                     "the 4 conflict rows of 20 B each way, which no longer cross HBM"},
-                start_timing=lambda: state.update(timing=True))
+                                     "the 4 conflict rows of 20 B each way, which no longer cross HBM"})
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -307,17 +296,10 @@ def mencius_setup(fa, dev, local_rank, rank, world, K, Wm):
                       torch.full((slot.numel(),), -7, dtype=torch.int32, device=dev),
                       start.contiguous(), end.contiguous(), torch.zeros_like(start),
                       torch.zeros(start.numel(), dtype=torch.uint8, device=dev)))
-    timer = Timer(K)
-    state = {"timing": False}
-
     def step(i):
         slot, rnd, val, ch, cv, start, end, rr, rch = steps[i]
         ctx.phase2_fused_dev(slot, rnd, val, None, ch, None, cv)
-        if state["timing"]:
-            with timer:
-                ctx.noop_ranges_fused_dev(start, end, rr, None, None, None, None, None, rch)
-        else:
-            ctx.noop_ranges_fused_dev(start, end, rr, None, None, None, None, None, rch)
+        ctx.noop_ranges_fused_dev(start, end, rr, None, None, None, None, None, rch)
 
     def verify(lo, hi):
         done = 0
@@ -327,10 +309,6 @@ def mencius_setup(fa, dev, local_rank, rank, world, K, Wm):
             assert bool(rch.all()), "step %d: noop ranges" % i
             done += int(ch.sum().item()) + int(rch.sum().item()) * rows     # a chosen range commits its `rows` slots
         return done
-
-    def profile():
-        n2, ms2 = ctx.profile_read()
-        return n2, ms2 + timer.avg_ms() * timer.k        # both kernels of the step: k_phase2 + the K4 chain
 
     def cpu():
         from oracle import pyoracle
@@ -362,11 +340,11 @@ def mencius_setup(fa, dev, local_rank, rank, world, K, Wm):
                          "others skip theirs with one noop range each (fused K4)"
                          % (L, band, "one batch in slot order across the leader groups" if os.environ.get("FPX_CFG5_ORDER") == "slot"
                             else "the proposing leader groups' batches back to back, each in slot order"),
-                kernel="k_phase2 (fused K3) + K4 chain (k_ranges_open .. k_ranges_tally)", profile=profile,
+                kernel="k_phase2 (fused K3) + K4 (k_ranges_fill_lg, k_ranges_chain)", region_timed=True,
                 metric="committed log slots/sec (BASELINE.json configs[4])", cpu=cpu,
                 extra={"slots_per_step_per_gpu": band, "leader_groups_per_gpu": L, "replicas": R,
                        "ranges_per_step_per_gpu": L // 2},
-                start_timing=lambda: state.update(timing=True), scaling="strong")
+                scaling="strong")
 
 
 def traffic_of(config):
@@ -400,17 +378,22 @@ def run(args, fa, dist, dev, rank, world, local_rank, all_reduce):
     for i in range(Wm):
         w["step"](i)
     assert ctx.sync() == 0
+    # kernel time: a step of one vote kernel is timed by the library (fpx_profile_*: events on the kernel's own dispatch
+    # packet); a step of several kernels (configs 4, 5) by one pair of events around the timed steps
+    region = RegionTimer() if w.get("region_timed") else None
     if hasattr(ctx, "profile_enable"):
-        ctx.profile_enable(True)
-    if "start_timing" in w:
-        w["start_timing"]()
+        ctx.profile_enable(region is None)
     fence()
     t0 = time.perf_counter()
+    if region:
+        region.start()
     for i in range(Wm, Wm + K):
         w["step"](i)
+    if region:
+        region.stop()
     fence()
     elapsed = time.perf_counter() - t0
-    launches, kernel_ms = w["profile"]()
+    launches, kernel_ms = (K, region.total_ms()) if region else w["profile"]()
     assert ctx.sync() == 0
     done = w["verify"](Wm, Wm + K)
     assert done == K * w["units"], (done, K * w["units"])
@@ -441,6 +424,9 @@ def run(args, fa, dist, dev, rank, world, local_rank, all_reduce):
                               "all kernels of one step summed), not measured in this run",
             "algorithmic_bytes_per_unit": w["bytes_per_unit"], "units_per_launch": w["units"],
             "avg_kernel_ms": kernel_ms / max(launches, 1), "launches_timed": launches,
+            "kernel_time_source": ("one pair of HIP events around the timed steps on the launch stream / steps: all kernels of "
+                                   "a step and the gaps between them" if region else
+                                   "HIP events on the vote kernel's own dispatch packet (hipExtLaunchKernelGGL; fpx_profile_*)"),
             "note": "small-row workloads (16-byte rows) run at 3.6 - 4.0 TB/s of actual traffic at best and are bound by "
                     "dependent-step latency below ~10^6 slots per launch: the fraction of the HBM peak is reported for "
                     "the contract, the absolute rate is the figure of merit",

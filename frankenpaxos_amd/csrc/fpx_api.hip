@@ -5,6 +5,7 @@
 #include "../../include/fpx.h"
 
 #include <dlfcn.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdint>
@@ -91,6 +92,9 @@ struct fpx_ctx {
   bool profiling = false;
   std::vector<hipEvent_t> ev;  // start/stop pairs
   size_t ev_used = 0;
+  // the events of the K1 / K3 launch being enqueued: they ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL),
+  // so a timed launch puts no marker packets on the stream (two hipEventRecords per launch cost 5 - 15 us of a step)
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   // host-pointer K3 on big batches: upload / K3 / download of consecutive pieces overlap on three streams
   hipStream_t up_stream = nullptr, down_stream = nullptr;
   HostSlot* hslots = nullptr;  // calls in flight on page-locked arrays (host_submit / host_wait)
@@ -282,9 +286,11 @@ void launch_phase2_3(fpx_ctx* ctx, const Batch& b0, bool fused, int grid) {
   if (fused) allow_lds(k_phase2<G, MODE, PS, true>, lds);
   else allow_lds(k_phase2<G, MODE, PS, false>, lds);
   if (fused)
-    hipLaunchKernelGGL((k_phase2<G, MODE, PS, true>), dim3(grid), dim3(256), lds, ctx->stream, ctx->g, ctx->st, b);
+    hipExtLaunchKernelGGL((k_phase2<G, MODE, PS, true>), dim3(grid), dim3(256), (uint32_t)lds, ctx->stream, ctx->ev_start,
+                          ctx->ev_stop, 0, ctx->g, ctx->st, b);
   else
-    hipLaunchKernelGGL((k_phase2<G, MODE, PS, false>), dim3(grid), dim3(256), lds, ctx->stream, ctx->g, ctx->st, b);
+    hipExtLaunchKernelGGL((k_phase2<G, MODE, PS, false>), dim3(grid), dim3(256), (uint32_t)lds, ctx->stream, ctx->ev_start,
+                          ctx->ev_stop, 0, ctx->g, ctx->st, b);
 }
 
 template <int G, int MODE>
@@ -390,20 +396,20 @@ int enqueue_phase2(fpx_ctx* ctx, Batch& b, bool fused) {
     b.run_done = (uint8_t*)ctx->d_run_done.p;
   }
   const bool prof = ctx->profiling && ctx->ev_used + 2 <= ctx->ev.size();
-  if (prof) HIPCHK(ctx, hipEventRecord(ctx->ev[ctx->ev_used], ctx->stream));
   for (int pass = two ? 0 : 1; pass < 2; ++pass) {
+    // start of the first vote kernel to end of the last (two with the packed walk ahead)
+    ctx->ev_start = prof && pass == (two ? 0 : 1) ? ctx->ev[ctx->ev_used] : nullptr;
+    ctx->ev_stop = prof && pass == 1 ? ctx->ev[ctx->ev_used + 1] : nullptr;
     b.parity = b.solo ? 0 : (int32_t)(ctx->phase2_launches++ & 1u);  // every other K1 / K3 launch is followed by its k_finalize
     if (++ctx->launch_seq == 0) ctx->launch_seq = 1;
     b.launch_seq = ctx->launch_seq;
     ctx->packed_pass = pass == 0;
     launch_phase2(ctx, b, fused, grid);
     ctx->packed_pass = false;
+    ctx->ev_start = ctx->ev_stop = nullptr;
     rc = launch_check(ctx);
     if (rc) return rc;
-    if (pass == 1 && prof) {
-      HIPCHK(ctx, hipEventRecord(ctx->ev[ctx->ev_used + 1], ctx->stream));
-      ctx->ev_used += 2;
-    }
+    if (pass == 1 && prof) ctx->ev_used += 2;
     if (b.solo) continue;
     const int ntab = ctx->g.ngroups * ctx->g.R;
     const int slices = std::max(FINALIZE_SLICES, std::min(256, grid / 32));  // ~8 partial rows per wavefront
