@@ -400,7 +400,6 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
   int k = blockIdx.x;
   if (k >= st.num_keys) return;
   fetch(k, cur);
-  if (threadIdx.x < N) rmin[threadIdx.x] = 0x7fffffff, rmax[threadIdx.x] = 0;
   __syncthreads();
   for (; k < st.num_keys; k += gridDim.x) {
     const int c = cur.len;  // <= TC
@@ -409,9 +408,6 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
     // ---- the records: i, number, flags field-major; per replica the command's sort word rank << 11 | slot at the
     // command's slot, ~0 where the replica takes no part (they sort last and are not counted)
     {
-      int lo[N], hi[N];
-#pragma unroll
-      for (int q = 0; q < N; ++q) lo[q] = 0x7fffffff, hi[q] = 0;
 #pragma unroll
       for (int j = 0; j < T::RQ; ++j) {
         const int sl = j * T::THREADS + threadIdx.x;
@@ -424,7 +420,6 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
           for (int q = 0; q < N; ++q) {
             const bool in = (part >> q) & 1u;
             sortA[(size_t)q * T::TC + sl] = in ? (((uint32_t)rk[q] << KP_SLOT_BITS) | (uint32_t)sl) : KP_INVALID;
-            lo[q] = in ? min(lo[q], rk[q]) : lo[q], hi[q] = in ? imax(hi[q], rk[q]) : hi[q];
           }
         } else if (sl < cpad) {
 #pragma unroll
@@ -434,31 +429,19 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
       for (int j = threadIdx.x; j < N * T::W * 2 * N; j += T::THREADS) tot[j] = 0;
       for (int j = threadIdx.x; j < N * T::NBK; j += T::THREADS) bk[j] = 0;
       if (threadIdx.x == 0) *degenerate = 0;
+      if (threadIdx.x < N) rmin[threadIdx.x] = 0x7fffffff, rmax[threadIdx.x] = 0;  // (only a second sorting attempt uses them)
       // the replicas' TopOne vectors of the key (KeyValueStore.scala:229-230), the carries of the scans: requested
       // here, parked in LDS before the scans need them (held in registers across the key they spilled)
       if (w == 0 && lane < 2 * N) {
         const size_t ib = ((size_t)r * st.num_keys + k) * N;
         carry_in = lane < N ? st.gets[ib + lane] : st.sets[ib + lane - N];
       }
-      // the spread of every replica's ranks (rmin / rmax were reset while the previous key was sorted): a reduction over
-      // each row of 16 lanes on the DPP network, then LDS atomics from the rows' last lanes
-#pragma unroll
-      for (int q = 0; q < N; ++q) {
-        if ((int)(threadIdx.x & ~63u) >= c) break;  // (a wavefront without records)
-        int mx = hi[q], mn = 0x7fffffff - lo[q];
-        mx = imax(mx, dpp0<0x111, 0xF>(mx)), mn = imax(mn, dpp0<0x111, 0xF>(mn));
-        mx = imax(mx, dpp0<0x112, 0xF>(mx)), mn = imax(mn, dpp0<0x112, 0xF>(mn));
-        mx = imax(mx, dpp0<0x114, 0xF>(mx)), mn = imax(mn, dpp0<0x114, 0xF>(mn));
-        mx = imax(mx, dpp0<0x118, 0xF>(mx)), mn = imax(mn, dpp0<0x118, 0xF>(mn));
-        mn = 0x7fffffff - mn;
-        if ((lane & 15) == 15 && mn <= mx) atomicMin(&rmin[q], mn), atomicMax(&rmax[q], mx);
-      }
     }
     const int kn = k + gridDim.x;
     const bool more = kn < st.num_keys;
     __syncthreads();
     // ---- the replica's words in rank order.  A wavefront owns a run of slots.  Bucket sort: the ranks of one key
-    // spread over [rmin, rmax]; NBK buckets of equal width hold about one word each, a word's place is its bucket's
+    // spread over the tick's [0, m) (or, failing that, the key's own [rmin, rmax]); NBK buckets of equal width hold about one word each, a word's place is its bucket's
     // start + the words of the bucket below it (found by looking at them: buckets are tiny) -- 4 LDS round trips per
     // word where an LSD radix sort of the 21 rank bits takes 3 passes of ~90 instructions per 64 words.  Ranks that
     // clump (a bucket with more than KP_MAX_OCC words) send the key through the radix sort below instead: any order of
@@ -470,10 +453,32 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
     uint32_t* mycnt = rcnt + (r * T::W + w) * KP_RADIX;
     uint32_t* mycur = rcur + (r * T::W + w) * KP_RADIX;
     int sort_passes = passes;
-    {
+    // First attempt: buckets over the whole tick's ranks [0, m) -- a rank row is a permutation of them, and a key whose
+    // commands arrive all through the tick spreads evenly there (no reduction over the key's ranks is needed: the
+    // per-key minimum / maximum cost 6.7 us of the kernel's 76).  A key whose commands arrive in a burst fills a few
+    // buckets only: second attempt over the key's own [rmin, rmax]; ranks that clump inside that as well go to the
+    // radix sort.
+#pragma nounroll
+    for (int attempt = 0; attempt < 2 && sort_passes != 0; ++attempt) {
       uint32_t* bkr = bk + r * T::NBK;
-      const int lo = rmin[r];
-      const unsigned span1 = rmax[r] >= lo ? (unsigned)(rmax[r] - lo) : 0u;  // span - 1
+      int lo = 0;
+      unsigned span1 = (unsigned)max(a.m - 1, 0);  // span - 1
+      if (attempt == 1) {
+        // (everybody has seen *degenerate == 1 behind the barrier below; the bucket table holds the first attempt's starts)
+        int mn = 0x7fffffff, mx = 0;
+        for (int p = p0 + lane; p < p1; p += 64) {
+          const uint32_t wd = src[p];
+          if (wd != KP_INVALID) mn = min(mn, (int)(wd >> KP_SLOT_BITS)), mx = imax(mx, (int)(wd >> KP_SLOT_BITS));
+        }
+        mx = __builtin_amdgcn_readlane(wave_incl_max(mx), 63);
+        mn = 0x7fffffff - __builtin_amdgcn_readlane(wave_incl_max(0x7fffffff - mn), 63);
+        if (lane == 0 && mn <= mx) atomicMin(&rmin[r], mn), atomicMax(&rmax[r], mx);
+        for (int j = threadIdx.x; j < N * T::NBK; j += T::THREADS) bk[j] = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) *degenerate = 0;
+        lo = rmin[r];
+        span1 = rmax[r] >= lo ? (unsigned)(rmax[r] - lo) : 0u;
+      }
       constexpr int LOG_NBK = T::NBK == 1024 ? 10 : 9;
       const int sh = max(0, (32 - __clz((int)span1 | 1)) - LOG_NBK);   // (span - 1) >> sh < NBK
       uint32_t ec[T::CPW], eq[T::CPW], ea[T::CPW];
@@ -486,9 +491,8 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
           ea[cc] = atomicAdd(&bkr[eq[cc]], 1u);
         }
       }
-      if (w == 0 && lane < 2 * N) base[r * 2 * N + lane] = carry_in;
+      if (attempt == 0 && w == 0 && lane < 2 * N) base[r * 2 * N + lane] = carry_in;
       __syncthreads();
-      if (threadIdx.x < N) rmin[threadIdx.x] = 0x7fffffff, rmax[threadIdx.x] = 0;  // (read above by everybody: free for the next key)
       if (w == 0) {  // bucket counts -> bucket starts, by one wavefront per replica: NBK / 64 consecutive buckets per lane
         constexpr int PL = T::NBK / 64;
         uint32_t v[PL], sum = 0, big = 0;
@@ -637,6 +641,19 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
     }
     if (more) fetch(kn, nxt);  // the next key's loads fly while this one is decided
     __syncthreads();
+    // ---- commit -> updateConflictIndex at every replica (Replica.scala:815-828): the key's watermarks learn every
+    // instance of the tick (each command was scanned by its leader's replica: the max over replicas is the tick).  The
+    // puts are complete once the words are sorted, so this runs here, on each replica's last wavefront (the first ones
+    // decide two commands per thread below), and not as a one-wavefront tail in front of the key's last barrier
+    if (w == T::W - 1 && lane < 2 * N) {
+      int v = 0;
+#pragma unroll
+      for (int j = 0; j < N * T::W; ++j) v = imax(v, tot[j * 2 * N + lane]);
+      const size_t ib = ((size_t)r * st.num_keys + k) * N;
+      int32_t* p = lane < N ? &st.gets[ib + lane] : &st.sets[ib + lane - N];
+      if (v > base[r * 2 * N + lane]) *p = v;
+    }
+    if (threadIdx.x == T::THREADS - 1) a.tot[(size_t)k * KP_TOT_STRIDE] = 0;  // the next tick claims from zero
     // ---- handlePreAcceptOk (Replica.scala:1291-1419): every counted answer is local conflicts U the PreAccept's
     // dependencies (handlePreAccept :1257-1262); fast path iff the n-2 answers are identical (popularItems); the union
     // the slow path proposes (preAcceptingSlowPath :796-813) is their column-wise max, which is the agreed row as well
@@ -766,16 +783,6 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
         }
       }
     }
-    // ---- commit -> updateConflictIndex at every replica (Replica.scala:815-828): the key's watermarks learn every
-    // instance of the tick (each command was scanned by its leader's replica: the max over replicas is the tick)
-    if (w == 0 && lane < 2 * N) {
-      int v = 0;
-      for (int j = 0; j < N * T::W; ++j) v = imax(v, tot[j * 2 * N + lane]);
-      const size_t ib = ((size_t)r * st.num_keys + k) * N;
-      int32_t* p = lane < N ? &st.gets[ib + lane] : &st.sets[ib + lane - N];
-      if (v > base[r * 2 * N + lane]) *p = v;
-    }
-    if (threadIdx.x == 0) a.tot[(size_t)k * KP_TOT_STRIDE] = 0;  // the next tick claims from zero
     __syncthreads();  // the tables are reused by the next key
     cur = nxt;
   }

@@ -1187,6 +1187,32 @@ def test_epaxos_clumped_ranks_take_the_radix_sort(oracle, n):
             assert [x.tolist() for x in gpu.read_index(r, k)] == [x.tolist() for x in ref.read_index(r, k)]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [3, 5, 7])
+def test_epaxos_a_burst_of_one_key_takes_the_second_bucket_attempt(oracle, n):
+    """k_epx_key2's first sorting attempt spreads a key's ranks over the whole tick's [0, m); a key whose commands all
+    arrive in one burst fills a handful of those buckets, and the second attempt buckets them over the key's own rank
+    range (a third of the keys here: bursts of 400 - 600 neighbours in the delivery order, the others spread out)"""
+    from frankenpaxos_amd.epaxos import EPaxos
+
+    num_keys, m = 12, 30000
+    gpu, ref = EPaxos(n, num_keys), oracle.EPaxos(n, num_keys)
+    rng = np.random.default_rng(170 + n)
+    nxt = [0] * n
+    for tick in range(3):
+        leader, number, key, is_set, mask, rank = random_tick(rng, n, num_keys, m, nxt, 3.0, fifo=tick != 1)
+        key[:] = 4 + rng.integers(0, num_keys - 4, m)
+        for k, (at, length) in enumerate([(100, 600), (9000, 400), (20000, 500), (m - 450, 450)]):
+            key[at:at + length] = k
+        a, b = gpu.preaccept(leader, number, key, is_set, mask, rank), ref.preaccept(leader, number, key, is_set, mask, rank)
+        assert a[0] == b[0] == 0
+        for x, y in zip(a[1:], b[1:]):
+            np.testing.assert_array_equal(x, y)
+    for r in range(n):
+        for k in range(num_keys):
+            assert [x.tolist() for x in gpu.read_index(r, k)] == [x.tolist() for x in ref.read_index(r, k)]
+
+
 # ---- K8: Replica.handlePrepareOk, the recovering replica's decision (Replica.scala:1759-1884) ---------------------
 def test_oracle_handle_prepare_oks_by_hand(oracle):
     """n = 5 (f = 2, slow quorum 3), instance X = (0, 0), recovered by replica 4.
