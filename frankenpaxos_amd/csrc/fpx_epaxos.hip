@@ -1512,6 +1512,8 @@ int launch_kp(fpx_epx* e, const EpxBatch& b, int32_t* d_packed, bool* done) {
                               (int)T::BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_kp_hist), hipFuncAttributeMaxDynamicSharedMemorySize,
                               KP_HG * KP_MAXB * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_kp_scatter<N>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)KpScat<N>::BYTES);
     e->kp_lds_allowed = true;
   }
   // (Round 4 tried the partition of tick t + 1 on a stream of its own beside the key kernel of tick t: the key kernel's
@@ -1519,7 +1521,8 @@ int launch_kp(fpx_epx* e, const EpxBatch& b, int32_t* d_packed, bool* done) {
   // room beside it, and the two event hops between the streams cost 15 us per tick -- 0.125 ms against 0.119 in order.)
   hipStream_t ps = e->stream;
   hipLaunchKernelGGL(k_kp_hist, dim3(a.groups), dim3(128 * KP_HG), (size_t)KP_HG * a.B * 4, ps, e->st, b, a);
-  hipLaunchKernelGGL((k_kp_scatter<N>), dim3(8 * ((a.tiles + 7) / 8)), dim3(KP_ST), 0, ps, e->st, b, a);
+  const int units = (a.tiles + KpScat<N>::TILES - 1) / KpScat<N>::TILES;
+  hipLaunchKernelGGL((k_kp_scatter<N>), dim3(8 * ((units + 7) / 8)), dim3(KpScat<N>::THREADS), KpScat<N>::BYTES, ps, e->st, b, a);
   // k_epx_key2 is enqueued at once -- it returns at its first instruction when a key does not fit -- and the host then
   // learns, while the GPU works on, whether the first form has to take the tick after all (launching the kernel
   // only after the answer left the GPU idle for ~30 us per tick when ticks were enqueued back to back)

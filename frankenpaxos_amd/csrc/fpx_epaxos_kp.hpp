@@ -11,9 +11,10 @@
 //                  scan over tiles: round 3's k_kp_scan and its table of per-tile counts in key order are gone); a
 //                  claim that runs past the segment (more commands of one key than the on-chip tables take) is
 //                  reported: such a tick goes the first form's way, nothing of it is applied here
-//   k_kp_scatter   validates the tick, writes record(i) = {i | header, number, rank[0..n) packed} to its place (the
-//                  tile's claimed run + a tile-local LDS counter), accumulates the fingerprints that tell a permutation
-//                  from a non-permutation, and tells the host through a page-locked word whether a claim overflowed
+//   k_kp_scatter   validates the tick, packs record(i) = {i | header, number, rank[0..n) packed}, stages the tile's records
+//                  in LDS in key order and writes every key's run to its place (the tile's claimed run) from consecutive
+//                  lanes, accumulates the fingerprints that tell a permutation from a non-permutation, and tells the
+//                  host through a page-locked word whether a claim overflowed
 //   k_epx_key2<N>  one persistent workgroup per CU, key after key, the next key's records in flight: a thread unpacks a
 //                  record into the per-replica sort words (rank << 11 | slot; ~0 where the replica takes no part) IN
 //                  PLACE of a compaction pass; the words are ordered by a bucket sort in LDS (LSD radix sort for
@@ -37,7 +38,6 @@ constexpr int KP_TOT_STRIDE = 16;        // words between two keys' claim counte
 constexpr int KP_IDX_BITS = 21;          // message indices and ranks: m < 2^21
 constexpr uint32_t KP_IDX_MASK = (1u << KP_IDX_BITS) - 1u;
 constexpr uint32_t KP_INVALID = 0xffffffffu;  // sort word of a command the replica takes no part in (sorts last)
-constexpr int KP_ST = 512;               // threads of a scatter workgroup: every thread's KP_TILE / KP_ST messages in flight at once
 
 template <int N> struct KpTile {
   // words per record.  n <= 5: {i | header << 21, number, ranks packed 21 bits each} -- 16 B (n = 3), 24 B (n = 5);
@@ -213,20 +213,43 @@ __global__ void __launch_bounds__(128 * KP_HG) k_kp_hist(const EpxState st, cons
   if (threadIdx.x == 0) a.big[blockIdx.x] = over ? 1u : 0u;
 }
 
-// validation of one message exactly as k_epx_keys, record out, fingerprints
+// The scatter workgroup: KpScat<N>::TILES neighbouring tiles of one k_kp_hist group (whose claimed runs are neighbours in
+// every key's segment, in tile order: the workgroup's commands of a key are ONE run starting where its first tile's
+// does).  Validation of one message exactly as k_epx_keys; the records are STAGED in LDS in key order and leave as
+// 8-byte words from consecutive lanes, so a key's run crosses the memory pipeline as requests of whole sectors instead of
+// a 16- and an 8-byte store per record at 2 M random places (as rounds 3 - 4 had it: 55 MB written for 25 MB of records;
+// staged: 27.5 MB).  One tile per workgroup (two of them fit a CU): with two tiles the runs are twice as long, but ONE
+// 1024-thread workgroup per CU loads, counts, stages and stores in lockstep with all the others -- measured 3 us slower
+// per tick (profiles/r04_k5.md).
+template <int N> struct KpScat {
+  static constexpr int TILES = 1;
+  static constexpr int SW = TILES * KP_TILE;           // records of one workgroup
+  static constexpr int THREADS = SW / 4;               // four messages per thread, all their loads in flight at once
+  static constexpr int NI = KpTile<N>::NI;
+  static constexpr size_t BYTES = ((size_t)2 * KP_MAXB + SW + (size_t)SW * NI) * 4;
+  static_assert(KP_HG % TILES == 0, "a workgroup's tiles belong to one k_kp_hist group");
+  static_assert(KP_MAXB % THREADS == 0 || THREADS % KP_MAXB == 0, "keys per thread in the scan");
+};
+
 template <int N>
-__global__ void __launch_bounds__(KP_ST) k_kp_scatter(const EpxState st, const EpxBatch b, const KpArgs a) {
+__global__ void __launch_bounds__(KpScat<N>::THREADS) k_kp_scatter(const EpxState st, const EpxBatch b, const KpArgs a) {
   using T = KpTile<N>;
-  __shared__ uint32_t cnt[KP_MAXB];
-  __shared__ uint32_t goff[KP_MAXB];  // the tile's first record of the key, in records from the start of a.recs
-  __shared__ unsigned long long fsum[KP_ST / 64][2 * (N + 1)];
+  using S = KpScat<N>;
+  extern __shared__ __align__(16) uint32_t kp_sc[];
+  uint32_t* cnt = kp_sc;                    // [KP_MAXB] the workgroup's commands of the key; after the scan: where its run starts in `stage`
+  uint32_t* goff = cnt + KP_MAXB;           // [KP_MAXB] the run's first record, in records from the start of a.recs
+  uint32_t* gpos = goff + KP_MAXB;          // [SW] where the staged record goes (~0: nowhere, a claim ran past its key's segment)
+  uint32_t* stage = gpos + S::SW;           // [SW][NI]
+  __shared__ unsigned long long fsum[S::THREADS / 64][2 * (N + 1)];
+  __shared__ uint32_t wsum[S::THREADS / 64];
   // workgroups go round-robin over the 8 XCDs: the ones of one XCD take consecutive tiles, whose records are neighbours
-  // in every key's segment -- their stores meet in the same L2 and leave it as whole lines
-  const int tps = (a.tiles + 7) / 8, tile = ((int)blockIdx.x % 8) * tps + (int)blockIdx.x / 8;
+  // in every key's segment -- their stores meet in the same L2
+  const int units = (a.tiles + S::TILES - 1) / S::TILES;
+  const int ups = (units + 7) / 8, unit = ((int)blockIdx.x % 8) * ups + (int)blockIdx.x / 8;
   if (blockIdx.x == 0) {
     // did a claim run past a key's segment?  the key kernel reads ctl[0], the host the page-locked word
     uint32_t nbig = 0;
-    for (int j = threadIdx.x; j < a.groups; j += KP_ST) nbig += a.big[j];
+    for (int j = threadIdx.x; j < a.groups; j += S::THREADS) nbig += a.big[j];
     nbig = (uint32_t)__syncthreads_count(nbig != 0);
     if (threadIdx.x == 0) {
       a.ctl[0] = nbig;
@@ -237,19 +260,21 @@ __global__ void __launch_bounds__(KP_ST) k_kp_scatter(const EpxState st, const E
       }
     }
   }
-  if ((int)blockIdx.x / 8 >= tps || tile >= a.tiles) return;
-  for (int k = threadIdx.x; k < a.B; k += KP_ST) cnt[k] = 0, goff[k] = (uint32_t)k * (uint32_t)a.tc + a.hist[(size_t)tile * a.B + k];
+  if ((int)blockIdx.x / 8 >= ups || unit >= units) return;
+  const int tile = unit * S::TILES;
+  for (int k = threadIdx.x; k < a.B; k += S::THREADS) cnt[k] = 0, goff[k] = (uint32_t)k * (uint32_t)a.tc + a.hist[(size_t)tile * a.B + k];
+  for (int k = a.B + threadIdx.x; k < KP_MAXB; k += S::THREADS) cnt[k] = 0;
   __syncthreads();
   unsigned long long f[2 * (N + 1)];
 #pragma unroll
   for (int q = 0; q < 2 * (N + 1); ++q) f[q] = 0ull;
   const int first = tile * KP_TILE;
-  constexpr int MB = KP_TILE / KP_ST;  // messages of one thread: all their loads are in flight together
+  constexpr int MB = S::SW / S::THREADS;  // messages of one thread: all their loads are in flight together
   int Lq[MB], kq[MB], xq[MB], rkq[MB][N];
   unsigned mq[MB], sq[MB], tq[MB];
 #pragma unroll
   for (int u = 0; u < MB; ++u) {
-    const int i = first + u * KP_ST + threadIdx.x;
+    const int i = first + u * S::THREADS + threadIdx.x;
     const bool in = i < a.m;
     Lq[u] = in ? b.leader[i] : 0, kq[u] = in ? b.key[i] : 0, xq[u] = in ? b.number[i] : 0;
     mq[u] = in ? b.resp_mask[i] : 0u, tq[u] = in ? b.is_set[i] : 0u;
@@ -257,13 +282,14 @@ __global__ void __launch_bounds__(KP_ST) k_kp_scatter(const EpxState st, const E
 #pragma unroll
     for (int r = 0; r < N; ++r) rkq[u][r] = in ? b.rank[(size_t)r * a.m + i] : 0;
   }
+  uint32_t at[MB];  // the command's number among the workgroup's commands of its key; ~0: no record
 #pragma unroll
   for (int u = 0; u < MB; ++u) {
-    const int i = first + u * KP_ST + threadIdx.x;
+    const int i = first + u * S::THREADS + threadIdx.x;
+    at[u] = ~0u;
     if (i >= a.m) continue;
     const int L = Lq[u], k = kq[u], x = xq[u];
     const unsigned mask = mq[u], seen = sq[u];
-    const int is_set = tq[u] ? 1 : 0;
     bool ok = L >= 0 && L < N && x >= 0 && k >= 0 && k < a.B;
     ok = ok && !((mask >> (ok ? L : 0)) & 1u) && (mask >> N) == 0 && (int)__popc(mask) == N - 2;
     ok = ok && (mask & ~seen) == 0 && !((seen >> (ok ? L : 0)) & 1u) && (seen >> N) == 0;
@@ -285,22 +311,50 @@ __global__ void __launch_bounds__(KP_ST) k_kp_scatter(const EpxState st, const E
       kp_reject(a, i);
       continue;
     }
-    const uint32_t pos = goff[k] + atomicAdd(&cnt[k], 1u);
-    if (pos >= (uint32_t)(k + 1) * (uint32_t)a.tc) continue;  // past the key's segment: the tick goes the first form's way
-    uint32_t w[T::NI];
-    kp_pack<N>(w, i, x, L, is_set, mask, seen, rkq[u]);
-    uint32_t* rec = a.recs + (size_t)pos * T::NI;
-    if constexpr (T::NI == 6) {  // 24 bytes at an 8-byte boundary: 16 + 8 or 8 + 16
-      if (pos & 1u) {
-        *reinterpret_cast<uint2*>(rec) = make_uint2(w[0], w[1]);
-        *reinterpret_cast<uint4*>(rec + 2) = make_uint4(w[2], w[3], w[4], w[5]);
-      } else {
-        *reinterpret_cast<uint4*>(rec) = make_uint4(w[0], w[1], w[2], w[3]);
-        *reinterpret_cast<uint2*>(rec + 4) = make_uint2(w[4], w[5]);
-      }
-    } else {
+    at[u] = atomicAdd(&cnt[k], 1u);
+  }
+  __syncthreads();
+  // the runs' starts in the staging buffer: exclusive sums of the counts, KP_MAXB / THREADS keys per thread
+  {
+    constexpr int E = KP_MAXB >= S::THREADS ? KP_MAXB / S::THREADS : 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool mine = (int)threadIdx.x * E < KP_MAXB;
+    uint32_t c[E], sum = 0;
 #pragma unroll
-      for (int q = 0; q < T::NI / 4; ++q) reinterpret_cast<uint4*>(rec)[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    for (int j = 0; j < E; ++j) c[j] = mine ? cnt[threadIdx.x * E + j] : 0u, sum += c[j];
+    uint32_t run = kp_wave_excl_sum(sum);
+    if (lane == 63) wsum[wv] = run + sum;
+    __syncthreads();
+    for (int q = 0; q < wv; ++q) run += wsum[q];
+#pragma unroll
+    for (int j = 0; j < E; ++j)
+      if (mine) cnt[threadIdx.x * E + j] = run, run += c[j];
+  }
+  __syncthreads();
+  int staged = 0;
+  for (int q = 0; q < S::THREADS / 64; ++q) staged += (int)wsum[q];
+#pragma unroll
+  for (int u = 0; u < MB; ++u) {
+    if (at[u] == ~0u) continue;
+    const int i = first + u * S::THREADS + threadIdx.x;
+    const int k = kq[u];
+    const uint32_t p = cnt[k] + at[u], pos = goff[k] + at[u];
+    gpos[p] = pos < (uint32_t)(k + 1) * (uint32_t)a.tc ? pos : ~0u;  // past the key's segment: the tick goes the first form's way
+    uint32_t w[T::NI];
+    kp_pack<N>(w, i, xq[u], Lq[u], tq[u] ? 1 : 0, mq[u], sq[u], rkq[u]);
+    uint2* rec = reinterpret_cast<uint2*>(stage + (size_t)p * T::NI);
+#pragma unroll
+    for (int h = 0; h < T::NI / 2; ++h) rec[h] = make_uint2(w[2 * h], w[2 * h + 1]);
+  }
+  __syncthreads();
+  {
+    constexpr int H = T::NI / 2;  // 8-byte words of a record
+    const uint2* src = reinterpret_cast<const uint2*>(stage);
+    uint2* dst = reinterpret_cast<uint2*>(a.recs);
+    for (int q = threadIdx.x; q < staged * H; q += S::THREADS) {
+      const int p = q / H, h = q - p * H;
+      const uint32_t g = gpos[p];
+      if (g != ~0u) dst[(size_t)g * H + h] = src[q];
     }
   }
   // the fingerprints: wavefront sums, then one 64-bit atomic per workgroup and word
@@ -315,7 +369,7 @@ __global__ void __launch_bounds__(KP_ST) k_kp_scatter(const EpxState st, const E
   __syncthreads();
   if (threadIdx.x < 2 * (N + 1)) {
     unsigned long long v = 0;
-    for (int q = 0; q < KP_ST / 64; ++q) v += fsum[q][threadIdx.x];
+    for (int q = 0; q < S::THREADS / 64; ++q) v += fsum[q][threadIdx.x];
     atomicAdd(&a.fp[threadIdx.x], v);
   }
 }
@@ -516,18 +570,19 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
         for (int cc = 0; cc < T::CPW; ++cc)
           if (ec[cc] != KP_INVALID) {
             const uint32_t s0 = bkr[eq[cc]], s1 = eq[cc] + 1 < (uint32_t)T::NBK ? bkr[eq[cc] + 1] : crr;
-            // the first six words of the bucket in flight at once (a bucket holds about one; what lies behind a short
-            // bucket is somebody else's word or the bucket table: read, not counted), a loop only for fuller buckets --
+            // the first four words of the bucket in flight at once (a bucket holds about one, one in 300 more than four;
+            // what lies behind a short bucket is somebody else's word or the bucket table: read, not counted), a loop
+            // only for fuller buckets (six in flight cost 1 us per tick more than the loop they spared) --
             // the plain loop was compiled into three nested divergent loops with an LDS round trip each
             const uint32_t nb = s1 - s0;
             uint32_t below = 0;
 #pragma unroll
-            for (uint32_t j = 0; j < 6; ++j) {
+            for (uint32_t j = 0; j < 4; ++j) {
               const uint32_t v = dst[s0 + j];
               below += ((j < nb) & (v < ec[cc])) ? 1u : 0u;
             }
 #pragma nounroll
-            for (uint32_t j = s0 + 6; j < s1; ++j) below += dst[j] < ec[cc] ? 1u : 0u;
+            for (uint32_t j = s0 + 4; j < s1; ++j) below += dst[j] < ec[cc] ? 1u : 0u;
             src[s0 + below] = ec[cc];
             // the word's place is known: its put (per column the largest id + 1) is part of the carry of the runs
             // behind the one it lands in
