@@ -1505,6 +1505,11 @@ int launch_kp(fpx_epx* e, const EpxBatch& b, int32_t* d_packed, bool* done) {
   a.tot = (uint32_t*)(misc + 1024);
   a.host_flag = e->kp_flag_dev, a.tc = T::TC;
   a.packed = d_packed, a.stride = fpx_epx_packed_stride(N);
+  {
+    uintptr_t bits = (uintptr_t)b.leader | (uintptr_t)b.key | (uintptr_t)b.number | (uintptr_t)b.rank | (uintptr_t)b.resp_mask |
+                     (uintptr_t)b.is_set | (uintptr_t)b.seen_mask;
+    a.vec = (bits & 15u) == 0 && (b.m & 3) == 0;
+  }
   if (!e->kp_lds_allowed) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_epx_key2<N, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)T::BYTES);

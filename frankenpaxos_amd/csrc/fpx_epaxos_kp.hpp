@@ -137,6 +137,8 @@ struct KpArgs {
   int tc;                           // KpTile<N>::TC
   int32_t* packed;                  // [m][stride] or null
   int stride;
+  int vec;                          // every input array starts at a 16-byte boundary and m % 4 == 0: a thread's four (sixteen) messages
+                                    // are neighbours and arrive as 16-byte loads
 };
 
 // the partition kernels' verdict on the tick: first reporter wins (seq grows from tick to tick)
@@ -182,15 +184,24 @@ __global__ void __launch_bounds__(128 * KP_HG) k_kp_hist(const EpxState st, cons
   const int tile = blockIdx.x * KP_HG + sub;
   uint32_t* h = kp_h + sub * a.B;
   const int first = tile * KP_TILE;
-  int k[KP_TILE / 128];
+  constexpr int KT = KP_TILE / 128;  // a thread's keys: neighbours in the tick
+  const int i0 = first + KT * t;
+  int k[KT];
+  if (a.vec && tile < a.tiles && i0 < a.m) {
+    static_assert(KT % 4 == 0, "16-byte loads");
 #pragma unroll
-  for (int j = 0; j < KP_TILE / 128; ++j) {
-    const int i = first + j * 128 + t;
-    k[j] = (tile < a.tiles && i < a.m) ? b.key[i] : -1;
+    for (int j = 0; j < KT; j += 4) {
+      const bool in = i0 + j < a.m;  // m % 4 == 0: four at a time are inside or outside
+      const int4 v = in ? *reinterpret_cast<const int4*>(b.key + i0 + j) : make_int4(-1, -1, -1, -1);
+      k[j] = v.x, k[j + 1] = v.y, k[j + 2] = v.z, k[j + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < KT; ++j) k[j] = (tile < a.tiles && i0 + j < a.m) ? b.key[i0 + j] : -1;
   }
 #pragma unroll
-  for (int j = 0; j < KP_TILE / 128; ++j) {
-    const int i = first + j * 128 + t;
+  for (int j = 0; j < KT; ++j) {
+    const int i = i0 + j;
     if (tile < a.tiles && i < a.m) {
       if (k[j] < 0 || k[j] >= a.B) kp_reject(a, i);
       else atomicAdd(&h[k[j]], 1u);
@@ -269,23 +280,49 @@ __global__ void __launch_bounds__(KpScat<N>::THREADS) k_kp_scatter(const EpxStat
 #pragma unroll
   for (int q = 0; q < 2 * (N + 1); ++q) f[q] = 0ull;
   const int first = tile * KP_TILE;
-  constexpr int MB = S::SW / S::THREADS;  // messages of one thread: all their loads are in flight together
+  constexpr int MB = S::SW / S::THREADS;  // messages of one thread, neighbours in the tick: all their loads are in flight together
+  static_assert(MB == 4, "a thread's messages are one 16-byte load per array");
+  const int i0 = first + MB * (int)threadIdx.x;
   int Lq[MB], kq[MB], xq[MB], rkq[MB][N];
   unsigned mq[MB], sq[MB], tq[MB];
+  if (a.vec && i0 < a.m) {  // (m % 4 == 0: all four are inside)
+    auto ld4 = [&](const int32_t* p, int* o) {
+      const int4 v = *reinterpret_cast<const int4*>(p + i0);
+      o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
+    };
+    auto ld4b = [&](const uint8_t* p, unsigned* o) {
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(p + i0);
+      o[0] = v & 0xffu, o[1] = (v >> 8) & 0xffu, o[2] = (v >> 16) & 0xffu, o[3] = v >> 24;
+    };
+    ld4(b.leader, Lq), ld4(b.key, kq), ld4(b.number, xq), ld4b(b.resp_mask, mq), ld4b(b.is_set, tq);
+    if (b.seen_mask) ld4b(b.seen_mask, sq);
+    else {
 #pragma unroll
-  for (int u = 0; u < MB; ++u) {
-    const int i = first + u * S::THREADS + threadIdx.x;
-    const bool in = i < a.m;
-    Lq[u] = in ? b.leader[i] : 0, kq[u] = in ? b.key[i] : 0, xq[u] = in ? b.number[i] : 0;
-    mq[u] = in ? b.resp_mask[i] : 0u, tq[u] = in ? b.is_set[i] : 0u;
-    sq[u] = in ? (b.seen_mask ? b.seen_mask[i] : mq[u]) : 0u;
+      for (int u = 0; u < MB; ++u) sq[u] = mq[u];
+    }
 #pragma unroll
-    for (int r = 0; r < N; ++r) rkq[u][r] = in ? b.rank[(size_t)r * a.m + i] : 0;
+    for (int r = 0; r < N; ++r) {
+      int v[MB];
+      ld4(b.rank + (size_t)r * a.m, v);
+#pragma unroll
+      for (int u = 0; u < MB; ++u) rkq[u][r] = v[u];
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < MB; ++u) {
+      const int i = i0 + u;
+      const bool in = i < a.m;
+      Lq[u] = in ? b.leader[i] : 0, kq[u] = in ? b.key[i] : 0, xq[u] = in ? b.number[i] : 0;
+      mq[u] = in ? b.resp_mask[i] : 0u, tq[u] = in ? b.is_set[i] : 0u;
+      sq[u] = in ? (b.seen_mask ? b.seen_mask[i] : mq[u]) : 0u;
+#pragma unroll
+      for (int r = 0; r < N; ++r) rkq[u][r] = in ? b.rank[(size_t)r * a.m + i] : 0;
+    }
   }
   uint32_t at[MB];  // the command's number among the workgroup's commands of its key; ~0: no record
 #pragma unroll
   for (int u = 0; u < MB; ++u) {
-    const int i = first + u * S::THREADS + threadIdx.x;
+    const int i = i0 + u;
     at[u] = ~0u;
     if (i >= a.m) continue;
     const int L = Lq[u], k = kq[u], x = xq[u];
@@ -336,7 +373,7 @@ __global__ void __launch_bounds__(KpScat<N>::THREADS) k_kp_scatter(const EpxStat
 #pragma unroll
   for (int u = 0; u < MB; ++u) {
     if (at[u] == ~0u) continue;
-    const int i = first + u * S::THREADS + threadIdx.x;
+    const int i = i0 + u;
     const int k = kq[u];
     const uint32_t p = cnt[k] + at[u], pos = goff[k] + at[u];
     gpos[p] = pos < (uint32_t)(k + 1) * (uint32_t)a.tc ? pos : ~0u;  // past the key's segment: the tick goes the first form's way

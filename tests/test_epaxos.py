@@ -322,7 +322,7 @@ def test_epaxos_invalid_ticks(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,num_keys,m", [(3, 8, 700), (5, 64, 5000), (7, 16, 3000)])
+@pytest.mark.parametrize("n,num_keys,m", [(3, 8, 700), (5, 64, 5000), (7, 16, 3000), (5, 64, 4999), (3, 8, 2049)])  # (m % 4 != 0: the partition's element-wise loads)
 def test_epaxos_not_thrifty_ticks_match_oracle(oracle, n, num_keys, m):
     """seen_mask: the PreAccept reaches every other replica (ThriftySystem.NotThrifty, the reference's
     default) or a random superset of the n-2 that are waited for"""
