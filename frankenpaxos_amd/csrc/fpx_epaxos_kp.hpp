@@ -158,16 +158,19 @@ __device__ __forceinline__ void kp_fp_add(unsigned long long* f, uint32_t v) {
   f[0] += kp_mix32(v + 0x9E3779B9u), f[1] += kp_mix32(v ^ 0x7F4A7C15u) ^ 0x5BD1E995u;
 }
 
-// wave64 exclusive sum of one value per lane
+// wave64 exclusive sum of one value per lane, on the DPP network (four row_shr steps inside each row of 16, row_bcast:15 /
+// row_bcast:31 carry the row totals on; lanes without a source add the 0 of `old`).  Six __shfl_up steps were six dependent
+// trips through the LDS crossbar: the one wavefront per replica that turns bucket counts into bucket starts waited 0.25 us
+// of the phase's 0.76 for them.
 __device__ __forceinline__ uint32_t kp_wave_excl_sum(uint32_t v) {
-  const int lane = threadIdx.x & 63;
-  uint32_t inc = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t o = __shfl_up(inc, d);
-    if (lane >= d) inc += o;
-  }
-  return inc - v;
+  int inc = (int)v;
+  inc += dpp0<0x111, 0xF>(inc);
+  inc += dpp0<0x112, 0xF>(inc);
+  inc += dpp0<0x114, 0xF>(inc);
+  inc += dpp0<0x118, 0xF>(inc);
+  inc += dpp0<0x142, 0xA>(inc);
+  inc += dpp0<0x143, 0xC>(inc);
+  return (uint32_t)inc - v;
 }
 
 // KP_HG tiles per workgroup (128 threads each).  After the count, thread j owns key j: the key's commands in the
@@ -599,19 +602,29 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
       if (*degenerate == 0) {
         const uint32_t crr = (uint32_t)cntr[r];
         const int perq = max(64, (((int)crr + T::W * 64 - 1) / (T::W * 64)) * 64);  // words of one wavefront's run in the scans
+        // bucket start and end are read in front of the barrier, with the word's first placing (the table does not change
+        // any more); kept as start | members << 16 (both < 2^11).  Lanes without a word read bucket 0 and write nothing.
+        uint32_t sn[T::CPW];
 #pragma unroll
-        for (int cc = 0; cc < T::CPW; ++cc)
-          if (ec[cc] != KP_INVALID) dst[bkr[eq[cc]] + ea[cc]] = ec[cc];
+        for (int cc = 0; cc < T::CPW; ++cc) {
+          const bool valid = ec[cc] != KP_INVALID;
+          const uint32_t q = eq[cc];  // (0 without a word)
+          const uint32_t s0 = bkr[q], s1 = bkr[min(q + 1u, (uint32_t)T::NBK - 1u)];
+          sn[cc] = s0 | (valid ? ((q + 1u < (uint32_t)T::NBK ? s1 : crr) - s0) << 16 : 0u);
+          if (valid) dst[s0 + ea[cc]] = ec[cc];
+        }
         __syncthreads();
 #pragma unroll
         for (int cc = 0; cc < T::CPW; ++cc)
           if (ec[cc] != KP_INVALID) {
-            const uint32_t s0 = bkr[eq[cc]], s1 = eq[cc] + 1 < (uint32_t)T::NBK ? bkr[eq[cc] + 1] : crr;
-            // the first four words of the bucket in flight at once (a bucket holds about one, one in 300 more than four;
-            // what lies behind a short bucket is somebody else's word or the bucket table: read, not counted), a loop
-            // only for fuller buckets (six in flight cost 1 us per tick more than the loop they spared) --
-            // the plain loop was compiled into three nested divergent loops with an LDS round trip each
-            const uint32_t nb = s1 - s0;
+            // a bucket holds about one word, one in 300 more than four: its first four members in flight at once (what
+            // lies behind a short bucket is somebody else's word or the bucket table: read, not counted), a loop only
+            // for fuller buckets (six in flight cost 1 us per tick more than the loop they spared; the plain loop was
+            // compiled into three nested divergent loops with an LDS round trip each; all chunks' members in flight at
+            // once spilled registers and was 1 us slower than chunk by chunk)
+            const uint32_t s0 = sn[cc] & 0xffffu, nb = sn[cc] >> 16;
+            const int sl = (int)(ec[cc] & KP_SLOT_MASK);
+            const int fl = RF(2, sl), id1 = RF(1, sl) + 1;
             uint32_t below = 0;
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
@@ -619,13 +632,15 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
               below += ((j < nb) & (v < ec[cc])) ? 1u : 0u;
             }
 #pragma nounroll
-            for (uint32_t j = s0 + 4; j < s1; ++j) below += dst[j] < ec[cc] ? 1u : 0u;
-            src[s0 + below] = ec[cc];
+            for (uint32_t j = s0 + 4; j < s0 + nb; ++j) below += dst[j] < ec[cc] ? 1u : 0u;
+            const uint32_t at = s0 + below;
+            src[at] = ec[cc];
             // the word's place is known: its put (per column the largest id + 1) is part of the carry of the runs
-            // behind the one it lands in
-            const int sl = (int)(ec[cc] & KP_SLOT_MASK);
-            const int fl = RF(2, sl);
-            atomicMax(&tot[(r * T::W + (int)((s0 + below) / (uint32_t)perq)) * 2 * N + ((fl >> 3) & 1) * N + (fl & 7)], RF(1, sl) + 1);
+            // behind the one it lands in (the run's number by comparisons: the division by perq was ~25 instructions)
+            int run = 0;
+#pragma unroll
+            for (int t = 1; t < T::W; ++t) run += at >= (uint32_t)(t * perq) ? 1 : 0;
+            atomicMax(&tot[(r * T::W + run) * 2 * N + ((fl >> 3) & 1) * N + (fl & 7)], id1);
           }
         __syncthreads();
         sort_passes = 0;  // sorted, in sortA
