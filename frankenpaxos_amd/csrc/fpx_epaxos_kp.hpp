@@ -535,7 +535,8 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
     const bool more = kn < st.num_keys;
     __syncthreads();
     // ---- the replica's words in rank order.  A wavefront owns a run of slots.  Bucket sort: the ranks of one key
-    // spread over the tick's [0, m) (or, failing that, the key's own [rmin, rmax]); NBK buckets of equal width hold about one word each, a word's place is its bucket's
+    // spread over the tick's [0, m) (or, failing that, the key's own [rmin, rmax]); NBK buckets of equal width hold
+    // about one word each, a word's place is its bucket's
     // start + the words of the bucket below it (found by looking at them: buckets are tiny) -- 4 LDS round trips per
     // word where an LSD radix sort of the 21 rank bits takes 3 passes of ~90 instructions per 64 words.  Ranks that
     // clump (a bucket with more than KP_MAX_OCC words) send the key through the radix sort below instead: any order of
