@@ -437,7 +437,9 @@ int32_t fpx_epx_preaccept(fpx_epx* epx, int32_t m, const int32_t* leader, const 
  * stream reaches this call -- and is read from a page-locked word while the next kernels (already enqueued) run.  The
  * call therefore returns when the stream has reached the tick's first two small kernels, not before; a tick with a
  * hotter key is then enqueued again in the general form (radix sort of all (key, message) pairs).  Not capturable
- * into a HIP graph.  FPX_EPX_V1 in the environment at fpx_epx_create selects the general form always. */
+ * into a HIP graph.  FPX_EPX_V1 in the environment at fpx_epx_create selects the general form always.
+ * Any alignment of the input arrays is accepted; arrays that all start at 16-byte boundaries, with m % 4 == 0, are read
+ * with 16-byte loads (~1 % of a 2^20-command tick). */
 int32_t fpx_epx_preaccept_dev(fpx_epx* epx, int32_t m, const int32_t* d_leader, const int32_t* d_number,
                               const int32_t* d_key, const uint8_t* d_is_set, const uint8_t* d_resp_mask,
                               const uint8_t* d_seen_mask, const int32_t* d_rank, const int32_t* d_triple_id,
