@@ -53,7 +53,7 @@ def key_stamps(s):
 
 def build(name, patch):
     d = tempfile.mkdtemp(prefix="k5" + name)
-    shutil.copytree(SRC, os.path.join(d, "csrc"), ignore=shutil.ignore_patterns("*.o", "*.so"))
+    shutil.copytree(SRC, os.path.join(d, "csrc"), ignore=shutil.ignore_patterns("*.o", "*.so", ".*"))
     shutil.copytree(os.path.join(ROOT, "include"), os.path.join(d, "include"))
     for f in os.listdir(os.path.join(d, "csrc")):
         p = os.path.join(d, "csrc", f)
