@@ -19,7 +19,11 @@
 //
 // Scope (DESIGN.md section 8): single-key get / set commands of the key-value store (statemachine/KeyValueStore.scala),
 // top-one dependencies, sequence number 0; the leader-side recovery timers (Replica.scala:1021-1078) stay with a
-// reference Replica if one is wanted -- Prepare / PrepareOk are answered here, not originated.
+// reference Replica if one is wanted -- Prepare / PrepareOk are answered here, not originated.  `leaderStates` (the
+// instances a replica is leading, :1243-1249 "stop leading when a larger ballot arrives") is empty between two bursts
+// here by construction: an instance this actor leads is pre-accepted, accepted if need be and committed inside the
+// flush that proposed it (flushTick checks the f + 1 votes), so a PreAccept in a larger ballot for it finds a
+// CommittedEntry and is answered with the Commit (:1228-1238, K7) -- there is no leader state or timer left to drop.
 package frankenpaxos.gpu
 
 import frankenpaxos.Actor
