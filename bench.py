@@ -290,7 +290,7 @@ def main():
     ap.add_argument("--validate", action="store_true",
                     help="keep the run-contract validation kernel in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", choices=["headline", "2", "3", "4", "5", "thrifty"], default="headline",
+    ap.add_argument("--config", choices=["headline", "2", "3", "4", "5", "thrifty", "thrifty_random", "acceptor_model", "host_path", "adversarial"], default="headline",
                     help="headline = BASELINE.json's metric grid (2^20 slots x 256 acceptors); 2..5 = the other "
                          "BASELINE.json configs as bench lines of the same schema (bench_configs.py)")
     ap.add_argument("--configs-block-steps", type=int, default=20,
@@ -516,11 +516,13 @@ def main():
         ctx.close()
         torch.cuda.empty_cache()
         configs_block = {}
-        for c in ("2", "3", "4", "5", "thrifty"):
+        # BASELINE.json's configs 2-5, the two thrifty deliveries, and what SURVEY.md 8(d) asks for beside the headline: the
+        # reference's actual acceptor model, the host-pointer path end to end, the adversarial stream at full size
+        for c in ("2", "3", "4", "5", "thrifty", "thrifty_random", "acceptor_model", "host_path", "adversarial"):
             t_c = time.perf_counter()
             try:
                 # config 4's ticks are drawn on the host (~0.5 s each): half as many of them
-                sub = types.SimpleNamespace(steps=max(1, args.configs_block_steps // 2) if c == "4" else args.configs_block_steps,
+                sub = types.SimpleNamespace(steps=max(1, args.configs_block_steps // 2) if c in ("4", "thrifty_random", "host_path") else args.configs_block_steps,
                                             warmup=2, ballot=args.ballot, config=c, no_cpu_baseline=True)
                 full = bench_configs.run(sub, fa, None, dev, 0, 1, local_rank, all_reduce)
                 configs_block[c] = {
@@ -528,9 +530,13 @@ def main():
                     "ms_per_step": full["ms_per_step"], "workload": full["config"]["workload"],
                     "roofline_frac": full["roofline"]["frac"], "achieved_GBs": full["roofline"]["achieved"],
                     "avg_kernel_ms": full["roofline"]["avg_kernel_ms"],
-                    "algorithmic_bytes_per_unit": full["roofline"]["algorithmic_bytes_per_unit"],
+                    "algorithmic_bytes_per_unit": full["roofline"].get("algorithmic_bytes_per_unit"),
                     "verified": full["config"].get("verified"), "wall_s": None,
+                    "traffic": full["roofline"].get("traffic"), "traffic_round": full["roofline"].get("traffic_round"),
                 }
+                for extra_key in ("pcie_GBs", "proposals", "chosen", "nacked", "ballot_model"):
+                    if extra_key in full["config"]:
+                        configs_block[c][extra_key] = full["config"][extra_key]
                 if "note" in full["roofline"]:
                     configs_block[c]["note"] = full["roofline"]["note"]
             except BaseException as e:  # noqa: BLE001 -- the headline line must survive a failing extra config
@@ -548,11 +554,12 @@ def main():
         avg_kernel_s = (kernel_ms / max(launches, 1)) * 1e-3
         slots_per_launch = SLOTS_PER_STEP
         achieved = bps * slots_per_launch / avg_kernel_s / 1e9 if launches else None
-        traffic = None
+        traffic, traffic_round = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(args.ballot)
+                te = json.load(open(tfile)).get(args.ballot) or {}
+                traffic, traffic_round = te.get("bytes"), te.get("round")
             except Exception:
                 traffic = None
         kernel = "k_phase2<64,vec4,%s,%s>" % ("per_slot" if ballot_mode == 1 else "acceptor",
@@ -590,7 +597,7 @@ def main():
                 "achieved_total": achieved,
                 "achieved_read": (read_bytes_per_slot(ballot_mode) * slots_per_launch / avg_kernel_s / 1e9) if launches else None,
                 "frac_read": (read_bytes_per_slot(ballot_mode) * slots_per_launch / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if launches else None,
-                "traffic": traffic,
+                "traffic": traffic, "traffic_round": traffic_round,
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command in an earlier profiled run "
                                   "(profiles/traffic.json; collection and calibration: profiles/r04_pmc_summary.md) -- not "
                                   "measured in this run",

@@ -7,6 +7,14 @@ roofline with that workload's algorithmic bytes, cpu_baseline from the oracle). 
   4  EPaxos, 5 replicas                                     K5, one step = one tick of 2^20 fresh commands, 1024 keys
   thrifty  MultiPaxos, R = 255, f = 127                     fused K3, every Phase2a to a rotating window of f + 1 acceptors (the
                                                             reference's default delivery, ProxyLeader.scala:190-191)
+  acceptor_model  the headline grid (2^20 x 256, threshold 128) under FPX_BALLOT_ACCEPTOR: one promised round per acceptor, the
+                  reference's actual acceptor (multipaxos/Acceptor.scala:95), 2064 B per slot, write-bound
+  thrifty_random  as `thrifty`, but every Phase2a goes to a RANDOM f + 1 of the 255 acceptors: what the reference literally
+                  draws (Random.shuffle(group).take(f + 1), ProxyLeader.scala:190-191)
+  host_path       the headline step through HOST pointers (fpx_phase2_fused_submit / _wait, page-locked arrays, 3 calls in
+                  flight): H2D proposals + fused step + D2H chosen records per 2^20 x 256 call
+  adversarial     SURVEY.md 8(d)'s parity / adversarial stream, seed 1, at full size (64 epochs, leader changes, Nacks,
+                  re-proposals, random target subsets), device-resident, proposals/s; every output == the oracle afterwards
   5  Mencius, 256 leader groups x 3 acceptors, 4M slots     one step = a band of 2^22 slots: the leader groups that have
                                                             commands propose them (fused K3), the others skip their
                                                             slots with one noop range each (fused K4); N > 1: leader
@@ -58,7 +66,13 @@ def multipaxos_setup(fa, dev, local_rank, ballot_mode, cfg, K, Wm):
         "3": dict(slots=1 << 20, R=4, groups=16, kw=dict(quorum_kind=fa.FPX_Q_GRID, grid_rows=2, grid_cols=2),
                   name="Compartmentalized MultiPaxos: 16 acceptor groups of 2x2 grids (slot % 16 -> group), fused "
                        "Phase-2 step, 2^20 fresh slots per step"),
+        "acceptor_model": dict(slots=1 << 20, R=256, groups=1, kw=dict(f=127, quorum_kind=fa.FPX_Q_THRESHOLD),
+                               name="MultiPaxos Phase-2 fused step on the headline grid (2^20 fresh slots x 256 acceptors per step, "
+                                    "threshold 128) with ONE promised round per acceptor (FPX_BALLOT_ACCEPTOR): the reference's "
+                                    "actual acceptor state, multipaxos/Acceptor.scala:95"),
     }[cfg]
+    if cfg == "acceptor_model":
+        ballot_mode = fa.FPX_BALLOT_ACCEPTOR
     n, R, G = shapes["slots"], shapes["R"], shapes["groups"]
     windows = K + Wm
     ctx = fa.Context(fa.make_config(num_slots=windows * n, num_replicas=R, num_groups=G, ballot_mode=ballot_mode,
@@ -87,6 +101,8 @@ def multipaxos_setup(fa, dev, local_rank, ballot_mode, cfg, K, Wm):
 
     cells = (3 if ballot_mode == 1 else 2) * 4 * R        # ballot read (per_slot) + voteRound + voteValue written
     bps = cells + 12 + 9 + 20                             # + proposal, chosen record, tally key row (16 read + 4 written)
+    if cfg == "acceptor_model":
+        bps = 8 + 8 * R + 8                               # SURVEY.md 8(d)'s faithful-scalar model: 2064 B per slot
 
     def cpu(fa_cfg_mode=ballot_mode):
         from oracle import pyoracle
@@ -107,7 +123,8 @@ def multipaxos_setup(fa, dev, local_rank, ballot_mode, cfg, K, Wm):
 
     return dict(ctx=ctx, step=step, verify=verify, units=n, unit="slots/s", bytes_per_unit=bps,
                 workload=shapes["name"], kernel="k_phase2 (fused K3)", profile=lambda: ctx.profile_read(),
-                metric="committed log slots/sec (BASELINE.json configs[%d])" % (int(cfg) - 1), cpu=cpu,
+                metric=("committed log slots/sec (BASELINE.json configs[%d])" % (int(cfg) - 1)) if cfg.isdigit() else
+                       "committed log slots/sec at 1M slots x 256 replicas, one promised round per acceptor (FPX_BALLOT_ACCEPTOR)", cpu=cpu,
                 extra={"slots_per_step": n, "replicas": R, "acceptor_groups": G,
                        "ballot_model": "per_slot" if ballot_mode == 1 else "acceptor"})
 
@@ -118,20 +135,41 @@ def multipaxos_setup(fa, dev, local_rank, ballot_mode, cfg, K, Wm):
 # window of neighbouring acceptors that rotates from slot to slot in steps of 16 (what jni/Native.scala's
 # GpuProxyLeader sends; any f + 1 will do) -- k_phase2's packed walk, two rows per wavefront step.
 # ------------------------------------------------------------------------------------------------------------------
-def thrifty_setup(fa, dev, local_rank, ballot_mode, K, Wm):
+def thrifty_setup(fa, dev, local_rank, ballot_mode, K, Wm, random_targets=False):
     n, R, F = 1 << 20, 255, 127
     windows = K + Wm
     ctx = fa.Context(fa.make_config(num_slots=windows * n, num_replicas=R, f=F, ballot_mode=ballot_mode, tally_ways=4,
-                                    device=local_rank, flags=fa.FPX_F_TRUSTED))
+                                    device=local_rank,
+                                    flags=fa.FPX_F_TRUSTED | (fa.FPX_F_SCATTERED_TARGETS if random_targets else 0)))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     assert ctx.acceptor_phase1a(0, 0)[0] == 0
     ctx.flush_promises()
     s = torch.arange(n, device=dev)[:, None]
     j = torch.arange(256, device=dev)[None, :]
     start = 16 * (s % ((R - (F + 1)) // 16 + 1))
-    bits = ((j >= start) & (j < start + F + 1)).view(-1, 4, 64).to(torch.int64)
     sh = torch.arange(64, device=dev, dtype=torch.int64)
-    tgt = ((bits[..., :63] << sh[:63]).sum(-1) | (bits[..., 63] << 63)).contiguous()
+
+    def pack(b):  # bool [k, 256] -> int64 [k, 4]
+        w = b.view(-1, 4, 64).to(torch.int64)
+        return ((w[..., :63] << sh[:63]).sum(-1) | (w[..., 63] << 63)).contiguous()
+
+    if random_targets:
+        # Random.shuffle(group).take(f + 1): a uniformly random f + 1 of the R acceptors per slot (seeded: the reference's
+        # own draw is the unseeded global RNG); acceptor 254's column is read back by verify()
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0xF9A405)
+        parts = []
+        for c0 in range(0, n, 1 << 16):
+            r = torch.rand((min(1 << 16, n - c0), R), device=dev, generator=gen)
+            kth = r.kthvalue(F + 1, dim=1, keepdim=True).values
+            b = torch.zeros((r.shape[0], 256), dtype=torch.bool, device=dev)
+            b[:, :R] = r <= kth
+            parts.append(pack(b))
+        tgt = torch.cat(parts).contiguous()
+        in_last = ((tgt[:, 3] >> 62) & 1).to(torch.bool).cpu().numpy()   # is acceptor 254 a target of slot s (every window)
+        del parts, r, b
+    else:
+        tgt = pack((j >= start) & (j < start + F + 1))
     steps = []
     for w in range(windows):
         slot = torch.arange(w * n, (w + 1) * n, dtype=torch.int32, device=dev)
@@ -148,6 +186,10 @@ def thrifty_setup(fa, dev, local_rank, ballot_mode, K, Wm):
             slot, rnd, val, ch, cr, cv = steps[i]
             assert bool(ch.all()) and bool((cv == val).all()) and bool((cr == 0).all()), "step %d" % i
             done += int(ch.sum().item())
+        if random_targets:   # acceptor 254 voted (round 0) exactly in the slots whose mask names it
+            col = np.asarray(ctx.read_acceptor(0, 254)[2])[lo * n:hi * n].reshape(-1, n)
+            assert bool(((col == 0) == in_last[None, :]).all()) and bool(((col == -1) == ~in_last[None, :]).all())
+            return done
         # the votes are where the targets were, nowhere else (one acceptor inside and one outside every window)
         vr, vv = ctx.read_acceptor(0, 127)[2], ctx.read_acceptor(0, 0)[2]
         assert bool((np.asarray(vr)[lo * n:hi * n] == 0).all())              # acceptor 127 is in every window
@@ -167,7 +209,7 @@ def thrifty_setup(fa, dev, local_rank, ballot_mode, K, Wm):
         ref = pyoracle.System(pyoracle.make_config(num_slots=S, num_replicas=R, f=F, ballot_mode=ballot_mode))
         ref.acceptor_phase1a(0, 0)
         slot, rnd, val = W.steady_stream(S)
-        t = W.bits_from_bool(W.run_subsets(np.random.default_rng(1), S, R, F + 1, F + 1))
+        t = W.bits_from_bool((W.fast_subsets if random_targets else W.run_subsets)(np.random.default_rng(1), S, R, F + 1, F + 1))
         t0 = time.perf_counter()
         out = ref.phase2_fused(slot, rnd, val, t)
         dt = time.perf_counter() - t0
@@ -175,6 +217,19 @@ def thrifty_setup(fa, dev, local_rank, ballot_mode, K, Wm):
         return {"value": S / dt, "unit": "slots/s", "cores": 1, "kind": "port",
                 "sample": "oracle/fpx_oracle.c fpo_phase2_fused with f + 1 target windows, %d slots, 1 thread" % S}
 
+    if random_targets:
+        return dict(ctx=ctx, step=step, verify=verify, units=n, unit="slots/s", bytes_per_unit=bps,
+                    workload="MultiPaxos thrifty delivery as the reference literally draws it: fused Phase-2 step, 2^20 fresh slots "
+                             "per step, each Phase2a to a uniformly RANDOM f + 1 = 128 of the 255 acceptors "
+                             "(Random.shuffle(group).take(f + 1), ProxyLeader.scala:190-191)",
+                    kernel="k_phase2<64, 2, *, fused> (FPX_F_SCATTERED_TARGETS: fresh rows are written as whole cells blended with "
+                           "-1; a random half of a row touches every 64-byte sector, so the traffic is the dense step's)",
+                    profile=lambda: ctx.profile_read(),
+                    metric="committed log slots/sec, thrifty delivery to a random f + 1 (ProxyLeader.scala:190-191)", cpu=cpu,
+                    extra={"slots_per_step": n, "replicas": R, "f": F, "targets_per_slot": F + 1,
+                           "ballot_model": "per_slot" if ballot_mode == 1 else "acceptor",
+                           "byte_model": "the 1077 (+512) B of `thrifty`: what the VOTERS' cells need; the kernel moves whole rows "
+                                         "(~2 x), see roofline.traffic"})
     return dict(ctx=ctx, step=step, verify=verify, units=n, unit="slots/s", bytes_per_unit=bps,
                 workload="MultiPaxos thrifty delivery (the reference's default): fused Phase-2 step, 2^20 fresh slots per step, "
                          "each Phase2a to f + 1 = 128 neighbouring acceptors of 255 (a window rotating in steps of 16)",
@@ -298,8 +353,10 @@ def mencius_setup(fa, dev, local_rank, rank, world, K, Wm):
                       torch.zeros(start.numel(), dtype=torch.uint8, device=dev)))
     def step(i):
         slot, rnd, val, ch, cv, start, end, rr, rch = steps[i]
-        ctx.phase2_fused_dev(slot, rnd, val, None, ch, None, cv)
-        ctx.noop_ranges_fused_dev(start, end, rr, None, None, None, None, None, rch)
+        # ONE call per step: the leader groups with commands and those with ranges alternate, never both in a step --
+        # fpx_mencius_band_fused_dev runs the halves side by side (FPX_CFG5_SERIAL=1: one after the other, as rounds 2 - 4 did)
+        ctx.mencius_band_fused_dev(slot, rnd, val, None, ch, None, cv, None, start, end, rr, None, None, None, None, None, rch,
+                                   independent=os.environ.get("FPX_CFG5_SERIAL") != "1")
 
     def verify(lo, hi):
         done = 0
@@ -340,31 +397,223 @@ def mencius_setup(fa, dev, local_rank, rank, world, K, Wm):
                          "others skip theirs with one noop range each (fused K4)"
                          % (L, band, "one batch in slot order across the leader groups" if os.environ.get("FPX_CFG5_ORDER") == "slot"
                             else "the proposing leader groups' batches back to back, each in slot order"),
-                kernel="k_phase2 (fused K3) + K4 (k_ranges_fill_lg, k_ranges_chain)", region_timed=True,
+                kernel="k_phase2 (fused K3) beside K4 (k_ranges_chain, k_ranges_fill_lg) on the context's second stream "
+                       "(fpx_mencius_band_fused_dev)", region_timed=True,
                 metric="committed log slots/sec (BASELINE.json configs[4])", cpu=cpu,
                 extra={"slots_per_step_per_gpu": band, "leader_groups_per_gpu": L, "replicas": R,
                        "ranges_per_step_per_gpu": L // 2},
                 scaling="strong")
 
 
-def traffic_of(config):
-    """HBM bytes per step from the PMC passes committed under profiles/ (None if that config was not profiled)"""
+# ------------------------------------------------------------------------------------------------------------------
+# host_path: SURVEY.md 8(d) (ii) -- the headline step end to end through the C ABI's HOST-pointer entry point
+# ------------------------------------------------------------------------------------------------------------------
+def host_path_line(args, fa, dev, local_rank):
+    """fpx_phase2_fused_submit / _wait on page-locked arrays (fpx_host_alloc), up to 3 calls in flight: per call 12 B per
+    slot of proposals go up, the fused 2^20 x 256 step runs, 9 B per slot of Chosen records come down.  PCIe-inclusive,
+    never bench.py's `value`."""
+    import ctypes as C
+    from tests import workloads as W
+    K, Wm = args.steps, args.warmup
+    B, R, F = 1 << 20, 256, 127
+    ballot_mode = fa.FPX_BALLOT_PER_SLOT if args.ballot == "per_slot" else fa.FPX_BALLOT_ACCEPTOR
+    ctx = fa.Context(fa.make_config(num_slots=B * (K + Wm), num_replicas=R, f=F, ballot_mode=ballot_mode, tally_ways=4,
+                                    device=local_rank))
+    assert ctx.acceptor_phase1a(0, 0)[0] == 0
+    ctx.flush_promises()
+    L = fa.lib()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    keep, batches = [], []
+    for k in range(K + Wm):
+        objs = [fa.PinnedArray((B,), dt) for dt in (np.int32, np.int32, np.int32, np.uint8, np.int32, np.int32)]
+        keep.append(objs)
+        sl, rd, vl, och, ocr, ocv = [x.array for x in objs]
+        sl[:] = np.arange(k * B, (k + 1) * B, dtype=np.int32)
+        rd[:] = 0
+        vl[:] = W.steady_values(sl)
+        ocr[:] = -7
+        ocv[:] = -7
+        batches.append((sl, rd, vl, och, ocr, ocv))
+    tick = C.c_int32()
+
+    def pump(lo, hi):
+        inflight = []
+        for sl, rd, vl, och, ocr, ocv in batches[lo:hi]:
+            if len(inflight) == 3:
+                assert L.fpx_phase2_fused_wait(ctx._h, inflight.pop(0)) == 0
+            assert L.fpx_phase2_fused_submit(ctx._h, B, p(sl), p(rd), p(vl), None, p(och), p(ocr), p(ocv), None, C.byref(tick)) == 0
+            inflight.append(tick.value)
+        while inflight:
+            assert L.fpx_phase2_fused_wait(ctx._h, inflight.pop(0)) == 0
+
+    pump(0, Wm)
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    pump(Wm, Wm + K)
+    elapsed = time.perf_counter() - t0
+    launches, kernel_ms = ctx.profile_read()
+    assert ctx.sync() == 0
+    done = 0
+    for sl, rd, vl, och, ocr, ocv in batches[Wm:]:
+        assert int(och.sum()) == B and bool((ocv == vl).all()) and bool((ocr == 0).all())
+        done += B
+    ctx.close()
+    bps = 3088 if ballot_mode == 1 else 2064
+    per = elapsed / K
+    return {
+        "metric": "committed log slots/sec END TO END through host pointers (SURVEY.md 8d (ii); PCIe-inclusive, never `value`)",
+        "value": done / elapsed, "unit": "slots/s", "n_gpus": 1, "steps": K, "warmup": Wm, "ms_per_step": per * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "the headline step through fpx_phase2_fused_submit / _wait: 2^20 fresh slots x 256 acceptors per call, "
+                               "proposals (12 B per slot) and Chosen records (9 B per slot) in page-locked HOST arrays, 3 calls in flight",
+                   "baseline_config": "host_path", "ballot_model": args.ballot, "slots_per_step": B, "replicas": R,
+                   "verified": "every timed call checked after the timed region: every slot chosen in round 0 with its proposed value",
+                   "pcie_bytes_per_slot": 21, "pcie_GBs": 21 * B / per / 1e9},
+        "roofline": {"bound": "hbm", "kernel": "k_phase2<64, 0, *, fused> between staging kernels on their own streams",
+                     "achieved": bps * B / per / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bps * B / per / 1e9 / HBM_PEAK_GBS,
+                     "traffic": traffic_of("host_path", args.ballot), "traffic_round": traffic_entry(traffic_key("host_path", args.ballot))[1],
+                     "algorithmic_bytes_per_unit": bps, "units_per_launch": B,
+                     "avg_kernel_ms": kernel_ms / max(launches, 1), "launches_timed": launches,
+                     "kernel_time_source": "`achieved` = algorithmic HBM bytes / WALL time per call (the PCIe transfers included); "
+                                           "avg_kernel_ms = the vote kernel alone (fpx_profile_*)",
+                     "note": "bound by PCIe (21 B per slot each call), not by HBM: the fraction says how far the host boundary "
+                             "keeps the kernel from its device-resident rate"},
+    }
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# adversarial: SURVEY.md 8(d)'s parity stream at full size, timed; every output against the oracle afterwards
+# ------------------------------------------------------------------------------------------------------------------
+def adversarial_line(args, fa, dev, local_rank, seed=1):
+    from oracle import pyoracle
+    from tests import workloads as W
+    S, R, Q = 1 << 20, 256, 128
+    ballot_mode = fa.FPX_BALLOT_PER_SLOT if args.ballot == "per_slot" else fa.FPX_BALLOT_ACCEPTOR
+    script = W.adversarial_script(S, R, Q, seed, epochs=64, fused=True, subsets=W.fast_subsets)
+    kw = dict(num_slots=S, num_replicas=R, f=Q - 1, ballot_mode=ballot_mode, tally_ways=8)
+    # the stream satisfies the run contract by construction (an epoch carries one round): no validation kernels
+    ctx = fa.Context(fa.make_config(device=local_rank, flags=fa.FPX_F_SCATTERED_TARGETS | fa.FPX_F_TRUSTED, **kw))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d = lambda a, view=None: torch.from_numpy(np.ascontiguousarray(a) if view is None else np.ascontiguousarray(a).view(view)).to(dev)
+    ops, proposals = [], 0
+    for op in script:
+        if op[0] == "phase1a":
+            _, g, rnd, wm, tgt = op
+            ops.append(("phase1a", g, rnd, wm, None if tgt is None else d(tgt, np.int64)))
+        else:
+            _, slot, rr, val, tgt = op
+            n = len(slot)
+            proposals += n
+            ops.append(("fused", d(slot), d(rr), d(val), d(tgt, np.int64), torch.zeros(n, dtype=torch.uint8, device=dev),
+                        torch.full((n,), -7, dtype=torch.int32, device=dev), torch.full((n,), -7, dtype=torch.int32, device=dev),
+                        torch.full((n,), -7, dtype=torch.int32, device=dev)))
+
+    def run():
+        for op in ops:
+            if op[0] == "phase1a":
+                ctx.acceptor_phase1a_dev(op[1], op[2], op[3], op[4])
+            else:
+                ctx.phase2_fused_dev(*op[1:])
+
+    reps = max(1, args.steps // 4)          # a "step" here is the WHOLE stream (64 epochs); a few repetitions, the last one verified
+    run()                                   # warm-up: scratch buffers reach their size
+    assert ctx.sync() == 0
+    times = []
+    for _ in range(reps):
+        ctx.reset()
+        assert ctx.sync() == 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        assert ctx.sync() == 0
+    dt = sorted(times)[len(times) // 2]
+    # AFTER the timed region: the oracle replays the script message by message; every output of every epoch must agree
+    pyoracle.build()
+    ref = pyoracle.System(pyoracle.make_config(**kw))
+    t_or = time.perf_counter()
+    want = W.run_script(ref, script)
+    t_or = time.perf_counter() - t_or
+    chosen = nacked = 0
+    fused_ops = [op for op in ops if op[0] == "fused"]
+    k = 0
+    for w_out in want:
+        if w_out[0] != "fused":
+            continue
+        _, st, ch, cr, cv, nr = w_out
+        op = fused_ops[k]
+        k += 1
+        assert st == 0
+        g_ch, g_cr, g_cv, g_nr = (op[j].cpu().numpy() for j in (5, 6, 7, 8))
+        np.testing.assert_array_equal(g_ch, ch)
+        m = ch.astype(bool)
+        np.testing.assert_array_equal(g_cr[m], cr[m])
+        np.testing.assert_array_equal(g_cv[m], cv[m])
+        np.testing.assert_array_equal(g_nr, nr)
+        chosen += int(ch.sum())
+        nacked += int((nr >= 0).sum())
+    np.testing.assert_array_equal(ctx.state_digest(), ref.state_digest())
+    ctx.close()
+    # per proposal: the dense model's 3088 (2064) B + the 32-byte target mask; random target subsets make most rows a
+    # read-modify-write of partially voted cells, which the model does not count
+    bps = (3088 if ballot_mode == 1 else 2064) + 32
+    return {
+        "metric": "proposals/sec on SURVEY.md 8(d)'s adversarial stream (seed %d) at 1M slots x 256 replicas" % seed,
+        "value": proposals / dt, "unit": "proposals/s", "n_gpus": 1, "steps": reps, "warmup": 1, "ms_per_step": dt * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "the parity / adversarial stream of SURVEY.md 8(d), seed %d, 2^20 slots x 256 acceptors: 64 epochs "
+                               "(one fused launch each), leader changes with 25 %% of the acceptors pre-promised (stale Phase2a's "
+                               "Nacked), 5 %% re-proposals, target masks = random subsets of U[q - 8, R] acceptors; device-resident, "
+                               "one step = the whole stream" % seed,
+                   "baseline_config": "adversarial", "ballot_model": args.ballot, "proposals": proposals,
+                   "fused_launches": len(fused_ops), "phase1a_calls": len(ops) - len(fused_ops), "chosen": chosen, "nacked": nacked,
+                   "verified": "AFTER the timed region: chosen flag / round / value and Nack round of every proposal of every epoch "
+                               "and the whole-state digest == the CPU oracle replaying the script message by message (%.1f s)" % t_or},
+        "roofline": {"bound": "hbm", "kernel": "k_phase2<64, 2, *, fused> x 64 + k_finalize + the Phase1a kernels",
+                     "achieved": bps * proposals / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": bps * proposals / dt / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of("adversarial", args.ballot),
+                     "traffic_round": traffic_entry(traffic_key("adversarial", args.ballot))[1],
+                     "algorithmic_bytes_per_unit": bps, "units_per_launch": proposals / max(1, len(fused_ops)),
+                     "avg_kernel_ms": dt * 1e3, "launches_timed": reps,
+                     "kernel_time_source": "wall clock around the whole stream (perf_counter between synchronisations), median of the repetitions",
+                     "note": "about 21 500 proposals per launch: each launch is a read-modify-write of partially voted rows at the HBM "
+                             "rate plus ~10 us of small dependent kernels (profiles/r03_adversarial.txt)"},
+    }
+
+
+def traffic_entry(key):
+    """(HBM bytes per step, the round they were measured in, where) from the PMC passes committed under profiles/ --
+    profiles/traffic.json, every key tagged with its round -- or (None, None, None) if that workload was never profiled"""
     import json
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("config%s" % config)
+        e = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
+        return (e["bytes"], e["round"], e.get("source")) if e else (None, None, None)
     except Exception:
-        return None
+        return (None, None, None)
+
+
+def traffic_key(config, ballot="per_slot"):
+    return ("config%s" % config) if str(config).isdigit() else ("%s_%s" % (config, ballot))
+
+
+def traffic_of(config, ballot="per_slot"):
+    return traffic_entry(traffic_key(config, ballot))[0]
 
 
 def run(args, fa, dist, dev, rank, world, local_rank, all_reduce):
     K, Wm = args.steps, args.warmup
     ballot_mode = fa.FPX_BALLOT_PER_SLOT if args.ballot == "per_slot" else fa.FPX_BALLOT_ACCEPTOR
-    if args.config in ("2", "3"):
+    if args.config == "host_path":
+        return host_path_line(args, fa, dev, local_rank) if rank == 0 else None
+    if args.config == "adversarial":
+        return adversarial_line(args, fa, dev, local_rank) if rank == 0 else None
+    if args.config in ("2", "3", "acceptor_model"):
         w = multipaxos_setup(fa, dev, local_rank, ballot_mode, args.config, K, Wm)
     elif args.config == "4":
         w = epaxos_setup(fa, dev, local_rank, K, Wm)
-    elif args.config == "thrifty":
-        w = thrifty_setup(fa, dev, local_rank, ballot_mode, K, Wm)
+    elif args.config in ("thrifty", "thrifty_random"):
+        w = thrifty_setup(fa, dev, local_rank, ballot_mode, K, Wm, random_targets=args.config == "thrifty_random")
     else:
         w = mencius_setup(fa, dev, local_rank, rank, world, K, Wm)
     ctx = w["ctx"]
@@ -419,9 +668,10 @@ def run(args, fa, dist, dev, rank, world, local_rank, all_reduce):
                        **w["extra"]),
         "roofline": {
             "bound": "hbm", "kernel": w["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic_of(args.config),
+            "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic_of(args.config, args.ballot),
+            "traffic_round": traffic_entry(traffic_key(args.config, args.ballot))[1],
             "traffic_source": "profiles/traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command, "
-                              "all kernels of one step summed), not measured in this run",
+                              "all kernels of one step summed; every key carries the round it was measured in), not measured in this run",
             "algorithmic_bytes_per_unit": w["bytes_per_unit"], "units_per_launch": w["units"],
             "avg_kernel_ms": kernel_ms / max(launches, 1), "launches_timed": launches,
             "kernel_time_source": ("one pair of HIP events around the timed steps on the launch stream / steps: all kernels of "

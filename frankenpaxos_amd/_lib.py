@@ -79,6 +79,8 @@ SIGNATURES = {
     "fpx_error_detail": (C.c_int32, [VP, I32P, I32P, I32P]),
     "fpx_last_hip_error": (C.c_int32, [VP]),
     "fpx_device_bytes": (C.c_int64, [VP]),
+    "fpx_placement_stats": (C.c_int32, [VP, C.POINTER(C.c_float)]),
+    "fpx_profile_read_launches": (C.c_int32, [VP, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "fpx_get_config": (C.c_int32, [VP, CFGP]),
     "fpx_host_alloc": (C.c_int32, [C.c_int64, C.POINTER(C.c_void_p)]),
     "fpx_host_free": (C.c_int32, [VP]),
@@ -110,6 +112,7 @@ SIGNATURES = {
     "fpx_proxy_phase2b_noop_ranges": (C.c_int32, [VP, C.c_int32, VP, VP, VP, VP, VP]),
     "fpx_noop_ranges_fused": (C.c_int32, [VP, C.c_int32] + [VP] * 9),
     "fpx_noop_ranges_fused_dev": (C.c_int32, [VP, C.c_int32] + [VP] * 9),
+    "fpx_mencius_band_fused_dev": (C.c_int32, [VP, C.c_int32] + [VP] * 8 + [C.c_int32] + [VP] * 9 + [C.c_int32]),
     "fpx_read_range_tally": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, I32P, VP]),
     "fpx_recycle_slots": (C.c_int32, [VP, C.c_int32, C.c_int32]),
     "fpx_proxy_forget": (C.c_int32, [VP, C.c_int32, C.c_int32]),

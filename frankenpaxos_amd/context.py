@@ -103,9 +103,26 @@ class Context:
             raise FpxError(st, "fpx_profile_read")
         return n.value, ms.value
 
+    def profile_read_launches(self, cap=4096):
+        """durations in ms of the timed launches since the last read, in launch order"""
+        out = (C.c_float * cap)()
+        n = C.c_int32()
+        st = self.L.fpx_profile_read_launches(self._h, cap, out, C.byref(n))
+        if st:
+            raise FpxError(st, "fpx_profile_read_launches")
+        return [float(out[i]) for i in range(min(cap, n.value))]
+
     @property
     def device_bytes(self):
         return self.L.fpx_device_bytes(self._h)
+
+    def placement_stats(self):
+        """how fpx_create placed the cell arrays: {"chunks": bool, "windows": n, "probe_ms": (min, median, max)}"""
+        out = (C.c_float * 5)()
+        st = self.L.fpx_placement_stats(self._h, out)
+        if st:
+            raise FpxError(st, "fpx_placement_stats")
+        return {"chunks": bool(out[0]), "windows": int(out[1]), "probe_ms": (float(out[2]), float(out[3]), float(out[4]))}
 
     # ---- host-pointer entry points (numpy) ---------------------------------------------------
     def acceptor_phase2a(self, slot, round_, value, target_mask=None):
@@ -343,6 +360,20 @@ class Context:
                                               _dp(nack_round), _dp(is_new), _dp(chosen))
         if st:
             raise FpxError(st, "fpx_noop_ranges_fused_dev")
+
+    def mencius_band_fused_dev(self, slot, round_, value, target_mask, chosen, chosen_round, chosen_value, nack_round,
+                               slot_start, slot_end, range_round, range_target_masks=None, range_vote_bits=None,
+                               range_nack_bits=None, range_nack_round=None, range_is_new=None, range_chosen=None,
+                               independent=False):
+        """one Mencius proxy-leader step: phase2_fused_dev on the commands + noop_ranges_fused_dev on the ranges; with
+        independent (no leader group has both) and FPX_F_TRUSTED the halves run side by side"""
+        st = self.L.fpx_mencius_band_fused_dev(
+            self._h, slot.numel(), _dp(slot), _dp(round_), _dp(value), _dp(target_mask), _dp(chosen), _dp(chosen_round),
+            _dp(chosen_value), _dp(nack_round), slot_start.numel(), _dp(slot_start), _dp(slot_end), _dp(range_round),
+            _dp(range_target_masks), _dp(range_vote_bits), _dp(range_nack_bits), _dp(range_nack_round), _dp(range_is_new),
+            _dp(range_chosen), 1 if independent else 0)
+        if st:
+            raise FpxError(st, "fpx_mencius_band_fused_dev")
 
     def read_range_tally(self, slot_start, slot_end, round_):
         state = C.c_int32()

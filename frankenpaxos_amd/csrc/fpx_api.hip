@@ -84,6 +84,10 @@ struct fpx_ctx {
   std::vector<int32_t> hround;
   // kernel timing (fpx_profile_*)
   void* slab = nullptr;  // vote_round | vote_value | ballot
+  // chunk placement (place_chunks): the slab is a reserved address range backed by 1 GiB physical allocations
+  std::vector<hipMemGenericAllocationHandle_t> vmm_chunks;  // the chunks mapped into the slab, in address order
+  size_t vmm_reserved = 0;                                  // bytes of the reservation at `slab` (0: the slab is one hipMalloc)
+  float placement[5] = {0, 0, 0, 0, 0};                     // mode (0 one allocation, 1 chunks), windows, min / median / max probe ms
   uint32_t phase2_launches = 0;
   uint32_t launch_seq = 0;  // stamps the partial-maxima rows of a K1 / K3 launch (never 0 in a row that counts)
   bool batch_increasing = false, batch_one_round = false;  // check_inputs' findings about the current host batch
@@ -108,6 +112,10 @@ struct fpx_ctx {
   RangeTable rt[2];
   int rt_cur = 0;
   DevBuf d_rng;  // staging of range batches
+  // fpx_mencius_band_fused_dev: the ranges' half of an independent step runs here, between a fork and a join event
+  hipStream_t band_stream = nullptr;
+  hipEvent_t band_fork = nullptr, band_join = nullptr;
+  DevBuf d_band;  // [num_leader_groups] marks: the leader groups with a range in the step being checked
   // multi-GPU (fpx_comm_*): one communicator per context, rank = this context's GPU
   RcclComm comm = nullptr;
   int comm_rank = 0, comm_world = 1;
@@ -507,8 +515,226 @@ int init_state(fpx_ctx* ctx) {
   return FPX_OK;
 }
 
+
+// ---- chunk placement of the cell slab (round 5; profiles/r05_placement.md) --------------------------------------------
+// The hot kernel streams row s of two or three arrays in lockstep: it reads the ballot row and WRITES the two vote rows.
+// How fast that goes depends on which physical memory the rows written together sit in: two 1 GiB regions are either
+// compatible (written side by side at 6.7 TB/s) or not (5.6 TB/s, the rate of one write stream alone) -- a property of the
+// pair's physical addresses, about half of all pairs each way, identical for every repetition; the read stream's region
+// matters a few percent more.  One hipMalloc of the whole slab pairs window w of vote_round with window w of vote_value at
+// whatever distance the allocation's shape dictates: stretches of windows at the slow rate, stretches at the fast one (the
+// "placement lottery" of rounds 1 - 4: 0.535 - 0.607 ms for the same launch).  So the slab is a reserved address range
+// backed by 1 GiB physical allocations (hipMemCreate), and WHICH allocation backs which gigabyte of which array is chosen
+// by measurement: for every gigabyte of vote_round a partner for vote_value that probes fast (k_probe: the hot access
+// pattern on half of the chunk), then the best of a few candidates for the ballots.  The kernels see one contiguous slab.
+constexpr size_t PLACE_CHUNK = (size_t)1 << 30;
+
+struct Placer {
+  fpx_ctx* ctx;
+  char* base = nullptr;
+  size_t reserved = 0;
+  std::vector<hipMemGenericAllocationHandle_t> h;  // pool; chunk i is mapped at base + i * PLACE_CHUNK while probing
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int q4 = 64, rows = 1 << 19;
+  int probes = 0;
+  char* at(int i) const { return base + (size_t)i * PLACE_CHUNK; }
+  // the hot access pattern on `rows` rows: write chunks b and c (c < 0: one stream), read chunk a (a < 0: none); min of 2
+  float probe(int b, int c, int a) {
+    float best = 1e30f;
+    for (int rep = 0; rep < 2; ++rep) {
+      (void)hipEventRecord(e0, ctx->stream);
+      hipLaunchKernelGGL(k_probe, dim3((rows + 127) / 128), dim3(256), 0, ctx->stream, a < 0 ? nullptr : (int32_t*)at(a), (int32_t*)at(b),
+                         c < 0 ? nullptr : (int32_t*)at(c), rows, q4, 1, (long long)rows);
+      (void)hipEventRecord(e1, ctx->stream);
+      if (hipEventSynchronize(e1) != hipSuccess) return -1.f;
+      float m = 0;
+      if (hipEventElapsedTime(&m, e0, e1) != hipSuccess) return -1.f;
+      best = std::min(best, m);
+    }
+    ++probes;
+    return best;
+  }
+  void release_all() {
+    if (base) {
+      for (size_t i = 0; i < h.size(); ++i) (void)hipMemUnmap((hipDeviceptr_t)at((int)i), PLACE_CHUNK);
+    }
+    for (auto x : h) (void)hipMemRelease(x);
+    h.clear();
+    if (base) (void)hipMemAddressFree((hipDeviceptr_t)base, reserved);
+    base = nullptr;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    e0 = e1 = nullptr;
+    (void)hipGetLastError();
+  }
+};
+
+// Builds the slab of `narr` arrays of `array_bytes` each out of chosen chunks.  On success: *slab_out / *stride_out (the
+// arrays' distance, a multiple of the chunk), the context owns the reservation and the chunks.  Any failure leaves nothing
+// behind and the caller falls back to one hipMalloc.
+bool place_chunks(fpx_ctx* ctx, int narr, size_t array_bytes, int q4, char** slab_out, size_t* stride_out) {
+  const int per = (int)((array_bytes + PLACE_CHUNK - 1) / PLACE_CHUNK), need = per * narr;
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = ctx->cfg.device;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0 || PLACE_CHUNK % gran) {
+    (void)hipGetLastError();
+    return false;
+  }
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+  // spare chunks give the search somewhere to go when the pool's mix is lopsided; they are released afterwards
+  int spare = std::min(need / 2 + 4, 24);
+  if (const char* e = getenv("FPX_PLACEMENT_SPARE")) spare = std::max(0, std::min(64, atoi(e)));
+  while (spare > 0 && free_b < (size_t)(need + spare) * PLACE_CHUNK + ((size_t)8 << 30)) --spare;
+  if (free_b < (size_t)need * PLACE_CHUNK + ((size_t)4 << 30)) return false;
+  const int pool = need + spare;
+  Placer P;
+  P.ctx = ctx, P.q4 = q4;
+  P.rows = (int)std::min<size_t>(PLACE_CHUNK / 2 / ((size_t)q4 * 16), (size_t)1 << 19);
+  P.reserved = (size_t)pool * PLACE_CHUNK;
+  hipDeviceptr_t va = nullptr;
+  if (hipMemAddressReserve(&va, P.reserved, PLACE_CHUNK, nullptr, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  P.base = (char*)va;
+  if (hipEventCreate(&P.e0) != hipSuccess || hipEventCreate(&P.e1) != hipSuccess) {
+    P.release_all();
+    return false;
+  }
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  for (int i = 0; i < pool; ++i) {
+    hipMemGenericAllocationHandle_t hd;
+    if (hipMemCreate(&hd, PLACE_CHUNK, &prop, 0) != hipSuccess) {
+      P.release_all();
+      return false;
+    }
+    P.h.push_back(hd);
+    if (hipMemMap((hipDeviceptr_t)P.at(i), PLACE_CHUNK, 0, hd, 0) != hipSuccess) {
+      P.h.pop_back();
+      (void)hipMemRelease(hd);
+      P.release_all();
+      return false;
+    }
+  }
+  if (hipMemSetAccess((hipDeviceptr_t)P.base, P.reserved, &acc, 1) != hipSuccess) {
+    P.release_all();
+    return false;
+  }
+  const bool dbg = getenv("FPX_DEBUG") != nullptr;
+  (void)P.probe(0, narr > 1 ? 1 : -1, -1);  // clocks up, code object loaded
+  std::vector<int> freec;                   // chunks not assigned yet, in allocation order
+  for (int i = 0; i < pool; ++i) freec.push_back(i);
+  std::vector<int> pb(per), pc(per, -1), pa(per, -1);
+  float pair_min = 1e30f, tri_min = 1e30f;
+  bool bad = false;
+  // vote_round's chunk of window w is the next free one; vote_value's the first candidate that probes within 6 % of the
+  // fastest pair seen (a slow pair is 18 - 20 % off), else the best of up to 16.  Compatible regions come in stretches of
+  // tens of gigabytes, so the candidates are taken SPREAD over the free list (its positions in bit-reversed order: the
+  // middle, the quarters, the eighths ..), not from its front -- eight neighbours were eight chunks of one kind and left
+  // 6 of 25 windows slow (profiles/r05_placement.md)
+  auto spread = [](int k, int nfree) {  // the k-th candidate position among nfree
+    int bits = 0;
+    while ((1 << bits) < nfree) ++bits;
+    for (int i = 0, seen = 0; i < (1 << bits); ++i) {
+      int r = 0;
+      for (int b = 0; b < bits; ++b) r |= ((i >> b) & 1) << (bits - 1 - b);
+      if (r < nfree && seen++ == k) return r;
+    }
+    return k % std::max(1, nfree);
+  };
+  for (int w = 0; w < per && !bad; ++w) {
+    pb[w] = freec.front();
+    freec.erase(freec.begin());
+    int best_k = -1;
+    float best_t = 1e30f;
+    const int nfree = (int)freec.size(), tries = std::min(nfree, 16);
+    for (int q = 0; q < tries; ++q) {
+      const int k = spread(q, nfree);
+      const float t = P.probe(pb[w], freec[k], -1);
+      if (t < 0) { bad = true; break; }
+      if (t < best_t) best_t = t, best_k = k;
+      pair_min = std::min(pair_min, t);
+      if ((w > 0 || q >= 11) && t <= pair_min * 1.06f) break;  // (window 0 looks at 12 at least: it calibrates pair_min)
+    }
+    if (bad || best_k < 0) { bad = true; break; }
+    pc[w] = freec[best_k];
+    freec.erase(freec.begin() + best_k);
+    if (dbg) fprintf(stderr, "libfpx: placement window %d: vote_round chunk %d + vote_value chunk %d: %.4f ms (fastest pair so far %.4f)\n", w, pb[w], pc[w], best_t, pair_min);
+  }
+  // the ballots' chunk: the best of 3 candidates under the full triple stream
+  std::vector<float> win_ms(per, 0.f);
+  for (int w = 0; w < per && !bad; ++w) {
+    if (narr < 3) {
+      win_ms[w] = P.probe(pb[w], pc[w], -1);
+      continue;
+    }
+    int best_k = -1;
+    float best_t = 1e30f;
+    const int left = per - w;  // windows that still need a chunk: never look at more candidates than can be spared
+    for (int k = 0; k < (int)freec.size() - (left - 1) && k < 3; ++k) {
+      const float t = P.probe(pb[w], pc[w], freec[k]);
+      if (t < 0) { bad = true; break; }
+      if (t < best_t) best_t = t, best_k = k;
+      tri_min = std::min(tri_min, t);
+      if (w > 0 && t <= tri_min * 1.01f) break;
+    }
+    if (bad || best_k < 0) { bad = true; break; }
+    pa[w] = freec[best_k];
+    freec.erase(freec.begin() + best_k);
+    win_ms[w] = best_t;
+  }
+  if (bad) {
+    P.release_all();
+    return false;
+  }
+  // the final order: array 0 = vote_round, 1 = vote_value, 2 = ballot, `per` chunks each; what is left goes back
+  std::vector<hipMemGenericAllocationHandle_t> order;
+  for (int w = 0; w < per; ++w) order.push_back(P.h[pb[w]]);
+  for (int w = 0; w < per; ++w) order.push_back(P.h[pc[w]]);
+  if (narr == 3)
+    for (int w = 0; w < per; ++w) order.push_back(P.h[pa[w]]);
+  for (int i = 0; i < pool; ++i) (void)hipMemUnmap((hipDeviceptr_t)P.at(i), PLACE_CHUNK);
+  for (int i : freec) (void)hipMemRelease(P.h[i]);
+  P.h = order;
+  bool ok = true;
+  for (int i = 0; i < need && ok; ++i) ok = hipMemMap((hipDeviceptr_t)P.at(i), PLACE_CHUNK, 0, P.h[i], 0) == hipSuccess;
+  ok = ok && hipMemSetAccess((hipDeviceptr_t)P.base, (size_t)need * PLACE_CHUNK, &acc, 1) == hipSuccess;
+  if (!ok) {
+    P.release_all();
+    return false;
+  }
+  std::vector<float> sorted(win_ms);
+  std::sort(sorted.begin(), sorted.end());
+  ctx->placement[0] = 1.f, ctx->placement[1] = (float)per, ctx->placement[2] = sorted.front(), ctx->placement[3] = sorted[per / 2],
+  ctx->placement[4] = sorted.back();
+  if (dbg)
+    fprintf(stderr, "libfpx: slab of %d x %d chunks of 1 GiB placed with %d probes (pool %d): per-window probe min %.4f median %.4f max %.4f ms\n",
+            narr, per, P.probes, pool, sorted.front(), sorted[per / 2], sorted.back());
+  (void)hipEventDestroy(P.e0);
+  (void)hipEventDestroy(P.e1);
+  ctx->vmm_chunks = P.h;
+  ctx->vmm_reserved = P.reserved;
+  ctx->slab = P.base;
+  *slab_out = P.base;
+  *stride_out = (size_t)per * PLACE_CHUNK;
+  return true;
+}
+
 void free_state(fpx_ctx* ctx) {
   State& st = ctx->st;
+  if (ctx->vmm_reserved) {  // the slab is a reservation backed by chunks
+    for (size_t i = 0; i < ctx->vmm_chunks.size(); ++i) (void)hipMemUnmap((hipDeviceptr_t)((char*)ctx->slab + i * PLACE_CHUNK), PLACE_CHUNK);
+    for (auto h : ctx->vmm_chunks) (void)hipMemRelease(h);
+    ctx->vmm_chunks.clear();
+    (void)hipMemAddressFree((hipDeviceptr_t)ctx->slab, ctx->vmm_reserved);
+    ctx->slab = nullptr, ctx->vmm_reserved = 0;
+  }
   void* ps[] = {st.promised, st.max_voted, ctx->slab, st.pl_key, st.pl_value,
                 st.pl_bits,  st.stamp,     st.run_round,  st.status,     st.part,
                 st.log_value, st.log_present, st.log_scalars, st.part_stamp, st.part_all,
@@ -540,6 +766,10 @@ void free_state(fpx_ctx* ctx) {
     delete[] ctx->hslots;
     ctx->hslots = nullptr;
   }
+  if (ctx->band_fork) (void)hipEventDestroy(ctx->band_fork);
+  if (ctx->band_join) (void)hipEventDestroy(ctx->band_join);
+  if (ctx->band_stream) (void)hipStreamDestroy(ctx->band_stream);
+  if (ctx->d_band.p) (void)hipFree(ctx->d_band.p);
   if (ctx->up_stream) (void)hipStreamDestroy(ctx->up_stream);
   if (ctx->down_stream) (void)hipStreamDestroy(ctx->down_stream);
   if (ctx->d_part.p) (void)hipFree(ctx->d_part.p);
@@ -1049,7 +1279,7 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
     size_t stagger = 0;
     if (const char* e = getenv("FPX_STAGGER")) stagger = (size_t)atoll(e) & ~(size_t)15;
     const int narr = g.per_slot ? 3 : 2;
-    const size_t stride = ncell * 4 + stagger;
+    size_t stride = ncell * 4 + stagger;
     // Placement: the very same kernel streams a slab at one of two speeds ~7 % apart depending on where the
     // allocation landed (deterministic per allocation, profiles/r02_placement.txt).  A big context therefore
     // allocates up to FPX_PLACEMENT_TRIES slabs (default 4, while free HBM allows), times the hot access pattern
@@ -1057,6 +1287,13 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
     int tries = stride * narr >= ((size_t)2 << 30) && g.RS >= 64 ? 4 : 1;
     if (const char* e = getenv("FPX_PLACEMENT_TRIES")) tries = std::max(1, std::min(8, atoi(e)));
     char* slab = nullptr;
+    // round 5: chunk placement first (place_chunks above) -- a big slab of separate arrays is built from 1 GiB physical
+    // chunks paired by measurement; one hipMalloc with candidate probing (rounds 2 - 4) stays the fallback
+    bool chunked = false;
+    if (tries > 1 && g.VS == g.RS && stagger == 0 && !(getenv("FPX_PLACEMENT_CHUNKS") && atoi(getenv("FPX_PLACEMENT_CHUNKS")) == 0)) {
+      size_t cstride = 0;
+      if (place_chunks(ctx, narr, ncell * 4, g.RS / 4, &slab, &cstride)) chunked = true, stride = cstride, tries = 0;
+    }
     float best_ms = 0;
     std::vector<char*> losers;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1102,6 +1339,7 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (!slab) return fail(FPX_ENOMEM);
+    if (!chunked) ctx->placement[0] = 0.f, ctx->placement[1] = 1.f, ctx->placement[2] = ctx->placement[3] = ctx->placement[4] = best_ms;
     ctx->bytes += (int64_t)(stride * narr);
     ctx->slab = slab;
     st.vote_round = (int32_t*)slab;
@@ -1220,6 +1458,21 @@ int32_t fpx_profile_read(fpx_ctx* ctx, int32_t* launches, double* total_ms) {
   return FPX_OK;
 }
 
+int32_t fpx_profile_read_launches(fpx_ctx* ctx, int32_t cap, float* ms_out, int32_t* launches) {
+  DeviceGuard _dg(ctx);
+  if (!ctx || cap < 0 || (cap > 0 && !ms_out)) return FPX_EINVAL;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  int32_t k = 0;
+  for (size_t i = 0; i + 1 < ctx->ev_used; i += 2, ++k) {
+    float ms = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
+    if (k < cap) ms_out[k] = ms;
+  }
+  if (launches) *launches = k;
+  ctx->ev_used = 0;
+  return FPX_OK;
+}
+
 int32_t fpx_last_hip_error(fpx_ctx* ctx) {
   DeviceGuard _dg(ctx); return ctx ? ctx->last_hip : 0; }
 int32_t fpx_get_config(fpx_ctx* ctx, fpx_config* out) {
@@ -1230,6 +1483,12 @@ int32_t fpx_get_config(fpx_ctx* ctx, fpx_config* out) {
 
 int64_t fpx_device_bytes(fpx_ctx* ctx) {
   DeviceGuard _dg(ctx); return ctx ? ctx->bytes : 0; }
+
+int32_t fpx_placement_stats(fpx_ctx* ctx, float out[5]) {
+  if (!ctx || !out) return FPX_EINVAL;
+  for (int i = 0; i < 5; ++i) out[i] = ctx->placement[i];
+  return FPX_OK;
+}
 
 int32_t fpx_host_alloc(int64_t bytes, void** out) {
   if (!out || bytes <= 0) return FPX_EINVAL;
@@ -1728,6 +1987,64 @@ int32_t fpx_noop_ranges_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot
   b.vote_bits = d_vote_bits ? d_vote_bits : (uint64_t*)((char*)ctx->d_rng.p + (((size_t)n * 4 + 63) & ~(size_t)63));
   b.nack_bits = d_nack_bits, b.nack_round = d_nack_round, b.is_new = d_is_new, b.chosen = d_chosen;
   return enqueue_ranges(ctx, b, RANGES_FUSED);
+}
+
+// One proxy-leader step of Mencius: fpx_phase2_fused_dev on the commands, then fpx_noop_ranges_fused_dev on the ranges --
+// and, when the caller says that no leader group has both (`independent`), the two halves side by side: the ranges on the
+// context's second stream between a fork and a join event (profiles/r05_cfg5.md).
+int32_t fpx_mencius_band_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round, const int32_t* d_value_id,
+                                   const uint64_t* d_target_mask, uint8_t* d_chosen, int32_t* d_chosen_round, int32_t* d_chosen_value,
+                                   int32_t* d_nack_round, int32_t n_ranges, const int32_t* d_slot_start, const int32_t* d_slot_end,
+                                   const int32_t* d_range_round, const uint64_t* d_range_target_masks, uint64_t* d_range_vote_bits,
+                                   uint64_t* d_range_nack_bits, int32_t* d_range_nack_round, uint8_t* d_range_is_new,
+                                   uint8_t* d_range_chosen, int32_t independent) {
+  DeviceGuard _dg(ctx);
+  if (!ctx || n < 0 || n_ranges < 0) return FPX_EINVAL;
+  int rc;
+  if (!independent || n == 0 || n_ranges == 0 || ctx->g.per_slot) {  // the serial order (what the two calls would do)
+    if ((rc = fpx_phase2_fused_dev(ctx, n, d_slot, d_round, d_value_id, d_target_mask, d_chosen, d_chosen_round, d_chosen_value, d_nack_round)))
+      return rc;
+    return fpx_noop_ranges_fused_dev(ctx, n_ranges, d_slot_start, d_slot_end, d_range_round, d_range_target_masks, d_range_vote_bits,
+                                     d_range_nack_bits, d_range_nack_round, d_range_is_new, d_range_chosen);
+  }
+  if (!ctx->band_stream) {
+    if (hipStreamCreateWithFlags(&ctx->band_stream, hipStreamNonBlocking) != hipSuccess) return FPX_EHIP;
+    if (hipEventCreateWithFlags(&ctx->band_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->band_join, hipEventDisableTiming) != hipSuccess)
+      return FPX_EHIP;
+  }
+  const bool validate = !((ctx->cfg.flags & FPX_F_TRUSTED) && !ctx->force_validate);
+  if (validate) {
+    // is the caller's word good?  Checked before anything is applied (FPX_EORDER, nothing applied); the halves themselves
+    // then run one after the other: their run-contract checks share one scratch table (State::run_round)
+    const int L = ctx->g.num_leader_groups;
+    if ((rc = grow(ctx, &ctx->d_band, (size_t)L * 4))) return rc;
+    fill32(ctx, (int32_t*)ctx->d_band.p, 0, (size_t)L);
+    hipLaunchKernelGGL(k_band_mark, dim3((n_ranges + 255) / 256), dim3(256), 0, ctx->stream, ctx->g, n_ranges, d_slot_start, (int32_t*)ctx->d_band.p);
+    hipLaunchKernelGGL(k_band_check, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->g, ctx->st, n, d_slot, d_round,
+                       (const int32_t*)ctx->d_band.p);
+    if ((rc = fpx_phase2_fused_dev(ctx, n, d_slot, d_round, d_value_id, d_target_mask, d_chosen, d_chosen_round, d_chosen_value, d_nack_round)))
+      return rc;
+    return fpx_noop_ranges_fused_dev(ctx, n_ranges, d_slot_start, d_slot_end, d_range_round, d_range_target_masks, d_range_vote_bits,
+                                     d_range_nack_bits, d_range_nack_round, d_range_is_new, d_range_chosen);
+  }
+  // the ranges' scratch is sized on the main stream (grow may reallocate: nothing of the side stream is in flight here,
+  // the previous step joined)
+  const size_t words = (size_t)n_ranges * ctx->g.num_groups * 4;
+  if ((rc = ranges_ctx_ok(ctx, n_ranges))) return rc;
+  if ((rc = grow(ctx, &ctx->d_rng, (size_t)n_ranges * 4 + 64 + (d_range_vote_bits ? 0 : words * 8)))) return rc;
+  HIPCHK(ctx, hipEventRecord(ctx->band_fork, ctx->stream));
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->band_stream, ctx->band_fork, 0));
+  hipStream_t main_stream = ctx->stream;
+  ctx->stream = ctx->band_stream;
+  rc = fpx_noop_ranges_fused_dev(ctx, n_ranges, d_slot_start, d_slot_end, d_range_round, d_range_target_masks, d_range_vote_bits,
+                                 d_range_nack_bits, d_range_nack_round, d_range_is_new, d_range_chosen);
+  const hipError_t je = hipEventRecord(ctx->band_join, ctx->band_stream);
+  ctx->stream = main_stream;
+  int rc2 = fpx_phase2_fused_dev(ctx, n, d_slot, d_round, d_value_id, d_target_mask, d_chosen, d_chosen_round, d_chosen_value, d_nack_round);
+  if (je == hipSuccess) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->band_join, 0));
+  if (je != hipSuccess) return FPX_EHIP;
+  return rc ? rc : rc2;
 }
 
 namespace {

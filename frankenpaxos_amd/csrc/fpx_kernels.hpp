@@ -1689,7 +1689,7 @@ __global__ void __launch_bounds__(256) k_probe(int32_t* a_read, int32_t* b_write
     int4v v = {i, i, i, i};
     if (a_read) v = *reinterpret_cast<const int4v*>(a_read + o);
     row_store(v, reinterpret_cast<int4v*>(b_write + o));
-    row_store(v, reinterpret_cast<int4v*>(c_write + o));
+    if (c_write) row_store(v, reinterpret_cast<int4v*>(c_write + o));
   }
 }
 

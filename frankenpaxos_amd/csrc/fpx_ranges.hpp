@@ -82,6 +82,25 @@ __global__ void __launch_bounds__(256) k_ranges_validate(const Geom g, const Sta
   }
 }
 
+// One step of a Mencius proxy leader = the commands of the leader groups that have some + the noop ranges of those that skip
+// (fpx_mencius_band_fused_dev).  The two halves touch disjoint rows, tallies and acceptor scalars iff no leader group
+// (slot % numLeaderGroups, mencius/ProxyLeader.scala:231-234) has both a command and a range in the step: then they may
+// run side by side.  The caller says so; unless the context is FPX_F_TRUSTED these two kernels hold it to its word before
+// anything is applied (FPX_EORDER, nothing applied).
+__global__ void __launch_bounds__(256) k_band_mark(const Geom g, int n, const int32_t* start, int32_t* lg_mark) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int s = start[i];
+  if (s >= 0) lg_mark[s % g.num_leader_groups] = 1;
+}
+__global__ void __launch_bounds__(256) k_band_check(const Geom g, const State st, int n, const int32_t* slot, const int32_t* round,
+                                                    const int32_t* lg_mark) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int s = slot[i];
+  if (s >= 0 && lg_mark[s % g.num_leader_groups] != 0) report_abort(st, 6 /*FPX_EORDER*/, i, s, round[i]);
+}
+
 // mencius/ProxyLeader.scala:255-303.  lookup = 1: find only (the Phase2bNoopRange entry point).
 // Returns the table entry (-1 unknown / refused, -2 swallowed).  *inserted: this call created the entry; *shared: the
 // entry was created by ANOTHER message of this launch (the same key twice in one batch).  count_hint: a value of

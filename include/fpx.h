@@ -179,6 +179,13 @@ int32_t fpx_error_detail(fpx_ctx* ctx, int32_t* index, int32_t* slot, int32_t* r
 int32_t fpx_last_hip_error(fpx_ctx* ctx);
 /* HBM bytes held by the context */
 int64_t fpx_device_bytes(fpx_ctx* ctx);
+/* How the cell arrays (Acceptor.states of every acceptor, multipaxos/Acceptor.scala:98) were placed in HBM by fpx_create:
+ * out[0] = 1 if the slab is built from 1 GiB physical chunks paired by measurement (vote_round's and vote_value's chunk of
+ * a gigabyte of rows must be a pair the chip writes side by side at the fast rate; contexts of 2 GiB and more with groups
+ * of 61+ acceptors), 0 if it is one allocation; out[1] = gigabyte windows probed; out[2..4] = min / median / max over the
+ * windows of the hot access pattern's time on half a window, in ms (0 when nothing was probed).  Diagnostics only:
+ * results never depend on the placement.  FPX_PLACEMENT_CHUNKS=0 in the environment keeps one allocation. */
+int32_t fpx_placement_stats(fpx_ctx* ctx, float out[5]);
 /* the configuration the context was created with (replicas_total filled in): a binding sizes its buffers from the
  * handle, not from what its caller says the handle is */
 int32_t fpx_get_config(fpx_ctx* ctx, fpx_config* out);
@@ -193,6 +200,9 @@ int32_t fpx_host_free(void* p);
  * and returns the number of bracketed launches since the last read and the sum of their durations. */
 int32_t fpx_profile_enable(fpx_ctx* ctx, int32_t on);
 int32_t fpx_profile_read(fpx_ctx* ctx, int32_t* launches, double* total_ms);
+/* the same read launch by launch: the durations of the first `cap` timed launches since the last read, in order, into
+ * ms_out; *launches = how many there were (the variance of one kernel over the log's windows: profiles/r05_placement.md) */
+int32_t fpx_profile_read_launches(fpx_ctx* ctx, int32_t cap, float* ms_out, int32_t* launches);
 
 /* ---- a7: roundsystem.ClassicRoundRobin (RoundSystem.scala:60-87); pure host scalars ----------- */
 int32_t fpx_round_leader(int32_t num_leaders, int32_t round);                         /* :63     */
@@ -364,6 +374,23 @@ int32_t fpx_noop_ranges_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot
                                   const int32_t* d_slot_end, const int32_t* d_round,
                                   const uint64_t* d_target_masks, uint64_t* d_vote_bits, uint64_t* d_nack_bits,
                                   int32_t* d_nack_round, uint8_t* d_is_new, uint8_t* d_chosen);
+/* One step of a Mencius proxy leader: the Phase2as of the leader groups that have commands AND the Phase2aNoopRanges
+ * of the leader groups that skip their slots (mencius/ProxyLeader.scala:231-234 slot -> leader group; :216-303 the two
+ * handlers) = fpx_phase2_fused_dev(the first ten arguments) followed by fpx_noop_ranges_fused_dev(the next ten), with
+ * exactly their outputs and errors.  independent != 0: the caller states that no leader group has both a command and a
+ * range in this step (a leader either proposes in its slots or skips them).  Then the two halves touch disjoint rows,
+ * tallies and acceptors, no order between them is observable, and under FPX_F_TRUSTED they run side by side -- the
+ * ranges on a second stream of the context between a fork and a join event (0.097 -> see profiles/r05_cfg5.md per band
+ * of 2^22 slots).  A context that validates its batches checks the statement first: a leader group with both makes
+ * the step FPX_EORDER with nothing applied (call again with independent = 0), and the halves run one after the other. */
+int32_t fpx_mencius_band_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,
+                                   const int32_t* d_value_id, const uint64_t* d_target_mask, uint8_t* d_chosen,
+                                   int32_t* d_chosen_round, int32_t* d_chosen_value, int32_t* d_nack_round,
+                                   int32_t n_ranges, const int32_t* d_slot_start, const int32_t* d_slot_end,
+                                   const int32_t* d_range_round, const uint64_t* d_range_target_masks,
+                                   uint64_t* d_range_vote_bits, uint64_t* d_range_nack_bits,
+                                   int32_t* d_range_nack_round, uint8_t* d_range_is_new, uint8_t* d_range_chosen,
+                                   int32_t independent);
 /* batches of one (bitmaps num_groups x 4 words) */
 int32_t fpx_acceptor_phase2a_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end,
                                         int32_t round, const uint64_t* target_masks,

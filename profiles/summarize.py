@@ -43,7 +43,7 @@ for f, label, alg in (("bench", "per_slot", 3088), ("bench_acceptor", "acceptor"
     fe = pick(agg(os.path.join(base, "pmc_FETCH_SIZE", f + "_counter_collection.csv")), "k_phase2")
     wr = pick(agg(os.path.join(base, "pmc_WRITE_SIZE", f + "_counter_collection.csv")), "k_phase2")
     rd_b, wr_b = fe * fetch_scale * 1024, wr * write_scale * 1024
-    traffic[label] = rd_b + wr_b
+    traffic[label] = {"bytes": rd_b + wr_b, "round": tag, "source": "profiles/%s_pmc_summary.md" % tag}
     rows.append((label, fe, wr, rd_b, wr_b, rd_b + wr_b, alg * (1 << 20)))
 try:  # keep the entries other scripts maintain (config4: profiles/microbench/k5_pmc.sh)
     kept = json.load(open(os.path.join(out, "traffic.json")))

@@ -192,6 +192,106 @@ def test_config5_mencius_256_leader_groups_4m_slots(fa, oracle, row_layout):
             np.testing.assert_array_equal(x, y)
 
 
+def _band_on_device(fa, gpu, fused_op, ranges_op, independent):
+    """one proxy-leader step through fpx_mencius_band_fused_dev on device-resident arrays; returns the two halves' outputs
+    in the order of phase2_fused / noop_ranges_fused"""
+    import torch
+    dev = torch.device("cuda:0")
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    _, slot, rr, val, tgt = fused_op
+    _, st_, en_, rn_, tm = ranges_op
+    n, k, A = len(slot), len(st_), gpu.cfg.num_groups
+    ch, cr, cv, nr = (torch.zeros(n, dtype=torch.uint8, device=dev), torch.full((n,), -1, dtype=torch.int32, device=dev),
+                      torch.full((n,), -1, dtype=torch.int32, device=dev), torch.full((n,), -1, dtype=torch.int32, device=dev))
+    vb, nb = (torch.zeros((k, A, 4), dtype=torch.int64, device=dev) for _ in range(2))
+    rnr, new, rch = (torch.full((k,), -1, dtype=torch.int32, device=dev), torch.zeros(k, dtype=torch.uint8, device=dev),
+                     torch.zeros(k, dtype=torch.uint8, device=dev))
+    gpu.mencius_band_fused_dev(d(slot), d(rr), d(val), d(tgt.view(np.int64)), ch, cr, cv, nr, d(st_), d(en_), d(rn_),
+                               d(np.ascontiguousarray(tm).view(np.int64)), vb, nb, rnr, new, rch, independent=independent)
+    st = gpu.sync()
+    h = lambda t: t.cpu().numpy()
+    return st, (h(ch), h(cr), h(cv), h(nr)), (h(vb).view(np.uint64), h(nb).view(np.uint64), h(rnr), h(new), h(rch))
+
+
+def test_config5_band_entry_point_halves_side_by_side(fa, oracle, row_layout):
+    """configs[4] at size through fpx_mencius_band_fused_dev -- the commands of the leader groups that
+    propose and the noop ranges of those that skip in ONE call, the two halves on two streams (FPX_F_TRUSTED, the leader
+    groups of an epoch's two batches are disjoint by construction) -- every output of both halves, the state digest and
+    the acceptors' scalars == the oracle running the halves one after the other (mencius/ProxyLeader.scala:216-303)."""
+    import torch
+    S, L, R = 1 << 22, 256, 3
+    kw = dict(num_slots=S, num_replicas=R, num_groups=1, num_leader_groups=L, f=1, tally_ways=4)
+    gpu, ref = fa.Context(fa.make_config(flags=fa.FPX_F_TRUSTED, **kw)), oracle.System(oracle.make_config(**kw))
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    pending, steps = None, 0
+    for op in mencius_stream(S, L, R, epochs=16, seed=7):
+        if op[0] == "phase1a":
+            a, b = gpu.acceptor_phase1a(*op[1:]), ref.acceptor_phase1a(*op[1:])
+            assert a[0] == b[0] == 0
+            np.testing.assert_array_equal(a[1], b[1])
+        elif op[0] == "fused":
+            pending = op
+        else:
+            st, cmd, rng_ = _band_on_device(fa, gpu, pending, op, independent=True)
+            assert st == 0
+            b1, b2 = ref.phase2_fused(*pending[1:]), ref.noop_ranges_fused(*op[1:])
+            assert b1[0] == b2[0] == 0
+            chosen = b1[1].astype(bool)
+            np.testing.assert_array_equal(cmd[0], b1[1])
+            np.testing.assert_array_equal(cmd[1][chosen], b1[2][chosen])
+            np.testing.assert_array_equal(cmd[2][chosen], b1[3][chosen])
+            np.testing.assert_array_equal(cmd[3], b1[4])
+            for x, y in zip(rng_, b2[1:]):
+                np.testing.assert_array_equal(x, np.asarray(y).reshape(x.shape))
+            steps += 1
+    assert steps == 16
+    np.testing.assert_array_equal(gpu.state_digest(), ref.state_digest())
+    pg, mg = gpu.read_scalars()
+    pr, mr = ref.read_scalars()
+    np.testing.assert_array_equal(pg, pr)
+    np.testing.assert_array_equal(mg, mr)
+
+
+def test_band_entry_point_when_the_halves_share_a_leader_group(fa, oracle, row_layout):
+    """the halves are NOT independent: leader group 2 proposes commands in some of its slots and skips others with a range
+    in the same step, and a range covers a slot that carries a command.  A validating context refuses the caller's
+    `independent` (FPX_EORDER, nothing applied: the state digest does not move) and runs the step in order without it;
+    a trusted context told the truth (independent = 0) runs it in order too: == the oracle, commands first."""
+    import torch
+    S, L, R = 1 << 14, 8, 3
+    kw = dict(num_slots=S, num_replicas=R, num_groups=1, num_leader_groups=L, f=1, tally_ways=4)
+    rows = np.arange(0, 512)
+    slot = np.sort(np.concatenate([rows * L + 0, rows * L + 1, rows[:128] * L + 2])).astype(np.int32)
+    fused = ("fused", slot, np.zeros(len(slot), np.int32), W.steady_values(slot), W.bits_from_bool(np.ones((len(slot), R), bool)))
+    starts = np.array([64 * L + 2, 0 * L + 3, 100 * L + 3], np.int32)      # leader group 2 again: overlaps its commands 64 .. 127
+    ends = np.array([400 * L + 2 + 1, 100 * L + 3, 511 * L + 3 + 1], np.int32)
+    ranges = ("ranges", starts, ends, np.zeros(3, np.int32), W.bits_from_bool(np.ones((3, R), bool)).reshape(3, 1, 4))
+    for flags in (0, fa.FPX_F_TRUSTED):
+        gpu, ref = fa.Context(fa.make_config(flags=flags, **kw)), oracle.System(oracle.make_config(**kw))
+        gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+        for lg in range(L):
+            assert gpu.acceptor_phase1a(lg, 0)[0] == 0 and ref.acceptor_phase1a(lg, 0)[0] == 0
+        if flags == 0:
+            before = gpu.state_digest()
+            st, cmd, rng_ = _band_on_device(fa, gpu, fused, ranges, independent=True)
+            assert st == fa.FPX_EORDER and not cmd[0].any() and not rng_[4].any()
+            np.testing.assert_array_equal(gpu.state_digest(), before)
+        st, cmd, rng_ = _band_on_device(fa, gpu, fused, ranges, independent=False)
+        assert st == 0
+        b1, b2 = ref.phase2_fused(*fused[1:]), ref.noop_ranges_fused(*ranges[1:])
+        np.testing.assert_array_equal(cmd[0], b1[1])
+        np.testing.assert_array_equal(cmd[2][b1[1].astype(bool)], b1[3][b1[1].astype(bool)])
+        for x, y in zip(rng_, b2[1:]):
+            np.testing.assert_array_equal(x, np.asarray(y).reshape(x.shape))
+        np.testing.assert_array_equal(gpu.state_digest(), ref.state_digest())
+        for r in range(R):
+            a, b = gpu.read_acceptor(2, r), ref.read_acceptor(2, r)
+            assert a[:2] == b[:2]
+            for x, y in zip(a[2:], b[2:]):
+                np.testing.assert_array_equal(x, y)
+        gpu.close()
+
+
 def test_epaxos_full_size_scenario_with_the_command_log(oracle):
     """BASELINE.json configs[3] end to end AT SIZE with the command log kept (K6 / K7 were only
     held at <= 5 000 messages): a tick of 2^20 commands (K5) -> every slow-path command through the Accept phase
