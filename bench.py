@@ -33,7 +33,9 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
-SLOTS_PER_STEP = 1 << 20
+# (FPX_BENCH_SLOTS_LOG2: test hook of tests/test_bench_distributed.py -- many ranks on ONE GPU with small windows; never set
+# by the driver, and config.slots_per_step in the line always says what was run)
+SLOTS_PER_STEP = 1 << int(os.environ.get("FPX_BENCH_SLOTS_LOG2", "20"))
 REPLICAS = 256
 F = 127
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -166,9 +168,12 @@ def setup_comm(fa, ctx, dist, backend, dev, rank, world):
     """The RCCL communicator lives behind the C ABI (fpx_comm_create); its 128-byte id travels over
     torch.distributed, which is control plane only here.  Under the gloo test hook the ranks share one GPU,
     which RCCL refuses (duplicate device): no communicator, the caller falls back to a host exchange."""
-    if backend != "nccl":
+    if backend != "nccl" and os.environ.get("FPX_BENCH_FPX_COMM") != "1":
         return False
-    idt = torch.zeros(fa.FPX_COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+    # (FPX_BENCH_FPX_COMM=1, test hook: the ranks share one GPU and rendezvous over gloo, but the data path still goes
+    # through fpx_comm_create and the library's collectives -- bound to the test double FPX_RCCL_LIB names, since RCCL
+    # itself refuses two ranks on one device: tests/test_bench_distributed.py runs the 8-rank lines that way)
+    idt = torch.zeros(fa.FPX_COMM_ID_BYTES, dtype=torch.uint8, device=dev if backend == "nccl" else "cpu")
     if rank == 0:
         idt.copy_(torch.frombuffer(bytearray(fa.comm_unique_id()), dtype=torch.uint8))
     dist.broadcast(idt, 0)
@@ -490,7 +495,7 @@ def main():
     # small context + one all-gather of Chosen records), so that `rccl` in the line does not depend on the extra
     # row having finished; deadline-guarded like the row.
     rccl_info = None
-    if world > 1 and backend == "nccl" and not hung:
+    if world > 1 and (backend == "nccl" or os.environ.get("FPX_BENCH_FPX_COMM") == "1") and not hung:
         def rccl_probe():
             pctx = fa.Context(fa.make_config(num_slots=4096, num_replicas=4, f=1, device=local_rank))
             pctx.set_stream(torch.cuda.current_stream().cuda_stream)

@@ -80,6 +80,7 @@ SIGNATURES = {
     "fpx_last_hip_error": (C.c_int32, [VP]),
     "fpx_device_bytes": (C.c_int64, [VP]),
     "fpx_placement_stats": (C.c_int32, [VP, C.POINTER(C.c_float)]),
+    "fpx_acceptor_max_voted_in": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, I32P]),
     "fpx_profile_read_launches": (C.c_int32, [VP, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "fpx_get_config": (C.c_int32, [VP, CFGP]),
     "fpx_host_alloc": (C.c_int32, [C.c_int64, C.POINTER(C.c_void_p)]),
@@ -129,6 +130,7 @@ SIGNATURES = {
     "fpx_epx_handle_prepare_oks": (C.c_int32, [VP, C.c_int32] + [VP] * 8 + [C.c_int32] + [VP] * 3),
     "fpx_epx_prepare": (C.c_int32, [VP, C.c_int32] + [VP] * 12),
     "fpx_epx_accept": (C.c_int32, [VP, C.c_int32] + [VP] * 13),
+    "fpx_epx_handle_commit": (C.c_int32, [VP, C.c_int32] + [VP] * 8),
     "fpx_epx_read_cmdlog": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, VP]),
     "fpx_epx_read_cmdlog_deps": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, VP, VP]),
     "fpx_epx_handle_preaccept": (C.c_int32, [VP, C.c_int32] + [VP] * 18),

@@ -116,6 +116,15 @@ class Context:
     def device_bytes(self):
         return self.L.fpx_device_bytes(self._h)
 
+    def acceptor_max_voted_in(self, group, replica, first_slot=0, count=None):
+        """Acceptor.maxVotedSlot over the slots [first_slot, first_slot + count) of the acceptor's group (-1: no vote there)"""
+        out = C.c_int32(-1)
+        st = self.L.fpx_acceptor_max_voted_in(self._h, group, replica, first_slot, self.cfg.num_slots - first_slot if count is None else count,
+                                              C.byref(out))
+        if st:
+            raise FpxError(st, "fpx_acceptor_max_voted_in")
+        return out.value
+
     def placement_stats(self):
         """how fpx_create placed the cell arrays: {"chunks": bool, "windows": n, "probe_ms": (min, median, max)}"""
         out = (C.c_float * 5)()

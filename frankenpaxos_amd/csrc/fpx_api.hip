@@ -46,6 +46,8 @@ struct RcclApi {
   int (*ReduceScatter)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;  // optional: several collectives as one launch (fpx_comm_allgather_chosen_dev)
+  int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
 static_assert(sizeof(RcclUniqueId) == FPX_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
@@ -648,26 +650,56 @@ bool place_chunks(fpx_ctx* ctx, int narr, size_t array_bytes, int q4, char** sla
     }
     return k % std::max(1, nfree);
   };
+  std::vector<int> aside;  // chunks that found no partner as vote_round's: back into the pool for the ballots / as spares
   for (int w = 0; w < per && !bad; ++w) {
-    pb[w] = freec.front();
-    freec.erase(freec.begin());
-    int best_k = -1;
-    float best_t = 1e30f;
-    const int nfree = (int)freec.size(), tries = std::min(nfree, 16);
-    for (int q = 0; q < tries; ++q) {
-      const int k = spread(q, nfree);
-      const float t = P.probe(pb[w], freec[k], -1);
-      if (t < 0) { bad = true; break; }
-      if (t < best_t) best_t = t, best_k = k;
-      pair_min = std::min(pair_min, t);
-      if ((w > 0 || q >= 11) && t <= pair_min * 1.06f) break;  // (window 0 looks at 12 at least: it calibrates pair_min)
+    // up to 4 different chunks for vote_round: late in the search the pool may have run out of partners for the kind of
+    // chunk at its front (both other arrays draw from it); such a chunk is set aside and the next one tried
+    int fb = -1, fcid = -1;  // the pair so far (chunk ids)
+    float ft = 1e30f;
+    for (int attempt = 0; attempt < 4 && !bad; ++attempt) {
+      if ((int)freec.size() + (int)aside.size() < 2 + (per - w - 1) * 2 || freec.size() < 2) break;  // (the windows after this one need two chunks each)
+      const int b = freec.front();
+      freec.erase(freec.begin());
+      int best_c = -1;
+      float best_t = 1e30f;
+      const int nfree = (int)freec.size(), tries = std::min(nfree, 16);
+      bool fast = false;
+      for (int q = 0; q < tries; ++q) {
+        const int c = freec[spread(q, nfree)];
+        const float t = P.probe(b, c, -1);
+        if (t < 0) { bad = true; break; }
+        if (t < best_t) best_t = t, best_c = c;
+        pair_min = std::min(pair_min, t);
+        if ((w > 0 || q >= 11) && t <= pair_min * 1.06f) { fast = true; break; }  // (window 0 looks at 12 at least: it calibrates pair_min)
+      }
+      if (bad) break;
+      if (w == 0 && best_t <= pair_min * 1.06f) fast = true;
+      if (fb < 0 || best_t < ft) {
+        if (fb >= 0) aside.push_back(fb);
+        fb = b, fcid = best_c, ft = best_t;
+      } else {
+        aside.push_back(b);
+      }
+      if (fast) break;
     }
-    if (bad || best_k < 0) { bad = true; break; }
-    pc[w] = freec[best_k];
-    freec.erase(freec.begin() + best_k);
-    if (dbg) fprintf(stderr, "libfpx: placement window %d: vote_round chunk %d + vote_value chunk %d: %.4f ms (fastest pair so far %.4f)\n", w, pb[w], pc[w], best_t, pair_min);
+    if (bad || fb < 0 || fcid < 0) { bad = true; break; }
+    // the partner is still free: in the pool, or set aside after a turn as vote_round's candidate
+    auto take = [&](std::vector<int>& from) {
+      auto it = std::find(from.begin(), from.end(), fcid);
+      if (it == from.end()) return false;
+      from.erase(it);
+      return true;
+    };
+    if (!take(freec) && !take(aside)) { bad = true; break; }
+    pb[w] = fb, pc[w] = fcid;
+    if (dbg) fprintf(stderr, "libfpx: placement window %d: vote_round chunk %d + vote_value chunk %d: %.4f ms (fastest pair so far %.4f)\n", w, pb[w], pc[w], ft, pair_min);
   }
-  // the ballots' chunk: the best of 3 candidates under the full triple stream
+  freec.insert(freec.end(), aside.begin(), aside.end());
+  // the ballots' chunk: the first candidate (spread over what is left, as above) within 1 % of the fastest triple stream
+  // seen, else the best of 12 (FPX_PLACEMENT_A_TRIES).  The read stream's region matters as much as the pair's: with three
+  // candidates 3 of 25 windows ended 10 % slow, with eight none (profiles/r05_placement.md)
+  int a_tries = 12;
+  if (const char* e = getenv("FPX_PLACEMENT_A_TRIES")) a_tries = std::max(1, atoi(e));
   std::vector<float> win_ms(per, 0.f);
   for (int w = 0; w < per && !bad; ++w) {
     if (narr < 3) {
@@ -677,7 +709,9 @@ bool place_chunks(fpx_ctx* ctx, int narr, size_t array_bytes, int q4, char** sla
     int best_k = -1;
     float best_t = 1e30f;
     const int left = per - w;  // windows that still need a chunk: never look at more candidates than can be spared
-    for (int k = 0; k < (int)freec.size() - (left - 1) && k < 3; ++k) {
+    const int na = std::max(1, std::min({(int)freec.size() - (left - 1), a_tries, 16}));
+    for (int q = 0; q < na; ++q) {
+      const int k = spread(q, (int)freec.size());
       const float t = P.probe(pb[w], pc[w], freec[k]);
       if (t < 0) { bad = true; break; }
       if (t < best_t) best_t = t, best_k = k;
@@ -688,6 +722,7 @@ bool place_chunks(fpx_ctx* ctx, int narr, size_t array_bytes, int q4, char** sla
     pa[w] = freec[best_k];
     freec.erase(freec.begin() + best_k);
     win_ms[w] = best_t;
+    if (dbg) fprintf(stderr, "libfpx: placement window %d: ballot chunk %d: %.4f ms (fastest triple so far %.4f)\n", w, pa[w], best_t, tri_min);
   }
   if (bad) {
     P.release_all();
@@ -2433,6 +2468,26 @@ int32_t fpx_read_acceptor(fpx_ctx* ctx, int32_t group, int32_t replica, int32_t*
   return FPX_OK;
 }
 
+int32_t fpx_acceptor_max_voted_in(fpx_ctx* ctx, int32_t group, int32_t replica, int32_t first_slot, int32_t count,
+                                  int32_t* max_slot) {
+  DeviceGuard _dg(ctx);
+  if (!ctx || !max_slot || group < 0 || group >= ctx->g.ngroups || replica < 0 || replica >= ctx->g.R || first_slot < 0 || count < 0 ||
+      (int64_t)first_slot + count > ctx->g.S)
+    return FPX_EINVAL;
+  *max_slot = -1;
+  if (count == 0) return FPX_OK;
+  int rc;
+  if ((rc = grow(ctx, &ctx->d_scratch, 128))) return rc;
+  int32_t* d = (int32_t*)ctx->d_scratch.p;
+  fill32(ctx, d, -1, 1);
+  hipLaunchKernelGGL(k_max_voted_in, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, ctx->g, ctx->st, group, replica,
+                     first_slot, count, d);
+  if ((rc = launch_check(ctx))) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(max_slot, d, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FPX_OK;
+}
+
 // Acceptor.handlePhase1a's Phase1b.info (multipaxos/Acceptor.scala:166-178): the acceptor's votes in slots >=
 // chosen_watermark, ascending (states.iteratorFrom).  Phase 1 is off the steady path: one gather of the acceptor's
 // column, compacted on the host.
@@ -2497,6 +2552,9 @@ static RcclApi* rccl_bind() {
   api.ReduceScatter = reinterpret_cast<decltype(api.ReduceScatter)>(sym("ncclReduceScatter"));
   api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
   api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+  api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+  api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+  if (!api.GroupStart || !api.GroupEnd) api.GroupStart = api.GroupEnd = nullptr;
   api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
   if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.ReduceScatter || !api.AllGather) return nullptr;
   api.lib = h;
@@ -2643,9 +2701,18 @@ int32_t fpx_comm_allgather_chosen_dev(fpx_ctx* ctx, int32_t n_local, const uint8
   if (!r || !ctx->comm) return FPX_ERCCL;
   const bool prof = ctx->profiling && ctx->cev_used + 2 <= ctx->cev.size();
   if (prof) HIPCHK(ctx, hipEventRecord(ctx->cev[ctx->cev_used], ctx->stream));
-  if (d_chosen && d_all_chosen) RCCLCHK(ctx, r->AllGather(d_chosen, d_all_chosen, (size_t)n_local, RCCL_UINT8, ctx->comm, ctx->stream));
-  if (d_chosen_round && d_all_round) RCCLCHK(ctx, r->AllGather(d_chosen_round, d_all_round, (size_t)n_local, RCCL_INT32, ctx->comm, ctx->stream));
-  if (d_chosen_value && d_all_value) RCCLCHK(ctx, r->AllGather(d_chosen_value, d_all_value, (size_t)n_local, RCCL_INT32, ctx->comm, ctx->stream));
+  // the three arrays of the Chosen records travel as ONE group: one launch and one ring set-up instead of three
+  // (ncclGroupStart / ncclGroupEnd; an RCCL without them gets three calls)
+  if (r->GroupStart) RCCLCHK(ctx, r->GroupStart());
+  int grc = 0;
+  if (d_chosen && d_all_chosen) grc = r->AllGather(d_chosen, d_all_chosen, (size_t)n_local, RCCL_UINT8, ctx->comm, ctx->stream);
+  if (!grc && d_chosen_round && d_all_round) grc = r->AllGather(d_chosen_round, d_all_round, (size_t)n_local, RCCL_INT32, ctx->comm, ctx->stream);
+  if (!grc && d_chosen_value && d_all_value) grc = r->AllGather(d_chosen_value, d_all_value, (size_t)n_local, RCCL_INT32, ctx->comm, ctx->stream);
+  if (r->GroupEnd) {  // (always closed, also after a failed call inside the group)
+    const int erc = r->GroupEnd();
+    if (!grc) grc = erc;
+  }
+  RCCLCHK(ctx, grc);
   if (prof) {
     HIPCHK(ctx, hipEventRecord(ctx->cev[ctx->cev_used + 1], ctx->stream));
     ctx->cev_used += 2;

@@ -15,7 +15,11 @@
 //   closure  c_v[l] = the largest watermark such that v reaches every (l, y < c_v[l]).  c_v = cover_v  v  max over l' of
 //            P[l'][c_v[l']], P[l'][w] = prefix max of the closures of column l' below w: a monotone fixed point; every
 //            round doubles the hop distance covered, rounds alternate a prefix-max scan per column with a gather per
-//            vertex until nothing moves (2 - 4 rounds on what K5 commits: a tick's closures saturate after two hops)
+//            vertex until nothing moves (5 - 6 rounds on what K5 commits at 2^20 commands).  Round 5: the loop lives on the
+//            device -- DG_ROUNDS rounds are enqueued at once, a round whose predecessor moved nothing returns at its first
+//            instruction (pre[] then belongs to the final closures), the gather of round r also folds the tile maxima
+//            round r + 1 scans from (k_dg_tilemax runs for the first round only), and everything behind the loop reads
+//            the number of executables from the device: ONE host read per call (round 4: one per round + two)
 //   cycles   v lies on a cycle iff the closure of one of its DIRECT dependencies covers x in column L
 //   SCCs     two vertices on cycles are in one component iff their closures are equal (u in reach(v) gives c_u <= c_v, and
 //            both ways gives equality; conversely equal closures of two cyclic vertices contain both)
@@ -28,6 +32,8 @@
 #pragma once
 
 constexpr int DG_TILE = 2048;  // vertices per scan tile
+constexpr int DG_ROUNDS = 8;   // closure rounds enqueued per chunk (a round doubles the hops covered)
+constexpr int DG_SUB = DG_TILE / 256;  // workgroups of k_dg_relax per tile: each leaves its own row of maxima (no atomics)
 
 template <int N> struct DgRow { static constexpr int NP = N <= 4 ? 4 : 8; };
 
@@ -43,11 +49,14 @@ struct DgArgs {
   int32_t* direct;                  // [m][NP] direct dependency covers (own column: max(watermark, values end))
   int32_t* clo;                     // [m][NP] closure
   int32_t* pre;                     // [m][NP] prefix max of clo within the column
-  int32_t* tmax;                    // [ntiles][NP]
+  int32_t* tmax;                    // [ntiles][DG_SUB][NP]: what the next round's scan carries in from the tiles before it (one row
+                                    // per workgroup of k_dg_relax; k_dg_tilemax fills row 0 of a tile for the first round)
+  int32_t* tstarts;                 // [out tiles] component starts per tile of the sorted order
   uint2* pairs;                     // [m] (sort key, vertex)
   uint2* pairs2;
   uint32_t* key32;                  // [m] the main sort key of a vertex (pairs carry the closure's hash first)
-  int32_t* ctl;                     // [0] changed, [1] malformed, [2] needs the host path, [3] executables, [4] components
+  int32_t* ctl;                     // [1] malformed, [2] needs the host path, [3] executables, [4] components,
+                                    // [8 + k] something moved in round k of the chunk of rounds being enqueued
   volatile int32_t* host;           // page-locked mirror of ctl (8 ints) + [7] = seq
   int32_t seq;
   int32_t* order;                   // [m] message indices in execution order
@@ -64,7 +73,6 @@ template <int N>
 __global__ void __launch_bounds__(256) k_dg_scatter(const DgArgs a) {
   constexpr int NP = DgRow<N>::NP;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) a.ctl[0] = 0, a.ctl[3] = 0, a.ctl[4] = 0;
   if (i >= a.m) return;
   const int L = a.leader[i], x = a.number[i];
   const int v = (L >= 0 && L < N) ? dg_vertex(a, L, x) : -1;
@@ -123,15 +131,19 @@ __global__ void __launch_bounds__(256) k_dg_tilemax(const DgArgs a) {
     if (lane == 0) sh[w][l] = tot;
   }
   __syncthreads();
-  if (threadIdx.x < NP) a.tmax[(size_t)blockIdx.x * NP + threadIdx.x] = imax(imax(sh[0][threadIdx.x], sh[1][threadIdx.x]), imax(sh[2][threadIdx.x], sh[3][threadIdx.x]));
+  if (threadIdx.x < NP) a.tmax[(size_t)blockIdx.x * DG_SUB * NP + threadIdx.x] = imax(imax(sh[0][threadIdx.x], sh[1][threadIdx.x]), imax(sh[2][threadIdx.x], sh[3][threadIdx.x]));
+  else if (threadIdx.x < DG_SUB * NP) a.tmax[(size_t)blockIdx.x * DG_SUB * NP + threadIdx.x] = 0;
 }
 
 // pre[v] = max of the closures of the column's vertices up to and including v
+// r = the round (absolute: the tile maxima's half), k = its number within the chunk enqueued at once
 template <int N>
-__global__ void __launch_bounds__(256) k_dg_prefix(const DgArgs a) {
+__global__ void __launch_bounds__(256) k_dg_prefix(const DgArgs a, int r, int k) {
   constexpr int NP = DgRow<N>::NP;
   __shared__ int carry[NP];
   __shared__ int wtot[4][NP];
+  if (k > 1 && a.ctl[8 + k - 1] == 0) return;  // the round before moved nothing: pre[] is final
+  (void)r;
   int col = 0;
   while (col + 1 < N && (int)blockIdx.x >= a.tile_base[col + 1]) ++col;
   const int t = blockIdx.x - a.tile_base[col];
@@ -141,10 +153,13 @@ __global__ void __launch_bounds__(256) k_dg_prefix(const DgArgs a) {
     int mx[NP];
 #pragma unroll
     for (int l = 0; l < NP; ++l) mx[l] = 0;
-    for (int j = lane; j < t; j += 64) {
-      const int32_t* tm = a.tmax + (size_t)(a.tile_base[col] + j) * NP;
+    for (int j = lane; j < t * DG_SUB; j += 64) {
+      const int4* tm = reinterpret_cast<const int4*>(a.tmax + ((size_t)a.tile_base[col] * DG_SUB + j) * NP);
 #pragma unroll
-      for (int l = 0; l < NP; ++l) mx[l] = imax(mx[l], tm[l]);
+      for (int q = 0; q < NP / 4; ++q) {
+        const int4 x = tm[q];
+        mx[4 * q] = imax(mx[4 * q], x.x), mx[4 * q + 1] = imax(mx[4 * q + 1], x.y), mx[4 * q + 2] = imax(mx[4 * q + 2], x.z), mx[4 * q + 3] = imax(mx[4 * q + 3], x.w);
+      }
     }
 #pragma unroll
     for (int l = 0; l < NP; ++l) {
@@ -194,52 +209,72 @@ __global__ void __launch_bounds__(256) k_dg_prefix(const DgArgs a) {
   }
 }
 
-// c_v = c_v  v  max over l of pre[column l][c_v[l] - 1]
+// c_v = c_v  v  max over l of pre[column l][c_v[l] - 1]; and what the next round's scan carries from tile to tile: the
+// grid is laid over the scan tiles (DG_SUB workgroups of 256 vertices per tile), so a workgroup's maxima are ONE row of
+// tmax written with plain stores.  (A first version folded them with atomicMax from vertex-order workgroups: 160 atomics
+// on each tile's 32-byte line cost 55 us per launch, profiles/r05_depgraph_dev.md.)
 template <int N>
-__global__ void __launch_bounds__(256) k_dg_relax(const DgArgs a) {
+__global__ void __launch_bounds__(256) k_dg_relax(const DgArgs a, int r, int k) {
   constexpr int NP = DgRow<N>::NP;
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= a.m) return;
-  if (a.msg_of[v] < 0) {  // an instance of the column that was not handed in: the columns are not dense
-    a.ctl[1] = 1;
-    return;
-  }
+  (void)r;
+  __shared__ int sh[4][NP];
+  if (k > 1 && a.ctl[8 + k - 1] == 0) return;
+  const int tile = blockIdx.x / DG_SUB, sub = blockIdx.x % DG_SUB;
+  int col = 0;
+  while (col + 1 < N && tile >= a.tile_base[col + 1]) ++col;
+  const int j = (tile - a.tile_base[col]) * DG_TILE + sub * 256 + threadIdx.x;
+  const bool live = j < a.count[col];
+  const int v = a.base[col] + j;
   int c[NP], o[NP];
-  {
-    const int4* cp = reinterpret_cast<const int4*>(a.clo + (size_t)v * NP);
 #pragma unroll
-    for (int q = 0; q < NP / 4; ++q) {
-      const int4 x = cp[q];
-      c[4 * q] = o[4 * q] = x.x, c[4 * q + 1] = o[4 * q + 1] = x.y, c[4 * q + 2] = o[4 * q + 2] = x.z, c[4 * q + 3] = o[4 * q + 3] = x.w;
-    }
-  }
-#pragma unroll
-  for (int l = 0; l < N; ++l) {
-    const int j = min(o[l], a.first[l] + a.count[l]) - a.first[l] - 1;  // the last vertex of column l below the watermark
-    if (j >= 0) {
-      const int4* pp = reinterpret_cast<const int4*>(a.pre + (size_t)(a.base[l] + j) * NP);
+  for (int l = 0; l < NP; ++l) c[l] = o[l] = 0;
+  bool moved = false;
+  if (live) {
+    if (a.msg_of[v] < 0) a.ctl[1] = 1;  // an instance of the column that was not handed in: the columns are not dense
+    {
+      const int4* cp = reinterpret_cast<const int4*>(a.clo + (size_t)v * NP);
 #pragma unroll
       for (int q = 0; q < NP / 4; ++q) {
-        const int4 x = pp[q];
-        c[4 * q] = imax(c[4 * q], x.x), c[4 * q + 1] = imax(c[4 * q + 1], x.y), c[4 * q + 2] = imax(c[4 * q + 2], x.z), c[4 * q + 3] = imax(c[4 * q + 3], x.w);
+        const int4 x = cp[q];
+        c[4 * q] = o[4 * q] = x.x, c[4 * q + 1] = o[4 * q + 1] = x.y, c[4 * q + 2] = o[4 * q + 2] = x.z, c[4 * q + 3] = o[4 * q + 3] = x.w;
       }
     }
-  }
-  bool moved = false;
 #pragma unroll
-  for (int l = 0; l < N; ++l) moved = moved || c[l] != o[l];
-  if (moved) {
-    int4* cp = reinterpret_cast<int4*>(a.clo + (size_t)v * NP);
+    for (int l = 0; l < N; ++l) {
+      const int jj = min(o[l], a.first[l] + a.count[l]) - a.first[l] - 1;  // the last vertex of column l below the watermark
+      if (jj >= 0) {
+        const int4* pp = reinterpret_cast<const int4*>(a.pre + (size_t)(a.base[l] + jj) * NP);
 #pragma unroll
-    for (int q = 0; q < NP / 4; ++q) cp[q] = make_int4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+        for (int q = 0; q < NP / 4; ++q) {
+          const int4 x = pp[q];
+          c[4 * q] = imax(c[4 * q], x.x), c[4 * q + 1] = imax(c[4 * q + 1], x.y), c[4 * q + 2] = imax(c[4 * q + 2], x.z), c[4 * q + 3] = imax(c[4 * q + 3], x.w);
+        }
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < N; ++l) moved = moved || c[l] != o[l];
+    if (moved) {
+      int4* cp = reinterpret_cast<int4*>(a.clo + (size_t)v * NP);
+#pragma unroll
+      for (int q = 0; q < NP / 4; ++q) cp[q] = make_int4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+    }
   }
-  if (__any(moved) && (threadIdx.x & 63) == 0 && a.ctl[0] != a.seq) a.ctl[0] = a.seq;
+  if (__any(moved) && (threadIdx.x & 63) == 0 && a.ctl[8 + k] == 0) a.ctl[8 + k] = 1;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int l = 0; l < NP; ++l) {
+    const int tot = __builtin_amdgcn_readlane(wave_incl_max(c[l]), 63);
+    if (lane == 0) sh[w][l] = tot;
+  }
+  __syncthreads();
+  if (threadIdx.x < NP)
+    a.tmax[(size_t)blockIdx.x * NP + threadIdx.x] = imax(imax(sh[0][threadIdx.x], sh[1][threadIdx.x]), imax(sh[2][threadIdx.x], sh[3][threadIdx.x]));
 }
 
 // publishes the control words of the round to the host (one workgroup, after the round's kernels)
 __global__ void k_dg_publish(const DgArgs a, int round) {
   (void)round;
-  if (threadIdx.x < 7) a.host[threadIdx.x] = a.ctl[threadIdx.x];
+  if (threadIdx.x < 7) a.host[threadIdx.x] = threadIdx.x == 5 ? a.ctl[8 + DG_ROUNDS] : a.ctl[threadIdx.x];  // [5]: the chunk's last round still moved
   __threadfence_system();
   if (threadIdx.x == 0) a.host[7] = a.seq;  // (call, round): what the host waits for
 }
@@ -289,15 +324,19 @@ __global__ void __launch_bounds__(256) k_dg_keys(const DgArgs a) {
     eligible = eligible && c[l] <= a.first[l] + a.count[l];
     sum += (uint32_t)max(0, c[l] - a.first[l]);
   }
-  // on a cycle iff the closure of a direct dependency covers x in column L
+  // on a cycle iff the closure of a direct dependency covers x in column L.  Only a vertex that can execute is asked: one
+  // that is not committed has 0x3fffffff in every column of d[] and would walk the rest of its column, load by load
+  // (O(m^2) per tick with a few percent of the tick uncommitted)
   int back = 0;
+  if (eligible) {
 #pragma unroll
-  for (int l = 0; l < N; ++l) {
-    const int bound = l == L ? min(d[l], x) : d[l];  // own column: the prefix below x here, the explicit ids below
-    const int j = min(bound, a.first[l] + a.count[l]) - a.first[l] - 1;
-    if (j >= 0) back = imax(back, a.pre[(size_t)(a.base[l] + j) * NP + L]);
+    for (int l = 0; l < N; ++l) {
+      const int bound = l == L ? min(d[l], x) : d[l];  // own column: the prefix below x here, the explicit ids below
+      const int j = min(bound, a.first[l] + a.count[l]) - a.first[l] - 1;
+      if (j >= 0) back = imax(back, a.pre[(size_t)(a.base[l] + j) * NP + L]);
+    }
+    for (int y = x + 1; y < min(d[L], a.first[L] + a.count[L]); ++y) back = imax(back, a.clo[(size_t)(a.base[L] + y - a.first[L]) * NP + L]);
   }
-  for (int y = x + 1; y < min(d[L], a.first[L] + a.count[L]); ++y) back = imax(back, a.clo[(size_t)(a.base[L] + y - a.first[L]) * NP + L]);
   const uint32_t kind = back > x ? 0u : (c[L] > x ? 1u : 2u);
   const uint32_t key = eligible ? ((sum << 2) | kind) : 0xffffffffu;
   if (eligible && sum >= (1u << 29)) a.ctl[2] = 1;
@@ -331,7 +370,7 @@ __device__ __forceinline__ int dg_cmp_clo(const DgArgs& a, uint32_t u, uint32_t 
 // cyclic neighbours with one key belong together iff their closures are equal.  Two DIFFERENT closures with one key and
 // one hash would leave their members interleaved: that is seen here and sends the tick the host's way.
 template <int N>
-__device__ __forceinline__ uint32_t dg_starts(const DgArgs& a, int p, int executables) {
+__device__ __forceinline__ uint32_t dg_starts(const DgArgs& a, int p, int executables) {  // executables = ctl[3], read by the caller
   constexpr int NP = DgRow<N>::NP;
   if (p >= executables) return 0u;
   const uint2 e = a.pairs[p];
@@ -344,19 +383,20 @@ __device__ __forceinline__ uint32_t dg_starts(const DgArgs& a, int p, int execut
 }
 
 template <int N>
-__global__ void __launch_bounds__(256) k_dg_emit(const DgArgs a, int executables) {
+__global__ void __launch_bounds__(256) k_dg_emit(const DgArgs a) {
   __shared__ uint32_t sh[8];
   __shared__ uint32_t before_tile;
+  const int executables = a.ctl[3];
   auto starts = [&](int p) -> uint32_t { return dg_starts<N>(a, p, executables); };
   const int t0 = blockIdx.x * DG_TILE;
   // flags of my tile
   uint32_t mine[DG_TILE / 256], total = 0;
 #pragma unroll
   for (int j = 0; j < DG_TILE / 256; ++j) mine[j] = starts(t0 + j * 256 + threadIdx.x), total += mine[j];
-  // the components that start before my tile were counted into tmax[tile] by k_dg_count_starts
+  // the components that start before my tile were counted into tstarts[tile] by k_dg_count_starts
   if (threadIdx.x == 0) {
     uint32_t s = 0;
-    for (int t = 0; t < (int)blockIdx.x; ++t) s += (uint32_t)a.tmax[t];
+    for (int t = 0; t < (int)blockIdx.x; ++t) s += (uint32_t)a.tstarts[t];
     before_tile = s;
   }
   __syncthreads();
@@ -379,8 +419,9 @@ __global__ void __launch_bounds__(256) k_dg_emit(const DgArgs a, int executables
 }
 
 template <int N>
-__global__ void __launch_bounds__(256) k_dg_count_starts(const DgArgs a, int executables) {
+__global__ void __launch_bounds__(256) k_dg_count_starts(const DgArgs a) {
   __shared__ uint32_t sh[8];
+  const int executables = a.ctl[3];
   const int t0 = blockIdx.x * DG_TILE;
   uint32_t total = 0;
   for (int j = 0; j < DG_TILE / 256; ++j) {
@@ -388,5 +429,5 @@ __global__ void __launch_bounds__(256) k_dg_count_starts(const DgArgs a, int exe
     total += dg_starts<N>(a, p, executables);
   }
   const uint32_t ex = block_excl_sum(total, sh);
-  if (threadIdx.x == 255) a.tmax[blockIdx.x] = (int32_t)(ex + total);
+  if (threadIdx.x == 255) a.tstarts[blockIdx.x] = (int32_t)(ex + total);
 }

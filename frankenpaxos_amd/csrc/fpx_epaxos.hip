@@ -1110,6 +1110,37 @@ __global__ void __launch_bounds__(256) k_cl_commit(const EpxState st, const ClBa
   if (b.committed) b.committed[i] = done;
 }
 
+// Replica.handleCommit (:1567-1575) -> commit (:815-830) at replica r for message i: one thread per (i, r).  A Commit is
+// final: no ballot is looked at, whatever entry the replica held is replaced (:826-827), the conflict index learns the
+// command (:828).
+struct LcBatch {
+  int m;
+  const int32_t* leader;
+  const int32_t* number;
+  const int32_t* triple;
+  const int32_t* key;
+  const uint8_t* is_set;
+  const int32_t* deps;      // [m][n] or null: the triple is known by its id alone
+  const int32_t* deps_end;  // [m] or null
+  const uint8_t* target;
+};
+__global__ void __launch_bounds__(256) k_cl_learn_commit(const EpxState st, const LcBatch b) {
+  const int n = st.n;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)b.m * n) return;
+  const int r = (int)(t / b.m), i = (int)(t % b.m);
+  if (!((b.target[i] >> r) & 1u)) return;
+  const size_t c = ((size_t)r * n + b.leader[i]) * st.num_instances + b.number[i];
+  st.cl_status[c] = CL_COMMITTED, st.cl_ballot[c] = -1, st.cl_vote[c] = -1, st.cl_triple[c] = b.triple[i];
+  if (b.deps) {
+    for (int l = 0; l < n; ++l) st.cl_deps[c * n + l] = b.deps[(size_t)i * n + l];
+    st.cl_dend[c] = b.deps_end ? b.deps_end[i] : 0;
+  } else {
+    deps_by_id(st, c);
+  }
+  index_put(st, r, b.key[i], b.is_set[i], b.leader[i], b.number[i]);
+}
+
 // ---- K8: Replica.handlePrepareOk (Replica.scala:1759-1884), the recovering replica's decision -- one thread per instance
 struct RcBatch {
   int m, as_intended;
@@ -1575,15 +1606,16 @@ int dg_execute(fpx_epx* e, int m, const int32_t* d_leader, const int32_t* d_numb
   if ((rc = grow(e, &e->dg_direct, (size_t)m * NP * 4))) return rc;
   if ((rc = grow(e, &e->dg_clo, (size_t)m * NP * 4))) return rc;
   if ((rc = grow(e, &e->dg_pre, (size_t)m * NP * 4))) return rc;
-  if ((rc = grow(e, &e->dg_tmax, (size_t)std::max(a.ntiles * NP, out_tiles) * 4 + 64))) return rc;
+  if ((rc = grow(e, &e->dg_tmax, ((size_t)DG_SUB * a.ntiles * NP + out_tiles) * 4 + 64))) return rc;
   if ((rc = grow(e, &e->dg_pairs, (size_t)m * 8))) return rc;
   if ((rc = grow(e, &e->dg_pairs2, (size_t)m * 8))) return rc;
   if ((rc = grow(e, &e->dg_key, (size_t)m * 4))) return rc;
-  if ((rc = grow(e, &e->dg_ctl, 64))) return rc;
+  if ((rc = grow(e, &e->dg_ctl, 256))) return rc;
   if (!e->kp_flag_dev) return FPX_EHIP;
   a.leader = d_leader, a.number = d_number, a.packed = d_packed, a.mask = d_mask;
   a.msg_of = (int32_t*)e->dg_msg.p, a.direct = (int32_t*)e->dg_direct.p, a.clo = (int32_t*)e->dg_clo.p, a.pre = (int32_t*)e->dg_pre.p;
-  a.tmax = (int32_t*)e->dg_tmax.p, a.pairs = (uint2*)e->dg_pairs.p, a.pairs2 = (uint2*)e->dg_pairs2.p, a.ctl = (int32_t*)e->dg_ctl.p;
+  a.tmax = (int32_t*)e->dg_tmax.p, a.tstarts = a.tmax + (size_t)DG_SUB * a.ntiles * NP;
+  a.pairs = (uint2*)e->dg_pairs.p, a.pairs2 = (uint2*)e->dg_pairs2.p, a.ctl = (int32_t*)e->dg_ctl.p;
   a.key32 = (uint32_t*)e->dg_key.p;
   a.host = reinterpret_cast<volatile int32_t*>(e->kp_flag_dev + 8);  // the second half of the page-locked line
   a.order = d_order, a.comp = d_comp;
@@ -1603,45 +1635,42 @@ int dg_execute(fpx_epx* e, int m, const int32_t* d_leader, const int32_t* d_numb
     return host[7] == want ? FPX_OK : FPX_EHIP;
   };
   EHIP(e, hipMemsetAsync(a.msg_of, 0xFF, (size_t)m * 4, e->stream));
-  EHIP(e, hipMemsetAsync(a.ctl, 0, 32, e->stream));
+  EHIP(e, hipMemsetAsync(a.ctl, 0, 256, e->stream));
   const int grid = (m + 255) / 256;
   hipLaunchKernelGGL((k_dg_scatter<N>), dim3(grid), dim3(256), 0, e->stream, a);
-  int round = 0;
-  for (;;) {
-    ++round;
-    a.seq = call * 64 + round;
-    hipLaunchKernelGGL((k_dg_tilemax<N>), dim3(a.ntiles), dim3(256), 0, e->stream, a);
-    hipLaunchKernelGGL((k_dg_prefix<N>), dim3(a.ntiles), dim3(256), 0, e->stream, a);
-    hipLaunchKernelGGL((k_dg_relax<N>), dim3(grid), dim3(256), 0, e->stream, a);
-    hipLaunchKernelGGL(k_dg_publish, dim3(1), dim3(64), 0, e->stream, a, round);
-    if ((rc = wait_for(round))) return rc;
+  // round 1 scans from the direct covers' tile maxima; every later round from what the gather before it folded
+  hipLaunchKernelGGL((k_dg_tilemax<N>), dim3(a.ntiles), dim3(256), 0, e->stream, a);
+  int round = 0, executables = 0;
+  for (int chunk = 0;; ++chunk) {
+    // DG_ROUNDS closure rounds at once: a round returns at its first instruction when the one before it moved nothing,
+    // and everything behind them is enqueued right away -- one host read per chunk, and one chunk covers 2^8 hops
+    if (chunk > 0) EHIP(e, hipMemsetAsync(a.ctl + 8, 0, (DG_ROUNDS + 1) * 4, e->stream));
+    for (int k = 1; k <= DG_ROUNDS; ++k) {
+      ++round;
+      hipLaunchKernelGGL((k_dg_prefix<N>), dim3(a.ntiles), dim3(256), 0, e->stream, a, round, k);
+      hipLaunchKernelGGL((k_dg_relax<N>), dim3(a.ntiles * DG_SUB), dim3(256), 0, e->stream, a, round, k);
+    }
+    EHIP(e, hipMemsetAsync(a.ctl + 3, 0, 8, e->stream));
+    hipLaunchKernelGGL((k_dg_keys<N>), dim3(grid), dim3(256), 0, e->stream, a);
+    // least significant first: the closures' hashes, then (stable) the closure sums and kinds
+    uint2* sorted = radix_sort_pairs(e, 1, m, DG_HASH_BITS, a.pairs, a.pairs2, nullptr, &rc, nullptr, nullptr);
+    if (rc) return rc;
+    if (sorted != a.pairs) std::swap(a.pairs, a.pairs2);
+    hipLaunchKernelGGL(k_dg_rekey, dim3(grid), dim3(256), 0, e->stream, a);
+    sorted = radix_sort_pairs(e, 1, m, 24, a.pairs, a.pairs2, nullptr, &rc, nullptr, nullptr);
+    if (rc) return rc;
+    if (sorted != a.pairs) std::swap(a.pairs, a.pairs2);
+    // (the number of executables stays on the device: both kernels cover all m positions and leave at once beyond it)
+    hipLaunchKernelGGL((k_dg_count_starts<N>), dim3(out_tiles), dim3(256), 0, e->stream, a);
+    hipLaunchKernelGGL((k_dg_emit<N>), dim3(out_tiles), dim3(256), 0, e->stream, a);
+    a.seq = call * 64 + (chunk & 31) + 1;
+    hipLaunchKernelGGL(k_dg_publish, dim3(1), dim3(64), 0, e->stream, a, chunk);
+    if ((rc = wait_for((chunk & 31) + 1))) return rc;
     if (host[1] != 0) return FPX_EINVAL;        // an instance outside its column, twice, or missing
-    if (host[0] != a.seq) break;                // nothing moved: pre[] belongs to the final closures
+    executables = host[3];
+    if (host[5] == 0) break;                    // the chunk's last round moved nothing (or never ran): converged
     if (round >= 48) return FPX_EHIP;           // (a round doubles the hops covered: 2^48 hops do not exist)
   }
-  hipLaunchKernelGGL((k_dg_keys<N>), dim3(grid), dim3(256), 0, e->stream, a);
-  // least significant first: the closures' hashes, then (stable) the closure sums and kinds
-  uint2* sorted = radix_sort_pairs(e, 1, m, DG_HASH_BITS, a.pairs, a.pairs2, nullptr, &rc, nullptr, nullptr);
-  if (rc) return rc;
-  if (sorted != a.pairs) std::swap(a.pairs, a.pairs2);
-  hipLaunchKernelGGL(k_dg_rekey, dim3(grid), dim3(256), 0, e->stream, a);
-  sorted = radix_sort_pairs(e, 1, m, 24, a.pairs, a.pairs2, nullptr, &rc, nullptr, nullptr);
-  if (rc) return rc;
-  if (sorted != a.pairs) std::swap(a.pairs, a.pairs2);
-  ++round;
-  a.seq = call * 64 + round;
-  hipLaunchKernelGGL(k_dg_publish, dim3(1), dim3(64), 0, e->stream, a, round);   // the number of executables sizes what follows
-  if ((rc = wait_for(round))) return rc;
-  const int executables = host[3];
-  if (executables > 0) {
-    const int et = (executables + DG_TILE - 1) / DG_TILE;
-    hipLaunchKernelGGL((k_dg_count_starts<N>), dim3(et), dim3(256), 0, e->stream, a, executables);
-    hipLaunchKernelGGL((k_dg_emit<N>), dim3(et), dim3(256), 0, e->stream, a, executables);
-  }
-  ++round;
-  a.seq = call * 64 + round;
-  hipLaunchKernelGGL(k_dg_publish, dim3(1), dim3(64), 0, e->stream, a, round);
-  if ((rc = wait_for(round))) return rc;
   if (nexec) *nexec = executables;
   if (ncomp) *ncomp = executables > 0 ? host[4] : 0;
   if (needs_host) *needs_host = host[2];
@@ -2031,6 +2060,55 @@ int32_t fpx_epx_prepare(fpx_epx* e, int32_t m, const int32_t* leader, const int3
                         int32_t* reply_triple) {
   return cl_run(e, 0, m, leader, number, ballot_ordering, ballot_replica, nullptr, nullptr, nullptr, target_mask, ok_bits,
                 nack_bits, commit_bits, nack_ballot, nullptr, reply_status, reply_vote_ballot, reply_triple);
+}
+
+int32_t fpx_epx_handle_commit(fpx_epx* e, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* triple_id,
+                              const int32_t* key, const uint8_t* is_set, const int32_t* deps, const int32_t* deps_values_end,
+                              const uint8_t* target_mask) {
+  if (!e || m < 0) return FPX_EINVAL;
+  EpxDeviceGuard _dg(e->cfg.device);
+  if (e->st.num_instances <= 0) return FPX_EINVAL;
+  if (m == 0) return FPX_OK;
+  if (!leader || !number || !triple_id || !key || !is_set || !target_mask) return FPX_EINVAL;
+  const int n = e->st.n;
+  for (int i = 0; i < m; ++i) {  // host arrays: checked here, nothing is applied on a bad one
+    if (leader[i] < 0 || leader[i] >= n || number[i] < 0 || number[i] >= e->st.num_instances || key[i] < -1 || key[i] >= e->st.num_keys ||
+        (target_mask[i] >> n) != 0)
+      return FPX_EINVAL;
+    if (deps) {
+      for (int l = 0; l < n; ++l)
+        if (deps[(size_t)i * n + l] < 0) return FPX_EINVAL;
+      const int end = deps_values_end ? deps_values_end[i] : 0;
+      if (end != 0 && (end <= number[i] + 1 || deps[(size_t)i * n + leader[i]] > number[i])) return FPX_EINVAL;
+    }
+  }
+  const size_t mp = ((size_t)m + 63) & ~(size_t)63;
+  int rc;
+  if ((rc = grow(e, &e->cl, mp * 4 * 5 + mp * 2 + (size_t)m * n * 4 + 1024))) return rc;
+  char* p = (char*)e->cl.p;
+  auto take = [&](size_t sz) { char* q = p; p += (sz + 63) & ~(size_t)63; return q; };
+  int32_t *d_leader = (int32_t*)take(mp * 4), *d_number = (int32_t*)take(mp * 4), *d_tr = (int32_t*)take(mp * 4);
+  int32_t *d_key = (int32_t*)take(mp * 4), *d_end = (int32_t*)take(mp * 4);
+  uint8_t *d_set = (uint8_t*)take(mp), *d_tgt = (uint8_t*)take(mp);
+  int32_t* d_deps = (int32_t*)take((size_t)m * n * 4);
+  EHIP(e, hipMemcpyAsync(d_leader, leader, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+  EHIP(e, hipMemcpyAsync(d_number, number, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+  EHIP(e, hipMemcpyAsync(d_tr, triple_id, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+  EHIP(e, hipMemcpyAsync(d_key, key, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+  EHIP(e, hipMemcpyAsync(d_set, is_set, (size_t)m, hipMemcpyHostToDevice, e->stream));
+  EHIP(e, hipMemcpyAsync(d_tgt, target_mask, (size_t)m, hipMemcpyHostToDevice, e->stream));
+  if (deps) EHIP(e, hipMemcpyAsync(d_deps, deps, (size_t)m * n * 4, hipMemcpyHostToDevice, e->stream));
+  if (deps && deps_values_end) EHIP(e, hipMemcpyAsync(d_end, deps_values_end, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+  LcBatch b;
+  b.m = m, b.leader = d_leader, b.number = d_number, b.triple = d_tr, b.key = d_key, b.is_set = d_set;
+  b.deps = deps ? d_deps : nullptr, b.deps_end = (deps && deps_values_end) ? d_end : nullptr, b.target = d_tgt;
+  hipLaunchKernelGGL(k_cl_learn_commit, dim3((unsigned)(((long long)m * n + 255) / 256)), dim3(256), 0, e->stream, e->st, b);
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) {
+    e->last_hip = (int)le;
+    return FPX_EHIP;
+  }
+  return fpx_epx_sync(e);
 }
 
 int32_t fpx_epx_handle_prepare_oks(fpx_epx* e, int32_t m, const int32_t* leader, const int32_t* number,

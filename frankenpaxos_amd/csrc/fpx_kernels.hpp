@@ -1480,6 +1480,26 @@ __global__ void __launch_bounds__(256) k_gather_acceptor(const Geom g, const Sta
   bl[s] = (mine && st.ballot) ? st.ballot[c] : -1;
 }
 
+// Acceptor.maxVotedSlot restricted to a window of the log (the read path, multipaxos/Acceptor.scala:222-254): the largest
+// slot of [first, first + count) of the acceptor's group in which it holds a vote, -1 if none.  The scalar max_voted is
+// that maximum over ALL rows; a caller that maps an unbounded log onto the rows (row = slot % S, jni/Native.scala) needs
+// it over the rows of one lap.  One strided column read; off the steady path.
+__global__ void __launch_bounds__(256) k_max_voted_in(const Geom g, const State st, int group, int replica, int first, int count,
+                                                      int32_t* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int best = -1;
+  if (i < count) {
+    const int s = first + i;
+    if (group_of_slot(g, s) == group && st.vote_round[(size_t)phys_slot(g, s) * g.VS + replica] != -1) best = s;
+  }
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) {
+    const int o = __shfl_xor(best, k);
+    best = o > best ? o : best;
+  }
+  if ((threadIdx.x & 63) == 0 && best >= 0) atomicMax(out, best);
+}
+
 // ------------------------------------------------------------------------------------------------
 // f1: the replica's log.  Replica.handleChosen (multipaxos/Replica.scala:572-590): a slot that is
 // already in the log is ignored, otherwise log.put + numChosen += 1; executeLog (:394-404) advances

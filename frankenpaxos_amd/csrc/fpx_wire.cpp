@@ -275,6 +275,31 @@ int64_t fpx_wire_encode_leader_nack(uint8_t* out, int64_t cap, int32_t round) {
   return wrapped(out, cap, 6, i32_len(round), [&](Writer& w) { w.i32(1, round); });
 }
 
+int64_t fpx_wire_encode_client_max_slot_reply(uint8_t* out, int64_t cap, const uint8_t* command_id, int32_t command_id_len,
+                                              int32_t group_index, int32_t acceptor_index, int32_t slot) {
+  if (command_id_len < 0 || (command_id_len > 0 && !command_id)) return 0;
+  const int64_t inner = 1 + varint_len((uint64_t)command_id_len) + command_id_len + i32_len(group_index) + i32_len(acceptor_index) + i32_len(slot);
+  return wrapped(out, cap, 4, inner, [&](Writer& w) {
+    w.tag(1, 2);
+    w.varint((uint64_t)command_id_len);
+    w.bytes(command_id, command_id_len);
+    w.i32(2, group_index);
+    w.i32(3, acceptor_index);
+    w.i32(4, slot);
+  });
+}
+
+int64_t fpx_wire_encode_read_batcher_batch_max_slot_reply(uint8_t* out, int64_t cap, int32_t read_batcher_index,
+                                                          int32_t read_batcher_id, int32_t acceptor_index, int32_t slot) {
+  const int64_t inner = i32_len(read_batcher_index) + i32_len(read_batcher_id) + i32_len(acceptor_index) + i32_len(slot);
+  return wrapped(out, cap, 4, inner, [&](Writer& w) {
+    w.i32(1, read_batcher_index);
+    w.i32(2, read_batcher_id);
+    w.i32(3, acceptor_index);
+    w.i32(4, slot);
+  });
+}
+
 int64_t fpx_wire_encode_leader_phase1b(uint8_t* out, int64_t cap, int32_t group_index, int32_t acceptor_index,
                                        int32_t round, int32_t n_info, const int32_t* slot, const int32_t* vote_round,
                                        const uint8_t* values, const int64_t* value_off, const int32_t* value_len,

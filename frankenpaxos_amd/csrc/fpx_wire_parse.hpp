@@ -143,7 +143,8 @@ FPX_HD inline bool parse_proxy_leader_inbound(const uint8_t* base, Reader r, Msg
   return r.ok;
 }
 
-// AcceptorInbound { oneof request { Phase1a phase1a = 1; Phase2a phase2a = 2; MaxSlotRequest ...; } }   :293-300
+// AcceptorInbound { oneof request { Phase1a phase1a = 1; Phase2a phase2a = 2; MaxSlotRequest max_slot_request = 3;
+//                                   BatchMaxSlotRequest batch_max_slot_request = 4; } }   MultiPaxos.proto:550-562
 FPX_HD inline bool parse_acceptor_inbound(const uint8_t* base, Reader r, Msg* o) {
   while (r.more()) {
     const uint64_t tag = r.varint();
@@ -159,8 +160,45 @@ FPX_HD inline bool parse_acceptor_inbound(const uint8_t* base, Reader r, Msg* o)
       *o = Msg();
       o->kind = 1, o->slot = f.i[1], o->round = f.i[2];
       o->is_noop = f.value.is_noop, o->value_off = f.value.at - base, o->value_len = f.value.len;
+    } else if (field == 3 && wt == 2) {  // MaxSlotRequest { CommandId command_id = 1 }   MultiPaxos.proto:316-321
+      // (the linearizable read path, Acceptor.scala:222-237: the reply carries the CommandId back unchanged, so what the
+      // caller gets is WHERE the serialised CommandId lies -- value_off / value_len -- after a check of its required fields)
+      Reader m = r.sub();
+      if (!r.ok) return false;
+      bool have = false;
+      const uint8_t* at = nullptr;
+      int32_t len = -1;
+      while (m.more()) {
+        const uint64_t t2 = m.varint();
+        const uint32_t f2 = (uint32_t)(t2 >> 3), w2 = (uint32_t)(t2 & 7);
+        if (f2 == 1 && w2 == 2) {  // CommandId { bytes client_address = 1; int32 client_pseudonym = 2; int32 client_id = 3 }
+          Reader c = m.sub();
+          if (!m.ok) return false;
+          at = c.p, len = (int32_t)(c.end - c.p);
+          unsigned seen = 0;
+          while (c.more()) {
+            const uint64_t t3 = c.varint();
+            const uint32_t f3 = (uint32_t)(t3 >> 3), w3 = (uint32_t)(t3 & 7);
+            if (f3 == 1 && w3 == 2) (void)c.sub(), seen |= 2u;
+            else if ((f3 == 2 || f3 == 3) && w3 == 0) (void)c.varint(), seen |= 1u << f3;
+            else c.skip(w3);
+          }
+          if (!c.ok || seen != 0xeu) return false;
+          have = true;
+        } else {
+          m.skip(w2);
+        }
+      }
+      if (!m.ok || !have) return false;
+      *o = Msg();
+      o->kind = 10, o->value_off = at - base, o->value_len = len;
+    } else if (field == 4 && wt == 2) {  // BatchMaxSlotRequest { read_batcher_index = 1; read_batcher_id = 2 }   :333-339
+      Fields f;
+      if (!parse_flat(r.sub(), 0, &f) || !r.ok || (f.seen & 0x6) != 0x6) return false;
+      *o = Msg();
+      o->kind = 11, o->slot = f.i[1], o->round = f.i[2];  // slot = read_batcher_index, round = read_batcher_id
     } else {
-      r.skip(wt);  // MaxSlotRequest, BatchMaxSlotRequest: not this path's
+      r.skip(wt);
     }
   }
   return r.ok;

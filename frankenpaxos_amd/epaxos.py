@@ -125,6 +125,19 @@ class EPaxos:
                                    p(ok), p(nack), p(com), p(nb), p(done))
         return st, ok, nack, com, nb, done
 
+    def handle_commit(self, leader, number, triple_id, target_mask, key=None, is_set=None, deps=None, deps_values_end=None):
+        """Replica.handleCommit at the replicas of target_mask: CommittedEntry(triple) whatever was there, the conflict
+        index learns the command.  key None = Noops; deps None = the triple is known by its id alone.  -> status"""
+        a32 = lambda x: None if x is None else np.ascontiguousarray(x, dtype=np.int32)
+        leader, number, tr = a32(leader), a32(number), a32(triple_id)
+        m = len(leader)
+        tgt = np.ascontiguousarray(target_mask, dtype=np.uint8)
+        key = np.full(m, -1, np.int32) if key is None else a32(key)
+        is_set = np.zeros(m, np.uint8) if is_set is None else np.ascontiguousarray(is_set, dtype=np.uint8)
+        d, de = a32(deps), a32(deps_values_end)
+        p = lambda a: None if a is None else a.ctypes.data
+        return self.L.fpx_epx_handle_commit(self._h, m, p(leader), p(number), p(tr), p(key), p(is_set), p(d), p(de), p(tgt))
+
     def handle_preaccept(self, leader, number, ballot_ordering, ballot_replica, key, is_set, triple_id, deps_in,
                          deps_in_values_end, target_mask):
         """Replica.handlePreAccept in full at the replicas of target_mask (key -1 = Noop): (status, ok_bits,

@@ -11,7 +11,9 @@
 //   * `GpuAcceptor` stands at EVERY acceptor address (all instances share the engine): the Leader's Phase1a
 //     (multipaxos/Leader.scala:231, 410-420) is answered with the Phase1b / Nack of
 //     multipaxos/Acceptor.scala:148-182, built from fpx_acceptor_phase1a + fpx_acceptor_phase1b_info, which
-//     is what the unchanged Leader.handlePhase1b (Leader.scala:504-577) needs to recover and re-propose.
+//     is what the unchanged Leader.handlePhase1b (Leader.scala:504-577) needs to recover and re-propose; and the
+//     read path -- MaxSlotRequest / BatchMaxSlotRequest are answered with Acceptor.maxVotedSlot (Acceptor.scala:
+//     222-254), which the engine follows per acceptor (GpuPhase2Engine.maxVotedSlot).
 package frankenpaxos.gpu
 
 import frankenpaxos.Actor
@@ -131,6 +133,8 @@ object Native {
   @native def acceptorPhase1bInfo(handle: Long, group: Int, replica: Int, chosenWatermark: Int, cap: Int,
                                   slot: Array[Int], voteRound: Array[Int], voteValue: Array[Int]): Int // count, < 0: -status
   @native def acceptorRound(handle: Long, group: Int, replica: Int): Int // Acceptor.round, < -1: -status - 1
+  // the largest row of [firstRow, firstRow + count) in which the acceptor holds a vote, -1: none, < -1: -status - 1
+  @native def acceptorMaxVotedIn(handle: Long, group: Int, replica: Int, firstRow: Int, count: Int): Int
   @native def recycleSlots(handle: Long, firstSlot: Int, count: Int): Int
   @native def proxyForget(handle: Long, firstSlot: Int, count: Int): Int
   // wire adapter, acceptor side: AcceptorInbound bytes -> fields = kind | slot | round | isNoop | valueLen |
@@ -265,6 +269,55 @@ class GpuPhase2Engine[Transport <: frankenpaxos.Transport[Transport]](
     moved
   }
 
+  // ---- the read path: Acceptor.maxVotedSlot (multipaxos/Acceptor.scala:104, 208) of every acceptor, in SLOTS.  The
+  // device keeps the scalar over rows, which stops being the maximum over slots once the window has wrapped; so the
+  // engine follows it here.  A message nobody Nacked was voted for by every acceptor it went to (Acceptor.scala:201-219):
+  // the tick's outputs say that much without any per-acceptor answer.  After a tick with a Nack the engine does not know
+  // which of the message's acceptors voted; the group is marked stale and the next read asks the device for the largest
+  // voted row of each lap of the window (fpx_acceptor_max_voted_in) -- exact again, and only after leader changes.
+  private val ctxGroups = if (config.flexible) 1 else numGroups
+  private val ctxReplicas = if (config.flexible) numGroups * perGroup else perGroup
+  private val maxVoted = Array.fill(ctxGroups, ctxReplicas)(-1)
+  private val maxVotedStale = Array.fill(ctxGroups)(false)
+  private def groupOfSlot(slot: Int): Int = if (config.flexible) 0 else slot % numGroups
+
+  // after a tick: `slot` = the messages' slots (log positions, not rows), masks = their targets (null: everyone)
+  private def noteVotes(slots: Array[Int], nackRound: Array[Int], masks: Array[Long]): Unit = {
+    // descending by slot: an acceptor's maximum is the first Nack-free message that reached it
+    val order = slots.indices.sortBy(i => -slots(i).toLong)
+    val covered = Array.fill(ctxGroups)(new java.util.BitSet(ctxReplicas))
+    for (i <- order) {
+      val g = groupOfSlot(slots(i))
+      if (nackRound(i) >= 0) maxVotedStale(g) = true
+      else if (covered(g).cardinality < ctxReplicas) {
+        for (a <- 0 until ctxReplicas
+             if !covered(g).get(a) && (masks == null || (masks(4 * i + (a >> 6)) & (1L << (a & 63))) != 0)) {
+          covered(g).set(a)
+          maxVoted(g)(a) = math.max(maxVoted(g)(a), slots(i))
+        }
+      }
+    }
+  }
+
+  // Acceptor.handleMaxSlotRequest / handleBatchMaxSlotRequest reply with this (Acceptor.scala:222-254)
+  def maxVotedSlot(groupIndex: Int, index: Int): Int = {
+    val g = ctxGroup(groupIndex); val a = ctxReplica(groupIndex, index)
+    if (maxVotedStale(g)) {
+      val r0 = row(base)
+      for (b <- 0 until ctxReplicas) {
+        // the older lap of the window lives in rows [r0, numSlots), the newer one in [0, r0)
+        val hi = if (r0 > 0) Native.acceptorMaxVotedIn(handle, g, b, 0, r0) else -1
+        val lo = if (hi < 0) Native.acceptorMaxVotedIn(handle, g, b, r0, numSlots - r0) else -1
+        if (hi < -1) Native.check(-hi - 1, logger)
+        if (lo < -1) Native.check(-lo - 1, logger)
+        val slot = if (hi >= 0) base + (numSlots - r0) + hi else if (lo >= 0) base + (lo - r0) else -1
+        maxVoted(g)(b) = math.max(maxVoted(g)(b), slot)
+      }
+      maxVotedStale(g) = false
+    }
+    maxVoted(g)(a)
+  }
+
   // ---- which acceptors a Phase2a goes to.  A window of f + 1 neighbouring acceptors: on groups of 253 .. 256 acceptors it
   // moves in steps of 16 (a 64-byte sector of the group's row in HBM) and does not wrap over the end of the row -- the
   // runs libfpx walks two rows per wavefront step (include/fpx.h, FPX_F_SCATTERED_TARGETS); on the small groups of an
@@ -305,6 +358,7 @@ class GpuPhase2Engine[Transport <: frankenpaxos.Transport[Transport]](
           m
         } else null
       if (n > 0) Native.check(Native.phase2Fused(handle, n, slot, round, value, masks, chosen, cr, cv, nr), logger)
+      noteVotes(now.map(_.slot).toArray, nr, masks)
       for (i <- 0 until n) {
         if (chosen(i) != 0) {
           chosenOut += Chosen(slot = now(i).slot, commandBatchOrNoop = valueOf(cv(i))) // ProxyLeader.scala:246-253
@@ -359,7 +413,11 @@ class GpuPhase2Engine[Transport <: frankenpaxos.Transport[Transport]](
                                         Array(intern(row(p.slot), p.commandBatchOrNoop)), target, votes, nacks, nr),
                  logger)
     if (nr(0) >= 0) Left(Nack(round = nr(0)))
-    else Right(Phase2b(groupIndex = groupIndex, acceptorIndex = index, slot = p.slot, round = p.round))
+    else {
+      val g = ctxGroup(groupIndex)
+      maxVoted(g)(a) = math.max(maxVoted(g)(a), p.slot)                               // Acceptor.scala:208
+      Right(Phase2b(groupIndex = groupIndex, acceptorIndex = index, slot = p.slot, round = p.round))
+    }
   }
 
   def close(): Unit = Native.check(Native.destroy(handle), logger)
@@ -442,8 +500,16 @@ class GpuAcceptor[Transport <: frankenpaxos.Transport[Transport]](
             chan[ProxyLeader[Transport]](src, ProxyLeader.serializer)
               .send(ProxyLeaderInbound().withPhase2B(phase2b))
         }
-      case AcceptorInbound.Request.MaxSlotRequest(_) | AcceptorInbound.Request.BatchMaxSlotRequest(_) =>
-        logger.fatal("GpuAcceptor does not serve the read path (MaxSlotRequest): outside the Phase-2 path.")
+      case AcceptorInbound.Request.MaxSlotRequest(r) =>                               // Acceptor.scala:222-237
+        chan[Client[Transport]](src, Client.serializer).send(
+          ClientInbound().withMaxSlotReply(
+            MaxSlotReply(commandId = r.commandId, groupIndex = groupIndex, acceptorIndex = index,
+                         slot = engine.maxVotedSlot(groupIndex, index))))
+      case AcceptorInbound.Request.BatchMaxSlotRequest(r) =>                          // Acceptor.scala:239-254
+        chan[ReadBatcher[Transport]](src, ReadBatcher.serializer).send(
+          ReadBatcherInbound().withBatchMaxSlotReply(
+            BatchMaxSlotReply(readBatcherIndex = r.readBatcherIndex, readBatcherId = r.readBatcherId,
+                              acceptorIndex = index, slot = engine.maxVotedSlot(groupIndex, index))))
       case AcceptorInbound.Request.Empty =>
         logger.fatal("Empty AcceptorInbound encountered.")
     }

@@ -666,6 +666,15 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_acceptorRound(JNIEnv* env, j
   return st == FPX_OK ? round : -(st + 1);
 }
 
+/* Acceptor.maxVotedSlot over the rows [firstRow, firstRow + count) of one acceptor (fpx_acceptor_max_voted_in; the read
+ * path, multipaxos/Acceptor.scala:222-254): >= -1, or -(status + 1) <= -2 on error. */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_acceptorMaxVotedIn(JNIEnv* env, jclass cls, jlong h, jint group, jint replica,
+                                                                       jint firstRow, jint count) {
+  int32_t row = -1;
+  int32_t st = fpx_acceptor_max_voted_in(CTX(h), group, replica, firstRow, count, &row);
+  return st == FPX_OK ? row : -(st + 1);
+}
+
 /* ---- calls in flight on page-locked batches (fpx_phase2_fused_submit / _wait): every buffer a direct ByteBuffer over
  * hostAlloc memory.  submit returns the ticket (>= 0) or -status */
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_phase2FusedSubmitDirect(

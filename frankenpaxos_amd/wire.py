@@ -8,6 +8,7 @@ from . import _lib
 
 OTHER, PHASE2A, PHASE2B, PHASE1A, CHOSEN, NACK, PHASE2A_NOOP_RANGE, PHASE2B_NOOP_RANGE, CHOSEN_NOOP_RANGE = range(9)
 PHASE1B = 9
+MAX_SLOT_REQUEST, BATCH_MAX_SLOT_REQUEST = 10, 11      # the acceptor's read path (multipaxos/Acceptor.scala:222-254)
 EPX_PRE_ACCEPT, EPX_PRE_ACCEPT_OK, EPX_ACCEPT, EPX_ACCEPT_OK, EPX_COMMIT, EPX_PREPARE, EPX_PREPARE_OK, EPX_NACK = range(16, 24)
 
 
@@ -60,6 +61,10 @@ def _L():
         L.fpx_wire_encode_proxy_leader_phase2b.argtypes = [VP, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
         L.fpx_wire_encode_replica_chosen.argtypes = [VP, C.c_int64, C.c_int32, VP, C.c_int32, C.c_int32]
         L.fpx_wire_encode_leader_nack.argtypes = [VP, C.c_int64, C.c_int32]
+        L.fpx_wire_encode_client_max_slot_reply.argtypes = [VP, C.c_int64, VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        L.fpx_wire_encode_client_max_slot_reply.restype = C.c_int64
+        L.fpx_wire_encode_read_batcher_batch_max_slot_reply.argtypes = [VP, C.c_int64] + [C.c_int32] * 4
+        L.fpx_wire_encode_read_batcher_batch_max_slot_reply.restype = C.c_int64
         L.fpx_wire_encode_leader_phase1b.argtypes = [VP, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [VP] * 6
         L.fpx_wire_encode_leader_phase1b.restype = C.c_int64
         L.fpx_wire_decode_leader_inbound.argtypes = [VP, C.c_int64, VP, C.c_int32] + [VP] * 6 + [C.c_int32, I32P] + [VP] * 5 + [I32P]
@@ -170,6 +175,18 @@ def encode_replica_chosen(slot, value):
 
 def encode_leader_nack(round_):
     return _enc(_L().fpx_wire_encode_leader_nack, round_)
+
+
+def encode_client_max_slot_reply(command_id, group_index, acceptor_index, slot):
+    """ClientInbound{MaxSlotReply}: command_id = the serialised CommandId of the request (decode_acceptor_inbound's
+    value_off / value_len), slot = Acceptor.maxVotedSlot (multipaxos/Acceptor.scala:222-237)"""
+    keep = np.frombuffer(bytes(command_id), np.uint8).copy() if len(command_id) else np.zeros(1, np.uint8)
+    return _enc(_L().fpx_wire_encode_client_max_slot_reply, keep.ctypes.data, len(command_id), group_index, acceptor_index, slot)
+
+
+def encode_read_batcher_batch_max_slot_reply(read_batcher_index, read_batcher_id, acceptor_index, slot):
+    """ReadBatcherInbound{BatchMaxSlotReply} (multipaxos/Acceptor.scala:239-254)"""
+    return _enc(_L().fpx_wire_encode_read_batcher_batch_max_slot_reply, read_batcher_index, read_batcher_id, acceptor_index, slot)
 
 
 def encode_leader_phase1b(group_index, acceptor_index, round_, info):

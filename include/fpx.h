@@ -597,6 +597,17 @@ int32_t fpx_epx_handle_preaccept(fpx_epx* epx, int32_t m, const int32_t* leader,
                                  const int32_t* deps_in_values_end, const uint8_t* target_mask, uint8_t* ok_bits,
                                  uint8_t* resend_bits, uint8_t* nack_bits, uint8_t* commit_bits, int32_t* nack_ballot,
                                  int32_t* reply_deps, int32_t* reply_values_end, int32_t* reply_triple);
+/* Replica.handleCommit (epaxos/Replica.scala:1567-1575 -> commit, :815-830) at every replica of target_mask: whatever the
+ * replica's command log held for the instance is replaced by CommittedEntry(triple) -- a Commit is final, no ballot is
+ * compared (:826-827) -- and its conflict index learns the command (:828; key -1 = Noop).  deps: n watermarks per
+ * message + deps_values_end (the explicit ids number + 1 .. end - 1 of the own-leader column, 0 = none), or NULL: the
+ * triple is known by its id alone, as after an Accept.  Instances of one call that repeat must carry the same triple.
+ * Timers, leaderStates and the dependency graph (:822, :831, :859-875) are the caller's.  FPX_EINVAL, nothing applied:
+ * an instance outside the command log, a key outside the index, a replica outside target_mask's n bits, negative
+ * watermarks, explicit ids that do not lie above the instance. */
+int32_t fpx_epx_handle_commit(fpx_epx* epx, int32_t m, const int32_t* leader, const int32_t* number,
+                              const int32_t* triple_id, const int32_t* key, const uint8_t* is_set, const int32_t* deps,
+                              const int32_t* deps_values_end, const uint8_t* target_mask);
 /* one command-log entry: out[0..4] = kind, ballot, voteBallot, triple id, the replica's largestBallot */
 int32_t fpx_epx_read_cmdlog(fpx_epx* epx, int32_t replica, int32_t leader, int32_t number, int32_t out[5]);
 /* the dependencies kept with that entry: deps[n] watermarks (deps[0] = -1: known by triple id only), *values_end */
@@ -640,6 +651,14 @@ int32_t fpx_leader_phase1b_scan(fpx_ctx* ctx, int32_t chosen_watermark, const ui
                                 int32_t cap, int32_t* max_slot, int32_t* safe_round,
                                 int32_t* safe_value);
 
+/* Acceptor.maxVotedSlot (multipaxos/Acceptor.scala:104, 208) as the read path reports it (handleMaxSlotRequest /
+ * handleBatchMaxSlotRequest, :222-254), restricted to the slots [first_slot, first_slot + count) of the acceptor's group:
+ * the largest of them in which the acceptor holds a vote, -1 if there is none.  With first_slot = 0 and count = num_slots
+ * this is the scalar fpx_read_acceptor returns; a caller that maps an unbounded log onto the context's rows (row =
+ * slot % num_slots: jni/Native.scala) asks lap by lap, because the maximum over rows is not the maximum over slots once
+ * the window has wrapped.  Synchronous; one strided read of the acceptor's column. */
+int32_t fpx_acceptor_max_voted_in(fpx_ctx* ctx, int32_t group, int32_t replica, int32_t first_slot, int32_t count,
+                                  int32_t* max_slot);
 /* Acceptor.handlePhase1a's reply (multipaxos/Acceptor.scala:163-181; mencius/Acceptor.scala:181-199): the
  * Phase1b.info of acceptor `replica` of `group` -- one Phase1bSlotInfo(slot, voteRound, voteValue) per slot >=
  * chosen_watermark in which the acceptor has voted, in ascending slot order (states.iteratorFrom).  *count = how

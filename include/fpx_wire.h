@@ -45,6 +45,9 @@ enum {
   FPX_WIRE_CHOSEN = 4,
   FPX_WIRE_NACK = 5,
   FPX_WIRE_PHASE1B = 9,
+  /* the acceptor's read path (multipaxos/Acceptor.scala:222-254) */
+  FPX_WIRE_MAX_SLOT_REQUEST = 10,
+  FPX_WIRE_BATCH_MAX_SLOT_REQUEST = 11,
   /* mencius/Mencius.proto */
   FPX_WIRE_PHASE2A_NOOP_RANGE = 6,
   FPX_WIRE_PHASE2B_NOOP_RANGE = 7,
@@ -72,7 +75,8 @@ int32_t fpx_wire_decode_proxy_leader_inbound(const uint8_t* buf, int64_t buf_len
                                              int32_t* value_len, int32_t* group_index, int32_t* acceptor_index,
                                              int32_t* bad_index);
 /* Decodes n AcceptorInbound messages: kind PHASE1A (round, chosen_watermark) / PHASE2A (slot, round, value) /
- * OTHER (MaxSlotRequest ...). */
+ * MAX_SLOT_REQUEST (value_off, value_len = where the serialised CommandId lies: the reply returns it unchanged) /
+ * BATCH_MAX_SLOT_REQUEST (slot = read_batcher_index, round = read_batcher_id) / OTHER. */
 int32_t fpx_wire_decode_acceptor_inbound(const uint8_t* buf, int64_t buf_len, const int64_t* offsets, int32_t n, int32_t* kind,
                                          int32_t* slot, int32_t* round, int32_t* is_noop, int64_t* value_off,
                                          int32_t* value_len, int32_t* chosen_watermark, int32_t* bad_index);
@@ -130,6 +134,17 @@ int64_t fpx_wire_encode_proxy_leader_phase2b(uint8_t* out, int64_t cap, int32_t 
 int64_t fpx_wire_encode_replica_chosen(uint8_t* out, int64_t cap, int32_t slot, const uint8_t* value,
                                        int32_t value_len, int32_t is_noop);
 int64_t fpx_wire_encode_leader_nack(uint8_t* out, int64_t cap, int32_t round);
+/* The acceptor's answers on the read path (multipaxos/Acceptor.scala:222-254):
+ *   ClientInbound { oneof request { ...; MaxSlotReply max_slot_reply = 4; ... } }                 MultiPaxos.proto:489-499
+ *   MaxSlotReply { CommandId command_id = 1; group_index = 2; acceptor_index = 3; slot = 4 }      :323-331
+ *   ReadBatcherInbound { oneof request { ...; BatchMaxSlotReply batch_max_slot_reply = 4; } }     :513-523
+ *   BatchMaxSlotReply { read_batcher_index = 1; read_batcher_id = 2; acceptor_index = 3; slot = 4 }   :341-349
+ * command_id / command_id_len: the serialised CommandId as the decoder located it.  slot = Acceptor.maxVotedSlot (-1 before
+ * the first vote: a negative int32 is a ten-byte varint). */
+int64_t fpx_wire_encode_client_max_slot_reply(uint8_t* out, int64_t cap, const uint8_t* command_id, int32_t command_id_len,
+                                              int32_t group_index, int32_t acceptor_index, int32_t slot);
+int64_t fpx_wire_encode_read_batcher_batch_max_slot_reply(uint8_t* out, int64_t cap, int32_t read_batcher_index,
+                                                          int32_t read_batcher_id, int32_t acceptor_index, int32_t slot);
 
 /* The acceptor's answer to a Phase1a (multipaxos/Acceptor.scala:163-181), as the Leader parses it:
  *   LeaderInbound { oneof request { Phase1b phase1b = 1; ...; Nack nack = 6; ... } }          MultiPaxos.proto:525-539

@@ -699,6 +699,46 @@ int fpo_epx_accept(fpo_epx* e, int32_t m, const int32_t* leader, const int32_t* 
   return status;
 }
 
+/* Replica.handleCommit (epaxos/Replica.scala:1567-1575) -> commit(.., informOthers = false) (:815-830) at every replica of
+ * target_mask, messages in array order: whatever the replica's command log held for the instance is replaced by
+ * CommittedEntry(triple) (:826-827, no ballot is looked at: a Commit is final), and the conflict index learns the
+ * command (:828).  deps = n watermarks per message + deps_values_end (the explicit values number + 1 .. end - 1 of the own
+ * column), or NULL: the triple is known by its id alone, as after an Accept.  key -1 = Noop.  Timers and leaderStates
+ * (:822, :831) are the caller's; so is the dependency graph (:859-875). */
+int fpo_epx_handle_commit(fpo_epx* e, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* triple_id,
+                              const int32_t* key, const uint8_t* is_set, const int32_t* deps, const int32_t* deps_values_end,
+                              const uint8_t* target_mask) {
+  if (!e || m < 0 || e->num_instances <= 0) return 1;
+  if (m == 0) return 0;
+  if (!leader || !number || !triple_id || !key || !is_set || !target_mask) return 1;
+  const int n = e->n;
+  for (int i = 0; i < m; ++i) {
+    if (leader[i] < 0 || leader[i] >= n || number[i] < 0 || number[i] >= e->num_instances || key[i] < -1 || key[i] >= e->num_keys ||
+        (target_mask[i] >> n) != 0)
+      return 1;
+    if (deps) {
+      for (int l = 0; l < n; ++l)
+        if (deps[(size_t)i * n + l] < 0) return 1;
+      const int end = deps_values_end ? deps_values_end[i] : 0;
+      if (end != 0 && (end <= number[i] + 1 || deps[(size_t)i * n + leader[i]] > number[i])) return 1;
+    }
+  }
+  for (int i = 0; i < m; ++i)
+    for (int r = 0; r < n; ++r) {
+      if (!((target_mask[i] >> r) & 1u)) continue;
+      const size_t c = ((size_t)r * n + leader[i]) * e->num_instances + number[i];
+      e->cl_status[c] = CL_COMMITTED, e->cl_ballot[c] = e->cl_vote[c] = -1, e->cl_triple[c] = triple_id[i];
+      if (deps) {
+        for (int l = 0; l < n; ++l) e->cl_deps[c * (size_t)n + l] = deps[(size_t)i * n + l];
+        e->cl_dend[c] = deps_values_end ? deps_values_end[i] : 0;
+      } else {
+        deps_by_id(e, c);
+      }
+      if (key[i] >= 0) conflict_index_put(e, r, key[i], is_set[i], leader[i], number[i]);
+    }
+  return 0;
+}
+
 /* Replica.handlePreAccept in full (epaxos/Replica.scala:1159-1289) at every replica of target_mask, messages delivered
  * in array order; the instances of one call are pairwise distinct.  Message i = PreAccept(instance (leader, number),
  * ballot (b_ord, b_rep), commandOrNoop = single-key get / set on key[i] or Noop (key[i] == -1), sequenceNumber 0,

@@ -630,6 +630,20 @@ class EPaxos:
                                   _p(nb, I32P), _p(done, U8P))
         return st, ok, nack, com, nb, done
 
+    def handle_commit(self, leader, number, triple_id, target_mask, key=None, is_set=None, deps=None, deps_values_end=None):
+        """Replica.handleCommit at the replicas of target_mask; key None = Noops, deps None = the triple by id alone"""
+        leader, number, tr = _i32(leader), _i32(number), _i32(triple_id)
+        m = len(leader)
+        tgt = np.ascontiguousarray(target_mask, dtype=np.uint8)
+        key = np.full(m, -1, np.int32) if key is None else _i32(key)
+        is_set = np.zeros(m, np.uint8) if is_set is None else np.ascontiguousarray(is_set, dtype=np.uint8)
+        d = None if deps is None else np.ascontiguousarray(deps, dtype=np.int32)
+        de = None if deps_values_end is None else _i32(deps_values_end)
+        fn = lib().fpo_epx_handle_commit
+        fn.argtypes = [C.c_void_p, C.c_int32, I32P, I32P, I32P, I32P, U8P, I32P, I32P, U8P]
+        return fn(self._h, m, _p(leader, I32P), _p(number, I32P), _p(tr, I32P), _p(key, I32P), _p(is_set, U8P), _p(d, I32P),
+                  _p(de, I32P), _p(tgt, U8P))
+
     def read_cmdlog(self, replica, leader, number):
         out = np.zeros(5, np.int32)
         if lib().fpo_epx_read_cmdlog(self._h, replica, leader, number, _p(out, I32P)):

@@ -4,7 +4,9 @@ produces for the Phase-2 messages of the reference, from descriptors transcribed
 /root/reference/shared/src/main/scala/frankenpaxos/multipaxos/MultiPaxos.proto (Noop :183-186, CommandId
 :188-196, Command :198-204, CommandBatch :206-211, CommandBatchOrNoop :213-221, Phase1a :238-253, Phase1bSlotInfo :254-261, Phase1b :263-271, Phase2a
 :273-281, Phase2b :283-291, Chosen :293-299, Nack :455-460, LeaderInbound.phase1b = 1 :530, LeaderInbound.nack = 6 :535, ProxyLeaderInbound
-:541-549, AcceptorInbound :551-561, ReplicaInbound :563-575).
+:541-549, AcceptorInbound :551-561, ReplicaInbound :563-575).  Round 5: the acceptor's read path -- MaxSlotRequest :316-321,
+MaxSlotReply :323-331, BatchMaxSlotRequest :333-339, BatchMaxSlotReply :341-349, ClientInbound.max_slot_reply = 4 :497,
+ReadBatcherInbound.batch_max_slot_reply = 4 :521, AcceptorInbound.max_slot_request = 3 / batch_max_slot_request = 4 :558-559.
 
 Round 3: the same for mencius/Mencius.proto (Phase1a :104-117, Phase2a :151-158, Phase2aNoopRange :160-167, Phase2b
 :169-176, Phase2bNoopRange :178-187, Chosen :189-195, ChosenNoopRange :197-203, Nack :266-271, LeaderInbound.nack = 7
@@ -61,7 +63,17 @@ def build():
     msg("Chosen", ("slot", 1, I32, REQ, None, None), ("command_batch_or_noop", 2, MSG, REQ, "CommandBatchOrNoop", None))
     msg("Nack", ("round", 1, I32, REQ, None, None))
     msg("ProxyLeaderInbound", ("phase2a", 1, MSG, OPT, "Phase2a", "request"), ("phase2b", 2, MSG, OPT, "Phase2b", "request"))
-    msg("AcceptorInbound", ("phase1a", 1, MSG, OPT, "Phase1a", "request"), ("phase2a", 2, MSG, OPT, "Phase2a", "request"))
+    msg("MaxSlotRequest", ("command_id", 1, MSG, REQ, "CommandId", None))
+    msg("MaxSlotReply", ("command_id", 1, MSG, REQ, "CommandId", None), ("group_index", 2, I32, REQ, None, None),
+        ("acceptor_index", 3, I32, REQ, None, None), ("slot", 4, I32, REQ, None, None))
+    msg("BatchMaxSlotRequest", ("read_batcher_index", 1, I32, REQ, None, None), ("read_batcher_id", 2, I32, REQ, None, None))
+    msg("BatchMaxSlotReply", ("read_batcher_index", 1, I32, REQ, None, None), ("read_batcher_id", 2, I32, REQ, None, None),
+        ("acceptor_index", 3, I32, REQ, None, None), ("slot", 4, I32, REQ, None, None))
+    msg("ClientInbound", ("max_slot_reply", 4, MSG, OPT, "MaxSlotReply", "request"))
+    msg("ReadBatcherInbound", ("batch_max_slot_reply", 4, MSG, OPT, "BatchMaxSlotReply", "request"))
+    msg("AcceptorInbound", ("phase1a", 1, MSG, OPT, "Phase1a", "request"), ("phase2a", 2, MSG, OPT, "Phase2a", "request"),
+        ("max_slot_request", 3, MSG, OPT, "MaxSlotRequest", "request"),
+        ("batch_max_slot_request", 4, MSG, OPT, "BatchMaxSlotRequest", "request"))
     msg("ReplicaInbound", ("chosen", 1, MSG, OPT, "Chosen", "request"))
     msg("LeaderInbound", ("phase1b", 1, MSG, OPT, "Phase1b", "request"), ("nack", 6, MSG, OPT, "Nack", "request"))
     pool = descriptor_pool.DescriptorPool()
@@ -69,7 +81,8 @@ def build():
     get = lambda n: message_factory.GetMessageClass(pool.FindMessageTypeByName("frankenpaxos.multipaxos." + n))
     return {n: get(n) for n in ("Noop", "CommandId", "Command", "CommandBatch", "CommandBatchOrNoop", "Phase1a", "Phase1bSlotInfo", "Phase1b", "Phase2a",
                                 "Phase2b", "Chosen", "Nack", "ProxyLeaderInbound", "AcceptorInbound", "ReplicaInbound",
-                                "LeaderInbound")}
+                                "LeaderInbound", "MaxSlotRequest", "MaxSlotReply", "BatchMaxSlotRequest", "BatchMaxSlotReply",
+                                "ClientInbound", "ReadBatcherInbound")}
 
 
 def _file(name, package, messages, enums=()):
@@ -343,6 +356,26 @@ def main():
         vectors.append({"msg": "phase1b", "group_index": g, "acceptor_index": a_, "round": rnd,
                         "info": [[slot, vr, vname, value(M, vals[vname]).SerializeToString().hex()] for slot, vr, vname in info],
                         "leader_inbound": l.SerializeToString().hex()})
+    # the acceptor's read path (Acceptor.scala:222-254)
+    for addr, pseud, cid, g, a_, slot in [(b"\x0a\x00\x00\x01:9000", 3, 17, 0, 0, -1), (b"", 0, 0, 0, 2, 0), (b"client-7", 2147483647, -5, 15, 255, 1 << 20),
+                                          (bytes(range(200)), 128, 300, 1, 1, 2147483647)]:
+        q = M["AcceptorInbound"]()
+        q.max_slot_request.command_id.client_address = addr
+        q.max_slot_request.command_id.client_pseudonym, q.max_slot_request.command_id.client_id = pseud, cid
+        r = M["ClientInbound"]()
+        r.max_slot_reply.command_id.CopyFrom(q.max_slot_request.command_id)
+        r.max_slot_reply.group_index, r.max_slot_reply.acceptor_index, r.max_slot_reply.slot = g, a_, slot
+        vectors.append({"msg": "max_slot", "command_id_hex": q.max_slot_request.command_id.SerializeToString().hex(),
+                        "group_index": g, "acceptor_index": a_, "slot": slot,
+                        "acceptor_inbound": q.SerializeToString().hex(), "client_inbound": r.SerializeToString().hex()})
+    for rbi, rbid, a_, slot in [(0, 0, 0, -1), (1, 7, 2, 0), (300, 2147483647, 255, 1 << 20), (5, 128, 1, 2147483647)]:
+        q = M["AcceptorInbound"]()
+        q.batch_max_slot_request.read_batcher_index, q.batch_max_slot_request.read_batcher_id = rbi, rbid
+        r = M["ReadBatcherInbound"]()
+        b = r.batch_max_slot_reply
+        b.read_batcher_index, b.read_batcher_id, b.acceptor_index, b.slot = rbi, rbid, a_, slot
+        vectors.append({"msg": "batch_max_slot", "read_batcher_index": rbi, "read_batcher_id": rbid, "acceptor_index": a_, "slot": slot,
+                        "acceptor_inbound": q.SerializeToString().hex(), "read_batcher_inbound": r.SerializeToString().hex()})
     vectors += mencius_vectors() + epaxos_vectors()
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "wire_vectors.json")
     json.dump({"generator": "google.protobuf " + __import__("google.protobuf").protobuf.__version__,

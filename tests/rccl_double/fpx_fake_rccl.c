@@ -1,5 +1,5 @@
 /* fpx_fake_rccl.c -- TEST DOUBLE of the RCCL entry points libfpx binds at run time (fpx_api.hip rccl_bind: ncclGetUniqueId,
- * ncclCommInitRank, ncclCommDestroy, ncclReduceScatter, ncclAllGather, ncclAllReduce, ncclGetErrorString), selected with
+ * ncclCommInitRank, ncclCommDestroy, ncclReduceScatter, ncclAllGather, ncclAllReduce, ncclGroupStart / End, ncclGetErrorString), selected with
  * FPX_RCCL_LIB.  Test infrastructure only.
  *
  * Why: fpx_phase2_replica_sharded_dev (K1 on my acceptor columns -> reduce-scatter of the partial vote bitmaps ->
@@ -105,6 +105,16 @@ int ncclCommDestroy(void* comm) {
   free(c);
   return 0;
 }
+
+/* groups: this double runs every collective inside its call, so a group only checks that it is opened and closed in pairs */
+static int group_depth, groups_closed;
+int ncclGroupStart(void) { return ++group_depth > 8 ? 5 /* ncclInvalidUsage */ : 0; }
+int ncclGroupEnd(void) {
+  if (group_depth <= 0) return 5;
+  --group_depth, ++groups_closed;
+  return 0;
+}
+int fpx_fake_rccl_groups_closed(void) { return groups_closed; } /* for the tests */
 
 const char* ncclGetErrorString(int code) { return code == 0 ? "no error" : "fpx_fake_rccl: error"; }
 

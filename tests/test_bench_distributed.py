@@ -133,3 +133,41 @@ def test_bench_spawns_eight_ranks():
     assert d["n_gpus"] == 8 and d["steps"] == 2 and d["scaling"] == "weak"
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 8 * (1 << 20)) < 1e-3 * 8 * (1 << 20)
     assert d["cpu_baseline"]["cores"] == 1
+
+
+def _double():
+    from tests.test_gpu_sharding_world2 import build_double
+    return build_double()
+
+
+@pytest.mark.parametrize("shard", ["group", "replica"])
+def test_eight_rank_lines_through_the_library_communicator(shard):
+    """the lines the driver's 8-GPU run prints, end to end with EIGHT ranks before the driver does --
+    all on cuda:0, rendezvous over gloo, but the data path through fpx_comm_create and the library's own collectives
+    (FPX_BENCH_FPX_COMM=1; RCCL refuses two ranks on one device, so its symbols come from tests/rccl_double).  group: the
+    weak-scaling headline + the replica-axis row (32 acceptors per rank, 8-slice reduce-scatter, all-reduce(max) of the
+    Nack rounds) + the all-gather of Chosen records of the `rccl` probe; replica: the strong-scaling line itself."""
+    env = dict(os.environ, FPX_BENCH_SHARE_GPU="1", FPX_BENCH_BACKEND="gloo", FPX_BENCH_FPX_COMM="1", FPX_RCCL_LIB=_double(),
+               FPX_BENCH_SLOTS_LOG2="16")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    extra = ["--replica-row-steps", "2"] if shard == "group" else ["--shard", "replica"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"] + extra,
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    n = 1 << 16
+    assert d["n_gpus"] == 8 and d["steps"] == 2 and d["config"]["slots_per_step"] == n
+    assert d["rccl_ranks"] == 8
+    if shard == "group":
+        assert d["scaling"] == "weak" and abs(d["value"] * d["ms_per_step"] * 1e-3 - 8 * n) < 1e-3 * 8 * n
+        r = d["replica_axis"]
+        assert "error" not in r, r
+        assert r["rccl_ranks"] == 8 and r["steps"] == 2 and r["collective_avg_ms_max_over_ranks"] > 0
+        assert abs(r["value"] * r["ms_per_step"] * 1e-3 - n) < 1e-3 * n
+        assert d["rccl"] == {"ranks": 8, "allgather_of_chosen_records_ok": True}
+    else:
+        assert d["scaling"] == "strong" and d["collective"]["calls_timed"] == 2 and d["collective"]["avg_ms"] > 0
+        assert abs(d["value"] * d["ms_per_step"] * 1e-3 - n) < 1e-3 * n

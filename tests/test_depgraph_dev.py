@@ -78,6 +78,30 @@ def random_prefix_graph(rng, n, m, jitter, holes, from_zero=False):
     return leader, number, first, cnt.astype(np.int32), deps, own
 
 
+def run_device_only(n, leader, number, first, count, deps, own, committed=None):
+    """the device call alone on resident inputs (a second call: buffers at their size), synchronised"""
+    import torch
+    from frankenpaxos_amd.epaxos import EPaxos
+
+    m = len(leader)
+    dev = torch.device("cuda:0")
+    epx = EPaxos(n, 4)
+    packed = np.zeros((m, epx.packed_stride()), np.int32)
+    packed[:, :n] = deps
+    packed[:, 2 * n] = own[:, 0]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    order, comp = torch.full((m,), -1, dtype=torch.int32, device=dev), torch.full((m,), -1, dtype=torch.int32, device=dev)
+    args = (t(leader), t(number), t(packed), first, count, order, comp)
+    cm = None if committed is None else t(committed.astype(np.uint8))
+    epx.execute_dev(*args, committed=cm)
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    out = epx.execute_dev(*args, committed=cm)
+    torch.cuda.synchronize()
+    return out, time.perf_counter() - t0
+
+
 def run_both(n, leader, number, first, count, deps, own, committed=None, kind="tarjan"):
     import torch
     from frankenpaxos_amd import depgraph as P
@@ -125,7 +149,7 @@ def test_device_components_equal_the_host_graphs(n, m, jitter, holes):
         assert nc < m                                       # there were cycles
 
 
-@pytest.mark.parametrize("n,m", [(5, 3000), (3, 800)])
+@pytest.mark.parametrize("n,m", [(5, 3000), (3, 800), (5, 400000)])
 def test_device_waits_for_what_is_not_committed(n, m):
     """a tenth of the instances is not committed yet: they, and whatever reaches them, stay; the rest executes -- the same
     set the host graph executes"""
@@ -135,6 +159,11 @@ def test_device_waits_for_what_is_not_committed(n, m):
     committed[:3 * m // 4] = True                            # (the early instances are all there: a prefix executes)
     (ne, nc, nh, order, comp), (el, ei, cs) = run_both(n, leader, number, first, count, deps, own, committed)
     assert not nh and ne == len(el) and 0 < ne < m
+    if m > 100000:
+        # an uncommitted vertex used to walk the rest of its column in k_dg_keys, one load per step -- O(m^2)
+        # per tick, seconds at this size; the walk is now asked of executable vertices only
+        out, dt = run_device_only(n, leader, number, first, count, deps, own, committed)
+        assert out[0] == ne and dt < 0.05, dt
     host = labels(n, leader, number, el, ei, np.repeat(np.arange(len(cs)), cs))
     mine = labels(n, leader, number, leader[order], number[order], comp)
     assert mine == host

@@ -651,6 +651,90 @@ def test_epaxos_prepare_accept_match_oracle(oracle, n, NI, m):
     assert EPaxos(n, 8).accept([1], [1], [0], [1], [0], [0b001])[0] == fa.FPX_EINVAL
 
 
+def test_oracle_handle_commit_by_hand(oracle):
+    """Replica.handleCommit (epaxos/Replica.scala:1567-1575 -> commit :815-830), n = 5, by hand: replica 2 holds an
+    AcceptedEntry for (0, 5) in Ballot(3, 1) (one AcceptOk + the proposer's own = 2 < f + 1 = 3: not committed); a Commit
+    for (0, 5) with another triple arrives at replicas {2, 3}: the entry is replaced WITHOUT a ballot comparison
+    (:826-827 -- a Commit is final), the ballots become the null ballot, the triple's dependencies are what the Commit
+    carried, the conflict index of key 1 learns (0, 5) as a set at replicas 2 and 3 (:828); replica 4 knows nothing.  A
+    later Prepare in Ballot(9, 0) finds the CommittedEntry and is answered with the Commit (:1746-1756)."""
+    e = oracle.EPaxos(5, 4, num_instances=16)
+    assert e.accept([0], [5], [3], [1], [77], [0b00100], key=[2], is_set=[0])[0] == 0     # proposer 1 -> replica 2
+    assert e.read_cmdlog(2, 0, 5)[:4] == (3, enc(3, 1), enc(3, 1), 77)
+    assert e.handle_commit([0], [5], [88], [0b01100], key=[1], is_set=[1], deps=[[0, 3, 2, 0, 1]], deps_values_end=[0]) == 0
+    for r in (2, 3):
+        assert e.read_cmdlog(r, 0, 5)[:4] == (4, -1, -1, 88)
+        d, end = e.read_cmdlog_deps(r, 0, 5)
+        assert d.tolist() == [0, 3, 2, 0, 1] and end == 0
+        assert e.read_index(r, 1)[1].tolist() == [6, 0, 0, 0, 0]               # sets: TopOne of leader 0 = 5 + 1
+    assert e.read_cmdlog(4, 0, 5)[0] == 0 and e.read_index(4, 1)[1].tolist() == [0] * 5
+    assert e.read_cmdlog(1, 0, 5)[0] == 3                                      # the proposer was not among the recipients
+    st, ok, nack, com, nb, rs, rv, rt = e.prepare([0], [5], [9], [0], [0b01100])
+    assert st == 0 and ok[0] == 0 and nack[0] == 0 and com[0] == 0b01100
+    # explicit ids of the own column must lie above the instance; a key outside the index: nothing applied
+    assert e.handle_commit([0], [6], [1], [0b00001], key=[0], is_set=[0], deps=[[7, 0, 0, 0, 0]], deps_values_end=[9]) == 1
+    assert e.handle_commit([0], [6], [1], [0b00001], key=[4], is_set=[0]) == 1
+    assert e.read_cmdlog(0, 0, 6)[0] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,NI,m", [(3, 64, 40), (5, 512, 700), (7, 300, 1500)])
+def test_epaxos_handle_commit_matches_oracle(oracle, n, NI, m):
+    """Commits from outside (Replica.handleCommit) between Accept / Prepare batches and pre-accept ticks: instances in every
+    state, with dependencies or by triple id alone, Noops among them, arbitrary recipients -- the command log, the stored
+    dependencies and the conflict indices, GPU == oracle; and the replies of the Prepares that follow (a CommittedEntry is
+    answered with the Commit)"""
+    from frankenpaxos_amd.epaxos import EPaxos
+    import frankenpaxos_amd as fa
+
+    K = 8
+    gpu, ref = EPaxos(n, K, num_instances=NI), oracle.EPaxos(n, K, num_instances=NI)
+    rng = np.random.default_rng(n * 7 + NI)
+    nxt = [0] * n
+    commits = 0
+    for step in range(9):
+        kind = step % 3
+        if kind == 0 and max(nxt) + 60 < NI // 2:
+            leader, number, key, is_set, mask, rank = random_tick(rng, n, K, 100, nxt, 3.0)
+            tr = rng.integers(0, 1 << 20, 100).astype(np.int32)
+            a, b = gpu.preaccept(leader, number, key, is_set, mask, rank, triple_id=tr), ref.preaccept(leader, number, key, is_set, mask, rank, triple_id=tr)
+            assert a[0] == b[0] == 0
+        elif kind == 1:
+            leader, number, _, _, tgt = _cl_batch(rng, n, NI, m, nxt)
+            k = len(leader)
+            tr = rng.integers(0, 1 << 20, k).astype(np.int32)
+            key = rng.integers(-1, K, k).astype(np.int32)
+            is_set = rng.integers(0, 2, k).astype(np.uint8)
+            deps = rng.integers(0, NI, (k, n)).astype(np.int32)
+            ends = np.zeros(k, np.int32)
+            own = deps[np.arange(k), leader]
+            holes = rng.random(k) < 0.3                           # the own column as watermark <= number + explicit ids above
+            deps[np.arange(k), leader] = np.where(holes, np.minimum(own, number), own)
+            ends[holes] = number[holes] + 2 + rng.integers(0, 5, int(holes.sum()))
+            by_id = step == 4
+            args = dict(key=key, is_set=is_set) if by_id else dict(key=key, is_set=is_set, deps=deps, deps_values_end=ends)
+            assert gpu.handle_commit(leader, number, tr, tgt, **args) == ref.handle_commit(leader, number, tr, tgt, **args) == 0
+            commits += k
+        else:
+            leader, number, b_ord, b_rep, tgt = _cl_batch(rng, n, NI, m, nxt)
+            a, b = gpu.prepare(leader, number, b_ord, b_rep, tgt), ref.prepare(leader, number, b_ord, b_rep, tgt)
+            assert a[0] == b[0] == 0
+            for x, y in zip(a[1:], b[1:]):
+                np.testing.assert_array_equal(x, y)
+    assert commits > 0
+    for r in range(n):
+        for inst in rng.choice(n * NI, size=min(300, n * NI), replace=False):
+            L, x = int(inst) // NI, int(inst) % NI
+            assert gpu.read_cmdlog(r, L, x) == ref.read_cmdlog(r, L, x)
+            (da, ea), (db, eb) = gpu.read_cmdlog_deps(r, L, x), ref.read_cmdlog_deps(r, L, x)
+            assert ea == eb and np.array_equal(da, db)
+        for k in range(K):
+            for x, y in zip(gpu.read_index(r, k), ref.read_index(r, k)):
+                np.testing.assert_array_equal(x, y)
+    assert gpu.handle_commit([0], [NI], [1], [1]) == fa.FPX_EINVAL and gpu.handle_commit([0], [1], [1], [1 << n]) == fa.FPX_EINVAL
+    assert EPaxos(n, K).handle_commit([0], [1], [1], [1]) == fa.FPX_EINVAL
+
+
 # ------------------------------------------------ handlePreAccept in full: ballots, Nacks, re-sent replies ----
 def test_oracle_handle_preaccept_every_branch_by_hand(oracle):
     """n = 5, instance X = (0, 0): set k1 led by replica 0.  Replica 1 already knows the conflicting instance (2, 6).

@@ -4,7 +4,10 @@ slots, fpx_api.hip -- with a world of TWO ranks.  The boxes this build runs on h
 on one device, so the two ranks are two processes with a libfpx context each on the one GPU, and the collectives are
 tests/rccl_double/fpx_fake_rccl.c (FPX_RCCL_LIB: the hook libfpx binds RCCL through).  Everything above the five ncclXxx
 symbols is the product's own code and the oracle is the unsharded group.  ("so that the first real
-8-GPU run is not also the first run of that code with N > 1".)"""
+8-GPU run is not also the first run of that code with N > 1".)  Round 5: the same with worlds of
+FOUR and EIGHT ranks -- the geometry the driver's 8-GPU run uses: 32 acceptors per rank (the G = 8 kernels), an 8-slice
+reduce-scatter, the all-reduce(max) of Nack rounds over eight ranks, the all-gather of Chosen records inside one
+ncclGroupStart / ncclGroupEnd, and a batch whose size the world does not divide refused with FPX_EINVAL."""
 import multiprocessing as mp
 import os
 import subprocess
@@ -105,6 +108,13 @@ def _rank_main(rank, world, so, conn, ballot_mode):
             assert gpu.read_tally(int(s)) == whole.read_tally(int(s)), "tally of slot %d" % s
         n_coll, _ = gpu.profile_read_collective()
         assert n_coll == 2 + 2                               # a reduce-scatter per step, an all-gather group per step
+        import ctypes
+        assert ctypes.CDLL(so).fpx_fake_rccl_groups_closed() == 2      # the three all-gathers of a step travel as ONE group
+        # a batch the world does not divide has no slice for every rank: refused before anything is launched
+        k = S - 1 if (S - 1) % world else S - 3
+        with pytest.raises(fa.FpxError) as err:
+            gpu.phase2_replica_sharded_dev(t(slot[:k]), t(np.full(k, 6, np.int32)), t(val[:k]), None, ch, cr, cv, nr)
+        assert err.value.status == fa.FPX_EINVAL
         gpu.comm_destroy()
         gpu.set_stream(None)
         gpu.close()
@@ -114,21 +124,22 @@ def _rank_main(rank, world, so, conn, ballot_mode):
         conn.send("rank %d: %s\n%s" % (rank, e, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("ballot_mode", [0, 1])
-def test_replica_sharded_entry_point_world_two(ballot_mode):
+@pytest.mark.parametrize("world,ballot_mode", [(2, 0), (2, 1), (4, 1), (8, 0), (8, 1)])
+def test_replica_sharded_entry_point_world_two(world, ballot_mode):
     so = build_double()
     ctx = mp.get_context("spawn")
-    pipes = [ctx.Pipe() for _ in range(2)]
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, so, pipes[r][1], ballot_mode)) for r in range(2)]
+    pipes = [ctx.Pipe() for _ in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, so, pipes[r][1], ballot_mode)) for r in range(world)]
     for p in procs:
         p.start()
     try:
-        assert pipes[0][0].poll(240), "rank 0 never produced the communicator id"
+        assert pipes[0][0].poll(400), "rank 0 never produced the communicator id"
         uid = pipes[0][0].recv()
         assert isinstance(uid, bytes), uid
-        pipes[1][0].send(uid)
-        for r in range(2):
-            assert pipes[r][0].poll(300), "rank %d did not finish" % r
+        for r in range(1, world):
+            pipes[r][0].send(uid)
+        for r in range(world):
+            assert pipes[r][0].poll(600), "rank %d did not finish" % r
             msg = pipes[r][0].recv()
             assert msg == "ok", msg
     finally:

@@ -431,6 +431,136 @@ def test_a_leader_change_on_wire_bytes_through_the_shim(jvm, oracle):
     assert jvm.call("destroy", C.c_int32, h) == 0
 
 
+@pytest.mark.gpu
+def test_the_acceptors_read_path_through_the_shim(jvm, oracle):
+    """GpuAcceptor answers MaxSlotRequest / BatchMaxSlotRequest with Acceptor.maxVotedSlot (multipaxos/Acceptor.scala:
+    222-254) as GpuPhase2Engine follows it (jni/Native.scala: noteVotes / maxVotedSlot), on wire bytes through the
+    natives it calls:
+      1. thrifty ticks nobody Nacks: every targeted acceptor voted -- the engine's bookkeeping alone == the oracle's
+         Acceptor.maxVotedSlot, no native asked
+      2. a competing leader pre-promises acceptor 1; the old leader's tick is Nacked by it: the group is stale, the
+         read asks the device (acceptorMaxVotedIn, lap by lap) and is exact again: acceptor 1 did NOT vote, 0 and 2 did
+      3. the window wraps (rows 0..2047 recycled, slots 4096.. land in them): the device's scalar over ROWS is no longer
+         the maximum over SLOTS; the two-lap read is
+      4. the requests and replies as bytes: AcceptorInbound{MaxSlotRequest}, {BatchMaxSlotRequest} decoded by the shim's
+         decoder, ClientInbound{MaxSlotReply} / ReadBatcherInbound{BatchMaxSlotReply} carrying that slot"""
+    from frankenpaxos_amd import wire
+
+    S, R, F = 4096, 3, 1
+    cfg = np.array([S, R, 1, 1, F, 0, 0, 0, 2, 0, 8, 0, 0, 0, 0], np.int32)
+    h = jvm.call("create", C.c_int64, jvm.arr(cfg))
+    assert h > 0
+    ref = oracle.System(oracle.make_config(num_slots=S, num_replicas=R, f=F, tally_ways=8, num_leaders=2))
+    i32 = lambda a: jvm.arr(np.asarray(a, np.int32))
+    base = 0                                                   # GpuPhase2Engine.base: first slot of the window
+    max_voted, stale, voted_truth = [-1] * R, [False], [-1] * R  # the engine's table; what really happened (by hand)
+
+    def phase1a(rnd, acceptors):
+        bits = jvm.arr(np.zeros(8, np.int64))
+        tgt = oracle.bits_of(acceptors)
+        assert jvm.call("acceptorPhase1a", C.c_int32, h, 0, rnd, 0, jvm.arr(tgt.view(np.int64)), bits) == 0
+        assert ref.acceptor_phase1a(0, rnd, 0, tgt)[0] == 0
+
+    def tick(slots, rnd, targets, check_oracle=True):
+        """GpuPhase2Engine.phase2Tick + noteVotes: slots are log positions, rows = slot % S"""
+        n = len(slots)
+        rows = np.asarray(slots, np.int32) % S
+        val = np.arange(n, dtype=np.int32) + 7
+        tgt = np.stack([oracle.bits_of(t) for t in targets])
+        ch, cr, cv, nr = (jvm.arr(np.zeros(n, t)) for t in (np.int8, np.int32, np.int32, np.int32))
+        assert jvm.call("phase2Fused", C.c_int32, h, n, i32(rows), i32(np.full(n, rnd)), i32(val), jvm.arr(tgt.view(np.int64)), ch, cr, cv, nr) == 0
+        nr = jvm.read(nr, np.int32, n)
+        if check_oracle:
+            st, ch_r, cr_r, cv_r, nr_r = ref.phase2_fused(rows, np.full(n, rnd, np.int32), val, tgt)
+            assert st == 0
+            np.testing.assert_array_equal(nr, nr_r)
+        covered = set()
+        for i in sorted(range(n), key=lambda i: -int(slots[i])):          # noteVotes
+            if nr[i] >= 0:
+                stale[0] = True
+            else:
+                for a in targets[i]:
+                    if a not in covered:
+                        covered.add(a)
+                        max_voted[a] = max(max_voted[a], int(slots[i]))
+        return nr
+
+    def read(a):
+        """GpuPhase2Engine.maxVotedSlot"""
+        if stale[0]:
+            r0 = base % S
+            for b in range(R):
+                hi = jvm.call("acceptorMaxVotedIn", C.c_int32, h, 0, b, 0, r0) if r0 > 0 else -1
+                lo = jvm.call("acceptorMaxVotedIn", C.c_int32, h, 0, b, r0, S - r0) if hi < 0 else -1
+                assert hi >= -1 and lo >= -1
+                slot = base + (S - r0) + hi if hi >= 0 else (base + (lo - r0) if lo >= 0 else -1)
+                max_voted[b] = max(max_voted[b], slot)
+            stale[0] = False
+        return max_voted[a]
+
+    # 1. rotating windows of f + 1 = 2 neighbours, nobody Nacks
+    phase1a(0, [0, 1, 2])
+    slots = list(range(0, 300))
+    targets = [[(s % R), (s + 1) % R] for s in slots]
+    tick(slots, 0, targets)
+    for a in range(R):
+        voted_truth[a] = max(s for s, t in zip(slots, targets) if a in t)
+        assert read(a) == voted_truth[a] == ref.read_acceptor(0, a)[1]
+    # 2. acceptor 1 promises round 1; the round-0 tick that follows is Nacked by it wherever it is a target
+    phase1a(1, [1])
+    slots = list(range(300, 330))
+    targets = [[(s % R), (s + 1) % R] for s in slots]
+    nr = tick(slots, 0, targets)
+    assert (nr >= 0).any() and stale[0]
+    for a in (0, 2):
+        voted_truth[a] = max(s for s, t in zip(slots, targets) if a in t)
+    for a in range(R):
+        assert read(a) == voted_truth[a] == ref.read_acceptor(0, a)[1]
+    assert not stale[0] and voted_truth[1] < 300                      # acceptor 1 has not voted since its promise
+    # 3. the new leader takes over (round 1) and proposes far ahead in the window; then the window moves on: rows
+    #    0 .. 2047 are recycled, base = 2048, and the log goes on in slots 4096 .. -- in rows 0 ..
+    phase1a(1, [0, 2])
+    slots = list(range(3000, 3030))
+    targets = [[(s % R), (s + 1) % R] for s in slots]
+    tick(slots, 1, targets)
+    for a in range(R):
+        voted_truth[a] = max(s for s, t in zip(slots, targets) if a in t)
+        assert read(a) == voted_truth[a] == ref.read_acceptor(0, a)[1]
+    assert jvm.call("recycleSlots", C.c_int32, h, 0, 2048) == 0
+    base = 2048
+    slots = list(range(4096, 4160))
+    targets = [[(s % R), (s + 1) % R] for s in slots]
+    tick(slots, 1, targets, check_oracle=False)
+    for a in range(R):
+        voted_truth[a] = max(s for s, t in zip(slots, targets) if a in t)
+        assert read(a) == voted_truth[a]
+    # ... and if the engine has to ask (a Nack somewhere): the two laps, newest first -- not the scalar over rows
+    stale[0], max_voted[:] = True, [-1] * R
+    for a in range(R):
+        assert read(a) == voted_truth[a]
+    # (the maximum over ALL rows -- what the device's scalar is -- is a row of the OLD lap: slot 3029's, not slot 4158's row 62)
+    assert jvm.call("acceptorMaxVotedIn", C.c_int32, h, 0, 0, 0, S) == 3029 and voted_truth[0] == 4158
+    assert jvm.call("acceptorMaxVotedIn", C.c_int32, h, 0, 0, 0, S + 1) < -1      # FPX_EINVAL comes back as -(status + 1)
+    # 4. on the wire
+    cid = bytes.fromhex("0a0d") + b"10.0.0.1:9000" + bytes.fromhex("1003" "1811")        # CommandId{address, pseudonym 3, id 17}
+    req = bytes([0x1a, len(cid) + 2, 0x0a, len(cid)]) + cid                                  # AcceptorInbound{max_slot_request = 3}
+    breq = bytes.fromhex("22" "04" "0805" "1007")                                           # {batch_max_slot_request = 4 {5, 7}}
+    buf, off = wire.pack([req, breq])
+    fields, voff, bad = jvm.arr(np.zeros(12, np.int32)), jvm.arr(np.zeros(2, np.int64)), jvm.arr(np.zeros(1, np.int32))
+    d = C.c_void_p(jvm.lib.mock_new_direct(len(buf)))
+    C.memmove(jvm.lib.mock_data(d), bytes(buf), len(buf))
+    assert jvm.call("wireDecodeAcceptorInbound", C.c_int32, d, jvm.arr(off), 2, fields, voff, bad) == 0
+    f = jvm.read(fields, np.int32, 12).reshape(6, 2)
+    vo = jvm.read(voff, np.int64, 2)
+    assert f[0].tolist() == [wire.MAX_SLOT_REQUEST, wire.BATCH_MAX_SLOT_REQUEST]
+    assert bytes(buf[vo[0]:vo[0] + f[4][0]]) == cid and (f[1][1], f[2][1]) == (5, 7)
+    reply = wire.encode_client_max_slot_reply(bytes(buf[vo[0]:vo[0] + f[4][0]]), 0, 2, read(2))
+    assert reply == bytes([0x22, len(cid) + 2 + 7]) + bytes([0x0a, len(cid)]) + cid + bytes.fromhex("1000" "1802") + bytes([0x20]) + bytes.fromhex("bf20")
+    breply = wire.encode_read_batcher_batch_max_slot_reply(5, 7, 1, read(1))
+    assert breply == bytes.fromhex("22" "09" "0805" "1007" "1801" "20bf20")
+    assert jvm.call("destroy", C.c_int32, h) == 0
+
+
 def _direct(jvm, b):
     d = C.c_void_p(jvm.lib.mock_new_direct(max(1, len(b))))
     if len(b):

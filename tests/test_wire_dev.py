@@ -127,7 +127,11 @@ def odd_messages(rng, n, acceptor):
         for _m in range(int(rng.integers(1, 3))):
             which = int(rng.integers(0, 3))
             if acceptor:
-                num, parts = [(1, ints(2)), (2, phase2a()), (3, [])][which]
+                # (round 5: the read path's members too -- MaxSlotRequest{CommandId{address, pseudonym, id}}, BatchMaxSlotRequest{2 ints})
+                which = int(rng.integers(0, 5))
+                cid = [_field(1, 2, bytes(rng.integers(0, 256, int(rng.integers(0, 24)), dtype=np.uint8)))] + ints(3)[1:]
+                cid = [cid[i] for i in rng.permutation(3)] + [unknown() for _u in range(int(rng.integers(0, 2)))]
+                num, parts = [(1, ints(2)), (2, phase2a()), (9, []), (3, [_field(1, 2, b"".join(cid))]), (4, ints(2))][which]
             else:
                 num, parts = [(1, phase2a()), (2, ints(4)), (7, ints(1))][which]
             parts = parts + [unknown() for _u in range(int(rng.integers(0, 3)))]
@@ -147,7 +151,8 @@ def test_random_ticks_match_the_host_decoder(gpu, wire, which):
     msgs = odd_messages(rng, 20000, which == "acceptor_inbound") + [b""]
     host = (wire.decode_proxy_leader_inbound if which == "proxy_leader_inbound" else wire.decode_acceptor_inbound)(msgs)
     assert host["status"] == 0
-    assert len(set(host["kind"].tolist())) == 3  # Phase2a, the other member, OTHER: all present
+    # Phase2a, the other member(s), OTHER: all present (AcceptorInbound: Phase1a, MaxSlotRequest, BatchMaxSlotRequest)
+    assert len(set(host["kind"].tolist())) == (5 if which == "acceptor_inbound" else 3)
     st, d = dev_decode(gpu, wire, which, msgs, base=7)
     assert st == 0
     same(host, d, PLI if which == "proxy_leader_inbound" else ACC, 7)
