@@ -279,7 +279,8 @@ __global__ void k_dg_publish(const DgArgs a, int round) {
   if (threadIdx.x == 0) a.host[7] = a.seq;  // (call, round): what the host waits for
 }
 
-// the sort key of every vertex: (sum of the closure beyond the columns' executed prefixes) << 2 | kind, kind 0 = on a
+// the sort key of every vertex: 3 x (sum of the closure beyond the columns' executed prefixes) + kind (the sum is at most m,
+// so the key fits ceil(log2(3 m + 4)) bits: 22 at 2^20 commands = TWO 11-bit sort passes; `sum << 2 | kind` took three), kind 0 = on a
 // cycle, 1 = inside its own prefix (explicit ids reach over it) but on no cycle, 2 = neither; ~0 = cannot execute yet
 constexpr int DG_HASH_BITS = 22;
 template <int N>
@@ -338,7 +339,7 @@ __global__ void __launch_bounds__(256) k_dg_keys(const DgArgs a) {
     for (int y = x + 1; y < min(d[L], a.first[L] + a.count[L]); ++y) back = imax(back, a.clo[(size_t)(a.base[L] + y - a.first[L]) * NP + L]);
   }
   const uint32_t kind = back > x ? 0u : (c[L] > x ? 1u : 2u);
-  const uint32_t key = eligible ? ((sum << 2) | kind) : 0xffffffffu;
+  const uint32_t key = eligible ? (sum * 3u + kind) : 0xffffffffu;  // (all ones: behind every executable in the bits that are sorted)
   if (eligible && sum >= (1u << 29)) a.ctl[2] = 1;
   a.key32[v] = key;
   // vertices on cycles with one closure sum can belong to several components: the closure's hash orders them first, so
@@ -374,7 +375,7 @@ __device__ __forceinline__ uint32_t dg_starts(const DgArgs& a, int p, int execut
   constexpr int NP = DgRow<N>::NP;
   if (p >= executables) return 0u;
   const uint2 e = a.pairs[p];
-  if ((e.x & 3u) != 0u || p == 0) return 1u;
+  if (e.x % 3u != 0u || p == 0) return 1u;
   const uint2 f = a.pairs[p - 1];
   if (f.x != e.x) return 1u;
   if (dg_cmp_clo<N>(a, f.y, e.y) == 0) return 0u;

@@ -1657,7 +1657,9 @@ int dg_execute(fpx_epx* e, int m, const int32_t* d_leader, const int32_t* d_numb
     if (rc) return rc;
     if (sorted != a.pairs) std::swap(a.pairs, a.pairs2);
     hipLaunchKernelGGL(k_dg_rekey, dim3(grid), dim3(256), 0, e->stream, a);
-    sorted = radix_sort_pairs(e, 1, m, 24, a.pairs, a.pairs2, nullptr, &rc, nullptr, nullptr);
+    unsigned key_bits = 2;  // the keys are 3 x sum + kind <= 3 m + 2; an inexecutable vertex is all ones: strictly behind them
+    while (((1ull << key_bits) - 1) <= 3ull * (unsigned long long)m + 2) ++key_bits;
+    sorted = radix_sort_pairs(e, 1, m, key_bits, a.pairs, a.pairs2, nullptr, &rc, nullptr, nullptr);
     if (rc) return rc;
     if (sorted != a.pairs) std::swap(a.pairs, a.pairs2);
     // (the number of executables stays on the device: both kernels cover all m positions and leave at once beyond it)

@@ -17,19 +17,32 @@
 // The same natives driven on wire bytes -- two conflicting commands met in different orders, differing PreAcceptOks, the
 // slow path, Accept, AcceptOk, Commit -- against the oracle: tests/test_jni_shim.py::test_an_epaxos_slow_path_commit_...
 //
+// Execution (round 5; ADVICE r04): a committed instance goes through the reference's OWN classes -- a
+// frankenpaxos.depgraph.DependencyGraph[Instance, Int, InstancePrefixSet] (the one ReplicaMain builds, :127), a
+// frankenpaxos.statemachine.StateMachine and a frankenpaxos.clienttable.ClientTable per actor, exactly as
+// Replica.commit / execute / executeCommand use them (:859-960): every hosted replica executes every commit, the
+// instance's leader answers the client (:951-960), a request whose answer is in the client table is answered from it
+// (:1121-1147).  A Commit from a replica outside is recorded in the device's command log and conflict index
+// (Native.epxHandleCommit: Replica.handleCommit :1567-1575) and executed like the others.
+//
 // Scope (DESIGN.md section 8): single-key get / set commands of the key-value store (statemachine/KeyValueStore.scala),
 // top-one dependencies, sequence number 0; the leader-side recovery timers (Replica.scala:1021-1078) stay with a
-// reference Replica if one is wanted -- Prepare / PrepareOk are answered here, not originated.  `leaderStates` (the
+// reference Replica if one is wanted -- Prepare / PrepareOk are answered here, not originated; the answers carry what
+// the reference's handlePrepareOk reads (:1819-1843: sequenceNumber and dependencies of a PreAccepted / Accepted entry,
+// the Commit for a committed one, Replica.nullBallot for an instance never seen).  `leaderStates` (the
 // instances a replica is leading, :1243-1249 "stop leading when a larger ballot arrives") is empty between two bursts
 // here by construction: an instance this actor leads is pre-accepted, accepted if need be and committed inside the
 // flush that proposed it (flushTick checks the f + 1 votes), so a PreAccept in a larger ballot for it finds a
 // CommittedEntry and is answered with the Commit (:1228-1238, K7) -- there is no leader state or timer left to drop.
 package frankenpaxos.gpu
 
+import com.google.protobuf.ByteString
 import frankenpaxos.Actor
 import frankenpaxos.Logger
+import frankenpaxos.clienttable.ClientTable
+import frankenpaxos.depgraph.DependencyGraph
 import frankenpaxos.epaxos._
-import frankenpaxos.statemachine.{GetRequest, KeyValueStoreInput, SetRequest}
+import frankenpaxos.statemachine.{GetRequest, KeyValueStoreInput, SetRequest, StateMachine}
 import scala.collection.mutable
 
 class GpuEPaxosEngine[Transport <: frankenpaxos.Transport[Transport]](
@@ -44,7 +57,12 @@ class GpuEPaxosEngine[Transport <: frankenpaxos.Transport[Transport]](
 
   // a command's triple id is its index here (the GPU carries the int32; Accept and Commit name a triple by it)
   val triples = mutable.ArrayBuffer[CommandOrNoop]()
-  val depsOf = mutable.Map[(Int, Int), Array[Int]]()        // instance -> the dependency watermarks it committed with
+  // instance -> the dependencies it committed with: n watermarks + the end of the own column's explicit ids (0 = none)
+  val depsOf = mutable.Map[(Int, Int), (Array[Int], Int)]()
+  // triple id -> the dependencies an Accept carried (the device names an accepted triple by its id alone)
+  val tripleDeps = mutable.Map[Int, (Array[Int], Int)]()
+  // the actors over this engine: what one of them commits inside its flush the others learn here, not over the transport
+  val actors = mutable.Buffer[GpuEPaxosReplica[Transport]]()
   val nextNumber: Array[Int] = Array.fill(n)(0)             // Replica.nextAvailableInstance, per hosted leader
   private val keyIds = mutable.Map[String, Int]()
   def keyOf(k: String): Int = keyIds.getOrElseUpdate(k, { logger.check(keyIds.size < numKeys); keyIds.size })
@@ -65,7 +83,10 @@ class GpuEPaxosReplica[Transport <: frankenpaxos.Transport[Transport]](
     transport: Transport,
     logger: Logger,
     config: Config[Transport],
-    engine: GpuEPaxosEngine[Transport]
+    engine: GpuEPaxosEngine[Transport],
+    // what epaxos/ReplicaMain.scala hands a Replica (:120-135): this replica's copy of the state machine and its graph
+    stateMachine: StateMachine,
+    dependencyGraph: DependencyGraph[Instance, Int, InstancePrefixSet]
 ) extends Actor(address, transport, logger) {
   override type InboundMessage = ReplicaInbound
   override val serializer = ReplicaInboundSerializer
@@ -74,11 +95,54 @@ class GpuEPaxosReplica[Transport <: frankenpaxos.Transport[Transport]](
   private val index = config.replicaAddresses.indexOf(address)
   logger.check(index >= 0)
   private val replicas = for (a <- config.replicaAddresses) yield chan[Replica[Transport]](a, Replica.serializer)
+  engine.actors += this
+
+  // ---- execution: Replica.commit's tail, execute and executeCommand (epaxos/Replica.scala:859-960) on the reference's classes
+  implicit private val addressSerializer = transport.addressSerializer
+  private val clientTable = ClientTable[(Transport#Address, Int), Array[Byte]]()
+  private val committed = mutable.Map[Instance, CommandOrNoop]()       // CommittedEntry.triple.commandOrNoop, until executed
+  private val executables = mutable.Buffer[Instance]()
+  private val blockers = mutable.Set[Instance]()
+
+  // every actor of the process learns every commit: from its own flush, from another hosted actor's, or from a Commit message
+  def learnCommit(instance: Instance, commandOrNoop: CommandOrNoop, dependencies: InstancePrefixSetProto): Unit = {
+    if (committed.contains(instance)) return                            // a re-sent Commit
+    committed(instance) = commandOrNoop
+    dependencyGraph.commit(instance, 0, InstancePrefixSet.fromProto(dependencies))       // :866-868
+  }
+  def executeGraph(): Unit = {                                           // :883-917
+    dependencyGraph.appendExecute(None, executables, blockers)
+    for (i <- executables) {
+      committed.remove(i) match {
+        case None                => logger.fatal(s"Instance $i is ready for execution but was never committed here.")
+        case Some(commandOrNoop) => executeCommand(i, commandOrNoop)
+      }
+    }
+    executables.clear(); blockers.clear()
+  }
+  private def executeCommand(instance: Instance, commandOrNoop: CommandOrNoop): Unit = commandOrNoop.value match {   // :919-965
+    case CommandOrNoop.Value.Empty   => logger.fatal("Empty CommandOrNoop.")
+    case CommandOrNoop.Value.Noop(_) => ()
+    case CommandOrNoop.Value.Command(Command(clientAddressBytes, clientPseudonym, clientId, command)) =>
+      val clientAddress = transport.addressSerializer.fromBytes(clientAddressBytes.toByteArray)
+      val clientIdentity = (clientAddress, clientPseudonym)
+      clientTable.executed(clientIdentity, clientId) match {
+        case ClientTable.Executed(_) => ()                               // never execute a command twice
+        case ClientTable.NotExecuted =>
+          val output = stateMachine.run(command.toByteArray)
+          clientTable.execute(clientIdentity, clientId, output)
+          if (index == instance.replicaIndex)                            // the instance's leader answers the client
+            chan[Client[Transport]](clientAddress, Client.serializer).send(
+              ClientInbound().withClientReply(ClientReply(clientPseudonym = clientPseudonym, clientId = clientId,
+                                                          result = ByteString.copyFrom(output))))
+      }
+  }
 
   private val requests = mutable.Buffer[(Transport#Address, ClientRequest)]()
   private val preAccepts = mutable.Buffer[(Transport#Address, PreAccept)]()
   private val accepts = mutable.Buffer[(Transport#Address, Accept)]()
   private val prepares = mutable.Buffer[(Transport#Address, Prepare)]()
+  private val commits = mutable.Buffer[Commit]()
   private var queued = 0
   private val tick = timer("gpuEPaxosTick", java.time.Duration.ZERO, () => flushTick())
   private def enqueue[T](q: mutable.Buffer[T], x: T): Unit = { if (queued == 0) tick.start(); q += x; queued += 1 }
@@ -86,11 +150,21 @@ class GpuEPaxosReplica[Transport <: frankenpaxos.Transport[Transport]](
   override def receive(src: Transport#Address, inbound: ReplicaInbound): Unit = {
     import ReplicaInbound.Request
     inbound.request match {
-      case Request.ClientRequest(r) => enqueue(requests, (src, r))
+      case Request.ClientRequest(r) =>
+        // Replica.handleClientRequest (:1121-1147): an answer that is already in the client table is relayed, a stale
+        // request ignored; everything else is led in the next flush
+        clientTable.executed((src, r.command.clientPseudonym), r.command.clientId) match {
+          case ClientTable.NotExecuted    => enqueue(requests, (src, r))
+          case ClientTable.Executed(None) => ()
+          case ClientTable.Executed(Some(output)) =>
+            chan[Client[Transport]](src, Client.serializer).send(
+              ClientInbound().withClientReply(ClientReply(clientPseudonym = r.command.clientPseudonym,
+                                                          clientId = r.command.clientId, result = ByteString.copyFrom(output))))
+        }
       case Request.PreAccept(r)     => enqueue(preAccepts, (src, r))
       case Request.Accept(r)        => enqueue(accepts, (src, r))
       case Request.Prepare(r)       => enqueue(prepares, (src, r))
-      case Request.Commit(_)        => ()   // a hosted replica's log already holds what the tick committed
+      case Request.Commit(r)        => enqueue(commits, r)   // from a replica outside this process (Replica.handleCommit :1567)
       case Request.PreAcceptOk(_) | Request.AcceptOk(_) | Request.PrepareOk(_) | Request.Nack(_) =>
         // replies to a leader role: between hosted replicas they never leave the device; from a replica outside, they
         // belong to a reference Replica that originated the round (see the scope note above)
@@ -140,12 +214,34 @@ class GpuEPaxosReplica[Transport <: frankenpaxos.Transport[Transport]](
       // commit (:815-860): every replica outside this process learns it; the hosted ones already hold the CommittedEntry
       for (i <- 0 until m) {
         val w = deps.slice(i * n, (i + 1) * n)
-        engine.depsOf((index, number(i))) = w
+        engine.depsOf((index, number(i))) = (w, ends(2 * i))
         val commit = Commit(instance = Instance(index, number(i)), commandOrNoop = engine.triples(first + i), sequenceNumber = 0,
                             dependencies = prefixSet(w, index, ends(2 * i), number(i)))
         for ((a, r) <- config.replicaAddresses.zipWithIndex if !hosted(a)) replicas(r).send(ReplicaInbound().withCommit(commit))
+        engine.actors.foreach(_.learnCommit(commit.instance, commit.commandOrNoop, commit.dependencies))
       }
       requests.clear()
+      engine.actors.foreach(_.executeGraph())   // :869-873 with executeGraphBatchSize = the burst
+    }
+    // ---- Commits from replicas outside (Replica.handleCommit :1567-1575): the device's command log and conflict index at
+    // THIS replica learn them (a later Prepare / PreAccept for the instance is answered with the Commit), then the graph
+    if (commits.nonEmpty) {
+      val k = commits.size
+      val keyset = commits.map(c => if (c.commandOrNoop.value.isNoop) (-1, false) else engine.classify(c.commandOrNoop.getCommand))
+      val first = engine.triples.size; commits.foreach(c => engine.triples += c.commandOrNoop)
+      val own = commits.map(c => c.dependencies.intPrefixSet(c.instance.replicaIndex).value)
+      val endsIn = own.map(v => if (v.isEmpty) 0 else v.max + 1).toArray
+      Native.check(Native.epxHandleCommit(engine.handle, k, n, commits.map(_.instance.replicaIndex).toArray,
+                                          commits.map(_.instance.instanceNumber).toArray, Array.tabulate(k)(first + _),
+                                          keyset.map(_._1).toArray, keyset.map(x => (if (x._2) 1 else 0).toByte).toArray,
+                                          commits.flatMap(c => watermarks(c.dependencies)).toArray, endsIn,
+                                          Array.fill(k)(bit(index))), logger)
+      for ((c, i) <- commits.zipWithIndex) {
+        engine.depsOf((c.instance.replicaIndex, c.instance.instanceNumber)) = (watermarks(c.dependencies), endsIn(i))
+        learnCommit(c.instance, c.commandOrNoop, c.dependencies)
+      }
+      commits.clear()
+      executeGraph()
     }
     // ---- PreAccepts from replicas outside (a leader's re-sent PreAccept, a recovering replica's): Replica.handlePreAccept
     // in full (:1159-1289) at THIS replica; Nack / PreAcceptOk / Commit back to the sender
@@ -171,9 +267,10 @@ class GpuEPaxosReplica[Transport <: frankenpaxos.Transport[Transport]](
           back.send(ReplicaInbound().withPreAcceptOk(PreAcceptOk(p.instance, p.ballot, index, 0,
             prefixSet(w, p.instance.replicaIndex, ret(i * n + index), p.instance.instanceNumber))))
         } else if ((replies(3 * k + i) & bit(index)) != 0)                                      // :1228-1238 the Commit back
-          engine.depsOf.get((p.instance.replicaIndex, p.instance.instanceNumber)).foreach(w =>
+          engine.depsOf.get((p.instance.replicaIndex, p.instance.instanceNumber)).foreach { case (w, end) =>
             back.send(ReplicaInbound().withCommit(Commit(p.instance, engine.triples(ret(k * n + i * n + index)), 0,
-                                                         prefixSet(w, p.instance.replicaIndex, 0, p.instance.instanceNumber)))))
+                                                         prefixSet(w, p.instance.replicaIndex, end, p.instance.instanceNumber))))
+          }
       }
       preAccepts.clear()
     }
@@ -182,6 +279,10 @@ class GpuEPaxosReplica[Transport <: frankenpaxos.Transport[Transport]](
       val k = accepts.size; val as = accepts.map(_._2)
       val keyset = as.map(a => if (a.commandOrNoop.value.isNoop) (-1, false) else engine.classify(a.commandOrNoop.getCommand))
       val first = engine.triples.size; as.foreach(a => engine.triples += a.commandOrNoop)
+      for ((a, i) <- as.zipWithIndex) {   // the device keeps an accepted triple by its id: its dependencies stay here
+        val v = a.dependencies.intPrefixSet(a.instance.replicaIndex).value
+        engine.tripleDeps(first + i) = (watermarks(a.dependencies), if (v.isEmpty) 0 else v.max + 1)
+      }
       val replies = new Array[Byte](4 * k); val nb = new Array[Int](k)
       Native.check(Native.epxAccept(engine.handle, k, as.map(_.instance.replicaIndex).toArray, as.map(_.instance.instanceNumber).toArray,
                                     as.map(_.ballot.ordering).toArray, as.map(_.ballot.replicaIndex).toArray, Array.tabulate(k)(first + _),
@@ -202,13 +303,36 @@ class GpuEPaxosReplica[Transport <: frankenpaxos.Transport[Transport]](
                                      replies, nb, ok), logger)
       for (((src, p), i) <- prepares.zipWithIndex) {
         val back = chan[Replica[Transport]](src, Replica.serializer)
+        val L = p.instance.replicaIndex; val x = p.instance.instanceNumber
         if ((replies(k + i) & bit(index)) != 0) back.send(ReplicaInbound().withNack(Nack(p.instance, Ballot(nb(i) >> 3, nb(i) & 7))))
-        else if ((replies(i) & bit(index)) != 0) {
+        else if ((replies(2 * k + i) & bit(index)) != 0) {
+          // :1746-1756 a CommittedEntry: "No need to run the protocol" -- the Commit goes back
+          val entry = new Array[Int](6 + n)
+          Native.check(Native.epxReadCmdlog(engine.handle, n, index, L, x, entry), logger)
+          engine.depsOf.get((L, x)).foreach { case (w, end) =>
+            back.send(ReplicaInbound().withCommit(Commit(p.instance, engine.triples(entry(3)), 0, prefixSet(w, L, end, x))))
+          }
+        } else if ((replies(i) & bit(index)) != 0) {
           val status = ok(i * n + index); val vote = ok(k * n + i * n + index); val triple = ok(2 * k * n + i * n + index)
+          // the entry's triple: its dependencies are in the command log (what THIS replica answered the PreAccept with), or
+          // -- an entry an Accept wrote names its triple by id -- with the engine (tripleDeps)
+          val seen = status != 0 && triple >= 0
+          val deps: Option[InstancePrefixSetProto] =
+            if (!seen) None
+            else {
+              val entry = new Array[Int](6 + n)
+              Native.check(Native.epxReadCmdlog(engine.handle, n, index, L, x, entry), logger)
+              val (w, end) = if (entry(5) >= 0) (entry.slice(5, 5 + n), entry(5 + n))
+                             else engine.tripleDeps.getOrElse(triple, engine.depsOf.getOrElse((L, x), (Array.fill(n)(0), 0)))
+              Some(prefixSet(w, L, end, x))
+            }
           back.send(ReplicaInbound().withPrepareOk(PrepareOk(
-            ballot = p.ballot, instance = p.instance, replicaIndex = index, voteBallot = Ballot(vote >> 3, vote & 7),
-            status = status match { case 0 => CommandStatus.NotSeen; case 2 => CommandStatus.PreAccepted; case _ => CommandStatus.Accepted },
-            commandOrNoop = if (triple >= 0) Some(engine.triples(triple)) else None)))
+            ballot = p.ballot, instance = p.instance, replicaIndex = index,
+            voteBallot = if (vote < 0) Replica.nullBallot else Ballot(vote >> 3, vote & 7),       // (-1, -1), Replica.scala:256
+            status = status match { case 0 | 1 => CommandStatus.NotSeen; case 2 => CommandStatus.PreAccepted; case _ => CommandStatus.Accepted },
+            commandOrNoop = if (seen) Some(engine.triples(triple)) else None,
+            sequenceNumber = if (seen) Some(0) else None,                                          // :1711-1737
+            dependencies = deps)))
         }
       }
       prepares.clear()

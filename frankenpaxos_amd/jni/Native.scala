@@ -110,6 +110,10 @@ object Native {
                         ballotOrdering: Array[Int], ballotReplica: Array[Int], tripleId: Array[Int],
                         key: Array[Int], isSet: Array[Byte],
                         targetMask: Array[Byte], replies: Array[Byte], nackBallot: Array[Int]): Int
+  // Replica.handleCommit at the replicas of targetMask: deps m x n + depsValuesEnd m, or both null (triple by id alone)
+  @native def epxHandleCommit(handle: Long, m: Int, numReplicas: Int, leader: Array[Int], number: Array[Int],
+                              tripleId: Array[Int], key: Array[Int], isSet: Array[Byte], deps: Array[Int],
+                              depsValuesEnd: Array[Int], targetMask: Array[Byte]): Int
   @native def epxHandlePreaccept(handle: Long, m: Int, numReplicas: Int, leader: Array[Int],
                                  number: Array[Int], ballotOrdering: Array[Int],
                                  ballotReplica: Array[Int], key: Array[Int], isSet: Array[Byte],

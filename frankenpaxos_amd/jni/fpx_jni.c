@@ -464,6 +464,29 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxAccept(JNIEnv* env, jclas
   return st;
 }
 
+/* Replica.handleCommit at the replicas of targetMask (fpx_epx_handle_commit): key -1 = Noop; deps m x n with depsValuesEnd m,
+ * or both null (the triple by its id alone) */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxHandleCommit(JNIEnv* env, jclass cls, jlong h, jint m, jint numReplicas,
+                                                                    jintArray leader, jintArray number, jintArray tripleId,
+                                                                    jintArray key, jbyteArray isSet, jintArray deps,
+                                                                    jintArray depsValuesEnd, jbyteArray targetMask) {
+  if (m < 0 || numReplicas < 3 || !epx_n_is(h, numReplicas)) return FPX_EINVAL;
+  if (m == 0) return FPX_OK;
+  const jlong mn = (jlong)m * numReplicas;
+  if (!has(env, leader, m) || !has(env, number, m) || !has(env, tripleId, m) || !has(env, key, m) || !has(env, isSet, m) ||
+      !opt(env, deps, mn) || !opt(env, depsValuesEnd, m) || !has(env, targetMask, m) || (depsValuesEnd && !deps))
+    return FPX_EINVAL;
+  jint *l = in_ints(env, leader, m), *nu = in_ints(env, number, m), *tr = in_ints(env, tripleId, m), *k = in_ints(env, key, m);
+  jint* d = deps ? in_ints(env, deps, mn) : NULL;
+  jint* de = depsValuesEnd ? in_ints(env, depsValuesEnd, m) : NULL;
+  jbyte *is = in_bytes(env, isSet, m), *tg = in_bytes(env, targetMask, m);
+  int32_t st = (!l || !nu || !tr || !k || !is || !tg || (deps && !d) || (depsValuesEnd && !de))
+                   ? FPX_ENOMEM
+                   : fpx_epx_handle_commit((fpx_epx*)(intptr_t)h, m, l, nu, tr, k, (const uint8_t*)is, d, de, (const uint8_t*)tg);
+  free(l); free(nu); free(tr); free(k); free(d); free(de); free(is); free(tg);
+  return st;
+}
+
 /* key -1 = Noop; depsIn m x n, depsInValuesEnd m (may be null); replies = okBits | resendBits | nackBits | commitBits
  * (4 x m bytes); replyDeps m x n x n, replyEndTriple = valuesEnd | tripleId (2 x m x n ints) */
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxHandlePreaccept(

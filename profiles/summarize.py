@@ -64,6 +64,24 @@ with open(os.path.join(out, tag + "_pmc_summary.md"), "w") as f:
             % (k2["Name"].split("(")[0], k2["Calls"], float(k2["AverageNs"]) / 1e3, float(k2["MinNs"]) / 1e3,
                float(k2["MaxNs"]) / 1e3, bench["roofline"]["avg_kernel_ms"] * 1e3,
                bench["roofline"]["launches_timed"], tag))
+    # the same kernel instantiation is also launched by the line's `configs` block (configs.host_path: beside staging kernels on
+    # other streams, so slower): the headline's launches are the first warmup + steps of the trace, in order
+    tr = os.path.join(base, "trace", "bench_kernel_trace.csv")
+    if os.path.exists(tr):
+        name = k2["Name"].split("(")[0].replace("void ", "")
+        rows_ = sorted((r for r in csv.DictReader(open(tr)) if name in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows_]
+        W, K = bench["warmup"], bench["steps"]
+        t = d[W:W + K]
+        if len(t) == K:
+            mean = sum(t) / K
+            sd = (sum((x - mean) ** 2 for x in t) / K) ** 0.5
+            f.write("Of those calls the first %d are the headline's (%d warm-up + %d timed, in trace order); the TIMED %d: average "
+                    "**%.1f us** (min %.1f, max %.1f, sigma %.1f = %.2f %%) -- the figure that has to agree with the HIP-event "
+                    "average above.  The other %d calls belong to the line's `configs` block (`host_path` runs this kernel beside "
+                    "its staging kernels: average %.1f us).\n\n"
+                    % (W + K, W, K, K, mean, min(t), max(t), sd, 100 * sd / mean, len(d) - W - K,
+                       (sum(d[W + K:]) / max(1, len(d) - W - K))))
     f.write("## Counter calibration on known byte counts (profiles/microbench/hbm_mix.hip, 1 GiB per stream)\n\n")
     f.write("| kernel | KiB read | FETCH_SIZE | KiB written | WRITE_SIZE |\n|---|---|---|---|---|\n")
     f.write("| k_mix<1,0> read | 1,048,576 | %.0f | 0 | %.0f |\n" % (f_read, pick(cal_w, "k_mix<1, 0, false, 4>")))

@@ -276,6 +276,21 @@ def test_epaxos_command_log_through_the_shim(jvm, oracle):
         assert tuple(got[:5]) == ref.read_cmdlog(r, 1, 3)
         deps, end = ref.read_cmdlog_deps(r, 1, 3)
         assert got[5:5 + n].tolist() == deps.tolist() and got[5 + n] == end
+    # a Commit from a replica outside (GpuEPaxosReplica's Request.Commit branch -> Native.epxHandleCommit): recorded at ONE
+    # replica, with its dependencies; then by triple id alone at another; a short array is refused
+    assert jvm.call("epxHandleCommit", C.c_int32, h, 2, n, i32([2, 0]), i32([7, 1]), i32([90, 91]), i32([3, -1]), i8([0, 0]),
+                    i32([1, 0, 5, 0, 2, 0, 0, 0, 0, 0]), i32([10, 0]), i8([0b01000, 0b00011])) == 0
+    assert ref.handle_commit([2, 0], [7, 1], [90, 91], [0b01000, 0b00011], key=[3, -1], is_set=[0, 0],
+                             deps=[[1, 0, 5, 0, 2], [0, 0, 0, 0, 0]], deps_values_end=[10, 0]) == 0
+    assert jvm.call("epxHandleCommit", C.c_int32, h, 1, n, i32([3]), i32([2]), i32([92]), i32([1]), i8([1]), None, None, i8([0b10000])) == 0
+    assert ref.handle_commit([3], [2], [92], [0b10000], key=[1], is_set=[1]) == 0
+    for r, L, x in ((3, 2, 7), (0, 0, 1), (1, 0, 1), (4, 3, 2), (2, 2, 7)):
+        assert jvm.call("epxReadCmdlog", C.c_int32, h, n, r, L, x, entry) == 0
+        got = jvm.read(entry, np.int32, 6 + n)
+        assert tuple(got[:5]) == ref.read_cmdlog(r, L, x)
+        deps, end = ref.read_cmdlog_deps(r, L, x)
+        assert got[5:5 + n].tolist() == deps.tolist() and got[5 + n] == end
+    assert jvm.call("epxHandleCommit", C.c_int32, h, 2, n, i32([3]), i32([2]), i32([92]), i32([1]), i8([1]), None, None, i8([0b10000])) == 1
     assert jvm.call("epxDestroy", C.c_int32, h) == 0
 
 
