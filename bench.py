@@ -295,7 +295,7 @@ def main():
     ap.add_argument("--validate", action="store_true",
                     help="keep the run-contract validation kernel in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", choices=["headline", "2", "3", "4", "5", "thrifty", "thrifty_random", "acceptor_model", "host_path", "adversarial"], default="headline",
+    ap.add_argument("--config", choices=["headline", "2", "3", "4", "5", "thrifty", "thrifty_random", "acceptor_model", "host_path", "adversarial", "4_execute"], default="headline",
                     help="headline = BASELINE.json's metric grid (2^20 slots x 256 acceptors); 2..5 = the other "
                          "BASELINE.json configs as bench lines of the same schema (bench_configs.py)")
     ap.add_argument("--configs-block-steps", type=int, default=20,
@@ -451,10 +451,12 @@ def main():
     fence()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    launches, kernel_ms = ctx.profile_read()
+    per_launch = ctx.profile_read_launches()
+    launches, kernel_ms = len(per_launch), float(sum(per_launch))
     coll_n, coll_ms = ctx.profile_read_collective()
     assert ctx.sync() == 0
     hbm_bytes = ctx.device_bytes
+    placement = ctx.placement_stats()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         all_reduce(t, dist.ReduceOp.MAX)
@@ -523,11 +525,11 @@ def main():
         configs_block = {}
         # BASELINE.json's configs 2-5, the two thrifty deliveries, and what SURVEY.md 8(d) asks for beside the headline: the
         # reference's actual acceptor model, the host-pointer path end to end, the adversarial stream at full size
-        for c in ("2", "3", "4", "5", "thrifty", "thrifty_random", "acceptor_model", "host_path", "adversarial"):
+        for c in ("2", "3", "4", "4_execute", "5", "thrifty", "thrifty_random", "acceptor_model", "host_path", "adversarial"):
             t_c = time.perf_counter()
             try:
                 # config 4's ticks are drawn on the host (~0.5 s each): half as many of them
-                sub = types.SimpleNamespace(steps=max(1, args.configs_block_steps // 2) if c in ("4", "thrifty_random", "host_path") else args.configs_block_steps,
+                sub = types.SimpleNamespace(steps=max(1, args.configs_block_steps // 2) if c in ("4", "4_execute", "thrifty_random", "host_path") else args.configs_block_steps,
                                             warmup=2, ballot=args.ballot, config=c, no_cpu_baseline=True)
                 full = bench_configs.run(sub, fa, None, dev, 0, 1, local_rank, all_reduce)
                 configs_block[c] = {
@@ -589,6 +591,10 @@ def main():
                 "ballot_model": args.ballot, "sharding": args.shard if world > 1 else "none",
                 "run_contract_validation_in_timed_region": bool(args.validate),
                 "log_windows_in_hbm": windows, "hbm_bytes": hbm_bytes,
+                # how fpx_create placed the cell arrays (profiles/r05_placement.md): chunks paired by measurement, and the hot
+                # access pattern's time on half a window, min / median / max over the windows
+                "placement": {"chunks_paired_by_measurement": placement["chunks"], "windows": placement["windows"],
+                              "probe_ms_min_median_max": list(placement["probe_ms"])},
                 "steps_reproposing_old_slots": sum(1 for i in range(Wm, Wm + K) if i // windows > 0),
             },
             "roofline": {
@@ -608,6 +614,11 @@ def main():
                                   "measured in this run",
                 "algorithmic_bytes_per_slot": bps, "slots_per_launch": slots_per_launch,
                 "avg_kernel_ms": kernel_ms / max(launches, 1), "launches_timed": launches,
+                "kernel_ms_min_max_sigma": ([min(per_launch), max(per_launch), float(np.std(per_launch))] if per_launch else None),
+                # SURVEY.md 8(d)'s read-only accounting against north_star's ">= 40 % HBM-read roofline": the byte model has 2056 B
+                # written per 1032 B read, so even a kernel that moved its bytes at the full 8 TB/s would read at 1032 / 3088 of
+                # it -- frac_read cannot exceed 0.334 on this workload
+                "frac_read_cap": read_bytes_per_slot(ballot_mode) / algorithmic_bytes_per_slot(ballot_mode),
                 "kernel_time_source": "HIP events on the vote kernel's own dispatch packet (hipExtLaunchKernelGGL start / stop "
                                       "events on the context's stream; fpx_profile_*), every timed launch",
                 # what bare streaming kernels reach on this chip (profiles/microbench/hbm_mix.hip, best of the

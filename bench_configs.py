@@ -318,6 +318,75 @@ def epaxos_setup(fa, dev, local_rank, K, Wm):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# 4_execute: what a configs[3] tick commits, through dependency-graph execution on the device
+# ------------------------------------------------------------------------------------------------------------------
+def epaxos_execute_setup(fa, dev, local_rank, K, Wm, fifo=True):
+    from frankenpaxos_amd.epaxos import EPaxos
+    from tests import workloads as W
+    from tests.workloads import random_tick
+
+    n, num_keys, m = 5, 1024, 1 << 20
+    epx = EPaxos(n, num_keys, device=local_rank)
+    epx.set_stream(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(45)
+    nxt = [0] * n
+    leader, number, key, is_set, mask, rank = random_tick(rng, n, num_keys, m, nxt, 64.0, fifo=fifo)
+    key = (W.splitmix64_at(np.arange(m, dtype=np.uint64)) % np.uint64(num_keys)).astype(np.int32)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    dl, dn = d(leader), d(number)
+    packed = torch.zeros((m, epx.packed_stride()), dtype=torch.int32, device=dev)
+    epx.preaccept_packed_dev(dl, dn, d(key), d(is_set), d(mask), d(rank), packed)     # the tick (K5): every command is decided
+    assert epx.sync() == 0
+    order = torch.full((m,), -1, dtype=torch.int32, device=dev)
+    comp = torch.full((m,), -1, dtype=torch.int32, device=dev)
+    first, count = np.zeros(n, np.int32), np.asarray(nxt, np.int32)
+    results = []
+
+    def step(i):
+        results.append(epx.execute_dev(dl, dn, packed, first, count, order, comp))
+
+    def verify(lo, hi):
+        from tests.test_epaxos import check_execution_order
+        for ne, nc, nh in results:
+            assert ne == m and nh == 0 and 0 < nc <= m, (ne, nc, nh)
+        fast, deps, ldeps, own = (x.cpu().numpy() for x in epx.unpack(packed))
+        o = order.cpu().numpy()
+        # a valid execution order of the whole tick: every instance once, no component before one it depends on
+        check_execution_order(n, leader, number, deps, own[:, 0], leader[o], number[o], np.bincount(comp.cpu().numpy()))
+        return (hi - lo) * m
+
+    def cpu():
+        from frankenpaxos_amd import depgraph as P
+        mm = 1 << 17
+        fast, deps, ldeps, own = (x.cpu().numpy() for x in epx.unpack(packed))
+        sel = np.zeros(m, bool)
+        for L in range(n):                                   # a dense prefix of every column: 2^17 instances in all
+            idx = np.nonzero(leader == L)[0]
+            sel[idx[number[idx] < mm // n]] = True
+        g = P.DependencyGraph(n, kind=P.FPX_DG_ZIGZAG)
+        t0 = time.perf_counter()
+        g.commit_epx(leader[sel], number[sel], np.minimum(deps[sel], mm // n), own[sel] * 0)
+        out = g.execute_arrays()
+        dt = time.perf_counter() - t0
+        return {"value": int(sel.sum()) / dt, "unit": "commands/s", "cores": 1, "kind": "port",
+                "sample": "csrc/fpx_depgraph.cpp (the library's HOST graph, a C++ restatement of ZigzagTarjanDependencyGraph.scala held to "
+                          "the reference's test vectors), the first %d instances of the tick, 1 thread" % int(sel.sum())}
+
+    # per command, what must cross HBM: the instance (8 B) and its packed line (64 B) in, its place and component out (8 B)
+    return dict(ctx=epx, step=step, verify=verify, units=m, unit="commands/s", bytes_per_unit=80,
+                workload="EPaxos n = 5: what one tick of 2^20 single-key commands (1024 keys) commits -- every command with its agreed "
+                         "dependencies -- through dependency-graph execution ON THE DEVICE (fpx_epx_execute_dev: strongly connected "
+                         "components in reverse topological order, depgraph/TarjanDependencyGraph.scala:225-276); one step = the whole "
+                         "tick executed (the same tick every step), the call ends with the counts on the host",
+                kernel="closure rounds on 16-byte rows (k_dp_relax + k_dp_carry), k_dp_keys, two LSD radix sorts, k_dp_count_starts, k_dp_emit "
+                       "(csrc/fpx_depgraph_pk.hpp)", region_timed=True,
+                metric="EPaxos commands executed/sec (dependency-graph execution of a BASELINE.json configs[3] tick's commits)", cpu=cpu,
+                extra={"commands_per_tick": m, "replicas": n, "keys": num_keys, "channels": "fifo" if fifo else "reordering",
+                       "byte_model": "8 B instance + 64 B packed line in, 8 B (position, component) out per command; the closure rounds' "
+                                     "traffic (128 B per vertex and round, 4 - 7 rounds) is the algorithm's own"})
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # config 5: Mencius bands -- commands from half of the leader groups, noop ranges from the other half
 # ------------------------------------------------------------------------------------------------------------------
 def mencius_setup(fa, dev, local_rank, rank, world, K, Wm):
@@ -613,6 +682,8 @@ def run(args, fa, dist, dev, rank, world, local_rank, all_reduce):
         w = multipaxos_setup(fa, dev, local_rank, ballot_mode, args.config, K, Wm)
     elif args.config == "4":
         w = epaxos_setup(fa, dev, local_rank, K, Wm)
+    elif args.config == "4_execute":
+        w = epaxos_execute_setup(fa, dev, local_rank, K, Wm)
     elif args.config in ("thrifty", "thrifty_random"):
         w = thrifty_setup(fa, dev, local_rank, ballot_mode, K, Wm, random_targets=args.config == "thrifty_random")
     else:
@@ -665,7 +736,8 @@ def run(args, fa, dist, dev, rank, world, local_rank, all_reduce):
         "config": dict({"workload": w["workload"], "baseline_config": int(args.config) if args.config.isdigit() else args.config,
                         "verified": "every timed step checked after the timed region" +
                                     (": first timed tick == the CPU oracle on every output, all ticks by path counts"
-                                     if args.config == "4" else ": every slot chosen with its proposed value")},
+                                     if args.config == "4" else ": every instance executed once, in an order in which no component "
+                                     "precedes one it depends on" if args.config == "4_execute" else ": every slot chosen with its proposed value")},
                        **w["extra"]),
         "roofline": {
             "bound": "hbm", "kernel": w["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

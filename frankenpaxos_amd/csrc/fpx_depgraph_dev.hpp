@@ -59,6 +59,7 @@ struct DgArgs {
                                     // [8 + k] something moved in round k of the chunk of rounds being enqueued
   volatile int32_t* host;           // page-locked mirror of ctl (8 ints) + [7] = seq
   int32_t seq;
+  int32_t count_moved;              // debug: count the vertices a round moves into ctl[24 + k]
   int32_t* order;                   // [m] message indices in execution order
   int32_t* comp;                    // [m] component number of position p (0, 1, ..)
 };
@@ -260,6 +261,10 @@ __global__ void __launch_bounds__(256) k_dg_relax(const DgArgs a, int r, int k) 
     }
   }
   if (__any(moved) && (threadIdx.x & 63) == 0 && a.ctl[8 + k] == 0) a.ctl[8 + k] = 1;
+  if (a.count_moved) {  // FPX_DG_DEBUG: how many vertices each round moves
+    const unsigned long long bal = __ballot(moved);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&a.ctl[24 + k], (int)__popcll(bal));
+  }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int l = 0; l < NP; ++l) {

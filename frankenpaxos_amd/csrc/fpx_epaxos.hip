@@ -650,6 +650,7 @@ __global__ void __launch_bounds__(256) k_epx_decide(const EpxState st, const Epx
 
 #include "fpx_epaxos_kp.hpp"
 #include "fpx_depgraph_dev.hpp"
+#include "fpx_depgraph_pk.hpp"
 
 // ---- scan + decide of ONE key on chip ------------------------------------------------------------------------
 // k_epx_scan hands every (command, replica) conflict row to k_epx_decide through HBM at [command][replica]: n * m
@@ -1582,6 +1583,115 @@ int launch_kp(fpx_epx* e, const EpxBatch& b, int32_t* d_packed, bool* done) {
   return FPX_OK;
 }
 
+// the packed path of the device dependency graph (fpx_depgraph_pk.hpp): n <= 5, columns of fewer than 2^21 - 2 instances
+template <int N>
+int dg_execute_packed(fpx_epx* e, int m, const int32_t* d_leader, const int32_t* d_number, const int32_t* d_packed, const uint8_t* d_mask,
+                      const int32_t* first, const int32_t* count, int32_t* d_order, int32_t* d_comp, int64_t* nexec, int64_t* ncomp,
+                      int32_t* needs_host) {
+  static_assert(N <= 5, "five 21-bit watermarks per 16-byte row");
+  DpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.m = m, a.n = N, a.stride = fpx_epx_packed_stride(N);
+  long long total = 0;
+  for (int l = 0; l < N; ++l) {
+    a.first[l] = first[l], a.count[l] = count[l], a.base[l] = (int32_t)total;
+    a.nblk[l] = (count[l] + 255) / 256, a.blk_base[l] = a.nblocks;
+    a.nblocks += a.nblk[l], total += count[l];
+  }
+  for (int l = N; l < 8; ++l) a.base[l] = (int32_t)total, a.blk_base[l] = a.nblocks;
+  int rc;
+  const int out_tiles = (m + DG_TILE - 1) / DG_TILE;
+  const size_t nb = (size_t)std::max(a.nblocks, 1);
+  if ((rc = grow(e, &e->dg_msg, (size_t)m * 4))) return rc;
+  if ((rc = grow(e, &e->dg_direct, (size_t)m * 16))) return rc;
+  if ((rc = grow(e, &e->dg_clo, (size_t)m * 16))) return rc;
+  if ((rc = grow(e, &e->dg_pre, (size_t)m * 32))) return rc;
+  if ((rc = grow(e, &e->dg_tmax, nb * 16 * 4 + (size_t)out_tiles * 4 + 64))) return rc;
+  if ((rc = grow(e, &e->dg_pairs, (size_t)m * 8))) return rc;
+  if ((rc = grow(e, &e->dg_pairs2, (size_t)m * 8))) return rc;
+  if ((rc = grow(e, &e->dg_key, (size_t)m * 4))) return rc;
+  if ((rc = grow(e, &e->dg_ctl, 256))) return rc;
+  if (!e->kp_flag_dev) return FPX_EHIP;
+  a.leader = d_leader, a.number = d_number, a.packed = d_packed, a.mask = d_mask;
+  a.msg_of = (int32_t*)e->dg_msg.p, a.direct = (ulonglong2*)e->dg_direct.p, a.clo = (ulonglong2*)e->dg_clo.p;
+  a.lp[0] = (ulonglong2*)e->dg_pre.p, a.lp[1] = a.lp[0] + m;
+  a.bt[0] = (ulonglong2*)e->dg_tmax.p, a.bt[1] = a.bt[0] + nb, a.cy[0] = a.bt[1] + nb, a.cy[1] = a.cy[0] + nb;
+  a.tstarts = (int32_t*)(a.cy[1] + nb);
+  a.pairs = (uint2*)e->dg_pairs.p, a.pairs2 = (uint2*)e->dg_pairs2.p, a.ctl = (int32_t*)e->dg_ctl.p;
+  a.key32 = (uint32_t*)e->dg_key.p;
+  a.host = reinterpret_cast<volatile int32_t*>(e->kp_flag_dev + 8);
+  a.order = d_order, a.comp = d_comp;
+  volatile int32_t* host = reinterpret_cast<volatile int32_t*>(e->kp_flag + 8);
+  const int call = (++e->dg_seq) & 0xffff;
+  a.count_moved = getenv("FPX_DG_DEBUG") ? 1 : 0;
+  auto wait_for = [&](int round) -> int {
+    const int32_t want = call * 64 + round;
+    for (long spin = 0; spin < 400000000L; ++spin) {
+      if (host[7] == want) return FPX_OK;
+      if ((spin & 0xfffff) == 0xfffff) {
+        const hipError_t q = hipStreamQuery(e->stream);
+        (void)hipGetLastError();
+        if (q != hipErrorNotReady) break;
+      }
+    }
+    EHIP(e, hipStreamSynchronize(e->stream));
+    return host[7] == want ? FPX_OK : FPX_EHIP;
+  };
+  EHIP(e, hipMemsetAsync(a.msg_of, 0xFF, (size_t)m * 4, e->stream));
+  EHIP(e, hipMemsetAsync(a.ctl, 0, 256, e->stream));
+  const int grid = (m + 255) / 256;
+  hipLaunchKernelGGL((k_dp_scatter<N>), dim3(grid), dim3(256), 0, e->stream, a);
+  hipLaunchKernelGGL((k_dp_scan0<N>), dim3(a.nblocks), dim3(256), 0, e->stream, a);
+  hipLaunchKernelGGL((k_dp_carry<N>), dim3(N), dim3(1024), 0, e->stream, a, 0, 1);
+  int cur = 0, executables = 0;
+  for (int chunk = 0;; ++chunk) {
+    if (chunk > 0) EHIP(e, hipMemsetAsync(a.ctl + 8, 0, (DG_ROUNDS + 1) * 4, e->stream));
+    for (int k = 1; k <= DG_ROUNDS; ++k) {
+      // round k gathers from half `cur` and leaves its scan in the other half.  (A skipped round does not flip anything on
+      // the device, but after the round that moved nothing both halves hold the same, final values.)
+      hipLaunchKernelGGL((k_dp_relax<N>), dim3(a.nblocks), dim3(256), 0, e->stream, a, cur, k);
+      hipLaunchKernelGGL((k_dp_carry<N>), dim3(N), dim3(1024), 0, e->stream, a, cur ^ 1, k);
+      cur ^= 1;
+    }
+    EHIP(e, hipMemsetAsync(a.ctl + 3, 0, 8, e->stream));
+    hipLaunchKernelGGL((k_dp_keys<N>), dim3(grid), dim3(256), 0, e->stream, a);
+    uint2* sorted = radix_sort_pairs(e, 1, m, DG_HASH_BITS, a.pairs, a.pairs2, nullptr, &rc, nullptr, nullptr);
+    if (rc) return rc;
+    if (sorted != a.pairs) std::swap(a.pairs, a.pairs2);
+    hipLaunchKernelGGL(k_dp_rekey, dim3(grid), dim3(256), 0, e->stream, a);
+    unsigned key_bits = 2;
+    while (((1ull << key_bits) - 1) <= 3ull * (unsigned long long)m + 2) ++key_bits;
+    sorted = radix_sort_pairs(e, 1, m, key_bits, a.pairs, a.pairs2, nullptr, &rc, nullptr, nullptr);
+    if (rc) return rc;
+    if (sorted != a.pairs) std::swap(a.pairs, a.pairs2);
+    hipLaunchKernelGGL(k_dp_count_starts, dim3(out_tiles), dim3(256), 0, e->stream, a);
+    hipLaunchKernelGGL(k_dp_emit, dim3(out_tiles), dim3(256), 0, e->stream, a);
+    a.seq = call * 64 + (chunk & 31) + 1;
+    hipLaunchKernelGGL(k_dp_publish, dim3(1), dim3(64), 0, e->stream, a);
+    if ((rc = wait_for((chunk & 31) + 1))) return rc;
+    if (host[1] != 0) return FPX_EINVAL;
+    if (a.count_moved) {
+      int32_t dbg[64];
+      EHIP(e, hipMemcpy(dbg, a.ctl, sizeof(dbg), hipMemcpyDeviceToHost));
+      fprintf(stderr, "libfpx: depgraph (packed) chunk %d, vertices moved per round:", chunk);
+      for (int k = 1; k <= DG_ROUNDS; ++k) fprintf(stderr, " %d", dbg[24 + k]);
+      fprintf(stderr, "\n");
+    }
+    executables = host[3];
+    if (host[5] == 0) break;
+    if (chunk >= 6) return FPX_EHIP;
+  }
+  if (nexec) *nexec = executables;
+  if (ncomp) *ncomp = executables > 0 ? host[4] : 0;
+  if (needs_host) *needs_host = host[2];
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) {
+    e->last_hip = (int)le;
+    return FPX_EHIP;
+  }
+  return FPX_OK;
+}
+
 // device dependency-graph execution of one tick's commits (fpx_depgraph_dev.hpp)
 template <int N>
 int dg_execute(fpx_epx* e, int m, const int32_t* d_leader, const int32_t* d_number, const int32_t* d_packed, const uint8_t* d_mask,
@@ -1600,6 +1710,11 @@ int dg_execute(fpx_epx* e, int m, const int32_t* d_leader, const int32_t* d_numb
   }
   for (int l = N; l < 8; ++l) a.base[l] = (int32_t)total, a.tile_base[l] = a.ntiles;
   if (total != m) return FPX_EINVAL;  // the columns are dense: every instance first[l] .. first[l] + count[l] - 1, once
+  if constexpr (N <= 5) {
+    bool fits = !getenv("FPX_DG_WIDE");
+    for (int l = 0; l < N; ++l) fits = fits && count[l] <= PK_MAX_COUNT;
+    if (fits) return dg_execute_packed<N>(e, m, d_leader, d_number, d_packed, d_mask, first, count, d_order, d_comp, nexec, ncomp, needs_host);
+  }
   int rc;
   const int out_tiles = (m + DG_TILE - 1) / DG_TILE;
   if ((rc = grow(e, &e->dg_msg, (size_t)m * 4))) return rc;
@@ -1621,6 +1736,7 @@ int dg_execute(fpx_epx* e, int m, const int32_t* d_leader, const int32_t* d_numb
   a.order = d_order, a.comp = d_comp;
   volatile int32_t* host = reinterpret_cast<volatile int32_t*>(e->kp_flag + 8);
   const int call = (++e->dg_seq) & 0xffff;
+  a.count_moved = getenv("FPX_DG_DEBUG") ? 1 : 0;
   auto wait_for = [&](int round) -> int {
     const int32_t want = call * 64 + round;
     for (long spin = 0; spin < 400000000L; ++spin) {
@@ -1669,6 +1785,13 @@ int dg_execute(fpx_epx* e, int m, const int32_t* d_leader, const int32_t* d_numb
     hipLaunchKernelGGL(k_dg_publish, dim3(1), dim3(64), 0, e->stream, a, chunk);
     if ((rc = wait_for((chunk & 31) + 1))) return rc;
     if (host[1] != 0) return FPX_EINVAL;        // an instance outside its column, twice, or missing
+    if (a.count_moved) {
+      int32_t dbg[64];
+      EHIP(e, hipMemcpy(dbg, a.ctl, sizeof(dbg), hipMemcpyDeviceToHost));
+      fprintf(stderr, "libfpx: depgraph chunk %d, vertices moved per round:", chunk);
+      for (int k = 1; k <= DG_ROUNDS; ++k) fprintf(stderr, " %d", dbg[24 + k]);
+      fprintf(stderr, "\n");
+    }
     executables = host[3];
     if (host[5] == 0) break;                    // the chunk's last round moved nothing (or never ran): converged
     if (round >= 48) return FPX_EHIP;           // (a round doubles the hops covered: 2^48 hops do not exist)

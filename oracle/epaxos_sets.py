@@ -14,7 +14,8 @@ sets and compares).  Pure-Python loops: small cases only.
     epaxos/Replica.scala:633-729    transitionToPreAcceptPhase           :1159-1289  handlePreAccept
     epaxos/Replica.scala:1291-1419  handlePreAcceptOk, :796-813 preAcceptingSlowPath, :815-860 commit
     epaxos/Replica.scala:732-792    transitionToAcceptPhase              :1421-1565  handleAccept / handleAcceptOk
-    epaxos/Replica.scala:1632-1757  handlePrepare
+    epaxos/Replica.scala:1632-1757  handlePrepare                        :1759-1884  handlePrepareOk (round 5)
+    epaxos/Replica.scala:1567-1575  handleCommit (round 5)
 """
 
 NONE, NO_COMMAND, PRE_ACCEPTED, ACCEPTED, COMMITTED = range(5)
@@ -188,3 +189,45 @@ class EPaxos:
                 rep.cmd_log[instance] = Entry(COMMITTED, triple_id=triple_id, deps=None)
                 put(rep)                                                              # commit :828
         return False, replies, committed
+
+    # ---- Replica.handleCommit (:1567-1575) -> commit (:815-830) at the replicas of `targets` ----------------------
+    def handle_commit(self, instance, triple_id, deps, targets, key=-1, is_set=False):
+        """deps: the Commit's dependencies as a set of instances, or None (the triple is known by its id alone)"""
+        for r in targets:
+            rep = self.replicas[r]
+            # cmdLog -= instance; cmdLog(instance) = CommittedEntry(triple) (:826-827): no ballot is looked at
+            rep.cmd_log[instance] = Entry(COMMITTED, triple_id=triple_id, deps=None if deps is None else frozenset(deps))
+            if key >= 0:
+                rep.index_put(key, is_set, instance)                                  # updateConflictIndex :828
+
+    # ---- Replica.handlePrepareOk (:1759-1884): what the recovering replica `me` decides once `responses` are in ----
+    def handle_prepare_oks(self, instance, ballot, me, responses, as_intended=False):
+        """responses: {replica: (status, vote_ballot, triple_id, deps)} -- PrepareOk.status as an entry kind (NONE =
+        CommandStatus.NotSeen), voteBallot as a tuple, the triple as (id, frozenset of dependencies or None).
+        Returns ("wait",) | ("accept", replica, triple_id) | ("preaccept", replica, triple_id) | ("noop",).
+
+        as_intended = False restates the handler AS SCALA EVALUATES IT:
+          :1810  prepareOks.find(_.status == Some(CommandStatus.Accepted)) compares a CommandStatus with an Option: never true;
+          :1831  .filter(p => p.ballot == Ballot(0, p.instance.replicaIndex)) reads PrepareOk.ballot -- the ballot of the
+                 Prepare being answered, the same for every response -- not the ballot the vote was cast in.
+        as_intended = True is what the comments beside them describe (:1806-1809, :1826-1829)."""
+        if len(responses) < self.f + 1:                                               # :1799 slowQuorumSize
+            return ("wait",)
+        max_ballot = max(v[1] for v in responses.values())                            # :1805 (BallotHelpers.Ordering)
+        oks = {r: v for r, v in responses.items() if v[1] == max_ballot}              # :1806
+        if as_intended:
+            for r in sorted(oks):                                                     # :1810-1824 "if some response was accepted"
+                if oks[r][0] == ACCEPTED:
+                    return ("accept", r, oks[r][2])
+        # :1830-1843 PreAccepted responses in the default ballot, not from the recovering replica itself
+        default = (0, instance[0])
+        in_default = (max_ballot == default) if as_intended else (ballot == default)
+        cands = [(r, v) for r, v in sorted(oks.items()) if v[0] == PRE_ACCEPTED and in_default and r != me]
+        for r, v in cands:                                                            # Util.popularItems(.., config.f): :1844-1851
+            same = sum(1 for _, w in cands if (w[2], w[3]) == (v[2], v[3]))          # CommandTriple equality: command + dependencies
+            if same >= self.f:
+                return ("accept", r, v[2])
+        for r in sorted(oks):                                                         # :1856-1868
+            if oks[r][0] == PRE_ACCEPTED:
+                return ("preaccept", r, oks[r][2])
+        return ("noop",)
