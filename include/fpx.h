@@ -494,10 +494,15 @@ int32_t fpx_epx_sync(fpx_epx* epx);
  * Outputs: d_order[p] = the message executed p-th, d_component[p] = its component's number (consecutive from 0; equal
  * numbers = one strongly connected component), for p < *num_executed; *num_components.  Where the reference leaves the
  * order open (components that do not depend on each other) this path takes its own; the SET of components and the
- * validity of the order equal fpx_depgraph's.  *needs_host_path != 0: a component too large to regroup on the device (a
- * hot key under reordering channels) -- the outputs are not valid, run the tick through fpx_depgraph_commit_epx.
- * Device pointers, the context's stream; a few host waits on page-locked words inside (the closure rounds), so the call
- * returns when the order is on the device: not capturable into a HIP graph. */
+ * validity of the order equal fpx_depgraph's.  *needs_host_path != 0: the members of a strongly connected component could
+ * not be made neighbours of the order -- two DIFFERENT closures of vertices on cycles have the same closure sum AND the same
+ * 22-bit closure hash, so their members may interleave (detected where component starts are found; components of any size
+ * are handled on the device, this is a hash collision, probability ~2^-22 per pair of such closures), or a closure sum of
+ * 2^29 and more (not reachable with m < 2^21) -- the outputs are not valid, run the tick through fpx_depgraph_commit_epx.
+ * Device pointers, the context's stream; ONE host wait on a page-locked word at the end (round 4: one per closure round),
+ * so the call returns when the order is on the device: not capturable into a HIP graph.  n <= 5 with columns of fewer
+ * than 2^21 - 2 instances runs on 16-byte rows (csrc/fpx_depgraph_pk.hpp), everything else on 32-byte rows;
+ * FPX_DG_WIDE=1 in the environment forces the latter (the results do not depend on it). */
 int32_t fpx_epx_execute_dev(fpx_epx* epx, int32_t m, const int32_t* d_leader, const int32_t* d_number,
                             const int32_t* d_packed, const uint8_t* d_committed, const int32_t* first,
                             const int32_t* count, int32_t* d_order, int32_t* d_component, int64_t* num_executed,
