@@ -99,7 +99,8 @@ def run_device_only(n, leader, number, first, count, deps, own, committed=None):
     t0 = time.perf_counter()
     out = epx.execute_dev(*args, committed=cm)
     torch.cuda.synchronize()
-    return out, time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    return out, dt, order.cpu().numpy()[:out[0]], comp.cpu().numpy()[:out[0]]
 
 
 def run_both(n, leader, number, first, count, deps, own, committed=None, kind="tarjan"):
@@ -161,8 +162,7 @@ def test_device_components_equal_the_host_graphs(n, m, jitter, holes, dg_path):
         assert nc < m                                       # there were cycles
 
 
-@pytest.mark.parametrize("n,m,dg_path", [(5, 3000, "packed"), (5, 3000, "wide"), (3, 800, "packed"), (3, 800, "wide"), (5, 400000, "packed")],
-                         indirect=["dg_path"])
+@pytest.mark.parametrize("n,m,dg_path", [(5, 3000, "packed"), (5, 3000, "wide"), (3, 800, "packed"), (3, 800, "wide")], indirect=["dg_path"])
 def test_device_waits_for_what_is_not_committed(n, m, dg_path):
     """a tenth of the instances is not committed yet: they, and whatever reaches them, stay; the rest executes -- the same
     set the host graph executes"""
@@ -172,14 +172,30 @@ def test_device_waits_for_what_is_not_committed(n, m, dg_path):
     committed[:3 * m // 4] = True                            # (the early instances are all there: a prefix executes)
     (ne, nc, nh, order, comp), (el, ei, cs) = run_both(n, leader, number, first, count, deps, own, committed)
     assert not nh and ne == len(el) and 0 < ne < m
-    if m > 100000:
-        # an uncommitted vertex used to walk the rest of its column in k_dg_keys, one load per step -- O(m^2)
-        # per tick, seconds at this size; the walk is now asked of executable vertices only
-        out, dt = run_device_only(n, leader, number, first, count, deps, own, committed)
-        assert out[0] == ne and dt < 0.05, dt
     host = labels(n, leader, number, el, ei, np.repeat(np.arange(len(cs)), cs))
     mine = labels(n, leader, number, leader[order], number[order], comp)
     assert mine == host
+
+
+def test_uncommitted_instances_at_size_do_not_walk_their_columns(monkeypatch):
+    """an uncommitted vertex used to walk the rest of its column in k_dg_keys, one load per step -- O(m^2) per
+    tick, seconds at this size; the walk is now asked of executable vertices only.  400 000 instances, 2.5 % of them not
+    committed: the call stays in the tens of milliseconds, and the two forms of the closure rounds (16- and 32-byte rows)
+    execute the same instances in the same components.  (The host graph takes minutes at this size with a committed mask;
+    the small cases above hold the device to it.)"""
+    n, m = 5, 400000
+    rng = np.random.default_rng(m)
+    leader, number, first, count, deps, own = random_prefix_graph(rng, n, m, 0, False)
+    committed = rng.random(m) > 0.1
+    committed[:3 * m // 4] = True
+    monkeypatch.delenv("FPX_DG_WIDE", raising=False)
+    (ne, nc, nh), dt, order, comp = run_device_only(n, leader, number, first, count, deps, own, committed)
+    assert not nh and 3 * m // 4 <= ne < m and dt < 0.05, (ne, dt)
+    assert committed[order].all()
+    monkeypatch.setenv("FPX_DG_WIDE", "1")
+    (ne2, nc2, nh2), dt2, order2, comp2 = run_device_only(n, leader, number, first, count, deps, own, committed)
+    assert (ne2, nc2, nh2) == (ne, nc, nh) and dt2 < 0.05
+    assert labels(n, leader, number, leader[order], number[order], comp) == labels(n, leader, number, leader[order2], number[order2], comp2)
 
 
 def test_device_refuses_columns_that_are_not_dense():
