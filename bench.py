@@ -529,8 +529,12 @@ def main():
             t_c = time.perf_counter()
             try:
                 # config 4's ticks are drawn on the host (~0.5 s each): half as many of them
-                sub = types.SimpleNamespace(steps=max(1, args.configs_block_steps // 2) if c in ("4", "4_execute", "thrifty_random", "host_path") else args.configs_block_steps,
-                                            warmup=2, ballot=args.ballot, config=c, no_cpu_baseline=True)
+                # configs 2 and 3 get ten times the steps: 20 steps of 12 - 40 us are a timed region of a quarter of a
+                # millisecond, which measures the GPU waking up after the fence, not the step -- config 2: 0.018 - 0.032 ms
+                # per step over 20 steps, 0.0121 - 0.0129 over 200 (profiles/r05_small_steps.md)
+                sub_steps = (max(1, args.configs_block_steps // 2) if c in ("4", "4_execute", "thrifty_random", "host_path") else
+                             10 * args.configs_block_steps if c in ("2", "3") else args.configs_block_steps)
+                sub = types.SimpleNamespace(steps=sub_steps, warmup=2, ballot=args.ballot, config=c, no_cpu_baseline=True)
                 full = bench_configs.run(sub, fa, None, dev, 0, 1, local_rank, all_reduce)
                 configs_block[c] = {
                     "metric": full["metric"], "value": full["value"], "unit": full["unit"], "steps": full["steps"],
@@ -546,6 +550,15 @@ def main():
                         configs_block[c][extra_key] = full["config"][extra_key]
                 if "note" in full["roofline"]:
                     configs_block[c]["note"] = full["roofline"]["note"]
+                if c == "2" and args.ballot == "per_slot":
+                    # BASELINE.json configs[1] is the reference's own f = 1 deployment: its acceptors keep ONE round each
+                    # (multipaxos/Acceptor.scala:95) -- the same steps under FPX_BALLOT_ACCEPTOR, beside the
+                    # ballot-per-cell figures this block reports for continuity with the headline's model
+                    sub2 = types.SimpleNamespace(steps=sub_steps, warmup=2, ballot="acceptor", config="2", no_cpu_baseline=True)
+                    alt = bench_configs.run(sub2, fa, None, dev, 0, 1, local_rank, all_reduce)
+                    configs_block[c]["acceptor_model"] = {"value": alt["value"], "ms_per_step": alt["ms_per_step"],
+                                                          "avg_kernel_ms": alt["roofline"]["avg_kernel_ms"],
+                                                          "verified": alt["config"].get("verified")}
             except BaseException as e:  # noqa: BLE001 -- the headline line must survive a failing extra config
                 configs_block[c] = {"error": "%s: %s" % (type(e).__name__, e)}
             configs_block[c]["wall_s"] = time.perf_counter() - t_c

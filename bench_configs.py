@@ -121,7 +121,11 @@ def multipaxos_setup(fa, dev, local_rank, ballot_mode, cfg, K, Wm):
         return {"value": S / dt, "unit": "slots/s", "cores": 1, "kind": "port",
                 "sample": "oracle/fpx_oracle.c fpo_phase2_fused, %d slots of the same workload, 1 thread" % S}
 
-    return dict(ctx=ctx, step=step, verify=verify, units=n, unit="slots/s", bytes_per_unit=bps,
+    # (steps of ~10 - 40 us are timed by ONE pair of events around the timed region, like configs 4 and 5, and want a few
+    # hundred of them: over 20 steps the region is a quarter of a millisecond and measures the GPU waking up after the fence
+    # -- 0.018 - 0.032 ms per 65 536 x 3 step over 20 steps, 0.0121 (round per acceptor) / 0.0129 (ballot per cell) over 200;
+    # profiles/r05_small_steps.md.  A captured HIP graph of the steps is no faster: the step is its two dependent launches.)
+    return dict(ctx=ctx, step=step, verify=verify, units=n, unit="slots/s", bytes_per_unit=bps, region_timed=(cfg in ("2", "3")),
                 workload=shapes["name"], kernel="k_phase2 (fused K3)", profile=lambda: ctx.profile_read(),
                 metric=("committed log slots/sec (BASELINE.json configs[%d])" % (int(cfg) - 1)) if cfg.isdigit() else
                        "committed log slots/sec at 1M slots x 256 replicas, one promised round per acceptor (FPX_BALLOT_ACCEPTOR)", cpu=cpu,
@@ -757,7 +761,8 @@ def run(args, fa, dist, dev, rank, world, local_rank, all_reduce):
     }
     if args.config == "2":
         line["roofline"]["bound_in_practice"] = "launch latency: a 65 536-slot x 3 step is one ~6 us vote kernel and a ~4 us " \
-                                                "k_finalize, two launches from Python per step (profiles/r03_small_n.txt); " \
+                                                "k_finalize with a dependent-launch gap behind each (profiles/r03_small_n.txt; a " \
+                                                "captured HIP graph of the steps runs no faster: r05_small_step_graph.py); " \
                                                 "the config is BASELINE.json's bring-up / bit-exactness case, not a bandwidth case"
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = w["cpu"]()
