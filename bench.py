@@ -532,8 +532,11 @@ def main():
                 # configs 2 and 3 get ten times the steps: 20 steps of 12 - 40 us are a timed region of a quarter of a
                 # millisecond, which measures the GPU waking up after the fence, not the step -- config 2: 0.018 - 0.032 ms
                 # per step over 20 steps, 0.0121 - 0.0129 over 200 (profiles/r05_small_steps.md)
-                sub_steps = (max(1, args.configs_block_steps // 2) if c in ("4", "4_execute", "thrifty_random", "host_path") else
-                             10 * args.configs_block_steps if c in ("2", "3") else args.configs_block_steps)
+                # (config 5's 85 us bands likewise: twice the steps -- its 4M-slot bands are 2 GB of state each; config 4's ticks are drawn on the host, 0.5 s each)
+                sub_steps = (max(1, args.configs_block_steps // 2) if c in ("4_execute", "thrifty_random", "host_path") else
+                             max(1, 3 * args.configs_block_steps // 4) if c == "4" else
+                             10 * args.configs_block_steps if c in ("2", "3") else
+                             2 * args.configs_block_steps if c == "5" else args.configs_block_steps)
                 sub = types.SimpleNamespace(steps=sub_steps, warmup=2, ballot=args.ballot, config=c, no_cpu_baseline=True)
                 full = bench_configs.run(sub, fa, None, dev, 0, 1, local_rank, all_reduce)
                 configs_block[c] = {
