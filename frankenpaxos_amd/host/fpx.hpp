@@ -328,6 +328,15 @@ class Phase2Engine {
     return out;
   }
 
+  // ---- Acceptor.handleMaxSlotRequest / handleBatchMaxSlotRequest (Acceptor.scala:222-254): what the reply's `slot` is --
+  // the acceptor's maxVotedSlot, over the whole log or over the slots [firstSlot, firstSlot + count) of it
+  int acceptorMaxVotedSlot(int groupIndex, int acceptorIndex, int firstSlot = 0, int count = -1) {
+    int32_t slot = -1;
+    check(fpx_acceptor_max_voted_in(ctx_, groupIndex, acceptorIndex, firstSlot, count < 0 ? fcfg_.num_slots - firstSlot : count, &slot),
+          "Acceptor.handleMaxSlotRequest");
+    return slot;
+  }
+
   // ---- Leader.handlePhase1b once a read quorum of Phase1b's is in (Leader.scala:543-566): for every
   // slot in [chosenWatermark, maxSlot] the safe value (Leader.scala:306-329) to re-propose.
   // quorum[g] = acceptor indices of group g whose Phase1b the leader holds.
@@ -897,6 +906,26 @@ class PreAcceptEngine {
     return out;
   }
 
+ public:
+  // Replica.handleCommit (Replica.scala:1567-1575 -> commit :815-830) at the replicas `at`: CommittedEntry(triple) whatever
+  // their command logs held, the conflict index learns the command (key -1 = Noop).  dependencies: n watermarks (empty =
+  // the triple is known by its id alone) + ownValuesEnd.
+  void handleCommit(const Instance& instance, int tripleId, int key, bool isSet, const std::vector<int>& at,
+                    const std::vector<int32_t>& dependencies = {}, int ownValuesEnd = 0) {
+    if (!dependencies.empty() && (int)dependencies.size() != n_) throw std::invalid_argument("one watermark per replica");
+    const int32_t L = instance.replicaIndex, x = instance.instanceNumber, tr = tripleId, k = key, end = ownValuesEnd;
+    const uint8_t set = isSet ? 1 : 0;
+    uint8_t mask = 0;
+    for (int r : at) {
+      if (r < 0 || r >= n_) throw std::invalid_argument("replica index out of range");
+      mask |= (uint8_t)(1u << r);
+    }
+    check(fpx_epx_handle_commit(epx_, 1, &L, &x, &tr, &k, &set, dependencies.empty() ? nullptr : dependencies.data(),
+                                dependencies.empty() ? nullptr : &end, &mask),
+          "Replica.handleCommit");
+  }
+
+ private:
   int n_;
   fpx_epx* epx_ = nullptr;
 };

@@ -243,6 +243,12 @@ static void multiPaxosRecovery() {
   SHOULD_BE(chosen.size(), (size_t)3);
   SHOULD_BE(engine.replicaHandleChosen(chosen), 5);
   SHOULD_BE(engine.numChosen(), 5);  // 3 and 4 were chosen before: redundantly chosen, not counted again
+  // the read path (Acceptor.scala:222-254): maxVotedSlot of every acceptor.  Slots 0, 2, 4 belong to group 0 (slot % 2), 1 and 3
+  // to group 1; round 1 re-proposed 2, 3, 4 everywhere
+  for (int a = 0; a < 3; ++a) SHOULD_BE(engine.acceptorMaxVotedSlot(0, a), 4);
+  for (int a = 0; a < 3; ++a) SHOULD_BE(engine.acceptorMaxVotedSlot(1, a), 3);
+  SHOULD_BE(engine.acceptorMaxVotedSlot(0, 1, 0, 3), 2);   // among the slots 0 .. 2 only
+  SHOULD_BE(engine.acceptorMaxVotedSlot(1, 2, 4, 60), -1);  // nothing of group 1 from slot 4 on
 }
 
 // mencius noop ranges, mencius/Acceptor.scala:237-291 and mencius/ProxyLeader.scala:255-303, 355-411
@@ -423,6 +429,22 @@ static void epaxosCommandLog() {
     SHOULD_BE(asIntended.source, 0);
     oks[0].ok = {0, 1};  // only two of them in hand: no slow quorum yet
     SHOULD_BE((int)engine.handlePrepareOks(prep, oks)[0].action, (int)RecoveryDecision::Wait);
+  }
+  // g) a Commit from outside (Replica.handleCommit :1567-1575) for Y at {1, 2}: CommittedEntry whatever was there -- replica 1
+  //    held Y PreAccepted in Ballot(1, 4) since the Prepare, replica 2 (Y's own leader) nothing --, the dependencies it carried,
+  //    and a Prepare that comes later is answered with the Commit (:1746-1756)
+  {
+    const Instance Y{2, 3};
+    engine.handleCommit(Y, 61, 0, true, {1, 2}, {1, 0, 3, 0, 2}, 0);
+    SHOULD_BE((int)engine.cmdLog(1, Y).kind, (int)EntryKind::Committed);
+    SHOULD_BE((int)engine.cmdLog(2, Y).kind, (int)EntryKind::Committed);
+    SHOULD_BE(engine.cmdLog(2, Y).tripleId, 61);
+    SHOULD_BE(engine.cmdLog(2, Y).dependencies, (V{1, 0, 3, 0, 2}));
+    SHOULD_BE((int)engine.cmdLog(0, Y).kind, (int)EntryKind::PreAccepted);   // not among the recipients
+    InstanceReplies p2 = engine.handlePrepare({{Y, {7, 0}, {1, 2}}})[0];
+    SHOULD_BE(p2.commits, (std::vector<int>{1, 2}));
+    SHOULD_BE(p2.ok.empty(), true);
+    SHOULD_THROW(engine.handleCommit(Y, 61, 9, true, {1}));                  // a key outside the index
   }
   // two messages for one instance in a batch; a PreAccept that depends on itself
   SHOULD_THROW(engine.handlePrepare({{{1, 1}, {1, 0}, {2}}, {{1, 1}, {1, 0}, {3}}}));
