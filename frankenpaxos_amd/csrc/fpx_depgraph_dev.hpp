@@ -60,6 +60,8 @@ struct DgArgs {
   volatile int32_t* host;           // page-locked mirror of ctl (8 ints) + [7] = seq
   int32_t seq;
   int32_t count_moved;              // debug: count the vertices a round moves into ctl[24 + k]
+  int32_t hash_bits;                // bits of the closure hash the cyclic vertices are grouped by (DG_HASH_BITS; fewer under
+                                    // FPX_DG_HASH_BITS, which tests use to force the collisions ctl[2] reports)
   int32_t* order;                   // [m] message indices in execution order
   int32_t* comp;                    // [m] component number of position p (0, 1, ..)
 };
@@ -289,11 +291,11 @@ __global__ void k_dg_publish(const DgArgs a, int round) {
 // cycle, 1 = inside its own prefix (explicit ids reach over it) but on no cycle, 2 = neither; ~0 = cannot execute yet
 constexpr int DG_HASH_BITS = 22;
 template <int N>
-__device__ __forceinline__ uint32_t dg_hash(const int* c) {
+__device__ __forceinline__ uint32_t dg_hash(const int* c, int bits) {
   uint32_t h = 0x9E3779B9u;
 #pragma unroll
   for (int l = 0; l < N; ++l) h = kp_mix32(h ^ (uint32_t)c[l]) + 0x7F4A7C15u;
-  return h >> (32 - DG_HASH_BITS);
+  return h >> (32 - bits);
 }
 __global__ void __launch_bounds__(256) k_dg_rekey(const DgArgs a) {  // after the sort on the hash: the main key, by vertex
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -349,7 +351,7 @@ __global__ void __launch_bounds__(256) k_dg_keys(const DgArgs a) {
   a.key32[v] = key;
   // vertices on cycles with one closure sum can belong to several components: the closure's hash orders them first, so
   // that the members of a component (equal closures) end up neighbours
-  a.pairs[v] = make_uint2((eligible && kind == 0u) ? dg_hash<N>(c) : 0u, (uint32_t)v);
+  a.pairs[v] = make_uint2((eligible && kind == 0u) ? dg_hash<N>(c, a.hash_bits) : 0u, (uint32_t)v);
   }
   // the number of executables: wave -> workgroup (LDS) -> ONE atomic per workgroup on the counter (an atomic per
   // wavefront was 16 384 of them queueing on one address: most of this kernel's 217 us, profiles/r04_depgraph_dev.md)
@@ -384,7 +386,7 @@ __device__ __forceinline__ uint32_t dg_starts(const DgArgs& a, int p, int execut
   const uint2 f = a.pairs[p - 1];
   if (f.x != e.x) return 1u;
   if (dg_cmp_clo<N>(a, f.y, e.y) == 0) return 0u;
-  if (dg_hash<N>(a.clo + (size_t)f.y * NP) == dg_hash<N>(a.clo + (size_t)e.y * NP)) a.ctl[2] = 1;
+  if (dg_hash<N>(a.clo + (size_t)f.y * NP, a.hash_bits) == dg_hash<N>(a.clo + (size_t)e.y * NP, a.hash_bits)) a.ctl[2] = 1;
   return 1u;
 }
 

@@ -28,13 +28,13 @@ __device__ __forceinline__ ulonglong2 pk_pack(const int* c) {
   r.y = (unsigned long long)(unsigned)c[3] | ((unsigned long long)(unsigned)c[4] << PK_BITS);
   return r;
 }
-__device__ __forceinline__ uint32_t pk_hash(const ulonglong2 r) {
+__device__ __forceinline__ uint32_t pk_hash(const ulonglong2 r, int bits) {
   uint32_t h = 0x9E3779B9u;
   h = kp_mix32(h ^ (uint32_t)r.x) + 0x7F4A7C15u;
   h = kp_mix32(h ^ (uint32_t)(r.x >> 32)) + 0x7F4A7C15u;
   h = kp_mix32(h ^ (uint32_t)r.y) + 0x7F4A7C15u;
   h = kp_mix32(h ^ (uint32_t)(r.y >> 32)) + 0x7F4A7C15u;
-  return h >> (32 - DG_HASH_BITS);
+  return h >> (32 - bits);
 }
 
 struct DpArgs {
@@ -60,6 +60,7 @@ struct DpArgs {
   volatile int32_t* host;
   int32_t seq;
   int32_t count_moved;
+  int32_t hash_bits;                     // as DgArgs::hash_bits
   int32_t* order;
   int32_t* comp;
 };
@@ -284,7 +285,7 @@ __global__ void __launch_bounds__(256) k_dp_keys(const DpArgs a) {
     }
     const uint32_t kind = back > x ? 0u : (c[L] > x ? 1u : 2u);
     a.key32[v] = eligible ? (sum * 3u + kind) : 0xffffffffu;
-    a.pairs[v] = make_uint2((eligible && kind == 0u) ? pk_hash(cr) : 0u, (uint32_t)v);
+    a.pairs[v] = make_uint2((eligible && kind == 0u) ? pk_hash(cr, a.hash_bits) : 0u, (uint32_t)v);
   }
   const unsigned long long bal = __ballot(eligible);
   if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&block_eligible, (int)__popcll(bal));
@@ -306,7 +307,7 @@ __device__ __forceinline__ uint32_t dp_starts(const DpArgs& a, int p, int execut
   if (f.x != e.x) return 1u;
   const ulonglong2 ce = a.clo[e.y], cf = a.clo[f.y];
   if (ce.x == cf.x && ce.y == cf.y) return 0u;
-  if (pk_hash(ce) == pk_hash(cf)) a.ctl[2] = 1;  // two different closures with one key and one hash: their members may interleave
+  if (pk_hash(ce, a.hash_bits) == pk_hash(cf, a.hash_bits)) a.ctl[2] = 1;  // two different closures with one key and one hash: their members may interleave
   return 1u;
 }
 

@@ -1583,6 +1583,14 @@ int launch_kp(fpx_epx* e, const EpxBatch& b, int32_t* d_packed, bool* done) {
   return FPX_OK;
 }
 
+// bits of the closure hash that groups the cyclic vertices of one sort key into components.  FPX_DG_HASH_BITS (2 .. 22) is a
+// test hook: with few bits different closures of one key share a hash, which is exactly the case needs_host_path reports
+int dg_hash_bits() {
+  const char* s = getenv("FPX_DG_HASH_BITS");
+  const int b = s ? atoi(s) : DG_HASH_BITS;
+  return b < 2 ? 2 : b > DG_HASH_BITS ? DG_HASH_BITS : b;
+}
+
 // the packed path of the device dependency graph (fpx_depgraph_pk.hpp): n <= 5, columns of fewer than 2^21 - 2 instances
 template <int N>
 int dg_execute_packed(fpx_epx* e, int m, const int32_t* d_leader, const int32_t* d_number, const int32_t* d_packed, const uint8_t* d_mask,
@@ -1624,6 +1632,7 @@ int dg_execute_packed(fpx_epx* e, int m, const int32_t* d_leader, const int32_t*
   volatile int32_t* host = reinterpret_cast<volatile int32_t*>(e->kp_flag + 8);
   const int call = (++e->dg_seq) & 0xffff;
   a.count_moved = getenv("FPX_DG_DEBUG") ? 1 : 0;
+  a.hash_bits = dg_hash_bits();
   auto wait_for = [&](int round) -> int {
     const int32_t want = call * 64 + round;
     for (long spin = 0; spin < 400000000L; ++spin) {
@@ -1655,7 +1664,7 @@ int dg_execute_packed(fpx_epx* e, int m, const int32_t* d_leader, const int32_t*
     }
     EHIP(e, hipMemsetAsync(a.ctl + 3, 0, 8, e->stream));
     hipLaunchKernelGGL((k_dp_keys<N>), dim3(grid), dim3(256), 0, e->stream, a);
-    uint2* sorted = radix_sort_pairs(e, 1, m, DG_HASH_BITS, a.pairs, a.pairs2, nullptr, &rc, nullptr, nullptr);
+    uint2* sorted = radix_sort_pairs(e, 1, m, (unsigned)a.hash_bits, a.pairs, a.pairs2, nullptr, &rc, nullptr, nullptr);
     if (rc) return rc;
     if (sorted != a.pairs) std::swap(a.pairs, a.pairs2);
     hipLaunchKernelGGL(k_dp_rekey, dim3(grid), dim3(256), 0, e->stream, a);
@@ -1737,6 +1746,7 @@ int dg_execute(fpx_epx* e, int m, const int32_t* d_leader, const int32_t* d_numb
   volatile int32_t* host = reinterpret_cast<volatile int32_t*>(e->kp_flag + 8);
   const int call = (++e->dg_seq) & 0xffff;
   a.count_moved = getenv("FPX_DG_DEBUG") ? 1 : 0;
+  a.hash_bits = dg_hash_bits();
   auto wait_for = [&](int round) -> int {
     const int32_t want = call * 64 + round;
     for (long spin = 0; spin < 400000000L; ++spin) {
@@ -1769,7 +1779,7 @@ int dg_execute(fpx_epx* e, int m, const int32_t* d_leader, const int32_t* d_numb
     EHIP(e, hipMemsetAsync(a.ctl + 3, 0, 8, e->stream));
     hipLaunchKernelGGL((k_dg_keys<N>), dim3(grid), dim3(256), 0, e->stream, a);
     // least significant first: the closures' hashes, then (stable) the closure sums and kinds
-    uint2* sorted = radix_sort_pairs(e, 1, m, DG_HASH_BITS, a.pairs, a.pairs2, nullptr, &rc, nullptr, nullptr);
+    uint2* sorted = radix_sort_pairs(e, 1, m, (unsigned)a.hash_bits, a.pairs, a.pairs2, nullptr, &rc, nullptr, nullptr);
     if (rc) return rc;
     if (sorted != a.pairs) std::swap(a.pairs, a.pairs2);
     hipLaunchKernelGGL(k_dg_rekey, dim3(grid), dim3(256), 0, e->stream, a);

@@ -502,7 +502,8 @@ int32_t fpx_epx_sync(fpx_epx* epx);
  * Device pointers, the context's stream; ONE host wait on a page-locked word at the end (round 4: one per closure round),
  * so the call returns when the order is on the device: not capturable into a HIP graph.  n <= 5 with columns of fewer
  * than 2^21 - 2 instances runs on 16-byte rows (csrc/fpx_depgraph_pk.hpp), everything else on 32-byte rows;
- * FPX_DG_WIDE=1 in the environment forces the latter (the results do not depend on it). */
+ * FPX_DG_WIDE=1 in the environment forces the latter (the results do not depend on it); FPX_DG_HASH_BITS=b (2 .. 22) shortens
+ * the closure hash -- a test hook that makes the collisions needs_host_path reports happen (tests/test_depgraph_dev.py). */
 int32_t fpx_epx_execute_dev(fpx_epx* epx, int32_t m, const int32_t* d_leader, const int32_t* d_number,
                             const int32_t* d_packed, const uint8_t* d_committed, const int32_t* first,
                             const int32_t* count, int32_t* d_order, int32_t* d_component, int64_t* num_executed,

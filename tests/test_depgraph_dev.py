@@ -198,6 +198,46 @@ def test_uncommitted_instances_at_size_do_not_walk_their_columns(monkeypatch):
     assert labels(n, leader, number, leader[order], number[order], comp) == labels(n, leader, number, leader[order2], number[order2], comp2)
 
 
+def two_families_of_cycles(K):
+    """n = 5: {(0, k), (1, k)} and {(2, k), (3, k)} are cycles of two for every k < K, each reaching everything before it in its
+    own two columns: closures (k + 1, k + 1, 0, 0, 0) and (0, 0, k + 1, k + 1, 0) -- DIFFERENT closures with the SAME sum, i.e.
+    the same sort key, K times over; column 4 is a chain of singletons"""
+    n, m = 5, 5 * K
+    leader = np.tile(np.arange(5, dtype=np.int32), K)
+    number = np.repeat(np.arange(K, dtype=np.int32), 5)
+    deps = np.zeros((m, n), np.int32)
+    for i in range(m):
+        L, k = int(leader[i]), int(number[i])
+        deps[i, L] = k
+        if L < 4:
+            deps[i, L ^ 1] = k + 1
+    return n, leader, number, np.zeros(n, np.int32), np.full(n, K, np.int32), deps, np.zeros((m, 2), np.int32)
+
+
+def test_a_hash_collision_between_closures_of_one_key_is_reported(dg_path, monkeypatch):
+    """needs_host_path = two different cyclic closures with one sort key AND one hash met in the sorted order
+    (their members may interleave, so the call's components are not to be used and the caller takes fpx_depgraph_commit_epx
+    + execute instead).  With the library's 22 hash bits that does not happen in any test; FPX_DG_HASH_BITS=2 leaves four
+    hash values for 64 pairs of closures that share their keys: the flag must come up, on both row widths -- and with
+    the full hash the same graph comes back as the host graph has it."""
+    K = 64
+    n, leader, number, first, count, deps, own = two_families_of_cycles(K)
+    monkeypatch.delenv("FPX_DG_HASH_BITS", raising=False)
+    (ne, nc, nh, order, comp), (el, ei, cs) = run_both(n, leader, number, first, count, deps, own)
+    assert not nh and ne == 5 * K == len(el) and nc == 3 * K == len(cs)
+    host = labels(n, leader, number, el, ei, np.repeat(np.arange(len(cs)), cs))
+    assert labels(n, leader, number, leader[order], number[order], comp) == host
+    check_valid_order(n, first, leader, number, deps, own[:, 0], order, comp)
+    monkeypatch.setenv("FPX_DG_HASH_BITS", "2")
+    (ne, nc, nh), _, _, _ = run_device_only(n, leader, number, first, count, deps, own)
+    assert nh == 1                                          # (whatever else the call returned is not used)
+    # a graph without cycles has nothing to group by the hash: no flag however few bits
+    rng = np.random.default_rng(5)
+    l2, n2, f2, c2, d2, o2 = random_prefix_graph(rng, 5, 2000, 0, False)
+    (ne, nc, nh), _, order, comp = run_device_only(5, l2, n2, f2, c2, d2, o2)
+    assert not nh and ne == nc == 2000
+
+
 def test_device_refuses_columns_that_are_not_dense():
     import torch
     import frankenpaxos_amd as fa
