@@ -207,6 +207,16 @@ void make_geom(const fpx_config& c, Geom* g) {
   g->lg_rows = (c.num_leader_groups > 1 && c.num_slots % c.num_leader_groups == 0 && c.num_replicas <= 32 &&
                 !(c.flags & FPX_F_SLOT_MAJOR_ROWS) && !getenv("FPX_SLOT_MAJOR"))
                    ? c.num_slots / c.num_leader_groups : 0;
+  // slot / L and row / A by multiplication (fpx_kernels.hpp: fast_div)
+  auto magic = [](int d, uint32_t* m, int32_t* sh) {
+    *m = 0, *sh = 0;
+    if (d < 2) return;
+    int k = 0;
+    while ((1ll << (k + 1)) < d) ++k;  // 2^k < d <= 2^(k + 1)
+    *sh = k, *m = (uint32_t)(((1ull << (32 + k)) / (uint64_t)d) + 1ull);
+  };
+  magic(c.num_leader_groups, &g->l_magic, &g->l_shift);
+  magic(c.num_groups, &g->a_magic, &g->a_shift);
   g->qkind = c.quorum_kind;
   g->total = c.replicas_total ? c.replicas_total : c.num_replicas;
   g->base = c.replica_base;
@@ -1287,8 +1297,10 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
   ctx->lanes_per_slot = G;
   // small groups (R <= 16, the reference's everyday f = 1..3): a 64-slot chunk is three dependent round
   // trips and a workgroup's fixed costs (LDS tables, the final reduction) dominate -- 4 workgroups per CU,
-  // each wave walking many chunks, measured 2x faster at R = 3 (profiles/r01_small_r.txt)
-  ctx->max_grid = ctx->num_cus * (G <= 4 ? 4 : 32);
+  // each wave walking many chunks, measured 2x faster at R = 3 (profiles/r01_small_r.txt).  Six per CU is what the kernel's
+  // LDS (23.5 KB with the column-quad staging) lets be resident at once: 3 - 4 % faster than four on BASELINE.json configs[4],
+  // 5 - 15 % on configs[2]; seven and more (a second round of workgroups) are 8 % slower (profiles/r05_cfg5.md)
+  ctx->max_grid = ctx->num_cus * (G <= 4 ? 6 : 32);
   if (const char* e = getenv("FPX_MAX_GRID")) ctx->max_grid = std::max(1, atoi(e));  // tuning aid
   ctx->vec = true;  // rows are padded to a multiple of 4 cells (Geom::RS)
   // big tables: fewer resident blocks so that the partial table stays small

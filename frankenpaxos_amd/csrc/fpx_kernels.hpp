@@ -84,7 +84,31 @@ struct Geom {
   int32_t base, total;                             // replica_base, replicas_total
   uint64_t member[4];                              // bits [0, total)
   int32_t part_rows;                               // rows of State::part (= the largest launch grid)
+  // slot / L and slot / A without a division (fast_div): a 32-bit divide by a kernel argument is ~30 VALU instructions,
+  // and the small-group vote kernel -- VALU-bound: 3900 VALU instructions per wavefront on BASELINE.json configs[4],
+  // profiles/r05_cfg5.md -- met four of them per slot.  0 = divisor 1
+  uint32_t l_magic, a_magic;
+  int32_t l_shift, a_shift;
 };
+
+// s / d for 0 <= s < 2^31 and the (magic, shift) of d >= 2 that make_geom computes: shift = ceil(log2 d) - 1,
+// magic = floor(2^(32 + shift) / d) + 1 < 2^32 (the error term s / 2^(32 + shift) stays below 1 / d because d <= 2^(shift + 1))
+__device__ __forceinline__ int fast_div(int s, uint32_t magic, int shift) {
+  return (int)(__umulhi((uint32_t)s, magic) >> shift);
+}
+// slot -> (leader group, row inside the leader group)
+__device__ __forceinline__ void split_slot(const Geom& g, int s, int* lg, int* row) {
+  const int q = g.l_magic ? fast_div(s, g.l_magic, g.l_shift) : s;
+  *row = q, *lg = s - q * g.num_leader_groups;
+}
+// where slot s lives (phys_slot) and the acceptor group that votes in it (group_of_slot), from one split
+__device__ __forceinline__ void place_of_slot(const Geom& g, int s, int* phys, int* grp) {
+  int lg, row;
+  split_slot(g, s, &lg, &row);
+  *phys = g.lg_rows ? lg * g.lg_rows + row : s;
+  const int ag = g.a_magic ? row - fast_div(row, g.a_magic, g.a_shift) * g.num_groups : 0;
+  *grp = g.ngroups == 1 ? 0 : lg * g.num_groups + ag;
+}
 
 struct State {
   int32_t* promised;    // [ngroups][R]   Acceptor.round
@@ -150,15 +174,19 @@ struct Batch {
 __device__ __forceinline__ int group_of_slot(const Geom& g, int slot) {
   // multipaxos/ProxyLeader.scala:190 ; mencius/ProxyLeader.scala:169-176,231-234
   if (g.ngroups == 1) return 0;
-  const int lg = slot % g.num_leader_groups;
-  const int ag = (slot / g.num_leader_groups) % g.num_groups;
+  int lg, row;
+  split_slot(g, slot, &lg, &row);
+  const int ag = g.a_magic ? row - fast_div(row, g.a_magic, g.a_shift) * g.num_groups : 0;
   return lg * g.num_groups + ag;
 }
 
 // where slot s lives in the cell arrays and the tally tables (vote_round, vote_value, ballot, pl_key, pl_value, pl_bits),
 // row_voted), and which slot a row holds; stamp and the replica log are indexed by the slot itself
 __device__ __forceinline__ int phys_slot(const Geom& g, int s) {
-  return g.lg_rows ? (s % g.num_leader_groups) * g.lg_rows + s / g.num_leader_groups : s;
+  if (!g.lg_rows) return s;
+  int lg, row;
+  split_slot(g, s, &lg, &row);
+  return lg * g.lg_rows + row;
 }
 // k_phase2: leader-group-major rows exist only for groups of at most 32 acceptors (make_geom), so the instantiations
 // for bigger groups -- the headline's among them -- carry no trace of them
@@ -607,8 +635,14 @@ __global__ void __launch_bounds__(256)
     // a slot nobody has voted in yet (the common case: a first proposal) holds -1 in every cell, so a partial
     // vote -- thrifty delivery to a random f+1 of the group (ProxyLeader.scala:190-191), or some acceptors
     // Nacking -- can be stored as whole 16-byte cells blended with -1: full-line traffic, nothing read
+    // the slot's row and acceptor group, ONCE per message: the walk takes them from this lane (small groups only -- at
+    // G > 8 a row is the slot itself and there is one acceptor group per leader group)
+    int myphys = myslot, mygrp = 0;
+    if constexpr (G <= 8) {
+      if (g.lg_rows || !one_group) place_of_slot(g, myslot, &myphys, &mygrp);
+    }
     bool myfresh = false;
-    if constexpr (TGT) myfresh = mv && st.row_voted[phys_slot_g<G>(g, myslot)] == 0;
+    if constexpr (TGT) myfresh = mv && st.row_voted[myphys] == 0;
     // MODE 3: is this chunk the packed walk's?  Decided from the messages' masks before anything else of the chunk is
     // loaded (a chunk that is not costs this launch its masks and row_voted bytes, nothing more)
     int mycell0 = 0, myncell = 0;
@@ -629,7 +663,7 @@ __global__ void __launch_bounds__(256)
     int myway = -1;
     bool mydeliver = mv;
     if (FUSED && mv) {
-      const uint32_t* kr = st.pl_key + (size_t)phys_slot_g<G>(g, myslot) * g.wp;
+      const uint32_t* kr = st.pl_key + (size_t)myphys * g.wp;
       const uint4v k0 = *reinterpret_cast<const uint4v*>(kr);
       uint4v k1 = uint4v{0, 0, 0, 0};
       if (g.wp == 8) k1 = *reinterpret_cast<const uint4v*>(kr + 4);
@@ -660,15 +694,25 @@ __global__ void __launch_bounds__(256)
     }
 
     // ---- walk the chunk, Q slots per step; the ballot row of the next step is already in flight ----
-    auto load_thr = [&](int step, int& s_out, int& grp_out) -> int4v {
+    // message src of the chunk as seen from this lane (at G = 1 a lane walks its own message: nothing to fetch)
+    auto pick = [&](int v, int src) -> int {
+      if constexpr (G == 1) return v;
+      else return __shfl(v, src);
+    };
+    auto load_thr = [&](int step, int& s_out, int& grp_out, int& phys_out) -> int4v {
       const int src = step * Q + q;
-      const int s = __shfl(myslot, src);
+      const int s = pick(myslot, src);
       s_out = s;
       grp_out = 0;
+      phys_out = s;
+      // (fetched by every lane, outside the branch below: a lane that sits the branch out could not be read from)
+      if constexpr (G <= 8) phys_out = pick(myphys, src), grp_out = pick(mygrp, src);
       int4v thr = init_thr;
       if (s >= 0) {
-        const size_t row = (size_t)phys_slot_g<G>(g, s) * (size_t)g.RS + (size_t)r0;
-        if (!one_group) grp_out = group_of_slot(g, s);
+        const size_t row = (size_t)phys_out * (size_t)g.RS + (size_t)r0;
+        if constexpr (G > 8) {
+          if (!one_group) grp_out = group_of_slot(g, s);
+        }
         if (PERSLOT) {
           if (VEC) {
 #if FPX_NT_LOAD
@@ -824,21 +868,21 @@ __global__ void __launch_bounds__(256)
     // body, where -- vmcnt counts stores on gfx9 -- it makes every step wait for the rows the step before it wrote.
     // In the FPX_BALLOT_ACCEPTOR model the walk then has no vector-memory wait at all: rows stream out back to back.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt and lgkmcnt untouched
-    int s_cur, grp_cur;
-    int4v thr_cur = load_thr(0, s_cur, grp_cur);
+    int s_cur, grp_cur, phys_cur;
+    int4v thr_cur = load_thr(0, s_cur, grp_cur, phys_cur);
     for (int t = 0; t < G * CH / 64; ++t) {
 #if FPX_PREFETCH
-      int s_nxt = -1, grp_nxt = 0;
+      int s_nxt = -1, grp_nxt = 0, phys_nxt = 0;
       int4v thr_nxt = init_thr;
-      if (t + 1 < G) thr_nxt = load_thr(t + 1, s_nxt, grp_nxt);
+      if (t + 1 < G) thr_nxt = load_thr(t + 1, s_nxt, grp_nxt, phys_nxt);
 #endif
       const int src = t * Q + q;
       const int s = s_cur;
-      const int rnd = __shfl(myround, src);
-      const int val = __shfl(myvalue, src);
-      const bool deliver = __shfl((int)mydeliver, src) != 0 && s >= 0;
+      const int rnd = pick(myround, src);
+      const int val = pick(myvalue, src);
+      const bool deliver = pick((int)mydeliver, src) != 0 && s >= 0;
       bool fresh = false;
-      if constexpr (TGT) fresh = __shfl((int)myfresh, src) != 0;
+      if constexpr (TGT) fresh = pick((int)myfresh, src) != 0;
       const int4v thr = thr_cur;
       uint64_t tw = ~0ull;
       if constexpr (TGT) {
@@ -872,7 +916,7 @@ __global__ void __launch_bounds__(256)
         // first votes of the slot: cells whose acceptor does not vote hold -1 / -1.  ONE store path for the whole
         // row (fully voted cells included): two half-masked store instructions per array cost the issue
         // slots of two full ones
-        const size_t ps = (size_t)phys_slot_g<G>(g, s), row = ps * (size_t)g.RS + (size_t)r0, vrow = ps * (size_t)g.VS + (size_t)r0;
+        const size_t ps = (size_t)phys_cur, row = ps * (size_t)g.RS + (size_t)r0, vrow = ps * (size_t)g.VS + (size_t)r0;
         int4v rr, vv, nb = thr;
         bool ballot_moves = false;
 #pragma unroll
@@ -885,7 +929,7 @@ __global__ void __launch_bounds__(256)
         row_store(vv, reinterpret_cast<int4v*>(st.vote_value + vrow));
         if (PERSLOT && ballot_moves) row_store(nb, reinterpret_cast<int4v*>(st.ballot + row));
       } else if (acc) {
-        const size_t ps = (size_t)phys_slot_g<G>(g, s), row = ps * (size_t)g.RS + (size_t)r0, vrow = ps * (size_t)g.VS + (size_t)r0;
+        const size_t ps = (size_t)phys_cur, row = ps * (size_t)g.RS + (size_t)r0, vrow = ps * (size_t)g.VS + (size_t)r0;
         // whole-lane fast path: every acceptor this lane owns voted (padding cells may be overwritten)
         if (VEC && full_cell) {
           const int4v rr = {rnd, rnd, rnd, rnd};
@@ -947,10 +991,11 @@ __global__ void __launch_bounds__(256)
               table_used = true;
               const int e = g0 * g.R;
               if (__all(acc == 0 || acc == own)) {  // every acceptor of the group voted wherever one did
-                const int ms = wave_max_to_lane63(acc ? s + 1 : 0), mr = wave_max_to_lane63(acc ? rnd + 1 : 0);
-                if (lane == 63) {
-                  for (int k = 0; k < g.R; ++k) atomicMax(&tab_mv[e + k], ms - 1), atomicMax(&tab_pr[e + k], mr - 1);
-                }
+                // (lane k raises acceptor k's words: one pass instead of R passes of lane 63 alone -- every pass costs
+                // the wavefront its issue slots whoever is active)
+                const int ms = __builtin_amdgcn_readlane(wave_max_to_lane63(acc ? s + 1 : 0), 63);
+                const int mr = __builtin_amdgcn_readlane(wave_max_to_lane63(acc ? rnd + 1 : 0), 63);
+                if (lane < g.R) atomicMax(&tab_mv[e + lane], ms - 1), atomicMax(&tab_pr[e + lane], mr - 1);
               } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -1009,14 +1054,14 @@ __global__ void __launch_bounds__(256)
       } else {
         // ProxyLeader.scala:235-256: record votes, test the quorum, Chosen exactly once
         bool ch = false;
-        const int way = __shfl(myway, src);
+        const int way = pick(myway, src);
         if (deliver) {
           uint64_t x[4];
 #pragma unroll
           for (int w = 0; w < 4; ++w) x[w] = vb[w] & g.member[w];
           ch = is_write_quorum(g, x);
           if (!ch && gi == 0) {  // stays Pending: keep the votes (the key word is written below)
-            const size_t e = (size_t)phys_slot_g<G>(g, s) * g.wp + way;
+            const size_t e = (size_t)phys_cur * g.wp + way;
 #pragma unroll
             for (int w = 0; w < 4; ++w) st.pl_bits[e * 4 + w] = x[w];
           }
@@ -1027,9 +1072,9 @@ __global__ void __launch_bounds__(256)
         }
       }
 #if FPX_PREFETCH
-      s_cur = s_nxt, grp_cur = grp_nxt, thr_cur = thr_nxt;
+      s_cur = s_nxt, grp_cur = grp_nxt, phys_cur = phys_nxt, thr_cur = thr_nxt;
 #else
-      if (t + 1 < G) thr_cur = load_thr(t + 1, s_cur, grp_cur);
+      if (t + 1 < G) thr_cur = load_thr(t + 1, s_cur, grp_cur, phys_cur);
 #endif
     }
     }  // (the walk, one row per step)
@@ -1037,7 +1082,7 @@ __global__ void __launch_bounds__(256)
     // ---- outputs of the 64 messages leave as coalesced lines ------------------------------------
     wave_lds_sync();
     // the slot's row is no longer known to be all -1 (marked even if every acceptor Nacked: that only costs the shortcut)
-    if (TGT ? (myfresh && mydeliver) : (mv && mydeliver)) st.row_voted[phys_slot_g<G>(g, myslot)] = 1;
+    if (TGT ? (myfresh && mydeliver) : (mv && mydeliver)) st.row_voted[myphys] = 1;
     if (mv) {
       if constexpr (!FUSED) {
         if (b.vote_bits) {
@@ -1054,7 +1099,7 @@ __global__ void __launch_bounds__(256)
         const bool ch = wo->chosen[lane] != 0;
         if (mydeliver) {
           // states(slotround) = Done (ProxyLeader.scala:256) or Pending(phase2a, votes) (:213)
-          const size_t e = (size_t)phys_slot_g<G>(g, myslot) * g.wp + myway;
+          const size_t e = (size_t)myphys * g.wp + myway;
           st.pl_key[e] = ((uint32_t)myround + 1u) | (ch ? KEY_DONE : 0u);
           if (!ch) st.pl_value[e] = myvalue;
         }
