@@ -427,11 +427,11 @@ def mencius_setup(fa, dev, local_rank, rank, world, K, Wm):
     def step(i):
         slot, rnd, val, ch, cv, start, end, rr, rch = steps[i]
         # ONE call per step (fpx_mencius_band_fused_dev).  The leader groups with commands and those with ranges alternate,
-        # never both in a step, so the halves MAY run side by side (FPX_CFG5_PARALLEL=1: the ranges on the context's second
-        # stream) -- measured slower than one after the other, 0.0906 against 0.0850 ms per band: the fork and join packets
-        # cost more than the 26 us of range kernels they hide (profiles/r05_cfg5.md); the default is the serial order
+        # never both in a step, and the call says so (`independent`): the step is then two launches -- the vote kernel with
+        # the range chain as its first workgroup, the ranges' fill with the vote kernel's fold of maxima in its grid -- instead
+        # of four (profiles/r05_cfg5.md).  FPX_CFG5_SERIAL=1: the two halves one after the other, as rounds 2 - 4 ran them
         ctx.mencius_band_fused_dev(slot, rnd, val, None, ch, None, cv, None, start, end, rr, None, None, None, None, None, rch,
-                                   independent=os.environ.get("FPX_CFG5_PARALLEL") == "1")
+                                   independent=os.environ.get("FPX_CFG5_SERIAL") != "1")
 
     def verify(lo, hi):
         done = 0
@@ -472,7 +472,7 @@ def mencius_setup(fa, dev, local_rank, rank, world, K, Wm):
                          "others skip theirs with one noop range each (fused K4)"
                          % (L, band, "one batch in slot order across the leader groups" if os.environ.get("FPX_CFG5_ORDER") == "slot"
                             else "the proposing leader groups' batches back to back, each in slot order"),
-                kernel="k_phase2 (fused K3) + K4 (k_ranges_chain, k_ranges_fill_lg), one call per step (fpx_mencius_band_fused_dev)", region_timed=True,
+                kernel="k_phase2_band (fused K3 + the range chain) + k_ranges_fill_lg_fin (K4 fill + the fold of the vote kernel's maxima), one call per step (fpx_mencius_band_fused_dev)", region_timed=True,
                 metric="committed log slots/sec (BASELINE.json configs[4])", cpu=cpu,
                 extra={"slots_per_step_per_gpu": band, "leader_groups_per_gpu": L, "replicas": R,
                        "ranges_per_step_per_gpu": L // 2},

@@ -133,6 +133,10 @@ class Context:
             raise FpxError(st, "fpx_placement_stats")
         return {"chunks": bool(out[0]), "windows": int(out[1]), "probe_ms": (float(out[2]), float(out[3]), float(out[4]))}
 
+    def band_merged_steps(self):
+        """diagnostic: the mencius_band_fused_dev steps that ran in the two-launch form"""
+        return int(self.L.fpx_band_merged_steps(self._h))
+
     # ---- host-pointer entry points (numpy) ---------------------------------------------------
     def acceptor_phase2a(self, slot, round_, value, target_mask=None):
         slot, round_, value, target_mask = _i32(slot), _i32(round_), _i32(value), _u64(target_mask)
@@ -375,7 +379,7 @@ class Context:
                                range_nack_bits=None, range_nack_round=None, range_is_new=None, range_chosen=None,
                                independent=False):
         """one Mencius proxy-leader step: phase2_fused_dev on the commands + noop_ranges_fused_dev on the ranges; with
-        independent (no leader group has both) and FPX_F_TRUSTED the halves run side by side"""
+        independent (no leader group has both) and FPX_F_TRUSTED the step is two launches (or the halves side by side)"""
         st = self.L.fpx_mencius_band_fused_dev(
             self._h, slot.numel(), _dp(slot), _dp(round_), _dp(value), _dp(target_mask), _dp(chosen), _dp(chosen_round),
             _dp(chosen_value), _dp(nack_round), slot_start.numel(), _dp(slot_start), _dp(slot_end), _dp(range_round),

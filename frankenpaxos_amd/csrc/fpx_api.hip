@@ -116,6 +116,7 @@ struct fpx_ctx {
   DevBuf d_rng;  // staging of range batches
   // fpx_mencius_band_fused_dev: the ranges' half of an independent step runs here, between a fork and a join event
   hipStream_t band_stream = nullptr;
+  int64_t band_merged_steps = 0;
   hipEvent_t band_fork = nullptr, band_join = nullptr;
   DevBuf d_band;  // [num_leader_groups] marks: the leader groups with a range in the step being checked
   // multi-GPU (fpx_comm_*): one communicator per context, rank = this context's GPU
@@ -285,10 +286,9 @@ void allow_lds(K kernel, size_t lds) {
   if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-template <int G, int MODE, int PS>
-void launch_phase2_3(fpx_ctx* ctx, const Batch& b0, bool fused, int grid) {
-  size_t lds = lds_bytes(ctx, fused, MODE != 0);
-  Batch b = b0;
+// dynamic LDS of one vote-kernel launch; the offsets of its optional parts go into the batch
+size_t phase2_lds(fpx_ctx* ctx, Batch& b, bool fused, bool targets, bool acceptor_rounds) {
+  size_t lds = lds_bytes(ctx, fused, targets);
   // leader-group-major rows: 3 KiB of LDS per wavefront for the column quads of a slot-ordered batch (k_phase2), when
   // every array they move as 16 bytes is aligned for it
   auto al = [](const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
@@ -298,11 +298,18 @@ void launch_phase2_3(fpx_ctx* ctx, const Batch& b0, bool fused, int grid) {
     b.sc_lds = (int32_t)lds;
     lds += 4 * 3 * 4 * 64 * sizeof(int32_t);
   }
-  if (PS == 0 && ctx->g.ngroups != 1) {  // the acceptors' rounds of every group, staged per workgroup
+  if (acceptor_rounds && ctx->g.ngroups != 1) {  // the acceptors' rounds of every group, staged per workgroup
     lds = (lds + 15) & ~(size_t)15;
     b.th_lds = (int32_t)lds;
     lds += (size_t)ctx->g.ngroups * ctx->g.R * sizeof(int32_t);
   }
+  return lds;
+}
+
+template <int G, int MODE, int PS>
+void launch_phase2_3(fpx_ctx* ctx, const Batch& b0, bool fused, int grid) {
+  Batch b = b0;
+  const size_t lds = phase2_lds(ctx, b, fused, MODE != 0, PS == 0);
   if (fused) allow_lds(k_phase2<G, MODE, PS, true>, lds);
   else allow_lds(k_phase2<G, MODE, PS, false>, lds);
   if (fused)
@@ -347,6 +354,22 @@ void launch_phase2(fpx_ctx* ctx, const Batch& b, bool fused, int grid) {
     case 16: launch_phase2_2<16>(ctx, b, fused, grid); break;
     case 32: launch_phase2_2<32>(ctx, b, fused, grid); break;
     default: launch_phase2_2<64>(ctx, b, fused, grid); break;
+  }
+}
+
+// the vote kernel of a Mencius band with the band's range chain as its first workgroup (enqueue_band_merged)
+template <int G>
+void launch_band_g(fpx_ctx* ctx, const Batch& b, size_t lds, int grid, const RangeTable& rt, const RangeBatch& rb) {
+  allow_lds(k_phase2_band<G, 0, 0, true>, lds);
+  hipExtLaunchKernelGGL((k_phase2_band<G, 0, 0, true>), dim3(grid + 1), dim3(256), (uint32_t)lds, ctx->stream, ctx->ev_start,
+                        ctx->ev_stop, 0, ctx->g, ctx->st, b, rt, rb);
+}
+void launch_band(fpx_ctx* ctx, const Batch& b, size_t lds, int grid, const RangeTable& rt, const RangeBatch& rb) {
+  switch (ctx->lanes_per_slot) {
+    case 1: launch_band_g<1>(ctx, b, lds, grid, rt, rb); break;
+    case 2: launch_band_g<2>(ctx, b, lds, grid, rt, rb); break;
+    case 4: launch_band_g<4>(ctx, b, lds, grid, rt, rb); break;
+    default: launch_band_g<8>(ctx, b, lds, grid, rt, rb); break;
   }
 }
 
@@ -2036,9 +2059,61 @@ int32_t fpx_noop_ranges_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot
   return enqueue_ranges(ctx, b, RANGES_FUSED);
 }
 
+// A band whose halves are independent, in TWO launches instead of four (profiles/r05_cfg5.md): the vote kernel with the
+// range chain as its first workgroup (k_phase2_band), then the fill with the vote kernel's k_finalize in further rows of
+// its grid (k_ranges_fill_lg_fin).  Only for the everyday shape -- groups of at most 32 acceptors on leader-group-major
+// rows, dense delivery, a chain that fits the vote kernel's own LDS, more than one workgroup of commands; *done = false
+// with nothing enqueued otherwise (the caller takes the serial order).
+static int enqueue_band_merged(fpx_ctx* ctx, Batch& b, RangeBatch& rb, bool* done) {
+  *done = false;
+  const Geom& g = ctx->g;
+  const int G = ctx->lanes_per_slot;
+  if (G > 8 || b.target || !g.lg_rows || g.per_slot || getenv("FPX_BAND_SERIAL")) return FPX_OK;
+  const long long chain_words = ranges_chain_words(rb.n, g.num_groups);
+  if (rb.n > RANGES_CHAIN_MAX || chain_words > RANGES_CHAIN_LDS_WORDS || (long long)rb.n * g.num_groups * g.R > 8 * 1024 ||
+      getenv("FPX_RANGES_NO_CHAIN"))
+    return FPX_OK;
+  b.chunk = chunk_for(ctx, b.n);
+  if ((b.n + b.chunk - 1) / b.chunk <= 8) return FPX_OK;  // one workgroup of commands: it finalises itself (`solo`)
+  // (the launch's LDS is every workgroup's: the chain may raise it to what still lets six workgroups share a CU)
+  const size_t lds = std::max(phase2_lds(ctx, b, true, false, true), (size_t)chain_words * 4);
+  if (lds > 26000) return FPX_OK;
+  // -- from here on as enqueue_phase2 and enqueue_ranges (FPX_F_TRUSTED: no validation passes) --
+  b.index_base = ctx->index_base;
+  int rc = enqueue_validate(ctx, b, true);
+  if (rc) return rc;
+  const int grid = grid_for(ctx, b.n);
+  b.solo = 0;
+  b.parity = (int32_t)(ctx->phase2_launches++ & 1u);
+  if (++ctx->launch_seq == 0) ctx->launch_seq = 1;
+  b.launch_seq = ctx->launch_seq;
+  rb.run_id = ++ctx->run_id;
+  rb.fused = 1;
+  rb.quorum = ctx->cfg.f + 1;
+  const bool prof = ctx->profiling && ctx->ev_used + 2 <= ctx->ev.size();
+  ctx->ev_start = prof ? ctx->ev[ctx->ev_used] : nullptr;
+  ctx->ev_stop = prof ? ctx->ev[ctx->ev_used + 1] : nullptr;
+  const RangeTable& rt = ctx->rt[ctx->rt_cur];
+  launch_band(ctx, b, lds, grid, rt, rb);
+  ctx->ev_start = ctx->ev_stop = nullptr;
+  if (prof) ctx->ev_used += 2;
+  if ((rc = launch_check(ctx))) return rc;
+  const int ntab = g.ngroups * g.R;
+  const int slices = std::max(FINALIZE_SLICES, std::min(256, grid / 32)), fgx = (ntab + 63) / 64;
+  const int gy = std::min(rb.n, 4096);
+  const int gx = std::max(1, std::min(ctx->num_cus * 16 / gy, 64));
+  const int fin_rows = (fgx * slices + gx - 1) / gx;
+  hipLaunchKernelGGL(k_ranges_fill_lg_fin, dim3(gx, gy + fin_rows), dim3(256), 0, ctx->stream, g, ctx->st, rb, gy, fin_rows, (int)b.parity,
+                     grid, b.launch_seq, fgx, slices);
+  *done = true;
+  ++ctx->band_merged_steps;
+  return launch_check(ctx);
+}
+
 // One proxy-leader step of Mencius: fpx_phase2_fused_dev on the commands, then fpx_noop_ranges_fused_dev on the ranges --
-// and, when the caller says that no leader group has both (`independent`), the two halves side by side: the ranges on the
-// context's second stream between a fork and a join event (profiles/r05_cfg5.md).
+// and, when the caller says that no leader group has both (`independent`), the two halves in two launches
+// (enqueue_band_merged) or side by side: the ranges on the context's second stream between a fork and a join event
+// (profiles/r05_cfg5.md).
 int32_t fpx_mencius_band_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round, const int32_t* d_value_id,
                                    const uint64_t* d_target_mask, uint8_t* d_chosen, int32_t* d_chosen_round, int32_t* d_chosen_value,
                                    int32_t* d_nack_round, int32_t n_ranges, const int32_t* d_slot_start, const int32_t* d_slot_end,
@@ -2080,6 +2155,20 @@ int32_t fpx_mencius_band_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slo
   const size_t words = (size_t)n_ranges * ctx->g.num_groups * 4;
   if ((rc = ranges_ctx_ok(ctx, n_ranges))) return rc;
   if ((rc = grow(ctx, &ctx->d_rng, (size_t)n_ranges * 4 + 64 + (d_range_vote_bits ? 0 : words * 8)))) return rc;
+  {
+    Batch b;
+    memset(&b, 0, sizeof(b));
+    b.n = n, b.slot = d_slot, b.round = d_round, b.value = d_value_id, b.target = d_target_mask;
+    b.chosen = d_chosen, b.chosen_round = d_chosen_round, b.chosen_value = d_chosen_value, b.nack_round = d_nack_round;
+    RangeBatch rb;
+    memset(&rb, 0, sizeof(rb));
+    rb.n = n_ranges, rb.start = d_slot_start, rb.end = d_slot_end, rb.round = d_range_round, rb.target = d_range_target_masks;
+    rb.entry = (int32_t*)ctx->d_rng.p;
+    rb.vote_bits = d_range_vote_bits ? d_range_vote_bits : (uint64_t*)((char*)ctx->d_rng.p + (((size_t)n_ranges * 4 + 63) & ~(size_t)63));
+    rb.nack_bits = d_range_nack_bits, rb.nack_round = d_range_nack_round, rb.is_new = d_range_is_new, rb.chosen = d_range_chosen;
+    bool done = false;
+    if ((rc = enqueue_band_merged(ctx, b, rb, &done)) || done) return rc;
+  }
   HIPCHK(ctx, hipEventRecord(ctx->band_fork, ctx->stream));
   HIPCHK(ctx, hipStreamWaitEvent(ctx->band_stream, ctx->band_fork, 0));
   hipStream_t main_stream = ctx->stream;
@@ -2093,6 +2182,8 @@ int32_t fpx_mencius_band_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slo
   if (je != hipSuccess) return FPX_EHIP;
   return rc ? rc : rc2;
 }
+
+int64_t fpx_band_merged_steps(fpx_ctx* ctx) { return ctx ? ctx->band_merged_steps : 0; }
 
 namespace {
 struct RangeKey {

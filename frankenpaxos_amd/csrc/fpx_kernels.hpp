@@ -483,738 +483,17 @@ struct WaveOut<true> {     // K3: only the chosen flags are staged; bitmaps stay
   int32_t chosen[64];
 };
 
-template <int G, int MODE, int PS, bool FUSED>
-__global__ void __launch_bounds__(256)
-    k_phase2(const Geom g, const State st, const Batch b) {
-  // PS 0: the acceptor's round is a scalar (FPX_BALLOT_ACCEPTOR); 1: ballot[S][R] in HBM; 2: the same with lazy
-  // Phase1a promises to honour (only while some are outstanding: 8 VGPRs the steady state does not pay)
-  constexpr bool PERSLOT = PS != 0;
-  constexpr bool LAZY = PS == 2;
-  // MODE 0: no target masks (dense delivery) -- the lean kernel of the steady state; 1: target masks; 2: target
-  // masks + FPX_F_SCATTERED_TARGETS.  The target-mask code (LDS staging, fresh-row blend) costs 6-12 VGPRs = one
-  // wave per SIMD, which the dense stream would pay for nothing.
-  constexpr bool TGT = MODE != 0;
-  constexpr bool RMW = MODE == 2;  // (3: target masks that are all runs of neighbouring acceptors, see PACK below)
-  constexpr bool VEC = true;  // 16-byte row accesses
-  constexpr int Q = 64 / G;           // slots per step
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  if (st.status[ST_ABORT] != 0) return;  // a failed validation applies nothing
-
-  const int lane = threadIdx.x & 63;
-  const int wib = threadIdx.x >> 6;
-  if constexpr (G == 64 && (MODE == 1 || MODE == 2)) {
-    // behind a packed walk: a workgroup all of whose chunks that walk took leaves before it sets anything up (8192
-    // workgroups that only found out in their unit loop were 24 us of a 260 us step)
-    if (b.run_done) {
-      const int nunits = (b.n + b.chunk - 1) / b.chunk;
-      bool mine = false;
-      for (int unit = blockIdx.x * 4 + wib; unit < nunits; unit += gridDim.x * 4) mine = mine || b.run_done[unit] == 0;
-      if (!__syncthreads_or(mine)) return;
-    }
-  }
-  const int gi = lane & (G - 1);
-  const int q = lane / G;
-  const int ntab = g.ngroups * g.R;
-  int32_t* tab_pr = reinterpret_cast<int32_t*>(smem);
-  int32_t* tab_mv = tab_pr + ntab;
-  // [0] this workgroup used the tables, [1] its partial-table row, [2] [3] whole-group maxima (round, slot)
-  int32_t* blk_flag = tab_pr + 2 * ntab;
-  WaveOut<FUSED>* wo = reinterpret_cast<WaveOut<FUSED>*>(smem + (((size_t)ntab * 8 + 16 + 15) & ~(size_t)15)) + wib;
-  // launches that carry target masks: the chunk's masks (64 x 32 B per wave) are staged here with one coalesced
-  // load, so that the walk has no global load of its own in the ACCEPTOR model (a dependent load per row made
-  // thrifty delivery latency-bound: 0.88 ms per 2^20 rows against 0.42 ms dense, profiles/r02_thrifty.txt)
-  uint64_t* wt = reinterpret_cast<uint64_t*>(smem + (((size_t)ntab * 8 + 16 + 15) & ~(size_t)15) + 4 * sizeof(WaveOut<FUSED>)) +
-                 (size_t)wib * (256 + 16);
-
-  for (int i = threadIdx.x; i < 2 * ntab + 4; i += blockDim.x) tab_pr[i] = (i < 2 * ntab || i >= 2 * ntab + 2) ? -1 : 0;
-  // FPX_BALLOT_ACCEPTOR with several acceptor groups: every step needs the rounds of ITS group's acceptors.  They are
-  // staged in LDS once per workgroup: as global loads inside the walk they put an s_waitcnt vmcnt(0) into every step,
-  // and on gfx9 vmcnt counts STORES too -- each step then waited until the rows of the step before had reached memory
-  // (a full store round trip per row and wavefront)
-  int32_t* tab_th = reinterpret_cast<int32_t*>(smem + b.th_lds);
-  if (!PERSLOT && g.ngroups != 1)
-    for (int i = threadIdx.x; i < ntab; i += blockDim.x) tab_th[i] = st.promised[i];
-  __syncthreads();
-  int w_slot = -1, w_round = -1;  // maxima over the steps in which the whole group voted (wave-uniform)
-  bool table_used = false;
-
-  const bool one_group = g.ngroups == 1;
-  const int r0 = 4 * gi;  // first local acceptor of this lane
-  uint32_t own = 0;       // which of my 4 acceptors exist
-#pragma unroll
-  for (int k = 0; k < 4; ++k) own |= (r0 + k < g.R) ? (1u << k) : 0u;
-  const int bitpos = g.base + r0;  // global bit of my first acceptor
-
-  // per-lane maxima when there is one acceptor group (registers; folded into LDS at the end)
-  int acc_pr[4] = {-1, -1, -1, -1}, acc_mv[4] = {-1, -1, -1, -1};
-  int4v init_thr = {-1, -1, -1, -1};
-  if (!PERSLOT && one_group) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (own >> k & 1) init_thr[k] = st.promised[r0 + k];
-  }
-
-  // the packed walk (below): lane (half, l32) owns the cells l32 and 32 + l32 of every row it meets
-  // MODE 3 (G = 64 only): the packed walk alone, for the chunks all of whose messages go to runs; the others are left
-  // to a MODE 1 / 2 launch behind this one (Batch::run_done) -- with both walks in one kernel the register count went
-  // from 85 to 141
-  constexpr bool PACK = G == 64 && MODE == 3;
-  static_assert(MODE != 3 || (G == 64 && PS != 2), "the packed walk: 256-cell rows, no lazy promises");
-  int pk_pr[8] = {-1, -1, -1, -1, -1, -1, -1, -1}, pk_mv[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
-  bool pk_used = false;
-
-  int lzr[4] = {-1, -1, -1, -1}, lzf[4] = {0, 0, 0, 0};
-  if (LAZY && one_group) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (own >> k & 1) lzr[k] = st.lz_round[r0 + k], lzf[k] = st.lz_from[r0 + k];
-  }
-
-  // messages per wavefront chunk: 64, or at G = 64 the launch's choice (32 for big batches, fewer when the batch
-  // would not otherwise fill the chip: a wave walks its chunk one row at a time)
-  const int CH = (G == 64) ? b.chunk : 64;
-  // Leader-group-major rows (Geom::lg_rows) want the 64 messages of a wavefront to be 64 consecutive slots of ONE
-  // leader group.  A batch that comes as the leader groups' batches back to back is that already.  A batch in slot
-  // order across P proposing leader groups (message i + P is the next slot of message i's group) is walked COLUMN BY
-  // COLUMN instead: in tiles of 64 P messages, a wavefront takes every P-th message of its tile.  P is read off the
-  // batch (the first message after message 0 with message 0's leader group); any P gives a permutation of the
-  // messages, so a batch without that regularity only loses the speed, and outputs stay indexed by message.  The
-  // workgroups of one XCD take neighbouring columns (they share the tile's input and output lines in that L2).
-  // Measured on BASELINE.json configs[4] (profiles/r03_cfg5.md): 241 -> 92 us for the slot-ordered batch, against 50 us
-  // for the same messages grouped by leader group -- inputs and outputs are one L2 request per message and array here
-  // (a workgroup taking 32 neighbouring columns itself, for the L1's sake: 105 us, fewer workgroups in flight); with the
-  // column quads below the step is 0.118 ms against 0.109 ms for the grouped batch.
-  int period = 1, bx = blockIdx.x;
-  // (small groups only: at R > 32 a slot's row is 128 bytes or more by itself, and the G = 64 kernel of the headline
-  // must not pay registers for this)
-  constexpr bool COLS = G <= 8;
-  if (COLS && g.lg_rows && CH == 64 && b.n >= 128) {
-    const int L = g.num_leader_groups, lg0 = b.slot[0] % L, lim = b.n < 2 * L ? b.n : 2 * L;
-    for (int k0 = 1; k0 < lim; k0 += 64) {
-      const int k = k0 + lane;
-      const uint64_t hit = __ballot(k < lim && b.slot[k] % L == lg0);
-      if (hit) {
-        period = k0 + (int)__ffsll((unsigned long long)hit) - 1;
-        break;
-      }
-    }
-    if (period > 1 && (gridDim.x & 7) == 0) bx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  }
-  // a period that is a multiple of 4: a wavefront takes FOUR neighbouring columns in one go -- lane j reads the 16
-  // bytes (row j, columns c0 .. c0 + 3) of each input array (a quarter of the L2 requests of four strided dword loads)
-  // into its own four words of LDS, walks the columns one after the other, parks each column's result there and stores
-  // the four results of its row as 16 bytes per output array
-  const int kc = (COLS && period > 1 && (period & 3) == 0 && b.sc_lds) ? 4 : 1;
-  const int tile = 64 * period, tiled = period > 1 ? (b.n / tile) * tile : 0;
-  const int u1 = tiled / (64 * kc), per_tile = period / kc;  // units of kc columns x 64 rows; units per tile
-  const int units = u1 + (b.n - tiled + CH - 1) / CH;        // + the plain chunks behind the tiles
-  int32_t* sc = reinterpret_cast<int32_t*>(smem + b.sc_lds) + wib * (3 * 4 * 64);  // [3][4][64] per wavefront
-  for (int unit = bx * 4 + wib; unit < units; unit += gridDim.x * 4) {
-    if constexpr (G == 64 && (MODE == 1 || MODE == 2)) {
-      if (b.run_done && b.run_done[unit]) continue;  // the packed walk of the launch before this one took the chunk
-    }
-    const bool strided = COLS && unit < u1;
-    const bool quad = COLS && strided && kc == 4;
-    const int v0 = tiled + (unit - u1) * CH;  // plain chunk: its first message
-    const int mbase = strided ? (unit / per_tile) * tile + lane * period + (unit % per_tile) * kc : v0 + lane;
-    if (quad) {
-      const int4 a = *reinterpret_cast<const int4*>(b.slot + mbase), c = *reinterpret_cast<const int4*>(b.round + mbase),
-                 d = *reinterpret_cast<const int4*>(b.value + mbase);
-      sc[0 * 256 + 0 * 64 + lane] = a.x, sc[0 * 256 + 1 * 64 + lane] = a.y, sc[0 * 256 + 2 * 64 + lane] = a.z, sc[0 * 256 + 3 * 64 + lane] = a.w;
-      sc[1 * 256 + 0 * 64 + lane] = c.x, sc[1 * 256 + 1 * 64 + lane] = c.y, sc[1 * 256 + 2 * 64 + lane] = c.z, sc[1 * 256 + 3 * 64 + lane] = c.w;
-      sc[2 * 256 + 0 * 64 + lane] = d.x, sc[2 * 256 + 1 * 64 + lane] = d.y, sc[2 * 256 + 2 * 64 + lane] = d.z, sc[2 * 256 + 3 * 64 + lane] = d.w;
-    }
-    for (int cc = 0; cc < (quad ? 4 : 1); ++cc) {
-    // ---- stage the chunk: lane i owns message i (or every period-th message of the unit's tile) ----
-    const int m = mbase + cc;
-    const bool mv = strided || (lane < CH && m < b.n);
-    const int myslot = quad ? sc[0 * 256 + cc * 64 + lane] : (mv ? b.slot[m] : -1);
-    const int myround = quad ? sc[1 * 256 + cc * 64 + lane] : (mv ? b.round[m] : 0);
-    const int myvalue = quad ? sc[2 * 256 + cc * 64 + lane] : (mv ? b.value[m] : 0);
-    // a slot nobody has voted in yet (the common case: a first proposal) holds -1 in every cell, so a partial
-    // vote -- thrifty delivery to a random f+1 of the group (ProxyLeader.scala:190-191), or some acceptors
-    // Nacking -- can be stored as whole 16-byte cells blended with -1: full-line traffic, nothing read
-    // the slot's row and acceptor group, ONCE per message: the walk takes them from this lane (small groups only -- at
-    // G > 8 a row is the slot itself and there is one acceptor group per leader group)
-    int myphys = myslot, mygrp = 0;
-    if constexpr (G <= 8) {
-      if (g.lg_rows || !one_group) place_of_slot(g, myslot, &myphys, &mygrp);
-    }
-    bool myfresh = false;
-    if constexpr (TGT) myfresh = mv && st.row_voted[myphys] == 0;
-    // MODE 3: is this chunk the packed walk's?  Decided from the messages' masks before anything else of the chunk is
-    // loaded (a chunk that is not costs this launch its masks and row_voted bytes, nothing more)
-    int mycell0 = 0, myncell = 0;
-    if constexpr (PACK) {
-      bool okm = true;
-      if (mv) {
-        const uint64_t* tp = b.target + (size_t)m * 4;
-        const uint64_t tm[4] = {tp[0] & g.member[0], tp[1] & g.member[1], tp[2] & g.member[2], tp[3] & g.member[3]};
-        okm = myfresh && classify_run(tm, g.R, &mycell0, &myncell);
-      }
-      const bool packed = __all(okm);
-      if (lane == 0) b.run_done[unit] = packed ? 1 : 0;
-      if (!packed) continue;  // nothing of this chunk has been touched: the launch behind this one walks it row by row
-    }
-    // ProxyLeader.handlePhase2a for 64 messages at once (ProxyLeader.scala:176-184): lane i reads the
-    // tally-key row of its slot (one gathered 16-byte access per lane), detects a known (slot, round)
-    // and picks the free way.  The key word is written back after the walk, one lane per message.
-    int myway = -1;
-    bool mydeliver = mv;
-    if (FUSED && mv) {
-      const uint32_t* kr = st.pl_key + (size_t)myphys * g.wp;
-      const uint4v k0 = *reinterpret_cast<const uint4v*>(kr);
-      uint4v k1 = uint4v{0, 0, 0, 0};
-      if (g.wp == 8) k1 = *reinterpret_cast<const uint4v*>(kr + 4);
-      const uint32_t want = (uint32_t)myround + 1u;
-      const uint32_t keys[8] = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
-      bool dup = false;
-#pragma unroll
-      for (int w = 7; w >= 0; --w) {
-        if (w < g.ways) {
-          dup = dup || ((keys[w] & KEY_ROUND_MASK) == want);
-          if (keys[w] == 0) myway = w;
-        }
-      }
-      mydeliver = !dup && myway >= 0;  // a known (slot, round) is ignored and NOT forwarded
-      if (!dup && myway < 0) report(st, 5 /*FPX_ECAPACITY*/, m + b.index_base, myslot, myround);
-    }
-
-    if constexpr (TGT) {
-      if (strided) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w) wt[lane * 4 + w] = b.target[(size_t)m * 4 + w];
-      } else {
-        const size_t w0 = (size_t)v0 * 4, wend = (size_t)b.n * 4;
-        for (int w = lane; w < CH * 4; w += 64)
-          if (w0 + w < wend) wt[w] = b.target[w0 + w];
-      }
-      wave_lds_sync();
-    }
-
-    // ---- walk the chunk, Q slots per step; the ballot row of the next step is already in flight ----
-    // message src of the chunk as seen from this lane (at G = 1 a lane walks its own message: nothing to fetch)
-    auto pick = [&](int v, int src) -> int {
-      if constexpr (G == 1) return v;
-      else return __shfl(v, src);
-    };
-    auto load_thr = [&](int step, int& s_out, int& grp_out, int& phys_out) -> int4v {
-      const int src = step * Q + q;
-      const int s = pick(myslot, src);
-      s_out = s;
-      grp_out = 0;
-      phys_out = s;
-      // (fetched by every lane, outside the branch below: a lane that sits the branch out could not be read from)
-      if constexpr (G <= 8) phys_out = pick(myphys, src), grp_out = pick(mygrp, src);
-      int4v thr = init_thr;
-      if (s >= 0) {
-        const size_t row = (size_t)phys_out * (size_t)g.RS + (size_t)r0;
-        if constexpr (G > 8) {
-          if (!one_group) grp_out = group_of_slot(g, s);
-        }
-        if (PERSLOT) {
-          if (VEC) {
-#if FPX_NT_LOAD
-            if (own) thr = __builtin_nontemporal_load(reinterpret_cast<const int4v*>(st.ballot + row));
-#else
-            if (own) thr = *reinterpret_cast<const int4v*>(st.ballot + row);
-#endif
-          } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              if (own >> k & 1) thr[k] = st.ballot[row + k];
-          }
-        } else if (!one_group) {
-          const int32_t* pr = tab_th + grp_out * g.R + r0;
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (own >> k & 1) thr[k] = pr[k];
-        }
-        if constexpr (LAZY) {
-          if (one_group) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int lz = s >= lzf[k] ? lzr[k] : -1;
-              thr[k] = lz > thr[k] ? lz : thr[k];
-            }
-          } else {
-            const size_t e = (size_t)grp_out * g.R + r0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              if (own >> k & 1) {
-                const int lz = s >= st.lz_from[e + k] ? st.lz_round[e + k] : -1;
-                thr[k] = lz > thr[k] ? lz : thr[k];
-              }
-            }
-          }
-        }
-      }
-      return thr;
-    };
-
-    // ---- thrifty delivery to RUNS of acceptors: two rows per step -------------------------------------------------
-    // The walk below costs ~180 vector instructions per row whatever the row moves: 0.31 ms per 2^20 rows, the time of
-    // a dense step, for half the bytes (profiles/r04_thrifty.md).  When every message of the chunk goes to a sector-aligned run of
-    // at most 128 acceptors of a fresh row (classify_run), a wavefront takes TWO rows per step, 32 lanes each.  A run
-    // is a window of 32 consecutive cells (mod 64), which holds exactly one of the cells l32 and 32 + l32 for every
-    // l32: lane (half, l32) takes that one, so it only ever meets two fixed cells -- its acceptors' rounds and maxima
-    // stay in registers.  With no Nack in the step the votes of a row ARE its target set: the bitmap is not assembled.
-    if constexpr (PACK) {
-      pk_used = true;
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // the chunk's own loads (see below)
-      const int half = lane >> 5, l32 = lane & 31;
-      uint32_t own_hi = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) own_hi |= (128 + 4 * l32 + k < g.R) ? (1u << k) : 0u;
-      int4v th_lo = {-1, -1, -1, -1}, th_hi = {-1, -1, -1, -1};
-      if (!PERSLOT) {
-        th_lo = *reinterpret_cast<const int4v*>(st.promised + 4 * l32);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (own_hi >> k & 1) th_hi[k] = st.promised[128 + 4 * l32 + k];
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-      }
-      uint64_t* scr = wt + 256 + half * 8;  // [2][4]: votes, Nacks of my row when somebody Nacks
-      for (int t = 0; t < CH / 2; ++t) {
-        const int src = 2 * t + half;
-        const int s = __shfl(myslot, src);
-        const int rnd = __shfl(myround, src);
-        const int val = __shfl(myvalue, src);
-        const bool deliver = __shfl((int)mydeliver, src) != 0 && s >= 0;
-        const int c0 = __shfl(mycell0, src), nc = __shfl(myncell, src);
-        const int j = (l32 - c0) & 31;   // my place in the run's window
-        const int c = (c0 + j) & 63;     // my cell of this row
-        const bool hi = c >= 32, active = j < nc && deliver;
-        const int bp = 4 * c;
-        const uint32_t own_c = hi ? own_hi : 0xFu;
-        const uint64_t tw = active ? wt[src * 4 + (bp >> 6)] : 0ull;
-        const uint32_t tn = own_c & (uint32_t)((tw >> (bp & 63)) & 0xFull);
-        const size_t row = (size_t)s * (size_t)g.RS + (size_t)bp, vrow = (size_t)s * (size_t)g.VS + (size_t)bp;
-        int4v thr = hi ? th_hi : th_lo;
-        if (PERSLOT && active) thr = *reinterpret_cast<const int4v*>(st.ballot + row);
-        uint32_t acc = 0, nck = 0;
-        int nr = -1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const bool tk = (tn >> k) & 1u;
-          const bool ok = tk && (rnd >= thr[k]);  // Acceptor.scala:192
-          acc |= ok ? (1u << k) : 0u;
-          if (tk && !ok) nck |= 1u << k, nr = thr[k] > nr ? thr[k] : nr;
-        }
-        if (active) {  // a fresh row: every cell of the sectors the run touches is written whole, -1 where nobody votes
-          int4v rr, vv, nb = thr;
-          bool ballot_moves = false;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const bool a = (acc >> k) & 1u;
-            rr[k] = a ? rnd : -1, vv[k] = a ? val : -1;
-            if (a) ballot_moves = ballot_moves || thr[k] != rnd, nb[k] = rnd;
-          }
-          row_store(rr, reinterpret_cast<int4v*>(st.vote_round + vrow));
-          row_store(vv, reinterpret_cast<int4v*>(st.vote_value + vrow));
-          if (PERSLOT && ballot_moves) row_store(nb, reinterpret_cast<int4v*>(st.ballot + row));
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const bool a = (acc >> k) & 1u;
-          const bool al = a && !hi, ah = a && hi;
-          pk_mv[k] = (al && s > pk_mv[k]) ? s : pk_mv[k], pk_pr[k] = (al && rnd > pk_pr[k]) ? rnd : pk_pr[k];
-          pk_mv[4 + k] = (ah && s > pk_mv[4 + k]) ? s : pk_mv[4 + k], pk_pr[4 + k] = (ah && rnd > pk_pr[4 + k]) ? rnd : pk_pr[4 + k];
-        }
-        uint64_t vb[4], nbits[4] = {0, 0, 0, 0};
-        int nrm = -1;
-        if (!__any(nck != 0u)) {  // everybody asked voted: the votes are the targets
-#pragma unroll
-          for (int w = 0; w < 4; ++w) vb[w] = deliver ? (wt[src * 4 + w] & g.member[w]) : 0ull;
-        } else {
-          if (l32 < 8) scr[l32] = 0ull;
-          wave_lds_sync();
-          if (acc) atomicOr(reinterpret_cast<unsigned long long*>(&scr[bp >> 6]), (unsigned long long)acc << (bp & 63));
-          if (nck) atomicOr(reinterpret_cast<unsigned long long*>(&scr[4 + (bp >> 6)]), (unsigned long long)nck << (bp & 63));
-          wave_lds_sync();
-#pragma unroll
-          for (int w = 0; w < 4; ++w) vb[w] = scr[w], nbits[w] = scr[4 + w];
-          nrm = group_max<32>(nr);
-          wave_lds_sync();
-        }
-        if constexpr (!FUSED) {
-          if (l32 == 0) {
-#pragma unroll
-            for (int w = 0; w < 4; ++w) wo->votes[src][w] = vb[w], wo->nacks[src][w] = b.nack_bits ? nbits[w] : 0ull;
-            wo->nack_round[src] = nrm;
-          }
-        } else {
-          bool ch = false;  // ProxyLeader.scala:235-256
-          const int way = __shfl(myway, src);
-          if (deliver) {
-            uint64_t x[4];
-#pragma unroll
-            for (int w = 0; w < 4; ++w) x[w] = vb[w] & g.member[w];
-            ch = is_write_quorum(g, x);
-            if (!ch && l32 == 0) {
-              const size_t e = (size_t)s * g.wp + way;
-#pragma unroll
-              for (int w = 0; w < 4; ++w) st.pl_bits[e * 4 + w] = x[w];
-            }
-          }
-          if (l32 == 0) wo->chosen[src] = ch ? 1 : 0, wo->nack_round[src] = nrm;
-        }
-      }
-    }
-    if constexpr (!PACK) {
-    // Everything the chunk loaded (messages, tally keys, row_voted, masks, and at kernel start the acceptors' rounds) is
-    // waited for HERE: left to the compiler, the s_waitcnt vmcnt(0) of a first use inside the walk sits in the loop
-    // body, where -- vmcnt counts stores on gfx9 -- it makes every step wait for the rows the step before it wrote.
-    // In the FPX_BALLOT_ACCEPTOR model the walk then has no vector-memory wait at all: rows stream out back to back.
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt and lgkmcnt untouched
-    int s_cur, grp_cur, phys_cur;
-    int4v thr_cur = load_thr(0, s_cur, grp_cur, phys_cur);
-    for (int t = 0; t < G * CH / 64; ++t) {
-#if FPX_PREFETCH
-      int s_nxt = -1, grp_nxt = 0, phys_nxt = 0;
-      int4v thr_nxt = init_thr;
-      if (t + 1 < G) thr_nxt = load_thr(t + 1, s_nxt, grp_nxt, phys_nxt);
-#endif
-      const int src = t * Q + q;
-      const int s = s_cur;
-      const int rnd = pick(myround, src);
-      const int val = pick(myvalue, src);
-      const bool deliver = pick((int)mydeliver, src) != 0 && s >= 0;
-      bool fresh = false;
-      if constexpr (TGT) fresh = pick((int)myfresh, src) != 0;
-      const int4v thr = thr_cur;
-      uint64_t tw = ~0ull;
-      if constexpr (TGT) {
-        if (own && s >= 0) tw = wt[src * 4 + (bitpos >> 6)];
-      }
-
-      // Acceptor.scala:192: phase2a.round < round -> Nack ; else vote
-      const uint32_t tn = deliver ? (own & (uint32_t)((tw >> (bitpos & 63)) & 0xFull)) : 0u;
-      uint32_t acc = 0, nck = 0;
-      int nr = -1;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const bool tk = (tn >> k) & 1u;
-        const bool ok = tk && (rnd >= thr[k]);
-        acc |= ok ? (1u << k) : 0u;
-        if (tk && !ok) {
-          nck |= 1u << k;
-          nr = thr[k] > nr ? thr[k] : nr;
-        }
-      }
-      // Acceptor.scala:204-208: round = phase2a.round; states(slot) = State(round, value)
-      const bool full_cell = (acc | (~own & 0xFu)) == 0xFu;
-      // does any acceptor of my 64-byte sector (4 lanes x 16 B) vote?  A fresh sector nobody votes in stays as it is
-      // (contiguous target runs would otherwise write twice the bytes); one somebody votes in is written whole
-      uint32_t sector_acc = 0;
-      if constexpr (TGT) {
-        sector_acc = acc | (uint32_t)__shfl_xor((int)acc, 1);
-        sector_acc |= (uint32_t)__shfl_xor((int)sector_acc, 2);
-      }
-      if (TGT && fresh && deliver && own && sector_acc) {
-        // first votes of the slot: cells whose acceptor does not vote hold -1 / -1.  ONE store path for the whole
-        // row (fully voted cells included): two half-masked store instructions per array cost the issue
-        // slots of two full ones
-        const size_t ps = (size_t)phys_cur, row = ps * (size_t)g.RS + (size_t)r0, vrow = ps * (size_t)g.VS + (size_t)r0;
-        int4v rr, vv, nb = thr;
-        bool ballot_moves = false;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const bool a = (acc >> k) & 1u;
-          rr[k] = a ? rnd : -1, vv[k] = a ? val : -1;
-          if (a) ballot_moves = ballot_moves || thr[k] != rnd, nb[k] = rnd;
-        }
-        row_store(rr, reinterpret_cast<int4v*>(st.vote_round + vrow));
-        row_store(vv, reinterpret_cast<int4v*>(st.vote_value + vrow));
-        if (PERSLOT && ballot_moves) row_store(nb, reinterpret_cast<int4v*>(st.ballot + row));
-      } else if (acc) {
-        const size_t ps = (size_t)phys_cur, row = ps * (size_t)g.RS + (size_t)r0, vrow = ps * (size_t)g.VS + (size_t)r0;
-        // whole-lane fast path: every acceptor this lane owns voted (padding cells may be overwritten)
-        if (VEC && full_cell) {
-          const int4v rr = {rnd, rnd, rnd, rnd};
-          const int4v vv = {val, val, val, val};
-          row_store(rr, reinterpret_cast<int4v*>(st.vote_round + vrow));
-          row_store(vv, reinterpret_cast<int4v*>(st.vote_value + vrow));
-          if (PERSLOT) {
-            if (((own & 1u) && thr[0] != rnd) || ((own & 2u) && thr[1] != rnd) || ((own & 4u) && thr[2] != rnd) ||
-                ((own & 8u) && thr[3] != rnd))
-              row_store(rr, reinterpret_cast<int4v*>(st.ballot + row));
-          }
-        } else if (RMW) {
-          // some of the lane's acceptors voted (thrifty delivery to a random f+1): read-modify-write of whole
-          // 16-byte cells keeps the traffic full-line -- 4-byte stores leave the L2 with partially written
-          // sectors that cost a DRAM read-modify-write each at eviction (+15 % on random f+1 of 255,
-          // profiles/r01_thrifty.txt).  Its own instantiation: the load in the step costs registers (one
-          // wave less per SIMD) and a wait that contiguous or dense targets do not want.
-          int4v* pr = reinterpret_cast<int4v*>(st.vote_round + vrow);
-          int4v* pv = reinterpret_cast<int4v*>(st.vote_value + vrow);
-          int4v orr = *pr, ovv = *pv;
-          int4v nb = {thr[0], thr[1], thr[2], thr[3]};
-          bool ballot_moves = false;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            if (acc >> k & 1u) {
-              orr[k] = rnd, ovv[k] = val;
-              ballot_moves = ballot_moves || thr[k] != rnd;
-              nb[k] = rnd;
-            }
-          }
-          row_store(orr, pr);
-          row_store(ovv, pv);
-          if (PERSLOT && ballot_moves) row_store(nb, reinterpret_cast<int4v*>(st.ballot + row));
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            if (acc >> k & 1u) {
-              st.vote_round[vrow + k] = rnd;
-              st.vote_value[vrow + k] = val;
-              if (PERSLOT && thr[k] != rnd) st.ballot[row + k] = rnd;
-            }
-          }
-        }
-      }
-      // maxVotedSlot (Acceptor.scala:209) and the acceptor's new round.  When the WHOLE group voted
-      // (the steady state) the maxima are the same for every acceptor: two wave-uniform scalars.
-      const bool whole_group = (G == 64) && one_group && __all(acc == own);
-      // G = 1 with several acceptor groups: a step whose 64 slots belong to ONE group (a leader group's batch; with
-      // leader-group-major rows the batches of a launch are best sent that way) would send 64 lanes to the same LDS
-      // words, 2 R serialized atomics each.  Fold such a step in registers; lane 63 alone touches the table.
-      bool folded = false;
-      if constexpr (G == 1) {
-        if (!one_group) {
-          const uint64_t have = __ballot(acc != 0);
-          if (have) {
-            const int g0 = __shfl(grp_cur, (int)__ffsll((unsigned long long)have) - 1);
-            if (__all(acc == 0 || grp_cur == g0)) {
-              folded = true;
-              table_used = true;
-              const int e = g0 * g.R;
-              if (__all(acc == 0 || acc == own)) {  // every acceptor of the group voted wherever one did
-                // (lane k raises acceptor k's words: one pass instead of R passes of lane 63 alone -- every pass costs
-                // the wavefront its issue slots whoever is active)
-                const int ms = __builtin_amdgcn_readlane(wave_max_to_lane63(acc ? s + 1 : 0), 63);
-                const int mr = __builtin_amdgcn_readlane(wave_max_to_lane63(acc ? rnd + 1 : 0), 63);
-                if (lane < g.R) atomicMax(&tab_mv[e + lane], ms - 1), atomicMax(&tab_pr[e + lane], mr - 1);
-              } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                  const bool a = (acc >> k) & 1u;
-                  const int ms = wave_max_to_lane63(a ? s + 1 : 0), mr = wave_max_to_lane63(a ? rnd + 1 : 0);
-                  if (lane == 63 && ms > 0) atomicMax(&tab_mv[e + k], ms - 1), atomicMax(&tab_pr[e + k], mr - 1);
-                }
-              }
-            }
-          }
-        }
-      }
-      if (whole_group) {
-        w_slot = s > w_slot ? s : w_slot;
-        w_round = rnd > w_round ? rnd : w_round;
-      } else if (acc && !folded) {
-        if (one_group) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            if (acc >> k & 1u) {
-              acc_mv[k] = s > acc_mv[k] ? s : acc_mv[k];
-              acc_pr[k] = rnd > acc_pr[k] ? rnd : acc_pr[k];
-            }
-          }
-        } else {
-          table_used = true;
-          const int e = grp_cur * g.R + r0;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            if (acc >> k & 1u) {
-              atomicMax(&tab_mv[e + k], s);
-              atomicMax(&tab_pr[e + k], rnd);
-            }
-          }
-        }
-      }
-
-      // ---- the slot's vote bitmap, in registers -----------------------------------------------
-      uint64_t vb[4];
-      assemble_bits<G>(acc, lane, g.base, vb);
-      int nrm = -1;
-      const bool any_nack = __any(nck != 0u);  // wave-uniform: the Nack reductions are rare
-      if (any_nack) nrm = group_max<G>(nr);
-
-      if constexpr (!FUSED) {
-        uint64_t nb[4] = {0, 0, 0, 0};
-        if (b.nack_bits && any_nack) assemble_bits<G>(nck, lane, g.base, nb);
-        if (gi == 0) {
-#pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            wo->votes[src][w] = vb[w];
-            wo->nacks[src][w] = nb[w];
-          }
-          wo->nack_round[src] = nrm;
-        }
-      } else {
-        // ProxyLeader.scala:235-256: record votes, test the quorum, Chosen exactly once
-        bool ch = false;
-        const int way = pick(myway, src);
-        if (deliver) {
-          uint64_t x[4];
-#pragma unroll
-          for (int w = 0; w < 4; ++w) x[w] = vb[w] & g.member[w];
-          ch = is_write_quorum(g, x);
-          if (!ch && gi == 0) {  // stays Pending: keep the votes (the key word is written below)
-            const size_t e = (size_t)phys_cur * g.wp + way;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) st.pl_bits[e * 4 + w] = x[w];
-          }
-        }
-        if (gi == 0) {
-          wo->chosen[src] = ch ? 1 : 0;
-          wo->nack_round[src] = nrm;
-        }
-      }
-#if FPX_PREFETCH
-      s_cur = s_nxt, grp_cur = grp_nxt, phys_cur = phys_nxt, thr_cur = thr_nxt;
-#else
-      if (t + 1 < G) thr_cur = load_thr(t + 1, s_cur, grp_cur, phys_cur);
-#endif
-    }
-    }  // (the walk, one row per step)
-
-    // ---- outputs of the 64 messages leave as coalesced lines ------------------------------------
-    wave_lds_sync();
-    // the slot's row is no longer known to be all -1 (marked even if every acceptor Nacked: that only costs the shortcut)
-    if (TGT ? (myfresh && mydeliver) : (mv && mydeliver)) st.row_voted[myphys] = 1;
-    if (mv) {
-      if constexpr (!FUSED) {
-        if (b.vote_bits) {
-          uint64_t* o = b.vote_bits + (size_t)m * 4;
-#pragma unroll
-          for (int w = 0; w < 4; ++w) o[w] = wo->votes[lane][w];
-        }
-        if (b.nack_bits) {
-          uint64_t* o = b.nack_bits + (size_t)m * 4;
-#pragma unroll
-          for (int w = 0; w < 4; ++w) o[w] = wo->nacks[lane][w];
-        }
-      } else {
-        const bool ch = wo->chosen[lane] != 0;
-        if (mydeliver) {
-          // states(slotround) = Done (ProxyLeader.scala:256) or Pending(phase2a, votes) (:213)
-          const size_t e = (size_t)myphys * g.wp + myway;
-          st.pl_key[e] = ((uint32_t)myround + 1u) | (ch ? KEY_DONE : 0u);
-          if (!ch) st.pl_value[e] = myvalue;
-        }
-        if (quad) {  // parked: chosen flag and nack_round; the round and the value are still there
-          sc[0 * 256 + cc * 64 + lane] = ((wo->nack_round[lane] + 1) << 1) | (ch ? 1 : 0);
-        } else {
-          if (b.chosen) b.chosen[m] = ch ? 1 : 0;
-          if (b.chosen_round) b.chosen_round[m] = ch ? myround : -1;
-          if (b.chosen_value) b.chosen_value[m] = ch ? myvalue : -1;
-        }
-      }
-      if (b.nack_round && !(FUSED && quad)) b.nack_round[m] = wo->nack_round[lane];
-    }
-    wave_lds_sync();
-    }  // columns of the unit
-    if (FUSED && quad) {  // the four results of my row, 16 bytes per output array
-      int4 cr, cv, nr;
-      uint32_t chb = 0;
-      int* crp = &cr.x;
-      int* cvp = &cv.x;
-      int* nrp = &nr.x;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int w = sc[0 * 256 + k * 64 + lane];
-        const bool ch = w & 1;
-        chb |= (ch ? 1u : 0u) << (8 * k);
-        crp[k] = ch ? sc[1 * 256 + k * 64 + lane] : -1;
-        cvp[k] = ch ? sc[2 * 256 + k * 64 + lane] : -1;
-        nrp[k] = (w >> 1) - 1;
-      }
-      if (b.chosen) *reinterpret_cast<uint32_t*>(b.chosen + mbase) = chb;
-      if (b.chosen_round) *reinterpret_cast<int4*>(b.chosen_round + mbase) = cr;
-      if (b.chosen_value) *reinterpret_cast<int4*>(b.chosen_value + mbase) = cv;
-      if (b.nack_round) *reinterpret_cast<int4*>(b.nack_round + mbase) = nr;
-      wave_lds_sync();
-    }
-  }
-
-  // ---- fold maxima --------------------------------------------------------------------------------
-  // (a) steps in which the WHOLE group voted only raised two wave-uniform scalars: one pair of
-  //     atomics per wavefront into a 64-way sharded table (the common case: nothing else to do);
-  // (b) everything else went through registers / LDS tables: the workgroup appends ONE row to the
-  //     partial table, claimed with a counter, only if it saw such a step.
-  const int par = b.parity;
-  if (lane == 0 && w_slot >= 0) {  // wave -> workgroup (LDS)
-    atomicMax(&blk_flag[2], w_round);
-    atomicMax(&blk_flag[3], w_slot);
-  }
-  if constexpr (PACK) {
-    if (__any(pk_used)) {  // cell gi's maxima sit in the lanes gi & 31 of both halves, in their low or high set
-      const int la = lane & 31, lb = 32 + (lane & 31);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int m0 = __shfl(pk_mv[k], la), m1 = __shfl(pk_mv[k], lb), m2 = __shfl(pk_mv[4 + k], la), m3 = __shfl(pk_mv[4 + k], lb);
-        const int p0 = __shfl(pk_pr[k], la), p1 = __shfl(pk_pr[k], lb), p2 = __shfl(pk_pr[4 + k], la), p3 = __shfl(pk_pr[4 + k], lb);
-        const int mm = lane < 32 ? (m0 > m1 ? m0 : m1) : (m2 > m3 ? m2 : m3), pp = lane < 32 ? (p0 > p1 ? p0 : p1) : (p2 > p3 ? p2 : p3);
-        acc_mv[k] = mm > acc_mv[k] ? mm : acc_mv[k], acc_pr[k] = pp > acc_pr[k] ? pp : acc_pr[k];
-      }
-    }
-  }
-  bool any_table = false;
-  if (one_group) {
-    // the 64 / G lanes with the same gi hold maxima of the same acceptors: fold them across the wavefront first, one
-    // lane per acceptor quad touches the LDS table (at G = 1 all 256 lanes of the workgroup would otherwise queue on
-    // the same 2 R words: 12 us of a 19 us kernel on a 65 536 x 3 step, profiles/r03_small_n.txt)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if constexpr (G == 1) {
-        acc_mv[k] = wave_max_to_lane63(acc_mv[k] + 1) - 1, acc_pr[k] = wave_max_to_lane63(acc_pr[k] + 1) - 1;
-      } else if constexpr (G < 64) {
-#pragma unroll
-        for (int m = G; m < 64; m <<= 1) {
-          const int a = __shfl_xor(acc_mv[k], m), c = __shfl_xor(acc_pr[k], m);
-          acc_mv[k] = a > acc_mv[k] ? a : acc_mv[k], acc_pr[k] = c > acc_pr[k] ? c : acc_pr[k];
-        }
-      }
-    }
-    const bool folder = G == 1 ? lane == 63 : q == 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (folder && (own >> k & 1u)) {
-        if (acc_mv[k] >= 0) atomicMax(&tab_mv[r0 + k], acc_mv[k]), any_table = true;
-        if (acc_pr[k] >= 0) atomicMax(&tab_pr[r0 + k], acc_pr[k]), any_table = true;
-      }
-    }
-  } else {
-    any_table = table_used;
-  }
-  if (any_table) blk_flag[0] = 1;
-  __syncthreads();
-  if (b.solo) {
-    // a small batch (a tick of a few hundred messages is the reference's everyday case): the launch is this one
-    // workgroup, so its LDS tables ARE the launch's maxima -- what k_finalize would fold out of the partial rows.
-    // One launch instead of two: ~16 -> ~9 us per fused step (profiles/r03_small_n.txt)
-    const int wr = blk_flag[2], ws = blk_flag[3];
-    int32_t* top = g.per_slot ? st.max_ballot : st.promised;
-    for (int e = threadIdx.x; e < ntab; e += blockDim.x) {
-      int pr = tab_pr[e], mv = tab_mv[e];
-      if (g.ngroups == 1) pr = wr > pr ? wr : pr, mv = ws > mv ? ws : mv;
-      if (pr > top[e]) top[e] = pr;
-      if (mv > st.max_voted[e]) st.max_voted[e] = mv;
-    }
-    return;
-  }
-  if (threadIdx.x == 0 && blk_flag[3] >= 0) {  // workgroup -> one of 64 cache lines (2 atomics per workgroup)
-    int32_t* pa = st.part_all + ((size_t)par * 64 + (blockIdx.x & 63)) * PART_ALL_STRIDE;
-    atomicMax(&pa[0], blk_flag[2]);
-    atomicMax(&pa[1], blk_flag[3]);
-  }
-  if (blk_flag[0] && (int)blockIdx.x < g.part_rows) {  // (the grid never exceeds part_rows: never write out of bounds)
-    int32_t* prow = st.part + (size_t)blockIdx.x * 2 * ntab;
-    for (int i = threadIdx.x; i < 2 * ntab; i += blockDim.x) prow[i] = tab_pr[i];
-    if (threadIdx.x == 0) st.part_stamp[blockIdx.x] = b.launch_seq;
-  }
-}
+#define FPX_P2_NAME k_phase2
+#define FPX_P2_EXTRA_PARAMS
+#define FPX_P2_NBLK gridDim.x
+#define FPX_P2_BID blockIdx.x
+#define FPX_P2_PROLOGUE
+#include "fpx_phase2_body.inc"
+#undef FPX_P2_NAME
+#undef FPX_P2_EXTRA_PARAMS
+#undef FPX_P2_NBLK
+#undef FPX_P2_BID
+#undef FPX_P2_PROLOGUE
 
 // ------------------------------------------------------------------------------------------------
 // k_finalize: promised[e] = max(promised[e], max_b part[b][0][e]); max_voted likewise.
@@ -1223,20 +502,22 @@ __global__ void __launch_bounds__(256)
 // grid = (ceil(ntab / 64), FINALIZE_SLICES): blockIdx.y strides over the rows of the partial table,
 // the 4 waves of a block stride within that; one atomicMax per (entry, blockIdx.y) that improves.
 constexpr int FINALIZE_SLICES = 8;  // at least; the launch uses more for big grids (about 8 rows per wavefront)
-__global__ void __launch_bounds__(256) k_finalize(const Geom g, const State st, int par, int grid, uint32_t seq) {
+// (the body by workgroup coordinates: k_finalize is its own grid, k_ranges_fill_lg_fin -- fpx_ranges.hpp -- appends
+// these workgroups to a Mencius band's fill)
+__device__ __forceinline__ void finalize_body(const Geom& g, const State& st, int par, int grid, uint32_t seq, int fx, int fy, int slices) {
   __shared__ int32_t red[2][4][64];
   // the buffers of the OTHER parity are used by the next launch: clear them here, whatever happens
-  if (blockIdx.x == 0 && blockIdx.y == 0) {
+  if (fx == 0 && fy == 0) {
     if (threadIdx.x < 128)
       st.part_all[((size_t)(par ^ 1) * 64 + (threadIdx.x >> 1)) * PART_ALL_STRIDE + (threadIdx.x & 1)] = -1;
   }
   if (st.status[ST_ABORT] != 0) return;
   const int ntab = g.ngroups * g.R;
   const int nblocks = grid < g.part_rows ? grid : g.part_rows;
-  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int e = fx * 64 + (threadIdx.x & 63);
   const int slice = threadIdx.x >> 6;
   int pr = -1, mvs = -1;
-  if (blockIdx.y == 0 && slice == 0 && g.ngroups == 1) {
+  if (fy == 0 && slice == 0 && g.ngroups == 1) {
     // steps in which the whole group voted (k_phase2 (a)): the same maxima for every acceptor
     const int32_t* pa = st.part_all + (size_t)par * 64 * PART_ALL_STRIDE;
     for (int i = 0; i < 64; ++i) {
@@ -1246,7 +527,7 @@ __global__ void __launch_bounds__(256) k_finalize(const Geom g, const State st, 
   }
   if (e < ntab) {
 #pragma unroll 4
-    for (int bl = blockIdx.y * 4 + slice; bl < nblocks; bl += 4 * (int)gridDim.y) {
+    for (int bl = fy * 4 + slice; bl < nblocks; bl += 4 * slices) {
       // stamp and row are loaded together (no dependent chain); a row of another launch is simply not used
       const bool mine = st.part_stamp[bl] == seq;  // that workgroup of THIS launch used the tables
       const int32_t* prow = st.part + (size_t)bl * 2 * ntab;
@@ -1268,6 +549,9 @@ __global__ void __launch_bounds__(256) k_finalize(const Geom g, const State st, 
     if (pr > top[e]) atomicMax(&top[e], pr);
     if (mvs > st.max_voted[e]) atomicMax(&st.max_voted[e], mvs);
   }
+}
+__global__ void __launch_bounds__(256) k_finalize(const Geom g, const State st, int par, int grid, uint32_t seq) {
+  finalize_body(g, st, par, grid, seq, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
 }
 
 // ------------------------------------------------------------------------------------------------

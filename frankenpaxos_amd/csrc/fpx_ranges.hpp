@@ -366,12 +366,14 @@ __global__ void __launch_bounds__(256) k_ranges_fill_rows(const Geom g, const St
 // row_voted bytes -- every 128-byte line leaves the wavefront whole.  blockIdx.y strides over the ranges, x over the
 // range's rows.  A range that shares rows with another range of its leader group in the same launch, acceptor groups
 // that differ in who voted (A > 1), or interleaved vote arrays go row by row through the union of the covering ranges.
-__global__ void __launch_bounds__(256) k_ranges_fill_lg(const Geom g, const State st, const RangeBatch b) {
+// (the body by the workgroup's row `by` of `gy`: k_ranges_fill_lg is its own grid; k_ranges_fill_lg_fin gives further
+// rows of the grid to the vote kernel's k_finalize)
+__device__ __forceinline__ void ranges_fill_lg_body(const Geom& g, const State& st, const RangeBatch& b, int by, int gy) {
   __shared__ int overlap;
   if (st.status[ST_ABORT] != 0) return;
   const int A = g.num_groups, L = g.num_leader_groups, Q = g.RS >> 2;
   const int tid = threadIdx.x;
-  for (int i = blockIdx.y; i < b.n; i += gridDim.y) {
+  for (int i = by; i < b.n; i += gy) {
     if (b.fused && b.entry[i] < 0) continue;
     const int s0 = b.start[i], e0 = b.end[i];
     if (e0 <= s0) continue;
@@ -469,6 +471,23 @@ __global__ void __launch_bounds__(256) k_ranges_fill_lg(const Geom g, const Stat
   }
 }
 
+__global__ void __launch_bounds__(256) k_ranges_fill_lg(const Geom g, const State st, const RangeBatch b) {
+  ranges_fill_lg_body(g, st, b, (int)blockIdx.y, (int)gridDim.y);
+}
+// A Mencius band whose halves are independent (fpx_mencius_band_fused_dev): the first fin_rows rows of the grid are the
+// vote kernel's k_finalize (fgx x slices workgroups, laid row by row over the grid's width), the other gy rows the fill --
+// what the commands raised in promised / max_voted is of no concern to the ranges of OTHER leader groups, so the two
+// need no order, and one launch (and its gap) less is on the step's critical path
+__global__ void __launch_bounds__(256) k_ranges_fill_lg_fin(const Geom g, const State st, const RangeBatch b, int gy, int fin_rows, int par,
+                                                            int grid, uint32_t seq, int fgx, int slices) {
+  if ((int)blockIdx.y >= fin_rows) {
+    ranges_fill_lg_body(g, st, b, (int)blockIdx.y - fin_rows, gy);
+    return;
+  }
+  const int f = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+  if (f < fgx * slices) finalize_body(g, st, par, grid, seq, f % fgx, f / fgx, slices);
+}
+
 // mencius/ProxyLeader.scala:355-411: one thread per range
 __device__ __forceinline__ void ranges_tally_one(const Geom& g, const State& st, const RangeTable& rt, const RangeBatch& b, int i) {
   uint8_t ch = 0;
@@ -523,8 +542,9 @@ __global__ void __launch_bounds__(256) k_ranges_tally(const Geom g, const State 
 // 16 -> 6 us for the 256 ranges of BASELINE.json configs[4] (profiles/r04_cfg5.md).
 constexpr int RANGES_CHAIN_MAX = 2048, RANGES_CHAIN_LDS_WORDS = 36000;  // 144 KB of the CU's 160
 __host__ __device__ inline long long ranges_chain_words(int n, int A) { return 5ll * n + 16ll * n * A; }
-__global__ void __launch_bounds__(1024) k_ranges_chain(const Geom g, const State st, const RangeTable rt, const RangeBatch b) {
-  extern __shared__ uint32_t ch_lds[];
+// (NT threads: k_ranges_chain is one workgroup of 1024; the first workgroup of k_phase2_band walks the chain with 256)
+template <int NT>
+__device__ __forceinline__ void ranges_chain_body(const Geom& g, const State& st, const RangeTable& rt, const RangeBatch& b, uint32_t* ch_lds) {
   __shared__ int shared_keys;
   if (st.status[ST_ABORT] != 0) return;
   const int tid = threadIdx.x, n = b.n, A = g.num_groups, R = g.R, L = g.num_leader_groups;
@@ -536,8 +556,8 @@ __global__ void __launch_bounds__(1024) k_ranges_chain(const Geom g, const State
   uint32_t* c_votes = reinterpret_cast<uint32_t*>(c_nr + n);  // [n][A][8]
   uint32_t* c_nacks = c_votes + (size_t)n * A * 8;
   const int count0 = __hip_atomic_load(rt.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int i = tid; i < n; i += 1024) c_start[i] = b.start[i], c_end[i] = b.end[i], c_round[i] = b.round[i], c_nr[i] = -1;
-  for (int t = tid; t < n * A * 16; t += 1024) c_votes[t] = 0;
+  for (int i = tid; i < n; i += NT) c_start[i] = b.start[i], c_end[i] = b.end[i], c_round[i] = b.round[i], c_nr[i] = -1;
+  for (int t = tid; t < n * A * 16; t += NT) c_votes[t] = 0;
   if (tid == 0) shared_keys = 0;
   __syncthreads();
   // the acceptor this thread plays in the vote step: its round is requested now, the open step runs while it travels
@@ -547,19 +567,19 @@ __global__ void __launch_bounds__(1024) k_ranges_chain(const Geom g, const State
   int pr0 = 0;
   if (tid < cells) pr0 = st.promised[(size_t)((c_start[tid / per] % L) * A + (tid % per) / R) * R + (tid % per) % R];
   // open (mencius/ProxyLeader.scala:255-303)
-  bool mine[2] = {false, false};
-  for (int i = tid, k = 0; i < n; i += 1024, ++k) {
+  uint32_t mine = 0;  // bit k: the range of my k-th pass was inserted by this launch (RANGES_CHAIN_MAX / NT <= 8 passes)
+  for (int i = tid, k = 0; i < n; i += NT, ++k) {
     bool inserted, shared;
     c_entry[i] = ranges_open_core(g, st, rt, b, 0, i, c_start[i], c_end[i], c_round[i], count0, &inserted, &shared);
-    mine[k] = inserted;
+    mine |= inserted ? 1u << k : 0u;
     if (shared) shared_keys = 1;
   }
   __syncthreads();
   // resolve: is_new <=> this launch created the entry and i is the lowest index that carries its key
   const bool twice = shared_keys != 0;
-  for (int i = tid, k = 0; i < n; i += 1024, ++k) {
+  for (int i = tid, k = 0; i < n; i += NT, ++k) {
     const int e = c_entry[i];
-    bool fresh = mine[k];
+    bool fresh = (mine >> k) & 1u;
     if (twice && e >= 0) {
       const uint64_t k1 = __hip_atomic_load(&rt.key[(size_t)e * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       fresh = (uint32_t)(k1 >> 32) == b.run_id && __hip_atomic_load(&rt.owner[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == i;
@@ -578,7 +598,7 @@ __global__ void __launch_bounds__(1024) k_ranges_chain(const Geom g, const State
   }
   __syncthreads();
   // acceptors (mencius/Acceptor.scala:237-260, 279-290): one thread per (range, acceptor group, acceptor)
-  for (int idx = tid; idx < cells; idx += 1024) {
+  for (int idx = tid; idx < cells; idx += NT) {
     const int i = idx / per, rem = idx % per;
     if (c_entry[i] < 0) continue;
     const int ag = rem / R, r = rem % R, bit = g.base + r;
@@ -606,7 +626,7 @@ __global__ void __launch_bounds__(1024) k_ranges_chain(const Geom g, const State
   }
   __syncthreads();
   // tally (mencius/ProxyLeader.scala:355-411) of the entries this launch created: no earlier votes, Pending
-  for (int i = tid; i < n; i += 1024) {
+  for (int i = tid; i < n; i += NT) {
     const int e = c_entry[i];
     uint8_t ch = 0;
     if (e >= 0) {
@@ -633,11 +653,35 @@ __global__ void __launch_bounds__(1024) k_ranges_chain(const Geom g, const State
   }
   uint32_t* vo = reinterpret_cast<uint32_t*>(b.vote_bits);
   uint32_t* no = reinterpret_cast<uint32_t*>(b.nack_bits);
-  for (int t = tid; t < n * A * 8; t += 1024) {
+  for (int t = tid; t < n * A * 8; t += NT) {
     vo[t] = c_votes[t];
     if (no) no[t] = c_nacks[t];
   }
 }
+__global__ void __launch_bounds__(1024) k_ranges_chain(const Geom g, const State st, const RangeTable rt, const RangeBatch b) {
+  extern __shared__ uint32_t ch_lds[];
+  ranges_chain_body<1024>(g, st, rt, b, ch_lds);
+}
+
+// k_phase2 whose FIRST workgroup walks the range chain of the same Mencius band (fpx_mencius_band_fused_dev, independent
+// halves): the chain -- one workgroup, a string of dependent steps -- hides under the vote kernel instead of standing in
+// front of the fill.  (The first, not the last: a grid that fills the chip's LDS would start its last workgroup when the
+// first voters are done.)
+#define FPX_P2_NAME k_phase2_band
+#define FPX_P2_EXTRA_PARAMS , const RangeTable rt, const RangeBatch rb
+#define FPX_P2_NBLK (gridDim.x - 1)
+#define FPX_P2_BID (blockIdx.x - 1)
+#define FPX_P2_PROLOGUE                                                        \
+  if (blockIdx.x == 0) {                                                       \
+    ranges_chain_body<256>(g, st, rt, rb, reinterpret_cast<uint32_t*>(smem)); \
+    return;                                                                    \
+  }
+#include "fpx_phase2_body.inc"
+#undef FPX_P2_NAME
+#undef FPX_P2_EXTRA_PARAMS
+#undef FPX_P2_NBLK
+#undef FPX_P2_BID
+#undef FPX_P2_PROLOGUE
 
 // fpx_proxy_forget: live entries that do not lie inside [first, first + count) move to the other buffer
 __global__ void __launch_bounds__(256) k_ranges_rehash(const RangeTable from, const RangeTable to, int words, int first, int count) {

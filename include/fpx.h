@@ -379,10 +379,15 @@ int32_t fpx_noop_ranges_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot
  * handlers) = fpx_phase2_fused_dev(the first ten arguments) followed by fpx_noop_ranges_fused_dev(the next ten), with
  * exactly their outputs and errors.  independent != 0: the caller states that no leader group has both a command and a
  * range in this step (a leader either proposes in its slots or skips them).  Then the two halves touch disjoint rows,
- * tallies and acceptors, no order between them is observable, and under FPX_F_TRUSTED they run side by side -- the
- * ranges on a second stream of the context between a fork and a join event (0.097 -> see profiles/r05_cfg5.md per band
- * of 2^22 slots).  A context that validates its batches checks the statement first: a leader group with both makes
- * the step FPX_EORDER with nothing applied (call again with independent = 0), and the halves run one after the other. */
+ * tallies and acceptors, no order between them is observable, and under FPX_F_TRUSTED the step is TWO launches instead
+ * of four where its shape allows (groups of at most 32 acceptors on leader-group-major rows, commands delivered to every
+ * acceptor -- d_target_mask NULL --, more than 512 commands, a range chain that fits the vote kernel's LDS): the vote
+ * kernel with the ranges' chain of dependent steps as its first workgroup, then the ranges' fill with the vote kernel's
+ * fold of maxima as further rows of its grid (profiles/r05_cfg5.md); other shapes run the halves side by side, the
+ * ranges on a second stream of the context between a fork and a join event.  A context that validates its batches
+ * checks the statement first: a leader group with both makes the step FPX_EORDER with nothing applied (call again with
+ * independent = 0), and the halves run one after the other.  FPX_BAND_SERIAL=1 in the environment keeps the two-launch
+ * form off. */
 int32_t fpx_mencius_band_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,
                                    const int32_t* d_value_id, const uint64_t* d_target_mask, uint8_t* d_chosen,
                                    int32_t* d_chosen_round, int32_t* d_chosen_value, int32_t* d_nack_round,
@@ -391,6 +396,8 @@ int32_t fpx_mencius_band_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slo
                                    uint64_t* d_range_vote_bits, uint64_t* d_range_nack_bits,
                                    int32_t* d_range_nack_round, uint8_t* d_range_is_new, uint8_t* d_range_chosen,
                                    int32_t independent);
+/* diagnostic: the steps of fpx_mencius_band_fused_dev that ran in the two-launch form since fpx_create */
+int64_t fpx_band_merged_steps(fpx_ctx* ctx);
 /* batches of one (bitmaps num_groups x 4 words) */
 int32_t fpx_acceptor_phase2a_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t slot_end,
                                         int32_t round, const uint64_t* target_masks,

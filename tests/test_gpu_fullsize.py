@@ -206,18 +206,22 @@ def _band_on_device(fa, gpu, fused_op, ranges_op, independent):
     vb, nb = (torch.zeros((k, A, 4), dtype=torch.int64, device=dev) for _ in range(2))
     rnr, new, rch = (torch.full((k,), -1, dtype=torch.int32, device=dev), torch.zeros(k, dtype=torch.uint8, device=dev),
                      torch.zeros(k, dtype=torch.uint8, device=dev))
-    gpu.mencius_band_fused_dev(d(slot), d(rr), d(val), d(tgt.view(np.int64)), ch, cr, cv, nr, d(st_), d(en_), d(rn_),
-                               d(np.ascontiguousarray(tm).view(np.int64)), vb, nb, rnr, new, rch, independent=independent)
+    gpu.mencius_band_fused_dev(d(slot), d(rr), d(val), None if tgt is None else d(tgt.view(np.int64)), ch, cr, cv, nr, d(st_), d(en_),
+                               d(rn_), d(np.ascontiguousarray(tm).view(np.int64)), vb, nb, rnr, new, rch, independent=independent)
     st = gpu.sync()
     h = lambda t: t.cpu().numpy()
     return st, (h(ch), h(cr), h(cv), h(nr)), (h(vb).view(np.uint64), h(nb).view(np.uint64), h(rnr), h(new), h(rch))
 
 
-def test_config5_band_entry_point_halves_side_by_side(fa, oracle, row_layout):
+@pytest.mark.parametrize("dense", [False, True])
+def test_config5_band_entry_point_halves_side_by_side(fa, oracle, row_layout, dense):
     """configs[4] at size through fpx_mencius_band_fused_dev -- the commands of the leader groups that
-    propose and the noop ranges of those that skip in ONE call, the two halves on two streams (FPX_F_TRUSTED, the leader
-    groups of an epoch's two batches are disjoint by construction) -- every output of both halves, the state digest and
-    the acceptors' scalars == the oracle running the halves one after the other (mencius/ProxyLeader.scala:216-303)."""
+    propose and the noop ranges of those that skip in ONE call (FPX_F_TRUSTED, the leader groups of an epoch's two batches
+    are disjoint by construction) -- every output of both halves, the state digest and the acceptors' scalars == the oracle
+    running the halves one after the other (mencius/ProxyLeader.scala:216-303).  With target masks on the commands the
+    halves run on two streams; dense (every command to every acceptor of its group: no mask) on leader-group-major rows
+    the step is TWO launches -- the range chain as the vote kernel's first workgroup, the vote kernel's fold of maxima in
+    the fill's grid -- which the context counts."""
     import torch
     S, L, R = 1 << 22, 256, 3
     kw = dict(num_slots=S, num_replicas=R, num_groups=1, num_leader_groups=L, f=1, tally_ways=4)
@@ -230,7 +234,7 @@ def test_config5_band_entry_point_halves_side_by_side(fa, oracle, row_layout):
             assert a[0] == b[0] == 0
             np.testing.assert_array_equal(a[1], b[1])
         elif op[0] == "fused":
-            pending = op
+            pending = op[:4] + (None,) if dense else op
         else:
             st, cmd, rng_ = _band_on_device(fa, gpu, pending, op, independent=True)
             assert st == 0
@@ -245,6 +249,9 @@ def test_config5_band_entry_point_halves_side_by_side(fa, oracle, row_layout):
                 np.testing.assert_array_equal(x, np.asarray(y).reshape(x.shape))
             steps += 1
     assert steps == 16
+    import os
+    merged = dense and row_layout == "leader-group-major" and not os.environ.get("FPX_BAND_SERIAL")
+    assert gpu.band_merged_steps() == (16 if merged else 0)
     np.testing.assert_array_equal(gpu.state_digest(), ref.state_digest())
     pg, mg = gpu.read_scalars()
     pr, mr = ref.read_scalars()
