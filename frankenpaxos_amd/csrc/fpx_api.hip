@@ -208,16 +208,9 @@ void make_geom(const fpx_config& c, Geom* g) {
   g->lg_rows = (c.num_leader_groups > 1 && c.num_slots % c.num_leader_groups == 0 && c.num_replicas <= 32 &&
                 !(c.flags & FPX_F_SLOT_MAJOR_ROWS) && !getenv("FPX_SLOT_MAJOR"))
                    ? c.num_slots / c.num_leader_groups : 0;
-  // slot / L and row / A by multiplication (fpx_kernels.hpp: fast_div)
-  auto magic = [](int d, uint32_t* m, int32_t* sh) {
-    *m = 0, *sh = 0;
-    if (d < 2) return;
-    int k = 0;
-    while ((1ll << (k + 1)) < d) ++k;  // 2^k < d <= 2^(k + 1)
-    *sh = k, *m = (uint32_t)(((1ull << (32 + k)) / (uint64_t)d) + 1ull);
-  };
-  magic(c.num_leader_groups, &g->l_magic, &g->l_shift);
-  magic(c.num_groups, &g->a_magic, &g->a_shift);
+  // slot / L and row / A by multiplication (fpx_fastdiv.hpp)
+  fast_div_magic(c.num_leader_groups, &g->l_magic, &g->l_shift);
+  fast_div_magic(c.num_groups, &g->a_magic, &g->a_shift);
   g->qkind = c.quorum_kind;
   g->total = c.replicas_total ? c.replicas_total : c.num_replicas;
   g->base = c.replica_base;

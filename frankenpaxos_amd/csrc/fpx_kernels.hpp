@@ -47,6 +47,8 @@
 #define FPX_NT 1  // vote rows are written once and not re-read soon: nontemporal stores
 #endif
 
+#include "fpx_fastdiv.hpp"
+
 namespace fpx {
 
 typedef int int4v __attribute__((ext_vector_type(4)));
@@ -84,18 +86,11 @@ struct Geom {
   int32_t base, total;                             // replica_base, replicas_total
   uint64_t member[4];                              // bits [0, total)
   int32_t part_rows;                               // rows of State::part (= the largest launch grid)
-  // slot / L and slot / A without a division (fast_div): a 32-bit divide by a kernel argument is ~30 VALU instructions,
-  // and the small-group vote kernel -- VALU-bound: 3900 VALU instructions per wavefront on BASELINE.json configs[4],
-  // profiles/r05_cfg5.md -- met four of them per slot.  0 = divisor 1
+  // slot / L and row / A by multiplication (fpx_fastdiv.hpp); magic 0 = divisor 1
   uint32_t l_magic, a_magic;
   int32_t l_shift, a_shift;
 };
 
-// s / d for 0 <= s < 2^31 and the (magic, shift) of d >= 2 that make_geom computes: shift = ceil(log2 d) - 1,
-// magic = floor(2^(32 + shift) / d) + 1 < 2^32 (the error term s / 2^(32 + shift) stays below 1 / d because d <= 2^(shift + 1))
-__device__ __forceinline__ int fast_div(int s, uint32_t magic, int shift) {
-  return (int)(__umulhi((uint32_t)s, magic) >> shift);
-}
 // slot -> (leader group, row inside the leader group)
 __device__ __forceinline__ void split_slot(const Geom& g, int s, int* lg, int* row) {
   const int q = g.l_magic ? fast_div(s, g.l_magic, g.l_shift) : s;
