@@ -33,9 +33,22 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
-# (FPX_BENCH_SLOTS_LOG2: test hook of tests/test_bench_distributed.py -- many ranks on ONE GPU with small windows; never set
-# by the driver, and config.slots_per_step in the line always says what was run)
-SLOTS_PER_STEP = 1 << int(os.environ.get("FPX_BENCH_SLOTS_LOG2", "20"))
+# Test hooks (tests/test_bench_distributed.py: many ranks on ONE GPU over gloo, small windows, the RCCL double) are
+# environment variables that only count together with the --test-hooks flag (a leaked variable must not
+# change the headline workload silently).  Without the flag a set hook is REFUSED, with it the line carries `test_hooks`.
+HOOK_VARS = ("FPX_BENCH_SLOTS_LOG2", "FPX_BENCH_SHARE_GPU", "FPX_BENCH_BACKEND", "FPX_BENCH_FPX_COMM", "FPX_BENCH_DRY_SPAWN")
+TEST_HOOKS = "--test-hooks" in sys.argv
+HOOKS_SET = sorted(v for v in HOOK_VARS if os.environ.get(v))
+if HOOKS_SET and not TEST_HOOKS:
+    raise SystemExit("bench.py: %s set without --test-hooks: refusing to run a workload other than the one the line names"
+                     % ", ".join(HOOKS_SET))
+
+
+def hook(name, default=None):
+    return os.environ.get(name, default) if TEST_HOOKS else default
+
+
+SLOTS_PER_STEP = 1 << int(hook("FPX_BENCH_SLOTS_LOG2", "20"))
 REPLICAS = 256
 F = 127
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -153,14 +166,11 @@ def cpu_baseline(ballot_mode, light=False):
     return {
         "value": S / dt, "unit": "slots/s", "cores": 1, "kind": "port",
         "all_cores_value": all_cores, "all_cores_threads": T,
-        "sample": "oracle/fpx_oracle.c fpo_phase2_fused (flat arrays), 2^19 slots x 256 acceptors, steady "
-                  "stream, 1 thread (reference Transport is single-threaded); same handlers behind a FIFO "
-                  "message pump on 2^15 slots: %.3e slots/s; with the reference's data-structure shapes "
-                  "(oracle/fpx_faithful.cpp: std::map per acceptor, hash map of Pending, heap message per "
-                  "Phase2a/2b) on 2^14 slots: %s slots/s; the flat port on %d threads (slots partitioned, 2^15 "
-                  "slots each): %.3e slots/s; C/C++ restatements, not the JVM; nproc=%d"
-                  % (Sp / dtp, ("%.3e" % faithful) if faithful else "n/a", T, all_cores, os.cpu_count()),
-        "faithful_shapes_value": faithful,
+        "fifo_pump_value": Sp / dtp, "faithful_shapes_value": faithful,
+        "sample": "C/C++ restatements of the reference handlers, not the JVM (none in this image), steady stream x 256 acceptors: "
+                  "value = flat arrays, 2^19 slots, 1 thread; fifo_pump = the same behind a FIFO message pump, 2^15 slots; "
+                  "faithful_shapes = the reference's container shapes (oracle/fpx_faithful.cpp), 2^14 slots; all_cores = flat on "
+                  "%d threads, 2^15 slots each; nproc=%d" % (T, os.cpu_count()),
     }
 
 
@@ -168,7 +178,7 @@ def setup_comm(fa, ctx, dist, backend, dev, rank, world):
     """The RCCL communicator lives behind the C ABI (fpx_comm_create); its 128-byte id travels over
     torch.distributed, which is control plane only here.  Under the gloo test hook the ranks share one GPU,
     which RCCL refuses (duplicate device): no communicator, the caller falls back to a host exchange."""
-    if backend != "nccl" and os.environ.get("FPX_BENCH_FPX_COMM") != "1":
+    if backend != "nccl" and hook("FPX_BENCH_FPX_COMM") != "1":
         return False
     # (FPX_BENCH_FPX_COMM=1, test hook: the ranks share one GPU and rendezvous over gloo, but the data path still goes
     # through fpx_comm_create and the library's collectives -- bound to the test double FPX_RCCL_LIB names, since RCCL
@@ -261,6 +271,39 @@ def replica_axis_row(fa, dist, backend, dev, rank, world, local_rank, ballot_mod
     }
 
 
+def sig(x, digits=5):
+    """a float rounded to `digits` significant digits (the line is kept short: the driver keeps 8 KB of it)"""
+    if x is None or isinstance(x, (bool, int)):
+        return x
+    return float("%.*g" % (digits, x))
+
+
+def round_floats(x, digits=7):
+    if isinstance(x, float):
+        return sig(x, digits)
+    if isinstance(x, dict):
+        return {k: round_floats(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [round_floats(v, digits) for v in x]
+    return x
+
+
+def compact_entry(full):
+    """One `configs` entry from a bench_configs line: the numbers only.  What the workload is, which kernels run, the byte
+    model and what was verified after the timed region are prose in bench_configs.md, keyed by the entry's name (VERDICT
+    r05 weak #9: the driver keeps the last 8 KB of the line, and the prose pushed three entries out of its record).
+    `verified: true` = the entry's post-region check ran and passed (a failing check raises: the entry is then an error)."""
+    r, c = full["roofline"], full["config"]
+    e = {"value": sig(full["value"]), "unit": full["unit"], "steps": full["steps"], "ms_per_step": sig(full["ms_per_step"]),
+         "avg_kernel_ms": sig(r["avg_kernel_ms"]), "roofline_frac": sig(r["frac"], 4),
+         "algorithmic_bytes_per_unit": r.get("algorithmic_bytes_per_unit"),
+         "traffic": sig(r.get("traffic"), 4), "traffic_round": r.get("traffic_round"), "verified": bool(c.get("verified"))}
+    for k in ("pcie_GBs", "proposals", "chosen", "nacked"):
+        if k in c:
+            e[k] = sig(c[k], 4)
+    return e
+
+
 def run_with_deadline(fn, seconds, dev):
     """fn() on a worker thread: (result, False), ({"error": ...}, False) if it raised, or ({"error": ...}, True) if it
     has not returned within `seconds` (the thread is left behind; the caller must end the process with os._exit)"""
@@ -303,6 +346,8 @@ def main():
                          "headline and reported in the line's `configs` block (0 = leave the block out)")
     ap.add_argument("--replica-row-deadline", type=int, default=120,
                     help="seconds the extra replica-axis row may take before the line is printed without it")
+    ap.add_argument("--test-hooks", action="store_true",
+                    help="honour the FPX_BENCH_* test hooks of tests/test_bench_distributed.py (refused without this flag)")
     ap.add_argument("--replica-row-steps", type=int, default=5,
                     help="N > 1, --shard group: steps of the extra replica-axis row (0 = skip it)")
     args = ap.parse_args()
@@ -317,7 +362,7 @@ def main():
         sock.close()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        if os.environ.get("FPX_BENCH_DRY_SPAWN") == "1":   # test hook: show the launch instead of doing it
+        if hook("FPX_BENCH_DRY_SPAWN") == "1":   # test hook: show the launch instead of doing it
             print(json.dumps({"spawn": cmd}))
             return
         sys.stdout.flush()
@@ -333,8 +378,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (libfpx has no CPU path)")
     # test hooks (tests/test_bench_distributed.py): run several ranks on ONE GPU over gloo, so that the
     # N > 1 control flow of this file can be exercised on a 1-GPU box.  Never set by the driver.
-    share_gpu = os.environ.get("FPX_BENCH_SHARE_GPU") == "1"
-    backend = os.environ.get("FPX_BENCH_BACKEND", "nccl")
+    share_gpu = hook("FPX_BENCH_SHARE_GPU") == "1"
+    backend = hook("FPX_BENCH_BACKEND", "nccl")
     if share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -497,7 +542,7 @@ def main():
     # small context + one all-gather of Chosen records), so that `rccl` in the line does not depend on the extra
     # row having finished; deadline-guarded like the row.
     rccl_info = None
-    if world > 1 and (backend == "nccl" or os.environ.get("FPX_BENCH_FPX_COMM") == "1") and not hung:
+    if world > 1 and (backend == "nccl" or hook("FPX_BENCH_FPX_COMM") == "1") and not hung:
         def rccl_probe():
             pctx = fa.Context(fa.make_config(num_slots=4096, num_replicas=4, f=1, device=local_rank))
             pctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -522,7 +567,7 @@ def main():
         import bench_configs
         ctx.close()
         torch.cuda.empty_cache()
-        configs_block = {}
+        configs_block = {"doc": "bench_configs.md (per entry: workload, kernels, byte model, what `verified` checked)"}
         # BASELINE.json's configs 2-5, the two thrifty deliveries, and what SURVEY.md 8(d) asks for beside the headline: the
         # reference's actual acceptor model, the host-pointer path end to end, the adversarial stream at full size
         for c in ("2", "3", "4", "4_execute", "5", "thrifty", "thrifty_random", "acceptor_model", "host_path", "adversarial"):
@@ -539,33 +584,22 @@ def main():
                              2 * args.configs_block_steps if c == "5" else args.configs_block_steps)
                 sub = types.SimpleNamespace(steps=sub_steps, warmup=2, ballot=args.ballot, config=c, no_cpu_baseline=True)
                 full = bench_configs.run(sub, fa, None, dev, 0, 1, local_rank, all_reduce)
-                configs_block[c] = {
-                    "metric": full["metric"], "value": full["value"], "unit": full["unit"], "steps": full["steps"],
-                    "ms_per_step": full["ms_per_step"], "workload": full["config"]["workload"],
-                    "roofline_frac": full["roofline"]["frac"], "achieved_GBs": full["roofline"]["achieved"],
-                    "avg_kernel_ms": full["roofline"]["avg_kernel_ms"],
-                    "algorithmic_bytes_per_unit": full["roofline"].get("algorithmic_bytes_per_unit"),
-                    "verified": full["config"].get("verified"), "wall_s": None,
-                    "traffic": full["roofline"].get("traffic"), "traffic_round": full["roofline"].get("traffic_round"),
-                }
-                for extra_key in ("pcie_GBs", "proposals", "chosen", "nacked", "ballot_model"):
-                    if extra_key in full["config"]:
-                        configs_block[c][extra_key] = full["config"][extra_key]
-                if "note" in full["roofline"]:
-                    configs_block[c]["note"] = full["roofline"]["note"]
+                configs_block[c] = compact_entry(full)
                 if c == "2" and args.ballot == "per_slot":
                     # BASELINE.json configs[1] is the reference's own f = 1 deployment: its acceptors keep ONE round each
                     # (multipaxos/Acceptor.scala:95) -- the same steps under FPX_BALLOT_ACCEPTOR, beside the
                     # ballot-per-cell figures this block reports for continuity with the headline's model
                     sub2 = types.SimpleNamespace(steps=sub_steps, warmup=2, ballot="acceptor", config="2", no_cpu_baseline=True)
-                    alt = bench_configs.run(sub2, fa, None, dev, 0, 1, local_rank, all_reduce)
-                    configs_block[c]["acceptor_model"] = {"value": alt["value"], "ms_per_step": alt["ms_per_step"],
-                                                          "avg_kernel_ms": alt["roofline"]["avg_kernel_ms"],
-                                                          "verified": alt["config"].get("verified")}
+                    configs_block["2_acceptor_model"] = compact_entry(bench_configs.run(sub2, fa, None, dev, 0, 1, local_rank, all_reduce))
             except BaseException as e:  # noqa: BLE001 -- the headline line must survive a failing extra config
-                configs_block[c] = {"error": "%s: %s" % (type(e).__name__, e)}
-            configs_block[c]["wall_s"] = time.perf_counter() - t_c
+                configs_block[c] = {"error": ("%s: %s" % (type(e).__name__, e))[:300]}
+            configs_block[c]["wall_s"] = round(time.perf_counter() - t_c, 1)
             torch.cuda.empty_cache()
+        # the oracle alone behind a FIFO message pump, on the host (no GPU involved)
+        try:
+            configs_block["1"] = bench_configs.config1_entry()
+        except BaseException as e:  # noqa: BLE001
+            configs_block["1"] = {"error": ("%s: %s" % (type(e).__name__, e))[:300]}
 
     if rank == 0:
         bps = algorithmic_bytes_per_slot(ballot_mode)
@@ -625,9 +659,7 @@ def main():
                 "achieved_read": (read_bytes_per_slot(ballot_mode) * slots_per_launch / avg_kernel_s / 1e9) if launches else None,
                 "frac_read": (read_bytes_per_slot(ballot_mode) * slots_per_launch / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if launches else None,
                 "traffic": traffic, "traffic_round": traffic_round,
-                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command in an earlier profiled run "
-                                  "(profiles/traffic.json; collection and calibration: profiles/r04_pmc_summary.md) -- not "
-                                  "measured in this run",
+                "traffic_source": "profiles/traffic.json: rocprofv3 --pmc passes of this command in an earlier profiled run",
                 "algorithmic_bytes_per_slot": bps, "slots_per_launch": slots_per_launch,
                 "avg_kernel_ms": kernel_ms / max(launches, 1), "launches_timed": launches,
                 "kernel_ms_min_max_sigma": ([min(per_launch), max(per_launch), float(np.std(per_launch))] if per_launch else None),
@@ -635,8 +667,7 @@ def main():
                 # written per 1032 B read, so even a kernel that moved its bytes at the full 8 TB/s would read at 1032 / 3088 of
                 # it -- frac_read cannot exceed 0.334 on this workload
                 "frac_read_cap": read_bytes_per_slot(ballot_mode) / algorithmic_bytes_per_slot(ballot_mode),
-                "kernel_time_source": "HIP events on the vote kernel's own dispatch packet (hipExtLaunchKernelGGL start / stop "
-                                      "events on the context's stream; fpx_profile_*), every timed launch",
+                "kernel_time_source": "HIP events on the vote kernel's dispatch packet, every timed launch (fpx_profile_*)",
                 # what bare streaming kernels reach on this chip (profiles/microbench/hbm_mix.hip, best of the
                 # grid / unroll sweep in profiles/r01_hbm_mix.txt): the practical ceiling beside the spec peak
                 "measured_stream_GBs": MEASURED_STREAM_GBS,
@@ -644,6 +675,8 @@ def main():
             },
         }
         # how many ranks an RCCL communicator created in THIS run actually spans (0 at N = 1: none is needed)
+        if TEST_HOOKS:
+            line["test_hooks"] = HOOKS_SET
         line["rccl_ranks"] = world if (have_comm or (replica_row or {}).get("rccl_ranks") or
                                        (rccl_info or {}).get("ranks") == world) else 0
         if rccl_info is not None:
@@ -661,7 +694,7 @@ def main():
             line["replica_axis"] = replica_row
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ballot_mode, light=world > 1)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(round_floats(line)), flush=True)
     if hung:  # a collective of the extra row never returned: no barrier, no teardown that could wait for it
         sys.stderr.write("bench.py: rank %d: the replica-axis row did not finish; exiting without it\n" % rank)
         sys.stderr.flush()

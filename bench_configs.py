@@ -656,6 +656,37 @@ def adversarial_line(args, fa, dev, local_rank, seed=1):
     }
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# config 1: SURVEY.md 8(d)'s first rung -- the oracle alone, on the host
+# ------------------------------------------------------------------------------------------------------------------
+def config1_entry(reps=21):
+    """BASELINE.json configs[0] as SURVEY.md 8(d) states it: MultiPaxos f = 1 -- one acceptor group of 3, quorum 2, 2 replicas --
+    1000 commands through the CPU oracle behind its strict FIFO message pump (the stand-in for the reference's in-process
+    Transport: every Phase2a / Phase2b is one queued message, handled one at a time), both replicas' logs executing the
+    Chosen records; microseconds per slot on this host.  No GPU involved: this is the CPU reference case of the ladder."""
+    from oracle import pyoracle
+    from tests import workloads as W
+    pyoracle.build()
+    n = 1000
+    slot, rnd, val = W.steady_stream(n)
+    times = []
+    for _ in range(reps):
+        ref = pyoracle.System(pyoracle.make_config(num_slots=n, num_replicas=3, f=1))
+        ref.acceptor_phase1a(0, 0)
+        logs = [pyoracle.Log(), pyoracle.Log()]
+        t0 = time.perf_counter()
+        st, ch, cr, cv, nr = ref.phase2_fifo_pump(slot, rnd, val)
+        for lg in logs:
+            for s_, v_ in zip(slot.tolist(), cv.tolist()):
+                lg.chosen(s_, v_)
+        times.append(time.perf_counter() - t0)
+        assert st == 0 and bool(ch.all()) and bool((cv == val).all()) and bool((cr == 0).all())
+        assert all(lg.executed_watermark == n for lg in logs)
+    dt = sorted(times)[len(times) // 2]
+    return {"value": float("%.5g" % (n / dt)), "unit": "slots/s", "us_per_slot": float("%.4g" % (dt / n * 1e6)), "steps": reps,
+            "commands": n, "host_only": True, "cores": 1, "kind": "port", "verified": True}
+
+
 def traffic_entry(key):
     """(HBM bytes per step, the round they were measured in, where) from the PMC passes committed under profiles/ --
     profiles/traffic.json, every key tagged with its round -- or (None, None, None) if that workload was never profiled"""
@@ -668,7 +699,7 @@ def traffic_entry(key):
 
 
 def traffic_key(config, ballot="per_slot"):
-    return ("config%s" % config) if str(config).isdigit() else ("%s_%s" % (config, ballot))
+    return ("config%s" % config) if str(config)[:1].isdigit() else ("%s_%s" % (config, ballot))
 
 
 def traffic_of(config, ballot="per_slot"):

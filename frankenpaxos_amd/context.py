@@ -131,7 +131,12 @@ class Context:
         st = self.L.fpx_placement_stats(self._h, out)
         if st:
             raise FpxError(st, "fpx_placement_stats")
-        return {"chunks": bool(out[0]), "windows": int(out[1]), "probe_ms": (float(out[2]), float(out[3]), float(out[4]))}
+        pr, un, ms = C.c_int32(0), C.c_int32(0), C.c_float(0)
+        st = self.L.fpx_placement_search(self._h, C.byref(pr), C.byref(un), C.byref(ms))
+        if st:
+            raise FpxError(st, "fpx_placement_search")
+        return {"chunks": bool(out[0]), "windows": int(out[1]), "probe_ms": (float(out[2]), float(out[3]), float(out[4])),
+                "search": {"probes": pr.value, "unprobed_decisions": un.value, "ms": float(ms.value)}}
 
     def band_merged_steps(self):
         """diagnostic: the mencius_band_fused_dev steps that ran in the two-launch form"""

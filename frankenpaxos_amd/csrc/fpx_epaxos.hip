@@ -1124,6 +1124,11 @@ struct LcBatch {
   const int32_t* deps;      // [m][n] or null: the triple is known by its id alone
   const int32_t* deps_end;  // [m] or null
   const uint8_t* target;
+  const uint8_t* writer;    // [m] the replicas whose ENTRY this message writes: target minus the replicas a later message of the
+                            // batch for the same instance goes to -- of several Commits for one instance the last one wins
+                            // WHOLE (triple, dependencies and all), as when the reference applies them in order; cell by cell
+                            // from different threads the entry could end up with one message's triple and another's
+                            // dependencies
 };
 __global__ void __launch_bounds__(256) k_cl_learn_commit(const EpxState st, const LcBatch b) {
   const int n = st.n;
@@ -1131,15 +1136,17 @@ __global__ void __launch_bounds__(256) k_cl_learn_commit(const EpxState st, cons
   if (t >= (long long)b.m * n) return;
   const int r = (int)(t / b.m), i = (int)(t % b.m);
   if (!((b.target[i] >> r) & 1u)) return;
-  const size_t c = ((size_t)r * n + b.leader[i]) * st.num_instances + b.number[i];
-  st.cl_status[c] = CL_COMMITTED, st.cl_ballot[c] = -1, st.cl_vote[c] = -1, st.cl_triple[c] = b.triple[i];
-  if (b.deps) {
-    for (int l = 0; l < n; ++l) st.cl_deps[c * n + l] = b.deps[(size_t)i * n + l];
-    st.cl_dend[c] = b.deps_end ? b.deps_end[i] : 0;
-  } else {
-    deps_by_id(st, c);
+  if ((b.writer[i] >> r) & 1u) {
+    const size_t c = ((size_t)r * n + b.leader[i]) * st.num_instances + b.number[i];
+    st.cl_status[c] = CL_COMMITTED, st.cl_ballot[c] = -1, st.cl_vote[c] = -1, st.cl_triple[c] = b.triple[i];
+    if (b.deps) {
+      for (int l = 0; l < n; ++l) st.cl_deps[c * n + l] = b.deps[(size_t)i * n + l];
+      st.cl_dend[c] = b.deps_end ? b.deps_end[i] : 0;
+    } else {
+      deps_by_id(st, c);
+    }
   }
-  index_put(st, r, b.key[i], b.is_set[i], b.leader[i], b.number[i]);
+  index_put(st, r, b.key[i], b.is_set[i], b.leader[i], b.number[i]);  // (a maximum: every message's put, in any order)
 }
 
 // ---- K8: Replica.handlePrepareOk (Replica.scala:1759-1884), the recovering replica's decision -- one thread per instance
@@ -2219,12 +2226,32 @@ int32_t fpx_epx_handle_commit(fpx_epx* e, int32_t m, const int32_t* leader, cons
   }
   const size_t mp = ((size_t)m + 63) & ~(size_t)63;
   int rc;
-  if ((rc = grow(e, &e->cl, mp * 4 * 5 + mp * 2 + (size_t)m * n * 4 + 1024))) return rc;
+  // who writes the entry: walking the batch from its end, a message leaves to the later messages of its instance the
+  // replicas they go to
+  std::vector<uint8_t> writer((size_t)m);
+  {
+    std::vector<std::pair<long long, int>> order((size_t)m);
+    for (int i = 0; i < m; ++i) order[i] = {(long long)leader[i] * e->st.num_instances + number[i], i};
+    std::sort(order.begin(), order.end());
+    for (size_t a = 0; a < order.size();) {
+      size_t z = a;
+      while (z < order.size() && order[z].first == order[a].first) ++z;
+      unsigned later = 0;
+      for (size_t q = z; q-- > a;) {  // the instance's messages, last first
+        const int i = order[q].second;
+        writer[i] = (uint8_t)(target_mask[i] & ~later);
+        later |= target_mask[i];
+      }
+      a = z;
+    }
+  }
+  if ((rc = grow(e, &e->cl, mp * 4 * 5 + mp * 3 + (size_t)m * n * 4 + 1024))) return rc;
   char* p = (char*)e->cl.p;
   auto take = [&](size_t sz) { char* q = p; p += (sz + 63) & ~(size_t)63; return q; };
   int32_t *d_leader = (int32_t*)take(mp * 4), *d_number = (int32_t*)take(mp * 4), *d_tr = (int32_t*)take(mp * 4);
   int32_t *d_key = (int32_t*)take(mp * 4), *d_end = (int32_t*)take(mp * 4);
-  uint8_t *d_set = (uint8_t*)take(mp), *d_tgt = (uint8_t*)take(mp);
+  uint8_t *d_set = (uint8_t*)take(mp), *d_tgt = (uint8_t*)take(mp), *d_wr = (uint8_t*)take(mp);
+  EHIP(e, hipMemcpyAsync(d_wr, writer.data(), (size_t)m, hipMemcpyHostToDevice, e->stream));
   int32_t* d_deps = (int32_t*)take((size_t)m * n * 4);
   EHIP(e, hipMemcpyAsync(d_leader, leader, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
   EHIP(e, hipMemcpyAsync(d_number, number, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
@@ -2236,7 +2263,7 @@ int32_t fpx_epx_handle_commit(fpx_epx* e, int32_t m, const int32_t* leader, cons
   if (deps && deps_values_end) EHIP(e, hipMemcpyAsync(d_end, deps_values_end, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
   LcBatch b;
   b.m = m, b.leader = d_leader, b.number = d_number, b.triple = d_tr, b.key = d_key, b.is_set = d_set;
-  b.deps = deps ? d_deps : nullptr, b.deps_end = (deps && deps_values_end) ? d_end : nullptr, b.target = d_tgt;
+  b.deps = deps ? d_deps : nullptr, b.deps_end = (deps && deps_values_end) ? d_end : nullptr, b.target = d_tgt, b.writer = d_wr;
   hipLaunchKernelGGL(k_cl_learn_commit, dim3((unsigned)(((long long)m * n + 255) / 256)), dim3(256), 0, e->stream, e->st, b);
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) {

@@ -94,11 +94,12 @@ __global__ void __launch_bounds__(256) k_band_mark(const Geom g, int n, const in
   if (s >= 0) lg_mark[s % g.num_leader_groups] = 1;
 }
 __global__ void __launch_bounds__(256) k_band_check(const Geom g, const State st, int n, const int32_t* slot, const int32_t* round,
-                                                    const int32_t* lg_mark) {
+                                                    const int32_t* lg_mark, int index_base) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int s = slot[i];
-  if (s >= 0 && lg_mark[s % g.num_leader_groups] != 0) report_abort(st, 6 /*FPX_EORDER*/, i, s, round[i]);
+  // (the reported index counts from the caller's first message, as k_validate's does: ADVICE r05)
+  if (s >= 0 && lg_mark[s % g.num_leader_groups] != 0) report_abort(st, 6 /*FPX_EORDER*/, i + index_base, s, round ? round[i] : 0);
 }
 
 // mencius/ProxyLeader.scala:255-303.  lookup = 1: find only (the Phase2bNoopRange entry point).

@@ -226,18 +226,36 @@ class GpuEPaxosReplica[Transport <: frankenpaxos.Transport[Transport]](
     // ---- Commits from replicas outside (Replica.handleCommit :1567-1575): the device's command log and conflict index at
     // THIS replica learn them (a later Prepare / PreAccept for the instance is answered with the Commit), then the graph
     if (commits.nonEmpty) {
-      val k = commits.size
-      val keyset = commits.map(c => if (c.commandOrNoop.value.isNoop) (-1, false) else engine.classify(c.commandOrNoop.getCommand))
-      val first = engine.triples.size; commits.foreach(c => engine.triples += c.commandOrNoop)
-      val own = commits.map(c => c.dependencies.intPrefixSet(c.instance.replicaIndex).value)
-      val endsIn = own.map(v => if (v.isEmpty) 0 else v.max + 1).toArray
-      Native.check(Native.epxHandleCommit(engine.handle, k, n, commits.map(_.instance.replicaIndex).toArray,
-                                          commits.map(_.instance.instanceNumber).toArray, Array.tabulate(k)(first + _),
-                                          keyset.map(_._1).toArray, keyset.map(x => (if (x._2) 1 else 0).toByte).toArray,
-                                          commits.flatMap(c => watermarks(c.dependencies)).toArray, endsIn,
-                                          Array.fill(k)(bit(index))), logger)
-      for ((c, i) <- commits.zipWithIndex) {
-        engine.depsOf((c.instance.replicaIndex, c.instance.instanceNumber)) = (watermarks(c.dependencies), endsIn(i))
+      // The device's command log holds an instance's own-leader column as (watermark <= number, explicit ids number + 1 ..
+      // end - 1): what dependencies.subtractOne(instance) makes of a cover (Replica.scala:582).  A reference Replica may send
+      // any InstancePrefixSet; a Commit whose own column is not of that shape is still learnt by the graph below, but the
+      // device's log does not take it -- logged and dropped there, not a fatal (ADVICE r05: input from outside is not an
+      // invariant of this process).  Of several Commits for one instance in the burst the LAST one wins whole, as when the
+      // reference applies them in order (the library takes care of that: fpx_epx_handle_commit).
+      def deviceShape(c: Commit): Boolean = {
+        val own = c.dependencies.intPrefixSet(c.instance.replicaIndex)
+        val x = c.instance.instanceNumber
+        own.value.isEmpty || (own.watermark <= x && own.value.sorted == (x + 1 to own.value.max))
+      }
+      val (forDevice, notForDevice) = commits.partition(deviceShape)
+      notForDevice.foreach(c => logger.warn(s"GpuEPaxosReplica: Commit of ${c.instance} carries an own-leader column the " +
+                                            "device's command log does not represent; learnt by the graph only."))
+      val endsOf = mutable.Map[Commit, Int]()
+      if (forDevice.nonEmpty) {
+        val k = forDevice.size
+        val keyset = forDevice.map(c => if (c.commandOrNoop.value.isNoop) (-1, false) else engine.classify(c.commandOrNoop.getCommand))
+        val first = engine.triples.size; forDevice.foreach(c => engine.triples += c.commandOrNoop)
+        val own = forDevice.map(c => c.dependencies.intPrefixSet(c.instance.replicaIndex).value)
+        val endsIn = own.map(v => if (v.isEmpty) 0 else v.max + 1).toArray
+        Native.check(Native.epxHandleCommit(engine.handle, k, n, forDevice.map(_.instance.replicaIndex).toArray,
+                                            forDevice.map(_.instance.instanceNumber).toArray, Array.tabulate(k)(first + _),
+                                            keyset.map(_._1).toArray, keyset.map(x => (if (x._2) 1 else 0).toByte).toArray,
+                                            forDevice.flatMap(c => watermarks(c.dependencies)).toArray, endsIn,
+                                            Array.fill(k)(bit(index))), logger)
+        for ((c, i) <- forDevice.zipWithIndex) endsOf(c) = endsIn(i)
+      }
+      for (c <- commits) {
+        endsOf.get(c).foreach(end => engine.depsOf((c.instance.replicaIndex, c.instance.instanceNumber)) = (watermarks(c.dependencies), end))
         learnCommit(c.instance, c.commandOrNoop, c.dependencies)
       }
       commits.clear()

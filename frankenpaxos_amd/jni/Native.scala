@@ -261,6 +261,7 @@ class GpuPhase2Engine[Transport <: frankenpaxos.Transport[Transport]](
     var moved = false
     while (chosenPrefix - base >= chunk && highestChosen - (base + chunk) >= retainSlots) {
       val r0 = row(base)                                 // chunk | numSlots: the chunk does not wrap
+      refreshStaleGroups()                               // (the votes of these rows are read before they are cleared)
       Native.check(Native.recycleSlots(handle, r0, chunk), logger)
       for (r <- r0 until r0 + chunk) {
         idsOfRow(r).foreach(id => { values(id) = null; freeIds.push(id) })
@@ -303,22 +304,30 @@ class GpuPhase2Engine[Transport <: frankenpaxos.Transport[Transport]](
     }
   }
 
+  // the rescan of one stale group: the largest voted row of each lap of the window, per acceptor, from the device
+  private def refreshMaxVoted(g: Int): Unit = {
+    val r0 = row(base)
+    for (b <- 0 until ctxReplicas) {
+      // the older lap of the window lives in rows [r0, numSlots), the newer one in [0, r0)
+      val hi = if (r0 > 0) Native.acceptorMaxVotedIn(handle, g, b, 0, r0) else -1
+      val lo = if (hi < 0) Native.acceptorMaxVotedIn(handle, g, b, r0, numSlots - r0) else -1
+      if (hi < -1) Native.check(-hi - 1, logger)
+      if (lo < -1) Native.check(-lo - 1, logger)
+      val slot = if (hi >= 0) base + (numSlots - r0) + hi else if (lo >= 0) base + (lo - r0) else -1
+      maxVoted(g)(b) = math.max(maxVoted(g)(b), slot)
+    }
+    maxVotedStale(g) = false
+  }
+  // ADVICE r05: a stale group is rescanned BEFORE any of its rows is recycled (advanceWindow) -- a vote cast in a Nacked
+  // message must be recorded before its row is cleared, or MaxSlotReply.slot would under-report (Acceptor.scala:208 never
+  // misses a vote, and a low slot is the unsafe direction for linearizable reads)
+  private def refreshStaleGroups(): Unit =
+    for (g <- 0 until ctxGroups if maxVotedStale(g)) refreshMaxVoted(g)
+
   // Acceptor.handleMaxSlotRequest / handleBatchMaxSlotRequest reply with this (Acceptor.scala:222-254)
   def maxVotedSlot(groupIndex: Int, index: Int): Int = {
     val g = ctxGroup(groupIndex); val a = ctxReplica(groupIndex, index)
-    if (maxVotedStale(g)) {
-      val r0 = row(base)
-      for (b <- 0 until ctxReplicas) {
-        // the older lap of the window lives in rows [r0, numSlots), the newer one in [0, r0)
-        val hi = if (r0 > 0) Native.acceptorMaxVotedIn(handle, g, b, 0, r0) else -1
-        val lo = if (hi < 0) Native.acceptorMaxVotedIn(handle, g, b, r0, numSlots - r0) else -1
-        if (hi < -1) Native.check(-hi - 1, logger)
-        if (lo < -1) Native.check(-lo - 1, logger)
-        val slot = if (hi >= 0) base + (numSlots - r0) + hi else if (lo >= 0) base + (lo - r0) else -1
-        maxVoted(g)(b) = math.max(maxVoted(g)(b), slot)
-      }
-      maxVotedStale(g) = false
-    }
+    if (maxVotedStale(g)) refreshMaxVoted(g)
     maxVoted(g)(a)
   }
 

@@ -186,6 +186,12 @@ int64_t fpx_device_bytes(fpx_ctx* ctx);
  * windows of the hot access pattern's time on half a window, in ms (0 when nothing was probed).  Diagnostics only:
  * results never depend on the placement.  FPX_PLACEMENT_CHUNKS=0 in the environment keeps one allocation. */
 int32_t fpx_placement_stats(fpx_ctx* ctx, float out[5]);
+/* What the placement search of fpx_create cost: probes run, decisions taken WITHOUT a probe because the search's budget
+ * was spent, and the wall clock of the search in ms.  The budget is FPX_PLACEMENT_BUDGET_MS in the environment (default
+ * 300 ms; 0 = no probing at all: the slab is built from the chunks in allocation order): once it is spent every remaining
+ * decision takes its first candidate, so N ranks creating contexts at once cannot stretch fpx_create without bound.  Any
+ * of the three pointers may be NULL.  Diagnostics only. */
+int32_t fpx_placement_search(fpx_ctx* ctx, int32_t* probes, int32_t* unprobed, float* ms);
 /* the configuration the context was created with (replicas_total filled in): a binding sizes its buffers from the
  * handle, not from what its caller says the handle is */
 int32_t fpx_get_config(fpx_ctx* ctx, fpx_config* out);
@@ -387,7 +393,10 @@ int32_t fpx_noop_ranges_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot
  * ranges on a second stream of the context between a fork and a join event.  A context that validates its batches
  * checks the statement first: a leader group with both makes the step FPX_EORDER with nothing applied (call again with
  * independent = 0), and the halves run one after the other.  FPX_BAND_SERIAL=1 in the environment keeps the two-launch
- * form off. */
+ * form off.  HAZARD: under FPX_F_TRUSTED the statement is NOT checked -- a leader group with both a command and a range
+ * in an `independent` step makes the range chain's store of an acceptor's round race with the vote kernel's fold of
+ * maxima, and the state is silently wrong.  FPX_DEBUG=1 in the environment checks the statement on trusted contexts too
+ * (FPX_EORDER, nothing applied; the halves then run one after the other). */
 int32_t fpx_mencius_band_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,
                                    const int32_t* d_value_id, const uint64_t* d_target_mask, uint8_t* d_chosen,
                                    int32_t* d_chosen_round, int32_t* d_chosen_value, int32_t* d_nack_round,

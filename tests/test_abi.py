@@ -133,13 +133,19 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     # ... and without a launcher around it, it launches its own ranks: one per GPU, 127.0.0.1 rendezvous
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["FPX_BENCH_DRY_SPAWN"] = "1"
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "5"],
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--test-hooks", "--gpus", "8", "--steps", "5"],
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr
     cmd = json.loads(out.stdout.strip().splitlines()[-1])["spawn"]
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
     assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
-    assert cmd[-4:] == ["--gpus", "8", "--steps", "5"] and cmd[-5].endswith("bench.py")
+    assert cmd[-5:] == ["--test-hooks", "--gpus", "8", "--steps", "5"] and cmd[-6].endswith("bench.py")
+    # a hook variable that leaked into the environment does not change what the line measures -- without
+    # --test-hooks the run is refused
+    env["FPX_BENCH_SLOTS_LOG2"] = "16"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], capture_output=True, text=True,
+                         env=env, timeout=300)
+    assert out.returncode != 0 and "without --test-hooks" in out.stderr
 
 
 def test_bench_deadline_helper():

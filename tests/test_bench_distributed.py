@@ -26,7 +26,7 @@ def _run(extra):
     env = dict(os.environ, FPX_BENCH_SHARE_GPU="1", FPX_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"] + extra
+           os.path.join(ROOT, "bench.py"), "--test-hooks", "--gpus", "2", "--steps", "3", "--warmup", "1"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -40,7 +40,7 @@ def test_bench_spawns_its_own_ranks():
     env = dict(os.environ, FPX_BENCH_SHARE_GPU="1", FPX_BENCH_BACKEND="gloo")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--test-hooks", "--gpus", "2", "--steps", "2",
                           "--warmup", "1", "--replica-row-steps", "2"],
                          capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
@@ -65,6 +65,7 @@ def test_group_sharded_bench_two_ranks():
     # the CPU baseline rides on every line, at N > 1 the single-thread flat port only (rank 0 times it)
     assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
     assert d["rccl_ranks"] == 0 and "rccl" not in d           # gloo hook: no RCCL communicator was created
+    assert d["test_hooks"] == ["FPX_BENCH_BACKEND", "FPX_BENCH_SHARE_GPU"]   # a hooked line says so
 
 
 def test_replica_sharded_bench_two_ranks():
@@ -124,7 +125,7 @@ def test_bench_spawns_eight_ranks():
     env = dict(os.environ, FPX_BENCH_SHARE_GPU="1", FPX_BENCH_BACKEND="gloo")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--test-hooks", "--gpus", "8", "--steps", "2", "--warmup", "1",
                           "--replica-row-steps", "0"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -152,7 +153,7 @@ def test_eight_rank_lines_through_the_library_communicator(shard):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     extra = ["--replica-row-steps", "2"] if shard == "group" else ["--shard", "replica"]
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"] + extra,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--test-hooks", "--gpus", "8", "--steps", "2", "--warmup", "1"] + extra,
                          capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]

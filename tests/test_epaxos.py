@@ -735,6 +735,41 @@ def test_epaxos_handle_commit_matches_oracle(oracle, n, NI, m):
     assert EPaxos(n, K).handle_commit([0], [1], [1], [1]) == fa.FPX_EINVAL
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [3, 5, 7])
+def test_epaxos_commits_of_one_instance_in_one_batch_apply_in_order(oracle, n):
+    """several Commits for ONE instance in one call (a re-sent Commit with another triple id, other dependencies,
+    other recipients): the reference applies them one after the other, so per replica the LAST message that reaches it wins
+    whole -- never one message's triple with another's dependencies; the conflict index sees every message's put"""
+    from frankenpaxos_amd.epaxos import EPaxos
+
+    NI, K = 64, 6
+    gpu, ref = EPaxos(n, K, num_instances=NI), oracle.EPaxos(n, K, num_instances=NI)
+    rng = np.random.default_rng(900 + n)
+    for rep in range(6):
+        base = 40
+        inst = rng.integers(0, n * 12, base)                       # 12 numbers per leader: many repeats among 40 messages
+        leader, number = (inst // 12).astype(np.int32), (inst % 12).astype(np.int32)
+        tr = (1000 * rep + np.arange(base)).astype(np.int32)      # every message its own triple id
+        key = rng.integers(0, K, base).astype(np.int32)
+        is_set = rng.integers(0, 2, base).astype(np.uint8)
+        deps = rng.integers(0, 12, (base, n)).astype(np.int32)
+        deps[np.arange(base), leader] = np.minimum(deps[np.arange(base), leader], number)
+        ends = np.where(rng.random(base) < 0.4, number + 2 + rng.integers(0, 3, base), 0).astype(np.int32)
+        tgt = rng.integers(1, 1 << n, base).astype(np.uint8)
+        args = dict(key=key, is_set=is_set, deps=deps, deps_values_end=ends)
+        assert gpu.handle_commit(leader, number, tr, tgt, **args) == ref.handle_commit(leader, number, tr, tgt, **args) == 0
+        for r in range(n):
+            for L in range(n):
+                for x in range(12):
+                    assert gpu.read_cmdlog(r, L, x) == ref.read_cmdlog(r, L, x), (rep, r, L, x)
+                    (da, ea), (db, eb) = gpu.read_cmdlog_deps(r, L, x), ref.read_cmdlog_deps(r, L, x)
+                    assert ea == eb and np.array_equal(da, db), (rep, r, L, x)
+            for k in range(K):
+                for x, y in zip(gpu.read_index(r, k), ref.read_index(r, k)):
+                    np.testing.assert_array_equal(x, y)
+
+
 # ------------------------------------------------ handlePreAccept in full: ballots, Nacks, re-sent replies ----
 def test_oracle_handle_preaccept_every_branch_by_hand(oracle):
     """n = 5, instance X = (0, 0): set k1 led by replica 0.  Replica 1 already knows the conflicting instance (2, 6).

@@ -73,3 +73,29 @@ def test_chunk_placement_survives_many_contexts_and_leaves_small_ones_alone(fa):
         c.close()
     torch.cuda.synchronize()
     assert abs(torch.cuda.mem_get_info()[0] - free0) < (256 << 20)
+
+
+def test_placement_search_keeps_to_its_budget(fa, monkeypatch):
+    """FPX_PLACEMENT_BUDGET_MS bounds the probe time of fpx_create -- with the budget spent every
+    remaining decision takes its first candidate unprobed (budget 0: the slab is the chunks in allocation order), results
+    are those of any other placement, and the default budget is reported kept on a quiet device."""
+    kw = dict(num_slots=3 << 20, num_replicas=256, f=127, ballot_mode=1, flags=fa.FPX_F_TRUSTED)
+    monkeypatch.delenv("FPX_PLACEMENT_CHUNKS", raising=False)
+    monkeypatch.setenv("FPX_PLACEMENT_BUDGET_MS", "0")
+    c = fa.Context(fa.make_config(**kw))
+    st = c.placement_stats()
+    assert st["chunks"] and st["windows"] == 3, st
+    assert st["search"]["unprobed_decisions"] >= 3 and st["search"]["probes"] <= 2, st      # (one warm-up probe)
+    slot, rnd, val = W.steady_stream(1 << 12)
+    assert c.acceptor_phase1a(0, 0)[0] == 0
+    for base in (0, 1 << 20, (3 << 20) - (1 << 12)):                   # rows of every gigabyte window
+        res = c.phase2_fused(slot + base, rnd, val)
+        assert res[0] == 0 and res[1].all() and (res[3] == val).all()
+    c.close()
+    monkeypatch.delenv("FPX_PLACEMENT_BUDGET_MS")
+    c = fa.Context(fa.make_config(**kw))
+    st = c.placement_stats()
+    # the search of a 9-chunk slab: tens of probes of ~0.2 ms each; the wall clock stays near the default budget of 300 ms
+    # (one probe may be in flight when it runs out)
+    assert st["chunks"] and st["search"]["probes"] > 3 and st["search"]["ms"] < 600, st
+    c.close()
