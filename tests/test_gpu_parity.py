@@ -847,3 +847,86 @@ def test_page_locked_calls_in_flight(fa, oracle):
     assert st == 0
     same(bad)                                                                        # ... the synchronous call splits it
     np.testing.assert_array_equal(gpu.state_digest(), ref.state_digest())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stage", ["carry", "engines"])
+@pytest.mark.parametrize("ballot_mode", [0, 1])
+def test_page_locked_calls_ride_in_each_others_vote_kernels(fa, oracle, monkeypatch, ballot_mode, stage):
+    """Round 6: on a dense 256-acceptor context the PCIe copies of a submitted call are workgroups of its neighbours' vote
+    kernels (k_phase2_host), and a call's fused step is launched when the NEXT call is submitted.  None of that may show:
+    calls pumped three deep, a burst that ends with calls still unlaunched, waits in any order, and other entry points
+    called in between (they launch what is pending first) all equal the oracle fed the same batches in the same order."""
+    import ctypes as C
+
+    if stage == "carry":
+        monkeypatch.setenv("FPX_HOST_STAGE", "carry")
+    else:
+        monkeypatch.delenv("FPX_HOST_STAGE", raising=False)   # the default: the copy engines on streams of their own
+    S, R, n = 1 << 19, 256, 1 << 15
+    kw = dict(num_slots=S, num_replicas=R, f=127, tally_ways=8, ballot_mode=ballot_mode)
+    gpu, ref = fa.Context(fa.make_config(**kw)), oracle.System(oracle.make_config(**kw))
+    assert gpu.acceptor_phase1a(0, 0)[0] == 0 and ref.acceptor_phase1a(0, 0)[0] == 0
+    L = fa.lib()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def batch(k, rnd=0):
+        a = {name: fa.PinnedArray((n,), dt) for name, dt in (("slot", np.int32), ("rnd", np.int32), ("val", np.int32),
+                                                             ("ch", np.uint8), ("cr", np.int32), ("cv", np.int32), ("nr", np.int32))}
+        a["slot"].array[:] = np.arange(k * n, (k + 1) * n)
+        a["rnd"].array[:] = rnd
+        a["val"].array[:] = W.steady_values(a["slot"].array) + k
+        for o in ("cr", "cv", "nr"):
+            a[o].array[:] = -7
+        return a
+
+    def submit(a):
+        t = C.c_int32(-1)
+        assert L.fpx_phase2_fused_submit(gpu._h, n, p(a["slot"].array), p(a["rnd"].array), p(a["val"].array), None,
+                                         p(a["ch"].array), p(a["cr"].array), p(a["cv"].array), p(a["nr"].array), C.byref(t)) == 0
+        return t.value
+
+    def same(a):
+        b = ref.phase2_fused(a["slot"].array.copy(), a["rnd"].array.copy(), a["val"].array.copy())
+        assert b[0] == 0
+        for k, want in zip(("ch", "cr", "cv", "nr"), b[1:]):
+            np.testing.assert_array_equal(a[k].array, want, err_msg=k)
+
+    bs = [batch(k) for k in range(9)]
+    # (1) the pump of bench.py --config host_path: three in flight, the oldest waited for before the next submit
+    inflight = []
+    for b in bs[:6]:
+        if len(inflight) == 3:
+            t, done = inflight.pop(0)
+            assert L.fpx_phase2_fused_wait(gpu._h, t) == 0
+            same(done)
+        inflight.append((submit(b), b))
+    # (2) the burst ends: two of the three calls in flight were never launched or never sent; newest first
+    for t, done in reversed(inflight):
+        assert L.fpx_phase2_fused_wait(gpu._h, t) == 0
+    for _, done in inflight:
+        same(done)
+    assert gpu.host_carried_launches() >= (4 if stage == "carry" else 0), gpu.host_carried_launches()
+    np.testing.assert_array_equal(gpu.state_digest(), ref.state_digest())
+    # (3) another entry point between submit and wait sees the submitted calls applied
+    t6, t7 = submit(bs[6]), submit(bs[7])
+    got = gpu.read_acceptor(0, 200)
+    ref.phase2_fused(bs[6]["slot"].array.copy(), bs[6]["rnd"].array.copy(), bs[6]["val"].array.copy())
+    ref.phase2_fused(bs[7]["slot"].array.copy(), bs[7]["rnd"].array.copy(), bs[7]["val"].array.copy())
+    want = ref.read_acceptor(0, 200)
+    assert got[:2] == want[:2]
+    for u, v in zip(got[2:], want[2:]):
+        np.testing.assert_array_equal(u, v)
+    assert L.fpx_phase2_fused_wait(gpu._h, t7) == 0 and L.fpx_phase2_fused_wait(gpu._h, t6) == 0
+    for k in (6, 7):
+        b = bs[k]
+        assert b["ch"].array.all() and (b["cv"].array == b["val"].array).all() and (b["cr"].array == 0).all()
+    # (4) a stale leader's batch among calls in flight: Nacks come back through the same records
+    assert gpu.acceptor_phase1a(0, 1)[0] == 0 and ref.acceptor_phase1a(0, 1)[0] == 0
+    stale = batch(8, rnd=0)
+    t8 = submit(stale)
+    assert L.fpx_phase2_fused_wait(gpu._h, t8) == 0
+    same(stale)
+    assert (stale["nr"].array == 1).all() and not stale["ch"].array.any()
+    np.testing.assert_array_equal(gpu.state_digest(), ref.state_digest())
+    gpu.close()
