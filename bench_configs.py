@@ -484,8 +484,8 @@ def mencius_setup(fa, dev, local_rank, rank, world, K, Wm):
 # ------------------------------------------------------------------------------------------------------------------
 def host_path_line(args, fa, dev, local_rank):
     """fpx_phase2_fused_submit / _wait on page-locked arrays (fpx_host_alloc), up to 3 calls in flight: per call 12 B per
-    slot of proposals go up, the fused 2^20 x 256 step runs, 9 B per slot of Chosen records come down.  PCIe-inclusive,
-    never bench.py's `value`."""
+    slot of proposals go up (copy engine), the fused 2^20 x 256 step runs and writes its 9 B per slot of Chosen records
+    straight into the caller's arrays (profiles/r06_host_path.md).  PCIe-inclusive, never bench.py's `value`."""
     import ctypes as C
     from tests import workloads as W
     K, Wm = args.steps, args.warmup
@@ -543,15 +543,17 @@ def host_path_line(args, fa, dev, local_rank):
                    "baseline_config": "host_path", "ballot_model": args.ballot, "slots_per_step": B, "replicas": R,
                    "verified": "every timed call checked after the timed region: every slot chosen in round 0 with its proposed value",
                    "pcie_bytes_per_slot": 21, "pcie_GBs": 21 * B / per / 1e9},
-        "roofline": {"bound": "hbm", "kernel": "k_phase2<64, 0, *, fused> between staging kernels on their own streams",
+        "roofline": {"bound": "hbm", "kernel": "k_phase2<64, 0, *, fused>: inputs staged in HBM by the copy engine, records written "
+                                               "straight into the caller's page-locked arrays; k_validate, k_finalize, k_status_snap around it",
                      "achieved": bps * B / per / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bps * B / per / 1e9 / HBM_PEAK_GBS,
                      "traffic": traffic_of("host_path", args.ballot), "traffic_round": traffic_entry(traffic_key("host_path", args.ballot))[1],
                      "algorithmic_bytes_per_unit": bps, "units_per_launch": B,
                      "avg_kernel_ms": kernel_ms / max(launches, 1), "launches_timed": launches,
                      "kernel_time_source": "`achieved` = algorithmic HBM bytes / WALL time per call (the PCIe transfers included); "
                                            "avg_kernel_ms = the vote kernel alone (fpx_profile_*)",
-                     "note": "bound by PCIe (21 B per slot each call), not by HBM: the fraction says how far the host boundary "
-                             "keeps the kernel from its device-resident rate"},
+                     "note": "NOT bound by PCIe (21 B per slot each call = pcie_GBs of a ~55 GB/s link): the call is the fused step "
+                             "(+3 % for its posted writes to host memory) + forced validation + finalize + status snapshot and the "
+                             "dependent-launch gaps between them; profiles/r06_host_path.md"},
     }
 
 

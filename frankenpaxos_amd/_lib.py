@@ -80,7 +80,6 @@ SIGNATURES = {
     "fpx_last_hip_error": (C.c_int32, [VP]),
     "fpx_device_bytes": (C.c_int64, [VP]),
     "fpx_placement_stats": (C.c_int32, [VP, C.POINTER(C.c_float)]),
-    "fpx_host_carried_launches": (C.c_int64, [VP]),
     "fpx_placement_search": (C.c_int32, [VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "fpx_band_merged_steps": (C.c_int64, [VP]),
     "fpx_acceptor_max_voted_in": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, I32P]),

@@ -138,10 +138,6 @@ class Context:
         return {"chunks": bool(out[0]), "windows": int(out[1]), "probe_ms": (float(out[2]), float(out[3]), float(out[4])),
                 "search": {"probes": pr.value, "unprobed_decisions": un.value, "ms": float(ms.value)}}
 
-    def host_carried_launches(self):
-        """diagnostic: fused steps of submit / wait calls whose launch carried the neighbouring calls' PCIe copies"""
-        return int(self.L.fpx_host_carried_launches(self._h))
-
     def band_merged_steps(self):
         """diagnostic: the mencius_band_fused_dev steps that ran in the two-launch form"""
         return int(self.L.fpx_band_merged_steps(self._h))

@@ -55,25 +55,17 @@ struct RcclApi {
 static_assert(sizeof(RcclUniqueId) == FPX_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
 enum { RCCL_SUM = 0, RCCL_MAX = 2, RCCL_UINT8 = 1, RCCL_INT32 = 2, RCCL_UINT64 = 5 };  // ncclRedOp_t / ncclDataType_t values
 
-// One call in flight: staging buffers of its own, the three events of its pipeline, a page-locked copy of the status
-// words taken right after its fused step.
+// One call in flight: staging buffers for its inputs, two events, a page-locked copy of the status words taken right after
+// its fused step.
 constexpr int HOST_DEPTH = 3;
 struct HostSlot {
-  DevBuf in[4], out[4];       // the call's staging buffers in HBM
-  const void* din[4] = {nullptr, nullptr, nullptr, nullptr};  // the caller's arrays (device addresses of mapped host memory)
-  void* dout[4] = {nullptr, nullptr, nullptr, nullptr};
-  const void* hin[4] = {nullptr, nullptr, nullptr, nullptr};  // ... and their host addresses (copy-engine mode)
-  void* hout[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t up = nullptr, k3 = nullptr;  // copy-engine mode: inputs are up / the fused step is done
-  bool by_flag = false;       // wait() looks at the call's word in page-locked memory before it waits for `done`
-  hipEvent_t done = nullptr;  // recorded behind whatever brings the call's records down
+  DevBuf in[4];               // the call's inputs staged in HBM (validation and the vote kernel read them there)
+  DevBuf sink[3];             // where the records go that the caller did not ask for (a null output array)
+  hipEvent_t up = nullptr;    // the inputs are up (the copy engine's stream)
+  hipEvent_t done = nullptr;  // validation + fused step + status snapshot are done: the records are in the caller's arrays
   int32_t* status = nullptr;  // page-locked, 8 words: the device's status right after the call (k_status_snap)
   int32_t* status_dev = nullptr;
-  unsigned int* ctr_dev = nullptr;  // device word: the out-workgroups' arrival counter
-  int32_t seq = 0;            // what status[8] reads once the call's records are in the caller's arrays
   bool busy = false;          // submitted, not waited for yet
-  bool launched = false;      // its validation + fused step are on the stream
-  bool out_enqueued = false;  // ... and so are the copies of its records
   int n = 0;
 };
 
@@ -120,12 +112,6 @@ struct fpx_ctx {
   hipStream_t up_stream = nullptr, down_stream = nullptr;
   HostSlot* hslots = nullptr;  // calls in flight on page-locked arrays (host_submit / host_wait)
   int hnext = 0;
-  int32_t host_seq = 0;
-  int host_pending = -1;       // the submitted call whose vote kernel waits for the next submit (or a wait) to be launched
-  int host_last = -1;          // the call launched last
-  bool in_host = false;        // inside the host pipeline's own code: its nested entry points do not flush
-  HostStage carry = {};        // copies the next dense fused launch takes into its grid (nblk = 0: none)
-  long long host_carried = 0;  // diagnostic: launches that carried their neighbours' copies
   std::vector<hipEvent_t> pipe_ev;  // [2 * pieces]: uploaded, computed
   int32_t index_base = 0;           // message index of the piece being launched (error reports are batch-relative)
   bool lazy_active = false;  // PER_SLOT: lazy Phase1a promises may be outstanding (k_phase2 runs its lazy-aware form)
@@ -163,18 +149,12 @@ namespace {
 // Every entry point runs with the context's device current and restores the caller's on return: allocations
 // (staging buffers, events) and launches otherwise land on whatever device the calling thread last selected --
 // two contexts on two GPUs in one process (or a torch.cuda.set_device elsewhere) would fault.
-int host_flush(fpx_ctx* ctx);
 struct DeviceGuard {
   int prev = -1;
   bool switched = false;
   explicit DeviceGuard(int device) { enter(device); }
-  // Every entry point that takes the context starts here.  Calls submitted through fpx_phase2_fused_submit whose vote
-  // kernel has not been launched yet (it waits for the next submit: see host_submit) are launched first, so that whatever
-  // the entry point does is ordered behind them as the ABI says; submit / wait themselves enter by device number.
   explicit DeviceGuard(const fpx_ctx* ctx) {
-    if (!ctx) return;
-    enter(ctx->cfg.device);
-    if (ctx->hslots && !ctx->in_host && (ctx->host_pending >= 0 || ctx->host_last >= 0)) (void)host_flush(const_cast<fpx_ctx*>(ctx));
+    if (ctx) enter(ctx->cfg.device);
   }
   void enter(int device) {
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
@@ -332,16 +312,6 @@ void launch_phase2_3(fpx_ctx* ctx, const Batch& b0, bool fused, int grid) {
   const size_t lds = phase2_lds(ctx, b, fused, MODE != 0, PS == 0);
   if (fused) allow_lds(k_phase2<G, MODE, PS, true>, lds);
   else allow_lds(k_phase2<G, MODE, PS, false>, lds);
-  if constexpr (G == 64 && MODE == 0) {
-    // a call of the host path: its neighbours' copies are the first workgroups of this launch (k_phase2_host)
-    if (fused && ctx->carry.nblk && !b.solo) {
-      allow_lds(k_phase2_host<64, 0, PS, true>, lds);
-      hipExtLaunchKernelGGL((k_phase2_host<64, 0, PS, true>), dim3(grid + ctx->carry.nblk), dim3(256), (uint32_t)lds, ctx->stream,
-                            ctx->ev_start, ctx->ev_stop, 0, ctx->g, ctx->st, b, ctx->carry);
-      ctx->carry.nblk = 0;
-      return;
-    }
-  }
   if (fused)
     hipExtLaunchKernelGGL((k_phase2<G, MODE, PS, true>), dim3(grid), dim3(256), (uint32_t)lds, ctx->stream, ctx->ev_start,
                           ctx->ev_stop, 0, ctx->g, ctx->st, b);
@@ -895,12 +865,10 @@ void free_state(fpx_ctx* ctx) {
       HostSlot& h = ctx->hslots[k];
       for (DevBuf& b : h.in)
         if (b.p) (void)hipFree(b.p);
-      for (DevBuf& b : h.out)
+      for (DevBuf& b : h.sink)
         if (b.p) (void)hipFree(b.p);
       if (h.done) (void)hipEventDestroy(h.done);
       if (h.up) (void)hipEventDestroy(h.up);
-      if (h.k3) (void)hipEventDestroy(h.k3);
-      if (h.ctr_dev) (void)hipFree(h.ctr_dev);
       if (h.status) (void)hipHostFree(h.status);
     }
     delete[] ctx->hslots;
@@ -1154,16 +1122,22 @@ int host_fused_pipelined(fpx_ctx* ctx, int n, const int32_t* slot, const int32_t
   return host_fused_replay(ctx, n, slot, round, target_mask != nullptr, from, chosen, chosen_round, chosen_value, nack_round);
 }
 
-// ---- page-locked host batches: staging by kernels instead of by the copy engines ------------------------------
-// hipMemcpyAsync of a page-locked buffer is one SDMA engine per direction: ~25 GB/s on this host interface, and
-// three 4 MB copies each way are 0.5 ms of a 1.09 ms call (profiles/r02_host_path.txt).  Memory from fpx_host_alloc is
-// mapped into the GPU's address space, so a kernel can move it itself with 16-byte accesses from a few thousand threads
-// (enough requests in flight to fill the link).  Round 6: the copies are workgroups of the vote kernel's own grid
-// (k_phase2_host, fpx_kernels.hpp) -- the stage-in of call k + 1 and the stage-out of call k - 1 ride in the vote kernel
-// of call k -- on ONE stream.  For that the vote kernel of a call is launched when the NEXT call is submitted (its inputs
-// are what the launch carries up) or when somebody waits for it; a call's outputs are on their way when the launch after
-// its own has been enqueued.  Any other entry point of the context first launches what is pending (DeviceGuard), so the
-// deferral is not observable through the ABI.  Used when EVERY array of the call is mapped host memory.
+// ---- page-locked host batches (fpx_phase2_fused_submit / _wait) ------------------------------------------------------
+// A call moves 12 B per slot up (slot, round, value) and 9 - 13 B per slot down (Chosen records, Nack rounds).  How, was
+// decided by measuring what each way of crossing PCIe costs the vote kernel it runs beside (profiles/r06_host_path.md,
+// microbench/r06_pcie_beside_vote.py; 2^20 x 256 step, vote kernel alone 0.546 ms):
+//   inputs by the copy engine on a stream of its own (hipMemcpyAsync, 51 GB/s, 3 x 82 us)             + 3 %
+//   inputs read by the vote kernel straight from the mapped arrays                                    + 12 %
+//   inputs copied by WORKGROUPS (a staging kernel beside the vote kernel: rounds 2 - 5; or workgroups of the vote
+//     kernel's own grid)                                                       + 14 % ... + 50 % with the requests in flight
+//   records written by the vote kernel straight into the mapped arrays (posted writes)               + 3 %
+//   records copied by workgroups                                                                      + 30 %
+// (a shader's reads of host memory hold entries of the L2's fabric queues for microseconds each and the vote kernel's HBM
+// requests queue behind them; the copy engine does not go through the L2.)  So: the inputs go up by the copy engine on
+// `up_stream` into staging buffers in HBM, validation and the fused step run on the context's stream behind ONE event,
+// and the vote kernel's output arrays ARE the caller's page-locked arrays -- no copy down, no third stream, no staging
+// kernel.  The status words of the call are snapshotted into page-locked words by a one-wavefront kernel behind the step.
+// Every array must be mapped host memory (FPX_EINVAL otherwise).
 
 // the device address of mapped (page-locked) host memory, nullptr for anything else
 void* mapped_host(const void* p) {
@@ -1176,123 +1150,15 @@ void* mapped_host(const void* p) {
   return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
 }
 
-// workgroups per direction (256 threads x 8 x 16 B in flight each: 2 MB on the link per direction)
-constexpr int HOST_STAGE_BLOCKS = 64;
-// how a submitted call's arrays cross PCIe: by the copy engines on streams of their own (default), or as workgroups of the
-// neighbouring calls' vote kernels (FPX_HOST_STAGE=carry; kept for the record of profiles/r06_host_path.md)
-enum { HOST_COPY_ENGINES = 0, HOST_CARRY = 1 };
-int host_mode() {  // (read at every submit: a test switches it between contexts)
-  const char* e = getenv("FPX_HOST_STAGE");
-  return (e && !strcmp(e, "carry")) ? HOST_CARRY : HOST_COPY_ENGINES;
-}
-
-// the copies of slot `in` (host -> staging) and slot `out` (staging -> host) as one job; either may be null
-void fill_stage(HostStage* hs, const HostSlot* in, const HostSlot* out) {
-  memset(hs, 0, sizeof(*hs));
-  static const size_t in_elem[4] = {4, 4, 4, 32}, out_elem[4] = {1, 4, 4, 4};
-  bool any = false;
-  for (int a = 0; a < 4; ++a) {
-    if (in && in->din[a]) hs->src[a] = in->din[a], hs->dst[a] = in->in[a].p, hs->bytes[a] = (size_t)in->n * in_elem[a], any = true;
-    if (out && out->dout[a]) hs->src[4 + a] = out->out[a].p, hs->dst[4 + a] = out->dout[a], hs->bytes[4 + a] = (size_t)out->n * out_elem[a], any = true;
-  }
-  (void)any;
-  int blocks = HOST_STAGE_BLOCKS;
-  if (const char* e = getenv("FPX_HOST_STAGE_BLOCKS")) blocks = std::max(1, std::min(512, atoi(e)));
-  hs->nblk_in = in ? blocks : 0;
-  hs->nblk_out = out ? blocks : 0;  // (also when the caller asked for no output array: the flag still has to be raised)
-  hs->nblk = hs->nblk_in + hs->nblk_out;
-  if (out) hs->out_ctr = out->ctr_dev, hs->out_flag = out->status_dev + 8, hs->out_seq = out->seq;
-}
-
-// copies with no vote kernel to ride in
-int host_stage_alone(fpx_ctx* ctx, HostSlot* in, HostSlot* out) {
-  HostStage hs;
-  fill_stage(&hs, in, out);
-  if (hs.nblk) hipLaunchKernelGGL(k_stage8, dim3(hs.nblk), dim3(256), 0, ctx->stream, hs);
-  if (out) {
-    HIPCHK(ctx, hipEventRecord(out->done, ctx->stream));
-    out->out_enqueued = true;
-  }
-  return launch_check(ctx);
-}
-
-// validation + fused step of the submitted call in slot t; its launch carries the stage-in of `in_next` and the stage-out
-// of `out_prev` (either may be null).  The status words the device holds right after the call go to the call's own
-// page-locked words (a run-contract violation aborts the call -- and the calls behind it -- before anything is applied).
-int host_launch(fpx_ctx* ctx, int t, HostSlot* in_next, HostSlot* out_prev) {
-  HostSlot& h = ctx->hslots[t];
-  fill_stage(&ctx->carry, in_next, out_prev);
-  int rc;
-  {
-    struct Guard {
-      fpx_ctx* c;
-      ~Guard() { c->force_validate = false; }
-    } _g{ctx};
-    ctx->force_validate = true;  // also under FPX_F_TRUSTED: that flag is a promise about _dev batches only
-    rc = fpx_phase2_fused_dev(ctx, h.n, (int32_t*)h.in[0].p, (int32_t*)h.in[1].p, (int32_t*)h.in[2].p,
-                              h.din[3] ? (uint64_t*)h.in[3].p : nullptr, (uint8_t*)h.out[0].p, (int32_t*)h.out[1].p,
-                              (int32_t*)h.out[2].p, (int32_t*)h.out[3].p);
-  }
-  h.launched = true;
-  if (rc) {
-    ctx->carry.nblk = 0;
-    (void)hipStreamSynchronize(ctx->stream);
-    return rc;
-  }
-  if (ctx->carry.nblk) {  // the launch took a shape that carries nothing (target masks, a tiny batch): the copies by themselves
-    hipLaunchKernelGGL(k_stage8, dim3(ctx->carry.nblk), dim3(256), 0, ctx->stream, ctx->carry);
-    ctx->carry.nblk = 0;
-  } else {
-    ++ctx->host_carried;
-  }
-  hipLaunchKernelGGL(k_status_snap, dim3(1), dim3(64), 0, ctx->stream, ctx->st.status, h.status_dev);
-  if (out_prev) {
-    HIPCHK(ctx, hipEventRecord(out_prev->done, ctx->stream));
-    out_prev->out_enqueued = true;
-  }
-  return launch_check(ctx);
-}
-
-// the newest launched call whose records are not on their way yet (at most one), or null
-HostSlot* host_unsent(fpx_ctx* ctx) {
-  if (ctx->host_last < 0) return nullptr;
-  HostSlot& h = ctx->hslots[ctx->host_last];
-  return (h.busy && h.launched && !h.out_enqueued) ? &h : nullptr;
-}
-
-// everything submitted is launched and every launched call's records are on their way (called by every other entry point
-// of the context before it touches the stream or the state, and by wait)
-int host_flush(fpx_ctx* ctx) {
-  if (!ctx->hslots || ctx->in_host) return FPX_OK;
-  struct In {
-    fpx_ctx* c;
-    ~In() { c->in_host = false; }
-  } _in{ctx};
-  ctx->in_host = true;
-  int rc = FPX_OK;
-  if (ctx->host_pending >= 0) {
-    const int p = ctx->host_pending;
-    ctx->host_pending = -1;
-    rc = host_launch(ctx, p, nullptr, host_unsent(ctx));
-    ctx->host_last = p;
-    if (rc) return rc;
-  }
-  if (HostSlot* u = host_unsent(ctx)) rc = host_stage_alone(ctx, nullptr, u);
-  return rc;
-}
-
-// submit: the call's arrays are noted and its inputs start their way up -- in the vote kernel of the call submitted before
-// it (launched now), or by themselves when there is none.  Every array must be mapped host memory (FPX_EINVAL otherwise).
 int host_submit(fpx_ctx* ctx, int n, const int32_t* slot, const int32_t* round, const int32_t* value_id,
                 const uint64_t* target_mask, uint8_t* chosen, int32_t* chosen_round, int32_t* chosen_value,
                 int32_t* nack_round, int* ticket) {
   const void* in[4] = {slot, round, value_id, target_mask};
   void* out[4] = {chosen, chosen_round, chosen_value, nack_round};
-  const void* din[4];
   void* dout[4];
   for (int a = 0; a < 4; ++a) {
-    din[a] = mapped_host(in[a]), dout[a] = mapped_host(out[a]);
-    if ((in[a] && !din[a]) || (out[a] && !dout[a])) return FPX_EINVAL;
+    dout[a] = mapped_host(out[a]);
+    if ((in[a] && !mapped_host(in[a])) || (out[a] && !dout[a])) return FPX_EINVAL;
   }
   if (!ctx->hslots) {
     ctx->hslots = new (std::nothrow) HostSlot[HOST_DEPTH];
@@ -1303,86 +1169,45 @@ int host_submit(fpx_ctx* ctx, int n, const int32_t* slot, const int32_t* round, 
     if (!ctx->hslots[(ctx->hnext + k) % HOST_DEPTH].busy) t = (ctx->hnext + k) % HOST_DEPTH;
   if (t < 0) return FPX_ECAPACITY;  // HOST_DEPTH calls in flight: wait for the oldest first
   HostSlot& h = ctx->hslots[t];
-  if (!h.done) {
+  if (!h.up) {
+    HIPCHK(ctx, hipEventCreateWithFlags(&h.up, hipEventDisableTiming));
     HIPCHK(ctx, hipEventCreateWithFlags(&h.done, hipEventDisableTiming));
     HIPCHK(ctx, hipHostMalloc((void**)&h.status, 64, hipHostMallocDefault));
     HIPCHK(ctx, hipHostGetDevicePointer((void**)&h.status_dev, h.status, 0));
-    HIPCHK(ctx, hipMalloc((void**)&h.ctr_dev, 64));
-    HIPCHK(ctx, hipMemsetAsync(h.ctr_dev, 0, 64, ctx->stream));
   }
-  const size_t in_elem[4] = {4, 4, 4, 32}, out_elem[4] = {1, 4, 4, 4};
+  if (!ctx->up_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+  const size_t in_elem[4] = {4, 4, 4, 32};
   int rc;
-  for (int a = 0; a < 4; ++a) {
+  for (int a = 0; a < 4; ++a)
     if (in[a] && (rc = grow(ctx, &h.in[a], (size_t)n * in_elem[a]))) return rc;
-    if ((rc = grow(ctx, &h.out[a], (size_t)n * out_elem[a]))) return rc;
-    h.din[a] = din[a], h.dout[a] = dout[a], h.hin[a] = in[a], h.hout[a] = out[a];
-  }
-  h.n = n, h.launched = false, h.out_enqueued = false;
-  memset(h.status, 0, 32);
-  if (++ctx->host_seq <= 0) ctx->host_seq = 1;
-  h.seq = ctx->host_seq;
-  struct In {
-    fpx_ctx* c;
-    ~In() { c->in_host = false; }
-  } _in{ctx};
-  ctx->in_host = true;
-  if (host_mode() == HOST_COPY_ENGINES) {
-    // The transfers by the copy engines on two streams of their own, the call's fused step at once on the context's:
-    // engines reach host memory through the fabric, not through the shader L2 whose queues the vote kernel fills
-    // (profiles/r06_host_path.md: copies by WORKGROUPS beside a saturating vote kernel slowed it by 14 - 50 %, the more
-    // requests they kept in flight the worse).  One engine moves ~25 GB/s: 12.6 MB up in 0.5 ms, 9.4 MB down in 0.38 ms,
-    // both under the 0.55 ms fused step of the neighbouring call.
-    if (!h.up) {
-      HIPCHK(ctx, hipEventCreateWithFlags(&h.up, hipEventDisableTiming));
-      HIPCHK(ctx, hipEventCreateWithFlags(&h.k3, hipEventDisableTiming));
+  const size_t out_elem[3] = {1, 4, 4};
+  for (int a = 0; a < 3; ++a)
+    if (!dout[a]) {  // (nack_round alone may be null for the vote kernel)
+      if ((rc = grow(ctx, &h.sink[a], (size_t)n * out_elem[a]))) return rc;
+      dout[a] = h.sink[a].p;
     }
-    if (!ctx->up_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
-    if (!ctx->down_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
-    for (int a = 0; a < 4; ++a)
-      if (in[a]) HIPCHK(ctx, hipMemcpyAsync(h.in[a].p, in[a], (size_t)n * in_elem[a], hipMemcpyHostToDevice, ctx->up_stream));
-    HIPCHK(ctx, hipEventRecord(h.up, ctx->up_stream));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, h.up, 0));
-    fill_stage(&ctx->carry, nullptr, nullptr);
-    {
-      struct Guard {
-        fpx_ctx* c;
-        ~Guard() { c->force_validate = false; }
-      } _g{ctx};
-      ctx->force_validate = true;  // also under FPX_F_TRUSTED: that flag is a promise about _dev batches only
-      rc = fpx_phase2_fused_dev(ctx, n, (int32_t*)h.in[0].p, (int32_t*)h.in[1].p, (int32_t*)h.in[2].p,
-                                target_mask ? (uint64_t*)h.in[3].p : nullptr, (uint8_t*)h.out[0].p, (int32_t*)h.out[1].p,
-                                (int32_t*)h.out[2].p, (int32_t*)h.out[3].p);
-    }
-    if (rc) {
-      (void)hipStreamSynchronize(ctx->stream);
-      return rc;
-    }
-    hipLaunchKernelGGL(k_status_snap, dim3(1), dim3(64), 0, ctx->stream, ctx->st.status, h.status_dev);
-    HIPCHK(ctx, hipEventRecord(h.k3, ctx->stream));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->down_stream, h.k3, 0));
-    for (int a = 0; a < 4; ++a)
-      if (out[a]) HIPCHK(ctx, hipMemcpyAsync(out[a], h.out[a].p, (size_t)n * out_elem[a], hipMemcpyDeviceToHost, ctx->down_stream));
-    HIPCHK(ctx, hipEventRecord(h.done, ctx->down_stream));
-    if ((rc = launch_check(ctx))) return rc;
-    h.launched = true, h.out_enqueued = true, h.by_flag = false, h.busy = true;
-    ctx->hnext = (t + 1) % HOST_DEPTH;
-    *ticket = t;
-    return FPX_OK;
+  for (int a = 0; a < 4; ++a)
+    if (in[a]) HIPCHK(ctx, hipMemcpyAsync(h.in[a].p, in[a], (size_t)n * in_elem[a], hipMemcpyHostToDevice, ctx->up_stream));
+  HIPCHK(ctx, hipEventRecord(h.up, ctx->up_stream));
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, h.up, 0));
+  {
+    struct Guard {
+      fpx_ctx* c;
+      ~Guard() { c->force_validate = false; }
+    } _g{ctx};
+    ctx->force_validate = true;  // also under FPX_F_TRUSTED: that flag is a promise about _dev batches only
+    rc = fpx_phase2_fused_dev(ctx, n, (int32_t*)h.in[0].p, (int32_t*)h.in[1].p, (int32_t*)h.in[2].p,
+                              target_mask ? (uint64_t*)h.in[3].p : nullptr, (uint8_t*)dout[0], (int32_t*)dout[1],
+                              (int32_t*)dout[2], (int32_t*)dout[3]);
   }
-  h.by_flag = true;
-  if (ctx->host_pending >= 0) {
-    // the call submitted before this one runs now: its vote kernel carries this call's inputs up and the records of the
-    // call before it down
-    const int p = ctx->host_pending;
-    ctx->host_pending = -1;
-    rc = host_launch(ctx, p, &h, host_unsent(ctx));
-    ctx->host_last = p;
-  } else {
-    rc = host_stage_alone(ctx, &h, host_unsent(ctx));
+  if (rc) {
+    (void)hipStreamSynchronize(ctx->stream);
+    return rc;
   }
-  if (rc) return rc;
-  h.busy = true;
-  ctx->host_pending = t;
+  hipLaunchKernelGGL(k_status_snap, dim3(1), dim3(64), 0, ctx->stream, ctx->st.status, h.status_dev);
+  HIPCHK(ctx, hipEventRecord(h.done, ctx->stream));
+  if ((rc = launch_check(ctx))) return rc;
+  h.busy = true, h.n = n;
   ctx->hnext = (t + 1) % HOST_DEPTH;
   *ticket = t;
   return FPX_OK;
@@ -1393,56 +1218,15 @@ int host_submit(fpx_ctx* ctx, int n, const int32_t* slot, const int32_t* round, 
 int host_wait(fpx_ctx* ctx, int ticket) {
   if (!ctx->hslots || ticket < 0 || ticket >= HOST_DEPTH || !ctx->hslots[ticket].busy) return FPX_EINVAL;
   HostSlot& h = ctx->hslots[ticket];
-  if (!h.launched || !h.out_enqueued) {
-    // the steady state never comes here: with calls submitted ahead, this call's records left in the launch of the call
-    // after it.  Otherwise: launch what is pending, send what is unsent
-    const int rc = host_flush(ctx);
-    if (rc) {
-      h.busy = false;
-      return rc;
-    }
-  }
-  // The records are there when the last out-workgroup has raised the call's word -- usually a third of the way into the
-  // vote kernel that carries them.  The event behind that kernel is the fallback (and the answer if the launch failed).
-  if (!h.by_flag) {
-    const hipError_t e = hipEventSynchronize(h.done);
-    if (e != hipSuccess) {
-      h.busy = false;
-      ctx->last_hip = (int)e;
-      return FPX_EHIP;
-    }
-  } else {
-    volatile int32_t* flag = h.status + 8;
-    bool seen = false;
-    for (long spin = 0; spin < 400000000L && !seen; ++spin) {
-      if (*flag == h.seq) seen = true;
-      else if ((spin & 0x3fff) == 0x3fff && hipEventQuery(h.done) != hipErrorNotReady) break;  // finished, or failed
-    }
-    if (!seen) {
-      const hipError_t e = hipEventSynchronize(h.done);
-      if (e != hipSuccess) {
-        h.busy = false;
-        ctx->last_hip = (int)e;
-        return FPX_EHIP;
-      }
-      if (*flag != h.seq) {
-        h.busy = false;
-        return FPX_EHIP;
-      }
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
-  }
+  const hipError_t e = hipEventSynchronize(h.done);
   h.busy = false;
+  if (e != hipSuccess) {
+    ctx->last_hip = (int)e;
+    return FPX_EHIP;
+  }
   const int st = h.status[0];
   if (st != 0) {
     // drain and clear the sticky status (the calls behind this one have aborted too and report it from their own copy)
-    (void)host_flush(ctx);
-    struct In {
-      fpx_ctx* c;
-      bool was;
-      ~In() { c->in_host = was; }
-    } _in{ctx, ctx->in_host};
-    ctx->in_host = true;
     const int now = fetch_status(ctx);
     if (now == 0) ctx->err_index = h.status[ST_INDEX], ctx->err_slot = h.status[ST_SLOT], ctx->err_round = h.status[ST_ROUND];
   }
@@ -1790,8 +1574,6 @@ int32_t fpx_placement_stats(fpx_ctx* ctx, float out[5]) {
   return FPX_OK;
 }
 
-int64_t fpx_host_carried_launches(fpx_ctx* ctx) { return ctx ? ctx->host_carried : 0; }
-
 int32_t fpx_placement_search(fpx_ctx* ctx, int32_t* probes, int32_t* unprobed, float* ms) {
   if (!ctx) return FPX_EINVAL;
   if (probes) *probes = ctx->placement_probes;
@@ -2029,8 +1811,7 @@ int32_t fpx_phase2_fused(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int
 int32_t fpx_phase2_fused_submit(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round, const int32_t* value_id,
                                 const uint64_t* target_mask, uint8_t* chosen, int32_t* chosen_round, int32_t* chosen_value,
                                 int32_t* nack_round, int32_t* ticket) {
-  if (!ctx) return FPX_EINVAL;
-  DeviceGuard _dg(ctx->cfg.device);  // (by device number: the pipeline's own entry points do not flush it)
+  DeviceGuard _dg(ctx);
   int rc = check_args(ctx, n, slot, round);
   if (rc) return rc;
   if (n == 0 || !value_id || !ticket) return FPX_EINVAL;
@@ -2041,8 +1822,8 @@ int32_t fpx_phase2_fused_submit(fpx_ctx* ctx, int32_t n, const int32_t* slot, co
 }
 
 int32_t fpx_phase2_fused_wait(fpx_ctx* ctx, int32_t ticket) {
+  DeviceGuard _dg(ctx);
   if (!ctx) return FPX_EINVAL;
-  DeviceGuard _dg(ctx->cfg.device);
   return host_wait(ctx, ticket);
 }
 

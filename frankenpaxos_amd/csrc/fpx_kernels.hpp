@@ -490,96 +490,11 @@ struct WaveOut<true> {     // K3: only the chosen flags are staged; bitmaps stay
 #undef FPX_P2_BID
 #undef FPX_P2_PROLOGUE
 
-// ---- the host path's staging inside the vote kernel's grid (round 6; fpx_phase2_fused_submit / _wait) ------------------
-// A call on page-locked host arrays moves 12 B per slot up (slot, round, value) and 9 B per slot down (Chosen records).
-// Rounds 2 - 5 did that with a 64-workgroup staging kernel per direction on streams of their own, beside the vote kernel.
-// profiles/r06_host_path.md: a kernel on another stream does not START while an 8192-workgroup vote kernel saturates the
-// chip (it got its first workgroup 140 - 220 us late, usually when the vote kernel had drained), then ran beside the NEXT
-// call's validation and vote kernel, whose dispatch it delayed by ~50 us -- 0.78 - 0.81 ms per call where the fused step
-// alone takes 0.55.  Here the copies are the first `nblk` workgroups of the vote kernel's own grid: the stage-in of the
-// NEXT call and the stage-out of the PREVIOUS one ride in the vote kernel of this one.  One stream, no events, no second
-// queue; they start with the launch and are done long before it ends (12.6 + 9.4 MB over a ~55 GB/s link).
-struct HostStage {
-  const void* src[8];          // [0..3] the next call's inputs (mapped host memory), [4..7] the previous call's records (HBM)
-  void* dst[8];
-  unsigned long long bytes[8];
-  int nblk;                    // workgroups that copy (0: none) = nblk_in + nblk_out
-  int nblk_in, nblk_out;       // ... the two directions on workgroups of their own: the link is full duplex
-  unsigned int* out_ctr;       // device word: out-workgroups that are done (the last one resets it)
-  volatile int32_t* out_flag;  // mapped host word: = out_seq once every record of the previous call is in the caller's arrays
-  int32_t out_seq;
-};
-// `nth` threads (this one is `tid`) copy the job's arrays [a0, a1).  Eight 16-byte loads in flight per thread: copies that
-// share the chip with a saturating vote kernel see every access queue behind its rows (profiles/r06_host_path.md: the same
-// copies took 0.74 ms with 64 workgroups x 4 loads in flight), so the link is kept full by requests in flight, not threads.
-__device__ __forceinline__ void stage_arrays(const HostStage& j, int a0, int a1, size_t tid, size_t nth) {
-#pragma unroll 1
-  for (int a = a0; a < a1; ++a) {
-    const size_t bytes = j.bytes[a];
-    if (!bytes) continue;
-    const unsigned char* sb = reinterpret_cast<const unsigned char*>(j.src[a]);
-    unsigned char* db = reinterpret_cast<unsigned char*>(j.dst[a]);
-    if (((reinterpret_cast<uintptr_t>(sb) | reinterpret_cast<uintptr_t>(db)) & 15u) == 0) {
-      const int4* s = reinterpret_cast<const int4*>(sb);
-      int4* d = reinterpret_cast<int4*>(db);
-      const size_t n16 = bytes >> 4;
-      size_t i = tid;
-      for (; i + 7 * nth < n16; i += 8 * nth) {
-        int4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = s[i + u * nth];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) d[i + u * nth] = v[u];
-      }
-      for (; i < n16; i += nth) d[i] = s[i];
-      for (size_t q = (n16 << 4) + tid; q < bytes; q += nth) db[q] = sb[q];
-    } else {
-      for (size_t q = tid; q < bytes; q += nth) db[q] = sb[q];
-    }
-  }
-}
-__device__ __forceinline__ void stage_body(const HostStage& j, int bid) {
-  if (bid < j.nblk_in) {
-    stage_arrays(j, 0, 4, (size_t)bid * blockDim.x + threadIdx.x, (size_t)j.nblk_in * blockDim.x);
-    return;
-  }
-  stage_arrays(j, 4, 8, (size_t)(bid - j.nblk_in) * blockDim.x + threadIdx.x, (size_t)j.nblk_out * blockDim.x);
-  // the records are in the caller's arrays when the LAST out-workgroup says so: the host waits for this word, not for the
-  // end of the vote kernel the copies ride in (waiting for the kernel let the GPU idle for a host round trip per call)
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0 && j.out_flag) {
-    const unsigned int before = __hip_atomic_fetch_add(j.out_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (before + 1u == (unsigned int)j.nblk_out) {
-      __hip_atomic_store(j.out_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence_system();
-      *j.out_flag = j.out_seq;
-      __threadfence_system();
-    }
-  }
-}
-// the copies alone (the first call of a burst has no vote kernel to ride in, the last one's records none to ride out in)
-__global__ void __launch_bounds__(256) k_stage8(const HostStage j) { stage_body(j, blockIdx.x); }
-// the device's status words as call k left them, into the call's page-locked words (what fpx_phase2_fused_wait reports)
+// the device's status words as a host-path call left them, into the call's page-locked words (what
+// fpx_phase2_fused_wait reports): a 32-byte posted write instead of a copy-engine packet on the compute stream
 __global__ void __launch_bounds__(64) k_status_snap(const int32_t* status, int32_t* out) {
   if (threadIdx.x < 8) out[threadIdx.x] = status[threadIdx.x];
 }
-
-#define FPX_P2_NAME k_phase2_host
-#define FPX_P2_EXTRA_PARAMS , const HostStage hs
-#define FPX_P2_NBLK (gridDim.x - hs.nblk)
-#define FPX_P2_BID (blockIdx.x - hs.nblk)
-#define FPX_P2_PROLOGUE                              \
-  if ((int)blockIdx.x < hs.nblk) {                   \
-    stage_body(hs, (int)blockIdx.x);                 \
-    return;                                          \
-  }
-#include "fpx_phase2_body.inc"
-#undef FPX_P2_NAME
-#undef FPX_P2_EXTRA_PARAMS
-#undef FPX_P2_NBLK
-#undef FPX_P2_BID
-#undef FPX_P2_PROLOGUE
 
 // ------------------------------------------------------------------------------------------------
 // k_finalize: promised[e] = max(promised[e], max_b part[b][0][e]); max_voted likewise.

@@ -321,13 +321,11 @@ int32_t fpx_phase2_fused(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int
 /* The same, asynchronous, for batches in PAGE-LOCKED host memory (fpx_host_alloc or any memory mapped into the GPU's
  * address space -- FPX_EINVAL otherwise): submit returns at once with a ticket, wait(ticket) blocks until that call's
  * outputs are in the caller's arrays and returns its status.  Up to 3 calls may be in flight (FPX_ECAPACITY: wait for
- * the oldest first); they execute in submission order.  The PCIe transfers are copies by the GPU itself (a staging
- * kernel's accesses to the mapped arrays, not a copy engine), and since round 6 they are workgroups of the fused step's
- * own launch: the vote kernel of call k carries the inputs of call k + 1 up and the Chosen records of call k - 1 down, on
- * ONE stream (profiles/r06_host_path.md: copies on streams of their own did not start while a vote kernel saturated the
- * chip).  The fused step of a call is therefore launched when the NEXT call is submitted -- or when somebody waits for it,
- * or when any other entry point of the context is called, which first launches what is pending: the deferral is not
- * observable through this ABI.  With calls submitted back to back the transfers cost nothing beside the fused step:
+ * the oldest first); they execute in submission order.  The inputs go up by the copy engine on a stream of their own
+ * into staging buffers in HBM; validation and the fused step follow on the context's stream; the vote kernel writes the
+ * Chosen records (and Nack rounds) STRAIGHT into the caller's page-locked arrays -- there is no copy down.  With calls
+ * submitted back to back the upload of call k + 1 hides behind the fused step of call k, which runs ~3 % longer for its
+ * posted writes over PCIe (profiles/r06_host_path.md has what every other way of crossing PCIe cost the vote kernel);
  * see profiles/r06_host_path.md for the rate per 2^20 x 256 call.  A call must be ONE device run (the run
  * contract above): a violation is FPX_EORDER from wait with nothing applied -- pass that batch to fpx_phase2_fused,
  * which cuts it into runs.  After an error the calls queued behind the failed one have applied nothing either and
@@ -409,9 +407,6 @@ int32_t fpx_mencius_band_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slo
                                    uint64_t* d_range_vote_bits, uint64_t* d_range_nack_bits,
                                    int32_t* d_range_nack_round, uint8_t* d_range_is_new, uint8_t* d_range_chosen,
                                    int32_t independent);
-/* diagnostic: the fused steps of fpx_phase2_fused_submit calls whose launch carried their neighbours' PCIe copies in its
- * own grid since fpx_create (the others -- target masks, tiny batches -- ran the copies as a kernel of their own) */
-int64_t fpx_host_carried_launches(fpx_ctx* ctx);
 /* diagnostic: the steps of fpx_mencius_band_fused_dev that ran in the two-launch form since fpx_create */
 int64_t fpx_band_merged_steps(fpx_ctx* ctx);
 /* batches of one (bitmaps num_groups x 4 words) */
