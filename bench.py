@@ -328,6 +328,115 @@ def run_with_deadline(fn, seconds, dev):
     return box.get("value"), False
 
 
+def preflight(args, fa, dist, backend, dev, rank, world, local_rank, all_reduce):
+    """what the first real multi-GPU run exercises for the first time, on its own and under
+    deadlines -- N ranks creating headline-sized contexts at once (the placement search of every rank probing beside the
+    others), ncclCommInitRank behind fpx_comm_create, one replica-sharded step (K1 -> reduce-scatter of the vote bitmaps ->
+    all-reduce(max) of the Nack rounds -> K2) and one all-gather of Chosen records.  Every rank reports; rank 0 prints ONE
+    line; a rank that does not answer in time makes the line say so and the process leave with status 1."""
+    out = {"rank": rank}
+    t0 = time.perf_counter()
+
+    def make():
+        R_local = REPLICAS // world
+        c = fa.Context(fa.make_config(num_slots=2 * SLOTS_PER_STEP, num_replicas=R_local, f=F, quorum_kind=fa.FPX_Q_THRESHOLD,
+                                      ballot_mode=fa.FPX_BALLOT_PER_SLOT, tally_ways=4, device=local_rank, flags=fa.FPX_F_TRUSTED,
+                                      replica_base=rank * R_local, replicas_total=REPLICAS))
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        return c
+    # (a context of the full 256 acceptors first: 6 GiB of cells, the shape whose slab is placed by measurement)
+    def make_full():
+        c = fa.Context(fa.make_config(num_slots=2 * SLOTS_PER_STEP, num_replicas=REPLICAS, f=F, ballot_mode=fa.FPX_BALLOT_PER_SLOT,
+                                      tally_ways=4, device=local_rank, flags=fa.FPX_F_TRUSTED))
+        st = c.placement_stats()
+        c.close()
+        return st
+    st, hung = run_with_deadline(make_full, args.comm_deadline, dev)
+    out["create_full_s"] = time.perf_counter() - t0
+    if hung or (isinstance(st, dict) and "error" in st):
+        out["error"] = "fpx_create: %s" % st.get("error")
+    else:
+        out["placement"] = {"chunks": st["chunks"], "windows": st["windows"], "search_ms": st["search"]["ms"],
+                            "probes": st["search"]["probes"], "unprobed_decisions": st["search"]["unprobed_decisions"]}
+    ctx = None
+    if "error" not in out:
+        t1 = time.perf_counter()
+        ctx, hung = run_with_deadline(make, args.comm_deadline, dev)
+        if hung or isinstance(ctx, dict):
+            out["error"] = "fpx_create (sharded): %s" % (ctx.get("error") if isinstance(ctx, dict) else "?")
+            ctx = None
+        out["create_sharded_s"] = time.perf_counter() - t1
+    if ctx is not None:
+        t2 = time.perf_counter()
+        res, hung = run_with_deadline(lambda: setup_comm(fa, ctx, dist, backend, dev, rank, world), args.comm_deadline, dev)
+        out["comm_create_s"] = time.perf_counter() - t2
+        if hung or isinstance(res, dict):
+            out["error"] = "fpx_comm_create: %s" % (res.get("error") if isinstance(res, dict) else "no answer")
+        elif res:
+            def one_step():
+                from frankenpaxos_amd import sharding
+                assert ctx.acceptor_phase1a(0, 0)[0] == 0
+                ctx.flush_promises()
+                lo, hi = sharding.slot_slice(SLOTS_PER_STEP, world, rank)
+                slot = torch.arange(0, SLOTS_PER_STEP, dtype=torch.int32, device=dev)
+                val = steady_values_torch(slot)
+                ch = torch.zeros(hi - lo, dtype=torch.uint8, device=dev)
+                cr = torch.full((hi - lo,), -7, dtype=torch.int32, device=dev)
+                cv = torch.full((hi - lo,), -7, dtype=torch.int32, device=dev)
+                ctx.profile_enable(True)
+                ctx.phase2_replica_sharded_dev(slot, torch.zeros_like(slot), val, None, ch, cr, cv)
+                assert ctx.sync() == 0
+                n, ms = ctx.profile_read_collective()
+                ok = bool(ch.all()) and bool((cv == val[lo:hi]).all()) and bool((cr == 0).all())
+                alls = [torch.zeros((SLOTS_PER_STEP,), dtype=t.dtype, device=dev) for t in (ch, cr, cv)]
+                equal = hi - lo == SLOTS_PER_STEP // world
+                if equal:
+                    ctx.comm_allgather_chosen_dev(ch, cr, cv, *alls)
+                    assert ctx.sync() == 0
+                    ok = ok and bool(alls[0].all()) and bool((alls[2] == val).all())
+                return {"step_ok": ok, "collective_ms": ms / max(n, 1), "allgather_checked": equal, "rccl_ranks": ctx.comm_info()[1]}
+            res2, hung = run_with_deadline(one_step, args.comm_deadline, dev)
+            if hung or "error" in res2:
+                out["error"] = "replica-sharded step: %s" % res2.get("error")
+            else:
+                out.update(res2)
+        else:
+            out["rccl_ranks"] = 0   # (gloo test hook without FPX_BENCH_FPX_COMM: no communicator to test)
+    # the ranks' reports meet on rank 0 over the control plane (gloo objects; under nccl through a byte tensor)
+    reports = [None] * world
+    def gather():
+        if backend == "nccl":
+            blob = json.dumps(out).encode()
+            buf = torch.zeros(4096, dtype=torch.uint8, device=dev)
+            buf[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+            allb = [torch.zeros_like(buf) for _ in range(world)]
+            dist.all_gather(allb, buf)
+            return [json.loads(bytes(b.cpu().numpy().tobytes()).rstrip(b"\0").decode()) for b in allb]
+        objs = [None] * world
+        dist.all_gather_object(objs, out)
+        return objs
+    got, hung = run_with_deadline(gather, 60, dev)
+    if hung or isinstance(got, dict):
+        reports = [out]
+        out.setdefault("error", "the ranks' reports did not meet: %s" % (got.get("error") if isinstance(got, dict) else "?"))
+    else:
+        reports = got
+    ok = all("error" not in r and r.get("step_ok", backend != "nccl") for r in reports)
+    if rank == 0:
+        print(json.dumps(round_floats({
+            "preflight": True, "ok": ok, "n_gpus": world, "backend": backend,
+            "rccl_ranks": min((r.get("rccl_ranks", 0) for r in reports), default=0),
+            "placement_search_ms_per_rank": [r.get("placement", {}).get("search_ms") for r in reports],
+            "placement_unprobed_decisions_per_rank": [r.get("placement", {}).get("unprobed_decisions") for r in reports],
+            "create_full_context_s_per_rank": [r.get("create_full_s") for r in reports],
+            "comm_create_s_per_rank": [r.get("comm_create_s") for r in reports],
+            "collective_ms_per_rank": [r.get("collective_ms") for r in reports],
+            "errors": {str(r["rank"]): r["error"] for r in reports if "error" in r},
+            "test_hooks": HOOKS_SET if TEST_HOOKS else None}, 5)), flush=True)
+    sys.stdout.flush()
+    os._exit(0 if ok else 1)   # (no teardown that could wait for a rank that is stuck)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -346,6 +455,12 @@ def main():
                          "headline and reported in the line's `configs` block (0 = leave the block out)")
     ap.add_argument("--replica-row-deadline", type=int, default=120,
                     help="seconds the extra replica-axis row may take before the line is printed without it")
+    ap.add_argument("--preflight", action="store_true",
+                    help="N > 1: do not run the bench; create a headline-sized context and an RCCL communicator on every rank "
+                         "under deadlines, run one replica-sharded step, and print per-rank placement / create / communicator "
+                         "times and the collective's event time as one JSON line (exit status 1 if any rank failed or hung)")
+    ap.add_argument("--comm-deadline", type=int, default=120,
+                    help="seconds fpx_comm_create may take on a rank before the run is given up (loudly, not hanging)")
     ap.add_argument("--test-hooks", action="store_true",
                     help="honour the FPX_BENCH_* test hooks of tests/test_bench_distributed.py (refused without this flag)")
     ap.add_argument("--replica-row-steps", type=int, default=5,
@@ -405,6 +520,11 @@ def main():
 
     import frankenpaxos_amd as fa
 
+    if args.preflight:
+        if world < 2:
+            raise SystemExit("bench.py --preflight is about N > 1 (--gpus N)")
+        preflight(args, fa, dist, backend, dev, rank, world, local_rank, all_reduce)
+
     if args.config != "headline":
         import bench_configs
         line = bench_configs.run(args, fa, dist, dev, rank, world, local_rank, all_reduce)
@@ -454,7 +574,16 @@ def main():
     if replica_shard:
         from frankenpaxos_amd import sharding
         lo, hi = sharding.slot_slice(SLOTS_PER_STEP, world, rank)
-        have_comm = setup_comm(fa, ctx, dist, backend, dev, rank, world)
+        # the communicator under a deadline: a rank that never comes back from ncclCommInitRank must not hang the job
+        res, stuck = run_with_deadline(lambda: setup_comm(fa, ctx, dist, backend, dev, rank, world), args.comm_deadline, dev)
+        if stuck or isinstance(res, dict):
+            sys.stderr.write("bench.py: rank %d: fpx_comm_create: %s -- giving up\n" % (rank, res.get("error") if isinstance(res, dict) else "?"))
+            sys.stderr.flush()
+            if rank == 0:
+                print(json.dumps({"metric": METRIC, "value": None, "n_gpus": world, "error": "fpx_comm_create on rank %d: %s" %
+                                  (rank, res.get("error") if isinstance(res, dict) else "?")}), flush=True)
+            os._exit(2)
+        have_comm = bool(res)
         if not have_comm:   # gloo test hook only: the exchange through torch.distributed on the host
             vb = torch.empty((SLOTS_PER_STEP, 4), dtype=torch.int64, device=dev)
             vb_mine = torch.empty((hi - lo, 4), dtype=torch.int64, device=dev)
@@ -644,7 +773,9 @@ def main():
                 # how fpx_create placed the cell arrays (profiles/r05_placement.md): chunks paired by measurement, and the hot
                 # access pattern's time on half a window, min / median / max over the windows
                 "placement": {"chunks_paired_by_measurement": placement["chunks"], "windows": placement["windows"],
-                              "probe_ms_min_median_max": list(placement["probe_ms"])},
+                              "probe_ms_min_median_max": list(placement["probe_ms"]),
+                              "search_ms": placement["search"]["ms"], "probes": placement["search"]["probes"],
+                              "unprobed_decisions": placement["search"]["unprobed_decisions"]},
                 "steps_reproposing_old_slots": sum(1 for i in range(Wm, Wm + K) if i // windows > 0),
             },
             "roofline": {

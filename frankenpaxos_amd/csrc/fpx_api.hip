@@ -267,9 +267,11 @@ size_t lds_bytes(const fpx_ctx* ctx, bool fused, bool targets) {
 // walking 32 dependent steps each on a machine with room for 6000
 int chunk_for(const fpx_ctx* ctx, int n) {
   if (ctx->lanes_per_slot != 64) return 64;
-  const long long want_waves = (long long)ctx->num_cus * 16;
+  static const int min_chunk = [] { const char* e = getenv("FPX_MIN_CHUNK"); return e ? std::max(1, atoi(e)) : 4; }();
+  static const int waves_per_cu = [] { const char* e = getenv("FPX_WANT_WAVES_PER_CU"); return e ? std::max(1, atoi(e)) : 16; }();
+  const long long want_waves = (long long)ctx->num_cus * waves_per_cu;
   int ch = FPX_CHUNK;
-  while (ch > 4 && (long long)(n + ch - 1) / ch < want_waves) ch >>= 1;
+  while (ch > min_chunk && (long long)(n + ch - 1) / ch < want_waves) ch >>= 1;
   return ch;
 }
 

@@ -172,3 +172,29 @@ def test_eight_rank_lines_through_the_library_communicator(shard):
     else:
         assert d["scaling"] == "strong" and d["collective"]["calls_timed"] == 2 and d["collective"]["avg_ms"] > 0
         assert abs(d["value"] * d["ms_per_step"] * 1e-3 - n) < 1e-3 * n
+
+
+def test_preflight_of_the_first_multi_gpu_run():
+    """`bench.py --gpus 8 --preflight` -- eight ranks creating headline-shaped contexts at once (their
+    placement searches probing one device together, each within its budget), fpx_comm_create under a deadline, one
+    replica-sharded step and one all-gather through the library's collectives (the RCCL double: the ranks share cuda:0),
+    every rank's times in ONE line, exit status 0; and a communicator that cannot come up (the double pointed at a file
+    that is no library) is reported with status != 0 instead of hanging"""
+    env = dict(os.environ, FPX_BENCH_SHARE_GPU="1", FPX_BENCH_BACKEND="gloo", FPX_BENCH_FPX_COMM="1", FPX_RCCL_LIB=_double())
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--test-hooks", "--gpus", "8", "--preflight"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["preflight"] and d["ok"] and d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and not d["errors"], d
+    assert len(d["placement_search_ms_per_rank"]) == 8 and all(0 < x < 5000 for x in d["placement_search_ms_per_rank"]), d
+    assert all(x > 0 for x in d["collective_ms_per_rank"]) and all(0 < x < 60 for x in d["comm_create_s_per_rank"]), d
+    env["FPX_RCCL_LIB"] = os.path.join(ROOT, "README.md")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--test-hooks", "--gpus", "2", "--preflight", "--comm-deadline", "20"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and out.returncode != 0, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert not d["ok"] and d["errors"], d
