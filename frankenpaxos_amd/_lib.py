@@ -129,6 +129,7 @@ SIGNATURES = {
     "fpx_epx_preaccept_packed_dev": (C.c_int32, [VP, C.c_int32] + [VP] * 9),
     "fpx_epx_packed_stride": (C.c_int32, [C.c_int32]),
     "fpx_epx_execute_dev": (C.c_int32, [VP, C.c_int32] + [VP] * 11),
+    "fpx_epx_execute": (C.c_int32, [VP, C.c_int32] + [VP] * 12),
     "fpx_epx_handle_prepare_oks": (C.c_int32, [VP, C.c_int32] + [VP] * 8 + [C.c_int32] + [VP] * 3),
     "fpx_epx_prepare": (C.c_int32, [VP, C.c_int32] + [VP] * 12),
     "fpx_epx_accept": (C.c_int32, [VP, C.c_int32] + [VP] * 13),

@@ -65,6 +65,21 @@ struct DpArgs {
   int32_t* comp;
 };
 
+// The gathers of a closure round (and of the cycle test) read rows of OTHER vertices: the prefix row just below each of a
+// vertex's n watermarks.  Neighbouring vertices of a column were proposed at neighbouring times, so their watermarks point
+// at neighbouring rows of every column -- a window of a few thousand rows per column that slides along with the vertices.
+// Workgroups are dealt round-robin to the 8 XCDs (each with an L2 of its own): with workgroup b on vertices 256 b .. the
+// 256 workgroups resident on one XCD sat 8 blocks apart, their windows covered half of every column (20 MB against a 4 MB
+// L2) and every 64-byte line of `lp` came from HBM ~17 times per round (280 MB read per round for a 16 MB array,
+// profiles/r06_cfg_pmc.md).  Here the workgroups of one XCD take CONSECUTIVE blocks: an XCD works its way through one
+// eighth of the vertices and its resident workgroups' windows overlap (profiles/r06_depgraph_dev.md).  Placement is a
+// matter of speed only: any mapping of workgroups to XCDs gives the same result.
+__device__ __forceinline__ int dp_logical_block(int bid, int nblocks) {
+  const int per = (nblocks + 7) >> 3;
+  return (bid & 7) * per + (bid >> 3);  // (may be >= nblocks: the caller leaves)
+}
+__host__ __device__ __forceinline__ int dp_grid(int nblocks) { return 8 * ((nblocks + 7) >> 3); }
+
 __device__ __forceinline__ int dp_col_of_block(const DpArgs& a, int n, int b) {
   int col = 0;
   while (col + 1 < n && b >= a.blk_base[col + 1]) ++col;
@@ -86,10 +101,14 @@ __global__ void __launch_bounds__(256) k_dp_scatter(const DpArgs a) {
     const int j = x - a.first[L];
     if (j >= 0 && j < a.count[L]) v = a.base[L] + j;
   }
-  if (v < 0 || atomicExch(&a.msg_of[v], i) != -1) {  // outside its column, or the instance twice
+  if (v < 0) {  // outside its column
     a.ctl[1] = 1;
     return;
   }
+  // (An instance handed in twice leaves another one of its column without a message -- the columns hold exactly m
+  // instances for m messages -- and k_dp_scan0 reports that one: no returning atomic per message is needed.  The plain
+  // store may race with the other copy's; either message's index is a valid owner for the error path that follows.)
+  a.msg_of[v] = i;
   const int32_t* line = a.packed + (size_t)i * a.stride;
   const bool committed = !a.mask || a.mask[i];
   int d[5] = {0, 0, 0, 0, 0};
@@ -136,8 +155,10 @@ __device__ __forceinline__ void dp_block_scan(int* c, int (*sh)[5], int* tot) {
 template <int N>
 __global__ void __launch_bounds__(256) k_dp_scan0(const DpArgs a) {
   __shared__ int sh[4][5];
-  const int col = dp_col_of_block(a, N, blockIdx.x);
-  const int j = ((int)blockIdx.x - a.blk_base[col]) * 256 + (int)threadIdx.x;
+  const int lb = dp_logical_block((int)blockIdx.x, a.nblocks);
+  if (lb >= a.nblocks) return;
+  const int col = dp_col_of_block(a, N, lb);
+  const int j = (lb - a.blk_base[col]) * 256 + (int)threadIdx.x;
   const bool live = j < a.count[col];
   const int v = a.base[col] + j;
   int c[5] = {0, 0, 0, 0, 0}, tot[5] = {0, 0, 0, 0, 0};
@@ -147,7 +168,7 @@ __global__ void __launch_bounds__(256) k_dp_scan0(const DpArgs a) {
   }
   dp_block_scan<N>(c, sh, tot);
   if (live) a.lp[0][v] = pk_pack(c);
-  if (threadIdx.x == 0) a.bt[0][blockIdx.x] = pk_pack(tot);
+  if (threadIdx.x == 0) a.bt[0][lb] = pk_pack(tot);
 }
 
 // cy[b] = max of bt over the workgroups of b's column before b: one workgroup per column
@@ -195,8 +216,10 @@ template <int N>
 __global__ void __launch_bounds__(256) k_dp_relax(const DpArgs a, int cur, int k) {
   __shared__ int sh[4][5];
   if (k > 1 && a.ctl[8 + k - 1] == 0) return;  // the round before moved nothing: lp / cy of both halves are final
-  const int col = dp_col_of_block(a, N, blockIdx.x);
-  const int j = ((int)blockIdx.x - a.blk_base[col]) * 256 + (int)threadIdx.x;
+  const int lb = dp_logical_block((int)blockIdx.x, a.nblocks);
+  if (lb >= a.nblocks) return;
+  const int col = dp_col_of_block(a, N, lb);
+  const int j = (lb - a.blk_base[col]) * 256 + (int)threadIdx.x;
   const bool live = j < a.count[col];
   const int v = a.base[col] + j;
   int c[5] = {0, 0, 0, 0, 0}, tot[5] = {0, 0, 0, 0, 0};
@@ -232,7 +255,7 @@ __global__ void __launch_bounds__(256) k_dp_relax(const DpArgs a, int cur, int k
   }
   dp_block_scan<N>(c, sh, tot);
   if (live) a.lp[cur ^ 1][v] = pk_pack(c);
-  if (threadIdx.x == 0) a.bt[cur ^ 1][blockIdx.x] = pk_pack(tot);
+  if (threadIdx.x == 0) a.bt[cur ^ 1][lb] = pk_pack(tot);
 }
 
 // the prefix max of column l below relative watermark w (w >= 1), from either half (both are final after the rounds)
@@ -247,7 +270,10 @@ __device__ __forceinline__ void dp_prefix(const DpArgs& a, int l, int w, int* ou
 template <int N>
 __global__ void __launch_bounds__(256) k_dp_keys(const DpArgs a) {
   __shared__ int block_eligible;
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  const int vblocks = (a.m + 255) >> 8;
+  const int lb = dp_logical_block((int)blockIdx.x, vblocks);
+  if (lb >= vblocks) return;
+  const int v = lb * 256 + (int)threadIdx.x;
   if (threadIdx.x == 0) block_eligible = 0;
   __syncthreads();
   bool eligible = false;
@@ -266,8 +292,11 @@ __global__ void __launch_bounds__(256) k_dp_keys(const DpArgs a) {
     }
     // on a cycle iff the closure of a direct dependency covers x in column L (asked of executable vertices only: one that
     // is not committed has "everything" in d[] and would walk the rest of its column)
+    // Every row the test gathers is the closure of something v reaches, so its column L lies below c[L]: a vertex whose own
+    // closure does not reach past itself in its column (c[L] <= x: nine in ten of a FIFO tick) is on no cycle and has no
+    // explicit ids to walk -- it asks nothing (79 -> ~25 us per 2^20 vertices, profiles/r06_depgraph_dev.md)
     int back = 0;
-    if (eligible) {
+    if (eligible && c[L] > x) {
 #pragma unroll
       for (int l = 0; l < N; ++l) {
         const int bound = l == L ? min(d[l], x) : d[l];  // own column: the prefix below x here, the explicit ids below
@@ -329,12 +358,15 @@ __global__ void __launch_bounds__(256) k_dp_emit(const DpArgs a) {
   uint32_t mine[DG_TILE / 256];
 #pragma unroll
   for (int j = 0; j < DG_TILE / 256; ++j) mine[j] = dp_starts(a, t0 + j * 256 + threadIdx.x, executables);
-  if (threadIdx.x == 0) {
+  {
+    // the components that start in the tiles before this one: 256 threads add up the tiles' counts (one thread walking up to
+    // 512 of them was ~10 us of the kernel)
     uint32_t s = 0;
-    for (int t = 0; t < (int)blockIdx.x; ++t) s += (uint32_t)a.tstarts[t];
-    before_tile = s;
+    for (int t = (int)threadIdx.x; t < (int)blockIdx.x; t += 256) s += (uint32_t)a.tstarts[t];
+    const uint32_t ex = block_excl_sum(s, sh);
+    if (threadIdx.x == 255) before_tile = ex + s;
+    __syncthreads();
   }
-  __syncthreads();
   uint32_t run = before_tile;
 #pragma unroll
   for (int j = 0; j < DG_TILE / 256; ++j) {
@@ -353,8 +385,18 @@ __global__ void __launch_bounds__(256) k_dp_emit(const DpArgs a) {
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a.ctl[4] = (int32_t)run;
 }
 
-__global__ void k_dp_publish(const DpArgs a) {
-  if (threadIdx.x < 7) a.host[threadIdx.x] = threadIdx.x == 5 ? a.ctl[8 + DG_ROUNDS] : a.ctl[threadIdx.x];
+// last_k: the rounds of the chunk that were enqueued.  [5] = the last of them still moved (another chunk is needed),
+// [6] = how many of them moved something (the next call enqueues one more than that: see dg_execute_packed)
+__global__ void k_dp_publish(const DpArgs a, int last_k) {
+  if (threadIdx.x < 7) {
+    int v = a.ctl[threadIdx.x];
+    if (threadIdx.x == 5) v = a.ctl[8 + last_k];
+    if (threadIdx.x == 6) {
+      v = 0;
+      for (int k = 1; k <= last_k; ++k) v += a.ctl[8 + k] != 0 ? 1 : 0;
+    }
+    a.host[threadIdx.x] = v;
+  }
   __threadfence_system();
   if (threadIdx.x == 0) a.host[7] = a.seq;
 }

@@ -1393,7 +1393,9 @@ struct fpx_epx {
   Buf p_fast, p_deps, p_ldeps, p_own;      // the four output arrays when a packed tick goes the first form's way
   Buf kp_hist, kp_recs, kp_misc;          // K5 second form (fpx_epaxos_kp.hpp)
   Buf dg_msg, dg_direct, dg_clo, dg_pre, dg_tmax, dg_pairs, dg_pairs2, dg_ctl, dg_key;  // device dependency-graph execution
+  Buf dgh_in, dgh_out;                    // fpx_epx_execute: the host arrays' stay on the device
   int32_t dg_seq = 0;
+  int dg_rounds_hint = 8;                 // closure rounds the first chunk of the next fpx_epx_execute_dev enqueues (DG_ROUNDS at first)
   uint32_t* kp_flag = nullptr;            // page-locked: [0] sequence number of the tick whose count [1] is valid
   uint32_t* kp_flag_dev = nullptr;
   uint32_t kp_seq = 0;
@@ -1657,20 +1659,25 @@ int dg_execute_packed(fpx_epx* e, int m, const int32_t* d_leader, const int32_t*
   EHIP(e, hipMemsetAsync(a.ctl, 0, 256, e->stream));
   const int grid = (m + 255) / 256;
   hipLaunchKernelGGL((k_dp_scatter<N>), dim3(grid), dim3(256), 0, e->stream, a);
-  hipLaunchKernelGGL((k_dp_scan0<N>), dim3(a.nblocks), dim3(256), 0, e->stream, a);
+  hipLaunchKernelGGL((k_dp_scan0<N>), dim3(dp_grid(a.nblocks)), dim3(256), 0, e->stream, a);
   hipLaunchKernelGGL((k_dp_carry<N>), dim3(N), dim3(1024), 0, e->stream, a, 0, 1);
   int cur = 0, executables = 0;
   for (int chunk = 0;; ++chunk) {
     if (chunk > 0) EHIP(e, hipMemsetAsync(a.ctl + 8, 0, (DG_ROUNDS + 1) * 4, e->stream));
-    for (int k = 1; k <= DG_ROUNDS; ++k) {
+    // How many rounds to enqueue: a round that finds "the one before moved nothing" leaves at its first instruction, but it
+    // is still a launch (and its carry kernel another): ~8 us per skipped round, four of them per FIFO tick.  The first
+    // chunk enqueues one round more than moved something in the context's previous call (ticks of one deployment need the
+    // same depth, 4 with FIFO channels, 7 - 8 with reordering ones); a tick that needs more gets full chunks as before.
+    const int rounds = chunk == 0 ? std::max(2, std::min(DG_ROUNDS, e->dg_rounds_hint)) : DG_ROUNDS;
+    for (int k = 1; k <= rounds; ++k) {
       // round k gathers from half `cur` and leaves its scan in the other half.  (A skipped round does not flip anything on
       // the device, but after the round that moved nothing both halves hold the same, final values.)
-      hipLaunchKernelGGL((k_dp_relax<N>), dim3(a.nblocks), dim3(256), 0, e->stream, a, cur, k);
+      hipLaunchKernelGGL((k_dp_relax<N>), dim3(dp_grid(a.nblocks)), dim3(256), 0, e->stream, a, cur, k);
       hipLaunchKernelGGL((k_dp_carry<N>), dim3(N), dim3(1024), 0, e->stream, a, cur ^ 1, k);
       cur ^= 1;
     }
     EHIP(e, hipMemsetAsync(a.ctl + 3, 0, 8, e->stream));
-    hipLaunchKernelGGL((k_dp_keys<N>), dim3(grid), dim3(256), 0, e->stream, a);
+    hipLaunchKernelGGL((k_dp_keys<N>), dim3(dp_grid(grid)), dim3(256), 0, e->stream, a);
     uint2* sorted = radix_sort_pairs(e, 1, m, (unsigned)a.hash_bits, a.pairs, a.pairs2, nullptr, &rc, nullptr, nullptr);
     if (rc) return rc;
     if (sorted != a.pairs) std::swap(a.pairs, a.pairs2);
@@ -1683,9 +1690,10 @@ int dg_execute_packed(fpx_epx* e, int m, const int32_t* d_leader, const int32_t*
     hipLaunchKernelGGL(k_dp_count_starts, dim3(out_tiles), dim3(256), 0, e->stream, a);
     hipLaunchKernelGGL(k_dp_emit, dim3(out_tiles), dim3(256), 0, e->stream, a);
     a.seq = call * 64 + (chunk & 31) + 1;
-    hipLaunchKernelGGL(k_dp_publish, dim3(1), dim3(64), 0, e->stream, a);
+    hipLaunchKernelGGL(k_dp_publish, dim3(1), dim3(64), 0, e->stream, a, rounds);
     if ((rc = wait_for((chunk & 31) + 1))) return rc;
     if (host[1] != 0) return FPX_EINVAL;
+    e->dg_rounds_hint = host[5] != 0 ? DG_ROUNDS : host[6] + 1;
     if (a.count_moved) {
       int32_t dbg[64];
       EHIP(e, hipMemcpy(dbg, a.ctl, sizeof(dbg), hipMemcpyDeviceToHost));
@@ -1919,7 +1927,7 @@ int32_t fpx_epx_destroy(fpx_epx* e) {
   for (Buf* b : bs)
     if (b->p) (void)hipFree(b->p);
   for (Buf* b : {&e->kp_hist, &e->kp_recs, &e->kp_misc, &e->p_fast, &e->p_deps, &e->p_ldeps, &e->p_own, &e->dg_msg, &e->dg_direct,
-                 &e->dg_clo, &e->dg_pre, &e->dg_tmax, &e->dg_pairs, &e->dg_pairs2, &e->dg_ctl, &e->dg_key})
+                 &e->dg_clo, &e->dg_pre, &e->dg_tmax, &e->dg_pairs, &e->dg_pairs2, &e->dg_ctl, &e->dg_key, &e->dgh_in, &e->dgh_out})
     if (b->p) (void)hipFree(b->p);
   if (e->kp_flag) (void)hipHostFree(e->kp_flag);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -2060,6 +2068,53 @@ int32_t fpx_epx_execute_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, cons
     case 5: return dg_execute<5>(e, m, d_leader, d_number, d_packed, d_committed, first, count, d_order, d_component, num_executed, num_components, needs_host_path);
     default: return dg_execute<7>(e, m, d_leader, d_number, d_packed, d_committed, first, count, d_order, d_component, num_executed, num_components, needs_host_path);
   }
+}
+
+int32_t fpx_epx_execute(fpx_epx* e, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* deps,
+                        const int32_t* deps_values_end, const uint8_t* committed, const int32_t* first, const int32_t* count,
+                        int32_t* order, int32_t* component, int64_t* num_executed, int64_t* num_components,
+                        int32_t* needs_host_path) {
+  if (!e || m < 0 || !first || !count || (m > 0 && (!leader || !number || !deps || !order || !component))) return FPX_EINVAL;
+  EpxDeviceGuard _dg(e->cfg.device);
+  if (num_executed) *num_executed = 0;
+  if (num_components) *num_components = 0;
+  if (needs_host_path) *needs_host_path = 0;
+  if (m == 0) return FPX_OK;
+  const int n = e->st.n, stride = fpx_epx_packed_stride(n);
+  // the packed lines fpx_epx_preaccept_packed_dev would have written: deps | leader_deps (unused here) | own_values_end | fast
+  std::vector<int32_t> lines((size_t)m * stride, 0);
+  for (int i = 0; i < m; ++i) {
+    if (leader[i] < 0 || leader[i] >= n) return FPX_EINVAL;
+    int32_t* line = lines.data() + (size_t)i * stride;
+    for (int l = 0; l < n; ++l) line[l] = deps[(size_t)i * n + l];
+    line[2 * n] = deps_values_end ? deps_values_end[i] : 0;
+  }
+  const size_t mp = ((size_t)m + 63) & ~(size_t)63;
+  int rc;
+  if ((rc = grow(e, &e->dgh_in, mp * 4 * 2 + mp + lines.size() * 4 + 256))) return rc;
+  if ((rc = grow(e, &e->dgh_out, mp * 4 * 2))) return rc;
+  char* p = (char*)e->dgh_in.p;
+  int32_t *d_leader = (int32_t*)p, *d_number = (int32_t*)(p + mp * 4), *d_packed = (int32_t*)(p + mp * 8);
+  uint8_t* d_mask = (uint8_t*)(p + mp * 8 + lines.size() * 4);
+  int32_t *d_order = (int32_t*)e->dgh_out.p, *d_comp = d_order + mp;
+  EHIP(e, hipMemcpyAsync(d_leader, leader, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+  EHIP(e, hipMemcpyAsync(d_number, number, (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+  EHIP(e, hipMemcpyAsync(d_packed, lines.data(), lines.size() * 4, hipMemcpyHostToDevice, e->stream));
+  if (committed) EHIP(e, hipMemcpyAsync(d_mask, committed, (size_t)m, hipMemcpyHostToDevice, e->stream));
+  EHIP(e, hipStreamSynchronize(e->stream));  // (the host arrays and `lines` may be pageable)
+  int64_t ne = 0, nc = 0;
+  int32_t nh = 0;
+  rc = fpx_epx_execute_dev(e, m, d_leader, d_number, d_packed, committed ? d_mask : nullptr, first, count, d_order, d_comp, &ne, &nc, &nh);
+  if (rc) return rc;
+  if (ne > 0 && !nh) {
+    EHIP(e, hipMemcpyAsync(order, d_order, (size_t)ne * 4, hipMemcpyDeviceToHost, e->stream));
+    EHIP(e, hipMemcpyAsync(component, d_comp, (size_t)ne * 4, hipMemcpyDeviceToHost, e->stream));
+    EHIP(e, hipStreamSynchronize(e->stream));
+  }
+  if (num_executed) *num_executed = ne;
+  if (num_components) *num_components = nc;
+  if (needs_host_path) *needs_host_path = nh;
+  return FPX_OK;
 }
 
 int32_t fpx_epx_preaccept_dev(fpx_epx* e, int32_t m, const int32_t* d_leader, const int32_t* d_number,

@@ -209,6 +209,24 @@ class EPaxos:
             raise FpxError(st, "fpx_epx_execute_dev")
         return ne.value, nc.value, nh.value
 
+    def execute(self, leader, number, deps, first, count, deps_values_end=None, committed=None):
+        """fpx_epx_execute: the same on host (numpy) arrays.  Returns (order, component, num_components, needs_host_path);
+        order / component hold the num_executed entries"""
+        leader, number = np.ascontiguousarray(leader, np.int32), np.ascontiguousarray(number, np.int32)
+        deps = np.ascontiguousarray(deps, np.int32)
+        m = len(leader)
+        ends = None if deps_values_end is None else np.ascontiguousarray(deps_values_end, np.int32)
+        cm = None if committed is None else np.ascontiguousarray(committed, np.uint8)
+        f, c = np.ascontiguousarray(first, np.int32), np.ascontiguousarray(count, np.int32)
+        order, comp = np.full(m, -1, np.int32), np.full(m, -1, np.int32)
+        ne, nc, nh = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        p = lambda a: None if a is None else a.ctypes.data
+        st = self.L.fpx_epx_execute(self._h, m, p(leader), p(number), p(deps), p(ends), p(cm), p(f), p(c), p(order), p(comp),
+                                    C.addressof(ne), C.addressof(nc), C.addressof(nh))
+        if st:
+            raise FpxError(st, "fpx_epx_execute")
+        return order[:ne.value], comp[:ne.value], nc.value, nh.value
+
     def unpack(self, packed):
         """packed [m, stride] (numpy or torch) -> fast [m], deps [m, n], leader_deps [m, n], own_values_end [m, 2]"""
         n = self.n

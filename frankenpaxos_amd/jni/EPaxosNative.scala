@@ -86,7 +86,11 @@ class GpuEPaxosReplica[Transport <: frankenpaxos.Transport[Transport]](
     engine: GpuEPaxosEngine[Transport],
     // what epaxos/ReplicaMain.scala hands a Replica (:120-135): this replica's copy of the state machine and its graph
     stateMachine: StateMachine,
-    dependencyGraph: DependencyGraph[Instance, Int, InstancePrefixSet]
+    dependencyGraph: DependencyGraph[Instance, Int, InstancePrefixSet],
+    // true: committed instances are ordered by libfpx's device dependency graph (Native.epxExecute, 2.2 - 2.6e9 commands/s
+    // at 2^20 instances per call, profiles/r06_depgraph_dev.md) instead of `dependencyGraph` (the reference's, 2 - 3e7/s);
+    // the state machine, the client table and the replies stay where they are.  Default off: the reference's own graph.
+    deviceExecution: Boolean = false
 ) extends Actor(address, transport, logger) {
   override type InboundMessage = ReplicaInbound
   override val serializer = ReplicaInboundSerializer
@@ -105,12 +109,81 @@ class GpuEPaxosReplica[Transport <: frankenpaxos.Transport[Transport]](
   private val blockers = mutable.Set[Instance]()
 
   // every actor of the process learns every commit: from its own flush, from another hosted actor's, or from a Commit message
+  // ---- deviceExecution: what this replica knows of every leader's column above its executed prefix.  The device graph
+  // wants DENSE columns (include/fpx.h, fpx_epx_execute): per leader the instances first .. first + count - 1, each once,
+  // everything below `first` executed.  So: executedPrefix(l) = the first number of leader l not executed here yet;
+  // pendingDeps = the committed instances at or above it that are not executed (watermarks, end of the own column's
+  // explicit ids); executedAbove = the ones above it that are (executed out of column order: handed in again as
+  // committed -- the device puts them in the order, the actor skips them); a number in the range with no Commit yet is
+  // handed in as "not committed": it and whatever reaches it wait (Replica.scala:883-917 `blockers`).
+  private val executedPrefix = Array.fill(n)(0)
+  private val pendingDeps = mutable.Map[Instance, (Array[Int], Int)]()
+  private val executedAbove = mutable.Map[Instance, (Array[Int], Int)]()
+  private def ownEnd(instance: Instance, deps: InstancePrefixSetProto): Int = {
+    val v = deps.intPrefixSet(instance.replicaIndex).value
+    if (v.isEmpty) 0 else v.max + 1
+  }
+
   def learnCommit(instance: Instance, commandOrNoop: CommandOrNoop, dependencies: InstancePrefixSetProto): Unit = {
     if (committed.contains(instance)) return                            // a re-sent Commit
+    if (deviceExecution) {
+      if (instance.instanceNumber < executedPrefix(instance.replicaIndex) || executedAbove.contains(instance)) return
+      committed(instance) = commandOrNoop
+      pendingDeps(instance) = (watermarks(dependencies), ownEnd(instance, dependencies))
+      return
+    }
     committed(instance) = commandOrNoop
     dependencyGraph.commit(instance, 0, InstancePrefixSet.fromProto(dependencies))       // :866-868
   }
+  private def executeGraphOnDevice(): Unit = {
+    if (pendingDeps.isEmpty) return
+    val first = executedPrefix.clone()
+    val count = Array.tabulate(n)(l => {
+      val known = (pendingDeps.keysIterator ++ executedAbove.keysIterator).filter(_.replicaIndex == l).map(_.instanceNumber)
+      if (known.isEmpty) 0 else known.max + 1 - first(l)
+    })
+    val m = count.sum
+    val leader = new Array[Int](m); val number = new Array[Int](m); val deps = new Array[Int](m * n); val ends = new Array[Int](m)
+    val isCommitted = new Array[Byte](m)
+    var i = 0
+    for (l <- 0 until n; x <- first(l) until first(l) + count(l)) {
+      leader(i) = l; number(i) = x
+      pendingDeps.get(Instance(l, x)).orElse(executedAbove.get(Instance(l, x))) match {
+        case Some((w, end)) => Array.copy(w, 0, deps, i * n, n); ends(i) = end; isCommitted(i) = 1
+        case None           => ()                                        // no Commit yet: blocks what reaches it
+      }
+      i += 1
+    }
+    val order = new Array[Int](m); val component = new Array[Int](m); val counts = new Array[Int](3)
+    Native.check(Native.epxExecute(engine.handle, m, n, leader, number, deps, ends, isCommitted, first, count, order, component, counts), logger)
+    if (counts(2) != 0) {
+      // two different closures with one sum and one 22-bit hash (probability ~2^-22 per pair: include/fpx.h): this batch
+      // goes through the reference's graph, which is told what has been executed so far (DependencyGraph.updateExecuted)
+      logger.warn("GpuEPaxosReplica: the device dependency graph asks for the host path; this batch runs on the reference's graph.")
+      // what this replica has executed: the prefixes, and the instances above them (depgraph/DependencyGraph.scala:176-186)
+      val done = InstancePrefixSet.fromWatermarks(executedPrefix.toBuffer)
+      executedAbove.keysIterator.foreach(done.add)
+      dependencyGraph.updateExecuted(done)
+      for ((inst, (w, end)) <- pendingDeps)
+        dependencyGraph.commit(inst, 0, InstancePrefixSet.fromProto(prefixSet(w, inst.replicaIndex, end, inst.instanceNumber)))
+      dependencyGraph.appendExecute(None, executables, blockers)
+    } else {
+      for (p <- 0 until counts(0)) executables += Instance(leader(order(p)), number(order(p)))
+    }
+    for (inst <- executables if !executedAbove.contains(inst)) {
+      committed.remove(inst) match {
+        case None                => logger.fatal(s"Instance $inst is ready for execution but was never committed here.")
+        case Some(commandOrNoop) => executeCommand(inst, commandOrNoop)
+      }
+      executedAbove(inst) = pendingDeps.remove(inst).get
+    }
+    executables.clear(); blockers.clear()
+    for (l <- 0 until n) {                                               // the executed prefixes move up; what lies below them is forgotten
+      while (executedAbove.remove(Instance(l, executedPrefix(l))).isDefined) executedPrefix(l) += 1
+    }
+  }
   def executeGraph(): Unit = {                                           // :883-917
+    if (deviceExecution) { executeGraphOnDevice(); return }
     dependencyGraph.appendExecute(None, executables, blockers)
     for (i <- executables) {
       committed.remove(i) match {

@@ -114,6 +114,12 @@ object Native {
   @native def epxHandleCommit(handle: Long, m: Int, numReplicas: Int, leader: Array[Int], number: Array[Int],
                               tripleId: Array[Int], key: Array[Int], isSet: Array[Byte], deps: Array[Int],
                               depsValuesEnd: Array[Int], targetMask: Array[Byte]): Int
+  // Replica.execute on the device: the dependency graph of the committed instances handed in (dense columns first(l) ..
+  // first(l) + count(l) - 1), strongly connected components in reverse topological order.  order / component: m each;
+  // counts = (executed, components, needsHostPath)
+  @native def epxExecute(handle: Long, m: Int, numReplicas: Int, leader: Array[Int], number: Array[Int], deps: Array[Int],
+                         depsValuesEnd: Array[Int], committed: Array[Byte], first: Array[Int], count: Array[Int],
+                         order: Array[Int], component: Array[Int], counts: Array[Int]): Int
   @native def epxHandlePreaccept(handle: Long, m: Int, numReplicas: Int, leader: Array[Int],
                                  number: Array[Int], ballotOrdering: Array[Int],
                                  ballotReplica: Array[Int], key: Array[Int], isSet: Array[Byte],

@@ -487,6 +487,40 @@ JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxHandleCommit(JNIEnv* env,
   return st;
 }
 
+/* Dependency-graph execution of committed instances on the device (fpx_epx_execute; Replica.execute, epaxos/Replica.scala:859-917,
+ * depgraph/TarjanDependencyGraph.scala:225-276).  deps m x n, depsValuesEnd m (may be null), committed m bytes (may be null = all),
+ * first / count n each (the columns are dense), order / component m each (out), counts = {executed, components, needsHostPath} (out) */
+JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxExecute(JNIEnv* env, jclass cls, jlong h, jint m, jint numReplicas,
+                                                               jintArray leader, jintArray number, jintArray deps,
+                                                               jintArray depsValuesEnd, jbyteArray committed, jintArray first,
+                                                               jintArray count, jintArray order, jintArray component,
+                                                               jintArray counts) {
+  if (m < 0 || numReplicas < 3 || !epx_n_is(h, numReplicas)) return FPX_EINVAL;
+  const jlong mn = (jlong)m * numReplicas;
+  if (!has(env, leader, m) || !has(env, number, m) || !has(env, deps, mn) || !opt(env, depsValuesEnd, m) || !opt(env, committed, m) ||
+      !has(env, first, numReplicas) || !has(env, count, numReplicas) || !has(env, order, m) || !has(env, component, m) ||
+      !has(env, counts, 3))
+    return FPX_EINVAL;
+  jint *l = in_ints(env, leader, m), *nu = in_ints(env, number, m), *d = in_ints(env, deps, mn);
+  jint* de = depsValuesEnd ? in_ints(env, depsValuesEnd, m) : NULL;
+  jbyte* cm = committed ? in_bytes(env, committed, m) : NULL;
+  jint *f = in_ints(env, first, numReplicas), *c = in_ints(env, count, numReplicas);
+  jint *o = (jint*)malloc(sizeof(jint) * (size_t)(m > 0 ? m : 1)), *co = (jint*)malloc(sizeof(jint) * (size_t)(m > 0 ? m : 1));
+  int64_t ne = 0, nc = 0;
+  int32_t nh = 0;
+  int32_t st = (!l || !nu || !d || !f || !c || !o || !co || (depsValuesEnd && !de) || (committed && !cm))
+                   ? FPX_ENOMEM
+                   : fpx_epx_execute((fpx_epx*)(intptr_t)h, m, l, nu, d, de, (const uint8_t*)cm, f, c, o, co, &ne, &nc, &nh);
+  if (st == FPX_OK) {
+    const jint out[3] = {(jint)ne, (jint)nc, (jint)nh};
+    put_ints(env, order, ne, o);
+    put_ints(env, component, ne, co);
+    (*env)->SetIntArrayRegion(env, counts, 0, 3, out);
+  }
+  free(l); free(nu); free(d); free(de); free(cm); free(f); free(c); free(o); free(co);
+  return st;
+}
+
 /* key -1 = Noop; depsIn m x n, depsInValuesEnd m (may be null); replies = okBits | resendBits | nackBits | commitBits
  * (4 x m bytes); replyDeps m x n x n, replyEndTriple = valuesEnd | tripleId (2 x m x n ints) */
 JNIEXPORT jint JNICALL Java_frankenpaxos_gpu_Native_epxHandlePreaccept(

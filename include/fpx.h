@@ -526,6 +526,16 @@ int32_t fpx_epx_execute_dev(fpx_epx* epx, int32_t m, const int32_t* d_leader, co
                             const int32_t* d_packed, const uint8_t* d_committed, const int32_t* first,
                             const int32_t* count, int32_t* d_order, int32_t* d_component, int64_t* num_executed,
                             int64_t* num_components, int32_t* needs_host_path);
+/* The same on HOST arrays (what a JNI caller holds: frankenpaxos_amd/jni/EPaxosNative.scala, `deviceExecution`): message i
+ * = instance (leader[i], number[i]) committed with the watermarks deps[i * n .. i * n + n) and, if deps_values_end is given
+ * and deps_values_end[i] > 0, the explicit ids number[i] + 1 .. deps_values_end[i] - 1 of its own column
+ * (dependencies.subtractOne, Replica.scala:582; then deps[i * n + leader[i]] must equal number[i]); committed (may be NULL =
+ * all) as above.  order / component: m entries each, filled for p < *num_executed.  Builds the packed lines, uploads,
+ * runs fpx_epx_execute_dev, downloads; synchronous. */
+int32_t fpx_epx_execute(fpx_epx* epx, int32_t m, const int32_t* leader, const int32_t* number, const int32_t* deps,
+                        const int32_t* deps_values_end, const uint8_t* committed, const int32_t* first,
+                        const int32_t* count, int32_t* order, int32_t* component, int64_t* num_executed,
+                        int64_t* num_components, int32_t* needs_host_path);
 
 /* ---- EPaxos beyond fresh instances: the per-instance Paxos on the command log (num_instances > 0) --------------
  * Ballots are (ordering, replicaIndex), compared lexicographically (epaxos/BallotHelpers.scala:11-21); where one

@@ -310,3 +310,58 @@ def test_config4_tick_executes_on_the_device(oracle, fifo, dg_path):
     from tests.test_epaxos import check_execution_order
     check_execution_order(n, leader, number, deps, own[:, 0], leader[order], number[order], np.bincount(comp))
     assert ne / best > (1.6e9 if dg_path == "packed" else 1e9)
+
+
+@pytest.mark.parametrize("n,m,jitter", [(5, 3000, 12), (5, 3000, 0), (3, 900, 4), (7, 2500, 0)])
+def test_host_array_entry_point_and_the_jni_native_execute_as_the_host_graph_does(n, m, jitter):
+    """fpx_epx_execute (host arrays in, order out) and Native.epxExecute over it on the mock JVM -- what GpuEPaxosReplica
+    calls with `deviceExecution` (jni/EPaxosNative.scala): the SET of components of the host graph, a valid execution
+    order (cycles: jitter > 0, everything committed), instances without a Commit and what reaches them left waiting
+    (jitter = 0: no cycles, a giant component would wait whole) -- and the same answer through both doors"""
+    import ctypes as C
+    from frankenpaxos_amd import depgraph as P
+    from frankenpaxos_amd.epaxos import EPaxos
+    from tests.test_jni_shim import build_shim
+
+    rng = np.random.default_rng(77 + n + m + jitter)
+    leader, number, first, count, deps, own = random_prefix_graph(rng, n, m, jitter, holes=jitter > 0)
+    committed = np.ones(m, bool)
+    if jitter == 0:
+        committed = (np.arange(m) < 3 * m // 4) | (rng.random(m) > 0.1)     # some of the later instances have no Commit yet
+    epx = EPaxos(n, 4)
+    order, comp, nc, nh = epx.execute(leader, number, deps, first, count, deps_values_end=own[:, 0], committed=committed)
+    assert not nh and 3 * m // 4 <= len(order) <= m and (len(order) < m) == (jitter == 0)
+    g = P.DependencyGraph(n, kind=P.FPX_DG_TARJAN)
+    g.update_executed(first)
+    g.commit_epx(leader[committed], number[committed], deps[committed], own[committed])
+    el, ei, cs, bl, bi = g.execute_arrays()
+    assert len(order) == len(el) and nc == len(cs)
+    assert labels(n, leader, number, leader[order], number[order], comp) == labels(n, leader, number, el, ei, np.repeat(np.arange(len(cs)), cs))
+    if jitter > 0:
+        check_valid_order(n, first, leader, number, deps, own[:, 0], order, comp)
+    else:
+        assert committed[order].all()
+    # the native on the mock JVM: the same arrays as Java arrays
+    L = C.CDLL(build_shim())
+    L.mock_env.restype = C.c_void_p
+    L.mock_new_array.restype = C.c_void_p
+    L.mock_new_array.argtypes = [C.c_int, C.c_int64, C.c_void_p]
+    L.mock_data.restype = C.c_void_p
+    L.mock_data.argtypes = [C.c_void_p]
+    env = C.c_void_p(L.mock_env())
+    arr = lambda a: C.c_void_p(L.mock_new_array(np.ascontiguousarray(a).dtype.itemsize, np.ascontiguousarray(a).size, np.ascontiguousarray(a).ctypes.data))
+    read = lambda o, k: np.ctypeslib.as_array(C.cast(L.mock_data(o), C.POINTER(C.c_int32)), (k,)).copy()
+    j_order, j_comp, j_counts = arr(np.full(m, -1, np.int32)), arr(np.full(m, -1, np.int32)), arr(np.zeros(3, np.int32))
+    fn = L.Java_frankenpaxos_gpu_Native_epxExecute
+    fn.restype = C.c_int32
+    st = fn(env, None, C.c_int64(epx._h if isinstance(epx._h, int) else epx._h.value), C.c_int32(m), C.c_int32(n), arr(leader), arr(number),
+            arr(deps.astype(np.int32)), arr(own[:, 0].astype(np.int32)), arr(committed.astype(np.int8)), arr(first.astype(np.int32)),
+            arr(count.astype(np.int32)), j_order, j_comp, j_counts)
+    assert st == 0
+    ne, nc2, nh2 = read(j_counts, 3)
+    assert (ne, nc2, nh2) == (len(order), nc, 0)
+    np.testing.assert_array_equal(read(j_order, m)[:ne], order)
+    np.testing.assert_array_equal(read(j_comp, m)[:ne], comp)
+    # short arrays are refused before anything is touched
+    assert fn(env, None, C.c_int64(epx._h if isinstance(epx._h, int) else epx._h.value), C.c_int32(m), C.c_int32(n), arr(leader[:-1]), arr(number),
+              arr(deps.astype(np.int32)), None, None, arr(first.astype(np.int32)), arr(count.astype(np.int32)), j_order, j_comp, j_counts) == 1
