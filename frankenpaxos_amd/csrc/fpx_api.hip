@@ -1450,7 +1450,7 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
   if ((rc = dalloc(ctx, &st.part_all, (size_t)2 * 64 * PART_ALL_STRIDE))) return fail(rc);
   if ((rc = dalloc(ctx, &st.log_value, (size_t)g.S))) return fail(rc);
   if ((rc = dalloc(ctx, &st.log_present, (size_t)g.S))) return fail(rc);
-  if ((rc = dalloc(ctx, &st.log_scalars, (size_t)8))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.log_scalars, (size_t)LG_PARTS_AT + 2 * LG_MAX_PARTS))) return fail(rc);
   if (!g.per_slot) {
     // noop-range tallies: at most cap / 2 live entries; sized for a few hundred ranges in flight per leader group,
     // bounded to 64 MiB of vote bitmaps per buffer (A x 32 B per entry)
@@ -2397,9 +2397,9 @@ int32_t fpx_replica_chosen_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, c
   b.n = n, b.slot = d_slot, b.value = d_value_id, b.mask = d_mask;
   int rc = enqueue_validate(ctx, b, false);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_log_ingest, dim3(std::max(1, std::min((n + 255) / 256, ctx->num_cus * 8))), dim3(256), 0, ctx->stream,
-                     ctx->g, ctx->st, b);
-  hipLaunchKernelGGL(k_log_prep, dim3(1), dim3(1), 0, ctx->stream, ctx->g, ctx->st);
+  const int ingest_grid = std::max(1, std::min({(n + 255) / 256, ctx->num_cus * 8, LG_MAX_PARTS}));
+  hipLaunchKernelGGL(k_log_ingest, dim3(ingest_grid), dim3(256), 0, ctx->stream, ctx->g, ctx->st, b);
+  hipLaunchKernelGGL(k_log_prep, dim3(1), dim3(256), 0, ctx->stream, ctx->g, ctx->st, ingest_grid);
   hipLaunchKernelGGL(k_log_scan, dim3(ctx->num_cus * 4), dim3(256), 0, ctx->stream, ctx->g, ctx->st);
   hipLaunchKernelGGL(k_log_commit, dim3(1), dim3(1), 0, ctx->stream, ctx->st);
   return launch_check(ctx);
@@ -2468,7 +2468,7 @@ int32_t fpx_replica_chosen_noop_range(fpx_ctx* ctx, int32_t slot_start, int32_t 
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   }
   if (first == count) {  // the handler ran to its end: executeLog (mencius/Replica.scala:485)
-    hipLaunchKernelGGL(k_log_prep, dim3(1), dim3(1), 0, ctx->stream, ctx->g, ctx->st);
+    hipLaunchKernelGGL(k_log_prep, dim3(1), dim3(256), 0, ctx->stream, ctx->g, ctx->st, 0);
     hipLaunchKernelGGL(k_log_scan, dim3(ctx->num_cus * 4), dim3(256), 0, ctx->stream, ctx->g, ctx->st);
     hipLaunchKernelGGL(k_log_commit, dim3(1), dim3(1), 0, ctx->stream, ctx->st);
     int rc = launch_check(ctx);

@@ -52,6 +52,7 @@ struct DgArgs {
   int32_t* tmax;                    // [ntiles][DG_SUB][NP]: what the next round's scan carries in from the tiles before it (one row
                                     // per workgroup of k_dg_relax; k_dg_tilemax fills row 0 of a tile for the first round)
   int32_t* tstarts;                 // [out tiles] component starts per tile of the sorted order
+  int32_t* belig;                   // [ceil(m / 256)] executable vertices per workgroup of k_dg_keys (summed by k_dg_rekey)
   uint2* pairs;                     // [m] (sort key, vertex)
   uint2* pairs2;
   uint32_t* key32;                  // [m] the main sort key of a vertex (pairs carry the closure's hash first)
@@ -298,8 +299,16 @@ __device__ __forceinline__ uint32_t dg_hash(const int* c, int bits) {
   return h >> (32 - bits);
 }
 __global__ void __launch_bounds__(256) k_dg_rekey(const DgArgs a) {  // after the sort on the hash: the main key, by vertex
+  __shared__ uint32_t sh[8];
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < a.m) a.pairs[p].x = a.key32[a.pairs[p].y];
+  if (blockIdx.x == 0) {  // the number of executables (ctl[3]) from the workgroups' counts of k_dg_keys
+    const int vblocks = (a.m + 255) >> 8;
+    uint32_t s = 0;
+    for (int b = (int)threadIdx.x; b < vblocks; b += 256) s += (uint32_t)a.belig[b];
+    const uint32_t ex = block_excl_sum(s, sh);
+    if (threadIdx.x == 255) a.ctl[3] = (int32_t)(ex + s);
+  }
 }
 
 template <int N>
@@ -358,7 +367,9 @@ __global__ void __launch_bounds__(256) k_dg_keys(const DgArgs a) {
   const unsigned long long bal = __ballot(eligible);
   if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&block_eligible, (int)__popcll(bal));
   __syncthreads();
-  if (threadIdx.x == 0 && block_eligible) atomicAdd(&a.ctl[3], block_eligible);
+  // (round 6: not even one atomic per workgroup on the counter -- 4096 of them on one word were ~35 us of the packed path's
+  // 54 us kernel, profiles/r06_depgraph_dev.md; each workgroup leaves its count, k_dg_rekey's first workgroup adds them up)
+  if (threadIdx.x == 0) a.belig[blockIdx.x] = block_eligible;
 }
 
 template <int N>

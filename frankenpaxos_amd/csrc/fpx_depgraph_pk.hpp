@@ -56,6 +56,7 @@ struct DpArgs {
   uint2* pairs2;
   uint32_t* key32;
   int32_t* tstarts;
+  int32_t* belig;                        // [ceil(m / 256)] executable vertices per workgroup of k_dp_keys (summed by k_dp_rekey)
   int32_t* ctl;                          // as DgArgs::ctl
   volatile int32_t* host;
   int32_t seq;
@@ -128,8 +129,7 @@ __global__ void __launch_bounds__(256) k_dp_scatter(const DpArgs a) {
     const int rel = w - a.first[l];
     d[l] = committed ? min(max(rel, 0), a.count[l] + 1) : a.count[l] + 1;
   }
-  const ulonglong2 r = pk_pack(d);
-  a.direct[v] = r, a.clo[v] = r;
+  a.direct[v] = pk_pack(d);  // (k_dp_scan0 copies it into the closure: in vertex order, as whole lines)
 }
 
 // inclusive max-scan of one row per thread over the workgroup's 256 vertices; returns the workgroup's maximum in tot[]
@@ -163,8 +163,13 @@ __global__ void __launch_bounds__(256) k_dp_scan0(const DpArgs a) {
   const int v = a.base[col] + j;
   int c[5] = {0, 0, 0, 0, 0}, tot[5] = {0, 0, 0, 0, 0};
   if (live) {
-    if (a.msg_of[v] < 0) a.ctl[1] = 1;  // an instance of the column that was not handed in: the columns are not dense
-    else pk_unpack(a.clo[v], c);
+    if (a.msg_of[v] < 0) {
+      a.ctl[1] = 1;  // an instance of the column that was not handed in: the columns are not dense
+    } else {
+      const ulonglong2 r = a.direct[v];
+      a.clo[v] = r;
+      pk_unpack(r, c);
+    }
   }
   dp_block_scan<N>(c, sh, tot);
   if (live) a.lp[0][v] = pk_pack(c);
@@ -267,20 +272,43 @@ __device__ __forceinline__ void dp_prefix(const DpArgs& a, int l, int w, int* ou
   for (int q = 0; q < 5; ++q) out[q] = imax(r1[q], r2[q]);
 }
 
+// the cycle test of one executable vertex whose closure reaches past it in its own column (c[L] > x): kind 0 = on a cycle
+// (the closure of a direct dependency covers x in column L), 1 = not
+template <int N>
+__device__ __forceinline__ uint32_t dp_kind_of_candidate(const DpArgs& a, int L, int x, const int* d) {
+  int back = 0;
+#pragma unroll
+  for (int l = 0; l < N; ++l) {
+    const int bound = l == L ? min(d[l], x) : d[l];  // own column: the prefix below x here, the explicit ids below
+    if (bound >= 1) {
+      int row[5];
+      dp_prefix(a, l, bound, row);
+      back = imax(back, row[L]);
+    }
+  }
+  for (int y = x + 1; y < min(d[L], a.count[L]); ++y) {
+    int row[5];
+    pk_unpack(a.clo[a.base[L] + y], row);
+    back = imax(back, row[L]);
+  }
+  return back > x ? 0u : 1u;
+}
+
 template <int N>
 __global__ void __launch_bounds__(256) k_dp_keys(const DpArgs a) {
-  __shared__ int block_eligible;
+  __shared__ int block_eligible, ncand;
+  __shared__ int cand[256];
   const int vblocks = (a.m + 255) >> 8;
   const int lb = dp_logical_block((int)blockIdx.x, vblocks);
   if (lb >= vblocks) return;
   const int v = lb * 256 + (int)threadIdx.x;
-  if (threadIdx.x == 0) block_eligible = 0;
+  if (threadIdx.x == 0) block_eligible = 0, ncand = 0;
   __syncthreads();
   bool eligible = false;
   if (v < a.m) {
-    int c[5], d[5];
+    int c[5];
     const ulonglong2 cr = a.clo[v];
-    pk_unpack(cr, c), pk_unpack(a.direct[v], d);
+    pk_unpack(cr, c);
     const int L = dp_col_of_vertex(a, N, v);
     const int x = v - a.base[L];  // relative id
     eligible = true;
@@ -290,41 +318,51 @@ __global__ void __launch_bounds__(256) k_dp_keys(const DpArgs a) {
       eligible = eligible && c[l] <= a.count[l];
       sum += (uint32_t)c[l];
     }
-    // on a cycle iff the closure of a direct dependency covers x in column L (asked of executable vertices only: one that
-    // is not committed has "everything" in d[] and would walk the rest of its column)
-    // Every row the test gathers is the closure of something v reaches, so its column L lies below c[L]: a vertex whose own
-    // closure does not reach past itself in its column (c[L] <= x: nine in ten of a FIFO tick) is on no cycle and has no
-    // explicit ids to walk -- it asks nothing (79 -> ~25 us per 2^20 vertices, profiles/r06_depgraph_dev.md)
-    int back = 0;
+    // Every row the cycle test gathers is the closure of something v reaches, so its column L lies below c[L]: a vertex
+    // whose own closure does not reach past itself in its column (c[L] <= x: nine in ten of a FIFO tick) is on no cycle
+    // and has no explicit ids to walk -- kind 2, nothing asked.  (An inexecutable vertex has "everything" in its rows and
+    // would walk the rest of its column: it is not asked either.)  The others -- a few per wavefront -- are handed to the
+    // workgroup's FIRST lanes below, so that one wavefront gathers with its lanes filled instead of four with a tenth each.
     if (eligible && c[L] > x) {
-#pragma unroll
-      for (int l = 0; l < N; ++l) {
-        const int bound = l == L ? min(d[l], x) : d[l];  // own column: the prefix below x here, the explicit ids below
-        if (bound >= 1) {
-          int row[5];
-          dp_prefix(a, l, bound, row);
-          back = imax(back, row[L]);
-        }
-      }
-      for (int y = x + 1; y < min(d[L], a.count[L]); ++y) {
-        int row[5];
-        pk_unpack(a.clo[a.base[L] + y], row);
-        back = imax(back, row[L]);
-      }
+      cand[atomicAdd(&ncand, 1)] = v;
+    } else {
+      a.key32[v] = eligible ? (sum * 3u + 2u) : 0xffffffffu;
+      a.pairs[v] = make_uint2(0u, (uint32_t)v);
     }
-    const uint32_t kind = back > x ? 0u : (c[L] > x ? 1u : 2u);
-    a.key32[v] = eligible ? (sum * 3u + kind) : 0xffffffffu;
-    a.pairs[v] = make_uint2((eligible && kind == 0u) ? pk_hash(cr, a.hash_bits) : 0u, (uint32_t)v);
   }
   const unsigned long long bal = __ballot(eligible);
   if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&block_eligible, (int)__popcll(bal));
   __syncthreads();
-  if (threadIdx.x == 0 && block_eligible) atomicAdd(&a.ctl[3], block_eligible);
+  if ((int)threadIdx.x < ncand) {
+    const int u = cand[threadIdx.x];
+    int c[5], d[5];
+    const ulonglong2 cr = a.clo[u];
+    pk_unpack(cr, c), pk_unpack(a.direct[u], d);
+    const int L = dp_col_of_vertex(a, N, u);
+    const int x = u - a.base[L];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int l = 0; l < N; ++l) sum += (uint32_t)c[l];
+    const uint32_t kind = dp_kind_of_candidate<N>(a, L, x, d);
+    a.key32[u] = sum * 3u + kind;
+    a.pairs[u] = make_uint2(kind == 0u ? pk_hash(cr, a.hash_bits) : 0u, (uint32_t)u);
+  }
+  // (4096 workgroups adding to ONE word serialise in its L2 channel: ~35 of this kernel's 54 us were that atomic, the same
+  // effect k_validate's round word showed in round 2; each workgroup leaves its count, k_dp_rekey's first workgroup adds them up)
+  if (threadIdx.x == 0) a.belig[lb] = block_eligible;
 }
 
 __global__ void __launch_bounds__(256) k_dp_rekey(const DpArgs a) {
+  __shared__ uint32_t sh[8];
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < a.m) a.pairs[p].x = a.key32[a.pairs[p].y];
+  if (blockIdx.x == 0) {  // the number of executables (what k_dp_count_starts / k_dp_emit / k_dp_publish read from ctl[3])
+    const int vblocks = (a.m + 255) >> 8;
+    uint32_t s = 0;
+    for (int b = (int)threadIdx.x; b < vblocks; b += 256) s += (uint32_t)a.belig[b];
+    const uint32_t ex = block_excl_sum(s, sh);
+    if (threadIdx.x == 255) a.ctl[3] = (int32_t)(ex + s);
+  }
 }
 
 // does a component start at position p of the sorted order?  (dg_starts on packed rows)

@@ -1623,7 +1623,7 @@ int dg_execute_packed(fpx_epx* e, int m, const int32_t* d_leader, const int32_t*
   if ((rc = grow(e, &e->dg_direct, (size_t)m * 16))) return rc;
   if ((rc = grow(e, &e->dg_clo, (size_t)m * 16))) return rc;
   if ((rc = grow(e, &e->dg_pre, (size_t)m * 32))) return rc;
-  if ((rc = grow(e, &e->dg_tmax, nb * 16 * 4 + (size_t)out_tiles * 4 + 64))) return rc;
+  if ((rc = grow(e, &e->dg_tmax, nb * 16 * 4 + (size_t)out_tiles * 4 + (size_t)((m + 255) / 256) * 4 + 64))) return rc;
   if ((rc = grow(e, &e->dg_pairs, (size_t)m * 8))) return rc;
   if ((rc = grow(e, &e->dg_pairs2, (size_t)m * 8))) return rc;
   if ((rc = grow(e, &e->dg_key, (size_t)m * 4))) return rc;
@@ -1634,6 +1634,7 @@ int dg_execute_packed(fpx_epx* e, int m, const int32_t* d_leader, const int32_t*
   a.lp[0] = (ulonglong2*)e->dg_pre.p, a.lp[1] = a.lp[0] + m;
   a.bt[0] = (ulonglong2*)e->dg_tmax.p, a.bt[1] = a.bt[0] + nb, a.cy[0] = a.bt[1] + nb, a.cy[1] = a.cy[0] + nb;
   a.tstarts = (int32_t*)(a.cy[1] + nb);
+  a.belig = a.tstarts + out_tiles;
   a.pairs = (uint2*)e->dg_pairs.p, a.pairs2 = (uint2*)e->dg_pairs2.p, a.ctl = (int32_t*)e->dg_ctl.p;
   a.key32 = (uint32_t*)e->dg_key.p;
   a.host = reinterpret_cast<volatile int32_t*>(e->kp_flag_dev + 8);
@@ -1745,7 +1746,7 @@ int dg_execute(fpx_epx* e, int m, const int32_t* d_leader, const int32_t* d_numb
   if ((rc = grow(e, &e->dg_direct, (size_t)m * NP * 4))) return rc;
   if ((rc = grow(e, &e->dg_clo, (size_t)m * NP * 4))) return rc;
   if ((rc = grow(e, &e->dg_pre, (size_t)m * NP * 4))) return rc;
-  if ((rc = grow(e, &e->dg_tmax, ((size_t)DG_SUB * a.ntiles * NP + out_tiles) * 4 + 64))) return rc;
+  if ((rc = grow(e, &e->dg_tmax, ((size_t)DG_SUB * a.ntiles * NP + out_tiles + (size_t)((m + 255) / 256)) * 4 + 64))) return rc;
   if ((rc = grow(e, &e->dg_pairs, (size_t)m * 8))) return rc;
   if ((rc = grow(e, &e->dg_pairs2, (size_t)m * 8))) return rc;
   if ((rc = grow(e, &e->dg_key, (size_t)m * 4))) return rc;
@@ -1754,6 +1755,7 @@ int dg_execute(fpx_epx* e, int m, const int32_t* d_leader, const int32_t* d_numb
   a.leader = d_leader, a.number = d_number, a.packed = d_packed, a.mask = d_mask;
   a.msg_of = (int32_t*)e->dg_msg.p, a.direct = (int32_t*)e->dg_direct.p, a.clo = (int32_t*)e->dg_clo.p, a.pre = (int32_t*)e->dg_pre.p;
   a.tmax = (int32_t*)e->dg_tmax.p, a.tstarts = a.tmax + (size_t)DG_SUB * a.ntiles * NP;
+  a.belig = a.tstarts + out_tiles;
   a.pairs = (uint2*)e->dg_pairs.p, a.pairs2 = (uint2*)e->dg_pairs2.p, a.ctl = (int32_t*)e->dg_ctl.p;
   a.key32 = (uint32_t*)e->dg_key.p;
   a.host = reinterpret_cast<volatile int32_t*>(e->kp_flag_dev + 8);  // the second half of the page-locked line

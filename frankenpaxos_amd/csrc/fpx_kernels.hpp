@@ -848,11 +848,15 @@ __device__ __forceinline__ void wave_atomic_min(int32_t* target, int v) {
 }
 
 enum { LG_WATERMARK = 0, LG_NUM_CHOSEN = 1, LG_LARGEST = 2, LG_FIRST_MISSING = 3, LG_RANGE_FIRST = 4 };
+// behind the scalars: one (count, largest key) pair per workgroup of k_log_ingest, folded by k_log_prep
+constexpr int LG_PARTS_AT = 8, LG_MAX_PARTS = 4096;
 
 __global__ void __launch_bounds__(256) k_log_ingest(const Geom g, const State st, const Batch b) {
   if (st.status[ST_ABORT] != 0) return;
-  // grid-stride, counts and the largest key accumulated per thread, then per workgroup: the two scalars see
-  // one atomic pair per workgroup (a pair per wavefront serialised 2^15 same-address atomics per 2^20 records)
+  // grid-stride, counts and the largest key accumulated per thread, then per workgroup; every workgroup leaves its pair
+  // behind the scalars and k_log_prep folds them.  (Round 1: an atomic pair per wavefront -- 2^15 same-address atomics per
+  // 2^20 records, 375 us; rounds 1 - 5: a pair per workgroup, still 2 x 2048 atomics on one cache line, ~35 of the kernel's
+  // 52 us -- the effect that cost k_dp_keys 43 us, profiles/r06_depgraph_dev.md.)
   __shared__ int w_cnt[4], w_top[4];
   int cnt = 0, top = -1;  // BufferMap.largestKey
   const int step = gridDim.x * blockDim.x;
@@ -882,17 +886,34 @@ __global__ void __launch_bounds__(256) k_log_ingest(const Geom g, const State st
       c += w_cnt[j];
       t = w_top[j] > t ? w_top[j] : t;
     }
-    if (c) {
-      atomicAdd(&st.log_scalars[LG_NUM_CHOSEN], c);
-      atomicMax(&st.log_scalars[LG_LARGEST], t);
-    }
+    st.log_scalars[LG_PARTS_AT + 2 * blockIdx.x] = c;
+    st.log_scalars[LG_PARTS_AT + 2 * blockIdx.x + 1] = t;
   }
 }
 
 // scan range = [executedWatermark, min(S, largestKey + 1)): the slot after largestKey is absent by
 // definition, so LG_FIRST_MISSING starts at the end of the range and only ever decreases
-__global__ void k_log_prep(const Geom g, const State st) {
+// nparts > 0: behind k_log_ingest -- its workgroups' (count, largest key) pairs are folded into numChosen / largestKey first
+__global__ void __launch_bounds__(256) k_log_prep(const Geom g, const State st, int nparts) {
+  __shared__ int s_cnt[256], s_top[256];
   if (st.status[ST_ABORT] != 0) return;
+  int c = 0, t = -1;
+  for (int j = threadIdx.x; j < nparts; j += 256) {
+    c += st.log_scalars[LG_PARTS_AT + 2 * j];
+    const int o = st.log_scalars[LG_PARTS_AT + 2 * j + 1];
+    t = o > t ? o : t;
+  }
+  s_cnt[threadIdx.x] = c, s_top[threadIdx.x] = t;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  if (nparts > 0) {
+    for (int j = 1; j < 256; ++j) {
+      c += s_cnt[j];
+      t = s_top[j] > t ? s_top[j] : t;
+    }
+    st.log_scalars[LG_NUM_CHOSEN] += c;
+    if (t > st.log_scalars[LG_LARGEST]) st.log_scalars[LG_LARGEST] = t;
+  }
   const int hi = st.log_scalars[LG_LARGEST] + 1;
   st.log_scalars[LG_FIRST_MISSING] = hi < g.S ? hi : g.S;
 }
