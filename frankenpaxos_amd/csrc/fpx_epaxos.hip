@@ -1677,7 +1677,8 @@ int dg_execute_packed(fpx_epx* e, int m, const int32_t* d_leader, const int32_t*
       hipLaunchKernelGGL((k_dp_carry<N>), dim3(N), dim3(1024), 0, e->stream, a, cur ^ 1, k);
       cur ^= 1;
     }
-    EHIP(e, hipMemsetAsync(a.ctl + 3, 0, 8, e->stream));
+    // (ctl[3], the executables, is WRITTEN by the rekey kernel's first workgroup since round 6 and ctl[4], the components,
+    // by the emit kernel's last: nothing accumulates in them any more, so nothing has to be cleared in front of the keys)
     hipLaunchKernelGGL((k_dp_keys<N>), dim3(dp_grid(grid)), dim3(256), 0, e->stream, a);
     uint2* sorted = radix_sort_pairs(e, 1, m, (unsigned)a.hash_bits, a.pairs, a.pairs2, nullptr, &rc, nullptr, nullptr);
     if (rc) return rc;
@@ -1793,7 +1794,8 @@ int dg_execute(fpx_epx* e, int m, const int32_t* d_leader, const int32_t* d_numb
       hipLaunchKernelGGL((k_dg_prefix<N>), dim3(a.ntiles), dim3(256), 0, e->stream, a, round, k);
       hipLaunchKernelGGL((k_dg_relax<N>), dim3(a.ntiles * DG_SUB), dim3(256), 0, e->stream, a, round, k);
     }
-    EHIP(e, hipMemsetAsync(a.ctl + 3, 0, 8, e->stream));
+    // (ctl[3], the executables, is WRITTEN by the rekey kernel's first workgroup since round 6 and ctl[4], the components,
+    // by the emit kernel's last: nothing accumulates in them any more, so nothing has to be cleared in front of the keys)
     hipLaunchKernelGGL((k_dg_keys<N>), dim3(grid), dim3(256), 0, e->stream, a);
     // least significant first: the closures' hashes, then (stable) the closure sums and kinds
     uint2* sorted = radix_sort_pairs(e, 1, m, (unsigned)a.hash_bits, a.pairs, a.pairs2, nullptr, &rc, nullptr, nullptr);
