@@ -707,7 +707,8 @@ def main():
                 # millisecond, which measures the GPU waking up after the fence, not the step -- config 2: 0.018 - 0.032 ms
                 # per step over 20 steps, 0.0121 - 0.0129 over 200 (profiles/r05_small_steps.md)
                 # (config 5's 85 us bands likewise: twice the steps -- its 4M-slot bands are 2 GB of state each; config 4's ticks are drawn on the host, 0.5 s each)
-                sub_steps = (max(1, args.configs_block_steps // 2) if c in ("4_execute", "thrifty_random", "host_path") else
+                # (host_path: the full count -- three calls in flight fill and drain once per region, 5 % of a 10-call region)
+                sub_steps = (max(1, args.configs_block_steps // 2) if c in ("4_execute", "thrifty_random") else
                              max(1, 3 * args.configs_block_steps // 4) if c == "4" else
                              10 * args.configs_block_steps if c in ("2", "3") else
                              2 * args.configs_block_steps if c == "5" else args.configs_block_steps)

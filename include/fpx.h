@@ -397,7 +397,7 @@ int32_t fpx_noop_ranges_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot
  * independent = 0), and the halves run one after the other.  FPX_BAND_SERIAL=1 in the environment keeps the two-launch
  * form off.  HAZARD: under FPX_F_TRUSTED the statement is NOT checked -- a leader group with both a command and a range
  * in an `independent` step makes the range chain's store of an acceptor's round race with the vote kernel's fold of
- * maxima, and the state is silently wrong.  FPX_DEBUG=1 in the environment checks the statement on trusted contexts too
+ * maxima, and the state is silently wrong.  FPX_DEBUG_CHECKS=1 in the environment checks the statement on trusted contexts too
  * (FPX_EORDER, nothing applied; the halves then run one after the other). */
 int32_t fpx_mencius_band_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,
                                    const int32_t* d_value_id, const uint64_t* d_target_mask, uint8_t* d_chosen,

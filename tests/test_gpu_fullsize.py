@@ -259,7 +259,7 @@ def test_config5_band_entry_point_halves_side_by_side(fa, oracle, row_layout, de
     np.testing.assert_array_equal(mg, mr)
 
 
-def test_band_entry_point_when_the_halves_share_a_leader_group(fa, oracle, row_layout):
+def test_band_entry_point_when_the_halves_share_a_leader_group(fa, oracle, row_layout, monkeypatch):
     """the halves are NOT independent: leader group 2 proposes commands in some of its slots and skips others with a range
     in the same step, and a range covers a slot that carries a command.  A validating context refuses the caller's
     `independent` (FPX_EORDER, nothing applied: the state digest does not move) and runs the step in order without it;
@@ -278,11 +278,15 @@ def test_band_entry_point_when_the_halves_share_a_leader_group(fa, oracle, row_l
         gpu.set_stream(torch.cuda.current_stream().cuda_stream)
         for lg in range(L):
             assert gpu.acceptor_phase1a(lg, 0)[0] == 0 and ref.acceptor_phase1a(lg, 0)[0] == 0
-        if flags == 0:
-            before = gpu.state_digest()
-            st, cmd, rng_ = _band_on_device(fa, gpu, fused, ranges, independent=True)
-            assert st == fa.FPX_EORDER and not cmd[0].any() and not rng_[4].any()
-            np.testing.assert_array_equal(gpu.state_digest(), before)
+        # a validating context checks the caller's word; a TRUSTED one only under FPX_DEBUG_CHECKS=1 (the
+        # hazard of a false `independent` there is silent state corruption, include/fpx.h)
+        if flags != 0:
+            monkeypatch.setenv("FPX_DEBUG_CHECKS", "1")
+        before = gpu.state_digest()
+        st, cmd, rng_ = _band_on_device(fa, gpu, fused, ranges, independent=True)
+        assert st == fa.FPX_EORDER and not cmd[0].any() and not rng_[4].any()
+        np.testing.assert_array_equal(gpu.state_digest(), before)
+        monkeypatch.delenv("FPX_DEBUG_CHECKS", raising=False)
         st, cmd, rng_ = _band_on_device(fa, gpu, fused, ranges, independent=False)
         assert st == 0
         b1, b2 = ref.phase2_fused(*fused[1:]), ref.noop_ranges_fused(*ranges[1:])
