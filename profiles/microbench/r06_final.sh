@@ -1,5 +1,5 @@
 set -u; O=gpurun_out/r06final; mkdir -p $O
-for i in 1 2; do FPX_DEBUG=1 timeout 900 python bench.py > $O/bench_$i.json 2> $O/bench_$i.err; echo "bench $i rc=$? bytes=$(wc -c < $O/bench_$i.json)"; done
+for i in 1 2; do timeout 900 python bench.py > $O/bench_$i.json 2> $O/bench_$i.err; echo "bench $i rc=$? bytes=$(wc -c < $O/bench_$i.json)"; done
 python - <<'PY'
 import json
 for i in (1,2):
