@@ -532,6 +532,23 @@ def test_the_acceptors_read_path_through_the_shim(jvm, oracle):
     for a in range(R):
         assert read(a) == voted_truth[a] == ref.read_acceptor(0, a)[1]
     assert not stale[0] and voted_truth[1] < 300                      # acceptor 1 has not voted since its promise
+    # 2b. ADVICE r05: a Nacked tick leaves the group stale, and its rows are recycled BEFORE anybody reads -- the votes
+    #     acceptors 0 and 2 cast in it must not be lost with the rows (Acceptor.scala:208 never misses a vote, and a low
+    #     MaxSlotReply.slot is the unsafe direction): advanceWindow rescans a stale group before it clears rows
+    slots = list(range(1000, 1030))
+    targets = [[(s % R), (s + 1) % R] for s in slots]
+    nr = tick(slots, 0, targets)
+    assert (nr >= 0).any() and stale[0]
+    for a in (0, 2):
+        voted_truth[a] = max(s for s, t in zip(slots, targets) if a in t)
+    if stale[0]:                                                       # GpuPhase2Engine.advanceWindow: refreshStaleGroups()
+        read(0)
+    assert jvm.call("recycleSlots", C.c_int32, h, 0, 2048) == 0
+    ref.recycle_slots(0, 2048)
+    for a in range(R):
+        assert read(a) == voted_truth[a] == ref.read_acceptor(0, a)[1]
+    # (the lazy rescan of round 5 -- recycle first, ask the device at the next read -- finds the rows empty:)
+    assert jvm.call("acceptorMaxVotedIn", C.c_int32, h, 0, 0, 0, 2048) == -1
     # 3. the new leader takes over (round 1) and proposes far ahead in the window; then the window moves on: rows
     #    0 .. 2047 are recycled, base = 2048, and the log goes on in slots 4096 .. -- in rows 0 ..
     phase1a(1, [0, 2])
