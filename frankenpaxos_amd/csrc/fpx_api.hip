@@ -267,9 +267,10 @@ size_t lds_bytes(const fpx_ctx* ctx, bool fused, bool targets) {
 // walking 32 dependent steps each on a machine with room for 6000
 int chunk_for(const fpx_ctx* ctx, int n) {
   if (ctx->lanes_per_slot != 64) return 64;
+  // (FPX_MIN_CHUNK: the sweep of profiles/r06_raw/adversarial_chunk_sweep.txt -- 8 / 4 / 2 / 1 messages per wavefront at ~21 500
+  // messages per launch: 6.12 / 6.50 / 6.55 / 6.53e8 proposals/s; 4 stays)
   static const int min_chunk = [] { const char* e = getenv("FPX_MIN_CHUNK"); return e ? std::max(1, atoi(e)) : 4; }();
-  static const int waves_per_cu = [] { const char* e = getenv("FPX_WANT_WAVES_PER_CU"); return e ? std::max(1, atoi(e)) : 16; }();
-  const long long want_waves = (long long)ctx->num_cus * waves_per_cu;
+  const long long want_waves = (long long)ctx->num_cus * 16;
   int ch = FPX_CHUNK;
   while (ch > min_chunk && (long long)(n + ch - 1) / ch < want_waves) ch >>= 1;
   return ch;
