@@ -2086,7 +2086,12 @@ int32_t fpx_epx_execute(fpx_epx* e, int32_t m, const int32_t* leader, const int3
   if (m == 0) return FPX_OK;
   const int n = e->st.n, stride = fpx_epx_packed_stride(n);
   // the packed lines fpx_epx_preaccept_packed_dev would have written: deps | leader_deps (unused here) | own_values_end | fast
-  std::vector<int32_t> lines((size_t)m * stride, 0);
+  std::vector<int32_t> lines;
+  try {
+    lines.assign((size_t)m * stride, 0);
+  } catch (const std::bad_alloc&) {  // (no exception crosses the C ABI)
+    return FPX_ENOMEM;
+  }
   for (int i = 0; i < m; ++i) {
     if (leader[i] < 0 || leader[i] >= n) return FPX_EINVAL;
     int32_t* line = lines.data() + (size_t)i * stride;
@@ -2287,9 +2292,14 @@ int32_t fpx_epx_handle_commit(fpx_epx* e, int32_t m, const int32_t* leader, cons
   int rc;
   // who writes the entry: walking the batch from its end, a message leaves to the later messages of its instance the
   // replicas they go to
-  std::vector<uint8_t> writer((size_t)m);
+  std::vector<uint8_t> writer;
+  std::vector<std::pair<long long, int>> order;
+  try {
+    writer.resize((size_t)m), order.resize((size_t)m);
+  } catch (const std::bad_alloc&) {  // (no exception crosses the C ABI)
+    return FPX_ENOMEM;
+  }
   {
-    std::vector<std::pair<long long, int>> order((size_t)m);
     for (int i = 0; i < m; ++i) order[i] = {(long long)leader[i] * e->st.num_instances + number[i], i};
     std::sort(order.begin(), order.end());
     for (size_t a = 0; a < order.size();) {
