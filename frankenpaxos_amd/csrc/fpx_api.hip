@@ -8,7 +8,6 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
-#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
