@@ -82,6 +82,7 @@ SIGNATURES = {
     "fpx_placement_stats": (C.c_int32, [VP, C.POINTER(C.c_float)]),
     "fpx_placement_search": (C.c_int32, [VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "fpx_band_merged_steps": (C.c_int64, [VP]),
+    "fpx_deferred_folds": (C.c_int64, [VP]),
     "fpx_acceptor_max_voted_in": (C.c_int32, [VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, I32P]),
     "fpx_profile_read_launches": (C.c_int32, [VP, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "fpx_get_config": (C.c_int32, [VP, CFGP]),

@@ -138,6 +138,10 @@ class Context:
         return {"chunks": bool(out[0]), "windows": int(out[1]), "probe_ms": (float(out[2]), float(out[3]), float(out[4])),
                 "search": {"probes": pr.value, "unprobed_decisions": un.value, "ms": float(ms.value)}}
 
+    def deferred_folds(self):
+        """diagnostic: fused steps whose launch carried the fold of the step before (include/fpx.h)"""
+        return int(self.L.fpx_deferred_folds(self._h))
+
     def band_merged_steps(self):
         """diagnostic: the mencius_band_fused_dev steps that ran in the two-launch form"""
         return int(self.L.fpx_band_merged_steps(self._h))

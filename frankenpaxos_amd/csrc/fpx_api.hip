@@ -97,6 +97,12 @@ struct fpx_ctx {
   float placement_ms = 0.f;                                 // wall clock of the search
   float placement[5] = {0, 0, 0, 0, 0};                     // mode (0 one allocation, 1 chunks), windows, min / median / max probe ms
   uint32_t phase2_launches = 0;
+  // the fold (k_finalize's work) of the last K3 launch, when it has not been launched: it rides in the next eligible vote
+  // kernel (k_phase2_fin) or is launched by whatever touches the context next (DeviceGuard -> flush_pending_fin)
+  FinJob pending_fin = {};       // nblk != 0: pending
+  FinJob carry_fin = {};         // what the launch being enqueued may take into its grid (consumed by launch_phase2_3)
+  State launch_st = {};          // the State of the launch being enqueued: st with ITS half of part / part_stamp
+  long long fins_carried = 0;    // diagnostic
   uint32_t launch_seq = 0;  // stamps the partial-maxima rows of a K1 / K3 launch (never 0 in a row that counts)
   bool batch_increasing = false, batch_one_round = false;  // check_inputs' findings about the current host batch
   bool force_validate = false;  // host-pointer K3's optimistic whole-batch run is validated even under FPX_F_TRUSTED
@@ -148,12 +154,18 @@ namespace {
 // Every entry point runs with the context's device current and restores the caller's on return: allocations
 // (staging buffers, events) and launches otherwise land on whatever device the calling thread last selected --
 // two contexts on two GPUs in one process (or a torch.cuda.set_device elsewhere) would fault.
+void flush_pending_fin(fpx_ctx* ctx);
 struct DeviceGuard {
   int prev = -1;
   bool switched = false;
   explicit DeviceGuard(int device) { enter(device); }
+  // Every entry point that takes the context starts here; all but fpx_phase2_fused_dev (which enters by device number
+  // and deals with a pending fold itself) first launch the fold of the last K3 launch if it is still pending -- so
+  // nothing that reads or moves the acceptors' scalars ever sees them short of a launch (see k_phase2_fin).
   explicit DeviceGuard(const fpx_ctx* ctx) {
-    if (ctx) enter(ctx->cfg.device);
+    if (!ctx) return;
+    enter(ctx->cfg.device);
+    if (ctx->pending_fin.nblk) flush_pending_fin(const_cast<fpx_ctx*>(ctx));
   }
   void enter(int device) {
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
@@ -314,12 +326,24 @@ void launch_phase2_3(fpx_ctx* ctx, const Batch& b0, bool fused, int grid) {
   const size_t lds = phase2_lds(ctx, b, fused, MODE != 0, PS == 0);
   if (fused) allow_lds(k_phase2<G, MODE, PS, true>, lds);
   else allow_lds(k_phase2<G, MODE, PS, false>, lds);
+  if constexpr ((G == 64 || G == 1) && (MODE == 0 || MODE == 2) && PS != 0) {
+    // the fold of the launch before rides in this one (k_phase2_fin: the shapes of the steady streams -- the headline,
+    // configs 2 and 3, the adversarial stream; other shapes leave it to the caller, who launches it by itself)
+    if (fused && ctx->carry_fin.nblk) {
+      allow_lds(k_phase2_fin<G, MODE, PS, true>, lds);
+      hipExtLaunchKernelGGL((k_phase2_fin<G, MODE, PS, true>), dim3(grid + ctx->carry_fin.nblk), dim3(256), (uint32_t)lds, ctx->stream,
+                            ctx->ev_start, ctx->ev_stop, 0, ctx->g, ctx->launch_st, b, ctx->carry_fin);
+      ctx->carry_fin.nblk = 0;
+      ++ctx->fins_carried;
+      return;
+    }
+  }
   if (fused)
     hipExtLaunchKernelGGL((k_phase2<G, MODE, PS, true>), dim3(grid), dim3(256), (uint32_t)lds, ctx->stream, ctx->ev_start,
-                          ctx->ev_stop, 0, ctx->g, ctx->st, b);
+                          ctx->ev_stop, 0, ctx->g, ctx->launch_st, b);
   else
     hipExtLaunchKernelGGL((k_phase2<G, MODE, PS, false>), dim3(grid), dim3(256), (uint32_t)lds, ctx->stream, ctx->ev_start,
-                          ctx->ev_stop, 0, ctx->g, ctx->st, b);
+                          ctx->ev_stop, 0, ctx->g, ctx->launch_st, b);
 }
 
 template <int G, int MODE>
@@ -364,7 +388,7 @@ template <int G>
 void launch_band_g(fpx_ctx* ctx, const Batch& b, size_t lds, int grid, const RangeTable& rt, const RangeBatch& rb) {
   allow_lds(k_phase2_band<G, 0, 0, true>, lds);
   hipExtLaunchKernelGGL((k_phase2_band<G, 0, 0, true>), dim3(grid + 1), dim3(256), (uint32_t)lds, ctx->stream, ctx->ev_start,
-                        ctx->ev_stop, 0, ctx->g, ctx->st, b, rt, rb);
+                        ctx->ev_stop, 0, ctx->g, ctx->launch_st, b, rt, rb);
 }
 void launch_band(fpx_ctx* ctx, const Batch& b, size_t lds, int grid, const RangeTable& rt, const RangeBatch& rb) {
   switch (ctx->lanes_per_slot) {
@@ -414,6 +438,41 @@ int enqueue_validate(fpx_ctx* ctx, Batch& b, bool check_round) {
   return launch_check(ctx);
 }
 
+// The launch counter of a K1 / K3 launch decides which third of part_all (Batch::parity) and which half of part /
+// part_stamp (the State handed to the launch and to its fold) it uses: see finalize_body / k_phase2_fin.
+void begin_phase2_launch(fpx_ctx* ctx, Batch& b) {
+  const uint32_t li = ctx->phase2_launches++;
+  b.parity = (int32_t)(li % 3u);
+  const size_t half = (size_t)(li & 1u), ntab = (size_t)ctx->g.ngroups * ctx->g.R;
+  ctx->launch_st = ctx->st;
+  ctx->launch_st.part = ctx->st.part + half * (size_t)ctx->max_grid * 2 * ntab;
+  ctx->launch_st.part_stamp = ctx->st.part_stamp + half * (size_t)ctx->max_grid;
+}
+
+FinJob fin_job_of(const fpx_ctx* ctx, const Batch& b, int grid) {
+  FinJob fj;
+  const int ntab = ctx->g.ngroups * ctx->g.R;
+  fj.fgx = (ntab + 63) / 64;
+  fj.slices = std::max(FINALIZE_SLICES, std::min(256, grid / 32));  // ~8 partial rows per wavefront
+  fj.nblk = fj.fgx * fj.slices;
+  fj.par = (int)b.parity, fj.grid = grid, fj.seq = b.launch_seq;
+  fj.part = ctx->launch_st.part, fj.part_stamp = ctx->launch_st.part_stamp;
+  return fj;
+}
+
+void launch_fin_alone(fpx_ctx* ctx, const FinJob& fj) {
+  State fs = ctx->st;
+  fs.part = fj.part, fs.part_stamp = fj.part_stamp;
+  hipLaunchKernelGGL(k_finalize, dim3(fj.fgx, fj.slices), dim3(256), 0, ctx->stream, ctx->g, fs, fj.par, fj.grid, fj.seq);
+}
+
+void flush_pending_fin(fpx_ctx* ctx) {
+  if (!ctx->pending_fin.nblk) return;
+  launch_fin_alone(ctx, ctx->pending_fin);
+  ctx->pending_fin.nblk = 0;
+  (void)launch_check(ctx);
+}
+
 // K1 / K3 on one device run
 int enqueue_phase2(fpx_ctx* ctx, Batch& b, bool fused) {
   if (b.n == 0) return FPX_OK;
@@ -445,23 +504,43 @@ int enqueue_phase2(fpx_ctx* ctx, Batch& b, bool fused) {
     // start of the first vote kernel to end of the last (two with the packed walk ahead)
     ctx->ev_start = prof && pass == (two ? 0 : 1) ? ctx->ev[ctx->ev_used] : nullptr;
     ctx->ev_stop = prof && pass == 1 ? ctx->ev[ctx->ev_used + 1] : nullptr;
-    b.parity = b.solo ? 0 : (int32_t)(ctx->phase2_launches++ & 1u);  // every other K1 / K3 launch is followed by its k_finalize
+    if (b.solo) {
+      // (the one workgroup of a solo launch raises the acceptors' scalars with plain loads and stores: nothing may fold
+      // beside it -- a pending fold goes first, by itself)
+      flush_pending_fin(ctx);
+      b.parity = 0, ctx->launch_st = ctx->st;
+    } else {
+      begin_phase2_launch(ctx, b);
+    }
     if (++ctx->launch_seq == 0) ctx->launch_seq = 1;
     b.launch_seq = ctx->launch_seq;
     ctx->packed_pass = pass == 0;
+    // the fold of the launch before, if it is still pending: offered to this launch (launch_phase2_3 takes it into its
+    // grid when the kernel has that form), else launched by itself behind it -- before the launch after this one either way
+    ctx->carry_fin = ctx->pending_fin;
+    ctx->pending_fin.nblk = 0;
     launch_phase2(ctx, b, fused, grid);
     ctx->packed_pass = false;
     ctx->ev_start = ctx->ev_stop = nullptr;
+    if (ctx->carry_fin.nblk) {
+      launch_fin_alone(ctx, ctx->carry_fin);
+      ctx->carry_fin.nblk = 0;
+    }
     rc = launch_check(ctx);
     if (rc) return rc;
     if (pass == 1 && prof) ctx->ev_used += 2;
     if (b.solo) continue;
-    const int ntab = ctx->g.ngroups * ctx->g.R;
-    const int slices = std::max(FINALIZE_SLICES, std::min(256, grid / 32));  // ~8 partial rows per wavefront
-    hipLaunchKernelGGL(k_finalize, dim3((ntab + 63) / 64, slices), dim3(256), 0, ctx->stream, ctx->g, ctx->st,
-                       (int)b.parity, grid, b.launch_seq);
-    rc = launch_check(ctx);
-    if (rc) return rc;
+    // this launch's own fold: with a ballot per cell no vote kernel reads what it writes -- it waits for the next launch
+    // (or for whatever touches the context next); with a round per acceptor the next vote kernel starts from it: at once
+    const FinJob fj = fin_job_of(ctx, b, grid);
+    const bool no_defer = getenv("FPX_NO_DEFER_FINALIZE") != nullptr;  // (read per launch: a test switches it between contexts)
+    if (fused && ctx->g.per_slot && !no_defer) {
+      ctx->pending_fin = fj;
+    } else {
+      launch_fin_alone(ctx, fj);
+      rc = launch_check(ctx);
+      if (rc) return rc;
+    }
   }
   return FPX_OK;
 }
@@ -532,8 +611,9 @@ int init_state(fpx_ctx* ctx) {
   ctx->lazy_active = false;
   HIPCHK(ctx, hipMemsetAsync(st.run_round, 0xFF, (size_t)g.ngroups * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.status, 0, 8 * 4, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(st.part_stamp, 0, (size_t)ctx->max_grid * 4, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(st.part_all, 0xFF, (size_t)2 * 64 * PART_ALL_STRIDE * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.part_stamp, 0, (size_t)2 * ctx->max_grid * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.part_all, 0xFF, (size_t)3 * 64 * PART_ALL_STRIDE * 4, ctx->stream));
+  ctx->pending_fin.nblk = 0, ctx->carry_fin.nblk = 0;
   HIPCHK(ctx, hipMemsetAsync(st.log_value, 0xFF, (size_t)g.S * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.log_present, 0, (size_t)g.S, ctx->stream));
   for (int k = 0; k < 2; ++k) {
@@ -1445,9 +1525,10 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
   if ((rc = dalloc(ctx, &st.run_round, (size_t)g.ngroups))) return fail(rc);
   if ((rc = dalloc(ctx, &st.status, (size_t)8))) return fail(rc);
   ctx->g.part_rows = ctx->max_grid;
-  if ((rc = dalloc(ctx, &st.part, (size_t)ctx->max_grid * 2 * ntab))) return fail(rc);
-  if ((rc = dalloc(ctx, &st.part_stamp, (size_t)ctx->max_grid))) return fail(rc);
-  if ((rc = dalloc(ctx, &st.part_all, (size_t)2 * 64 * PART_ALL_STRIDE))) return fail(rc);
+  // (two halves of the partial rows and their stamps, three thirds of the whole-group shards: finalize_body / k_phase2_fin)
+  if ((rc = dalloc(ctx, &st.part, (size_t)2 * ctx->max_grid * 2 * ntab))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.part_stamp, (size_t)2 * ctx->max_grid))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.part_all, (size_t)3 * 64 * PART_ALL_STRIDE))) return fail(rc);
   if ((rc = dalloc(ctx, &st.log_value, (size_t)g.S))) return fail(rc);
   if ((rc = dalloc(ctx, &st.log_present, (size_t)g.S))) return fail(rc);
   if ((rc = dalloc(ctx, &st.log_scalars, (size_t)LG_PARTS_AT + 2 * LG_MAX_PARTS))) return fail(rc);
@@ -1576,6 +1657,8 @@ int32_t fpx_placement_stats(fpx_ctx* ctx, float out[5]) {
   return FPX_OK;
 }
 
+int64_t fpx_deferred_folds(fpx_ctx* ctx) { return ctx ? ctx->fins_carried : 0; }
+
 int32_t fpx_placement_search(fpx_ctx* ctx, int32_t* probes, int32_t* unprobed, float* ms) {
   if (!ctx) return FPX_EINVAL;
   if (probes) *probes = ctx->placement_probes;
@@ -1687,8 +1770,8 @@ int32_t fpx_wire_decode_acceptor_inbound_dev(fpx_ctx* ctx, const uint8_t* d_buf,
 int32_t fpx_phase2_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot, const int32_t* d_round,
                              const int32_t* d_value_id, const uint64_t* d_target_mask, uint8_t* d_chosen,
                              int32_t* d_chosen_round, int32_t* d_chosen_value, int32_t* d_nack_round) {
-  DeviceGuard _dg(ctx);
   if (!ctx || n < 0) return FPX_EINVAL;
+  DeviceGuard _dg(ctx->cfg.device);  // (by device number: a pending fold of the launch before is this call's to carry)
   Batch b;
   memset(&b, 0, sizeof(b));
   b.n = n, b.slot = d_slot, b.round = d_round, b.value = d_value_id, b.target = d_target_mask;
@@ -1813,7 +1896,8 @@ int32_t fpx_phase2_fused(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int
 int32_t fpx_phase2_fused_submit(fpx_ctx* ctx, int32_t n, const int32_t* slot, const int32_t* round, const int32_t* value_id,
                                 const uint64_t* target_mask, uint8_t* chosen, int32_t* chosen_round, int32_t* chosen_value,
                                 int32_t* nack_round, int32_t* ticket) {
-  DeviceGuard _dg(ctx);
+  if (!ctx) return FPX_EINVAL;
+  DeviceGuard _dg(ctx->cfg.device);  // (by device number, like fpx_phase2_fused_dev: the fold of the call before rides in this one's)
   int rc = check_args(ctx, n, slot, round);
   if (rc) return rc;
   if (n == 0 || !value_id || !ticket) return FPX_EINVAL;
@@ -1824,8 +1908,8 @@ int32_t fpx_phase2_fused_submit(fpx_ctx* ctx, int32_t n, const int32_t* slot, co
 }
 
 int32_t fpx_phase2_fused_wait(fpx_ctx* ctx, int32_t ticket) {
-  DeviceGuard _dg(ctx);
   if (!ctx) return FPX_EINVAL;
+  DeviceGuard _dg(ctx->cfg.device);  // (waits for an event and reads the call's status words: no state is touched)
   return host_wait(ctx, ticket);
 }
 
@@ -2108,7 +2192,7 @@ static int enqueue_band_merged(fpx_ctx* ctx, Batch& b, RangeBatch& rb, bool* don
   if (rc) return rc;
   const int grid = grid_for(ctx, b.n);
   b.solo = 0;
-  b.parity = (int32_t)(ctx->phase2_launches++ & 1u);
+  begin_phase2_launch(ctx, b);
   if (++ctx->launch_seq == 0) ctx->launch_seq = 1;
   b.launch_seq = ctx->launch_seq;
   rb.run_id = ++ctx->run_id;
@@ -2127,8 +2211,8 @@ static int enqueue_band_merged(fpx_ctx* ctx, Batch& b, RangeBatch& rb, bool* don
   const int gy = std::min(rb.n, 4096);
   const int gx = std::max(1, std::min(ctx->num_cus * 16 / gy, 64));
   const int fin_rows = (fgx * slices + gx - 1) / gx;
-  hipLaunchKernelGGL(k_ranges_fill_lg_fin, dim3(gx, gy + fin_rows), dim3(256), 0, ctx->stream, g, ctx->st, rb, gy, fin_rows, (int)b.parity,
-                     grid, b.launch_seq, fgx, slices);
+  hipLaunchKernelGGL(k_ranges_fill_lg_fin, dim3(gx, gy + fin_rows), dim3(256), 0, ctx->stream, g, ctx->launch_st, rb, gy, fin_rows,
+                     (int)b.parity, grid, b.launch_seq, fgx, slices);
   *done = true;
   ++ctx->band_merged_steps;
   return launch_check(ctx);

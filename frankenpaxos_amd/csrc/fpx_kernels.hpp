@@ -128,7 +128,7 @@ struct State {
   int32_t* part;        // [grid][2][ngroups*R] per-workgroup maxima rows (accepted round, voted slot)
   uint32_t* part_stamp; // [grid] the launch (Batch::launch_seq) that wrote row b of `part`: a workgroup that used the
                         //        tables writes row blockIdx.x -- no claiming counter (8192 same-address atomics were 65 us)
-  int32_t* part_all;    // [2][64][PART_ALL_STRIDE] whole-group maxima (round, slot), 64 lines, per launch parity
+  int32_t* part_all;    // [3][64][PART_ALL_STRIDE] whole-group maxima (round, slot), 64 lines, per launch counter mod 3
   int32_t* log_value;   // [S]  the replica's log (BufferMap), -1 where absent
   uint8_t* log_present; // [S]
   int32_t* log_scalars; // [8]  LG_*: executedWatermark, numChosen, largestKey, scan result
@@ -149,7 +149,7 @@ struct Batch {
   uint8_t* is_new;         // k_open
   const uint8_t* mask;     // k_log_ingest: which messages are Chosen (null = all)
   uint32_t run_id;
-  int32_t parity;          // K1 / K3 launch counter & 1: which half of part_all this launch uses
+  int32_t parity;          // K1 / K3 launch counter mod 3: which third of part_all this launch uses
   uint32_t launch_seq;     // K1 / K3 launch counter (never 0): stamps the rows of `part` this launch writes
   int32_t check_round;     // validate: enforce one round per group (ACCEPTOR ballot mode)
   int32_t chunk;           // K1 / K3 at G = 64: messages per wavefront (4 .. FPX_CHUNK)
@@ -505,14 +505,22 @@ __global__ void __launch_bounds__(64) k_status_snap(const int32_t* status, int32
 constexpr int FINALIZE_SLICES = 8;  // at least; the launch uses more for big grids (about 8 rows per wavefront)
 // (the body by workgroup coordinates: k_finalize is its own grid, k_ranges_fill_lg_fin -- fpx_ranges.hpp -- appends
 // these workgroups to a Mencius band's fill)
-__device__ __forceinline__ void finalize_body(const Geom& g, const State& st, int par, int grid, uint32_t seq, int fx, int fy, int slices) {
+// part_all has THREE buffers (launch counter mod 3).  The fold of launch k may run as late as INSIDE launch k + 1 (round 6: the
+// deferred fold, k_phase2_fin below), which writes buffer k + 1; so the buffer a fold clears for reuse is k + 2's (last
+// folded by launch k - 1's fold, which was complete before launch k + 1 began).  A fold that runs at once behind its
+// launch clears the same one: launch k + 1's was cleared by the fold of launch k - 1.
+// carried: the fold rides in the NEXT launch, whose validation may have set ST_ABORT -- that is no statement about the launch
+// being folded (which, had IT been aborted, left nothing to fold: its shards read -1, none of its rows is stamped).
+__device__ __forceinline__ void finalize_body(const Geom& g, const State& st, int par, int grid, uint32_t seq, int fx, int fy, int slices,
+                                              bool carried = false) {
   __shared__ int32_t red[2][4][64];
-  // the buffers of the OTHER parity are used by the next launch: clear them here, whatever happens
+  // the shards of the launch after next: clear them here, whatever happens
   if (fx == 0 && fy == 0) {
+    const int clr = par >= 1 ? par - 1 : 2;  // (par + 2) % 3
     if (threadIdx.x < 128)
-      st.part_all[((size_t)(par ^ 1) * 64 + (threadIdx.x >> 1)) * PART_ALL_STRIDE + (threadIdx.x & 1)] = -1;
+      st.part_all[((size_t)clr * 64 + (threadIdx.x >> 1)) * PART_ALL_STRIDE + (threadIdx.x & 1)] = -1;
   }
-  if (st.status[ST_ABORT] != 0) return;
+  if (!carried && st.status[ST_ABORT] != 0) return;
   const int ntab = g.ngroups * g.R;
   const int nblocks = grid < g.part_rows ? grid : g.part_rows;
   const int e = fx * 64 + (threadIdx.x & 63);
@@ -554,6 +562,40 @@ __device__ __forceinline__ void finalize_body(const Geom& g, const State& st, in
 __global__ void __launch_bounds__(256) k_finalize(const Geom g, const State st, int par, int grid, uint32_t seq) {
   finalize_body(g, st, par, grid, seq, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
 }
+
+// ---- the fold of the launch BEFORE, as the first workgroups of this launch (round 6) --------------------------------------
+// Every K1 / K3 launch used to be followed by k_finalize: a dependent launch of ~5 us and the gap in front of it -- 12 us
+// of the headline's 560 us step, 9 of config 2's 13.  With a ballot per cell (FPX_BALLOT_PER_SLOT) no vote kernel reads what
+// the fold writes (max_ballot, max_voted: Phase1a and the read-backs do), so the fold of launch k may ride in launch k + 1:
+// k_phase2_fin = the vote kernel whose first fj.nblk workgroups fold the launch before (its shards of part_all, its half of
+// the partial rows -- the two halves of `part` / `part_stamp` alternate from launch to launch, the State a launch is
+// handed points at its own).  Anything else that touches the context first folds what is pending (DeviceGuard), so the
+// deferral is not observable through the ABI.  FPX_NO_DEFER_FINALIZE=1 switches it off.
+struct FinJob {
+  int nblk;              // workgroups that fold (fgx * slices; 0: nothing pending)
+  int fgx, slices, par, grid;
+  uint32_t seq;
+  int32_t* part;         // the folded launch's half of State::part / part_stamp
+  uint32_t* part_stamp;
+};
+#define FPX_P2_NAME k_phase2_fin
+#define FPX_P2_EXTRA_PARAMS , const FinJob fj
+#define FPX_P2_NBLK (gridDim.x - fj.nblk)
+#define FPX_P2_BID (blockIdx.x - fj.nblk)
+#define FPX_P2_PROLOGUE                                                                                                   \
+  if ((int)blockIdx.x < fj.nblk) {                                                                                        \
+    State fs = st;                                                                                                        \
+    fs.part = fj.part, fs.part_stamp = fj.part_stamp;                                                                     \
+    finalize_body(g, fs, fj.par, fj.grid, fj.seq, (int)blockIdx.x % fj.fgx, (int)blockIdx.x / fj.fgx, fj.slices, true); \
+    return;                                                                                                               \
+  }
+#include "fpx_phase2_body.inc"
+#undef FPX_P2_NAME
+#undef FPX_P2_EXTRA_PARAMS
+#undef FPX_P2_NBLK
+#undef FPX_P2_BID
+#undef FPX_P2_PROLOGUE
+
 
 // ------------------------------------------------------------------------------------------------
 // k_open: ProxyLeader.handlePhase2a bookkeeping (ProxyLeader.scala:175-184, 213). Thread / message.

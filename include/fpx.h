@@ -407,6 +407,13 @@ int32_t fpx_mencius_band_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slo
                                    uint64_t* d_range_vote_bits, uint64_t* d_range_nack_bits,
                                    int32_t* d_range_nack_round, uint8_t* d_range_is_new, uint8_t* d_range_chosen,
                                    int32_t independent);
+/* diagnostic: the fused steps since fpx_create whose launch carried the fold of the step before in its own grid.  Every K1 /
+ * K3 launch is followed by a fold of the maxima its workgroups left (Acceptor.round / maxVotedSlot, multipaxos/Acceptor.scala:
+ * 204-209, as scalars per acceptor); with a ballot per cell (FPX_BALLOT_PER_SLOT) no vote kernel reads those scalars, so the
+ * fold of one fpx_phase2_fused_dev call waits for the next one and rides in its launch (or is launched by whatever entry
+ * point touches the context first: the deferral is not observable through this ABI).  FPX_NO_DEFER_FINALIZE=1 in the
+ * environment launches every fold at once, as rounds 1 - 5 did. */
+int64_t fpx_deferred_folds(fpx_ctx* ctx);
 /* diagnostic: the steps of fpx_mencius_band_fused_dev that ran in the two-launch form since fpx_create */
 int64_t fpx_band_merged_steps(fpx_ctx* ctx);
 /* batches of one (bitmaps num_groups x 4 words) */

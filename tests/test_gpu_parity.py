@@ -924,3 +924,69 @@ def test_page_locked_calls_on_the_headline_shape(fa, oracle, ballot_mode):
     assert (stale["nr"].array == 1).all() and not stale["ch"].array.any()
     np.testing.assert_array_equal(gpu.state_digest(), ref.state_digest())
     gpu.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,q", [(256, 128), (4, 3)])
+def test_the_fold_that_rides_in_the_next_launch_is_not_observable(fa, oracle, monkeypatch, R, q):
+    """Round 6: with a ballot per cell the fold of a fused step's maxima (Acceptor.round / maxVotedSlot as per-acceptor
+    scalars) waits for the NEXT fused step and rides in its launch (k_phase2_fin; include/fpx.h, fpx_deferred_folds).
+    Device-resident steps back to back -- the adversarial stream with its Phase1a's (every one of them an entry point
+    that folds what is pending first), read-backs between steps, a reset in the middle -- leave exactly the state of a
+    context that folds at once (FPX_NO_DEFER_FINALIZE=1) and of the oracle; and folds did ride."""
+    import torch
+
+    S = 1 << 15
+    kw = dict(num_slots=S, num_replicas=R, f=q - 1, ballot_mode=1, tally_ways=8)
+    script = W.adversarial_script(S, R, q, 5, epochs=32, fused=True, subsets=W.fast_subsets)
+    dev = torch.device("cuda:0")
+    d = lambda a, view=None: torch.from_numpy(np.ascontiguousarray(a) if view is None else np.ascontiguousarray(a).view(view)).to(dev)
+
+    def run(ctx):
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        seen = []
+        for k, op in enumerate(script):
+            if op[0] == "phase1a":
+                _, g_, rnd, wm, tgt = op
+                ctx.acceptor_phase1a_dev(g_, rnd, wm, None if tgt is None else d(tgt, np.int64))
+            else:
+                _, slot, rr, val, tgt = op
+                n = len(slot)
+                outs = [torch.zeros(n, dtype=torch.uint8, device=dev)] + [torch.full((n,), -7, dtype=torch.int32, device=dev) for _ in range(3)]
+                ctx.phase2_fused_dev(d(slot), d(rr), d(val), d(tgt, np.int64), *outs)
+                if k % 7 == 3:
+                    seen.append(ctx.read_acceptor(0, R - 1)[:2])          # (promised, maxVotedSlot) between two steps
+        assert ctx.sync() == 0
+        return seen
+
+    monkeypatch.delenv("FPX_NO_DEFER_FINALIZE", raising=False)
+    a = fa.Context(fa.make_config(flags=fa.FPX_F_SCATTERED_TARGETS | fa.FPX_F_TRUSTED, **kw))
+    seen_a = run(a)
+    assert a.deferred_folds() > 8, a.deferred_folds()
+    monkeypatch.setenv("FPX_NO_DEFER_FINALIZE", "1")
+    b = fa.Context(fa.make_config(flags=fa.FPX_F_SCATTERED_TARGETS | fa.FPX_F_TRUSTED, **kw))
+    seen_b = run(b)
+    assert b.deferred_folds() == 0 and seen_a == seen_b
+    ref = oracle.System(oracle.make_config(**kw))
+    W.run_script(ref, script)
+    np.testing.assert_array_equal(a.state_digest(), b.state_digest())
+    np.testing.assert_array_equal(a.state_digest(), ref.state_digest())
+    for r in (0, R // 2, R - 1):
+        x, y, z = a.read_acceptor(0, r), b.read_acceptor(0, r), ref.read_acceptor(0, r)
+        assert x[:2] == y[:2] == z[:2]
+    # a reset with a fold pending, then the steady stream: the scalars are the new life's
+    monkeypatch.delenv("FPX_NO_DEFER_FINALIZE")
+    slot, rnd, val = W.steady_stream(4096)
+    outs = [torch.zeros(4096, dtype=torch.uint8, device=dev)] + [torch.full((4096,), -7, dtype=torch.int32, device=dev) for _ in range(3)]
+    a.phase2_fused_dev(d(slot), d(rnd + 40), d(val), None, *outs)
+    a.reset()
+    ref.reset()
+    assert a.acceptor_phase1a(0, 0)[0] == 0 and ref.acceptor_phase1a(0, 0)[0] == 0
+    a.phase2_fused_dev(d(slot), d(rnd), d(val), None, *outs)
+    a.phase2_fused_dev(d(slot + 4096), d(rnd), d(val), None, *outs)
+    ref.phase2_fused(slot, rnd, val)
+    ref.phase2_fused(slot + 4096, rnd, val)
+    assert a.sync() == 0 and bool(outs[0].all())
+    np.testing.assert_array_equal(a.state_digest(), ref.state_digest())
+    assert a.read_acceptor(0, 0)[:2] == ref.read_acceptor(0, 0)[:2]
+    a.close(), b.close()
