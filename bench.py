@@ -751,6 +751,9 @@ def main():
                 traffic = None
         kernel = "k_phase2<64,vec4,%s,%s>" % ("per_slot" if ballot_mode == 1 else "acceptor",
                                                "K1" if replica_shard else "fused")
+        if ballot_mode == 1 and not replica_shard and not os.environ.get("FPX_NO_DEFER_FINALIZE"):
+            # (round 6: the fold of the step before rides as the first workgroups of the vote kernel's launch)
+            kernel = "k_phase2_fin<64,vec4,per_slot,fused> (k_phase2 + the fold of the step before in its grid)"
         line = {
             "metric": METRIC,
             "value": committed / elapsed,

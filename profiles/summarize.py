@@ -22,9 +22,12 @@ def agg(path):
 
 
 def pick(d, needle):
-    for (k, c), v in d.items():
-        if needle in k:
-            return v
+    # (round 6: with a ballot per cell the steady launches are k_phase2_fin -- the vote kernel with the fold of the step
+    # before as its first workgroups; the first launch of a stream, with nothing to fold, is a plain k_phase2)
+    for n in ([needle.replace("k_phase2", "k_phase2_fin")] if needle.startswith("k_phase2") else []) + [needle]:
+        for (k, c), v in d.items():
+            if n in k:
+                return v
     return float("nan")
 
 
@@ -52,7 +55,7 @@ except Exception:
 kept.update(traffic)
 json.dump(kept, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 stats = list(csv.DictReader(open(os.path.join(out, tag + "_kernel_stats.csv"))))
-k2 = [r for r in stats if "k_phase2" in r["Name"]][0]
+k2 = ([r for r in stats if "k_phase2_fin<64" in r["Name"]] + [r for r in stats if "k_phase2" in r["Name"]])[0]
 bench = json.load(open(os.path.join(base, "trace_bench.json")))
 with open(os.path.join(out, tag + "_pmc_summary.md"), "w") as f:
     f.write("# %s rocprofv3 summary\n\n" % tag)
