@@ -594,17 +594,19 @@ def adversarial_line(args, fa, dev, local_rank, seed=1):
     reps = max(1, args.steps // 4)          # a "step" here is the WHOLE stream (64 epochs); a few repetitions, the last one verified
     run()                                   # warm-up: scratch buffers reach their size
     assert ctx.sync() == 0
-    times = []
+    times, t_enq = [], []
     for _ in range(reps):
         ctx.reset()
         assert ctx.sync() == 0
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run()
+        t_enq.append(time.perf_counter() - t0)
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
         assert ctx.sync() == 0
     dt = sorted(times)[len(times) // 2]
+    enqueue_ms = sorted(t_enq)[len(t_enq) // 2] * 1e3   # host time to enqueue one pass (92 calls): the stream must not be bound by it
     # AFTER the timed region: the oracle replays the script message by message; every output of every epoch must agree
     pyoracle.build()
     ref = pyoracle.System(pyoracle.make_config(**kw))
@@ -644,17 +646,18 @@ def adversarial_line(args, fa, dev, local_rank, seed=1):
                                "one step = the whole stream" % seed,
                    "baseline_config": "adversarial", "ballot_model": args.ballot, "proposals": proposals,
                    "fused_launches": len(fused_ops), "phase1a_calls": len(ops) - len(fused_ops), "chosen": chosen, "nacked": nacked,
+                   "host_enqueue_ms_per_pass": enqueue_ms,
                    "verified": "AFTER the timed region: chosen flag / round / value and Nack round of every proposal of every epoch "
                                "and the whole-state digest == the CPU oracle replaying the script message by message (%.1f s)" % t_or},
-        "roofline": {"bound": "hbm", "kernel": "k_phase2<64, 2, *, fused> x 64 + k_finalize + the Phase1a kernels",
+        "roofline": {"bound": "hbm", "kernel": "k_phase2_fin<64, 2, *, fused> x 64 (each with the fold of the launch before) + k_p1a_fast x 28",
                      "achieved": bps * proposals / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": bps * proposals / dt / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of("adversarial", args.ballot),
                      "traffic_round": traffic_entry(traffic_key("adversarial", args.ballot))[1],
                      "algorithmic_bytes_per_unit": bps, "units_per_launch": proposals / max(1, len(fused_ops)),
                      "avg_kernel_ms": dt * 1e3, "launches_timed": reps,
                      "kernel_time_source": "wall clock around the whole stream (perf_counter between synchronisations), median of the repetitions",
-                     "note": "about 21 500 proposals per launch: each launch is a read-modify-write of partially voted rows at the HBM "
-                             "rate plus ~10 us of small dependent kernels (profiles/r03_adversarial.txt)"},
+                     "note": "about 21 500 proposals per launch: each launch is a read-modify-write of partially voted rows (~3.9 KB of "
+                             "traffic per proposal) + 4.8 us of launch floor; a Phase1a is one 5 us launch (profiles/r06_phase1a.md)"},
     }
 
 

@@ -97,6 +97,8 @@ struct fpx_ctx {
   float placement_ms = 0.f;                                 // wall clock of the search
   float placement[5] = {0, 0, 0, 0, 0};                     // mode (0 one allocation, 1 chunks), windows, min / median / max probe ms
   uint32_t phase2_launches = 0;
+  int lz_min_from = 0x7fffffff;     // the smallest watermark of any Phase1a since the lazy records were last cleared: a Phase1a whose
+                                    // watermark is not above it cannot meet an older record that starts below its own (k_p1a_fast)
   // the fold (k_finalize's work) of the last K3 launch, when it has not been launched: it rides in the next eligible vote
   // kernel (k_phase2_fin) or is launched by whatever touches the context next (DeviceGuard -> flush_pending_fin)
   FinJob pending_fin = {};       // nblk != 0: pending
@@ -607,8 +609,8 @@ int init_state(fpx_ctx* ctx) {
   HIPCHK(ctx, hipMemsetAsync(st.lz_round, 0xFF, (nsc + 4) * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.lz_from, 0, (nsc + 4) * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.max_ballot, 0xFF, (nsc + 4) * 4, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(st.p1, 0, ((size_t)4 * g.R + 8) * 4, ctx->stream));
-  ctx->lazy_active = false;
+  HIPCHK(ctx, hipMemsetAsync(st.p1, 0, ((size_t)4 * g.R + 64) * 4, ctx->stream));
+  ctx->lazy_active = false, ctx->lz_min_from = 0x7fffffff;
   HIPCHK(ctx, hipMemsetAsync(st.run_round, 0xFF, (size_t)g.ngroups * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.status, 0, 8 * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(st.part_stamp, 0, (size_t)2 * ctx->max_grid * 4, ctx->stream));
@@ -1521,7 +1523,7 @@ int32_t fpx_create(const fpx_config* cfg, fpx_ctx** out) {
   if ((rc = dalloc(ctx, &st.lz_round, nsc + 4))) return fail(rc);
   if ((rc = dalloc(ctx, &st.lz_from, nsc + 4))) return fail(rc);
   if ((rc = dalloc(ctx, &st.max_ballot, nsc + 4))) return fail(rc);
-  if ((rc = dalloc(ctx, &st.p1, (size_t)4 * g.R + 8))) return fail(rc);
+  if ((rc = dalloc(ctx, &st.p1, (size_t)4 * g.R + 64))) return fail(rc);
   if ((rc = dalloc(ctx, &st.run_round, (size_t)g.ngroups))) return fail(rc);
   if ((rc = dalloc(ctx, &st.status, (size_t)8))) return fail(rc);
   ctx->g.part_rows = ctx->max_grid;
@@ -1968,20 +1970,35 @@ int32_t fpx_proxy_phase2b(fpx_ctx* ctx, int32_t n, const int32_t* slot, const in
   return fetch_status(ctx);
 }
 
-// Phase1a on device-resident arguments, asynchronous: d_target_mask 4 words or NULL, d_out 8 words = promised
-// bits then nack bits (zeroed here)
-static int enqueue_phase1a(fpx_ctx* ctx, int group, int round, int watermark, const uint64_t* d_tgt, uint64_t* d_out) {
+// Phase1a on device-resident arguments, asynchronous: d_target_mask 4 words or NULL, d_outp / d_outn 4 words each = promised
+// bits, nack bits (both written in full).  With a ballot per cell: ONE launch (k_p1a_fast) that leaves a pending fold pending
+// -- the callers enter by device number, like fpx_phase2_fused_dev; FPX_P1A_SPLIT=1 is the order of rounds 2 - 5 (fold,
+// k_p1a_decide, k_p1a_sweep as launches of their own).
+static int enqueue_phase1a(fpx_ctx* ctx, int group, int round, int watermark, const uint64_t* d_tgt, uint64_t* d_outp,
+                           uint64_t* d_outn) {
   int rc;
-  const dim3 gr(1), blk(256);  // R <= 256: one block, which also initialises d_out
+  const int wm = watermark < 0 ? 0 : watermark;
+  const dim3 gr(1), blk(256);  // R <= 256: one block, which also initialises the reply bits
   if (!ctx->g.per_slot) {
-    hipLaunchKernelGGL(k_phase1a_scalar, gr, blk, 0, ctx->stream, ctx->g, ctx->st, group, round, d_tgt, d_out);
-  } else {
+    flush_pending_fin(ctx);    // (nothing is ever pending with a round per acceptor)
+    hipLaunchKernelGGL(k_phase1a_scalar, gr, blk, 0, ctx->stream, ctx->g, ctx->st, group, round, d_tgt, d_outp, d_outn);
+  } else if (wm > ctx->lz_min_from || getenv("FPX_P1A_SPLIT")) {
+    // the watermark passes the start of an older lazy promise, maybe (the host knows every watermark it handed in): the
+    // cells in between keep the older promise, which k_p1a_sweep first writes into them
+    flush_pending_fin(ctx);
     // O(R) unless the Phase1a is stale for some acceptor or an older lazy promise has to be made explicit below
     // the new watermark: k_p1a_sweep returns at once in the common case; when it does sweep, its last block writes
     // the swept acceptors' promises (those none of whose cells was ahead)
-    hipLaunchKernelGGL(k_p1a_decide, gr, blk, 0, ctx->stream, ctx->g, ctx->st, group, round, watermark, d_tgt, d_out);
+    hipLaunchKernelGGL(k_p1a_decide, gr, blk, 0, ctx->stream, ctx->g, ctx->st, group, round, watermark, d_tgt, d_outp, d_outn);
     hipLaunchKernelGGL(k_p1a_sweep, dim3(ctx->num_cus * 2), dim3(256), 0, ctx->stream, ctx->g, ctx->st, group, round,
-                       watermark, d_out);
+                       watermark, d_outp, d_outn);
+    ctx->lz_min_from = std::min(ctx->lz_min_from, wm);
+    ctx->lazy_active = true;
+  } else {
+    // (the pending fold stays pending: the decision takes the launch's bound from its shards of part_all)
+    hipLaunchKernelGGL(k_p1a_fast, dim3(ctx->num_cus * 2), blk, 0, ctx->stream, ctx->g, ctx->st,
+                       ctx->pending_fin.nblk ? ctx->pending_fin.par : -1, group, round, watermark, d_tgt, d_outp, d_outn);
+    ctx->lz_min_from = std::min(ctx->lz_min_from, wm);
     ctx->lazy_active = true;
   }
   if ((rc = launch_check(ctx))) return rc;
@@ -1990,27 +2007,25 @@ static int enqueue_phase1a(fpx_ctx* ctx, int group, int round, int watermark, co
 
 int32_t fpx_acceptor_phase1a_dev(fpx_ctx* ctx, int32_t group, int32_t round, int32_t chosen_watermark,
                                  const uint64_t* d_target_mask, uint64_t* d_promised_bits, uint64_t* d_nack_bits) {
-  DeviceGuard _dg(ctx);
   if (!ctx || group < 0 || group >= ctx->g.ngroups || round < 0 || round > MAX_ROUND) return FPX_EINVAL;
+  DeviceGuard _dg(ctx->cfg.device);  // (a pending fold stays pending: enqueue_phase1a)
   int rc;
   if ((rc = grow(ctx, &ctx->d_scratch, 128))) return rc;
-  uint64_t* d_out = (uint64_t*)ctx->d_scratch.p;  // [8]: promised bits, nack bits
-  if ((rc = enqueue_phase1a(ctx, group, round, chosen_watermark, d_target_mask, d_out))) return rc;
-  if (d_promised_bits) HIPCHK(ctx, hipMemcpyAsync(d_promised_bits, d_out, 32, hipMemcpyDeviceToDevice, ctx->stream));
-  if (d_nack_bits) HIPCHK(ctx, hipMemcpyAsync(d_nack_bits, d_out + 4, 32, hipMemcpyDeviceToDevice, ctx->stream));
-  return FPX_OK;
+  uint64_t* d_out = (uint64_t*)ctx->d_scratch.p;  // [8]: promised bits, nack bits the caller does not want
+  return enqueue_phase1a(ctx, group, round, chosen_watermark, d_target_mask, d_promised_bits ? d_promised_bits : d_out,
+                         d_nack_bits ? d_nack_bits : d_out + 4);
 }
 
 int32_t fpx_acceptor_phase1a(fpx_ctx* ctx, int32_t group, int32_t round, int32_t chosen_watermark,
                              const uint64_t* target_mask, uint64_t* promised_bits, uint64_t* nack_bits) {
-  DeviceGuard _dg(ctx);
   if (!ctx || group < 0 || group >= ctx->g.ngroups || round < 0 || round > MAX_ROUND) return FPX_EINVAL;
+  DeviceGuard _dg(ctx->cfg.device);
   int rc;
   if ((rc = grow(ctx, &ctx->d_scratch, 128))) return rc;
   uint64_t* d_out = (uint64_t*)ctx->d_scratch.p;       // [8]: promised bits, nack bits
   uint64_t* d_tgt = target_mask ? d_out + 8 : nullptr;  // [4]
   if (target_mask) HIPCHK(ctx, hipMemcpyAsync(d_tgt, target_mask, 32, hipMemcpyHostToDevice, ctx->stream));
-  if ((rc = enqueue_phase1a(ctx, group, round, chosen_watermark, d_tgt, d_out))) return rc;
+  if ((rc = enqueue_phase1a(ctx, group, round, chosen_watermark, d_tgt, d_out, d_out + 4))) return rc;
   uint64_t h[8];
   HIPCHK(ctx, hipMemcpyAsync(h, d_out, 64, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -2028,7 +2043,7 @@ static int flush_promises(fpx_ctx* ctx) {
   hipLaunchKernelGGL(k_lazy_clear, dim3((nsc + 255) / 256), dim3(256), 0, ctx->stream, ctx->g, ctx->st);
   int rc = launch_check(ctx);
   if (rc) return rc;
-  ctx->lazy_active = false;
+  ctx->lazy_active = false, ctx->lz_min_from = 0x7fffffff;
   return FPX_OK;
 }
 

@@ -119,7 +119,7 @@ struct State {
   int32_t* lz_round;    // [ngroups][R]   -1 = none
   int32_t* lz_from;     // [ngroups][R]   first slot the lazy promise covers (the Phase1a's chosenWatermark)
   int32_t* max_ballot;  // [ngroups][R]   an upper bound of the acceptor's effective ballots
-  int32_t* p1;          // [4][R] + 1     scratch of one Phase1a: mode / a / b / c per acceptor, then the "sweep needed" flag
+  int32_t* p1;          // [4][R] + 8     scratch of one Phase1a: mode / a / b / c per acceptor, then its control words (P1_SWEEP ..)
   uint8_t* row_voted;   // [S]            0 = no acceptor of the slot's group has ever voted in it (its cells
                         //                are all -1): partially voted cells can then be written whole without a read
   uint32_t* stamp;      // [S]            run id of the last run that touched the slot
@@ -128,7 +128,7 @@ struct State {
   int32_t* part;        // [grid][2][ngroups*R] per-workgroup maxima rows (accepted round, voted slot)
   uint32_t* part_stamp; // [grid] the launch (Batch::launch_seq) that wrote row b of `part`: a workgroup that used the
                         //        tables writes row blockIdx.x -- no claiming counter (8192 same-address atomics were 65 us)
-  int32_t* part_all;    // [3][64][PART_ALL_STRIDE] whole-group maxima (round, slot), 64 lines, per launch counter mod 3
+  int32_t* part_all;    // [3][64][PART_ALL_STRIDE] whole-group maxima (round, slot) + the largest round of any message, 64 lines, per launch counter mod 3
   int32_t* log_value;   // [S]  the replica's log (BufferMap), -1 where absent
   uint8_t* log_present; // [S]
   int32_t* log_scalars; // [8]  LG_*: executedWatermark, numChosen, largestKey, scan result
@@ -519,6 +519,8 @@ __device__ __forceinline__ void finalize_body(const Geom& g, const State& st, in
     const int clr = par >= 1 ? par - 1 : 2;  // (par + 2) % 3
     if (threadIdx.x < 128)
       st.part_all[((size_t)clr * 64 + (threadIdx.x >> 1)) * PART_ALL_STRIDE + (threadIdx.x & 1)] = -1;
+    else if (threadIdx.x < 192)  // (word 2: the largest round a partial row of the launch holds, what k_p1a_fast reads)
+      st.part_all[((size_t)clr * 64 + (threadIdx.x - 128)) * PART_ALL_STRIDE + 2] = -1;
   }
   if (!carried && st.status[ST_ABORT] != 0) return;
   const int ntab = g.ngroups * g.R;
@@ -683,10 +685,10 @@ __global__ void __launch_bounds__(256) k_tally(const Geom g, const State st, con
 // ------------------------------------------------------------------------------------------------
 // Phase1a (Acceptor.scala:148-182)
 // ------------------------------------------------------------------------------------------------
-// ACCEPTOR mode: ONE block, one thread per acceptor of the group (R <= 256).  out[0..3] promised bits,
-// out[4..7] nack bits, assembled in LDS and written whole (no zeroing pass before the launch)
+// ACCEPTOR mode: ONE block, one thread per acceptor of the group (R <= 256).  outp[0..3] promised bits,
+// outn[0..3] nack bits, assembled in LDS and written whole (no zeroing pass before the launch)
 __global__ void __launch_bounds__(256) k_phase1a_scalar(const Geom g, const State st, int group, int round,
-                                                        const uint64_t* target, uint64_t* out) {
+                                                        const uint64_t* target, uint64_t* outp, uint64_t* outn) {
   __shared__ unsigned long long bits[8];
   const int r = threadIdx.x;
   if (r < 8) bits[r] = 0ull;
@@ -704,7 +706,7 @@ __global__ void __launch_bounds__(256) k_phase1a_scalar(const Geom g, const Stat
     }
   }
   __syncthreads();
-  if (r < 8) out[r] = bits[r];
+  if (r < 4) outp[r] = bits[r], outn[r] = bits[4 + r];
 }
 
 // PER_SLOT mode, Acceptor.handlePhase1a generalised to a ballot per cell: every cell of the group at or above the
@@ -715,10 +717,14 @@ __global__ void __launch_bounds__(256) k_phase1a_scalar(const Geom g, const Stat
 // (a stale Phase1a) the acceptor's column is checked cell by cell (mode 2).  k_p1a_sweep does that work and
 // returns at once when no acceptor asked for any.
 enum { P1_MODE = 0, P1_A = 1, P1_B = 2, P1_C = 3 };
-// ONE block (R <= 256).  Writes the reply bitmaps itself for every acceptor that needs no sweep: out[0..3] promised
-// bits, out[4..7] nack bits (zero here; a stale Phase1a's Nacks and promises come from the tail of k_p1a_sweep).
-__global__ void __launch_bounds__(256) k_p1a_decide(const Geom g, const State st, int group, int round, int watermark,
-                                                    const uint64_t* target, uint64_t* out) {
+// st.p1 + 4 R: the control words of a Phase1a
+enum { P1_SWEEP = 0,      // a sweep is needed (set by the deciding workgroup, cleared by the sweep's last workgroup)
+       P1_SWEPT = 1,      // sweep workgroups that are done
+       P1_NACKS = 8 };    // k_p1a_fast: [4] 64-bit words, the Nack bits of a sweep while it runs
+// ONE workgroup of 256 threads (R <= 256).  Writes the reply bitmaps itself for every acceptor that needs no sweep: outp[0..3]
+// promised bits, outn[0..3] nack bits (zero here; a stale Phase1a's Nacks and promises come from the tail of the sweep).
+__device__ __forceinline__ void p1a_decide_body(const Geom& g, const State& st, int group, int round, int watermark,
+                                                const uint64_t* target, uint64_t* outp, uint64_t* outn) {
   __shared__ unsigned long long bits[4];
   const int r = threadIdx.x;
   if (r < 4) bits[r] = 0ull;
@@ -735,28 +741,30 @@ __global__ void __launch_bounds__(256) k_p1a_decide(const Geom g, const State st
         if (lr >= 0 && wm > lf) {  // the cells of [lf, wm) keep the older promise: make it explicit there
           mode[r] = 1;
           st.p1[P1_A * g.R + r] = lf, st.p1[P1_B * g.R + r] = wm, st.p1[P1_C * g.R + r] = lr;
-          st.p1[4 * g.R] = 1;
+          st.p1[4 * g.R + P1_SWEEP] = 1;
         }
         st.lz_round[e] = round, st.lz_from[e] = wm;
         st.max_ballot[e] = round;
         atomicOr(&bits[bit >> 6], 1ull << (bit & 63));  // promised: nothing of this acceptor was ahead
       } else {
         mode[r] = 2;  // possibly stale: its column is checked cell by cell
-        st.p1[4 * g.R] = 1;
+        st.p1[4 * g.R + P1_SWEEP] = 1;
       }
     }
   }
   __syncthreads();
-  if (r < 4) out[r] = bits[r], out[4 + r] = 0ull;
+  if (r < 4) outp[r] = bits[r], outn[r] = 0ull;
 }
 
-__global__ void __launch_bounds__(256) k_p1a_sweep(const Geom g, const State st, int group, int round, int watermark,
-                                                   uint64_t* out) {
-  if (st.p1[4 * g.R] == 0) return;  // the common case: nothing to sweep
+// workgroup `bid` of `nblk` (256 threads each) of the sweep
+__device__ __forceinline__ void p1a_sweep_body(const Geom& g, const State& st, int group, int round, int watermark, uint64_t* outp,
+                                               uint64_t* outn, int bid, int nblk) {
+  int32_t* ctl = st.p1 + 4 * g.R;
+  if (ctl[P1_SWEEP] == 0) return;  // the common case: nothing to sweep
   const int32_t* mode = st.p1 + P1_MODE * g.R;
   const int wm = watermark < 0 ? 0 : watermark;
   const size_t ncell = (size_t)g.S * g.RS;
-  for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += (size_t)gridDim.x * blockDim.x) {
+  for (size_t c = (size_t)bid * blockDim.x + threadIdx.x; c < ncell; c += (size_t)nblk * blockDim.x) {
     const int s = slot_of_row(g, (int)(c / g.RS)), r = (int)(c % g.RS);
     if (r >= g.R) continue;
     const int m = mode[r];
@@ -773,7 +781,7 @@ __global__ void __launch_bounds__(256) k_p1a_sweep(const Geom g, const State st,
         // one bit per acceptor: test before the atomic, or a stale Phase1a that every cell Nacks would queue
         // S x R same-address atomics
         const int bit = g.base + r;
-        unsigned long long* word = (unsigned long long*)&out[4 + (bit >> 6)];
+        unsigned long long* word = (unsigned long long*)&outn[bit >> 6];
         if (!((__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (bit & 63)) & 1ull))
           atomicOr(word, 1ull << (bit & 63));
       } else if (cur != round) {
@@ -781,21 +789,118 @@ __global__ void __launch_bounds__(256) k_p1a_sweep(const Geom g, const State st,
       }
     }
   }
-  // the block that finishes last: the swept acceptors promise unless one of their cells was ahead; re-arm the flag
+  // the workgroup that finishes last: the swept acceptors promise unless one of their cells was ahead; re-arm the flag
   __shared__ int last;
   __threadfence();
   __syncthreads();
-  if (threadIdx.x == 0) last = atomicAdd(&st.p1[4 * g.R + 1], 1) == (int)gridDim.x - 1;
+  if (threadIdx.x == 0) last = atomicAdd(&ctl[P1_SWEPT], 1) == nblk - 1;
   __syncthreads();
   if (!last) return;
   __threadfence();
   const int r = threadIdx.x;
   if (r < g.R && mode[r] == 2) {
     const int bit = g.base + r;
-    const unsigned long long nack = __hip_atomic_load((unsigned long long*)&out[4 + (bit >> 6)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!((nack >> (bit & 63)) & 1ull)) atomicOr((unsigned long long*)&out[bit >> 6], 1ull << (bit & 63));
+    const unsigned long long nack = __hip_atomic_load((unsigned long long*)&outn[bit >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!((nack >> (bit & 63)) & 1ull)) atomicOr((unsigned long long*)&outp[bit >> 6], 1ull << (bit & 63));
   }
-  if (r == 0) st.p1[4 * g.R] = 0, st.p1[4 * g.R + 1] = 0;
+  if (r == 0) ctl[P1_SWEEP] = 0, ctl[P1_SWEPT] = 0;
+}
+
+// the three steps as launches of their own (FPX_P1A_SPLIT=1: rounds 2 - 5, with the fold of a pending launch in front)
+__global__ void __launch_bounds__(256) k_p1a_decide(const Geom g, const State st, int group, int round, int watermark,
+                                                    const uint64_t* target, uint64_t* outp, uint64_t* outn) {
+  p1a_decide_body(g, st, group, round, watermark, target, outp, outn);
+}
+__global__ void __launch_bounds__(256) k_p1a_sweep(const Geom g, const State st, int group, int round, int watermark,
+                                                   uint64_t* outp, uint64_t* outn) {
+  p1a_sweep_body(g, st, group, round, watermark, outp, outn, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ---- Phase1a as ONE launch that does not wait for a pending fold (round 6) ------------------------------------------------
+// A Phase1a on a context with a ballot per cell was the fold of the vote launch before it (the decision reads max_ballot,
+// which that fold raises), k_p1a_decide (one workgroup) and k_p1a_sweep (which returns at its first instruction unless the
+// Phase1a is stale for an acceptor or moves the watermark past an older lazy promise): three dependent launches of ~5 us,
+// 28 times per pass of SURVEY 8(d)'s adversarial stream -- a fifth of its time (profiles/r06_phase1a.md).  Here:
+//  * the decision does not need the fold: a vote launch leaves the largest round of any of its messages in its shards of
+//    part_all (word 2, beside the whole-group maxima; k_phase2's epilogue), which bounds whatever its fold will raise --
+//    max(max_ballot[e], that bound) > round sends the acceptor to the cell-by-cell check exactly as a folded max_ballot
+//    would, or (the bound being loose) a little more often, and the check is exact.  So the pending fold stays pending and
+//    rides in the NEXT vote launch as before (what it later does to max_ballot commutes with what the decision wrote);
+//  * every workgroup takes the decision for all R acceptors itself (R + 128 words of reads) instead of waiting for one
+//    that does: the test for "stale" reads only words the deciding workgroup never changes the verdict of (it overwrites
+//    max_ballot[e] by `round` where max_ballot[e] <= round held), so there is nothing to wait for; workgroup 0 writes the
+//    lazy records, and the reply bits when nobody is stale; when somebody is, all workgroups check those acceptors'
+//    columns and the last one to finish writes the reply bits.
+// The host takes this form only when the watermark does not pass an older lazy promise's start (it knows every watermark
+// it ever handed in: fpx_ctx::lz_min_from) -- that case (P1 mode 1) needs the older records as they were and goes
+// through the three launches.  (Also measured: the three steps in one launch behind each other, the sweep's workgroups
+// waiting for a ticket of the deciding one -- 2.7 - 5.6 ms per pass against 1.9: polls across the XCDs' L2s see the ticket
+// late, acquire fences per poll are cache invalidations; and fold + decision in one launch by a last-workgroup counter:
+// no faster than two launches.)
+__global__ void __launch_bounds__(256) k_p1a_fast(const Geom g, const State st, int par_pending, int group, int round, int watermark,
+                                                  const uint64_t* target, uint64_t* outp, uint64_t* outn) {
+  __shared__ unsigned long long prom[4], stale[4];
+  __shared__ int bound_s, last;
+  const int r = threadIdx.x;
+  if (r < 4) prom[r] = 0ull, stale[r] = 0ull;
+  if (r == 0) bound_s = -1;
+  __syncthreads();
+  if (par_pending >= 0 && r < 64) {  // what the vote launch whose fold is still pending can have raised, at most
+    const int32_t* pa = st.part_all + ((size_t)par_pending * 64 + r) * PART_ALL_STRIDE;
+    const int a = pa[0], c = pa[2];
+    const int v = group_max<64>(a > c ? a : c);
+    if (r == 0) bound_s = v;
+  }
+  __syncthreads();
+  const int wm = watermark < 0 ? 0 : watermark;
+  const int bit = g.base + r;
+  const size_t e = (size_t)group * g.R + (r < g.R ? r : 0);
+  bool tg = false, m2 = false;
+  if (r < g.R && (!target || ((target[bit >> 6] >> (bit & 63)) & 1ull))) {
+    tg = true;
+    const int mb = __hip_atomic_load(&st.max_ballot[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    m2 = (mb > bound_s ? mb : bound_s) > round;
+    atomicOr(m2 ? &stale[bit >> 6] : &prom[bit >> 6], 1ull << (bit & 63));
+  }
+  __syncthreads();
+  const bool need = (stale[0] | stale[1] | stale[2] | stale[3]) != 0ull;
+  if (blockIdx.x == 0) {
+    if (tg && !m2) st.lz_round[e] = round, st.lz_from[e] = wm, st.max_ballot[e] = round;
+    if (!need && r < 4) outp[r] = prom[r], outn[r] = 0ull;  // promised: nothing of these acceptors was ahead
+  }
+  if (!need) return;
+  // a stale Phase1a for some acceptor: its column cell by cell (p1a_sweep_body's mode 2)
+  int32_t* ctl = st.p1 + 4 * g.R;
+  unsigned long long* nacks = reinterpret_cast<unsigned long long*>(ctl + P1_NACKS);  // [4], zero between Phase1a's
+  const size_t ncell = (size_t)g.S * g.RS;
+  for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += (size_t)gridDim.x * blockDim.x) {
+    const int s = slot_of_row(g, (int)(c / g.RS)), rr = (int)(c % g.RS);
+    if (rr >= g.R) continue;
+    const int b2 = g.base + rr;
+    if (!((stale[b2 >> 6] >> (b2 & 63)) & 1ull) || group_of_slot(g, s) != group || s < wm) continue;
+    const size_t e2 = (size_t)group * g.R + rr;
+    const int cur = st.ballot[c];
+    const int lz = s >= st.lz_from[e2] ? st.lz_round[e2] : -1;
+    const int eff = lz > cur ? lz : cur;
+    if (eff > round) {
+      if (!((__hip_atomic_load(&nacks[b2 >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (b2 & 63)) & 1ull))
+        atomicOr(&nacks[b2 >> 6], 1ull << (b2 & 63));
+    } else if (cur != round) {
+      st.ballot[c] = round;
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(&ctl[P1_SWEPT], 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (r < 4) {  // the swept acceptors promise unless one of their cells was ahead
+    const unsigned long long nk = __hip_atomic_load(&nacks[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    outp[r] = prom[r] | (stale[r] & ~nk), outn[r] = nk;
+    nacks[r] = 0ull;
+  }
+  if (r == 0) ctl[P1_SWEPT] = 0;
 }
 
 // every outstanding lazy promise written into the cells it covers, the records cleared (readback / digests /

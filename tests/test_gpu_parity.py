@@ -670,9 +670,21 @@ def test_lazy_phase1a_promises_equal_the_sweep(fa, oracle, R, ngroups):
     np.testing.assert_array_equal(gpu.state_digest(), ref.state_digest())
 
 
-def test_phase1a_dev_is_asynchronous_and_equal(fa, oracle):
+@pytest.mark.parametrize("split", [False, True])
+def test_phase1a_dev_is_asynchronous_and_equal(fa, oracle, monkeypatch, split):
+    """Phase1a's on device-resident arguments between fused steps, nothing synchronised until the end: a fresh round for
+    everybody, for 30 % of the acceptors, a STALE one (every cell of the group is ahead: the sweep answers, cell by cell),
+    the round again, two that move the watermark past an older lazy promise (which the sweep first writes into the cells
+    it alone covers), and a stale one behind a step of PARTIAL votes (target masks) in a higher round.  With a ballot per
+    cell a Phase1a is ONE launch that does not wait for the fold of the step before it (k_p1a_fast: it bounds what that
+    fold will raise by what the step left in part_all; split: FPX_P1A_SPLIT=1, the launches of rounds 2 - 5); the reply
+    bits land where the caller wants them."""
     import torch
 
+    if split:
+        monkeypatch.setenv("FPX_P1A_SPLIT", "1")
+    else:
+        monkeypatch.delenv("FPX_P1A_SPLIT", raising=False)
     S, R = 4096, 256
     dev = torch.device("cuda:0")
     for ballot_mode in (0, 1):
@@ -682,23 +694,32 @@ def test_phase1a_dev_is_asynchronous_and_equal(fa, oracle):
         slot, rnd, val = W.steady_stream(S)
         t = lambda a: torch.from_numpy(a).to(dev)
         outs = []
-        for rr, frac in ((0, None), (3, 0.3), (2, None), (3, None)):
+        # (Phase1a round, fraction of the acceptors it goes to, watermark, round of the step behind it, that step's targets)
+        plan = ((0, None, 0, 0, None), (3, 0.3, 0, 3, None), (2, None, 0, 2, None), (3, None, 0, 3, None),
+                (5, None, S // 2, 5, None), (4, 0.5, S // 4, 5, None), (6, 0.5, 3 * S // 4, 9, (100, 200)),
+                (8, None, 0, 8, (1, 256)), (10, 0.7, 0, 10, None), (9, None, 0, 11, (120, 136)), (10, None, 0, 10, None))
+        for k, (rr, frac, wm, vr, tsub) in enumerate(plan):
             tgt = None if frac is None else W.bits_from_bool(rng.random((1, R)) < frac)[0]
-            pb = torch.zeros(4, dtype=torch.int64, device=dev)
-            nb = torch.zeros(4, dtype=torch.int64, device=dev)
-            gpu.acceptor_phase1a_dev(0, rr, 0, None if tgt is None else t(tgt.view(np.int64)), pb, nb)
+            pb = torch.full((4,), -1, dtype=torch.int64, device=dev)
+            nb = torch.full((4,), -1, dtype=torch.int64, device=dev)
+            only = k == 4  # one call that wants the promises only
+            gpu.acceptor_phase1a_dev(0, rr, wm, None if tgt is None else t(tgt.view(np.int64)), pb, None if only else nb)
             ch = torch.zeros(S, dtype=torch.uint8, device=dev)
             nr = torch.zeros(S, dtype=torch.int32, device=dev)
-            gpu.phase2_fused_dev(t(slot), t(np.full(S, rr, np.int32)), t(val), None, ch, None, None, nr)
-            outs.append((pb, nb, ch, nr, rr, tgt))          # nothing synchronised so far
+            vt = None if tsub is None else W.bits_from_bool(W.random_subsets(rng, S, R, tsub[0], tsub[1]))
+            gpu.phase2_fused_dev(t(slot), t(np.full(S, vr, np.int32)), t(val), None if vt is None else t(vt.view(np.int64)), ch, None, None, nr)
+            outs.append((pb, None if only else nb, ch, nr, rr, tgt, wm, vr, vt))          # nothing synchronised so far
         assert gpu.sync() == 0
-        for pb, nb, ch, nr, rr, tgt in outs:
-            st, pb_r, nb_r = ref.acceptor_phase1a(0, rr, 0, tgt)
-            st, ch_r, cr_r, cv_r, nr_r = ref.phase2_fused(slot, np.full(S, rr, np.int32), val)
+        for pb, nb, ch, nr, rr, tgt, wm, vr, vt in outs:
+            st, pb_r, nb_r = ref.acceptor_phase1a(0, rr, wm, tgt)
+            st, ch_r, cr_r, cv_r, nr_r = ref.phase2_fused(slot, np.full(S, vr, np.int32), val, vt)
             np.testing.assert_array_equal(pb.cpu().numpy().view(np.uint64), pb_r)
-            np.testing.assert_array_equal(nb.cpu().numpy().view(np.uint64), nb_r)
+            if nb is not None:
+                np.testing.assert_array_equal(nb.cpu().numpy().view(np.uint64), nb_r)
             np.testing.assert_array_equal(ch.cpu().numpy(), ch_r)
             np.testing.assert_array_equal(nr.cpu().numpy(), nr_r)
+        if ballot_mode == 1 and not split:
+            assert gpu.deferred_folds() >= 5, gpu.deferred_folds()   # folds kept riding in the vote launches, past the Phase1a's
         W.assert_same_state(gpu, ref, tally_slots=range(0, S, 211))
         gpu.set_stream(None)
 
