@@ -43,6 +43,9 @@
 #ifndef FPX_PREFETCH
 #define FPX_PREFETCH 0
 #endif
+#ifndef FPX_EARLY_THR
+#define FPX_EARLY_THR 1  // the first step's ballot row is requested with the chunk's other loads (fpx_phase2_body.inc)
+#endif
 #ifndef FPX_NT
 #define FPX_NT 1  // vote rows are written once and not re-read soon: nontemporal stores
 #endif
