@@ -173,6 +173,18 @@ __device__ __forceinline__ uint32_t kp_wave_excl_sum(uint32_t v) {
   return (uint32_t)inc - v;
 }
 
+// wave64 sum of one value per lane on the same network: the total arrives in lane 63
+__device__ __forceinline__ uint32_t kp_wave_sum_to_lane63(uint32_t v) {
+  int inc = (int)v;
+  inc += dpp0<0x111, 0xF>(inc);
+  inc += dpp0<0x112, 0xF>(inc);
+  inc += dpp0<0x114, 0xF>(inc);
+  inc += dpp0<0x118, 0xF>(inc);
+  inc += dpp0<0x142, 0xA>(inc);
+  inc += dpp0<0x143, 0xC>(inc);
+  return (uint32_t)inc;
+}
+
 // KP_HG tiles per workgroup (128 threads each).  After the count, thread j owns key j: the key's commands in the
 // workgroup's tiles are ONE claim in the key's segment (so the records of 8 neighbouring tiles are neighbours there, and
 // the workgroups of one XCD take neighbouring tiles in k_kp_scatter: their 24-byte stores meet in one L2 and leave it as
@@ -397,14 +409,16 @@ __global__ void __launch_bounds__(KpScat<N>::THREADS) k_kp_scatter(const EpxStat
       if (g != ~0u) dst[(size_t)g * H + h] = src[q];
     }
   }
-  // the fingerprints: wavefront sums, then one 64-bit atomic per workgroup and word
+  // the fingerprints: wavefront sums, then one 64-bit atomic per workgroup and word.  A thread's word is the sum of at
+  // most MB 32-bit values (< 2^34): its low 20 and its high 14 bits are added up separately on the DPP network (wavefront
+  // sums < 2^26 and < 2^20) -- 12 instructions per word where a butterfly of 64-bit shuffles was 72 dependent trips through
+  // the LDS crossbar per workgroup: 4.5 us at the end of every scatter workgroup (profiles/r04_k5.md, timelines)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  static_assert(MB <= 4, "a thread's fingerprint word fits 34 bits");
 #pragma unroll
   for (int q = 0; q < 2 * (N + 1); ++q) {
-    unsigned long long v = f[q];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if (lane == 0) fsum[wv][q] = v;
+    const uint32_t lo = kp_wave_sum_to_lane63((uint32_t)f[q] & 0xFFFFFu), hi = kp_wave_sum_to_lane63((uint32_t)(f[q] >> 20));
+    if (lane == 63) fsum[wv][q] = (unsigned long long)lo + ((unsigned long long)hi << 20);
   }
   __syncthreads();
   if (threadIdx.x < 2 * (N + 1)) {
