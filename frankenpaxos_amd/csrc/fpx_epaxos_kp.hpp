@@ -27,6 +27,12 @@
 // writes the entries of every replica that saw the PreAccept (or of every replica, for a fast-path commit).
 #pragma once
 
+#ifndef FPX_K5_NT_OUT
+#define FPX_K5_NT_OUT 1  // the packed lines leave k_epx_key2 as nontemporal stores: written once, read by nobody on the device --
+                         // 0.1057 -> 0.1030 ms per tick when no buffer is touched twice (profiles/r06_k5.md; the tick's inputs as
+                         // nontemporal loads on top of it: 0.1033, not kept)
+#endif
+
 constexpr int KP_TILE = 2048;   // messages per partition tile
 constexpr int KP_MAXB = 2048;   // keys (one LDS counter each in the partition passes)
 constexpr int KP_SLOT_BITS = 11;
@@ -834,7 +840,13 @@ __global__ void __launch_bounds__(KpTile<N>::THREADS) k_epx_key2(const EpxState 
       for (int t = threadIdx.x; t < c * Q; t += T::THREADS) {
         const int sl = t / Q, q = t - sl * Q;
         const int* o = rows + (size_t)sl * T::RSTR + 4 * q;
+#if FPX_K5_NT_OUT
+        typedef int kp_int4v __attribute__((ext_vector_type(4)));
+        const kp_int4v v = {o[0], o[1], o[2], o[3]};
+        __builtin_nontemporal_store(v, reinterpret_cast<kp_int4v*>(a.packed + (size_t)RF(0, sl) * a.stride) + q);
+#else
         reinterpret_cast<int4*>(a.packed + (size_t)RF(0, sl) * a.stride)[q] = make_int4(o[0], o[1], o[2], o[3]);
+#endif
       }
     }
     if (!a.packed) {

@@ -13,7 +13,7 @@ epx = EPaxos(n, num_keys)
 epx.set_stream(torch.cuda.current_stream().cuda_stream)
 rng = np.random.default_rng(4)
 nxt = [0] * n
-T = 8
+T = int(os.environ.get("K5_T", "8"))
 ticks = []
 for t in range(T):
     leader, number, key, is_set, mask, rank = random_tick(rng, n, num_keys, m, nxt, 64.0)
@@ -48,5 +48,17 @@ for mode in os.environ.get("K5_MODES", "packed,arrays").split(","):
             epx.preaccept_packed_dev(*ticks[t], packed)
     torch.cuda.synchronize()
     print("%s packed, %d ticks back to back: %.4f ms per tick (wall)" % (sys.argv[1] if len(sys.argv) > 1 else "", R * T, (time.perf_counter() - t0) * 1e3 / (R * T)), flush=True)
+    if os.environ.get("K5_ROTATE_OUT"):
+        # the same ticks, every one into an output buffer of its own (T x 64 MB: more than the 256 MB memory-side cache holds)
+        outs = [torch.zeros((m, epx.packed_stride()), dtype=torch.int32, device=dev) for _ in range(T)]
+        for t in range(T):
+            epx.preaccept_packed_dev(*ticks[t], outs[t])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for rep in range(R):
+            for t in range(T):
+                epx.preaccept_packed_dev(*ticks[t], outs[t])
+        torch.cuda.synchronize()
+        print("%s packed, %d ticks back to back, %d output buffers in turn: %.4f ms per tick (wall)" % (sys.argv[1] if len(sys.argv) > 1 else "", R * T, T, (time.perf_counter() - t0) * 1e3 / (R * T)), flush=True)
 rc = epx.sync()
 assert rc == 0 or "FPX_LIB" in os.environ, rc
