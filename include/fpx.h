@@ -255,8 +255,12 @@ int32_t fpx_acceptor_phase2a_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slot,
 int32_t fpx_acceptor_phase1a(fpx_ctx* ctx, int32_t group, int32_t round, int32_t chosen_watermark,
                              const uint64_t* target_mask, uint64_t* promised_bits,
                              uint64_t* nack_bits);
-/* the same on device-resident arguments (each 4 words in HBM, may be NULL), asynchronous on the context's
- * stream: a leader change in the middle of a device-resident stream costs no host round trip. */
+/* the same on device-resident arguments (each 4 words in HBM, 8-byte aligned, may be NULL), asynchronous on the context's
+ * stream: a leader change in the middle of a device-resident stream costs no host round trip.  With a ballot per cell it is
+ * ONE launch that writes the reply bits straight into the caller's words and does not wait for the fold of the fused step
+ * before it (fpx_deferred_folds): a vote launch leaves a bound on what its fold can raise, the decision uses that
+ * (csrc/fpx_kernels.hpp, k_p1a_fast) -- unless the watermark is above the smallest one handed in since the promises were
+ * last flushed, which takes the three launches of rounds 2 - 5 (as does FPX_P1A_SPLIT=1 in the environment). */
 int32_t fpx_acceptor_phase1a_dev(fpx_ctx* ctx, int32_t group, int32_t round, int32_t chosen_watermark,
                                  const uint64_t* d_target_mask, uint64_t* d_promised_bits,
                                  uint64_t* d_nack_bits);
@@ -411,7 +415,7 @@ int32_t fpx_mencius_band_fused_dev(fpx_ctx* ctx, int32_t n, const int32_t* d_slo
  * K3 launch is followed by a fold of the maxima its workgroups left (Acceptor.round / maxVotedSlot, multipaxos/Acceptor.scala:
  * 204-209, as scalars per acceptor); with a ballot per cell (FPX_BALLOT_PER_SLOT) no vote kernel reads those scalars, so the
  * fold of one fpx_phase2_fused_dev call waits for the next one and rides in its launch (or is launched by whatever entry
- * point touches the context first: the deferral is not observable through this ABI).  FPX_NO_DEFER_FINALIZE=1 in the
+ * point other than a Phase1a touches the context first: the deferral is not observable through this ABI).  FPX_NO_DEFER_FINALIZE=1 in the
  * environment launches every fold at once, as rounds 1 - 5 did. */
 int64_t fpx_deferred_folds(fpx_ctx* ctx);
 /* diagnostic: the steps of fpx_mencius_band_fused_dev that ran in the two-launch form since fpx_create */
